@@ -1,0 +1,252 @@
+/*
+ * mlsgpu_hip.h -- C-ABI of the MI355X (gfx950) per-bucket device pipeline.
+ *
+ * The reference (bmerry/mlsgpu) has no C plugin interface for this path: its
+ * boundary is the C++ class surface consumed by
+ * DeviceWorkerGroupBase::Worker::operator() (src/workers.cpp:232-286), typed on
+ * cl::Context / cl::CommandQueue / cl::Buffer / cl::Image2D.  This header is
+ * the C-ABI a maintainer binds instead; each entry point cites the reference
+ * interface it replaces.  mlsgpu_amd/host/ holds header-only C++ classes with
+ * the reference's own names (SplatTreeCL, MlsFunctor, Marching, ...) built on
+ * this ABI; INTEGRATION.md shows the reference-side changes.
+ *
+ * Conventions
+ *  - every function returns MLSGPU_OK (0) or an error code; the text of the
+ *    last error of the calling thread is mlsgpu_hip_last_error();
+ *  - error classes follow the reference's exceptions: MLSGPU_ERR_LENGTH ~
+ *    std::length_error, MLSGPU_ERR_INVALID ~ std::invalid_argument,
+ *    MLSGPU_ERR_HIP ~ cl::Error, MLSGPU_ERR_NOMEM ~ CL_MEM_OBJECT_ALLOCATION_FAILURE;
+ *  - objects are NOT thread-safe; one worker thread owns one context (= one
+ *    HIP stream) and the objects made from it (src/mls.h:74-77,
+ *    src/workers.h:183-206);
+ *  - "d" prefixed pointers are device pointers on the context's device.
+ */
+#ifndef MLSGPU_HIP_H
+#define MLSGPU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MLSGPU_OK 0
+#define MLSGPU_ERR_INVALID 1
+#define MLSGPU_ERR_LENGTH 2
+#define MLSGPU_ERR_HIP 3
+#define MLSGPU_ERR_NOMEM 4
+#define MLSGPU_ERR_CALLBACK 5
+
+/* struct Splat, src/splat.h:40-46 == kernels/octree.cl:32-36 (32 bytes, AoS).
+ * After mlsgpu_hip_tree_build the radius slot holds 1/radius^2 (octree.cl:193). */
+typedef struct mlsgpu_splat
+{
+    float position[3];
+    float radius;
+    float normal[3];
+    float quality;
+} mlsgpu_splat;
+
+/* MlsShape, src/mls.h:47-51 */
+#define MLSGPU_SHAPE_SPHERE 0
+#define MLSGPU_SHAPE_PLANE 1
+
+/* Marching::Swathe (+ImageParams), src/marching.h:173-198.  The distance
+ * field lives in a linear float buffer that is addressed exactly like the
+ * reference's 2-D image: corner (x, y, z) is field[(y + z*zStride + zBias) * pitch + x]. */
+typedef struct mlsgpu_swathe
+{
+    uint32_t width, height;
+    uint32_t zStride;
+    int32_t zBias;
+    uint32_t zFirst, zLast;   /* closed interval of corner slices */
+} mlsgpu_swathe;
+
+/* DeviceKeyMesh, src/mesh.h:101-123: packed float xyz vertices, uint32 index
+ * triplets, uint64 keys for all vertices (meaningful for external ones only);
+ * internal vertices first. */
+typedef struct mlsgpu_mesh
+{
+    float *dVertices;
+    uint32_t *dTriangles;
+    uint64_t *dVertexKeys;
+    uint64_t numVertices;
+    uint64_t numTriangles;
+    uint64_t numInternalVertices;
+} mlsgpu_mesh;
+
+typedef struct mlsgpu_ctx mlsgpu_ctx;
+typedef struct mlsgpu_tree mlsgpu_tree;
+typedef struct mlsgpu_mls mlsgpu_mls;
+typedef struct mlsgpu_marching mlsgpu_marching;
+typedef struct mlsgpu_worker mlsgpu_worker;
+
+/* Marching::Generator, src/marching.h:204-253.  enqueue() must enqueue (on
+ * `stream`, a hipStream_t) work that fills slices zFirst..zLast of dField. */
+typedef struct mlsgpu_generator
+{
+    uint32_t alignment[3];
+    int (*enqueue)(void *user, void *stream, float *dField, uint64_t pitch, const mlsgpu_swathe *swathe);
+    void *user;
+} mlsgpu_generator;
+
+/* Marching::OutputFunctor, src/marching.h:516-546.  The mesh is valid until
+ * the functor returns (it may enqueue reads on `stream` and must synchronise
+ * them itself, or copy with mlsgpu_hip_mesh_read). */
+typedef int (*mlsgpu_output_fn)(void *user, void *stream, const mlsgpu_mesh *mesh);
+
+const char *mlsgpu_hip_last_error(void);
+
+/* ---- context: one device + one in-order stream (cl::Context + cl::CommandQueue of a worker,
+ *      src/workers.cpp:207-221).  stream == NULL creates a private stream; otherwise the given
+ *      hipStream_t (e.g. a torch stream) is used and not destroyed. ---- */
+int mlsgpu_hip_ctx_create(int device, void *stream, mlsgpu_ctx **out);
+void mlsgpu_hip_ctx_destroy(mlsgpu_ctx *ctx);
+void *mlsgpu_hip_ctx_stream(mlsgpu_ctx *ctx);
+int mlsgpu_hip_ctx_synchronize(mlsgpu_ctx *ctx);
+int mlsgpu_hip_device_count(int *count);
+
+/* Device / pinned memory helpers (CLH::PinnedMemory, src/clh.h:334-477; cl::Buffer). */
+int mlsgpu_hip_malloc(mlsgpu_ctx *ctx, size_t bytes, void **dptr);
+int mlsgpu_hip_free(mlsgpu_ctx *ctx, void *dptr);
+int mlsgpu_hip_host_alloc(size_t bytes, void **hptr);
+int mlsgpu_hip_host_free(void *hptr);
+int mlsgpu_hip_memcpy_h2d(mlsgpu_ctx *ctx, void *dst, const void *src, size_t bytes, int async);
+int mlsgpu_hip_memcpy_d2h(mlsgpu_ctx *ctx, void *dst, const void *src, size_t bytes, int async);
+int mlsgpu_hip_memcpy_d2d(mlsgpu_ctx *ctx, void *dst, const void *src, size_t bytes);   /* async on the stream */
+int mlsgpu_hip_memset(mlsgpu_ctx *ctx, void *dst, int value, size_t bytes);
+
+/* Per-kernel device timing, the `--statistics-cl` facility (src/statistics_cl.cpp:62-160) with the
+ * reference's stat names (kernel.octree.*.time, kernel.mls.processCorners.time, kernel.marching.*.time,
+ * kernel.scaleBias.time).  Timing uses hipEvent pairs on the context's stream. */
+int mlsgpu_hip_ctx_set_timing(mlsgpu_ctx *ctx, int enabled);
+/* Synchronises, then returns total milliseconds and launch count of `name` since the last reset. */
+int mlsgpu_hip_ctx_get_stat(mlsgpu_ctx *ctx, const char *name, double *totalMs, uint64_t *launches);
+int mlsgpu_hip_ctx_reset_stats(mlsgpu_ctx *ctx);
+/* Writes "name total_ms launches\n" lines; returns number of bytes needed. */
+size_t mlsgpu_hip_ctx_dump_stats(mlsgpu_ctx *ctx, char *buf, size_t bufSize);
+
+/* ---- SplatTreeCL (src/splat_tree_cl.h:216-296) ---- */
+#define MLSGPU_TREE_MAX_LEVELS 10                          /* src/splat_tree_cl.h:76 */
+#define MLSGPU_TREE_MAX_SPLATS (((uint64_t) 1 << 31) / 16) /* src/splat_tree_cl.h:88 */
+int mlsgpu_hip_tree_create(mlsgpu_ctx *ctx, uint64_t maxLevels, uint64_t maxSplats, mlsgpu_tree **out);
+void mlsgpu_hip_tree_destroy(mlsgpu_tree *tree);
+/* SplatTreeCL::resourceUsage: device bytes a tree of this capacity allocates. */
+uint64_t mlsgpu_hip_tree_resource_usage(uint64_t maxLevels, uint64_t maxSplats);
+/* SplatTreeCL::enqueueBuild, src/splat_tree_cl.cpp:269-335.  Pure enqueue.  Borrows dSplats until
+ * mlsgpu_hip_tree_clear_splats and MUTATES it (radius -> 1/radius^2). */
+int mlsgpu_hip_tree_build(mlsgpu_tree *tree, mlsgpu_splat *dSplats, uint64_t firstSplat, uint64_t numSplats,
+                          const uint32_t size[3], const int32_t offset[3], uint32_t subsamplingShift);
+void mlsgpu_hip_tree_clear_splats(mlsgpu_tree *tree);
+const mlsgpu_splat *mlsgpu_hip_tree_splats(const mlsgpu_tree *tree);   /* getSplats   */
+const int32_t *mlsgpu_hip_tree_commands(const mlsgpu_tree *tree);      /* getCommands */
+const int32_t *mlsgpu_hip_tree_start(const mlsgpu_tree *tree);         /* getStart    */
+uint64_t mlsgpu_hip_tree_commands_size(const mlsgpu_tree *tree);       /* elements allocated */
+uint64_t mlsgpu_hip_tree_start_size(const mlsgpu_tree *tree);
+uint32_t mlsgpu_hip_tree_num_levels(const mlsgpu_tree *tree);          /* getNumLevels */
+
+/* ---- MlsFunctor (src/mls.h:79-170) ---- */
+int mlsgpu_hip_mls_create(mlsgpu_ctx *ctx, int shape, mlsgpu_mls **out);
+void mlsgpu_hip_mls_destroy(mlsgpu_mls *mls);
+/* MlsFunctor::set(offset, tree, subsamplingShift), src/mls.cpp:91-94 */
+int mlsgpu_hip_mls_set(mlsgpu_mls *mls, const int32_t offset[3], const mlsgpu_tree *tree, uint32_t subsamplingShift);
+/* the private MlsFunctor::set(offset, splats, commands, start, shift) used by test/test_mls.cpp:475 */
+int mlsgpu_hip_mls_set_buffers(mlsgpu_mls *mls, const int32_t offset[3], const mlsgpu_splat *dSplats,
+                               const int32_t *dCommands, const int32_t *dStart, uint32_t subsamplingShift);
+int mlsgpu_hip_mls_set_boundary_limit(mlsgpu_mls *mls, float limit);   /* src/mls.cpp:137-144 */
+/* MlsFunctor::enqueue, src/mls.cpp:101-135.  fieldRows = rows allocated in dField (bounds check). */
+int mlsgpu_hip_mls_enqueue(mlsgpu_mls *mls, float *dField, uint64_t pitch, uint64_t fieldRows,
+                           const mlsgpu_swathe *swathe);
+/* Fills *gen so the functor can be passed to mlsgpu_hip_marching_generate (alignment = wgs = {8,8,8}). */
+int mlsgpu_hip_mls_generator(mlsgpu_mls *mls, mlsgpu_generator *gen);
+/* Selects the kernel variant: 0 = sub-block culled (default), 1 = basic list walk. Same results. */
+int mlsgpu_hip_mls_set_variant(mlsgpu_mls *mls, int variant);
+/* Measurement aid: with a non-NULL device array of 3 uint64 the next enqueues run an instrumented kernel that
+ * adds [0] listed splats (Sigma L of SURVEY 8d), [1] (corner, splat) distance tests executed, [2] hits (H).
+ * Results are unchanged; NULL switches back to the production kernel. */
+int mlsgpu_hip_mls_set_stats(mlsgpu_mls *mls, uint64_t *dCounters);
+
+/* ---- Marching (src/marching.h:494-608) ---- */
+#define MLSGPU_MARCHING_MAX_DIMENSION 8192      /* src/marching.h:136 */
+#define MLSGPU_MARCHING_MAX_CELL_BYTES 872      /* src/marching.h:96-100 */
+int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, uint32_t maxHeight, uint32_t maxDepth,
+                               uint32_t maxSwathe, uint64_t meshMemory, const uint32_t alignment[3],
+                               mlsgpu_marching **out);
+void mlsgpu_hip_marching_destroy(mlsgpu_marching *m);
+uint64_t mlsgpu_hip_marching_resource_usage(uint32_t maxWidth, uint32_t maxHeight, uint32_t maxDepth,
+                                            uint32_t maxSwathe, uint64_t meshMemory, const uint32_t alignment[3]);
+/* Marching::generate, src/marching.cpp:745-824.  Blocks until the bucket is done (as the reference's does). */
+int mlsgpu_hip_marching_generate(mlsgpu_marching *m, const mlsgpu_generator *generator,
+                                 mlsgpu_output_fn output, void *outputUser,
+                                 const uint32_t size[3], const uint32_t keyOffset[3]);
+/* Counters marching.overflow / marching.shipouts / marching.slices.nonempty (src/marching.cpp:342-377) and
+ * work totals: out[0]=overflow out[1]=shipouts out[2]=nonempty swathes out[3]=occupied cells
+ * out[4]=unwelded vertices out[5]=indices out[6]=welded vertices out[7]=external vertices. */
+int mlsgpu_hip_marching_counters(const mlsgpu_marching *m, uint64_t out[8]);
+/* Lookup tables (src/marching.cpp:109-252): count[256][2] u8, start[257][2] u16, data[8192] u8, key[2432][3] u32 */
+int mlsgpu_hip_marching_tables(const mlsgpu_marching *m, uint8_t *count, uint16_t *start, uint8_t *data, uint32_t *key);
+/* Marching::copySlice (src/marching.cpp:447-498) on an arbitrary field buffer. */
+int mlsgpu_hip_marching_copy_slice(mlsgpu_marching *m, float *dField, uint64_t pitch, uint32_t src, uint32_t trg,
+                                   uint32_t width, uint32_t height, uint32_t zStride);
+/* kernels/marching.cl:295-326 stand-alone (test/test_marching.cpp:401-479). */
+int mlsgpu_hip_compact_vertices(mlsgpu_ctx *ctx, float *dOutVertices, uint64_t *dOutKeys, uint32_t *dIndexRemap,
+                                uint32_t *dFirstExternal, const uint32_t *dVertexUnique, const float *dInVertices4,
+                                const uint64_t *dInKeys, uint64_t minExternalKey, uint64_t keyOffset, uint64_t n);
+
+/* ---- mesh plumbing ---- */
+/* MeshSizes::getHostBytes, src/mesh.h:75-80 */
+uint64_t mlsgpu_hip_mesh_host_bytes(const mlsgpu_mesh *mesh);
+/* enqueueReadMesh into a HostKeyMesh blob [extKeys u64][vertices 3xf32][triangles 3xu32]
+ * (src/mesh.cpp:51-102).  hostBlob must be 8-byte aligned.  async != 0: caller synchronises. */
+int mlsgpu_hip_mesh_read(mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh, void *hostBlob, int async);
+/* ScaleBiasFilter, src/mesh_filter.cpp:69-113 + kernels/scale_bias.cl:33-41: in place. */
+int mlsgpu_hip_scale_bias(mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh, float scale, float bx, float by, float bz);
+
+/* ---- DeviceWorkerGroupBase::Worker (src/workers.cpp:207-286): tree + MlsFunctor + Marching + ScaleBias ---- */
+typedef struct mlsgpu_worker_config
+{
+    uint64_t maxBucketSplats;
+    uint32_t maxCells;          /* bucket side in cells; Marching gets maxCells+1 corners */
+    uint64_t meshMemory;        /* 0: (maxCells^2 * 2) worst-case cells as src/mlsgpu_core.cpp:359-370 */
+    uint32_t levels;            /* default 6 */
+    uint32_t subsampling;       /* default 3 */
+    float boundaryLimit;        /* default 1.0 */
+    int shape;
+    uint32_t maxSwathe;         /* 0: whole bucket depth (no 8192-row image limit on HBM buffers) */
+    float gridSpacing;          /* ScaleBiasFilter::setScaleBias(fullGrid): spacing and getVertex(0,0,0) */
+    float gridOrigin[3];
+} mlsgpu_worker_config;
+
+int mlsgpu_hip_worker_create(mlsgpu_ctx *ctx, const mlsgpu_worker_config *cfg, mlsgpu_worker **out);
+void mlsgpu_hip_worker_destroy(mlsgpu_worker *w);
+uint64_t mlsgpu_hip_worker_resource_usage(const mlsgpu_worker_config *cfg);
+/* One SubItem of a WorkItem (src/workers.cpp:235-285): lowExtent = sub.grid.getExtent(i).first,
+ * numVertices = sub.grid.numVertices(i).  dSplats is the WorkItem's device splat buffer. */
+int mlsgpu_hip_worker_process(mlsgpu_worker *w, mlsgpu_splat *dSplats, uint64_t firstSplat, uint64_t numSplats,
+                              const int32_t lowExtent[3], const uint32_t numVertices[3],
+                              mlsgpu_output_fn output, void *outputUser);
+mlsgpu_tree *mlsgpu_hip_worker_tree(mlsgpu_worker *w);
+mlsgpu_mls *mlsgpu_hip_worker_mls(mlsgpu_worker *w);
+mlsgpu_marching *mlsgpu_hip_worker_marching(mlsgpu_worker *w);
+
+/* DeviceWorkerGroupBase::computeMaxSwathe, src/workers.cpp:169-182 */
+uint32_t mlsgpu_hip_compute_max_swathe(uint32_t yMax, uint32_t y, uint32_t yAlign, uint32_t zAlign);
+
+/* ---- small device helpers that mirror the reference's one-work-item test kernels
+ *      (kernels/octree.cl:355-372, mls.cl:439-481, marching.cl:364-371); each runs on the GPU ---- */
+int mlsgpu_hip_test_make_code(mlsgpu_ctx *ctx, int x, int y, int z, uint32_t *out);
+int mlsgpu_hip_test_level_shift(mlsgpu_ctx *ctx, const int32_t lo[3], const int32_t hi[3], int32_t *out);
+int mlsgpu_hip_test_point_box_dist2(mlsgpu_ctx *ctx, const float p[3], const float lo[3], const float hi[3], float *out);
+int mlsgpu_hip_test_solve_quadratic(mlsgpu_ctx *ctx, float a, float b, float c, float *out);
+int mlsgpu_hip_test_fit_sphere(mlsgpu_ctx *ctx, const mlsgpu_splat *hSplats, uint32_t n, float out[5]);
+int mlsgpu_hip_test_compute_key(mlsgpu_ctx *ctx, const uint32_t coords[3], const uint32_t top[3], uint64_t *out);
+/* primitives: exclusive scan with seed (clogs::Scan) and stable radix sort on the low `bits` (clogs::Radixsort) */
+int mlsgpu_hip_test_scan_u32(mlsgpu_ctx *ctx, uint32_t *dData, uint64_t n, uint32_t seed);
+int mlsgpu_hip_test_sort_u32(mlsgpu_ctx *ctx, uint32_t *dKeys, uint32_t *dValues, uint64_t n, uint32_t bits);
+int mlsgpu_hip_test_sort_u64(mlsgpu_ctx *ctx, uint64_t *dKeys, uint32_t *dValues, uint64_t n, uint32_t bits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MLSGPU_HIP_H */

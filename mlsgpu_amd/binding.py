@@ -1,0 +1,552 @@
+"""ctypes binding of libmlsgpu_hip.so (include/mlsgpu_hip.h).
+
+Class and method names follow the reference's C++ surface (SplatTreeCL, MlsFunctor, Marching,
+DeviceWorkerGroupBase::Worker) so tests read like the reference's own.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+SPLAT_DTYPE = np.dtype([("position", np.float32, 3), ("radius", np.float32),
+                        ("normal", np.float32, 3), ("quality", np.float32)])
+
+SHAPE_SPHERE, SHAPE_PLANE = 0, 1
+
+
+class MlsError(Exception):
+    """Base class of errors raised through the C-ABI."""
+
+
+class InvalidArgument(MlsError, ValueError):
+    """std::invalid_argument in the reference (MLSGPU_ASSERT)."""
+
+
+class LengthError(MlsError, ValueError):
+    """std::length_error in the reference."""
+
+
+class HipError(MlsError, RuntimeError):
+    """cl::Error in the reference."""
+
+
+class Swathe(C.Structure):
+    """Marching::Swathe, src/marching.h:173-198."""
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("zStride", C.c_uint32),
+                ("zBias", C.c_int32), ("zFirst", C.c_uint32), ("zLast", C.c_uint32)]
+
+
+class Mesh(C.Structure):
+    """DeviceKeyMesh, src/mesh.h:101-123."""
+    _fields_ = [("dVertices", C.c_void_p), ("dTriangles", C.c_void_p), ("dVertexKeys", C.c_void_p),
+                ("numVertices", C.c_uint64), ("numTriangles", C.c_uint64), ("numInternalVertices", C.c_uint64)]
+
+
+ENQUEUE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(Swathe))
+OUTPUT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Mesh))
+
+
+class Generator(C.Structure):
+    """Marching::Generator, src/marching.h:204-253."""
+    _fields_ = [("alignment", C.c_uint32 * 3), ("enqueue", ENQUEUE_FN), ("user", C.c_void_p)]
+
+
+class WorkerConfig(C.Structure):
+    _fields_ = [("maxBucketSplats", C.c_uint64), ("maxCells", C.c_uint32), ("meshMemory", C.c_uint64),
+                ("levels", C.c_uint32), ("subsampling", C.c_uint32), ("boundaryLimit", C.c_float),
+                ("shape", C.c_int), ("maxSwathe", C.c_uint32), ("gridSpacing", C.c_float),
+                ("gridOrigin", C.c_float * 3)]
+
+
+def library_path():
+    return os.path.join(_HERE, "libmlsgpu_hip.so")
+
+
+_lib = None
+
+
+def lib():
+    """Loads the HIP library; there is deliberately no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(make -C mlsgpu_amd/csrc). mlsgpu_amd has no CPU fallback." % path)
+    L = C.CDLL(path)
+    u32, i32, u64, f32, vp, sz = C.c_uint32, C.c_int32, C.c_uint64, C.c_float, C.c_void_p, C.c_size_t
+    P = C.POINTER
+
+    def sig(name, res, *args):
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+
+    sig("mlsgpu_hip_last_error", C.c_char_p)
+    sig("mlsgpu_hip_ctx_create", C.c_int, C.c_int, vp, P(vp))
+    sig("mlsgpu_hip_ctx_destroy", None, vp)
+    sig("mlsgpu_hip_ctx_stream", vp, vp)
+    sig("mlsgpu_hip_ctx_synchronize", C.c_int, vp)
+    sig("mlsgpu_hip_device_count", C.c_int, P(C.c_int))
+    sig("mlsgpu_hip_malloc", C.c_int, vp, sz, P(vp))
+    sig("mlsgpu_hip_free", C.c_int, vp, vp)
+    sig("mlsgpu_hip_host_alloc", C.c_int, sz, P(vp))
+    sig("mlsgpu_hip_host_free", C.c_int, vp)
+    sig("mlsgpu_hip_memcpy_h2d", C.c_int, vp, vp, vp, sz, C.c_int)
+    sig("mlsgpu_hip_memcpy_d2h", C.c_int, vp, vp, vp, sz, C.c_int)
+    sig("mlsgpu_hip_memset", C.c_int, vp, vp, C.c_int, sz)
+    sig("mlsgpu_hip_memcpy_d2d", C.c_int, vp, vp, vp, sz)
+    sig("mlsgpu_hip_ctx_set_timing", C.c_int, vp, C.c_int)
+    sig("mlsgpu_hip_ctx_get_stat", C.c_int, vp, C.c_char_p, P(C.c_double), P(u64))
+    sig("mlsgpu_hip_ctx_reset_stats", C.c_int, vp)
+    sig("mlsgpu_hip_ctx_dump_stats", sz, vp, C.c_char_p, sz)
+    sig("mlsgpu_hip_tree_create", C.c_int, vp, u64, u64, P(vp))
+    sig("mlsgpu_hip_tree_destroy", None, vp)
+    sig("mlsgpu_hip_tree_resource_usage", u64, u64, u64)
+    sig("mlsgpu_hip_tree_build", C.c_int, vp, vp, u64, u64, vp, vp, u32)
+    sig("mlsgpu_hip_tree_clear_splats", None, vp)
+    sig("mlsgpu_hip_tree_splats", vp, vp)
+    sig("mlsgpu_hip_tree_commands", vp, vp)
+    sig("mlsgpu_hip_tree_start", vp, vp)
+    sig("mlsgpu_hip_tree_commands_size", u64, vp)
+    sig("mlsgpu_hip_tree_start_size", u64, vp)
+    sig("mlsgpu_hip_tree_num_levels", u32, vp)
+    sig("mlsgpu_hip_mls_create", C.c_int, vp, C.c_int, P(vp))
+    sig("mlsgpu_hip_mls_destroy", None, vp)
+    sig("mlsgpu_hip_mls_set", C.c_int, vp, vp, vp, u32)
+    sig("mlsgpu_hip_mls_set_buffers", C.c_int, vp, vp, vp, vp, vp, u32)
+    sig("mlsgpu_hip_mls_set_boundary_limit", C.c_int, vp, f32)
+    sig("mlsgpu_hip_mls_enqueue", C.c_int, vp, vp, u64, u64, P(Swathe))
+    sig("mlsgpu_hip_mls_generator", C.c_int, vp, P(Generator))
+    sig("mlsgpu_hip_mls_set_variant", C.c_int, vp, C.c_int)
+    sig("mlsgpu_hip_mls_set_stats", C.c_int, vp, vp)
+    sig("mlsgpu_hip_marching_create", C.c_int, vp, u32, u32, u32, u32, u64, vp, P(vp))
+    sig("mlsgpu_hip_marching_destroy", None, vp)
+    sig("mlsgpu_hip_marching_resource_usage", u64, u32, u32, u32, u32, u64, vp)
+    sig("mlsgpu_hip_marching_generate", C.c_int, vp, P(Generator), OUTPUT_FN, vp, vp, vp)
+    sig("mlsgpu_hip_marching_counters", C.c_int, vp, vp)
+    sig("mlsgpu_hip_marching_tables", C.c_int, vp, vp, vp, vp, vp)
+    sig("mlsgpu_hip_marching_copy_slice", C.c_int, vp, vp, u64, u32, u32, u32, u32, u32)
+    sig("mlsgpu_hip_compact_vertices", C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, u64, u64, u64)
+    sig("mlsgpu_hip_mesh_host_bytes", u64, P(Mesh))
+    sig("mlsgpu_hip_mesh_read", C.c_int, vp, P(Mesh), vp, C.c_int)
+    sig("mlsgpu_hip_scale_bias", C.c_int, vp, P(Mesh), f32, f32, f32, f32)
+    sig("mlsgpu_hip_worker_create", C.c_int, vp, P(WorkerConfig), P(vp))
+    sig("mlsgpu_hip_worker_destroy", None, vp)
+    sig("mlsgpu_hip_worker_resource_usage", u64, P(WorkerConfig))
+    sig("mlsgpu_hip_worker_process", C.c_int, vp, vp, u64, u64, vp, vp, OUTPUT_FN, vp)
+    sig("mlsgpu_hip_worker_tree", vp, vp)
+    sig("mlsgpu_hip_worker_mls", vp, vp)
+    sig("mlsgpu_hip_worker_marching", vp, vp)
+    sig("mlsgpu_hip_compute_max_swathe", u32, u32, u32, u32, u32)
+    sig("mlsgpu_hip_test_make_code", C.c_int, vp, C.c_int, C.c_int, C.c_int, P(u32))
+    sig("mlsgpu_hip_test_level_shift", C.c_int, vp, vp, vp, P(i32))
+    sig("mlsgpu_hip_test_point_box_dist2", C.c_int, vp, vp, vp, vp, P(f32))
+    sig("mlsgpu_hip_test_solve_quadratic", C.c_int, vp, f32, f32, f32, P(f32))
+    sig("mlsgpu_hip_test_fit_sphere", C.c_int, vp, vp, u32, vp)
+    sig("mlsgpu_hip_test_compute_key", C.c_int, vp, vp, vp, P(u64))
+    sig("mlsgpu_hip_test_scan_u32", C.c_int, vp, vp, u64, u32)
+    sig("mlsgpu_hip_test_sort_u32", C.c_int, vp, vp, vp, u64, u32)
+    sig("mlsgpu_hip_test_sort_u64", C.c_int, vp, vp, vp, u64, u32)
+    _lib = L
+    return L
+
+
+_ERRORS = {1: InvalidArgument, 2: LengthError, 3: HipError, 4: HipError, 5: MlsError}
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().mlsgpu_hip_last_error().decode("utf-8", "replace")
+        raise _ERRORS.get(rc, MlsError)("[%d] %s" % (rc, msg))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u3(v):
+    return np.ascontiguousarray(v, dtype=np.uint32)
+
+
+def _i3(v):
+    return np.ascontiguousarray(v, dtype=np.int32)
+
+
+class Context:
+    """One device + one in-order stream (the cl::Context + cl::CommandQueue of one worker)."""
+
+    def __init__(self, device=0, stream=None):
+        h = C.c_void_p()
+        check(lib().mlsgpu_hip_ctx_create(device, stream, C.byref(h)))
+        self.h = h
+        self.device = device
+
+    @property
+    def stream(self):
+        return lib().mlsgpu_hip_ctx_stream(self.h)
+
+    def synchronize(self):
+        check(lib().mlsgpu_hip_ctx_synchronize(self.h))
+
+    def set_timing(self, enabled):
+        check(lib().mlsgpu_hip_ctx_set_timing(self.h, int(enabled)))
+
+    def reset_stats(self):
+        check(lib().mlsgpu_hip_ctx_reset_stats(self.h))
+
+    def stat(self, name):
+        ms, n = C.c_double(), C.c_uint64()
+        check(lib().mlsgpu_hip_ctx_get_stat(self.h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def stats(self):
+        n = lib().mlsgpu_hip_ctx_dump_stats(self.h, None, 0)
+        buf = C.create_string_buffer(n + 16)
+        lib().mlsgpu_hip_ctx_dump_stats(self.h, buf, n + 16)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, ms, cnt = line.rsplit(" ", 2)
+            out[name] = (float(ms), int(cnt))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().mlsgpu_hip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    """A device allocation (cl::Buffer)."""
+
+    def __init__(self, ctx, nbytes=0, array=None, fill=None):
+        self.ctx = ctx
+        if array is not None:
+            array = np.ascontiguousarray(array)
+            nbytes = array.nbytes
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().mlsgpu_hip_malloc(ctx.h, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+        if fill is not None:
+            # pattern fill like createBuffer's 0xDEADBEEF (test/test_clh.cpp:88-99)
+            pat = np.full((self.nbytes + 3) // 4, fill, np.uint32)
+            check(lib().mlsgpu_hip_memcpy_h2d(ctx.h, self.ptr, _p(pat), self.nbytes, 0))
+        if array is not None:
+            self.upload(array)
+
+    def upload(self, array, offset=0):
+        array = np.ascontiguousarray(array)
+        assert offset + array.nbytes <= self.nbytes
+        check(lib().mlsgpu_hip_memcpy_h2d(self.ctx.h, self.ptr + offset, _p(array), array.nbytes, 0))
+
+    def download(self, dtype, count=None, offset=0):
+        dtype = np.dtype(dtype)
+        if count is None:
+            count = (self.nbytes - offset) // dtype.itemsize
+        out = np.empty(count, dtype)
+        check(lib().mlsgpu_hip_memcpy_d2h(self.ctx.h, _p(out), self.ptr + offset, out.nbytes, 0))
+        return out
+
+    def copy_from(self, other, nbytes=None):
+        """Device-to-device copy, asynchronous on the context's stream."""
+        check(lib().mlsgpu_hip_memcpy_d2d(self.ctx.h, self.ptr, other.ptr, self.nbytes if nbytes is None else nbytes))
+
+    def free(self):
+        if self.ptr:
+            lib().mlsgpu_hip_free(self.ctx.h, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def download_ptr(ctx, ptr, dtype, count):
+    out = np.empty(count, np.dtype(dtype))
+    if count:
+        check(lib().mlsgpu_hip_memcpy_d2h(ctx.h, _p(out), ptr, out.nbytes, 0))
+    return out
+
+
+class SplatTree:
+    """SplatTreeCL, src/splat_tree_cl.h:216-296."""
+
+    def __init__(self, ctx, max_levels, max_splats):
+        self.ctx = ctx
+        h = C.c_void_p()
+        check(lib().mlsgpu_hip_tree_create(ctx.h, max_levels, max_splats, C.byref(h)))
+        self.h = h
+
+    def enqueue_build(self, splats, first_splat, num_splats, size, offset, subsampling_shift):
+        check(lib().mlsgpu_hip_tree_build(self.h, splats.ptr, first_splat, num_splats, _p(_u3(size)),
+                                          _p(_i3(offset)), subsampling_shift))
+
+    def clear_splats(self):
+        lib().mlsgpu_hip_tree_clear_splats(self.h)
+
+    @property
+    def num_levels(self):
+        return lib().mlsgpu_hip_tree_num_levels(self.h)
+
+    def commands(self):
+        n = lib().mlsgpu_hip_tree_commands_size(self.h)
+        return download_ptr(self.ctx, lib().mlsgpu_hip_tree_commands(self.h), np.int32, n)
+
+    def start(self):
+        n = lib().mlsgpu_hip_tree_start_size(self.h)
+        return download_ptr(self.ctx, lib().mlsgpu_hip_tree_start(self.h), np.int32, n)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().mlsgpu_hip_tree_destroy(self.h)
+            self.h = None
+
+
+class MlsFunctor:
+    """MlsFunctor, src/mls.h:79-170."""
+    wgs = (8, 8, 8)
+    subsampling_min = 3
+
+    def __init__(self, ctx, shape=SHAPE_SPHERE):
+        self.ctx = ctx
+        h = C.c_void_p()
+        check(lib().mlsgpu_hip_mls_create(ctx.h, shape, C.byref(h)))
+        self.h = h
+
+    def set(self, offset, tree, subsampling_shift):
+        check(lib().mlsgpu_hip_mls_set(self.h, _p(_i3(offset)), tree.h, subsampling_shift))
+
+    def set_buffers(self, offset, splats, commands, start, subsampling_shift):
+        check(lib().mlsgpu_hip_mls_set_buffers(self.h, _p(_i3(offset)), splats.ptr, commands.ptr, start.ptr,
+                                               subsampling_shift))
+
+    def set_boundary_limit(self, limit):
+        check(lib().mlsgpu_hip_mls_set_boundary_limit(self.h, limit))
+
+    def set_variant(self, variant):
+        check(lib().mlsgpu_hip_mls_set_variant(self.h, variant))
+
+    def alignment(self):
+        return self.wgs
+
+    def enqueue(self, field, pitch, rows, swathe):
+        check(lib().mlsgpu_hip_mls_enqueue(self.h, field.ptr, pitch, rows, C.byref(swathe)))
+
+    def generator(self):
+        g = Generator()
+        check(lib().mlsgpu_hip_mls_generator(self.h, C.byref(g)))
+        return g
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().mlsgpu_hip_mls_destroy(self.h)
+            self.h = None
+
+
+def read_mesh(ctx, mesh):
+    """enqueueReadMesh into a HostKeyMesh blob, returned as numpy views (src/mesh.cpp:51-102)."""
+    nbytes = lib().mlsgpu_hip_mesh_host_bytes(C.byref(mesh))
+    nv, nt, ni = int(mesh.numVertices), int(mesh.numTriangles), int(mesh.numInternalVertices)
+    blob = np.zeros(max(nbytes // 8 + 1, 1), np.uint64)
+    if nv or nt:
+        check(lib().mlsgpu_hip_mesh_read(ctx.h, C.byref(mesh), _p(blob), 0))
+    raw = blob.view(np.uint8)
+    ne = nv - ni
+    keys = raw[:8 * ne].view(np.uint64).copy()
+    verts = raw[8 * ne:8 * ne + 12 * nv].view(np.float32).reshape(nv, 3).copy()
+    tris = raw[8 * ne + 12 * nv:8 * ne + 12 * nv + 12 * nt].view(np.uint32).reshape(nt, 3).copy()
+    full_keys = np.zeros(nv, np.uint64)
+    full_keys[ni:] = keys
+    return dict(vertices=verts, keys=full_keys, triangles=tris, num_internal=ni)
+
+
+class MeshCollector:
+    """An output functor that reads every batch back to the host."""
+
+    def __init__(self, ctx, scale_bias=None):
+        self.ctx = ctx
+        self.batches = []
+        self.error = None
+
+        def cb(user, stream, meshp):
+            try:
+                mesh = meshp.contents
+                if scale_bias is not None:
+                    check(lib().mlsgpu_hip_scale_bias(ctx.h, meshp, *scale_bias))
+                self.batches.append(read_mesh(ctx, mesh))
+                return 0
+            except Exception as e:   # never let an exception cross the C boundary
+                self.error = e
+                return 1
+        self.cb = OUTPUT_FN(cb)
+
+
+class SizeCollector:
+    """An output functor that only records mesh sizes (bench: outputs stay in HBM)."""
+
+    def __init__(self):
+        self.vertices = self.triangles = self.external = self.batches = 0
+
+        def cb(user, stream, meshp):
+            m = meshp.contents
+            self.vertices += m.numVertices
+            self.triangles += m.numTriangles
+            self.external += m.numVertices - m.numInternalVertices
+            self.batches += 1
+            return 0
+        self.cb = OUTPUT_FN(cb)
+
+
+class Marching:
+    """Marching, src/marching.h:494-608."""
+    MAX_CELL_BYTES = 872
+
+    def __init__(self, ctx, max_width, max_height, max_depth, max_swathe, mesh_memory, alignment):
+        self.ctx = ctx
+        h = C.c_void_p()
+        check(lib().mlsgpu_hip_marching_create(ctx.h, max_width, max_height, max_depth, max_swathe, mesh_memory,
+                                               _p(_u3(alignment)), C.byref(h)))
+        self.h = h
+
+    def generate(self, generator, size, key_offset=(0, 0, 0), collector=None):
+        """generator: a Generator struct (MlsFunctor.generator()) or host_generator(...)."""
+        col = collector or MeshCollector(self.ctx)
+        gen = generator if isinstance(generator, Generator) else generator.struct
+        rc = lib().mlsgpu_hip_marching_generate(self.h, C.byref(gen), col.cb, None, _p(_u3(size)),
+                                                _p(_u3(key_offset)))
+        if getattr(col, "error", None) is not None:
+            raise col.error
+        if getattr(generator, "error", None) is not None:
+            raise generator.error
+        check(rc)
+        return col.batches if isinstance(col, MeshCollector) else col
+
+    def counters(self):
+        out = np.zeros(8, np.uint64)
+        check(lib().mlsgpu_hip_marching_counters(self.h, _p(out)))
+        names = ["overflows", "shipouts", "nonempty", "occupied", "unwelded", "indices", "welded", "external"]
+        return dict(zip(names, [int(x) for x in out]))
+
+    def tables(self):
+        count = np.zeros((256, 2), np.uint8)
+        start = np.zeros((257, 2), np.uint16)
+        data = np.zeros(8192, np.uint8)
+        key = np.zeros((2432, 3), np.uint32)
+        check(lib().mlsgpu_hip_marching_tables(self.h, _p(count), _p(start), _p(data), _p(key)))
+        return count, start, data, key
+
+    def copy_slice(self, field, pitch, src, trg, width, height, z_stride):
+        check(lib().mlsgpu_hip_marching_copy_slice(self.h, field.ptr, pitch, src, trg, width, height, z_stride))
+        self.ctx.synchronize()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().mlsgpu_hip_marching_destroy(self.h)
+            self.h = None
+
+
+class HostGenerator:
+    """A Marching::Generator whose values come from a host function, like the HostGenerator of
+    test/test_marching.cpp:62-130: fn(xs, ys, z) -> float32 [height, width] per slice."""
+
+    def __init__(self, ctx, fn, alignment):
+        self.ctx = ctx
+        self.error = None
+
+        def enqueue(user, stream, field, pitch, swp):
+            try:
+                sw = swp.contents
+                ys, xs = np.meshgrid(np.arange(sw.height, dtype=np.uint32), np.arange(sw.width, dtype=np.uint32),
+                                     indexing="ij")
+                for z in range(sw.zFirst, sw.zLast + 1):
+                    vals = np.ascontiguousarray(fn(xs, ys, z), np.float32)
+                    # one contiguous copy per slice: rows are `pitch` apart, the padding columns it
+                    # overwrites are "undefined" by the Generator contract (src/marching.h:246-249)
+                    padded = np.zeros((sw.height, pitch), np.float32)
+                    padded[:, :sw.width] = vals
+                    flat = padded.reshape(-1)[:(sw.height - 1) * pitch + sw.width]
+                    row0 = z * sw.zStride + sw.zBias
+                    check(lib().mlsgpu_hip_memcpy_h2d(ctx.h, field + row0 * pitch * 4, _p(flat), flat.nbytes, 0))
+                return 0
+            except Exception as e:
+                self.error = e
+                return 5
+        self._enqueue = ENQUEUE_FN(enqueue)
+        self.struct = Generator()
+        for i in range(3):
+            self.struct.alignment[i] = alignment[i]
+        self.struct.enqueue = self._enqueue
+        self.struct.user = None
+
+
+class Worker:
+    """DeviceWorkerGroupBase::Worker, src/workers.cpp:207-286."""
+
+    def __init__(self, ctx, max_bucket_splats, max_cells=255, mesh_memory=0, levels=6, subsampling=3,
+                 boundary_limit=1.0, shape=SHAPE_SPHERE, max_swathe=0, grid_spacing=1.0, grid_origin=(0, 0, 0)):
+        self.ctx = ctx
+        cfg = WorkerConfig()
+        cfg.maxBucketSplats = max_bucket_splats
+        cfg.maxCells = max_cells
+        cfg.meshMemory = mesh_memory
+        cfg.levels = levels
+        cfg.subsampling = subsampling
+        cfg.boundaryLimit = boundary_limit
+        cfg.shape = shape
+        cfg.maxSwathe = max_swathe
+        cfg.gridSpacing = grid_spacing
+        for i in range(3):
+            cfg.gridOrigin[i] = grid_origin[i]
+        self.cfg = cfg
+        h = C.c_void_p()
+        check(lib().mlsgpu_hip_worker_create(ctx.h, C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def resource_usage(self):
+        return lib().mlsgpu_hip_worker_resource_usage(C.byref(self.cfg))
+
+    def process(self, splats, first_splat, num_splats, low_extent, num_vertices, collector=None):
+        col = collector or MeshCollector(self.ctx)
+        rc = lib().mlsgpu_hip_worker_process(self.h, splats.ptr, first_splat, num_splats, _p(_i3(low_extent)),
+                                             _p(_u3(num_vertices)), col.cb, None)
+        if getattr(col, "error", None) is not None:
+            raise col.error
+        check(rc)
+        return col.batches if isinstance(col, MeshCollector) else col
+
+    def set_mls_variant(self, variant):
+        check(lib().mlsgpu_hip_mls_set_variant(lib().mlsgpu_hip_worker_mls(self.h), variant))
+
+    def set_mls_stats(self, counters):
+        """counters: DeviceBuffer of 3 uint64 (or None): see mlsgpu_hip_mls_set_stats."""
+        check(lib().mlsgpu_hip_mls_set_stats(lib().mlsgpu_hip_worker_mls(self.h), counters.ptr if counters else None))
+
+    def marching_counters(self):
+        out = np.zeros(8, np.uint64)
+        check(lib().mlsgpu_hip_marching_counters(lib().mlsgpu_hip_worker_marching(self.h), _p(out)))
+        names = ["overflows", "shipouts", "nonempty", "occupied", "unwelded", "indices", "welded", "external"]
+        return dict(zip(names, [int(x) for x in out]))
+
+    def tree_arrays(self):
+        t = lib().mlsgpu_hip_worker_tree(self.h)
+        commands = download_ptr(self.ctx, lib().mlsgpu_hip_tree_commands(t), np.int32,
+                                lib().mlsgpu_hip_tree_commands_size(t))
+        start = download_ptr(self.ctx, lib().mlsgpu_hip_tree_start(t), np.int32, lib().mlsgpu_hip_tree_start_size(t))
+        return commands, start
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().mlsgpu_hip_worker_destroy(self.h)
+            self.h = None

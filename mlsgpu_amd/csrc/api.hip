@@ -1,0 +1,420 @@
+/*
+ * Context, memory, statistics and the per-bucket worker of the HIP path.
+ *
+ * mlsgpu_worker restates DeviceWorkerGroupBase::Worker (src/workers.cpp:207-286): one stream, one
+ * SplatTreeCL, one MlsFunctor, one Marching and a ScaleBiasFilter in front of the output functor.
+ */
+#include "common.hpp"
+
+#include <algorithm>
+#include <mutex>
+
+using namespace mlsgpu;
+
+namespace mlsgpu
+{
+
+static thread_local char lastError[512] = "";
+
+int setError(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(lastError, sizeof(lastError), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+} // namespace mlsgpu
+
+MLSGPU_API const char *mlsgpu_hip_last_error(void) { return mlsgpu::lastError; }
+
+/* ------------------------------------------------------------------ context */
+
+int mlsgpu_ctx::statId(const char *name)
+{
+    auto it = statIds.find(name);
+    if (it != statIds.end())
+        return it->second;
+    const int id = (int) statNames.size();
+    statNames.push_back(name);
+    stats.push_back(Stat());
+    statIds[name] = id;
+    return id;
+}
+
+int mlsgpu_ctx::beginTiming(int id)
+{
+    PendingTiming p;
+    p.nameId = id;
+    hipEvent_t ev[2];
+    for (int i = 0; i < 2; i++)
+    {
+        if (!eventPool.empty())
+        {
+            ev[i] = eventPool.back();
+            eventPool.pop_back();
+        }
+        else if (hipEventCreate(&ev[i]) != hipSuccess)
+            return -1;
+    }
+    p.start = ev[0];
+    p.stop = ev[1];
+    hipEventRecord(p.start, stream);
+    pending.push_back(p);
+    return (int) pending.size() - 1;
+}
+
+void mlsgpu_ctx::endTiming(int idx)
+{
+    hipEventRecord(pending[idx].stop, stream);
+}
+
+int mlsgpu_ctx::resolveTimings()
+{
+    HIP_CHECK(hipStreamSynchronize(stream));
+    for (const PendingTiming &p : pending)
+    {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess)
+        {
+            stats[p.nameId].totalMs += ms;
+            stats[p.nameId].launches++;
+        }
+        eventPool.push_back(p.start);
+        eventPool.push_back(p.stop);
+    }
+    pending.clear();
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_device_count(int *count)
+{
+    REQUIRE(count != nullptr, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipGetDeviceCount(count));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_ctx_create(int device, void *stream, mlsgpu_ctx **out)
+{
+    REQUIRE(out != nullptr, MLSGPU_ERR_INVALID);
+    int count = 0;
+    HIP_CHECK(hipGetDeviceCount(&count));
+    REQUIRE(device >= 0 && device < count, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(device));
+    mlsgpu_ctx *ctx = new mlsgpu_ctx;
+    ctx->device = device;
+    if (stream != nullptr)
+    {
+        ctx->stream = static_cast<hipStream_t>(stream);
+        ctx->ownStream = false;
+    }
+    else
+    {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess)
+        {
+            delete ctx;
+            return setError(MLSGPU_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+        }
+        ctx->ownStream = true;
+    }
+    *out = ctx;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API void mlsgpu_hip_ctx_destroy(mlsgpu_ctx *ctx)
+{
+    if (!ctx)
+        return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (const PendingTiming &p : ctx->pending)
+    {
+        hipEventDestroy(p.start);
+        hipEventDestroy(p.stop);
+    }
+    for (hipEvent_t e : ctx->eventPool)
+        hipEventDestroy(e);
+    if (ctx->ownStream)
+        hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+MLSGPU_API void *mlsgpu_hip_ctx_stream(mlsgpu_ctx *ctx) { return ctx ? ctx->stream : nullptr; }
+
+MLSGPU_API int mlsgpu_hip_ctx_synchronize(mlsgpu_ctx *ctx)
+{
+    REQUIRE(ctx != nullptr, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_malloc(mlsgpu_ctx *ctx, size_t bytes, void **dptr)
+{
+    REQUIRE(ctx != nullptr && dptr != nullptr, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipMalloc(dptr, bytes ? bytes : 4));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_free(mlsgpu_ctx *ctx, void *dptr)
+{
+    REQUIRE(ctx != nullptr, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipFree(dptr));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_host_alloc(size_t bytes, void **hptr)
+{
+    REQUIRE(hptr != nullptr, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipHostMalloc(hptr, bytes ? bytes : 8));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_host_free(void *hptr)
+{
+    HIP_CHECK(hipHostFree(hptr));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_memcpy_h2d(mlsgpu_ctx *ctx, void *dst, const void *src, size_t bytes, int async)
+{
+    REQUIRE(ctx != nullptr, MLSGPU_ERR_INVALID);
+    if (bytes == 0)
+        return MLSGPU_OK;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    int pend = -1;
+    if (ctx->timing) pend = ctx->beginTiming(ctx->statId("copy.write"));     /* src/workers.cpp:356-361 */
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (pend >= 0) ctx->endTiming(pend);
+    if (!async)
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_memcpy_d2h(mlsgpu_ctx *ctx, void *dst, const void *src, size_t bytes, int async)
+{
+    REQUIRE(ctx != nullptr, MLSGPU_ERR_INVALID);
+    if (bytes == 0)
+        return MLSGPU_OK;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (!async)
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_memcpy_d2d(mlsgpu_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    REQUIRE(ctx != nullptr, MLSGPU_ERR_INVALID);
+    if (bytes == 0)
+        return MLSGPU_OK;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_memset(mlsgpu_ctx *ctx, void *dst, int value, size_t bytes)
+{
+    REQUIRE(ctx != nullptr, MLSGPU_ERR_INVALID);
+    if (bytes == 0)
+        return MLSGPU_OK;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipMemsetAsync(dst, value, bytes, ctx->stream));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_ctx_set_timing(mlsgpu_ctx *ctx, int enabled)
+{
+    REQUIRE(ctx != nullptr, MLSGPU_ERR_INVALID);
+    if (!enabled && ctx->timing)
+        PROPAGATE(ctx->resolveTimings());
+    ctx->timing = enabled != 0;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_ctx_get_stat(mlsgpu_ctx *ctx, const char *name, double *totalMs, uint64_t *launches)
+{
+    REQUIRE(ctx != nullptr && name != nullptr, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    PROPAGATE(ctx->resolveTimings());
+    auto it = ctx->statIds.find(name);
+    double ms = 0.0;
+    uint64_t n = 0;
+    if (it != ctx->statIds.end())
+    {
+        ms = ctx->stats[it->second].totalMs;
+        n = ctx->stats[it->second].launches;
+    }
+    if (totalMs) *totalMs = ms;
+    if (launches) *launches = n;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_ctx_reset_stats(mlsgpu_ctx *ctx)
+{
+    REQUIRE(ctx != nullptr, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    PROPAGATE(ctx->resolveTimings());
+    for (Stat &s : ctx->stats)
+        s = Stat();
+    return MLSGPU_OK;
+}
+
+MLSGPU_API size_t mlsgpu_hip_ctx_dump_stats(mlsgpu_ctx *ctx, char *buf, size_t bufSize)
+{
+    if (!ctx)
+        return 0;
+    hipSetDevice(ctx->device);
+    ctx->resolveTimings();
+    std::string s;
+    char line[256];
+    for (size_t i = 0; i < ctx->statNames.size(); i++)
+    {
+        snprintf(line, sizeof(line), "%s %.6f %llu\n", ctx->statNames[i].c_str(), ctx->stats[i].totalMs,
+                 (unsigned long long) ctx->stats[i].launches);
+        s += line;
+    }
+    if (buf && bufSize)
+    {
+        const size_t n = std::min(bufSize - 1, s.size());
+        std::memcpy(buf, s.data(), n);
+        buf[n] = 0;
+    }
+    return s.size() + 1;
+}
+
+/* ------------------------------------------------------------------ worker */
+
+MLSGPU_API uint32_t mlsgpu_hip_compute_max_swathe(uint32_t yMax, uint32_t y, uint32_t yAlign, uint32_t zAlign)
+{
+    /* DeviceWorkerGroupBase::computeMaxSwathe, src/workers.cpp:169-182 */
+    y = roundUp(y, yAlign);
+    if (yMax < y)
+        return zAlign;
+    uint32_t chunks = (yMax - y) / (y * zAlign);
+    if (chunks == 0)
+        chunks = 1;
+    return chunks * zAlign;
+}
+
+struct mlsgpu_worker
+{
+    mlsgpu_ctx *ctx = nullptr;
+    mlsgpu_worker_config cfg;
+    mlsgpu_tree *tree = nullptr;
+    mlsgpu_mls *mls = nullptr;
+    mlsgpu_marching *marching = nullptr;
+    mlsgpu_output_fn userOutput = nullptr;
+    void *userOutputData = nullptr;
+};
+
+static void resolveConfig(mlsgpu_worker_config &c)
+{
+    if (c.levels == 0) c.levels = 6;                    /* src/mlsgpu_core.cpp:110-111 */
+    if (c.subsampling == 0) c.subsampling = 3;
+    if (c.maxCells == 0) c.maxCells = (1u << (c.levels + c.subsampling - 1)) - 1;   /* :601-602 */
+    if (c.meshMemory == 0)
+        c.meshMemory = (uint64_t) c.maxCells * c.maxCells * 2 * MLSGPU_MARCHING_MAX_CELL_BYTES;   /* :359-370 */
+    if (c.maxSwathe == 0)
+        c.maxSwathe = roundUp(c.maxCells + 1, 8);       /* whole bucket: HBM buffers have no 8192-row limit */
+    if (c.gridSpacing == 0.0f) c.gridSpacing = 1.0f;
+}
+
+MLSGPU_API uint64_t mlsgpu_hip_worker_resource_usage(const mlsgpu_worker_config *cfgIn)
+{
+    /* DeviceWorkerGroup::resourceUsage, src/workers.cpp:184-205 (per worker, without the item pool) */
+    mlsgpu_worker_config c = *cfgIn;
+    resolveConfig(c);
+    const uint32_t wgs[3] = {8, 8, 8};
+    const uint32_t block = c.maxCells + 1;
+    return mlsgpu_hip_marching_resource_usage(block, block, block, c.maxSwathe, c.meshMemory, wgs)
+        + mlsgpu_hip_tree_resource_usage(c.levels, c.maxBucketSplats);
+}
+
+MLSGPU_API int mlsgpu_hip_worker_create(mlsgpu_ctx *ctx, const mlsgpu_worker_config *cfgIn, mlsgpu_worker **out)
+{
+    REQUIRE(ctx != nullptr && cfgIn != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    mlsgpu_worker *w = new mlsgpu_worker;
+    w->ctx = ctx;
+    w->cfg = *cfgIn;
+    resolveConfig(w->cfg);
+    const mlsgpu_worker_config &c = w->cfg;
+    int rc = MLSGPU_OK;
+    /* option constraints of src/mlsgpu_core.cpp:411-442 */
+    if (!(c.subsampling >= 3 && c.levels >= 1 && c.levels <= 10 && c.subsampling + c.levels <= 14))
+        rc = setError(MLSGPU_ERR_INVALID, "worker: need subsampling >= 3, 1 <= levels <= 10, subsampling + levels <= 14");
+    if (rc == MLSGPU_OK && c.maxCells + 1 > (1u << (c.levels + c.subsampling - 1)))
+        rc = setError(MLSGPU_ERR_LENGTH, "worker: maxCells + 1 exceeds the octree side 2^(levels+subsampling-1)");
+    const uint32_t wgs[3] = {8, 8, 8};
+    const uint32_t block = c.maxCells + 1;
+    if (rc == MLSGPU_OK) rc = mlsgpu_hip_tree_create(ctx, c.levels, c.maxBucketSplats, &w->tree);
+    if (rc == MLSGPU_OK) rc = mlsgpu_hip_mls_create(ctx, c.shape, &w->mls);
+    if (rc == MLSGPU_OK) rc = mlsgpu_hip_mls_set_boundary_limit(w->mls, c.boundaryLimit);
+    if (rc == MLSGPU_OK) rc = mlsgpu_hip_marching_create(ctx, block, block, block, c.maxSwathe, c.meshMemory, wgs, &w->marching);
+    if (rc != MLSGPU_OK)
+    {
+        mlsgpu_hip_worker_destroy(w);
+        return rc;
+    }
+    *out = w;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API void mlsgpu_hip_worker_destroy(mlsgpu_worker *w)
+{
+    if (!w)
+        return;
+    mlsgpu_hip_marching_destroy(w->marching);
+    mlsgpu_hip_mls_destroy(w->mls);
+    mlsgpu_hip_tree_destroy(w->tree);
+    delete w;
+}
+
+/* MeshFilterChain::operator() with the one ScaleBiasFilter the worker installs
+ * (src/workers.cpp:226-230, src/mesh_filter.cpp:45-66): filter, then the user's output functor. */
+static int workerOutput(void *user, void *stream, const mlsgpu_mesh *mesh)
+{
+    mlsgpu_worker *w = static_cast<mlsgpu_worker *>(user);
+    const mlsgpu_worker_config &c = w->cfg;
+    if (mlsgpu_hip_scale_bias(w->ctx, mesh, c.gridSpacing, c.gridOrigin[0], c.gridOrigin[1], c.gridOrigin[2]) != MLSGPU_OK)
+        return 1;
+    if (w->userOutput)
+        return w->userOutput(w->userOutputData, stream, mesh);
+    return 0;
+}
+
+MLSGPU_API int mlsgpu_hip_worker_process(mlsgpu_worker *w, mlsgpu_splat *dSplats, uint64_t firstSplat, uint64_t numSplats,
+                                         const int32_t lowExtent[3], const uint32_t numVertices[3],
+                                         mlsgpu_output_fn output, void *outputUser)
+{
+    REQUIRE(w != nullptr && dSplats != nullptr && lowExtent != nullptr && numVertices != nullptr, MLSGPU_ERR_INVALID);
+    /* src/workers.cpp:237-261 */
+    uint32_t keyOffset[3], size[3], expanded[3];
+    for (int i = 0; i < 3; i++)
+    {
+        REQUIRE(lowExtent[i] >= 0, MLSGPU_ERR_INVALID);     /* keyOffset is cl_uint in the reference */
+        keyOffset[i] = (uint32_t) lowExtent[i];
+        size[i] = numVertices[i];
+        expanded[i] = roundUp(size[i], 8);
+    }
+    w->userOutput = output;
+    w->userOutputData = outputUser;
+    int pend = -1;
+    if (w->ctx->timing) pend = w->ctx->beginTiming(w->ctx->statId("device.compute"));
+    PROPAGATE(mlsgpu_hip_tree_build(w->tree, dSplats, firstSplat, numSplats, expanded, lowExtent, w->cfg.subsampling));
+    PROPAGATE(mlsgpu_hip_mls_set(w->mls, lowExtent, w->tree, w->cfg.subsampling));
+    mlsgpu_generator gen;
+    PROPAGATE(mlsgpu_hip_mls_generator(w->mls, &gen));
+    PROPAGATE(mlsgpu_hip_marching_generate(w->marching, &gen, workerOutput, w, size, keyOffset));
+    if (pend >= 0) w->ctx->endTiming(pend);
+    mlsgpu_hip_tree_clear_splats(w->tree);
+    return MLSGPU_OK;
+}
+
+MLSGPU_API mlsgpu_tree *mlsgpu_hip_worker_tree(mlsgpu_worker *w) { return w ? w->tree : nullptr; }
+MLSGPU_API mlsgpu_mls *mlsgpu_hip_worker_mls(mlsgpu_worker *w) { return w ? w->mls : nullptr; }
+MLSGPU_API mlsgpu_marching *mlsgpu_hip_worker_marching(mlsgpu_worker *w) { return w ? w->marching : nullptr; }

@@ -1,0 +1,152 @@
+/* Shared host/device plumbing of the HIP path: context, error reporting, launch timing, wave/block scans. */
+#ifndef MLSGPU_AMD_COMMON_HPP
+#define MLSGPU_AMD_COMMON_HPP
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/mlsgpu_hip.h"
+
+#define MLSGPU_API extern "C" __attribute__((visibility("default")))
+
+namespace mlsgpu
+{
+
+/* ---------------------------------------------------------------- errors */
+
+int setError(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define HIP_CHECK(expr)                                                                         \
+    do {                                                                                        \
+        hipError_t err__ = (expr);                                                              \
+        if (err__ != hipSuccess)                                                                \
+            return ::mlsgpu::setError(err__ == hipErrorOutOfMemory ? MLSGPU_ERR_NOMEM : MLSGPU_ERR_HIP, \
+                                      "%s failed: %s (%s:%d)", #expr, hipGetErrorString(err__), \
+                                      __FILE__, __LINE__);                                      \
+    } while (0)
+
+/* MLSGPU_ASSERT of src/errors.h:41-42: argument checks that raise length_error / invalid_argument */
+#define REQUIRE(cond, code)                                                                     \
+    do {                                                                                        \
+        if (!(cond))                                                                            \
+            return ::mlsgpu::setError(code, "requirement failed: %s (%s:%d)", #cond, __FILE__, __LINE__); \
+    } while (0)
+
+#define PROPAGATE(expr)                 \
+    do {                                \
+        int rc__ = (expr);              \
+        if (rc__ != MLSGPU_OK)          \
+            return rc__;                \
+    } while (0)
+
+/* ---------------------------------------------------------------- context */
+
+struct Stat
+{
+    double totalMs = 0.0;
+    uint64_t launches = 0;
+};
+
+struct PendingTiming
+{
+    int nameId;
+    hipEvent_t start, stop;
+};
+
+} // namespace mlsgpu
+
+struct mlsgpu_ctx
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    bool timing = false;
+    std::vector<std::string> statNames;
+    std::map<std::string, int> statIds;
+    std::vector<mlsgpu::Stat> stats;
+    std::vector<mlsgpu::PendingTiming> pending;
+    std::vector<hipEvent_t> eventPool;
+
+    int statId(const char *name);
+    int beginTiming(int id);          /* returns index into pending or -1 */
+    void endTiming(int pendingIdx);
+    int resolveTimings();             /* synchronises the stream */
+};
+
+namespace mlsgpu
+{
+
+/* Launch a kernel on the context's stream, timing it under a reference stat name when enabled. */
+#define LAUNCH(ctx, statName, kernel, grid, block, ...)                                       \
+    do {                                                                                      \
+        static thread_local int statId__ = -1;                                                \
+        static thread_local mlsgpu_ctx *statCtx__ = nullptr;                                  \
+        int pend__ = -1;                                                                      \
+        if ((ctx)->timing) {                                                                  \
+            if (statCtx__ != (ctx)) { statId__ = (ctx)->statId(statName); statCtx__ = (ctx); } \
+            pend__ = (ctx)->beginTiming(statId__);                                            \
+        }                                                                                     \
+        hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);               \
+        if (pend__ >= 0) (ctx)->endTiming(pend__);                                            \
+        HIP_CHECK(hipGetLastError());                                                         \
+    } while (0)
+
+static inline uint32_t divUp(uint64_t a, uint64_t b) { return (uint32_t) ((a + b - 1) / b); }
+static inline uint32_t roundUp(uint32_t a, uint32_t b) { return (a + b - 1) / b * b; }
+
+/* ---------------------------------------------------------------- device helpers */
+
+#ifdef __HIPCC__
+
+#define WAVE 64
+
+__device__ __forceinline__ uint32_t laneId()
+{
+    return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+/* number of set bits of `mask` strictly below this lane */
+__device__ __forceinline__ uint32_t popcBelow(uint64_t mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+}
+
+/* inclusive prefix sum across the 64 lanes of a wave */
+__device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v)
+{
+    const uint32_t lane = laneId();
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1)
+    {
+        uint32_t t = __shfl_up(v, d, WAVE);
+        if (lane >= (uint32_t) d)
+            v += t;
+    }
+    return v;
+}
+
+__device__ __forceinline__ uint32_t waveSum(uint32_t v)
+{
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1)
+        v += __shfl_xor(v, d, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t readLane(uint32_t v, int lane)
+{
+    return __builtin_amdgcn_readlane(v, lane);
+}
+
+#endif /* __HIPCC__ */
+
+} // namespace mlsgpu
+
+#endif

@@ -1,0 +1,1055 @@
+/*
+ * Marching tetrahedra with on-device welding on gfx950 -- the device half of Marching
+ * (reference: src/marching.{h,cpp}, kernels/marching.cl) plus ScaleBiasFilter
+ * (src/mesh_filter.cpp:69-113, kernels/scale_bias.cl) and enqueueReadMesh (src/mesh.cpp:62-102).
+ *
+ * Data contracts kept from the reference: lookup tables (makeTables), vertex-key bit layout,
+ * external-vertex rule, internal-first / external-last output order, DeviceKeyMesh layout, the
+ * swathe loop and the mesh-memory overflow protocol of addSlices / shipOut.
+ *
+ * Mechanism, MI355X-first:
+ *  - the distance field is a plain HBM buffer addressed like the reference's packed 2-D image
+ *    (CDNA has no image path); with no 8192-row image limit a swathe may span the whole bucket;
+ *  - occupied cells are compacted in cell-linear (z, y, x) order by a three-component scan
+ *    (cells, vertices, indices) whose producer classifies the cell and whose consumer writes the
+ *    cell and its output positions: deterministic, and no global atomics (the reference appends
+ *    with atomic_inc, kernels/marching.cl:114);
+ *  - welding sorts (compact key, vertex index) pairs on only the significant key bits
+ *    (1 + bits(2W) + bits(2H) + bits(2D) instead of 64) and moves the 16-byte positions once, in
+ *    the compaction pass, instead of through every sort pass;
+ *  - count-unique, its scan, compactVertices and the index remap table are one scan launch set.
+ *  - host synchronisations per bucket: one per swathe (totals) + one per ship-out (welded sizes).
+ */
+#include "common.hpp"
+#include "primitives.hpp"
+
+#include <algorithm>
+#include <cassert>
+
+using namespace mlsgpu;
+
+namespace
+{
+
+enum
+{
+    NUM_EDGES = 19,
+    NUM_TETRAHEDRA = 6,
+    NUM_CUBES = 256,
+    MAX_CELL_VERTICES = 13,
+    MAX_CELL_INDICES = 36,
+    KEY_AXIS_BITS = 21
+};
+const uint64_t KEY_EXTERNAL_FLAG = uint64_t(1) << 63;
+
+/* src/marching.cpp:50-81 */
+const unsigned char edgeIndices[NUM_EDGES][2] =
+{
+    {0, 1}, {0, 2}, {0, 3}, {1, 3}, {2, 3}, {0, 4}, {0, 5}, {1, 5}, {4, 5}, {0, 6},
+    {2, 6}, {4, 6}, {0, 7}, {1, 7}, {2, 7}, {3, 7}, {4, 7}, {5, 7}, {6, 7}
+};
+const unsigned char tetrahedronIndices[NUM_TETRAHEDRA][4] =
+{
+    {0, 7, 1, 3}, {0, 7, 3, 2}, {0, 7, 2, 6}, {0, 7, 6, 4}, {0, 7, 4, 5}, {0, 7, 5, 1}
+};
+
+struct HostTables
+{
+    uint8_t count[NUM_CUBES][2];
+    uint16_t start[NUM_CUBES + 1][2];
+    std::vector<uint8_t> data;      /* vertex edge ids, then index lists */
+    std::vector<uint32_t> key;      /* 3 per vertex entry */
+};
+
+unsigned int findEdge(unsigned int v0, unsigned int v1)
+{
+    if (v0 > v1) std::swap(v0, v1);
+    for (unsigned int i = 0; i < NUM_EDGES; i++)
+        if (edgeIndices[i][0] == v0 && edgeIndices[i][1] == v1)
+            return i;
+    return ~0u;
+}
+
+struct TetVertex
+{
+    unsigned char id;
+    bool outside;
+    bool operator<(const TetVertex &o) const { return id != o.id ? id < o.id : outside < o.outside; }
+    bool operator>(const TetVertex &o) const { return o < *this; }
+};
+
+unsigned int parity4(const TetVertex *v)
+{
+    unsigned int p = 0;
+    for (int i = 0; i < 4; i++)
+        for (int j = i + 1; j < 4; j++)
+            if (v[i] > v[j])
+                p ^= 1;
+    return p;
+}
+
+/* Marching::makeTables, src/marching.cpp:109-252: per cube code, walk the six tetrahedra around
+ * diagonal 0-7; canonicalise each to "outside vertices first" by the first even permutation (w.r.t.
+ * the tetrahedron's own orientation) that std::next_permutation yields, and emit 0, 1 or 2 triangles. */
+void makeTables(HostTables &t)
+{
+    std::vector<uint8_t> vertexTable, indexTable;
+    for (unsigned int cube = 0; cube < NUM_CUBES; cube++)
+    {
+        t.start[cube][0] = (uint16_t) vertexTable.size();
+        t.start[cube][1] = (uint16_t) indexTable.size();
+        std::vector<uint8_t> tri;
+        for (unsigned int j = 0; j < NUM_TETRAHEDRA; j++)
+        {
+            TetVertex tv[4];
+            unsigned int outside = 0;
+            for (int k = 0; k < 4; k++)
+            {
+                tv[k].id = tetrahedronIndices[j][k];
+                tv[k].outside = (cube >> tv[k].id) & 1;
+                outside += tv[k].outside;
+            }
+            unsigned int baseParity = parity4(tv);
+            if (outside > 2)
+            {
+                baseParity ^= 1;
+                for (int k = 0; k < 4; k++)
+                    tv[k].outside = !tv[k].outside;
+            }
+            std::sort(tv, tv + 4);
+            do
+            {
+                if (parity4(tv) != baseParity)
+                    continue;
+                unsigned int mask = 0;
+                for (int k = 0; k < 4; k++)
+                    mask |= (unsigned int) tv[k].outside << k;
+                const unsigned int t0 = tv[0].id, t1 = tv[1].id, t2 = tv[2].id, t3 = tv[3].id;
+                if (mask == 0)
+                    break;
+                if (mask == 1)
+                {
+                    tri.push_back(findEdge(t0, t1)); tri.push_back(findEdge(t0, t3)); tri.push_back(findEdge(t0, t2));
+                    break;
+                }
+                if (mask == 3)
+                {
+                    tri.push_back(findEdge(t0, t2)); tri.push_back(findEdge(t1, t2)); tri.push_back(findEdge(t1, t3));
+                    tri.push_back(findEdge(t1, t3)); tri.push_back(findEdge(t0, t3)); tri.push_back(findEdge(t0, t2));
+                    break;
+                }
+            } while (std::next_permutation(tv, tv + 4));
+        }
+        int compact[NUM_EDGES];
+        int pool = 0;
+        for (unsigned int e = 0; e < NUM_EDGES; e++)
+            if (std::count(tri.begin(), tri.end(), (uint8_t) e))
+            {
+                compact[e] = pool++;
+                vertexTable.push_back((uint8_t) e);
+                for (int axis = 0; axis < 3; axis++)
+                    t.key.push_back(((edgeIndices[e][0] >> axis) & 1) + ((edgeIndices[e][1] >> axis) & 1));
+            }
+        for (size_t k = 0; k < tri.size(); k++)
+            indexTable.push_back((uint8_t) compact[tri[k]]);
+        t.count[cube][0] = (uint8_t) (vertexTable.size() - t.start[cube][0]);
+        t.count[cube][1] = (uint8_t) (indexTable.size() - t.start[cube][1]);
+    }
+    t.start[NUM_CUBES][0] = (uint16_t) vertexTable.size();
+    t.start[NUM_CUBES][1] = (uint16_t) indexTable.size();
+    for (unsigned int i = 0; i <= NUM_CUBES; i++)
+        t.start[i][1] = (uint16_t) (t.start[i][1] + vertexTable.size());
+    t.data = vertexTable;
+    t.data.insert(t.data.end(), indexTable.begin(), indexTable.end());
+}
+
+/* ------------------------------------------------------------------ device side */
+
+struct DevTables
+{
+    const uchar2 *count;     /* [256]  (vertices, indices) */
+    const ushort2 *start;    /* [257] */
+    const uint8_t *data;     /* [8192] */
+    const uint32_t *key;     /* [2432] kx | ky<<8 | kz<<16 */
+};
+
+struct FieldView
+{
+    const float *field;
+    uint64_t pitch;
+    uint32_t zStride;
+    int32_t zBias;
+    __device__ __forceinline__ float at(uint32_t x, uint32_t row) const { return field[(uint64_t) row * pitch + x]; }
+};
+
+/* cell range of one (sub-)swathe: cells (x, y, z) with z in [zFirst, zLast) in (z, y, x) linear order */
+struct CellRange
+{
+    uint32_t cw, ch;         /* cells per row / rows per slice (width-1, height-1) */
+    uint32_t zFirst;
+    __device__ __forceinline__ void decode(uint64_t i64, uint32_t &x, uint32_t &y, uint32_t &z) const
+    {
+        const uint32_t i = (uint32_t) i64;      /* swathe cells < 2^32, checked at creation */
+        x = i % cw;
+        const uint32_t r = i / cw;
+        y = r % ch;
+        z = r / ch + zFirst;
+    }
+};
+
+__device__ __forceinline__ void loadIso(const FieldView &F, uint32_t x, uint32_t y, uint32_t z, float iso[8])
+{
+    /* kernels/marching.cl:95-107 */
+    const uint32_t y0 = y + F.zStride * z + (uint32_t) F.zBias;
+    const uint32_t y1 = y0 + F.zStride;
+    iso[0] = F.at(x, y0);     iso[1] = F.at(x + 1, y0);
+    iso[2] = F.at(x, y0 + 1); iso[3] = F.at(x + 1, y0 + 1);
+    iso[4] = F.at(x, y1);     iso[5] = F.at(x + 1, y1);
+    iso[6] = F.at(x, y1 + 1); iso[7] = F.at(x + 1, y1 + 1);
+}
+
+/* makeCode / isValid, kernels/marching.cl:41-63 */
+__device__ __forceinline__ uint32_t cellCode(const float iso[8], bool &valid)
+{
+    uint32_t code = 0;
+    valid = true;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+    {
+        code |= (iso[i] >= 0.0f ? 1u : 0u) << i;
+        valid = valid && isfinite(iso[i]);
+    }
+    return code;
+}
+
+/* genOccupied (kernels/marching.cl:84-120) as the producer of the compaction scan */
+struct ClassifyIn
+{
+    FieldView F;
+    CellRange R;
+    const uchar2 *countTable;
+    __device__ __forceinline__ U3 operator()(uint64_t i) const
+    {
+        uint32_t x, y, z;
+        R.decode(i, x, y, z);
+        float iso[8];
+        loadIso(F, x, y, z, iso);
+        bool valid;
+        const uint32_t code = cellCode(iso, valid);
+        if (valid && code != 0 && code != 255)
+        {
+            const uchar2 c = countTable[code];
+            return U3{1u, c.x, c.y};
+        }
+        return U3{0u, 0u, 0u};
+    }
+};
+
+/* ... and its consumer: the compacted cell list and each cell's first vertex / index slot
+ * (occupied / viCount after scanElements in the reference, src/marching.cpp:721) */
+struct CompactCellsOut
+{
+    CellRange R;
+    uint2 *cells;        /* x | y<<16, z */
+    uint2 *viStart;
+    uint32_t vBase, iBase;
+    __device__ __forceinline__ void operator()(uint64_t i, U3 excl, U3 val) const
+    {
+        if (val.a)
+        {
+            uint32_t x, y, z;
+            R.decode(i, x, y, z);
+            cells[excl.a] = make_uint2(x | (y << 16), z);
+            viStart[excl.a] = make_uint2(excl.b + vBase, excl.c + iBase);
+        }
+    }
+};
+
+/* per-slice (vertices, indices) histogram, only needed by the overflow path (src/marching.cpp:652-701) */
+__global__ __launch_bounds__(256) void sliceHistogramKernel(FieldView F, uint32_t cw, uint32_t ch, uint32_t zFirst,
+                                                            const uchar2 *countTable, uint2 *histogram)
+{
+    __shared__ uint32_t sv[4], si[4];
+    const uint32_t z = zFirst + blockIdx.x;
+    uint32_t v = 0, idx = 0;
+    const uint32_t cells = cw * ch;
+    for (uint32_t c = threadIdx.x; c < cells; c += 256)
+    {
+        float iso[8];
+        loadIso(F, c % cw, c / cw, z, iso);
+        bool valid;
+        const uint32_t code = cellCode(iso, valid);
+        if (valid && code != 0 && code != 255)
+        {
+            const uchar2 n = countTable[code];
+            v += n.x;
+            idx += n.y;
+        }
+    }
+    v = waveSum(v);
+    idx = waveSum(idx);
+    if ((threadIdx.x & 63) == 0)
+    {
+        sv[threadIdx.x >> 6] = v;
+        si[threadIdx.x >> 6] = idx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+        histogram[z] = make_uint2(sv[0] + sv[1] + sv[2] + sv[3], si[0] + si[1] + si[2] + si[3]);
+}
+
+/* Layout of the compact sort key: [ext][z2 : bz][y2 : by][x2 : bx], order-isomorphic to the
+ * reference's 64-bit key (kernels/marching.cl:148-154) for coordinates that fit the field widths. */
+struct KeyLayout
+{
+    uint32_t bx, by, bz;
+    __host__ __device__ __forceinline__ uint32_t bits() const { return bx + by + bz + 1; }
+};
+
+/* interp, kernels/marching.cl:130-138 (explicit fma, no other contraction) */
+__device__ __forceinline__ void interp(float iso0, float iso1, uint32_t gx, uint32_t gy, uint32_t gz,
+                                       uint32_t c0, uint32_t c1, float &ox, float &oy, float &oz)
+{
+    const float inv = 1.0f / (iso0 - iso1);
+    const float t = iso0 * inv;
+    const uint32_t o0x = c0 & 1, o0y = (c0 >> 1) & 1, o0z = (c0 >> 2) & 1;
+    const uint32_t o1x = c1 & 1, o1y = (c1 >> 1) & 1, o1z = (c1 >> 2) & 1;
+    ox = fmaf(t, (float) (o1x - o0x), (float) (gx + o0x));
+    oy = fmaf(t, (float) (o1y - o0y), (float) (gy + o0y));
+    oz = fmaf(t, (float) (o1z - o0z), (float) (gz + o0z));
+}
+
+__constant__ unsigned char dEdgeIndices[NUM_EDGES][2] =
+{
+    {0, 1}, {0, 2}, {0, 3}, {1, 3}, {2, 3}, {0, 4}, {0, 5}, {1, 5}, {4, 5}, {0, 6},
+    {2, 6}, {4, 6}, {0, 7}, {1, 7}, {2, 7}, {3, 7}, {4, 7}, {5, 7}, {6, 7}
+};
+
+/* generateElements, kernels/marching.cl:184-258.  One thread per occupied cell.  Only the vertices
+ * the cell's code uses are interpolated (the reference computes all 19 into local memory first);
+ * a vertex's value does not depend on which others are computed. */
+template<typename K>
+__global__ __launch_bounds__(256) void generateElementsKernel(float4 *vertices, K *sortKeys, uint32_t *indices,
+                                                              const uint2 *viStart, const uint2 *cells,
+                                                              FieldView F, DevTables T,
+                                                              uint32_t gox, uint32_t goy, uint32_t goz,
+                                                              uint32_t topx, uint32_t topy, uint32_t topz,
+                                                              KeyLayout L, uint32_t numCells)
+{
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= numCells)
+        return;
+    const uint2 cell = cells[gid];
+    const uint32_t x = cell.x & 0xFFFFu, y = cell.x >> 16, z = cell.y;
+    float iso[8];
+    loadIso(F, x, y, z, iso);
+    bool valid;
+    const uint32_t code = cellCode(iso, valid);
+    const uint2 vi = viStart[gid];
+    const ushort2 st = T.start[code], en = T.start[code + 1];
+    const uint32_t nv = en.x - st.x, ni = en.y - st.y;
+    const uint32_t gx = x + gox, gy = y + goy, gz = z + goz;
+    for (uint32_t i = 0; i < nv; i++)
+    {
+        const uint32_t e = T.data[st.x + i];
+        const uint32_t c0 = dEdgeIndices[e][0], c1 = dEdgeIndices[e][1];
+        float vx, vy, vz;
+        interp(iso[c0], iso[c1], gx, gy, gz, c0, c1, vx, vy, vz);
+        vertices[vi.x + i] = make_float4(vx, vy, vz, __uint_as_float(vi.x + i));
+        /* computeKey(2 * cell + keyTable[..], top), kernels/marching.cl:148-154,252 */
+        const uint32_t k = T.key[st.x + i];
+        const uint32_t kx = 2 * x + (k & 0xFF), ky = 2 * y + ((k >> 8) & 0xFF), kz = 2 * z + (k >> 16);
+        const bool ext = kx == 0 || ky == 0 || kx == topx || ky == topy || kz == topz;
+        sortKeys[vi.x + i] = ((K) (ext ? 1u : 0u) << (L.bx + L.by + L.bz)) | ((K) kz << (L.bx + L.by)) | ((K) ky << L.bx) | (K) kx;
+    }
+    for (uint32_t i = 0; i < ni; i++)
+        indices[vi.y + i] = vi.x + T.data[st.y + i];
+}
+
+/* countUniqueVertices (kernels/marching.cl:271-279): 1 for the LAST of each run of equal keys.
+ * The reference appends a ULONG_MAX sentinel; here the last element is simply always a run end. */
+template<typename K>
+struct UniqueIn
+{
+    const K *keys;
+    uint64_t n;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const
+    {
+        return (i + 1 >= n || keys[i] != keys[i + 1]) ? 1u : 0u;
+    }
+};
+
+/* compactVertices (kernels/marching.cl:295-326) as the consumer of that scan.  Positions are
+ * gathered here through the sorted vertex index instead of having travelled through the sort. */
+template<typename K>
+struct CompactVerticesOut
+{
+    const K *keys;
+    const uint32_t *order;       /* sorted original vertex indices */
+    const float4 *inVertices;
+    float *outVertices;
+    uint64_t *outKeys;
+    uint32_t *indexRemap;
+    uint32_t *firstExternal;
+    KeyLayout L;
+    uint32_t zMax2;              /* 2 * zMax: keys with z >= this are external (src/marching.cpp:593) */
+    uint64_t keyOffset;
+    uint64_t n;
+
+    __device__ __forceinline__ bool isExternal(K key) const
+    {
+        const uint32_t z2 = (uint32_t) ((key >> (L.bx + L.by)) & (((K) 1 << L.bz) - 1));
+        return ((key >> (L.bx + L.by + L.bz)) & 1) != 0 || z2 >= zMax2;
+    }
+
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t u, uint32_t isLast) const
+    {
+        const K key = keys[i];
+        const uint32_t orig = order[i];
+        if (isLast)
+        {
+            const float4 v = inVertices[orig];
+            outVertices[3 * (uint64_t) u + 0] = v.x;
+            outVertices[3 * (uint64_t) u + 1] = v.y;
+            outVertices[3 * (uint64_t) u + 2] = v.z;
+            const bool ext = isExternal(key);
+            const bool nextExt = (i + 1 >= n) || isExternal(keys[i + 1]);   /* sentinel counts as external */
+            if (ext)
+            {
+                const uint64_t x2 = (uint64_t) (key & (((K) 1 << L.bx) - 1));
+                const uint64_t y2 = (uint64_t) ((key >> L.bx) & (((K) 1 << L.by) - 1));
+                const uint64_t z2 = (uint64_t) ((key >> (L.bx + L.by)) & (((K) 1 << L.bz) - 1));
+                outKeys[u] = ((z2 << (2 * KEY_AXIS_BITS)) | (y2 << KEY_AXIS_BITS) | x2) + keyOffset;
+                if (u == 0)
+                    *firstExternal = 0;
+            }
+            else if (nextExt)
+                *firstExternal = u + 1;
+        }
+        indexRemap[orig] = u;
+    }
+};
+
+/* reindex, kernels/marching.cl:334-340 */
+__global__ __launch_bounds__(256) void reindexKernel(uint32_t *indices, const uint32_t *indexRemap, uint32_t n)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        indices[i] = indexRemap[indices[i]];
+}
+
+/* copySlice, kernels/marching.cl:349-358 / clEnqueueCopyImage in src/marching.cpp:447-498 */
+__global__ __launch_bounds__(256) void copySliceKernel(float *field, uint64_t pitch, uint32_t srcRow, uint32_t trgRow,
+                                                       uint32_t width, uint32_t height)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < width * height)
+    {
+        const uint32_t x = i % width, y = i / width;
+        field[(uint64_t) (trgRow + y) * pitch + x] = field[(uint64_t) (srcRow + y) * pitch + x];
+    }
+}
+
+/* scaleBiasVertices, kernels/scale_bias.cl:33-41 */
+__global__ __launch_bounds__(256) void scaleBiasKernel(float *vertices, uint64_t numFloats, float scale,
+                                                       float bx, float by, float bz)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < numFloats)
+    {
+        const uint32_t axis = (uint32_t) (i % 3);
+        const float b = axis == 0 ? bx : (axis == 1 ? by : bz);
+        vertices[i] = fmaf(vertices[i], scale, b);
+    }
+}
+
+/* the reference's compactVertices kernel verbatim in behaviour, for its known-answer test */
+__global__ void compactVerticesRefKernel(float *outVertices, uint64_t *outKeys, uint32_t *indexRemap,
+                                         uint32_t *firstExternal, const uint32_t *vertexUnique,
+                                         const float4 *inVertices, const uint64_t *inKeys,
+                                         uint64_t minExternalKey, uint64_t keyOffset, uint64_t n)
+{
+    const uint64_t gid = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= n)
+        return;
+    const uint32_t u = vertexUnique[gid];
+    const float4 v = inVertices[gid];
+    const uint64_t key = inKeys[gid];
+    const uint64_t nextKey = inKeys[gid + 1];
+    const bool ext = key >= minExternalKey;
+    if (key != nextKey)
+    {
+        outVertices[3 * (uint64_t) u + 0] = v.x;
+        outVertices[3 * (uint64_t) u + 1] = v.y;
+        outVertices[3 * (uint64_t) u + 2] = v.z;
+        if (ext)
+        {
+            outKeys[u] = (key & (KEY_EXTERNAL_FLAG - 1)) + keyOffset;
+            if (u == 0)
+                *firstExternal = 0;
+        }
+        else if (nextKey >= minExternalKey)
+            *firstExternal = u + 1;
+    }
+    indexRemap[__float_as_uint(v.w)] = u;
+}
+
+__global__ void computeKeyTestKernel(uint32_t cx, uint32_t cy, uint32_t cz, uint32_t tx, uint32_t ty, uint32_t tz,
+                                     uint64_t *out)
+{
+    /* computeKey, kernels/marching.cl:148-154 */
+    uint64_t key = ((uint64_t) cz << (2 * KEY_AXIS_BITS)) | ((uint64_t) cy << KEY_AXIS_BITS) | (uint64_t) cx;
+    if (cx == 0 || cy == 0 || cx == tx || cy == ty || cz == tz)
+        key |= KEY_EXTERNAL_FLAG;
+    *out = key;
+}
+
+uint32_t bitsFor(uint32_t maxValue)
+{
+    uint32_t b = 1;
+    while ((maxValue >> b) != 0)
+        b++;
+    return b;
+}
+
+struct Readback
+{
+    U3 totals;              /* occupied cells, vertices, indices of the (sub-)swathe */
+    uint32_t numWelded;
+    uint32_t firstExternal;
+};
+
+} // namespace
+
+struct mlsgpu_marching
+{
+    mlsgpu_ctx *ctx = nullptr;
+    uint32_t maxWidth = 0, maxHeight = 0, maxDepth = 0, maxSwathe = 0;
+    uint32_t imageWidth = 0, imageHeight = 0, zStride = 0;
+    uint64_t fieldRows = 0;
+    uint64_t vertexSpace = 0, indexSpace = 0, swatheCells = 0;
+    bool wideKeys = false;
+    HostTables tables;
+
+    float *dField = nullptr;
+    uchar2 *dCount = nullptr;
+    ushort2 *dStart = nullptr;
+    uint8_t *dData = nullptr;
+    uint32_t *dKey = nullptr;
+    uint2 *dCells = nullptr, *dViStart = nullptr, *dHistogram = nullptr;
+    U3 *dTileSums3 = nullptr;
+    float4 *dVertices = nullptr;
+    void *dKeysA = nullptr, *dKeysB = nullptr;
+    uint32_t *dValsA = nullptr, *dValsB = nullptr;
+    uint32_t *dIndices = nullptr, *dIndexRemap = nullptr;
+    float *dWelded = nullptr;
+    uint64_t *dWeldedKeys = nullptr;
+    uint32_t *dHist = nullptr, *dTileSums = nullptr;
+    Readback *dReadback = nullptr;          /* device words */
+    Readback *hReadback = nullptr;          /* pinned */
+    uint2 *hHistogram = nullptr;            /* pinned, maxDepth entries (viReadback in the reference) */
+
+    uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    /* per-generate state */
+    const mlsgpu_generator *generator = nullptr;
+    mlsgpu_output_fn output = nullptr;
+    void *outputUser = nullptr;
+    uint32_t keyOffset[3] = {0, 0, 0};
+    KeyLayout layout = {1, 1, 1};
+
+    FieldView view(const mlsgpu_swathe &sw) const { return FieldView{dField, imageWidth, sw.zStride, sw.zBias}; }
+    DevTables devTables() const { return DevTables{dCount, dStart, dData, dKey}; }
+
+    int generateCells(const mlsgpu_swathe &sw, U3 *totals);
+    int sliceHistogram(const mlsgpu_swathe &sw);
+    int shipOut(const uint32_t sizes[2], uint32_t zMax);
+    int addSlices(const mlsgpu_swathe &sw, uint32_t offsets[2], uint32_t &zTop, uint32_t *shipOuts);
+    template<typename K> int weld(uint32_t nv, uint32_t zMax);
+};
+
+namespace
+{
+
+uint64_t marchingSizes(uint32_t maxWidth, uint32_t maxHeight, uint32_t maxDepth, uint32_t maxSwathe,
+                       uint64_t meshMemory, const uint32_t alignment[3],
+                       uint32_t *imageWidth, uint32_t *imageHeight, uint32_t *swathe,
+                       uint64_t *vertexSpace, uint64_t *indexSpace, uint64_t *swatheCells, uint64_t *fieldRows)
+{
+    /* src/marching.cpp:273-284 */
+    *imageWidth = roundUp(maxWidth, alignment[0]);
+    *imageHeight = roundUp(maxHeight, alignment[1]);
+    *swathe = std::min(maxSwathe, maxDepth) / alignment[2] * alignment[2];
+    const uint64_t sliceCells = (uint64_t) (maxWidth - 1) * (maxHeight - 1);
+    *swatheCells = sliceCells * *swathe;
+    const uint64_t meshCells = meshMemory / MLSGPU_MARCHING_MAX_CELL_BYTES;
+    *vertexSpace = meshCells * MAX_CELL_VERTICES;
+    *indexSpace = meshCells * MAX_CELL_INDICES;
+    /* image height imageHeight * (maxSwathe + 1) (src/marching.cpp:380-381), plus the slack a
+     * generator may write when the last swathe is padded up to its Z alignment (src/marching.h:236-237) */
+    *fieldRows = (uint64_t) *imageHeight * (*swathe + 1 + alignment[2]);
+    const uint64_t vs = *vertexSpace, is = *indexSpace, sc = *swatheCells;
+    uint64_t bytes = *fieldRows * *imageWidth * 4;
+    bytes += sc * 16;                               /* cells + viStart */
+    bytes += (uint64_t) scanTiles(sc) * 12 + 12;    /* tile sums (U3) */
+    bytes += vs * 16;                               /* unwelded vertices */
+    bytes += vs * 8 * 2 + vs * 4 * 2;               /* sort keys + values, ping-pong */
+    bytes += is * 4 + vs * 4;                       /* indices, indexRemap */
+    bytes += vs * 12 + vs * 8;                      /* welded vertices + keys */
+    bytes += sortHistElems(vs) * 4 + (uint64_t) scanTiles(std::max(sortHistElems(vs), vs)) * 4;
+    bytes += (uint64_t) maxDepth * 8 + 512 + 1028 + 8192 + 2432 * 4;
+    return bytes;
+}
+
+} // namespace
+
+MLSGPU_API uint64_t mlsgpu_hip_marching_resource_usage(uint32_t maxWidth, uint32_t maxHeight, uint32_t maxDepth,
+                                                       uint32_t maxSwathe, uint64_t meshMemory, const uint32_t alignment[3])
+{
+    uint32_t iw, ih, sw;
+    uint64_t vs, is, sc, fr;
+    return marchingSizes(maxWidth, maxHeight, maxDepth, maxSwathe, meshMemory, alignment, &iw, &ih, &sw, &vs, &is, &sc, &fr);
+}
+
+MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, uint32_t maxHeight, uint32_t maxDepth,
+                                          uint32_t maxSwathe, uint64_t meshMemory, const uint32_t alignment[3],
+                                          mlsgpu_marching **out)
+{
+    REQUIRE(ctx != nullptr && out != nullptr && alignment != nullptr, MLSGPU_ERR_INVALID);
+    /* src/marching.cpp:359-363 */
+    REQUIRE(2 <= maxWidth && maxWidth <= MLSGPU_MARCHING_MAX_DIMENSION, MLSGPU_ERR_INVALID);
+    REQUIRE(2 <= maxHeight && maxHeight <= MLSGPU_MARCHING_MAX_DIMENSION, MLSGPU_ERR_INVALID);
+    REQUIRE(2 <= maxDepth && maxDepth <= MLSGPU_MARCHING_MAX_DIMENSION, MLSGPU_ERR_INVALID);
+    REQUIRE(alignment[0] >= 1 && alignment[1] >= 1 && alignment[2] >= 1, MLSGPU_ERR_INVALID);
+    REQUIRE(alignment[2] <= maxSwathe, MLSGPU_ERR_INVALID);
+    REQUIRE(meshMemory >= (uint64_t) (maxWidth - 1) * (maxHeight - 1) * MLSGPU_MARCHING_MAX_CELL_BYTES, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+
+    mlsgpu_marching *m = new mlsgpu_marching;
+    m->ctx = ctx;
+    m->maxWidth = maxWidth; m->maxHeight = maxHeight; m->maxDepth = maxDepth;
+    marchingSizes(maxWidth, maxHeight, maxDepth, maxSwathe, meshMemory, alignment, &m->imageWidth, &m->imageHeight,
+                  &m->maxSwathe, &m->vertexSpace, &m->indexSpace, &m->swatheCells, &m->fieldRows);
+    m->zStride = m->imageHeight;
+    if (m->vertexSpace >= (uint64_t(1) << 32) || m->indexSpace >= (uint64_t(1) << 32))
+    {
+        delete m;
+        return setError(MLSGPU_ERR_LENGTH, "Marching: meshMemory gives more than 2^32 vertices or indices");
+    }
+    if (m->swatheCells >= (uint64_t(1) << 32))
+    {
+        delete m;
+        return setError(MLSGPU_ERR_LENGTH, "Marching: more than 2^32 cells per swathe");
+    }
+    makeTables(m->tables);
+    assert(m->tables.data.size() == 8192 && m->tables.key.size() == 2432 * 3);    /* src/marching.cpp:248-251 */
+
+    int rc = MLSGPU_OK;
+    auto alloc = [&](void **p, uint64_t bytes) {
+        if (rc == MLSGPU_OK && hipMalloc(p, bytes ? bytes : 4) != hipSuccess)
+            rc = setError(MLSGPU_ERR_NOMEM, "Marching: cannot allocate %llu bytes", (unsigned long long) bytes);
+    };
+    const uint64_t vs = m->vertexSpace, is = m->indexSpace, sc = m->swatheCells;
+    alloc((void **) &m->dField, m->fieldRows * m->imageWidth * 4);
+    alloc((void **) &m->dCount, 512);
+    alloc((void **) &m->dStart, 257 * 4);
+    alloc((void **) &m->dData, 8192);
+    alloc((void **) &m->dKey, 2432 * 4);
+    alloc((void **) &m->dCells, sc * 8);
+    alloc((void **) &m->dViStart, sc * 8);
+    alloc((void **) &m->dHistogram, (uint64_t) maxDepth * 8);
+    alloc((void **) &m->dTileSums3, ((uint64_t) scanTiles(sc) + 1) * sizeof(U3));
+    alloc((void **) &m->dVertices, vs * 16);
+    alloc(&m->dKeysA, (vs + 1) * 8);
+    alloc(&m->dKeysB, (vs + 1) * 8);
+    alloc((void **) &m->dValsA, (vs + 1) * 4);
+    alloc((void **) &m->dValsB, (vs + 1) * 4);
+    alloc((void **) &m->dIndices, is * 4);
+    alloc((void **) &m->dIndexRemap, vs * 4);
+    alloc((void **) &m->dWelded, vs * 12);
+    alloc((void **) &m->dWeldedKeys, vs * 8);
+    alloc((void **) &m->dHist, (sortHistElems(vs) + 1) * 4);
+    alloc((void **) &m->dTileSums, ((uint64_t) scanTiles(std::max(sortHistElems(vs), vs)) + 1) * 4);
+    alloc((void **) &m->dReadback, sizeof(Readback));
+    if (rc == MLSGPU_OK && hipHostMalloc((void **) &m->hReadback, sizeof(Readback)) != hipSuccess)
+        rc = setError(MLSGPU_ERR_NOMEM, "Marching: cannot allocate pinned readback");
+    if (rc == MLSGPU_OK && hipHostMalloc((void **) &m->hHistogram, (uint64_t) maxDepth * 8) != hipSuccess)
+        rc = setError(MLSGPU_ERR_NOMEM, "Marching: cannot allocate pinned histogram");
+    if (rc != MLSGPU_OK)
+    {
+        mlsgpu_hip_marching_destroy(m);
+        return rc;
+    }
+    /* upload the tables */
+    std::vector<uint32_t> packedKey(2432);
+    for (int i = 0; i < 2432; i++)
+        packedKey[i] = m->tables.key[3 * i] | (m->tables.key[3 * i + 1] << 8) | (m->tables.key[3 * i + 2] << 16);
+    hipError_t e = hipMemcpy(m->dCount, m->tables.count, 512, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->dStart, m->tables.start, 257 * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->dData, m->tables.data.data(), 8192, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->dKey, packedKey.data(), 2432 * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess)
+    {
+        mlsgpu_hip_marching_destroy(m);
+        return setError(MLSGPU_ERR_HIP, "Marching: table upload failed: %s", hipGetErrorString(e));
+    }
+    *out = m;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API void mlsgpu_hip_marching_destroy(mlsgpu_marching *m)
+{
+    if (!m)
+        return;
+    hipSetDevice(m->ctx->device);
+    hipFree(m->dField); hipFree(m->dCount); hipFree(m->dStart); hipFree(m->dData); hipFree(m->dKey);
+    hipFree(m->dCells); hipFree(m->dViStart); hipFree(m->dHistogram); hipFree(m->dTileSums3);
+    hipFree(m->dVertices); hipFree(m->dKeysA); hipFree(m->dKeysB); hipFree(m->dValsA); hipFree(m->dValsB);
+    hipFree(m->dIndices); hipFree(m->dIndexRemap); hipFree(m->dWelded); hipFree(m->dWeldedKeys);
+    hipFree(m->dHist); hipFree(m->dTileSums); hipFree(m->dReadback);
+    if (m->hReadback) hipHostFree(m->hReadback);
+    if (m->hHistogram) hipHostFree(m->hHistogram);
+    delete m;
+}
+
+/* generateCells, src/marching.cpp:500-551: classify the cells of the swathe and return the totals.
+ * Leaves the scanned tile sums in dTileSums3 for the compaction pass. */
+int mlsgpu_marching::generateCells(const mlsgpu_swathe &sw, U3 *totals)
+{
+    const CellRange R{sw.width - 1, sw.height - 1, sw.zFirst};
+    const uint64_t n = (uint64_t) R.cw * R.ch * (sw.zLast - sw.zFirst);
+    ClassifyIn in{view(sw), R, dCount};
+    PROPAGATE((scanPhase1<U3, ClassifyIn>(ctx, "kernel.marching.genOccupied.time", in, n, U3{0, 0, 0},
+                                          dTileSums3, &dReadback->totals)));
+    int pend = -1;
+    if (ctx->timing) pend = ctx->beginTiming(ctx->statId("kernel.marching.readback.time"));
+    HIP_CHECK(hipMemcpyAsync(&hReadback->totals, &dReadback->totals, sizeof(U3), hipMemcpyDeviceToHost, ctx->stream));
+    if (pend >= 0) ctx->endTiming(pend);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));        /* the reference's queue.finish(), :548 */
+    *totals = hReadback->totals;
+    return MLSGPU_OK;
+}
+
+int mlsgpu_marching::sliceHistogram(const mlsgpu_swathe &sw)
+{
+    const uint32_t slices = sw.zLast - sw.zFirst;
+    LAUNCH(ctx, "kernel.marching.genOccupied.time", sliceHistogramKernel, dim3(slices), dim3(256),
+           view(sw), sw.width - 1, sw.height - 1, sw.zFirst, (const uchar2 *) dCount, dHistogram);
+    HIP_CHECK(hipMemcpyAsync(hHistogram + sw.zFirst, dHistogram + sw.zFirst, (size_t) slices * 8,
+                             hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MLSGPU_OK;
+}
+
+template<typename K>
+int mlsgpu_marching::weld(uint32_t nv, uint32_t zMax)
+{
+    K *keysA = static_cast<K *>(dKeysA), *keysB = static_cast<K *>(dKeysB);
+    SortResult<K> sorted;
+    PROPAGATE(radixSort<K>(ctx, "kernel.marching.sortVertices.time", keysA, dValsA, keysB, dValsB, nv, layout.bits(),
+                           true, dHist, dTileSums, &sorted));
+    const uint64_t keyOffsetL = ((uint64_t) keyOffset[2] << (2 * KEY_AXIS_BITS + 1))
+        | ((uint64_t) keyOffset[1] << (KEY_AXIS_BITS + 1))
+        | ((uint64_t) keyOffset[0] << 1);                                   /* src/marching.cpp:594-597 */
+    UniqueIn<K> in{sorted.keys, nv};
+    CompactVerticesOut<K> outF{sorted.keys, sorted.vals, dVertices, dWelded, dWeldedKeys, dIndexRemap,
+                               &dReadback->firstExternal, layout, 2 * zMax, keyOffsetL, nv};
+    return exclusiveScan<uint32_t>(ctx, "kernel.marching.compactVertices.time", in, outF, nv, 0u, dTileSums,
+                                   &dReadback->numWelded);
+}
+
+/* shipOut, src/marching.cpp:553-625 */
+int mlsgpu_marching::shipOut(const uint32_t sizes[2], uint32_t zMax)
+{
+    const uint32_t nv = sizes[0], ni = sizes[1];
+    if (wideKeys)
+        PROPAGATE(weld<uint64_t>(nv, zMax));
+    else
+        PROPAGATE(weld<uint32_t>(nv, zMax));
+    if (ni > 0)
+        LAUNCH(ctx, "kernel.marching.reindex.time", reindexKernel, dim3(divUp(ni, 256)), dim3(256),
+               dIndices, (const uint32_t *) dIndexRemap, ni);
+    HIP_CHECK(hipMemcpyAsync(&hReadback->numWelded, &dReadback->numWelded, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));        /* the reference's queue.finish(), :617 */
+
+    mlsgpu_mesh mesh;
+    mesh.dVertices = dWelded;
+    mesh.dTriangles = dIndices;
+    mesh.dVertexKeys = dWeldedKeys;
+    mesh.numVertices = hReadback->numWelded;
+    mesh.numTriangles = ni / 3;
+    mesh.numInternalVertices = hReadback->firstExternal;
+    counters[1]++;
+    counters[4] += nv;
+    counters[5] += ni;
+    counters[6] += mesh.numVertices;
+    counters[7] += mesh.numVertices - mesh.numInternalVertices;
+    if (output != nullptr)
+    {
+        const int rc = output(outputUser, ctx->stream, &mesh);
+        if (rc != 0)
+            return setError(MLSGPU_ERR_CALLBACK, "output functor failed with %d", rc);
+    }
+    return MLSGPU_OK;
+}
+
+/* addSlices, src/marching.cpp:627-743 */
+int mlsgpu_marching::addSlices(const mlsgpu_swathe &swathe, uint32_t offsets[2], uint32_t &zTop, uint32_t *shipOuts)
+{
+    uint32_t top[3] = {2 * (swathe.width - 1), 2 * (swathe.height - 1), 2 * zTop};
+    U3 totals;
+    PROPAGATE(generateCells(swathe, &totals));
+    const uint32_t compacted = totals.a;
+    if (compacted > 0)
+    {
+        uint32_t counts[2] = {totals.b, totals.c};
+        if (counts[0] > vertexSpace || counts[1] > indexSpace)
+        {
+            counters[0]++;
+            /* Swathe is too big on its own: split it into maximal runs of slices using the
+             * per-slice histogram and recurse (:652-701). */
+            PROPAGATE(sliceHistogram(swathe));
+            std::vector<uint2> hist(hHistogram + swathe.zFirst, hHistogram + swathe.zLast);
+            auto H = [&](uint32_t z, int j) -> uint64_t { return j == 0 ? hist[z - swathe.zFirst].x : hist[z - swathe.zFirst].y; };
+            uint32_t subFirst = swathe.zFirst;
+            while (subFirst < swathe.zLast)
+            {
+                uint32_t subLast = subFirst;
+                uint64_t c0 = 0, c1 = 0;
+                while (subLast < swathe.zLast
+                       && offsets[0] + c0 + H(subLast, 0) <= vertexSpace
+                       && offsets[1] + c1 + H(subLast, 1) <= indexSpace)
+                {
+                    c0 += H(subLast, 0);
+                    c1 += H(subLast, 1);
+                    subLast++;
+                }
+                if (subFirst == subLast)
+                {
+                    while (subLast < swathe.zLast
+                           && c0 + H(subLast, 0) <= vertexSpace
+                           && c1 + H(subLast, 1) <= indexSpace)
+                    {
+                        c0 += H(subLast, 0);
+                        c1 += H(subLast, 1);
+                        subLast++;
+                    }
+                }
+                if (subLast <= subFirst)
+                    return setError(MLSGPU_ERR_LENGTH, "Marching: a single slice exceeds the mesh memory");
+                mlsgpu_swathe sub = swathe;
+                sub.zFirst = subFirst;
+                sub.zLast = subLast;
+                PROPAGATE(addSlices(sub, offsets, zTop, shipOuts));
+                subFirst = subLast;
+            }
+        }
+        else
+        {
+            if ((uint64_t) offsets[0] + counts[0] > vertexSpace || (uint64_t) offsets[1] + counts[1] > indexSpace)
+            {
+                /* fits, but only after flushing what is buffered (:705-719) */
+                PROPAGATE(shipOut(offsets, swathe.zFirst));
+                (*shipOuts)++;
+                offsets[0] = offsets[1] = 0;
+                zTop = swathe.zFirst;
+                top[2] = 2 * swathe.zFirst;
+            }
+            /* scanElements + generateElements (:721-731): compaction pass, then one thread per cell */
+            const CellRange R{swathe.width - 1, swathe.height - 1, swathe.zFirst};
+            const uint64_t n = (uint64_t) R.cw * R.ch * (swathe.zLast - swathe.zFirst);
+            ClassifyIn in{view(swathe), R, dCount};
+            CompactCellsOut outF{R, dCells, dViStart, offsets[0], offsets[1]};
+            PROPAGATE((scanPhase2<U3, ClassifyIn, CompactCellsOut>(ctx, "kernel.marching.scanElements.time", in, outF, n,
+                                                                   (const U3 *) dTileSums3)));
+            const dim3 grid(divUp(compacted, 256)), block(256);
+            if (wideKeys)
+                LAUNCH(ctx, "kernel.marching.generateElements.time", (generateElementsKernel<uint64_t>), grid, block,
+                       dVertices, static_cast<uint64_t *>(dKeysA), dIndices, (const uint2 *) dViStart, (const uint2 *) dCells,
+                       view(swathe), devTables(), keyOffset[0], keyOffset[1], keyOffset[2], top[0], top[1], top[2],
+                       layout, compacted);
+            else
+                LAUNCH(ctx, "kernel.marching.generateElements.time", (generateElementsKernel<uint32_t>), grid, block,
+                       dVertices, static_cast<uint32_t *>(dKeysA), dIndices, (const uint2 *) dViStart, (const uint2 *) dCells,
+                       view(swathe), devTables(), keyOffset[0], keyOffset[1], keyOffset[2], top[0], top[1], top[2],
+                       layout, compacted);
+            offsets[0] += counts[0];
+            offsets[1] += counts[1];
+            counters[3] += compacted;
+        }
+    }
+    counters[2] += compacted > 0;
+    return MLSGPU_OK;
+}
+
+/* Marching::generate, src/marching.cpp:745-824 */
+MLSGPU_API int mlsgpu_hip_marching_generate(mlsgpu_marching *m, const mlsgpu_generator *generator,
+                                            mlsgpu_output_fn output, void *outputUser,
+                                            const uint32_t size[3], const uint32_t keyOffset[3])
+{
+    REQUIRE(m != nullptr && generator != nullptr && generator->enqueue != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(size != nullptr && keyOffset != nullptr, MLSGPU_ERR_INVALID);
+    mlsgpu_swathe swathe;
+    swathe.width = size[0];
+    swathe.height = size[1];
+    swathe.zStride = m->zStride;
+    const uint32_t depth = size[2];
+    REQUIRE(1u <= swathe.width && swathe.width <= m->maxWidth, MLSGPU_ERR_LENGTH);
+    REQUIRE(1u <= swathe.height && swathe.height <= m->maxHeight, MLSGPU_ERR_LENGTH);
+    REQUIRE(1u <= depth && depth <= m->maxDepth, MLSGPU_ERR_LENGTH);
+    /* global coordinates must fit the 20.1 key fields (MAX_GLOBAL_DIMENSION, src/marching.h:145-150) */
+    for (int i = 0; i < 3; i++)
+        REQUIRE((uint64_t) keyOffset[i] + size[i] <= (1u << 20) - 1, MLSGPU_ERR_LENGTH);
+    mlsgpu_ctx *ctx = m->ctx;
+    HIP_CHECK(hipSetDevice(ctx->device));
+
+    m->generator = generator;
+    m->output = output;
+    m->outputUser = outputUser;
+    for (int i = 0; i < 3; i++)
+        m->keyOffset[i] = keyOffset[i];
+    /* the generate-time key layout: only as many bits as this bucket's doubled local coordinates need */
+    m->layout.bx = bitsFor(2 * (swathe.width - 1));
+    m->layout.by = bitsFor(2 * (swathe.height - 1));
+    m->layout.bz = bitsFor(2 * (depth - 1));
+    m->wideKeys = m->layout.bits() > 32;
+
+    uint32_t offsets[2] = {0, 0};
+    uint32_t zTop = 0;
+    uint32_t shipOuts = 0;
+    for (uint32_t z = 0; z < depth; z += m->maxSwathe)
+    {
+        swathe.zFirst = z;
+        swathe.zLast = std::min(depth, z + m->maxSwathe) - 1;
+        swathe.zBias = (1 - (int32_t) z) * (int32_t) swathe.zStride;
+        if (z != 0)
+            PROPAGATE(mlsgpu_hip_marching_copy_slice(m, m->dField, m->imageWidth, m->maxSwathe, 0,
+                                                     swathe.width, swathe.height, swathe.zStride));
+        {
+            const int rc = generator->enqueue(generator->user, ctx->stream, m->dField, m->imageWidth, &swathe);
+            if (rc != 0)
+                return rc > 0 && rc <= MLSGPU_ERR_CALLBACK ? rc : setError(MLSGPU_ERR_CALLBACK, "generator failed with %d", rc);
+        }
+        if (z > 0)
+            swathe.zFirst--;
+        PROPAGATE(m->addSlices(swathe, offsets, zTop, &shipOuts));
+    }
+    if (offsets[0] > 0)
+    {
+        PROPAGATE(m->shipOut(offsets, depth - 1));
+        shipOuts++;
+    }
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_marching_counters(const mlsgpu_marching *m, uint64_t out[8])
+{
+    REQUIRE(m != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    std::memcpy(out, m->counters, sizeof(m->counters));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_marching_tables(const mlsgpu_marching *m, uint8_t *count, uint16_t *start, uint8_t *data, uint32_t *key)
+{
+    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
+    /* read back from the DEVICE copies so that the test sees what the kernels see */
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    HIP_CHECK(hipMemcpy(count, m->dCount, 512, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(start, m->dStart, 257 * 4, hipMemcpyDeviceToHost));
+    HIP_CHECK(hipMemcpy(data, m->dData, 8192, hipMemcpyDeviceToHost));
+    std::vector<uint32_t> packed(2432);
+    HIP_CHECK(hipMemcpy(packed.data(), m->dKey, 2432 * 4, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 2432; i++)
+    {
+        key[3 * i] = packed[i] & 0xFF;
+        key[3 * i + 1] = (packed[i] >> 8) & 0xFF;
+        key[3 * i + 2] = packed[i] >> 16;
+    }
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_marching_copy_slice(mlsgpu_marching *m, float *dField, uint64_t pitch, uint32_t src, uint32_t trg,
+                                              uint32_t width, uint32_t height, uint32_t zStride)
+{
+    REQUIRE(m != nullptr && dField != nullptr, MLSGPU_ERR_INVALID);
+    if (width == 0 || height == 0)
+        return MLSGPU_OK;
+    LAUNCH(m->ctx, "kernel.marching.copySlice.time", copySliceKernel, dim3(divUp((uint64_t) width * height, 256)), dim3(256),
+           dField, pitch, src * zStride, trg * zStride, width, height);
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_compact_vertices(mlsgpu_ctx *ctx, float *dOutVertices, uint64_t *dOutKeys, uint32_t *dIndexRemap,
+                                           uint32_t *dFirstExternal, const uint32_t *dVertexUnique,
+                                           const float *dInVertices4, const uint64_t *dInKeys,
+                                           uint64_t minExternalKey, uint64_t keyOffset, uint64_t n)
+{
+    REQUIRE(ctx != nullptr, MLSGPU_ERR_INVALID);
+    if (n == 0)
+        return MLSGPU_OK;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    LAUNCH(ctx, "kernel.marching.compactVertices.time", compactVerticesRefKernel, dim3(divUp(n, 64)), dim3(64),
+           dOutVertices, dOutKeys, dIndexRemap, dFirstExternal, dVertexUnique,
+           reinterpret_cast<const float4 *>(dInVertices4), dInKeys, minExternalKey, keyOffset, n);
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_test_compute_key(mlsgpu_ctx *ctx, const uint32_t c[3], const uint32_t top[3], uint64_t *out)
+{
+    REQUIRE(ctx != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    uint64_t *d = nullptr;
+    HIP_CHECK(hipMalloc(&d, 8));
+    hipLaunchKernelGGL(computeKeyTestKernel, dim3(1), dim3(1), 0, ctx->stream, c[0], c[1], c[2], top[0], top[1], top[2], d);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(out, d, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    hipFree(d);
+    return MLSGPU_OK;
+}
+
+/* ------------------------------------------------------------------ mesh plumbing */
+
+MLSGPU_API uint64_t mlsgpu_hip_mesh_host_bytes(const mlsgpu_mesh *mesh)
+{
+    /* MeshSizes::getHostBytes, src/mesh.h:75-80 */
+    return 12 * mesh->numVertices + 12 * mesh->numTriangles + 8 * (mesh->numVertices - mesh->numInternalVertices);
+}
+
+MLSGPU_API int mlsgpu_hip_mesh_read(mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh, void *hostBlob, int async)
+{
+    REQUIRE(ctx != nullptr && mesh != nullptr && hostBlob != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(mesh->numInternalVertices <= mesh->numVertices, MLSGPU_ERR_INVALID);             /* src/mesh.cpp:69 */
+    REQUIRE(reinterpret_cast<uintptr_t>(hostBlob) % 8 == 0, MLSGPU_ERR_INVALID);             /* src/mesh.cpp:55 */
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const uint64_t numExt = mesh->numVertices - mesh->numInternalVertices;
+    /* HostKeyMesh layout, src/mesh.cpp:51-60 */
+    uint64_t *hKeys = static_cast<uint64_t *>(hostBlob);
+    float *hVerts = reinterpret_cast<float *>(hKeys + numExt);
+    uint32_t *hTris = reinterpret_cast<uint32_t *>(hVerts + 3 * mesh->numVertices);
+    int pend = -1;
+    if (ctx->timing) pend = ctx->beginTiming(ctx->statId("device.read"));
+    if (mesh->numTriangles)
+        HIP_CHECK(hipMemcpyAsync(hTris, mesh->dTriangles, mesh->numTriangles * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (numExt)
+        HIP_CHECK(hipMemcpyAsync(hKeys, mesh->dVertexKeys + mesh->numInternalVertices, numExt * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (mesh->numVertices)
+        HIP_CHECK(hipMemcpyAsync(hVerts, mesh->dVertices, mesh->numVertices * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (pend >= 0) ctx->endTiming(pend);
+    if (!async)
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_scale_bias(mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh, float scale, float bx, float by, float bz)
+{
+    REQUIRE(ctx != nullptr && mesh != nullptr, MLSGPU_ERR_INVALID);
+    if (mesh->numVertices == 0)
+        return MLSGPU_OK;           /* empty mesh is legal, test/test_mesh_filter.cpp:340-361 */
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const uint64_t n = mesh->numVertices * 3;
+    LAUNCH(ctx, "kernel.scaleBias.time", scaleBiasKernel, dim3(divUp(n, 256)), dim3(256), mesh->dVertices, n, scale, bx, by, bz);
+    return MLSGPU_OK;
+}

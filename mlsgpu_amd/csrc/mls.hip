@@ -1,0 +1,528 @@
+/*
+ * Moving-least-squares corner evaluation on gfx950 -- the device half of MlsFunctor
+ * (reference: src/mls.{h,cpp}, kernels/mls.cl:299-433 processCorners).
+ *
+ * One 512-thread workgroup (8 waves) evaluates one 8x8x8 block of grid corners, all of which share
+ * one octree leaf and therefore one splat list (src/mls.cpp:53-54: wgs = {8,8,8}, subsamplingMin 3).
+ * Per corner the splats are accumulated in LIST ORDER (leaf range first, then each ancestor's),
+ * which fixes the floating-point summation order; both variants below keep that order, so their
+ * results are bit-identical to each other and to the oracle.
+ *
+ * Variant 0 (default, "culled"): the workgroup stages up to 512 listed splats per round into LDS
+ * (position/radius and normal/quality, one coalescable 32-byte record per thread) and tags each
+ * with an 8-bit mask of the 4x4x4 sub-blocks its support sphere can reach.  Each wave owns one
+ * sub-block (lane = x + 4y + 16z), ballots the mask 64 splats at a time and only visits the
+ * splats that can touch its 64 corners -- typically 4-6x fewer distance tests than the
+ * reference's every-corner-tests-every-listed-splat loop.  The cull test has the same fma
+ * structure as the per-corner distance, so by monotonicity of rounding it never drops a splat a
+ * corner would accept (DESIGN.md "processCorners").
+ * Variant 1 ("basic"): the reference's structure (every thread walks every staged splat).
+ *
+ * Floating-point contract: compiled with -ffp-contract=off; fmaf only where written.
+ */
+#include "common.hpp"
+
+using namespace mlsgpu;
+
+struct mlsgpu_tree;
+extern "C" const mlsgpu_splat *mlsgpu_hip_tree_splats(const mlsgpu_tree *);
+extern "C" const int32_t *mlsgpu_hip_tree_commands(const mlsgpu_tree *);
+extern "C" const int32_t *mlsgpu_hip_tree_start(const mlsgpu_tree *);
+
+struct mlsgpu_mls
+{
+    mlsgpu_ctx *ctx = nullptr;
+    int shape = MLSGPU_SHAPE_SPHERE;
+    int variant = 0;
+    const mlsgpu_splat *dSplats = nullptr;
+    const int32_t *dCommands = nullptr;
+    const int32_t *dStart = nullptr;
+    uint32_t startShift = 0;
+    int32_t offset[3] = {0, 0, 0};
+    float boundaryFactor = 0.0f;
+    bool isSet = false;
+    unsigned long long *dStats = nullptr;   /* optional work counters, see mlsgpu_hip_mls_set_stats */
+};
+
+namespace
+{
+
+#define RADIUS_CUTOFF 0.99f
+#define HITS_CUTOFF 4u
+#define STAGE 512
+
+/* kernels/mls.cl:105-108 */
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+    return fmaf(ax, bx, fmaf(ay, by, az * bz));
+}
+
+struct Fit
+{
+    float sumWpp, sumWpn;
+    float sumWpx, sumWpy, sumWpz;
+    float sumWnx, sumWny, sumWnz;
+    float sumW;
+    uint32_t hits;
+};
+
+__device__ __forceinline__ void fitInit(Fit &f)
+{
+    f.sumWpp = f.sumWpn = 0.0f;
+    f.sumWpx = f.sumWpy = f.sumWpz = 0.0f;
+    f.sumWnx = f.sumWny = f.sumWnz = 0.0f;
+    f.sumW = 0.0f;
+    f.hits = 0;
+}
+
+/* sphereFitAdd, kernels/mls.cl:129-139 (planeFitAdd :141-148 keeps a subset of the same sums). */
+__device__ __forceinline__ void fitAdd(Fit &f, float w, float px, float py, float pz, float pp,
+                                       float nx, float ny, float nz)
+{
+    const float wnx = w * nx, wny = w * ny, wnz = w * nz;
+    f.sumW = f.sumW + w;
+    f.sumWpx = fmaf(w, px, f.sumWpx);
+    f.sumWpy = fmaf(w, py, f.sumWpy);
+    f.sumWpz = fmaf(w, pz, f.sumWpz);
+    f.sumWnx = fmaf(w, nx, f.sumWnx);
+    f.sumWny = fmaf(w, ny, f.sumWny);
+    f.sumWnz = fmaf(w, nz, f.sumWnz);
+    f.sumWpp = fmaf(w, pp, f.sumWpp);
+    f.sumWpn = f.sumWpn + dot3(wnx, wny, wnz, px, py, pz);
+    f.hits++;
+}
+
+/* kernels/mls.cl:237-248 */
+__device__ __forceinline__ float solveQuadratic(float a, float b, float c)
+{
+    float bdet = b + sqrtf(b * b - 4.0f * a * c);
+    float x = -2.0f * c / bdet;
+    if (!isfinite(x))
+        x = bdet / (-2.0f * a);
+    return isfinite(x) ? x : __int_as_float(0x7FC00000);
+}
+
+/* fitSphere + projectOriginSphere + acceptance tests, kernels/mls.cl:210-229,263-267,394-408;
+ * plane variant :198-203,277-280,409-422. */
+template<int SHAPE>
+__device__ __forceinline__ float finishCorner(const Fit &fit, float boundaryFactor)
+{
+    float f = __int_as_float(0x7FC00000);
+    if (fit.hits >= HITS_CUTOFF)
+    {
+        if (SHAPE == MLSGPU_SHAPE_SPHERE)
+        {
+            const float invSumW = 1.0f / fit.sumW;
+            const float mx = fit.sumWpx * invSumW, my = fit.sumWpy * invSumW, mz = fit.sumWpz * invSumW;
+            const float qNum = fit.sumWpn - dot3(mx, my, mz, fit.sumWnx, fit.sumWny, fit.sumWnz);
+            const float qDen = fit.sumWpp - dot3(mx, my, mz, fit.sumWpx, fit.sumWpy, fit.sumWpz);
+            float q = qNum / qDen;
+            if (fabsf(qDen) < (4 * 1.1920928955078125e-07f) * (float) fit.hits * fabsf(fit.sumWpp) || !isfinite(q))
+                q = 0.0f;
+            const float a = 0.5f * q;
+            const float bx = (fit.sumWnx - q * fit.sumWpx) * invSumW;
+            const float by = (fit.sumWny - q * fit.sumWpy) * invSumW;
+            const float bz = (fit.sumWnz - q * fit.sumWpz) * invSumW;
+            const float c = (-a * fit.sumWpp - dot3(bx, by, bz, fit.sumWpx, fit.sumWpy, fit.sumWpz)) * invSumW;
+            const float b2 = dot3(bx, by, bz, bx, by, bz);
+            const float l = solveQuadratic(a * b2, b2, c);
+            const float ax = l * bx, ay = l * by, az = l * bz;
+            const float aa = dot3(ax, ay, az, ax, ay, az);
+            if (aa < 3.0f)
+            {
+                const float rhs = (fit.sumWpp - 2 * dot3(fit.sumWpx, fit.sumWpy, fit.sumWpz, ax, ay, az) + fit.sumW * aa);
+                if (qDen > boundaryFactor * rhs)
+                    f = -dot3(bx, by, bz, ax, ay, az) * (1.0f / sqrtf(b2));   /* half_rsqrt -> exact, DESIGN.md */
+            }
+        }
+        else
+        {
+            const float mx = fit.sumWpx / fit.sumW, my = fit.sumWpy / fit.sumW, mz = fit.sumWpz / fit.sumW;
+            const float inv = 1.0f / sqrtf(dot3(fit.sumWnx, fit.sumWny, fit.sumWnz, fit.sumWnx, fit.sumWny, fit.sumWnz));
+            const float nx = fit.sumWnx * inv, ny = fit.sumWny * inv, nz = fit.sumWnz * inv;
+            const float dist = -dot3(nx, ny, nz, mx, my, mz);
+            const float ax = nx * -dist, ay = ny * -dist, az = nz * -dist;
+            const float aa = dot3(ax, ay, az, ax, ay, az);
+            if (aa < 3.0f)
+            {
+                const float qDen = fit.sumWpp - dot3(mx, my, mz, fit.sumWpx, fit.sumWpy, fit.sumWpz);
+                const float rhs = (fit.sumWpp - 2 * dot3(fit.sumWpx, fit.sumWpy, fit.sumWpz, ax, ay, az) + fit.sumW * aa);
+                if (qDen > boundaryFactor * rhs)
+                    f = dist;
+            }
+        }
+    }
+    return f;
+}
+
+/* z-major Morton code of block-aligned coordinates, kernels/mls.cl:159-174 */
+__device__ __forceinline__ uint32_t spread3(uint32_t v)
+{
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+
+struct MlsArgs
+{
+    float *field;
+    uint64_t pitch;
+    const float4 *splats;        /* two float4 per splat */
+    const int32_t *commands;
+    const int32_t *start;
+    uint32_t startShift;
+    int32_t ox, oy, oz;
+    uint32_t zStride;
+    int32_t zBias;
+    uint32_t zFirst;
+    uint32_t blocksX, blocksY, blocksZ;
+    float boundaryFactor;
+    unsigned long long *stats;   /* [0] listed splats, [1] (corner, splat) distance tests, [2] hits */
+};
+
+/*
+ * Workgroup -> block mapping.  Workgroups are dealt round-robin to the 8 XCDs (each with its own
+ * L2), so consecutive ids land on different XCDs.  Remap so that each XCD walks one contiguous
+ * run of blocks in x-fastest order: neighbouring blocks share most of their splat lists, which
+ * then hit in that XCD's L2.  (Speed only; any mapping gives the same result.)
+ */
+__device__ __forceinline__ uint32_t xcdRemap(uint32_t id, uint32_t n)
+{
+    const uint32_t q = n / 8, r = n % 8;
+    const uint32_t xcd = id % 8, k = id / 8;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template<int SHAPE, bool CULL, bool STATS>
+__global__ __launch_bounds__(512) void processCornersKernel(MlsArgs A)
+{
+    __shared__ float4 sPosRad[STAGE];
+    __shared__ float4 sNormQ[STAGE];
+    __shared__ uint32_t sMask[STAGE];
+
+    const uint32_t nBlocks = A.blocksX * A.blocksY * A.blocksZ;
+    const uint32_t bid = xcdRemap(blockIdx.x, nBlocks);
+    const uint32_t gx = bid % A.blocksX, gy = (bid / A.blocksX) % A.blocksY, gz = bid / (A.blocksX * A.blocksY);
+    const int wx = (int) (gx * 8), wy = (int) (gy * 8), wz = (int) (gz * 8 + A.zFirst);
+    /* makeCode(wid) >> startShift (kernels/mls.cl:318) == makeCode(wid >> subsampling): Morton digits are independent */
+    const uint32_t sub = A.startShift / 3;
+    const uint32_t code = spread3((uint32_t) wx >> sub) | (spread3((uint32_t) wy >> sub) << 1) | (spread3((uint32_t) wz >> sub) << 2);
+    int32_t pos = A.start[code];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    /* wave = 4x4x4 sub-block (sx,sy,sz); lane = x + 4y + 16z inside it */
+    const int lx = (int) ((wave & 1) * 4 + (lane & 3));
+    const int ly = (int) (((wave >> 1) & 1) * 4 + ((lane >> 2) & 3));
+    const int lz = (int) ((wave >> 2) * 4 + (lane >> 4));
+
+    float f = __int_as_float(0x7FC00000);
+    if (pos >= 0)       /* uniform over the workgroup */
+    {
+        const float cx = (float) (wx + lx + A.ox), cy = (float) (wy + ly + A.oy), cz = (float) (wz + lz + A.oz);
+        /* corner-coordinate bounds of the two half-blocks per axis, for the cull masks */
+        const float bx0 = (float) (wx + A.ox), by0 = (float) (wy + A.oy), bz0 = (float) (wz + A.oz);
+        Fit fit;
+        fitInit(fit);
+        unsigned long long nListed = 0, nTests = 0;
+        int32_t end = A.commands[pos++];
+        while (pos < end)
+        {
+            /* stage up to STAGE listed splats (kernels/mls.cl:342-352 stages 256) */
+            const int32_t lpos = pos + (int32_t) tid;
+            const int32_t mine = lpos < end ? A.commands[lpos] : -1;
+            uint32_t mask = 0;
+            if (mine >= 0)
+            {
+                const float4 pr = A.splats[2 * (int64_t) mine];
+                const float4 nq = A.splats[2 * (int64_t) mine + 1];
+                sPosRad[tid] = pr;
+                sNormQ[tid] = nq;
+                if (CULL)
+                {
+                    /* distance from the splat centre to the corner range [b, b+3] of each half-block,
+                     * per axis; squared and summed with dot3's fma structure (monotone => conservative) */
+                    float d[3][2];
+                    const float p[3] = {pr.x, pr.y, pr.z};
+                    const float b[3] = {bx0, by0, bz0};
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+                        {
+                            const float lo = b[a] + (float) (4 * h), hi = b[a] + (float) (4 * h + 3);
+                            d[a][h] = fmaxf(fmaxf(lo - p[a], p[a] - hi), 0.0f);
+                        }
+#pragma unroll
+                    for (int s = 0; s < 8; s++)
+                    {
+                        const float dx = d[0][s & 1], dy = d[1][(s >> 1) & 1], dz = d[2][s >> 2];
+                        const float dd = dot3(dx, dy, dz, dx, dy, dz) * pr.w;
+                        mask |= (dd < RADIUS_CUTOFF ? 1u : 0u) << s;
+                    }
+                }
+                else
+                    mask = 0xFFu;
+            }
+            sMask[tid] = mask;
+            if (STATS)
+                nListed += __popcll(__ballot(mine >= 0));
+            const int32_t staged = min(end - pos, (int32_t) STAGE);
+
+            pos += STAGE;
+            if (pos >= end)
+            {
+                /* follow the jump (kernels/mls.cl:354-358): negative terminates */
+                pos = A.commands[end];
+                end = (pos >= 0) ? A.commands[pos++] : INT32_MIN;
+            }
+            __syncthreads();
+
+            for (int32_t g = 0; g < staged; g += 64)
+            {
+                const uint32_t m = sMask[g + lane];      /* entries beyond `staged` hold mask 0 */
+                uint64_t todo = __ballot((m >> wave) & 1u);
+                while (todo != 0)
+                {
+                    const int i = g + (int) __builtin_ctzll(todo);
+                    todo &= todo - 1;
+                    if (STATS)
+                        nTests += 64;
+                    const float4 pr = sPosRad[i];
+                    const float px = pr.x - cx, py = pr.y - cy, pz = pr.z - cz;
+                    const float pp = dot3(px, py, pz, px, py, pz);
+                    const float d = pp * pr.w;
+                    if (d < RADIUS_CUTOFF)
+                    {
+                        const float4 nq = sNormQ[i];
+                        float w = 1.0f - d;
+                        w *= w;
+                        w *= w;
+                        w *= nq.w;
+                        fitAdd(fit, w, px, py, pz, pp, nq.x, nq.y, nq.z);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        f = finishCorner<SHAPE>(fit, A.boundaryFactor);
+        if (STATS)
+        {
+            const unsigned long long hits = waveSum(fit.hits);
+            if (lane == 0)
+            {
+                atomicAdd(&A.stats[0], nListed);
+                atomicAdd(&A.stats[1], nTests);
+                atomicAdd(&A.stats[2], hits);
+            }
+        }
+    }
+
+    const int64_t row = (int64_t) (wy + ly) + (int64_t) (wz + lz) * A.zStride + A.zBias;
+    A.field[row * (int64_t) A.pitch + (wx + lx)] = f;
+}
+
+} // namespace
+
+/* ------------------------------------------------------------------ C-ABI */
+
+MLSGPU_API int mlsgpu_hip_mls_create(mlsgpu_ctx *ctx, int shape, mlsgpu_mls **out)
+{
+    REQUIRE(ctx != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(shape == MLSGPU_SHAPE_SPHERE || shape == MLSGPU_SHAPE_PLANE, MLSGPU_ERR_INVALID);
+    mlsgpu_mls *m = new mlsgpu_mls;
+    m->ctx = ctx;
+    m->shape = shape;
+    *out = m;
+    return mlsgpu_hip_mls_set_boundary_limit(m, 1.0f);     /* src/mls.cpp:72 */
+}
+
+MLSGPU_API void mlsgpu_hip_mls_destroy(mlsgpu_mls *m) { delete m; }
+
+MLSGPU_API int mlsgpu_hip_mls_set_buffers(mlsgpu_mls *m, const int32_t offset[3], const mlsgpu_splat *dSplats,
+                                          const int32_t *dCommands, const int32_t *dStart, uint32_t subsamplingShift)
+{
+    REQUIRE(m != nullptr && offset != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(dSplats != nullptr && dCommands != nullptr && dStart != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(subsamplingShift >= 3 && subsamplingShift <= 10, MLSGPU_ERR_LENGTH);   /* subsamplingMin, src/mls.cpp:54 */
+    m->dSplats = dSplats;
+    m->dCommands = dCommands;
+    m->dStart = dStart;
+    m->startShift = 3 * subsamplingShift;                   /* src/mls.cpp:86 */
+    for (int i = 0; i < 3; i++)
+        m->offset[i] = offset[i];
+    m->isSet = true;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_mls_set(mlsgpu_mls *m, const int32_t offset[3], const mlsgpu_tree *tree, uint32_t subsamplingShift)
+{
+    REQUIRE(m != nullptr && tree != nullptr, MLSGPU_ERR_INVALID);
+    return mlsgpu_hip_mls_set_buffers(m, offset, mlsgpu_hip_tree_splats(tree), mlsgpu_hip_tree_commands(tree),
+                                      mlsgpu_hip_tree_start(tree), subsamplingShift);
+}
+
+MLSGPU_API int mlsgpu_hip_mls_set_boundary_limit(mlsgpu_mls *m, float limit)
+{
+    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
+    /* src/mls.cpp:137-144 */
+    const float pi = 3.14159265358979323846f;
+    const float boundaryScale = (sqrtf(6.0f) * 512) / (693 * pi);
+    const float gamma = boundaryScale * limit;
+    m->boundaryFactor = 1.0f - gamma * gamma;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_mls_set_variant(mlsgpu_mls *m, int variant)
+{
+    REQUIRE(m != nullptr && (variant == 0 || variant == 1), MLSGPU_ERR_INVALID);
+    m->variant = variant;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_mls_set_stats(mlsgpu_mls *m, uint64_t *dCounters)
+{
+    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
+    m->dStats = reinterpret_cast<unsigned long long *>(dCounters);
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pitch, uint64_t fieldRows,
+                                      const mlsgpu_swathe *sw)
+{
+    REQUIRE(m != nullptr && dField != nullptr && sw != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(m->isSet, MLSGPU_ERR_INVALID);
+    /* src/mls.cpp:108-116 */
+    const uint32_t width = roundUp(sw->width, 8), height = roundUp(sw->height, 8);
+    REQUIRE(sw->width > 0 && sw->height > 0, MLSGPU_ERR_INVALID);
+    REQUIRE(sw->zStride >= height, MLSGPU_ERR_INVALID);
+    REQUIRE(sw->zFirst <= sw->zLast, MLSGPU_ERR_INVALID);
+    REQUIRE(sw->zFirst % 8 == 0, MLSGPU_ERR_INVALID);
+    REQUIRE(pitch >= width, MLSGPU_ERR_LENGTH);
+    const uint32_t blocksZ = divUp((uint64_t) sw->zLast - sw->zFirst + 1, 8);
+    /* the kernel writes whole 8x8x8 blocks (kernels/mls.cl:429-432): every row it touches must exist */
+    const int64_t firstRow = (int64_t) sw->zFirst * sw->zStride + sw->zBias;
+    const int64_t lastRow = (int64_t) (sw->zFirst + 8 * blocksZ - 1) * sw->zStride + sw->zBias + height - 1;
+    REQUIRE(firstRow >= 0 && (uint64_t) lastRow < fieldRows, MLSGPU_ERR_LENGTH);
+    const uint32_t sub = m->startShift / 3;
+    REQUIRE(((sw->zFirst + 8 * blocksZ - 1) >> sub) < 1024 && ((width - 1) >> sub) < 1024 && ((height - 1) >> sub) < 1024,
+            MLSGPU_ERR_LENGTH);
+
+    mlsgpu_ctx *ctx = m->ctx;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    MlsArgs A;
+    A.field = dField;
+    A.pitch = pitch;
+    A.splats = reinterpret_cast<const float4 *>(m->dSplats);
+    A.commands = m->dCommands;
+    A.start = m->dStart;
+    A.startShift = m->startShift;
+    A.ox = m->offset[0]; A.oy = m->offset[1]; A.oz = m->offset[2];
+    A.zStride = sw->zStride;
+    A.zBias = sw->zBias;
+    A.zFirst = sw->zFirst;
+    A.blocksX = width / 8;
+    A.blocksY = height / 8;
+    A.blocksZ = blocksZ;
+    A.boundaryFactor = m->boundaryFactor;
+    const dim3 grid(A.blocksX * A.blocksY * A.blocksZ), block(512);
+    const char *stat = "kernel.mls.processCorners.time";      /* src/mls.cpp:57 */
+    A.stats = m->dStats;
+#define MLS_LAUNCH(SHAPE, CULL, STATS) LAUNCH(ctx, stat, (processCornersKernel<SHAPE, CULL, STATS>), grid, block, A)
+    const bool sphere = m->shape == MLSGPU_SHAPE_SPHERE, cull = m->variant == 0;
+    if (m->dStats != nullptr)
+    {
+        /* instrumented build: only reachable through mlsgpu_hip_mls_set_stats, never in a timed run */
+        if (sphere) { if (cull) MLS_LAUNCH(MLSGPU_SHAPE_SPHERE, true, true); else MLS_LAUNCH(MLSGPU_SHAPE_SPHERE, false, true); }
+        else { if (cull) MLS_LAUNCH(MLSGPU_SHAPE_PLANE, true, true); else MLS_LAUNCH(MLSGPU_SHAPE_PLANE, false, true); }
+    }
+    else
+    {
+        if (sphere) { if (cull) MLS_LAUNCH(MLSGPU_SHAPE_SPHERE, true, false); else MLS_LAUNCH(MLSGPU_SHAPE_SPHERE, false, false); }
+        else { if (cull) MLS_LAUNCH(MLSGPU_SHAPE_PLANE, true, false); else MLS_LAUNCH(MLSGPU_SHAPE_PLANE, false, false); }
+    }
+#undef MLS_LAUNCH
+    return MLSGPU_OK;
+}
+
+static int mlsGeneratorEnqueue(void *user, void *stream, float *dField, uint64_t pitch, const mlsgpu_swathe *swathe)
+{
+    mlsgpu_mls *m = static_cast<mlsgpu_mls *>(user);
+    (void) stream;   /* the functor and Marching share the worker's context, hence its stream */
+    /* Marching guarantees the rows (src/marching.h:232-241); pass "unbounded" and let Marching's own check stand */
+    return mlsgpu_hip_mls_enqueue(m, dField, pitch, UINT64_MAX, swathe);
+}
+
+MLSGPU_API int mlsgpu_hip_mls_generator(mlsgpu_mls *m, mlsgpu_generator *gen)
+{
+    REQUIRE(m != nullptr && gen != nullptr, MLSGPU_ERR_INVALID);
+    gen->alignment[0] = gen->alignment[1] = gen->alignment[2] = 8;   /* MlsFunctor::wgs, src/mls.cpp:53 */
+    gen->enqueue = mlsGeneratorEnqueue;
+    gen->user = m;
+    return MLSGPU_OK;
+}
+
+/* ---- one-work-item test kernels of kernels/mls.cl:439-469 ---- */
+namespace
+{
+__global__ void testMlsKernel(int op, const float *in, uint32_t n, float *out)
+{
+    if (op == 0)
+        out[0] = solveQuadratic(in[0], in[1], in[2]);
+    else
+    {
+        /* testFitSphere: weights in the quality slot, positions in the local frame */
+        Fit fit;
+        fitInit(fit);
+        for (uint32_t i = 0; i < n; i++)
+        {
+            const float *s = in + 8 * i;
+            fitAdd(fit, s[7], s[0], s[1], s[2], dot3(s[0], s[1], s[2], s[0], s[1], s[2]), s[4], s[5], s[6]);
+        }
+        const float invSumW = 1.0f / fit.sumW;
+        const float mx = fit.sumWpx * invSumW, my = fit.sumWpy * invSumW, mz = fit.sumWpz * invSumW;
+        const float qNum = fit.sumWpn - dot3(mx, my, mz, fit.sumWnx, fit.sumWny, fit.sumWnz);
+        const float qDen = fit.sumWpp - dot3(mx, my, mz, fit.sumWpx, fit.sumWpy, fit.sumWpz);
+        float q = qNum / qDen;
+        if (fabsf(qDen) < (4 * 1.1920928955078125e-07f) * (float) fit.hits * fabsf(fit.sumWpp) || !isfinite(q))
+            q = 0.0f;
+        const float a = 0.5f * q;
+        const float bx = (fit.sumWnx - q * fit.sumWpx) * invSumW;
+        const float by = (fit.sumWny - q * fit.sumWpy) * invSumW;
+        const float bz = (fit.sumWnz - q * fit.sumWpz) * invSumW;
+        out[0] = bx; out[1] = by; out[2] = bz; out[3] = a;
+        out[4] = (-a * fit.sumWpp - dot3(bx, by, bz, fit.sumWpx, fit.sumWpy, fit.sumWpz)) * invSumW;
+    }
+}
+
+int runMlsTest(mlsgpu_ctx *ctx, int op, const float *in, size_t inFloats, uint32_t n, float *out, int outFloats)
+{
+    float *dIn = nullptr, *dOut = nullptr;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipMalloc(&dIn, inFloats * 4 + 4));
+    HIP_CHECK(hipMalloc(&dOut, 32));
+    HIP_CHECK(hipMemcpyAsync(dIn, in, inFloats * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(testMlsKernel, dim3(1), dim3(1), 0, ctx->stream, op, (const float *) dIn, n, dOut);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(out, dOut, outFloats * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    hipFree(dIn); hipFree(dOut);
+    return MLSGPU_OK;
+}
+} // namespace
+
+MLSGPU_API int mlsgpu_hip_test_solve_quadratic(mlsgpu_ctx *ctx, float a, float b, float c, float *out)
+{
+    REQUIRE(ctx != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    const float in[3] = {a, b, c};
+    return runMlsTest(ctx, 0, in, 3, 0, out, 1);
+}
+
+MLSGPU_API int mlsgpu_hip_test_fit_sphere(mlsgpu_ctx *ctx, const mlsgpu_splat *hSplats, uint32_t n, float out[5])
+{
+    REQUIRE(ctx != nullptr && hSplats != nullptr && out != nullptr && n > 0, MLSGPU_ERR_INVALID);
+    return runMlsTest(ctx, 1, reinterpret_cast<const float *>(hSplats), (size_t) n * 8, n, out, 5);
+}

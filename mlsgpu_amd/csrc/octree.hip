@@ -1,0 +1,473 @@
+/*
+ * Splat octree build on gfx950 -- the device half of SplatTreeCL
+ * (reference: src/splat_tree_cl.{h,cpp}, kernels/octree.cl).
+ *
+ * Output contract (identical to the reference, checked bit-for-bit against the oracle):
+ * `start` (one int per node, levels stored finest first) and `commands`
+ * ([end][ids...][jump] per non-empty node), see src/splat_tree.h:40-74.
+ *
+ * Differences in mechanism (not in results):
+ *  - the indicator (countCommands) and commandMap arrays are never materialised: the indicator
+ *    is recomputed from the sorted keys inside the scan, and writeSplatIds is the scan's consumer;
+ *  - the per-level writeStart launches (levels dependent launches in the reference) are one
+ *    launch: every node finds its nearest non-empty strict ancestor by itself;
+ *  - the sort handles 3*(maxShift-minShift)+1 key bits in ceil(bits/10) stable passes.
+ */
+#include "common.hpp"
+#include "primitives.hpp"
+
+using namespace mlsgpu;
+
+struct LevelOffsets
+{
+    uint32_t v[32];
+};
+
+struct mlsgpu_tree
+{
+    mlsgpu_ctx *ctx = nullptr;
+    uint64_t maxLevels = 0, maxSplats = 0;
+    uint64_t maxStart = 0, commandsSize = 0;
+    uint32_t numLevels = 0;
+    int32_t *dStart = nullptr, *dJumpPos = nullptr, *dCommands = nullptr;
+    uint32_t *dKeysA = nullptr, *dKeysB = nullptr, *dValsA = nullptr, *dValsB = nullptr;
+    uint32_t *dHist = nullptr, *dTileSums = nullptr;
+    mlsgpu_splat *dSplats = nullptr;   /* borrowed between build and clear_splats */
+};
+
+namespace
+{
+
+/* kernels/octree.cl:121-136 (z-major Morton); coordinates here are < 2^10 */
+__device__ __forceinline__ uint32_t spread3(uint32_t v)
+{
+    v &= 0x3FFu;
+    v = (v | (v << 16)) & 0x030000FFu;
+    v = (v | (v << 8)) & 0x0300F00Fu;
+    v = (v | (v << 4)) & 0x030C30C3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t makeCode(int x, int y, int z)
+{
+    return spread3((uint32_t) x) | (spread3((uint32_t) y) << 1) | (spread3((uint32_t) z) << 2);
+}
+
+/* general form for the test kernel (any non-negative ints), octree.cl:121-136 verbatim semantics */
+__device__ uint32_t makeCodeLoop(int x, int y, int z)
+{
+    uint32_t ans = 0, scale = 1;
+    y <<= 1;
+    z <<= 2;
+    while (x != 0 || y != 0 || z != 0)
+    {
+        uint32_t bits = (x & 1) | (y & 2) | (z & 4);
+        ans += bits * scale;
+        scale <<= 3;
+        x >>= 1; y >>= 1; z >>= 1;
+    }
+    return ans;
+}
+
+/* kernels/octree.cl:50-55 */
+__device__ __forceinline__ int levelShift(int lox, int loy, int loz, int hix, int hiy, int hiz)
+{
+    int big = max(max(hix - lox, hiy - loy), hiz - loz);
+    return big > 1 ? 32 - __clz(big - 1) : 0;
+}
+
+/* kernels/octree.cl:60-66: OpenCL dot() restated as a plain sum of products (no fma) */
+__device__ __forceinline__ float pointBoxDist2(float px, float py, float pz, float lx, float ly, float lz,
+                                                float hx, float hy, float hz)
+{
+    float dx = fmaxf(lx, fminf(hx, px)) - px;
+    float dy = fmaxf(ly, fminf(hy, py)) - py;
+    float dz = fmaxf(lz, fminf(hz, pz)) - pz;
+    return dx * dx + dy * dy + dz * dz;
+}
+
+/* convert_int_rtn: floor then saturating convert (v_cvt_i32_f32 saturates) */
+__device__ __forceinline__ int floorToInt(float v)
+{
+    float f = floorf(v);
+    if (!(f > -2147483648.0f)) return INT32_MIN;
+    if (!(f < 2147483648.0f)) return INT32_MAX;
+    return (int) f;
+}
+
+/* writeEntries, kernels/octree.cl:159-214.  One thread per splat; 8 (key, id) entries per splat written
+ * as two 16-byte stores per array.  Replaces splat.w by 1/r^2 (:193). */
+__global__ __launch_bounds__(256) void writeEntriesKernel(uint32_t *keys, uint32_t *values, mlsgpu_splat *splats,
+                                                          int bx, int by, int bz, LevelOffsets levelOffsets,
+                                                          int minShift, int maxShift, uint32_t firstSplat,
+                                                          uint32_t numSplats)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numSplats)
+        return;
+    const uint32_t gid = i + firstSplat;
+    float4 *sp = reinterpret_cast<float4 *>(splats + gid);
+    const float4 pr = sp[0];
+    /* prepare, octree.cl:79-90 */
+    const int lox = floorToInt(pr.x - pr.w), loy = floorToInt(pr.y - pr.w), loz = floorToInt(pr.z - pr.w);
+    const int hix = floorToInt(pr.x + pr.w), hiy = floorToInt(pr.y + pr.w), hiz = floorToInt(pr.z + pr.w);
+    int shift = levelShift(lox, loy, loz, hix, hiy, hiz);
+    shift = min(max(shift, minShift), maxShift);
+    const int ilx = max(lox - bx, 0) >> shift;
+    const int ily = max(loy - by, 0) >> shift;
+    const int ilz = max(loz - bz, 0) >> shift;
+
+    float radius2 = pr.w * pr.w;
+    reinterpret_cast<float *>(sp)[3] = 1.0f / radius2;
+    radius2 *= 1.00001f;
+    const uint32_t levelOffset = levelOffsets.v[shift];
+    const int bound = 1 << (maxShift - shift);
+    uint32_t k[8];
+#pragma unroll
+    for (int o = 0; o < 8; o++)
+    {
+        const int ax = ilx + (o & 1), ay = ily + ((o >> 1) & 1), az = ilz + (o >> 2);
+        /* goodEntry, octree.cl:100-110; int arithmetic wraps like OpenCL's */
+        const int blx = (int) ((uint32_t) ax << shift) + bx, bhx = (int) ((uint32_t) (ax + 1) << shift) + bx;
+        const int bly = (int) ((uint32_t) ay << shift) + by, bhy = (int) ((uint32_t) (ay + 1) << shift) + by;
+        const int blz = (int) ((uint32_t) az << shift) + bz, bhz = (int) ((uint32_t) (az + 1) << shift) + bz;
+        bool isect = pointBoxDist2(pr.x, pr.y, pr.z, (float) blx, (float) bly, (float) blz,
+                                   (float) bhx, (float) bhy, (float) bhz) < radius2;
+        isect = isect && ax < bound && ay < bound && az < bound;
+        /* inside the bounds the coordinates fit 10 bits (maxShift - shift <= 9 levels) */
+        k[o] = isect ? makeCode(ax, ay, az) + levelOffset : 0xFFFFFFFFu;
+    }
+    uint4 *kp = reinterpret_cast<uint4 *>(keys + (uint64_t) i * 8);
+    uint4 *vp = reinterpret_cast<uint4 *>(values + (uint64_t) i * 8);
+    kp[0] = make_uint4(k[0], k[1], k[2], k[3]);
+    kp[1] = make_uint4(k[4], k[5], k[6], k[7]);
+    vp[0] = make_uint4(gid, gid, gid, gid);
+    vp[1] = make_uint4(gid, gid, gid, gid);
+}
+
+/* countCommands (kernels/octree.cl:230-239) as the scan's producer.  The reference leaves the
+ * last indicator unwritten; an exclusive scan never reads it, so any value serves. */
+struct IndicatorIn
+{
+    const uint32_t *keys;
+    uint64_t n;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const
+    {
+        if (i + 1 >= n)
+            return 1u;
+        return keys[i] != keys[i + 1] ? 3u : 1u;
+    }
+};
+
+/* writeSplatIds (kernels/octree.cl:256-279) as the scan's consumer: cpos is the exclusive prefix. */
+struct SplatIdsOut
+{
+    int32_t *commands, *start, *jumpPos;
+    const uint32_t *keys, *ids;
+    uint64_t n;
+    __device__ __forceinline__ void operator()(uint64_t pos, uint32_t cpos, uint32_t) const
+    {
+        const uint32_t curKey = keys[pos];
+        if (curKey != 0xFFFFFFFFu)
+        {
+            commands[cpos] = (int32_t) ids[pos];
+            const uint32_t prevKey = pos > 0 ? keys[pos - 1] : 0xFFFFFFFFu;
+            const uint32_t nextKey = pos < n - 1 ? keys[pos + 1] : 0xFFFFFFFFu;
+            if (prevKey != curKey)
+                start[curKey] = (int32_t) (cpos - 1);
+            if (curKey != nextKey)
+                jumpPos[curKey] = (int32_t) (cpos + 1);
+        }
+    }
+};
+
+/*
+ * writeStartTop + writeStart for all levels in one launch (kernels/octree.cl:292-341, loop
+ * src/splat_tree_cl.cpp:320-331).  The reference walks levels coarse to fine and hands each node
+ * its parent's start.  Unrolled, that value is: the start of the nearest NON-EMPTY strict ancestor,
+ * or -1.  start[] of a non-empty node is written by writeSplatIds and never changes, so every node
+ * can fetch it independently.
+ */
+__global__ __launch_bounds__(256) void writeStartKernel(int32_t *start, int32_t *commands, const int32_t *jumpPos,
+                                                        LevelOffsets levelOffsets, int minShift, int maxShift,
+                                                        uint32_t numStart)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= numStart)
+        return;
+    int level = minShift;
+    while (level < maxShift && p >= levelOffsets.v[level + 1])
+        level++;
+    uint32_t code = p - levelOffsets.v[level];
+    int32_t prev = -1;
+    for (int l = level + 1; l <= maxShift; l++)
+    {
+        code >>= 3;
+        const uint32_t a = levelOffsets.v[l] + code;
+        if (jumpPos[a] >= 0)
+        {
+            prev = start[a];
+            break;
+        }
+    }
+    const int32_t jp = jumpPos[p];
+    if (jp >= 0)
+    {
+        commands[jp] = prev;
+        commands[start[p]] = jp;
+    }
+    else
+        start[p] = prev;
+}
+
+__global__ void testHelpersKernel(int op, const int32_t *iargs, const float *fargs, uint32_t *out)
+{
+    if (op == 0)
+        out[0] = makeCodeLoop(iargs[0], iargs[1], iargs[2]);
+    else if (op == 1)
+        out[0] = (uint32_t) levelShift(iargs[0], iargs[1], iargs[2], iargs[3], iargs[4], iargs[5]);
+    else if (op == 2)
+    {
+        float r = pointBoxDist2(fargs[0], fargs[1], fargs[2], fargs[3], fargs[4], fargs[5], fargs[6], fargs[7], fargs[8]);
+        out[0] = __float_as_uint(r);
+    }
+    else if (op == 3)
+        out[0] = makeCode(iargs[0], iargs[1], iargs[2]);   /* fast path must agree with the loop form */
+}
+
+int runTestHelper(mlsgpu_ctx *ctx, int op, const int32_t *iargs, int ni, const float *fargs, int nf, uint32_t *out)
+{
+    int32_t *dI = nullptr;
+    float *dF = nullptr;
+    uint32_t *dO = nullptr;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipMalloc(&dI, 64));
+    HIP_CHECK(hipMalloc(&dF, 64));
+    HIP_CHECK(hipMalloc(&dO, 16));
+    if (ni) HIP_CHECK(hipMemcpyAsync(dI, iargs, ni * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (nf) HIP_CHECK(hipMemcpyAsync(dF, fargs, nf * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(testHelpersKernel, dim3(1), dim3(1), 0, ctx->stream, op, (const int32_t *) dI, (const float *) dF, dO);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(out, dO, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    hipFree(dI); hipFree(dF); hipFree(dO);
+    return MLSGPU_OK;
+}
+
+} // namespace
+
+/* ------------------------------------------------------------------ C-ABI */
+
+static void treeSizes(uint64_t maxLevels, uint64_t maxSplats, uint64_t *maxStart, uint64_t *commandsSize)
+{
+    /* src/splat_tree_cl.cpp:112-123 */
+    *maxStart = (uint64_t(1) << (3 * maxLevels)) / 7;
+    const uint64_t maxRanges = *maxStart < 8 * maxSplats ? *maxStart : 8 * maxSplats;
+    *commandsSize = maxSplats * 8 + maxRanges * 2;
+}
+
+MLSGPU_API uint64_t mlsgpu_hip_tree_resource_usage(uint64_t maxLevels, uint64_t maxSplats)
+{
+    uint64_t maxStart, commandsSize;
+    treeSizes(maxLevels, maxSplats, &maxStart, &commandsSize);
+    const uint64_t entries = maxSplats * 8;
+    return maxStart * 4 * 2 + commandsSize * 4 + entries * 4 * 4
+        + sortHistElems(entries) * 4 + (uint64_t) scanTiles(sortHistElems(entries) > entries ? sortHistElems(entries) : entries) * 4;
+}
+
+MLSGPU_API int mlsgpu_hip_tree_create(mlsgpu_ctx *ctx, uint64_t maxLevels, uint64_t maxSplats, mlsgpu_tree **out)
+{
+    REQUIRE(ctx != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(1 <= maxSplats && maxSplats <= MLSGPU_TREE_MAX_SPLATS, MLSGPU_ERR_LENGTH);   /* src/splat_tree_cl.cpp:106 */
+    REQUIRE(1 <= maxLevels && maxLevels <= MLSGPU_TREE_MAX_LEVELS, MLSGPU_ERR_LENGTH);   /* :107 */
+    HIP_CHECK(hipSetDevice(ctx->device));
+    mlsgpu_tree *t = new mlsgpu_tree;
+    t->ctx = ctx;
+    t->maxLevels = maxLevels;
+    t->maxSplats = maxSplats;
+    treeSizes(maxLevels, maxSplats, &t->maxStart, &t->commandsSize);
+    const uint64_t entries = maxSplats * 8;
+    const uint64_t histElems = sortHistElems(entries);
+    const uint64_t tileSums = scanTiles(histElems > entries ? histElems : entries) + 1;
+    int rc = MLSGPU_OK;
+    auto alloc = [&](void **p, uint64_t bytes) {
+        if (rc == MLSGPU_OK && hipMalloc(p, bytes ? bytes : 4) != hipSuccess)
+            rc = setError(MLSGPU_ERR_NOMEM, "SplatTreeCL: cannot allocate %llu bytes", (unsigned long long) bytes);
+    };
+    alloc((void **) &t->dStart, t->maxStart * 4);
+    alloc((void **) &t->dJumpPos, t->maxStart * 4);
+    alloc((void **) &t->dCommands, t->commandsSize * 4);
+    alloc((void **) &t->dKeysA, entries * 4);
+    alloc((void **) &t->dKeysB, entries * 4);
+    alloc((void **) &t->dValsA, entries * 4);
+    alloc((void **) &t->dValsB, entries * 4);
+    alloc((void **) &t->dHist, histElems * 4);
+    alloc((void **) &t->dTileSums, tileSums * 4);
+    if (rc != MLSGPU_OK)
+    {
+        mlsgpu_hip_tree_destroy(t);
+        return rc;
+    }
+    *out = t;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API void mlsgpu_hip_tree_destroy(mlsgpu_tree *t)
+{
+    if (!t)
+        return;
+    hipSetDevice(t->ctx->device);
+    hipFree(t->dStart); hipFree(t->dJumpPos); hipFree(t->dCommands);
+    hipFree(t->dKeysA); hipFree(t->dKeysB); hipFree(t->dValsA); hipFree(t->dValsB);
+    hipFree(t->dHist); hipFree(t->dTileSums);
+    delete t;
+}
+
+MLSGPU_API int mlsgpu_hip_tree_build(mlsgpu_tree *t, mlsgpu_splat *dSplats, uint64_t firstSplat, uint64_t numSplats,
+                                     const uint32_t size[3], const int32_t offset[3], uint32_t subsamplingShift)
+{
+    REQUIRE(t != nullptr && dSplats != nullptr && size != nullptr && offset != nullptr, MLSGPU_ERR_INVALID);
+    /* src/splat_tree_cl.cpp:277-281 */
+    REQUIRE(numSplats <= t->maxSplats, MLSGPU_ERR_LENGTH);
+    REQUIRE(firstSplat < 0xFFFFFFFFull - numSplats, MLSGPU_ERR_LENGTH);
+    REQUIRE(t->maxLevels + subsamplingShift - 1 < 31, MLSGPU_ERR_LENGTH);
+    const uint32_t maxSize = 1u << (t->maxLevels + subsamplingShift - 1);
+    REQUIRE(size[0] <= maxSize && size[1] <= maxSize && size[2] <= maxSize, MLSGPU_ERR_LENGTH);
+    const int maxShift = (int) (t->maxLevels + subsamplingShift - 1);
+    const int minShift = (int) subsamplingShift < maxShift ? (int) subsamplingShift : maxShift;
+    mlsgpu_ctx *ctx = t->ctx;
+    HIP_CHECK(hipSetDevice(ctx->device));
+
+    LevelOffsets lo;
+    std::memset(&lo, 0, sizeof(lo));
+    uint64_t pos = 0;
+    for (int i = minShift; i <= maxShift; i++)
+    {
+        lo.v[i] = (uint32_t) pos;
+        pos += uint64_t(1) << (3 * (maxShift - i));
+    }
+    const uint32_t numStart = (uint32_t) pos;
+    REQUIRE(numStart <= t->maxStart, MLSGPU_ERR_LENGTH);
+    t->numLevels = (uint32_t) (maxShift - minShift + 1);
+    t->dSplats = dSplats;
+
+    /* fill(jumpPos, -1), kernels/octree.cl:346 */
+    {
+        int pend = -1;
+        if (ctx->timing) pend = ctx->beginTiming(ctx->statId("kernel.octree.fill.time"));
+        HIP_CHECK(hipMemsetAsync(t->dJumpPos, 0xFF, (size_t) numStart * 4, ctx->stream));
+        if (pend >= 0) ctx->endTiming(pend);
+    }
+    const uint64_t numEntries = numSplats * 8;
+    if (numSplats > 0)
+    {
+        LAUNCH(ctx, "kernel.octree.writeEntries.time", writeEntriesKernel, dim3(divUp(numSplats, 256)), dim3(256),
+               t->dKeysA, t->dValsA, dSplats, offset[0], offset[1], offset[2], lo, minShift, maxShift,
+               (uint32_t) firstSplat, (uint32_t) numSplats);
+        SortResult<uint32_t> sorted;
+        PROPAGATE(radixSort<uint32_t>(ctx, "kernel.octree.sort.time", t->dKeysA, t->dValsA, t->dKeysB, t->dValsB,
+                                      numEntries, (uint32_t) (3 * (maxShift - minShift) + 1), false,
+                                      t->dHist, t->dTileSums, &sorted));
+        /* countCommands + scan(seed 1) + writeSplatIds, src/splat_tree_cl.cpp:310-317 */
+        IndicatorIn in{sorted.keys, numEntries};
+        SplatIdsOut outF{t->dCommands, t->dStart, t->dJumpPos, sorted.keys, sorted.vals, numEntries};
+        PROPAGATE((exclusiveScan<uint32_t>(ctx, "kernel.octree.scan.time", in, outF, numEntries, 1u,
+                                           t->dTileSums, (uint32_t *) nullptr)));
+    }
+    LAUNCH(ctx, "kernel.octree.writeStart.time", writeStartKernel, dim3(divUp(numStart, 256)), dim3(256),
+           t->dStart, t->dCommands, (const int32_t *) t->dJumpPos, lo, minShift, maxShift, numStart);
+    return MLSGPU_OK;
+}
+
+MLSGPU_API void mlsgpu_hip_tree_clear_splats(mlsgpu_tree *t) { if (t) t->dSplats = nullptr; }
+MLSGPU_API const mlsgpu_splat *mlsgpu_hip_tree_splats(const mlsgpu_tree *t) { return t->dSplats; }
+MLSGPU_API const int32_t *mlsgpu_hip_tree_commands(const mlsgpu_tree *t) { return t->dCommands; }
+MLSGPU_API const int32_t *mlsgpu_hip_tree_start(const mlsgpu_tree *t) { return t->dStart; }
+MLSGPU_API uint64_t mlsgpu_hip_tree_commands_size(const mlsgpu_tree *t) { return t->commandsSize; }
+MLSGPU_API uint64_t mlsgpu_hip_tree_start_size(const mlsgpu_tree *t) { return t->maxStart; }
+MLSGPU_API uint32_t mlsgpu_hip_tree_num_levels(const mlsgpu_tree *t) { return t->numLevels; }
+
+MLSGPU_API int mlsgpu_hip_test_make_code(mlsgpu_ctx *ctx, int x, int y, int z, uint32_t *out)
+{
+    REQUIRE(ctx != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    int32_t a[3] = {x, y, z};
+    uint32_t loopForm = 0, fast = 0;
+    PROPAGATE(runTestHelper(ctx, 0, a, 3, nullptr, 0, &loopForm));
+    if (x >= 0 && y >= 0 && z >= 0 && x < 1024 && y < 1024 && z < 1024)
+    {
+        PROPAGATE(runTestHelper(ctx, 3, a, 3, nullptr, 0, &fast));
+        if (fast != loopForm)
+            return setError(MLSGPU_ERR_INVALID, "makeCode fast path disagrees with loop form");
+    }
+    *out = loopForm;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_test_level_shift(mlsgpu_ctx *ctx, const int32_t lo[3], const int32_t hi[3], int32_t *out)
+{
+    REQUIRE(ctx != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    int32_t a[6] = {lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]};
+    uint32_t r = 0;
+    PROPAGATE(runTestHelper(ctx, 1, a, 6, nullptr, 0, &r));
+    *out = (int32_t) r;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_test_point_box_dist2(mlsgpu_ctx *ctx, const float p[3], const float lo[3], const float hi[3],
+                                               float *out)
+{
+    REQUIRE(ctx != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    float a[9] = {p[0], p[1], p[2], lo[0], lo[1], lo[2], hi[0], hi[1], hi[2]};
+    uint32_t r = 0;
+    PROPAGATE(runTestHelper(ctx, 2, nullptr, 0, a, 9, &r));
+    std::memcpy(out, &r, 4);
+    return MLSGPU_OK;
+}
+
+/* ---- primitive tests ---- */
+MLSGPU_API int mlsgpu_hip_test_scan_u32(mlsgpu_ctx *ctx, uint32_t *dData, uint64_t n, uint32_t seed)
+{
+    REQUIRE(ctx != nullptr, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    uint32_t *dTiles = nullptr;
+    HIP_CHECK(hipMalloc(&dTiles, ((uint64_t) scanTiles(n) + 1) * 4));
+    int rc = exclusiveScan<uint32_t>(ctx, "test.scan", ArrayIn<uint32_t>{dData}, ArrayOut<uint32_t>{dData}, n, seed,
+                                     dTiles, (uint32_t *) nullptr);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(dTiles);
+    return rc;
+}
+
+template<typename K>
+static int testSort(mlsgpu_ctx *ctx, K *dKeys, uint32_t *dValues, uint64_t n, uint32_t bits)
+{
+    HIP_CHECK(hipSetDevice(ctx->device));
+    K *kb = nullptr;
+    uint32_t *vb = nullptr, *hist = nullptr, *tiles = nullptr;
+    HIP_CHECK(hipMalloc(&kb, (n + 1) * sizeof(K)));
+    HIP_CHECK(hipMalloc(&vb, (n + 1) * 4));
+    HIP_CHECK(hipMalloc(&hist, (sortHistElems(n) + 1) * 4));
+    HIP_CHECK(hipMalloc(&tiles, ((uint64_t) scanTiles(sortHistElems(n)) + 1) * 4));
+    SortResult<K> res;
+    int rc = radixSort<K>(ctx, "test.sort", dKeys, dValues, kb, vb, n, bits, false, hist, tiles, &res);
+    if (rc == MLSGPU_OK && res.keys != dKeys && n > 0)
+    {
+        hipMemcpyAsync(dKeys, res.keys, n * sizeof(K), hipMemcpyDeviceToDevice, ctx->stream);
+        hipMemcpyAsync(dValues, res.vals, n * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    }
+    hipStreamSynchronize(ctx->stream);
+    hipFree(kb); hipFree(vb); hipFree(hist); hipFree(tiles);
+    return rc;
+}
+
+MLSGPU_API int mlsgpu_hip_test_sort_u32(mlsgpu_ctx *ctx, uint32_t *dKeys, uint32_t *dValues, uint64_t n, uint32_t bits)
+{
+    REQUIRE(ctx != nullptr, MLSGPU_ERR_INVALID);
+    return testSort<uint32_t>(ctx, dKeys, dValues, n, bits);
+}
+
+MLSGPU_API int mlsgpu_hip_test_sort_u64(mlsgpu_ctx *ctx, uint64_t *dKeys, uint32_t *dValues, uint64_t n, uint32_t bits)
+{
+    REQUIRE(ctx != nullptr, MLSGPU_ERR_INVALID);
+    return testSort<uint64_t>(ctx, dKeys, dValues, n, bits);
+}

@@ -1,0 +1,366 @@
+/*
+ * Device-wide primitives of the HIP path, replacing third-party clogs 1.1 in the reference:
+ *  - exclusive prefix sum with a seed (clogs::Scan; call sites src/splat_tree_cl.cpp:313,
+ *    src/marching.cpp:583,721), as reduce -> scan of tile sums -> apply, with the element
+ *    producer and consumer fused in as functors so indicator / map arrays never hit HBM;
+ *  - stable LSD radix sort of (key, uint32 value) pairs on the low `bits` of the key
+ *    (clogs::Radixsort; src/splat_tree_cl.cpp:308, src/marching.cpp:572), ranking with
+ *    wave64 ballots so each wave's 64 keys are split stably without an LDS sort.
+ * Everything is integer and bit-exact by construction.
+ *
+ * Element order inside a tile: wave w owns PRIM_WAVE_SPAN contiguous elements and walks them
+ * in PRIM_ITEMS rounds of 64 contiguous elements (lane = element), so every global access is a
+ * fully coalesced 256-byte (u32) or 512-byte (u64) wave access and memory order == scan order.
+ */
+#ifndef MLSGPU_AMD_PRIMITIVES_HPP
+#define MLSGPU_AMD_PRIMITIVES_HPP
+
+#include "common.hpp"
+
+namespace mlsgpu
+{
+
+enum
+{
+    PRIM_BLOCK = 256,                       /* threads per block (4 waves) */
+    PRIM_WAVES = PRIM_BLOCK / 64,
+    PRIM_ITEMS = 16,                        /* rounds of 64 contiguous elements per wave */
+    PRIM_TILE = PRIM_BLOCK * PRIM_ITEMS,    /* elements per block */
+    PRIM_WAVE_SPAN = 64 * PRIM_ITEMS,       /* contiguous elements per wave */
+    SORT_MAX_DIGIT_BITS = 10,
+    SORT_MAX_BINS = 1 << SORT_MAX_DIGIT_BITS
+};
+
+/* (occupied cells, vertices, indices) triple scanned by Marching */
+struct U3
+{
+    uint32_t a, b, c;
+};
+
+#ifdef __HIPCC__
+
+__host__ __device__ __forceinline__ U3 operator+(const U3 &x, const U3 &y) { return U3{x.a + y.a, x.b + y.b, x.c + y.c}; }
+__host__ __device__ __forceinline__ uint32_t zeroOf(uint32_t) { return 0u; }
+__host__ __device__ __forceinline__ U3 zeroOf(U3) { return U3{0u, 0u, 0u}; }
+
+__device__ __forceinline__ uint32_t waveInclusiveScanT(uint32_t v) { return waveInclusiveScan(v); }
+__device__ __forceinline__ U3 waveInclusiveScanT(U3 v)
+{
+    return U3{waveInclusiveScan(v.a), waveInclusiveScan(v.b), waveInclusiveScan(v.c)};
+}
+/* value of lane-1; lane 0 gets zero */
+__device__ __forceinline__ uint32_t waveShiftUpT(uint32_t v)
+{
+    uint32_t t = __shfl_up(v, 1, 64);
+    return laneId() == 0 ? 0u : t;
+}
+__device__ __forceinline__ U3 waveShiftUpT(U3 v) { return U3{waveShiftUpT(v.a), waveShiftUpT(v.b), waveShiftUpT(v.c)}; }
+__device__ __forceinline__ uint32_t readLaneT(uint32_t v, int lane) { return readLane(v, lane); }
+__device__ __forceinline__ U3 readLaneT(U3 v, int lane)
+{
+    return U3{readLane(v.a, lane), readLane(v.b, lane), readLane(v.c, lane)};
+}
+
+/* ------------------------------------------------------------------ scan */
+
+/* tileSums[b] = sum of in(i) over tile b */
+template<typename T, typename In>
+__global__ __launch_bounds__(PRIM_BLOCK) void scanReduceKernel(In in, T *tileSums, uint64_t n)
+{
+    __shared__ T waveTotals[PRIM_WAVES];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t) blockIdx.x * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
+    T sum = zeroOf(T());
+#pragma unroll 4
+    for (int j = 0; j < PRIM_ITEMS; j++)
+    {
+        uint64_t i = base + (uint64_t) j * 64;
+        if (i < n)
+            sum = sum + in(i);
+    }
+    T incl = waveInclusiveScanT(sum);
+    if (lane == 63)
+        waveTotals[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        T t = waveTotals[0];
+        for (int w = 1; w < PRIM_WAVES; w++)
+            t = t + waveTotals[w];
+        tileSums[blockIdx.x] = t;
+    }
+}
+
+/* Single block: exclusive scan of the tile sums in place, starting at `seed`; grand total (incl. seed) to *total. */
+template<typename T>
+__global__ __launch_bounds__(PRIM_BLOCK) void scanTileSumsKernel(T *tileSums, uint32_t numTiles, T seed, T *total)
+{
+    __shared__ T waveTotals[PRIM_WAVES];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    T carry = seed;
+    for (uint32_t base = 0; base < numTiles; base += PRIM_BLOCK)
+    {
+        const uint32_t i = base + threadIdx.x;
+        T v = i < numTiles ? tileSums[i] : zeroOf(T());
+        T incl = waveInclusiveScanT(v);
+        if (lane == 63)
+            waveTotals[wave] = incl;
+        __syncthreads();
+        T before = carry;
+        T all = carry;
+        for (uint32_t w = 0; w < PRIM_WAVES; w++)
+        {
+            if (w < wave)
+                before = before + waveTotals[w];
+            all = all + waveTotals[w];
+        }
+        T excl = before + waveShiftUpT(incl);
+        if (i < numTiles)
+            tileSums[i] = excl;
+        carry = all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total != nullptr)
+        *total = carry;
+}
+
+/* out(i, exclusivePrefix(i), in(i)) for every i < n; tileSums already scanned */
+template<typename T, typename In, typename Out>
+__global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(In in, Out out, const T *tileSums, uint64_t n)
+{
+    __shared__ T waveTotals[PRIM_WAVES];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t) blockIdx.x * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
+    T vals[PRIM_ITEMS];
+    T excl[PRIM_ITEMS];
+    T running = zeroOf(T());        /* wave-uniform: sum of the previous rounds of this wave */
+#pragma unroll
+    for (int j = 0; j < PRIM_ITEMS; j++)
+    {
+        uint64_t i = base + (uint64_t) j * 64;
+        vals[j] = i < n ? in(i) : zeroOf(T());
+        T incl = waveInclusiveScanT(vals[j]);
+        excl[j] = running + waveShiftUpT(incl);
+        running = running + readLaneT(incl, 63);
+    }
+    if (lane == 0)
+        waveTotals[wave] = running;
+    __syncthreads();
+    T before = tileSums[blockIdx.x];
+    for (uint32_t w = 0; w < wave; w++)
+        before = before + waveTotals[w];
+#pragma unroll
+    for (int j = 0; j < PRIM_ITEMS; j++)
+    {
+        uint64_t i = base + (uint64_t) j * 64;
+        if (i < n)
+            out(i, before + excl[j], vals[j]);
+    }
+}
+
+#endif /* __HIPCC__ */
+
+/* Host driver.  Workspace: tileSums must hold scanTiles(n) elements of T. */
+static inline uint32_t scanTiles(uint64_t n) { return divUp(n, PRIM_TILE); }
+
+#ifdef __HIPCC__
+/* Phase 1: tile sums of in() scanned from `seed`; grand total (incl. seed) to *dTotal (may be null). */
+template<typename T, typename In>
+static int scanPhase1(mlsgpu_ctx *ctx, const char *statName, In in, uint64_t n, T seed, T *dTileSums, T *dTotal)
+{
+    const uint32_t tiles = scanTiles(n);
+    if (tiles > 0)
+        LAUNCH(ctx, statName, (scanReduceKernel<T, In>), dim3(tiles), dim3(PRIM_BLOCK), in, dTileSums, n);
+    LAUNCH(ctx, statName, (scanTileSumsKernel<T>), dim3(1), dim3(PRIM_BLOCK), dTileSums, tiles, seed, dTotal);
+    return MLSGPU_OK;
+}
+
+/* Phase 2: out(i, exclusivePrefix(i), in(i)) for all i, using the tile sums of phase 1. */
+template<typename T, typename In, typename Out>
+static int scanPhase2(mlsgpu_ctx *ctx, const char *statName, In in, Out out, uint64_t n, const T *dTileSums)
+{
+    const uint32_t tiles = scanTiles(n);
+    if (tiles > 0)
+        LAUNCH(ctx, statName, (scanApplyKernel<T, In, Out>), dim3(tiles), dim3(PRIM_BLOCK), in, out, dTileSums, n);
+    return MLSGPU_OK;
+}
+
+template<typename T, typename In, typename Out>
+static int exclusiveScan(mlsgpu_ctx *ctx, const char *statName, In in, Out out, uint64_t n, T seed,
+                         T *dTileSums, T *dTotal)
+{
+    PROPAGATE((scanPhase1<T, In>(ctx, statName, in, n, seed, dTileSums, dTotal)));
+    return scanPhase2<T, In, Out>(ctx, statName, in, out, n, (const T *) dTileSums);
+}
+
+/* plain array in / array out functors */
+template<typename T>
+struct ArrayIn
+{
+    const T *p;
+    __device__ __forceinline__ T operator()(uint64_t i) const { return p[i]; }
+};
+template<typename T>
+struct ArrayOut
+{
+    T *p;
+    __device__ __forceinline__ void operator()(uint64_t i, T excl, T) const { p[i] = excl; }
+};
+
+/* ------------------------------------------------------------------ radix sort */
+
+template<typename K>
+__global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(const K *keys, uint32_t *hist, uint64_t n,
+                                                             uint32_t shift, uint32_t digitBits, uint32_t numTiles)
+{
+    __shared__ uint32_t bins[SORT_MAX_BINS];
+    const uint32_t numBins = 1u << digitBits;
+    const K mask = (K) (numBins - 1);
+    for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
+        bins[d] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t) blockIdx.x * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
+#pragma unroll 4
+    for (int j = 0; j < PRIM_ITEMS; j++)
+    {
+        uint64_t i = base + (uint64_t) j * 64;
+        if (i < n)
+            atomicAdd(&bins[(uint32_t) ((keys[i] >> shift) & mask)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
+        hist[(uint64_t) d * numTiles + blockIdx.x] = bins[d];
+}
+
+/* hist has been exclusively scanned over the (digit-major, tile-minor) sequence. */
+template<typename K, bool IOTA>
+__global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn, const uint32_t *valsIn,
+                                                                K *keysOut, uint32_t *valsOut,
+                                                                const uint32_t *hist, uint64_t n,
+                                                                uint32_t shift, uint32_t digitBits, uint32_t numTiles)
+{
+    __shared__ uint32_t waveBins[PRIM_WAVES][SORT_MAX_BINS];
+    const uint32_t numBins = 1u << digitBits;
+    const K mask = (K) (numBins - 1);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
+    {
+#pragma unroll
+        for (int w = 0; w < PRIM_WAVES; w++)
+            waveBins[w][d] = 0;
+    }
+    __syncthreads();
+    const uint64_t base = (uint64_t) blockIdx.x * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
+    K keys[PRIM_ITEMS];
+#pragma unroll
+    for (int j = 0; j < PRIM_ITEMS; j++)
+    {
+        uint64_t i = base + (uint64_t) j * 64;
+        keys[j] = i < n ? keysIn[i] : (K) 0;
+        if (i < n)
+            atomicAdd(&waveBins[wave][(uint32_t) ((keys[j] >> shift) & mask)], 1u);
+    }
+    __syncthreads();
+    /* per digit: global start of this tile, then waves in order */
+    for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
+    {
+        uint32_t run = hist[(uint64_t) d * numTiles + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < PRIM_WAVES; w++)
+        {
+            uint32_t c = waveBins[w][d];
+            waveBins[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    /* stable split of each round: rank among the lanes of the wave holding the same digit */
+#pragma unroll
+    for (int j = 0; j < PRIM_ITEMS; j++)
+    {
+        const uint64_t i = base + (uint64_t) j * 64;
+        const bool valid = i < n;
+        const uint32_t digit = (uint32_t) ((keys[j] >> shift) & mask);
+        uint64_t peers = __ballot(valid);
+        for (uint32_t b = 0; b < digitBits; b++)
+        {
+            const bool bit = (digit >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        if (valid)
+        {
+            const uint32_t rank = popcBelow(peers);
+            const uint32_t dst = waveBins[wave][digit] + rank;
+            keysOut[dst] = keys[j];
+            valsOut[dst] = IOTA ? (uint32_t) i : valsIn[i];
+            if (rank == 0)
+                waveBins[wave][digit] = dst + (uint32_t) __popcll(peers);
+        }
+        /* LDS operations of one wave complete in program order, so the next round sees the update */
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+/* Where the sorted data ends up. */
+template<typename K>
+struct SortResult
+{
+    K *keys;
+    uint32_t *vals;
+};
+
+static inline uint32_t sortPasses(uint32_t bits) { return (bits + SORT_MAX_DIGIT_BITS - 1) / SORT_MAX_DIGIT_BITS; }
+/* elements of uint32 needed for the histogram of a sort of n keys */
+static inline uint64_t sortHistElems(uint64_t n) { return (uint64_t) SORT_MAX_BINS * scanTiles(n); }
+
+/*
+ * Sorts (keysA, valsA)[0..n) stably by key bits [0, bits).  keysB/valsB are same-sized temporaries
+ * (the reference aliases its sort temporaries onto other buffers the same way,
+ * src/splat_tree_cl.cpp:129, src/marching.cpp:405).  iota: values are 0..n-1 and valsA is not read.
+ * dHist: sortHistElems(n) uint32; dTileSums: scanTiles(sortHistElems(n)) uint32.
+ */
+template<typename K>
+static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *valsA, K *keysB, uint32_t *valsB,
+                     uint64_t n, uint32_t bits, bool iota, uint32_t *dHist, uint32_t *dTileSums,
+                     SortResult<K> *result)
+{
+    result->keys = keysA;
+    result->vals = valsA;
+    if (n == 0)
+        return MLSGPU_OK;
+    const uint32_t tiles = scanTiles(n);
+    if (bits == 0)
+        bits = 1;    /* still run one pass so that iota values are materialised */
+    const uint32_t passes = sortPasses(bits);
+    const uint32_t perPass = (bits + passes - 1) / passes;
+    uint32_t shift = 0;
+    K *kin = keysA, *kout = keysB;
+    uint32_t *vin = valsA, *vout = valsB;
+    for (uint32_t p = 0; p < passes; p++)
+    {
+        const uint32_t digitBits = (bits - shift) < perPass ? (bits - shift) : perPass;
+        const uint64_t histN = ((uint64_t) 1 << digitBits) * tiles;
+        LAUNCH(ctx, statName, (sortHistKernel<K>), dim3(tiles), dim3(PRIM_BLOCK),
+               (const K *) kin, dHist, n, shift, digitBits, tiles);
+        PROPAGATE((exclusiveScan<uint32_t>(ctx, statName, ArrayIn<uint32_t>{dHist}, ArrayOut<uint32_t>{dHist},
+                                           histN, 0u, dTileSums, (uint32_t *) nullptr)));
+        if (iota && p == 0)
+            LAUNCH(ctx, statName, (sortScatterKernel<K, true>), dim3(tiles), dim3(PRIM_BLOCK),
+                   (const K *) kin, (const uint32_t *) vin, kout, vout, (const uint32_t *) dHist, n, shift, digitBits, tiles);
+        else
+            LAUNCH(ctx, statName, (sortScatterKernel<K, false>), dim3(tiles), dim3(PRIM_BLOCK),
+                   (const K *) kin, (const uint32_t *) vin, kout, vout, (const uint32_t *) dHist, n, shift, digitBits, tiles);
+        shift += digitBits;
+        K *tk = kin; kin = kout; kout = tk;
+        uint32_t *tv = vin; vin = vout; vout = tv;
+    }
+    result->keys = kin;
+    result->vals = vin;
+    return MLSGPU_OK;
+}
+#endif /* __HIPCC__ */
+
+} // namespace mlsgpu
+#endif

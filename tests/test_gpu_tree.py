@@ -1,0 +1,103 @@
+"""SplatTreeCL on the GPU: the reference's own assertions (test/test_splat_tree*.cpp) and bit parity with the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from gpu_common import ctx  # noqa: F401
+from refdata import make_splats
+from test_oracle_tree import BUILD_SPLATS, check_build, check_random, random_splats
+
+pytestmark = pytest.mark.gpu
+
+
+def test_make_code(ctx):
+    import mlsgpu_amd as m
+    out = C.c_uint32()
+    for xyz, exp in [((0, 0, 0), 0), ((1, 1, 1), 7), ((2, 5, 3), 174), ((7, 7, 7), 511), ((123, 456, 789), 642569997)]:
+        m.binding.check(m.lib().mlsgpu_hip_test_make_code(ctx.h, *xyz, C.byref(out)))
+        assert out.value == exp
+
+
+def test_level_shift(ctx):
+    import mlsgpu_amd as m
+    cases = [(0, (0, 0, 0), (0, 0, 0)), (0, (1, 1, 1), (0, 0, 0)), (0, (0, 1, 2), (1, 2, 3)),
+             (1, (0, 1, 2), (2, 2, 3)), (1, (0, 1, 2), (1, 3, 3)), (1, (0, 1, 2), (1, 2, 4)),
+             (2, (31, 0, 0), (35, 0, 0)), (3, (31, 0, 0), (36, 0, 0)), (3, (27, 0, 0), (32, 0, 0)),
+             (5, (48, 0, 0), (79, 0, 0))]
+    out = C.c_int32()
+    for exp, lo, hi in cases:
+        m.binding.check(m.lib().mlsgpu_hip_test_level_shift(ctx.h, ob._p(np.array(lo, np.int32)),
+                                                             ob._p(np.array(hi, np.int32)), C.byref(out)))
+        assert out.value == exp
+
+
+def test_point_box_dist2(ctx):
+    import mlsgpu_amd as m
+    cases = [(0.0, (0.5, 0.5, 0.5), (0, 0, 0), (1, 1, 1)),
+             (4.0, (0.25, 0.5, 3.0), (-1.5, 0.0, 0.5), (1.5, 0.75, 1.0)),
+             (14.0, (9.0, 11.0, -10.0), (-1.0, 0.0, -7.0), (8.0, 9.0, 8.0))]
+    out = C.c_float()
+    for exp, p, lo, hi in cases:
+        arrs = [np.array(v, np.float32) for v in (p, lo, hi)]
+        m.binding.check(m.lib().mlsgpu_hip_test_point_box_dist2(ctx.h, *[ob._p(a) for a in arrs], C.byref(out)))
+        assert abs(out.value - exp) < 1e-4
+
+
+def gpu_build(ctx, splats, first, num, size, offset, subsampling, levels, max_splats=None):
+    import mlsgpu_amd as m
+    tree = m.SplatTree(ctx, levels, max_splats or max(len(splats), 1))
+    buf = m.DeviceBuffer(ctx, array=splats)
+    tree.enqueue_build(buf, first, num, size, offset, subsampling)
+    ctx.synchronize()
+    return tree.commands(), tree.start(), tree.num_levels, buf.download(m.SPLAT_DTYPE, len(splats))
+
+
+def compare_with_oracle(commands, start, mutated, splats, first, num, size, offset, subsampling, levels):
+    s2 = splats.copy()
+    t = ob.Tree(s2, first, num, size, offset, subsampling, levels)
+    np.testing.assert_array_equal(start[:t.num_start], t.start[:t.num_start])
+    np.testing.assert_array_equal(commands[:t.num_commands], t.commands[:t.num_commands])
+    np.testing.assert_array_equal(mutated.view(np.uint32), s2.view(np.uint32))
+
+
+def test_build(ctx):
+    """TestSplatTree::testBuild on the device result."""
+    splats = make_splats(BUILD_SPLATS)
+    commands, start, num_levels, mutated = gpu_build(ctx, splats, 0, len(splats), (16, 16, 12), (3, 0, 1), 0, 9,
+                                                     max_splats=1001)
+    check_build(splats, commands, start, num_levels)
+    compare_with_oracle(commands, start, mutated, splats, 0, len(splats), (16, 16, 12), (3, 0, 1), 0, 9)
+
+
+def test_random(ctx):
+    """TestSplatTree::testRandom on the device result."""
+    splats, cells = random_splats()
+    commands, start, _, mutated = gpu_build(ctx, splats, 0, len(splats), cells, (1, 2, -1), 2, 8, max_splats=1000)
+    check_random(commands, start, len(splats), cells, 2)
+    compare_with_oracle(commands, start, mutated, splats, 0, len(splats), cells, (1, 2, -1), 2, 8)
+
+
+@pytest.mark.parametrize("n,first", [(0, 0), (1, 0), (5000, 0), (200_000, 1234)])
+def test_parity_default_geometry(ctx, n, first):
+    """levels 6 / subsampling 3 (the reference defaults) on a 256-corner bucket, ragged sizes, firstSplat > 0."""
+    from mlsgpu_amd import synth
+    cloud = synth.uniform_cloud(n + first, 255.0, 0.5, 9.0, seed=77)   # radii span several octree levels
+    cloud["position"] += np.float32(40.0)                              # bucket offset below
+    commands, start, _, mutated = gpu_build(ctx, cloud, first, n, (256, 256, 256), (40, 40, 40), 3, 6)
+    compare_with_oracle(commands, start, mutated, cloud, first, n, (256, 256, 256), (40, 40, 40), 3, 6)
+
+
+def test_argument_checks(ctx):
+    import mlsgpu_amd as m
+    with pytest.raises(m.LengthError):
+        m.SplatTree(ctx, 11, 100)                   # MAX_LEVELS
+    with pytest.raises(m.LengthError):
+        m.SplatTree(ctx, 6, 0)
+    tree = m.SplatTree(ctx, 6, 100)
+    buf = m.DeviceBuffer(ctx, array=make_splats(BUILD_SPLATS))
+    with pytest.raises(m.LengthError):
+        tree.enqueue_build(buf, 0, 101, (8, 8, 8), (0, 0, 0), 3)        # numSplats > maxSplats
+    with pytest.raises(m.LengthError):
+        tree.enqueue_build(buf, 0, 8, (257, 8, 8), (0, 0, 0), 3)        # size > 2^(levels+sub-1)
