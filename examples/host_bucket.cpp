@@ -1,0 +1,108 @@
+/*
+ * Minimal C++ host for the HIP path, written against the reference-named classes of
+ * mlsgpu_amd/host/mlsgpu_hip.hpp: feeds buckets to a DeviceWorkerGroup the way CopyGroup does
+ * (src/workers.cpp:315-418) and collects the meshes the way OutputGeneratorBuilder does
+ * (src/workers.h:488-509, enqueueReadMesh into a HostKeyMesh blob).
+ *
+ * usage: host_bucket <splats.bin> <buckets.txt> <out.bin> [numWorkers]
+ *   splats.bin : raw mlsgpu_splat records (all buckets concatenated)
+ *   buckets.txt: one bucket per line: first count lowX lowY lowZ nvX nvY nvZ
+ *   out.bin    : per ship-out: u64 chunk, u64 numVertices, u64 numTriangles, u64 numInternal, then the
+ *                HostKeyMesh blob ([external keys][vertices][triangles]); written in completion order
+ */
+#include <cstdio>
+#include <fstream>
+#include <iostream>
+#include <mutex>
+#include <sstream>
+#include <vector>
+
+#include "../mlsgpu_amd/host/mlsgpu_hip.hpp"
+
+using namespace mlsgpu::hip;
+
+int main(int argc, char **argv)
+{
+    if (argc < 4)
+    {
+        std::cerr << "usage: host_bucket splats.bin buckets.txt out.bin [numWorkers]\n";
+        return 2;
+    }
+    const int numWorkers = argc > 4 ? atoi(argv[4]) : 2;
+    std::vector<Splat> splats;
+    {
+        std::ifstream in(argv[1], std::ios::binary | std::ios::ate);
+        splats.resize((std::size_t) in.tellg() / sizeof(Splat));
+        in.seekg(0);
+        in.read(reinterpret_cast<char *>(splats.data()), splats.size() * sizeof(Splat));
+    }
+    std::vector<DeviceWorkerGroup::SubItem> buckets;
+    std::size_t maxSplats = 1;
+    {
+        std::ifstream in(argv[2]);
+        std::string line;
+        while (std::getline(in, line))
+        {
+            std::istringstream ss(line);
+            DeviceWorkerGroup::SubItem s;
+            if (!(ss >> s.firstSplat >> s.numSplats >> s.grid.low[0] >> s.grid.low[1] >> s.grid.low[2]
+                  >> s.grid.numVertices[0] >> s.grid.numVertices[1] >> s.grid.numVertices[2]))
+                continue;
+            s.chunkId = buckets.size();
+            s.progressSplats = s.numSplats;
+            maxSplats = std::max(maxSplats, s.numSplats);
+            buckets.push_back(s);
+        }
+    }
+
+    std::mutex outMutex;
+    std::FILE *out = std::fopen(argv[3], "wb");
+    std::uint64_t totalV = 0, totalT = 0;
+    try
+    {
+        /* OutputGenerator: one functor per chunk; it reads the mesh back on the worker's stream */
+        DeviceWorkerGroup::OutputGenerator outputGenerator = [&](std::uint64_t chunk) -> Marching::OutputFunctor
+        {
+            return [&, chunk](void *stream, const DeviceKeyMesh &mesh)
+            {
+                (void) stream;
+                std::vector<std::uint64_t> blob(mesh.getHostBytes() / 8 + 1);
+                if (mesh.numVertices > 0)
+                {
+                    /* a synchronous read on a context that shares the worker's stream */
+                    Context same(0, stream);
+                    HostKeyMesh hMesh(blob.data(), mesh);
+                    enqueueReadMesh(same, mesh, hMesh);
+                    same.finish();
+                }
+                std::lock_guard<std::mutex> l(outMutex);
+                const std::uint64_t hdr[4] = {chunk, mesh.numVertices, mesh.numTriangles, mesh.numInternalVertices};
+                std::fwrite(hdr, 8, 4, out);
+                std::fwrite(blob.data(), 1, mesh.getHostBytes(), out);
+                totalV += mesh.numVertices;
+                totalT += mesh.numTriangles;
+            };
+        };
+        DeviceWorkerGroup group(numWorkers, 1, outputGenerator, 0, maxSplats, 63, 0, 6, 3, 1.0f, MLS_SHAPE_SPHERE);
+        const float origin[3] = {0.0f, 0.0f, 0.0f};
+        group.start(1.0f, origin);
+        for (std::size_t i = 0; i < buckets.size(); i++)
+        {
+            std::shared_ptr<DeviceWorkerGroup::WorkItem> item = group.get(buckets[i].numSplats);
+            DeviceWorkerGroup::SubItem sub = buckets[i];
+            item->splats->write(splats.data() + sub.firstSplat, sub.numSplats, 0, false);
+            sub.firstSplat = 0;
+            item->subItems.push_back(sub);
+            group.push(item);
+        }
+        group.stop();
+    }
+    catch (std::exception &e)
+    {
+        std::cerr << "error: " << e.what() << "\n";
+        return 1;
+    }
+    std::fclose(out);
+    std::cout << "buckets " << buckets.size() << " vertices " << totalV << " triangles " << totalT << "\n";
+    return 0;
+}

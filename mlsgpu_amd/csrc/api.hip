@@ -331,7 +331,7 @@ MLSGPU_API uint64_t mlsgpu_hip_worker_resource_usage(const mlsgpu_worker_config 
     resolveConfig(c);
     const uint32_t wgs[3] = {8, 8, 8};
     const uint32_t block = c.maxCells + 1;
-    return mlsgpu_hip_marching_resource_usage(block, block, block, c.maxSwathe, c.meshMemory, wgs)
+    return mlsgpu_hip_marching_resource_usage(block, block, roundUp(block, 8), c.maxSwathe, c.meshMemory, wgs)
         + mlsgpu_hip_tree_resource_usage(c.levels, c.maxBucketSplats);
 }
 
@@ -354,7 +354,9 @@ MLSGPU_API int mlsgpu_hip_worker_create(mlsgpu_ctx *ctx, const mlsgpu_worker_con
     if (rc == MLSGPU_OK) rc = mlsgpu_hip_tree_create(ctx, c.levels, c.maxBucketSplats, &w->tree);
     if (rc == MLSGPU_OK) rc = mlsgpu_hip_mls_create(ctx, c.shape, &w->mls);
     if (rc == MLSGPU_OK) rc = mlsgpu_hip_mls_set_boundary_limit(w->mls, c.boundaryLimit);
-    if (rc == MLSGPU_OK) rc = mlsgpu_hip_marching_create(ctx, block, block, block, c.maxSwathe, c.meshMemory, wgs, &w->marching);
+    /* depth padded to the MLS block size so that the default maxSwathe (whole bucket) is not rounded DOWN
+     * to a multiple of 8 below the bucket depth (src/marching.cpp:373), which would cost a second swathe */
+    if (rc == MLSGPU_OK) rc = mlsgpu_hip_marching_create(ctx, block, block, roundUp(block, 8), c.maxSwathe, c.meshMemory, wgs, &w->marching);
     if (rc != MLSGPU_OK)
     {
         mlsgpu_hip_worker_destroy(w);

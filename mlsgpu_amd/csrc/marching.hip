@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cassert>
+#include <cstdlib>
 
 using namespace mlsgpu;
 
@@ -222,21 +223,46 @@ __device__ __forceinline__ uint32_t cellCode(const float iso[8], bool &valid)
     return code;
 }
 
-/* genOccupied (kernels/marching.cl:84-120) as the producer of the compaction scan */
+/* genOccupied (kernels/marching.cl:84-120), step 1: one byte per cell of the swathe = the cell's cube code if
+ * the cell is occupied (all 8 corners finite, code not 0 / 255), else 0.  Every later pass (counting,
+ * compaction, per-slice histogram, lattice weld) reads this byte instead of 8 floats. */
+struct CodeView
+{
+    const uint8_t *codes;
+    uint32_t cw, ch;
+    uint32_t z0;             /* cell slice stored first */
+    __device__ __forceinline__ uint32_t at(uint32_t x, uint32_t y, uint32_t z) const
+    {
+        return codes[((uint64_t) (z - z0) * ch + y) * cw + x];
+    }
+};
+
+__global__ __launch_bounds__(256) void cellCodeKernel(uint8_t *codes, FieldView F, uint32_t cw, uint32_t ch,
+                                                       uint32_t zFirst, uint32_t numCells)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numCells)
+        return;
+    const uint32_t x = i % cw, r = i / cw, y = r % ch, z = r / ch + zFirst;
+    float iso[8];
+    loadIso(F, x, y, z, iso);
+    bool valid;
+    const uint32_t code = cellCode(iso, valid);
+    codes[i] = (valid && code != 255) ? (uint8_t) code : (uint8_t) 0;
+}
+
+/* ... step 2: the producer of the compaction scan */
 struct ClassifyIn
 {
-    FieldView F;
+    CodeView C;
     CellRange R;
     const uchar2 *countTable;
     __device__ __forceinline__ U3 operator()(uint64_t i) const
     {
         uint32_t x, y, z;
         R.decode(i, x, y, z);
-        float iso[8];
-        loadIso(F, x, y, z, iso);
-        bool valid;
-        const uint32_t code = cellCode(iso, valid);
-        if (valid && code != 0 && code != 255)
+        const uint32_t code = C.at(x, y, z);
+        if (code != 0)
         {
             const uchar2 c = countTable[code];
             return U3{1u, c.x, c.y};
@@ -266,20 +292,17 @@ struct CompactCellsOut
 };
 
 /* per-slice (vertices, indices) histogram, only needed by the overflow path (src/marching.cpp:652-701) */
-__global__ __launch_bounds__(256) void sliceHistogramKernel(FieldView F, uint32_t cw, uint32_t ch, uint32_t zFirst,
+__global__ __launch_bounds__(256) void sliceHistogramKernel(CodeView C, uint32_t zFirst,
                                                             const uchar2 *countTable, uint2 *histogram)
 {
     __shared__ uint32_t sv[4], si[4];
     const uint32_t z = zFirst + blockIdx.x;
     uint32_t v = 0, idx = 0;
-    const uint32_t cells = cw * ch;
+    const uint32_t cells = C.cw * C.ch;
     for (uint32_t c = threadIdx.x; c < cells; c += 256)
     {
-        float iso[8];
-        loadIso(F, c % cw, c / cw, z, iso);
-        bool valid;
-        const uint32_t code = cellCode(iso, valid);
-        if (valid && code != 0 && code != 255)
+        const uint32_t code = C.at(c % C.cw, c / C.cw, z);
+        if (code != 0)
         {
             const uchar2 n = countTable[code];
             v += n.x;
@@ -504,6 +527,210 @@ __global__ void computeKeyTestKernel(uint32_t cx, uint32_t cy, uint32_t cz, uint
     *out = key;
 }
 
+/* ------------------------------------------------------------------ lattice weld
+ *
+ * Sort-free replacement for generateElements + sortVertices + countUnique + compactVertices + reindex,
+ * used when the whole batch lies in the resident field (one swathe per bucket, the MI355X default).
+ *
+ * Every welded vertex sits on a grid edge whose endpoints have different signs, i.e. on one point of
+ * the HALF LATTICE (x2, y2, z2) = 2*cell + keyTable offset -- exactly the fixed-point coordinates the
+ * reference packs into its vertex key (kernels/marching.cl:148-154,252).  Sorting by key therefore
+ * equals enumerating half-lattice points in (z2, y2, x2) order, and a welded vertex's index is its
+ * rank in that order within its class:
+ *     class 0  internal                        (first in the output)
+ *     class 1  unflagged, z2 == 2*zMax         (external by "key >= minExternalKey", src/marching.cpp:593)
+ *     class 2  flagged (x2 == 0, y2 == 0, x2 == top.x, y2 == top.y or z2 == top.z; marching.cl:151-152)
+ * which is the order the reference's 64-bit sort produces (flag bit above z above y above x).
+ * A vertex exists on an edge iff some OCCUPIED cell of the batch contains the edge and sees different
+ * signs at its ends (every sign-changing edge of a cell is used by one of its tetrahedra, so this is
+ * exactly the set of vertices the per-cell tables emit).
+ *
+ * Rows are (z2, y2); each row is a bit mask over x2 plus per-word prefix counts, so an index is
+ * rowStart[class] + wordPrefix + popcount -- three small L2-resident reads instead of a global sort.
+ */
+struct Lattice
+{
+    uint64_t *mask;          /* [rows][nw] existence bits */
+    uint32_t *wordPrefix;    /* [rows][nw] main-class vertices in the preceding words of the row */
+    U3 *rowCounts;           /* [rows] per class; exclusive-scanned in place into row starts */
+    const U3 *totals;        /* device: class totals after the scan */
+    uint32_t nw;             /* 64-bit words per row */
+    uint32_t rowsPerLayer;   /* 2H - 1 */
+    uint32_t topx, topy;     /* 2(W-1), 2(H-1) */
+    uint32_t z2First;        /* 2 * zTop: first layer, also top.z */
+    uint32_t z2Last;         /* 2 * zMax: last layer */
+    uint32_t cw, ch;         /* cells per row / rows of cells */
+
+    __device__ __forceinline__ uint32_t rowClass(uint32_t y2, uint32_t z2) const
+    {
+        if (y2 == 0 || y2 == topy || z2 == z2First)
+            return 2;
+        return z2 == z2Last ? 1 : 0;
+    }
+    /* bits of word w that belong to columns x2 == 0 and x2 == top.x (class 2 inside class 0/1 rows) */
+    __device__ __forceinline__ uint64_t columnMask(uint32_t w) const
+    {
+        uint64_t m = w == 0 ? 1ull : 0ull;
+        if (w == (topx >> 6))
+            m |= 1ull << (topx & 63);
+        return m;
+    }
+    /* output index of the vertex at an existing half-lattice point */
+    __device__ __forceinline__ uint32_t index(uint32_t x2, uint32_t y2, uint32_t z2) const
+    {
+        const uint32_t row = (z2 - z2First) * rowsPerLayer + y2;
+        const uint32_t rc = rowClass(y2, z2);
+        const U3 rs = rowCounts[row];
+        const U3 tot = *totals;
+        const uint32_t off2 = tot.a + tot.b;
+        const uint32_t w = x2 >> 6;
+        const uint64_t bits = mask[(uint64_t) row * nw + w];
+        const uint64_t below = bits & ((1ull << (x2 & 63)) - 1);
+        if (rc == 2)
+            return off2 + rs.c + wordPrefix[(uint64_t) row * nw + w] + (uint32_t) __popcll(below);
+        if (x2 == 0)
+            return off2 + rs.c;
+        if (x2 == topx)
+            return off2 + rs.c + (uint32_t) (mask[(uint64_t) row * nw] & 1);
+        const uint32_t base = rc == 0 ? rs.a : tot.a + rs.b;
+        return base + wordPrefix[(uint64_t) row * nw + w] + (uint32_t) __popcll(below & ~columnMask(w));
+    }
+};
+
+/* One wave per row: existence bits, per-word prefixes, per-class row totals. */
+__global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, uint32_t zCellFirst, uint32_t zCellLast,
+                                                         uint32_t numRows)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= numRows)
+        return;
+    const uint32_t z2 = row / L.rowsPerLayer + L.z2First, y2 = row % L.rowsPerLayer;
+    const uint32_t cz = z2 >> 1, pz = z2 & 1, cy = y2 >> 1, py = y2 & 1;
+    const uint32_t rc = L.rowClass(y2, z2);
+    uint32_t running = 0, nFlag = 0;
+    for (uint32_t w = 0; w < L.nw; w++)
+    {
+        const uint32_t x2 = w * 64 + lane;
+        const uint32_t cx = x2 >> 1, px = x2 & 1;
+        uint32_t exists = 0;
+        if (x2 <= L.topx && (px | py | pz))
+        {
+            const uint32_t d = px | (py << 1) | (pz << 2);
+            /* cells containing the edge: along an axis the edge runs along, the owner's cell only;
+             * across, the owner's cell and the one before it */
+#pragma unroll
+            for (uint32_t oz = 0; oz < 2; oz++)
+#pragma unroll
+                for (uint32_t oy = 0; oy < 2; oy++)
+#pragma unroll
+                    for (uint32_t ox = 0; ox < 2; ox++)
+                    {
+                        if ((ox & px) | (oy & py) | (oz & pz))
+                            continue;
+                        const int ix = (int) cx - (int) ox, iy = (int) cy - (int) oy, iz = (int) cz - (int) oz;
+                        if (ix < 0 || iy < 0 || iz < (int) zCellFirst || ix >= (int) L.cw || iy >= (int) L.ch || iz >= (int) zCellLast)
+                            continue;
+                        const uint32_t code = C.at((uint32_t) ix, (uint32_t) iy, (uint32_t) iz);
+                        const uint32_t a = ox | (oy << 1) | (oz << 2);
+                        exists |= ((code >> a) ^ (code >> (a | d))) & 1u;
+                    }
+        }
+        const uint64_t bits = __ballot(exists != 0);
+        const uint64_t cm = rc == 2 ? 0ull : L.columnMask(w);
+        if (lane == 0)
+        {
+            L.mask[(uint64_t) row * L.nw + w] = bits;
+            L.wordPrefix[(uint64_t) row * L.nw + w] = running;
+        }
+        running += (uint32_t) __popcll(bits & ~cm);
+        nFlag += (uint32_t) __popcll(bits & cm);
+    }
+    if (lane == 0)
+    {
+        U3 c{0u, 0u, 0u};
+        if (rc == 0) { c.a = running; c.c = nFlag; }
+        else if (rc == 1) { c.b = running; c.c = nFlag; }
+        else c.c = running;
+        L.rowCounts[row] = c;
+    }
+}
+
+/* One wave per row: positions (interp, kernels/marching.cl:130-138) and external keys of the existing points. */
+__global__ __launch_bounds__(256) void latticeVerticesKernel(Lattice L, FieldView F, float *outVertices, uint64_t *outKeys,
+                                                             uint32_t gox, uint32_t goy, uint32_t goz,
+                                                             uint64_t keyOffset, uint32_t numRows)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= numRows)
+        return;
+    const uint32_t z2 = row / L.rowsPerLayer + L.z2First, y2 = row % L.rowsPerLayer;
+    const uint32_t cz = z2 >> 1, pz = z2 & 1, cy = y2 >> 1, py = y2 & 1;
+    const uint32_t rc = L.rowClass(y2, z2);
+    const U3 rs = L.rowCounts[row];
+    const U3 tot = *L.totals;
+    const uint32_t off2 = tot.a + tot.b;
+    const uint32_t mainBase = rc == 0 ? rs.a : (rc == 1 ? tot.a + rs.b : off2 + rs.c);
+    const uint32_t bit0 = (uint32_t) (L.mask[(uint64_t) row * L.nw] & 1);
+    for (uint32_t w = 0; w < L.nw; w++)
+    {
+        const uint64_t bits = L.mask[(uint64_t) row * L.nw + w];
+        if (!((bits >> lane) & 1))
+            continue;
+        const uint32_t x2 = w * 64 + lane;
+        const uint64_t below = bits & ((1ull << lane) - 1);
+        uint32_t idx;
+        uint32_t cls = rc;
+        if (rc != 2 && (x2 == 0 || x2 == L.topx))
+        {
+            cls = 2;
+            idx = off2 + rs.c + (x2 == 0 ? 0u : bit0);
+        }
+        else
+        {
+            const uint64_t cm = rc == 2 ? 0ull : L.columnMask(w);
+            idx = mainBase + L.wordPrefix[(uint64_t) row * L.nw + w] + (uint32_t) __popcll(below & ~cm);
+        }
+        const uint32_t cx = x2 >> 1, px = x2 & 1;
+        /* endpoint A = owner corner, B = A + (px,py,pz): A has the lower local corner id in every cell */
+        const uint32_t rowA = cy + F.zStride * cz + (uint32_t) F.zBias;
+        const uint32_t rowB = (cy + py) + F.zStride * (cz + pz) + (uint32_t) F.zBias;
+        const float iso0 = F.at(cx, rowA), iso1 = F.at(cx + px, rowB);
+        const float inv = 1.0f / (iso0 - iso1);
+        const float t = iso0 * inv;
+        outVertices[3 * (uint64_t) idx + 0] = fmaf(t, (float) px, (float) (cx + gox));
+        outVertices[3 * (uint64_t) idx + 1] = fmaf(t, (float) py, (float) (cy + goy));
+        outVertices[3 * (uint64_t) idx + 2] = fmaf(t, (float) pz, (float) (cz + goz));
+        if (cls != 0)
+            outKeys[idx] = (((uint64_t) z2 << (2 * KEY_AXIS_BITS)) | ((uint64_t) y2 << KEY_AXIS_BITS) | (uint64_t) x2) + keyOffset;
+    }
+}
+
+/* One thread per occupied cell: look up the welded index of each of the cell's vertices, then emit its
+ * triangles (the index half of generateElements + reindex). */
+__global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeView C, DevTables T, const uint2 *cells,
+                                                              const uint2 *viStart, uint32_t *indices, uint32_t numCells)
+{
+    __shared__ uint32_t sIdx[256][MAX_CELL_VERTICES];
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= numCells)
+        return;
+    const uint2 cell = cells[gid];
+    const uint32_t x = cell.x & 0xFFFFu, y = cell.x >> 16, z = cell.y;
+    const uint32_t code = C.at(x, y, z);
+    const ushort2 st = T.start[code], en = T.start[code + 1];
+    const uint32_t nv = en.x - st.x, ni = en.y - st.y;
+    for (uint32_t i = 0; i < nv; i++)
+    {
+        const uint32_t k = T.key[st.x + i];
+        sIdx[threadIdx.x][i] = L.index(2 * x + (k & 0xFF), 2 * y + ((k >> 8) & 0xFF), 2 * z + (k >> 16));
+    }
+    const uint32_t iStart = viStart[gid].y;
+    for (uint32_t i = 0; i < ni; i++)
+        indices[iStart + i] = sIdx[threadIdx.x][T.data[st.y + i]];
+}
+
 uint32_t bitsFor(uint32_t maxValue)
 {
     uint32_t b = 1;
@@ -517,6 +744,8 @@ struct Readback
     U3 totals;              /* occupied cells, vertices, indices of the (sub-)swathe */
     uint32_t numWelded;
     uint32_t firstExternal;
+    U3 classTotals;         /* lattice weld: welded vertices per class (internal, unflagged top, flagged) */
+    U3 batchTotals;         /* lattice weld: occupied cells / vertices / indices of the batch */
 };
 
 } // namespace
@@ -549,9 +778,21 @@ struct mlsgpu_marching
     Readback *hReadback = nullptr;          /* pinned */
     uint2 *hHistogram = nullptr;            /* pinned, maxDepth entries (viReadback in the reference) */
 
+    /* lattice weld (single-swathe buckets) */
+    uint8_t *dCellCode = nullptr;
+    uint64_t *dLatMask = nullptr;
+    uint32_t *dLatPrefix = nullptr;
+    U3 *dLatRows = nullptr;
+    uint64_t latRowsMax = 0;
+    uint32_t latWords = 0;
+    bool legacyBuffers = true;              /* false: every bucket fits one swathe, sort path never needed */
+
     uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
     /* per-generate state */
+    bool direct = false;                    /* this generate() call uses the lattice weld */
+    uint32_t codeZ0 = 0;                    /* first cell slice held in dCellCode */
+    uint32_t bufferedCells = 0;             /* occupied cells accounted since the last ship-out (direct mode) */
     const mlsgpu_generator *generator = nullptr;
     mlsgpu_output_fn output = nullptr;
     void *outputUser = nullptr;
@@ -559,11 +800,15 @@ struct mlsgpu_marching
     KeyLayout layout = {1, 1, 1};
 
     FieldView view(const mlsgpu_swathe &sw) const { return FieldView{dField, imageWidth, sw.zStride, sw.zBias}; }
+    CodeView codeView(const mlsgpu_swathe &sw) const { return CodeView{dCellCode, sw.width - 1, sw.height - 1, codeZ0}; }
     DevTables devTables() const { return DevTables{dCount, dStart, dData, dKey}; }
 
     int generateCells(const mlsgpu_swathe &sw, U3 *totals);
     int sliceHistogram(const mlsgpu_swathe &sw);
-    int shipOut(const uint32_t sizes[2], uint32_t zMax);
+    int computeCodes(const mlsgpu_swathe &sw);
+    int shipOut(const mlsgpu_swathe &sw, const uint32_t sizes[2], uint32_t zTop, uint32_t zMax);
+    int shipOutSorted(const uint32_t sizes[2], uint32_t zMax, mlsgpu_mesh *mesh);
+    int shipOutLattice(const mlsgpu_swathe &sw, const uint32_t sizes[2], uint32_t zTop, uint32_t zMax, mlsgpu_mesh *mesh);
     int addSlices(const mlsgpu_swathe &sw, uint32_t offsets[2], uint32_t &zTop, uint32_t *shipOuts);
     template<typename K> int weld(uint32_t nv, uint32_t zMax);
 };
@@ -589,14 +834,22 @@ uint64_t marchingSizes(uint32_t maxWidth, uint32_t maxHeight, uint32_t maxDepth,
      * generator may write when the last swathe is padded up to its Z alignment (src/marching.h:236-237) */
     *fieldRows = (uint64_t) *imageHeight * (*swathe + 1 + alignment[2]);
     const uint64_t vs = *vertexSpace, is = *indexSpace, sc = *swatheCells;
+    const bool legacy = *swathe < maxDepth;         /* some bucket may need more than one swathe */
+    const uint64_t latRows = (uint64_t) (2 * *swathe + 1) * (2 * maxHeight - 1);
+    const uint64_t latWords = (2 * maxWidth - 1 + 63) / 64;
     uint64_t bytes = *fieldRows * *imageWidth * 4;
-    bytes += sc * 16;                               /* cells + viStart */
-    bytes += (uint64_t) scanTiles(sc) * 12 + 12;    /* tile sums (U3) */
-    bytes += vs * 16;                               /* unwelded vertices */
-    bytes += vs * 8 * 2 + vs * 4 * 2;               /* sort keys + values, ping-pong */
-    bytes += is * 4 + vs * 4;                       /* indices, indexRemap */
+    bytes += sc * 16 + sc;                          /* cells + viStart + cell codes */
+    bytes += (uint64_t) scanTiles(std::max(sc, latRows)) * 12 + 12;    /* tile sums (U3) */
+    bytes += latRows * latWords * 12 + latRows * 12;                   /* lattice masks, prefixes, row counts */
+    if (legacy)
+    {
+        bytes += vs * 16;                           /* unwelded vertices */
+        bytes += vs * 8 * 2 + vs * 4 * 2;           /* sort keys + values, ping-pong */
+        bytes += vs * 4;                            /* indexRemap */
+        bytes += sortHistElems(vs) * 4 + (uint64_t) scanTiles(std::max(sortHistElems(vs), vs)) * 4;
+    }
+    bytes += is * 4;                                /* indices */
     bytes += vs * 12 + vs * 8;                      /* welded vertices + keys */
-    bytes += sortHistElems(vs) * 4 + (uint64_t) scanTiles(std::max(sortHistElems(vs), vs)) * 4;
     bytes += (uint64_t) maxDepth * 8 + 512 + 1028 + 8192 + 2432 * 4;
     return bytes;
 }
@@ -658,18 +911,28 @@ MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, ui
     alloc((void **) &m->dCells, sc * 8);
     alloc((void **) &m->dViStart, sc * 8);
     alloc((void **) &m->dHistogram, (uint64_t) maxDepth * 8);
-    alloc((void **) &m->dTileSums3, ((uint64_t) scanTiles(sc) + 1) * sizeof(U3));
-    alloc((void **) &m->dVertices, vs * 16);
-    alloc(&m->dKeysA, (vs + 1) * 8);
-    alloc(&m->dKeysB, (vs + 1) * 8);
-    alloc((void **) &m->dValsA, (vs + 1) * 4);
-    alloc((void **) &m->dValsB, (vs + 1) * 4);
+    m->legacyBuffers = m->maxSwathe < maxDepth;
+    m->latRowsMax = (uint64_t) (2 * m->maxSwathe + 1) * (2 * maxHeight - 1);
+    m->latWords = (2 * maxWidth - 1 + 63) / 64;
+    alloc((void **) &m->dTileSums3, ((uint64_t) scanTiles(std::max(sc, m->latRowsMax)) + 1) * sizeof(U3));
+    alloc((void **) &m->dCellCode, sc);
+    alloc((void **) &m->dLatMask, m->latRowsMax * m->latWords * 8);
+    alloc((void **) &m->dLatPrefix, m->latRowsMax * m->latWords * 4);
+    alloc((void **) &m->dLatRows, m->latRowsMax * sizeof(U3));
+    if (m->legacyBuffers)
+    {
+        alloc((void **) &m->dVertices, vs * 16);
+        alloc(&m->dKeysA, (vs + 1) * 8);
+        alloc(&m->dKeysB, (vs + 1) * 8);
+        alloc((void **) &m->dValsA, (vs + 1) * 4);
+        alloc((void **) &m->dValsB, (vs + 1) * 4);
+        alloc((void **) &m->dIndexRemap, vs * 4);
+        alloc((void **) &m->dHist, (sortHistElems(vs) + 1) * 4);
+        alloc((void **) &m->dTileSums, ((uint64_t) scanTiles(std::max(sortHistElems(vs), vs)) + 1) * 4);
+    }
     alloc((void **) &m->dIndices, is * 4);
-    alloc((void **) &m->dIndexRemap, vs * 4);
     alloc((void **) &m->dWelded, vs * 12);
     alloc((void **) &m->dWeldedKeys, vs * 8);
-    alloc((void **) &m->dHist, (sortHistElems(vs) + 1) * 4);
-    alloc((void **) &m->dTileSums, ((uint64_t) scanTiles(std::max(sortHistElems(vs), vs)) + 1) * 4);
     alloc((void **) &m->dReadback, sizeof(Readback));
     if (rc == MLSGPU_OK && hipHostMalloc((void **) &m->hReadback, sizeof(Readback)) != hipSuccess)
         rc = setError(MLSGPU_ERR_NOMEM, "Marching: cannot allocate pinned readback");
@@ -707,6 +970,7 @@ MLSGPU_API void mlsgpu_hip_marching_destroy(mlsgpu_marching *m)
     hipFree(m->dVertices); hipFree(m->dKeysA); hipFree(m->dKeysB); hipFree(m->dValsA); hipFree(m->dValsB);
     hipFree(m->dIndices); hipFree(m->dIndexRemap); hipFree(m->dWelded); hipFree(m->dWeldedKeys);
     hipFree(m->dHist); hipFree(m->dTileSums); hipFree(m->dReadback);
+    hipFree(m->dCellCode); hipFree(m->dLatMask); hipFree(m->dLatPrefix); hipFree(m->dLatRows);
     if (m->hReadback) hipHostFree(m->hReadback);
     if (m->hHistogram) hipHostFree(m->hHistogram);
     delete m;
@@ -718,7 +982,7 @@ int mlsgpu_marching::generateCells(const mlsgpu_swathe &sw, U3 *totals)
 {
     const CellRange R{sw.width - 1, sw.height - 1, sw.zFirst};
     const uint64_t n = (uint64_t) R.cw * R.ch * (sw.zLast - sw.zFirst);
-    ClassifyIn in{view(sw), R, dCount};
+    ClassifyIn in{codeView(sw), R, dCount};
     PROPAGATE((scanPhase1<U3, ClassifyIn>(ctx, "kernel.marching.genOccupied.time", in, n, U3{0, 0, 0},
                                           dTileSums3, &dReadback->totals)));
     int pend = -1;
@@ -734,7 +998,7 @@ int mlsgpu_marching::sliceHistogram(const mlsgpu_swathe &sw)
 {
     const uint32_t slices = sw.zLast - sw.zFirst;
     LAUNCH(ctx, "kernel.marching.genOccupied.time", sliceHistogramKernel, dim3(slices), dim3(256),
-           view(sw), sw.width - 1, sw.height - 1, sw.zFirst, (const uchar2 *) dCount, dHistogram);
+           codeView(sw), sw.zFirst, (const uchar2 *) dCount, dHistogram);
     HIP_CHECK(hipMemcpyAsync(hHistogram + sw.zFirst, dHistogram + sw.zFirst, (size_t) slices * 8,
                              hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -758,8 +1022,20 @@ int mlsgpu_marching::weld(uint32_t nv, uint32_t zMax)
                                    &dReadback->numWelded);
 }
 
-/* shipOut, src/marching.cpp:553-625 */
-int mlsgpu_marching::shipOut(const uint32_t sizes[2], uint32_t zMax)
+/* cellCodeKernel over the cells of one top-level swathe */
+int mlsgpu_marching::computeCodes(const mlsgpu_swathe &sw)
+{
+    const uint32_t cw = sw.width - 1, ch = sw.height - 1;
+    const uint64_t n = (uint64_t) cw * ch * (sw.zLast - sw.zFirst);
+    codeZ0 = sw.zFirst;
+    if (n > 0)
+        LAUNCH(ctx, "kernel.marching.genOccupied.time", cellCodeKernel, dim3(divUp(n, 256)), dim3(256),
+               dCellCode, view(sw), cw, ch, sw.zFirst, (uint32_t) n);
+    return MLSGPU_OK;
+}
+
+/* shipOut, src/marching.cpp:553-625, sort-based: works on the unwelded buffers filled by generateElements */
+int mlsgpu_marching::shipOutSorted(const uint32_t sizes[2], uint32_t zMax, mlsgpu_mesh *mesh)
 {
     const uint32_t nv = sizes[0], ni = sizes[1];
     if (wideKeys)
@@ -771,14 +1047,79 @@ int mlsgpu_marching::shipOut(const uint32_t sizes[2], uint32_t zMax)
                dIndices, (const uint32_t *) dIndexRemap, ni);
     HIP_CHECK(hipMemcpyAsync(&hReadback->numWelded, &dReadback->numWelded, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));        /* the reference's queue.finish(), :617 */
+    mesh->numVertices = hReadback->numWelded;
+    mesh->numInternalVertices = hReadback->firstExternal;
+    return MLSGPU_OK;
+}
 
+/* shipOut without a sort: the lattice weld over cells z in [zTop, zMax) of the resident swathe */
+int mlsgpu_marching::shipOutLattice(const mlsgpu_swathe &sw, const uint32_t sizes[2], uint32_t zTop, uint32_t zMax,
+                                    mlsgpu_mesh *mesh)
+{
+    (void) sizes;
+    const uint32_t W = sw.width, H = sw.height;
+    Lattice L;
+    L.mask = dLatMask;
+    L.wordPrefix = dLatPrefix;
+    L.rowCounts = dLatRows;
+    L.totals = &dReadback->classTotals;
+    L.nw = (2 * W - 1 + 63) / 64;
+    L.rowsPerLayer = 2 * H - 1;
+    L.topx = 2 * (W - 1);
+    L.topy = 2 * (H - 1);
+    L.z2First = 2 * zTop;
+    L.z2Last = 2 * zMax;
+    L.cw = W - 1;
+    L.ch = H - 1;
+    const uint32_t numRows = (2 * (zMax - zTop) + 1) * L.rowsPerLayer;
+    REQUIRE(numRows <= latRowsMax && L.nw <= latWords, MLSGPU_ERR_LENGTH);
+    const CodeView C = codeView(sw);
+    const char *stat = "kernel.marching.compactVertices.time";
+    LAUNCH(ctx, "kernel.marching.countUniqueVertices.time", latticeMaskKernel, dim3(divUp(numRows, 4)), dim3(256),
+           L, C, zTop, zMax, numRows);
+    PROPAGATE((exclusiveScan<U3>(ctx, "kernel.marching.scanUint.time", ArrayIn<U3>{dLatRows}, ArrayOut<U3>{dLatRows},
+                                 numRows, U3{0, 0, 0}, dTileSums3, &dReadback->classTotals)));
+    const uint64_t keyOffsetL = ((uint64_t) keyOffset[2] << (2 * KEY_AXIS_BITS + 1))
+        | ((uint64_t) keyOffset[1] << (KEY_AXIS_BITS + 1))
+        | ((uint64_t) keyOffset[0] << 1);                                   /* src/marching.cpp:594-597 */
+    LAUNCH(ctx, stat, latticeVerticesKernel, dim3(divUp(numRows, 4)), dim3(256),
+           L, view(sw), dWelded, dWeldedKeys, keyOffset[0], keyOffset[1], keyOffset[2], keyOffsetL, numRows);
+    /* compact the batch's occupied cells (cell-linear order) with their first index slot, then the triangles */
+    const CellRange R{W - 1, H - 1, zTop};
+    const uint64_t n = (uint64_t) R.cw * R.ch * (zMax - zTop);
+    ClassifyIn in{C, R, dCount};
+    CompactCellsOut outF{R, dCells, dViStart, 0u, 0u};
+    PROPAGATE((exclusiveScan<U3>(ctx, "kernel.marching.scanElements.time", in, outF, n, U3{0, 0, 0}, dTileSums3,
+                                 &dReadback->batchTotals)));
+    const uint32_t cellsInBatch = bufferedCells;
+    if (cellsInBatch > 0)
+        LAUNCH(ctx, "kernel.marching.generateElements.time", latticeTrianglesKernel, dim3(divUp(cellsInBatch, 256)), dim3(256),
+               L, C, devTables(), (const uint2 *) dCells, (const uint2 *) dViStart, dIndices, cellsInBatch);
+    HIP_CHECK(hipMemcpyAsync(&hReadback->classTotals, &dReadback->classTotals, 2 * sizeof(U3), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const U3 ct = hReadback->classTotals, bt = hReadback->batchTotals;
+    if (bt.a != cellsInBatch || bt.b != sizes[0] || bt.c != sizes[1])
+        return setError(MLSGPU_ERR_INVALID, "lattice weld: batch accounting mismatch (%u/%u cells, %u/%u vertices, %u/%u indices)",
+                        bt.a, cellsInBatch, bt.b, sizes[0], bt.c, sizes[1]);
+    mesh->numVertices = (uint64_t) ct.a + ct.b + ct.c;
+    mesh->numInternalVertices = ct.a;
+    return MLSGPU_OK;
+}
+
+/* shipOut, src/marching.cpp:553-625 */
+int mlsgpu_marching::shipOut(const mlsgpu_swathe &sw, const uint32_t sizes[2], uint32_t zTop, uint32_t zMax)
+{
+    const uint32_t nv = sizes[0], ni = sizes[1];
     mlsgpu_mesh mesh;
     mesh.dVertices = dWelded;
     mesh.dTriangles = dIndices;
     mesh.dVertexKeys = dWeldedKeys;
-    mesh.numVertices = hReadback->numWelded;
     mesh.numTriangles = ni / 3;
-    mesh.numInternalVertices = hReadback->firstExternal;
+    if (direct)
+        PROPAGATE(shipOutLattice(sw, sizes, zTop, zMax, &mesh));
+    else
+        PROPAGATE(shipOutSorted(sizes, zMax, &mesh));
+    bufferedCells = 0;
     counters[1]++;
     counters[4] += nv;
     counters[5] += ni;
@@ -849,30 +1190,38 @@ int mlsgpu_marching::addSlices(const mlsgpu_swathe &swathe, uint32_t offsets[2],
             if ((uint64_t) offsets[0] + counts[0] > vertexSpace || (uint64_t) offsets[1] + counts[1] > indexSpace)
             {
                 /* fits, but only after flushing what is buffered (:705-719) */
-                PROPAGATE(shipOut(offsets, swathe.zFirst));
+                PROPAGATE(shipOut(swathe, offsets, zTop, swathe.zFirst));
                 (*shipOuts)++;
                 offsets[0] = offsets[1] = 0;
                 zTop = swathe.zFirst;
                 top[2] = 2 * swathe.zFirst;
             }
-            /* scanElements + generateElements (:721-731): compaction pass, then one thread per cell */
-            const CellRange R{swathe.width - 1, swathe.height - 1, swathe.zFirst};
-            const uint64_t n = (uint64_t) R.cw * R.ch * (swathe.zLast - swathe.zFirst);
-            ClassifyIn in{view(swathe), R, dCount};
-            CompactCellsOut outF{R, dCells, dViStart, offsets[0], offsets[1]};
-            PROPAGATE((scanPhase2<U3, ClassifyIn, CompactCellsOut>(ctx, "kernel.marching.scanElements.time", in, outF, n,
-                                                                   (const U3 *) dTileSums3)));
-            const dim3 grid(divUp(compacted, 256)), block(256);
-            if (wideKeys)
-                LAUNCH(ctx, "kernel.marching.generateElements.time", (generateElementsKernel<uint64_t>), grid, block,
-                       dVertices, static_cast<uint64_t *>(dKeysA), dIndices, (const uint2 *) dViStart, (const uint2 *) dCells,
-                       view(swathe), devTables(), keyOffset[0], keyOffset[1], keyOffset[2], top[0], top[1], top[2],
-                       layout, compacted);
+            if (direct)
+            {
+                /* lattice weld: nothing to generate now -- the field stays resident, the ship-out works from it */
+                bufferedCells += compacted;
+            }
             else
-                LAUNCH(ctx, "kernel.marching.generateElements.time", (generateElementsKernel<uint32_t>), grid, block,
-                       dVertices, static_cast<uint32_t *>(dKeysA), dIndices, (const uint2 *) dViStart, (const uint2 *) dCells,
-                       view(swathe), devTables(), keyOffset[0], keyOffset[1], keyOffset[2], top[0], top[1], top[2],
-                       layout, compacted);
+            {
+                /* scanElements + generateElements (:721-731): compaction pass, then one thread per cell */
+                const CellRange R{swathe.width - 1, swathe.height - 1, swathe.zFirst};
+                const uint64_t n = (uint64_t) R.cw * R.ch * (swathe.zLast - swathe.zFirst);
+                ClassifyIn in{codeView(swathe), R, dCount};
+                CompactCellsOut outF{R, dCells, dViStart, offsets[0], offsets[1]};
+                PROPAGATE((scanPhase2<U3, ClassifyIn, CompactCellsOut>(ctx, "kernel.marching.scanElements.time", in, outF, n,
+                                                                       (const U3 *) dTileSums3)));
+                const dim3 grid(divUp(compacted, 256)), block(256);
+                if (wideKeys)
+                    LAUNCH(ctx, "kernel.marching.generateElements.time", (generateElementsKernel<uint64_t>), grid, block,
+                           dVertices, static_cast<uint64_t *>(dKeysA), dIndices, (const uint2 *) dViStart, (const uint2 *) dCells,
+                           view(swathe), devTables(), keyOffset[0], keyOffset[1], keyOffset[2], top[0], top[1], top[2],
+                           layout, compacted);
+                else
+                    LAUNCH(ctx, "kernel.marching.generateElements.time", (generateElementsKernel<uint32_t>), grid, block,
+                           dVertices, static_cast<uint32_t *>(dKeysA), dIndices, (const uint2 *) dViStart, (const uint2 *) dCells,
+                           view(swathe), devTables(), keyOffset[0], keyOffset[1], keyOffset[2], top[0], top[1], top[2],
+                           layout, compacted);
+            }
             offsets[0] += counts[0];
             offsets[1] += counts[1];
             counters[3] += compacted;
@@ -913,6 +1262,17 @@ MLSGPU_API int mlsgpu_hip_marching_generate(mlsgpu_marching *m, const mlsgpu_gen
     m->layout.by = bitsFor(2 * (swathe.height - 1));
     m->layout.bz = bitsFor(2 * (depth - 1));
     m->wideKeys = m->layout.bits() > 32;
+    /* One swathe covers the bucket: weld from the resident field without sorting.  Otherwise (or when forced
+     * with MLSGPU_HIP_WELD=sort) the reference's generate + sort + compact structure is used. */
+    m->direct = depth <= m->maxSwathe;
+    {
+        const char *force = getenv("MLSGPU_HIP_WELD");
+        if (force != nullptr && std::strcmp(force, "sort") == 0 && m->legacyBuffers)
+            m->direct = false;
+    }
+    if (!m->direct && !m->legacyBuffers)
+        return setError(MLSGPU_ERR_LENGTH, "Marching: depth %u needs several swathes but was created for one", depth);
+    m->bufferedCells = 0;
 
     uint32_t offsets[2] = {0, 0};
     uint32_t zTop = 0;
@@ -932,11 +1292,12 @@ MLSGPU_API int mlsgpu_hip_marching_generate(mlsgpu_marching *m, const mlsgpu_gen
         }
         if (z > 0)
             swathe.zFirst--;
+        PROPAGATE(m->computeCodes(swathe));
         PROPAGATE(m->addSlices(swathe, offsets, zTop, &shipOuts));
     }
     if (offsets[0] > 0)
     {
-        PROPAGATE(m->shipOut(offsets, depth - 1));
+        PROPAGATE(m->shipOut(swathe, offsets, zTop, depth - 1));
         shipOuts++;
     }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -103,7 +103,9 @@ def test_generate_manifold_and_parity(ctx, name):
 
 
 @pytest.mark.parametrize("swathe,mem_slices,alignment,key_offset", [
-    (8, 1, (8, 8, 8), (0, 0, 0)), (64, 300, (8, 8, 8), (100, 200, 300)), (24, 3, (8, 8, 8), (5, 6, 7))])
+    (8, 1, (8, 8, 8), (0, 0, 0)), (64, 300, (8, 8, 8), (100, 200, 300)), (24, 3, (8, 8, 8), (5, 6, 7)),
+    # one swathe for the whole volume: the sort-free lattice weld, incl. overflow splitting and mid-bucket ship-outs
+    (64, 1, (8, 8, 8), (0, 0, 0)), (72, 2, (8, 8, 8), (9, 8, 7)), (66, 7, (7, 5, 11), (1, 0, 2))])
 def test_generate_swathe_and_memory_variants(ctx, swathe, mem_slices, alignment, key_offset):
     """Same field through different swathe sizes / mesh memories: every variant equals the oracle run with the
     same parameters (overflow splitting, mid-bucket ship-outs, external flags at ship-out boundaries)."""
@@ -116,6 +118,27 @@ def test_generate_swathe_and_memory_variants(ctx, swathe, mem_slices, alignment,
     oracle = ob.MarchingOracle(mw, mh, md, swathe, mesh_memory, alignment)
     exp = oracle.generate(host_generator(fn), size, key_offset)
     assert_batches_equal(got, exp)
+
+
+@pytest.mark.parametrize("name", sorted(GENERATE_CASES))
+def test_lattice_and_sort_welds_agree(ctx, name, monkeypatch):
+    """The two weld mechanisms (lattice ranks vs. key sort) must produce identical batches."""
+    import mlsgpu_amd as m
+    (mw, mh, md), size, fn = GENERATE_CASES[name]
+    alignment = (8, 8, 8)
+    mw, mh, md = mw + 5, mh + 2, 72
+    mesh_memory = (mw - 1) * (mh - 1) * 872 * 5
+    # maxSwathe 64 < maxDepth 72 keeps the sort buffers allocated; depth 60/32 <= 64 selects the lattice weld
+    mc = m.Marching(ctx, mw, mh, md, 64, mesh_memory, alignment)
+    monkeypatch.delenv("MLSGPU_HIP_WELD", raising=False)
+    lattice = mc.generate(m.binding.HostGenerator(ctx, fn, alignment), size, (3, 1, 4))
+    monkeypatch.setenv("MLSGPU_HIP_WELD", "sort")
+    sort = mc.generate(m.binding.HostGenerator(ctx, fn, alignment), size, (3, 1, 4))
+    monkeypatch.delenv("MLSGPU_HIP_WELD")
+    assert len(lattice) >= 1
+    assert_batches_equal(lattice, sort)
+    exp = ob.MarchingOracle(mw, mh, md, 64, mesh_memory, alignment).generate(host_generator(fn), size, (3, 1, 4))
+    assert_batches_equal(lattice, exp)
 
 
 def test_empty_and_degenerate(ctx):
