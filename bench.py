@@ -35,7 +35,7 @@ def parse_args():
     p.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3"])
     p.add_argument("--dist", default="uniform", choices=["uniform", "shells"])
     p.add_argument("--scale", type=float, default=1.0, help="splat-count scale (debug only; 1.0 = BASELINE size)")
-    p.add_argument("--mesh-memory-mb", type=int, default=2048, help="Marching mesh arena per worker")
+    p.add_argument("--mesh-memory-mb", type=int, default=4096, help="Marching mesh arena per worker")
     p.add_argument("--variant", type=int, default=0, help="MLS kernel variant: 0 culled, 1 basic")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-timing", action="store_true", help="do not time individual kernels with HIP events")

@@ -180,6 +180,10 @@ uint64_t mlsgpu_hip_marching_resource_usage(uint32_t maxWidth, uint32_t maxHeigh
 int mlsgpu_hip_marching_generate(mlsgpu_marching *m, const mlsgpu_generator *generator,
                                  mlsgpu_output_fn output, void *outputUser,
                                  const uint32_t size[3], const uint32_t keyOffset[3]);
+/* Folds a ScaleBiasFilter (src/mesh_filter.cpp:69-113) into vertex emission: with enabled != 0 every vertex
+ * handed to the output functor is already fma(v, scale, bias), bit-identical to running mlsgpu_hip_scale_bias
+ * on the mesh afterwards, without the extra pass over HBM.  The worker uses this for its scale/bias filter. */
+int mlsgpu_hip_marching_set_vertex_transform(mlsgpu_marching *m, int enabled, float scale, float bx, float by, float bz);
 /* Counters marching.overflow / marching.shipouts / marching.slices.nonempty (src/marching.cpp:342-377) and
  * work totals: out[0]=overflow out[1]=shipouts out[2]=nonempty swathes out[3]=occupied cells
  * out[4]=unwelded vertices out[5]=indices out[6]=welded vertices out[7]=external vertices. */

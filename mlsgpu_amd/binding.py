@@ -127,6 +127,7 @@ def lib():
     sig("mlsgpu_hip_marching_destroy", None, vp)
     sig("mlsgpu_hip_marching_resource_usage", u64, u32, u32, u32, u32, u64, vp)
     sig("mlsgpu_hip_marching_generate", C.c_int, vp, P(Generator), OUTPUT_FN, vp, vp, vp)
+    sig("mlsgpu_hip_marching_set_vertex_transform", C.c_int, vp, C.c_int, f32, f32, f32, f32)
     sig("mlsgpu_hip_marching_counters", C.c_int, vp, vp)
     sig("mlsgpu_hip_marching_tables", C.c_int, vp, vp, vp, vp, vp)
     sig("mlsgpu_hip_marching_copy_slice", C.c_int, vp, vp, u64, u32, u32, u32, u32, u32)

@@ -357,6 +357,8 @@ MLSGPU_API int mlsgpu_hip_worker_create(mlsgpu_ctx *ctx, const mlsgpu_worker_con
     /* depth padded to the MLS block size so that the default maxSwathe (whole bucket) is not rounded DOWN
      * to a multiple of 8 below the bucket depth (src/marching.cpp:373), which would cost a second swathe */
     if (rc == MLSGPU_OK) rc = mlsgpu_hip_marching_create(ctx, block, block, roundUp(block, 8), c.maxSwathe, c.meshMemory, wgs, &w->marching);
+    if (rc == MLSGPU_OK)
+        rc = mlsgpu_hip_marching_set_vertex_transform(w->marching, 1, c.gridSpacing, c.gridOrigin[0], c.gridOrigin[1], c.gridOrigin[2]);
     if (rc != MLSGPU_OK)
     {
         mlsgpu_hip_worker_destroy(w);
@@ -382,8 +384,7 @@ static int workerOutput(void *user, void *stream, const mlsgpu_mesh *mesh)
 {
     mlsgpu_worker *w = static_cast<mlsgpu_worker *>(user);
     const mlsgpu_worker_config &c = w->cfg;
-    if (mlsgpu_hip_scale_bias(w->ctx, mesh, c.gridSpacing, c.gridOrigin[0], c.gridOrigin[1], c.gridOrigin[2]) != MLSGPU_OK)
-        return 1;
+    (void) c;   /* scale/bias is folded into Marching's vertex emission (mlsgpu_hip_marching_set_vertex_transform) */
     if (w->userOutput)
         return w->userOutput(w->userOutputData, stream, mesh);
     return 0;

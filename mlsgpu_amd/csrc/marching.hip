@@ -321,6 +321,14 @@ __global__ __launch_bounds__(256) void sliceHistogramKernel(CodeView C, uint32_t
         histogram[z] = make_uint2(sv[0] + sv[1] + sv[2] + sv[3], si[0] + si[1] + si[2] + si[3]);
 }
 
+/* ScaleBiasFilter (kernels/scale_bias.cl:33-41) folded into vertex emission: v = fma(v, scale, bias).
+ * Same operation on the same rounded value as the separate in-place pass, one HBM round trip less. */
+struct VertexTransform
+{
+    float scale, bx, by, bz;
+    int enabled;
+};
+
 /* Layout of the compact sort key: [ext][z2 : bz][y2 : by][x2 : bx], order-isomorphic to the
  * reference's 64-bit key (kernels/marching.cl:148-154) for coordinates that fit the field widths. */
 struct KeyLayout
@@ -418,6 +426,7 @@ struct CompactVerticesOut
     uint32_t zMax2;              /* 2 * zMax: keys with z >= this are external (src/marching.cpp:593) */
     uint64_t keyOffset;
     uint64_t n;
+    VertexTransform X;
 
     __device__ __forceinline__ bool isExternal(K key) const
     {
@@ -431,7 +440,13 @@ struct CompactVerticesOut
         const uint32_t orig = order[i];
         if (isLast)
         {
-            const float4 v = inVertices[orig];
+            float4 v = inVertices[orig];
+            if (X.enabled)
+            {
+                v.x = fmaf(v.x, X.scale, X.bx);
+                v.y = fmaf(v.y, X.scale, X.by);
+                v.z = fmaf(v.z, X.scale, X.bz);
+            }
             outVertices[3 * (uint64_t) u + 0] = v.x;
             outVertices[3 * (uint64_t) u + 1] = v.y;
             outVertices[3 * (uint64_t) u + 2] = v.z;
@@ -659,7 +674,7 @@ __global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, 
 /* One wave per row: positions (interp, kernels/marching.cl:130-138) and external keys of the existing points. */
 __global__ __launch_bounds__(256) void latticeVerticesKernel(Lattice L, FieldView F, float *outVertices, uint64_t *outKeys,
                                                              uint32_t gox, uint32_t goy, uint32_t goz,
-                                                             uint64_t keyOffset, uint32_t numRows)
+                                                             uint64_t keyOffset, VertexTransform X, uint32_t numRows)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -699,36 +714,57 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lattice L, FieldVie
         const float iso0 = F.at(cx, rowA), iso1 = F.at(cx + px, rowB);
         const float inv = 1.0f / (iso0 - iso1);
         const float t = iso0 * inv;
-        outVertices[3 * (uint64_t) idx + 0] = fmaf(t, (float) px, (float) (cx + gox));
-        outVertices[3 * (uint64_t) idx + 1] = fmaf(t, (float) py, (float) (cy + goy));
-        outVertices[3 * (uint64_t) idx + 2] = fmaf(t, (float) pz, (float) (cz + goz));
+        float vx = fmaf(t, (float) px, (float) (cx + gox));
+        float vy = fmaf(t, (float) py, (float) (cy + goy));
+        float vz = fmaf(t, (float) pz, (float) (cz + goz));
+        if (X.enabled)
+        {
+            vx = fmaf(vx, X.scale, X.bx);
+            vy = fmaf(vy, X.scale, X.by);
+            vz = fmaf(vz, X.scale, X.bz);
+        }
+        outVertices[3 * (uint64_t) idx + 0] = vx;
+        outVertices[3 * (uint64_t) idx + 1] = vy;
+        outVertices[3 * (uint64_t) idx + 2] = vz;
         if (cls != 0)
             outKeys[idx] = (((uint64_t) z2 << (2 * KEY_AXIS_BITS)) | ((uint64_t) y2 << KEY_AXIS_BITS) | (uint64_t) x2) + keyOffset;
     }
 }
 
 /* One thread per occupied cell: look up the welded index of each of the cell's vertices, then emit its
- * triangles (the index half of generateElements + reindex). */
+ * triangles (the index half of generateElements + reindex).  A block's cells are consecutive in the
+ * compacted list, so their index ranges are one contiguous span of the output: it is assembled in LDS
+ * and written with fully coalesced stores instead of 256 interleaved per-thread runs. */
 __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeView C, DevTables T, const uint2 *cells,
                                                               const uint2 *viStart, uint32_t *indices, uint32_t numCells)
 {
     __shared__ uint32_t sIdx[256][MAX_CELL_VERTICES];
+    __shared__ uint32_t sOut[256 * MAX_CELL_INDICES];
+    __shared__ uint32_t sSpan;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= numCells)
-        return;
-    const uint2 cell = cells[gid];
-    const uint32_t x = cell.x & 0xFFFFu, y = cell.x >> 16, z = cell.y;
-    const uint32_t code = C.at(x, y, z);
-    const ushort2 st = T.start[code], en = T.start[code + 1];
-    const uint32_t nv = en.x - st.x, ni = en.y - st.y;
-    for (uint32_t i = 0; i < nv; i++)
+    const uint32_t blockBase = viStart[blockIdx.x * blockDim.x].y;
+    if (gid < numCells)
     {
-        const uint32_t k = T.key[st.x + i];
-        sIdx[threadIdx.x][i] = L.index(2 * x + (k & 0xFF), 2 * y + ((k >> 8) & 0xFF), 2 * z + (k >> 16));
+        const uint2 cell = cells[gid];
+        const uint32_t x = cell.x & 0xFFFFu, y = cell.x >> 16, z = cell.y;
+        const uint32_t code = C.at(x, y, z);
+        const ushort2 st = T.start[code], en = T.start[code + 1];
+        const uint32_t nv = en.x - st.x, ni = en.y - st.y;
+        for (uint32_t i = 0; i < nv; i++)
+        {
+            const uint32_t k = T.key[st.x + i];
+            sIdx[threadIdx.x][i] = L.index(2 * x + (k & 0xFF), 2 * y + ((k >> 8) & 0xFF), 2 * z + (k >> 16));
+        }
+        const uint32_t local = viStart[gid].y - blockBase;
+        for (uint32_t i = 0; i < ni; i++)
+            sOut[local + i] = sIdx[threadIdx.x][T.data[st.y + i]];
+        if (gid == numCells - 1 || threadIdx.x == blockDim.x - 1)
+            sSpan = local + ni;
     }
-    const uint32_t iStart = viStart[gid].y;
-    for (uint32_t i = 0; i < ni; i++)
-        indices[iStart + i] = sIdx[threadIdx.x][T.data[st.y + i]];
+    __syncthreads();
+    const uint32_t span = sSpan;
+    for (uint32_t k = threadIdx.x; k < span; k += blockDim.x)
+        indices[blockBase + k] = sOut[k];
 }
 
 uint32_t bitsFor(uint32_t maxValue)
@@ -788,6 +824,7 @@ struct mlsgpu_marching
     bool legacyBuffers = true;              /* false: every bucket fits one swathe, sort path never needed */
 
     uint64_t counters[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    VertexTransform transform = {1.0f, 0.0f, 0.0f, 0.0f, 0};
 
     /* per-generate state */
     bool direct = false;                    /* this generate() call uses the lattice weld */
@@ -1017,7 +1054,7 @@ int mlsgpu_marching::weld(uint32_t nv, uint32_t zMax)
         | ((uint64_t) keyOffset[0] << 1);                                   /* src/marching.cpp:594-597 */
     UniqueIn<K> in{sorted.keys, nv};
     CompactVerticesOut<K> outF{sorted.keys, sorted.vals, dVertices, dWelded, dWeldedKeys, dIndexRemap,
-                               &dReadback->firstExternal, layout, 2 * zMax, keyOffsetL, nv};
+                               &dReadback->firstExternal, layout, 2 * zMax, keyOffsetL, nv, transform};
     return exclusiveScan<uint32_t>(ctx, "kernel.marching.compactVertices.time", in, outF, nv, 0u, dTileSums,
                                    &dReadback->numWelded);
 }
@@ -1083,7 +1120,7 @@ int mlsgpu_marching::shipOutLattice(const mlsgpu_swathe &sw, const uint32_t size
         | ((uint64_t) keyOffset[1] << (KEY_AXIS_BITS + 1))
         | ((uint64_t) keyOffset[0] << 1);                                   /* src/marching.cpp:594-597 */
     LAUNCH(ctx, stat, latticeVerticesKernel, dim3(divUp(numRows, 4)), dim3(256),
-           L, view(sw), dWelded, dWeldedKeys, keyOffset[0], keyOffset[1], keyOffset[2], keyOffsetL, numRows);
+           L, view(sw), dWelded, dWeldedKeys, keyOffset[0], keyOffset[1], keyOffset[2], keyOffsetL, transform, numRows);
     /* compact the batch's occupied cells (cell-linear order) with their first index slot, then the triangles */
     const CellRange R{W - 1, H - 1, zTop};
     const uint64_t n = (uint64_t) R.cw * R.ch * (zMax - zTop);
@@ -1301,6 +1338,14 @@ MLSGPU_API int mlsgpu_hip_marching_generate(mlsgpu_marching *m, const mlsgpu_gen
         shipOuts++;
     }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_marching_set_vertex_transform(mlsgpu_marching *m, int enabled, float scale,
+                                                        float bx, float by, float bz)
+{
+    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
+    m->transform = VertexTransform{scale, bx, by, bz, enabled ? 1 : 0};
     return MLSGPU_OK;
 }
 
