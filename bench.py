@@ -10,13 +10,18 @@ splats, multi-bucket stream), the configuration the north_star target is quoted 
 rank streams its own cloud of the same shape (weak scaling, no data-path collective: buckets are
 independent, cross-bucket welding is host work in the reference).
 
-Rank 0 prints ONE JSON line (see README / DESIGN.md "Measurement").
+Per GPU, `--workers` device worker threads (default 2, the reference's --device-threads,
+src/mlsgpu_core.cpp:114) each own a stream, an octree, an MLS functor and a Marching instance and take
+alternate buckets, so one worker's host synchronisations overlap the other's kernels.
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
 """
 import argparse
 import json
 import os
 import sys
 import time
+from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -36,6 +41,7 @@ def parse_args():
     p.add_argument("--dist", default="uniform", choices=["uniform", "shells"])
     p.add_argument("--scale", type=float, default=1.0, help="splat-count scale (debug only; 1.0 = BASELINE size)")
     p.add_argument("--mesh-memory-mb", type=int, default=4096, help="Marching mesh arena per worker")
+    p.add_argument("--workers", type=int, default=2, help="device worker threads per GPU")
     p.add_argument("--variant", type=int, default=0, help="MLS kernel variant: 0 culled, 1 basic")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-timing", action="store_true", help="do not time individual kernels with HIP events")
@@ -60,7 +66,7 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import mlsgpu_amd as m
-    from mlsgpu_amd import synth
+    from mlsgpu_amd import farm, synth
 
     # ---- workload (host side, untimed) ----
     t0 = time.time()
@@ -73,23 +79,35 @@ def main():
     max_cells = max(max(b.num_vertices) for b in buckets) - 1
     setup_s = time.time() - t0
 
-    ctx = m.Context(local_rank)
+    nworkers = max(1, min(args.workers, len(buckets)))
+    ctxs = [m.Context(local_rank) for _ in range(nworkers)]
+    ctx = ctxs[0]
     pristine = m.DeviceBuffer(ctx, array=bucketed)
     work = m.DeviceBuffer(ctx, nbytes=bucketed.nbytes)
-    worker = m.Worker(ctx, max_count, max_cells=max_cells, mesh_memory=args.mesh_memory_mb << 20)
-    worker.set_mls_variant(args.variant)
-    sizes_box = [m.binding.SizeCollector()]
+    workers = [m.Worker(c, max_count, max_cells=max_cells, mesh_memory=args.mesh_memory_mb << 20) for c in ctxs]
+    for w in workers:
+        w.set_mls_variant(args.variant)
+    pool = ThreadPoolExecutor(nworkers)
+    collectors = [m.binding.SizeCollector() for _ in range(nworkers)]
+
+    def run_share(k):
+        # worker k takes buckets k, k + nworkers, ... (ctypes releases the GIL inside the library)
+        w, col = workers[k], collectors[k]
+        for b in farm.worker_share(buckets, k, nworkers):
+            w.process(work, b.first, b.count, b.low, b.num_vertices, collector=col)
+        ctxs[k].synchronize()
 
     def step():
         # The octree build overwrites splat.w with 1/r^2 (kernels/octree.cl:193), so each pass starts from a
         # fresh copy of the resident splats: a device-to-device copy standing where the reference has its
         # host-to-device copy (src/workers.cpp:356-361).  It is inside the timed region.
         work.copy_from(pristine)
-        for b in buckets:
-            worker.process(work, b.first, b.count, b.low, b.num_vertices, collector=sizes_box[0])
+        ctx.synchronize()
+        list(pool.map(run_share, range(nworkers)))
 
     def barrier():
-        ctx.synchronize()
+        for c in ctxs:
+            c.synchronize()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -97,38 +115,57 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.reset_stats()
-    ctx.set_timing(not args.no_timing)
-    sizes_box[0] = m.binding.SizeCollector()
+    collectors[:] = [m.binding.SizeCollector() for _ in range(nworkers)]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    ctx.synchronize()
+    for c in ctxs:
+        c.synchronize()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    ctx.set_timing(False)
-    kernel_stats = ctx.stats()
+    # whole job: MAX of the elapsed time over ranks, SUM of the voxels (each rank ran `steps` passes of its cloud)
+    elapsed, total_voxels, _ = farm.combine(elapsed, voxels * args.steps, dist, "cuda" if dist is not None else None)
 
-    # ---- algorithmic work of the dominant kernel (one instrumented, untimed pass) ----
+    # ---- per-kernel durations: the same `steps` passes once more on ONE worker with HIP events around every
+    # launch.  Kept out of the headline region because with several workers the streams overlap and an event
+    # pair then measures a kernel sharing the GPU, not the kernel; single-worker durations are what the
+    # roofline divides by (and what `rocprofv3 --kernel-trace --stats ... --workers 1` reports). ----
+    kernel_stats = {}
+    if not args.no_timing:
+        ctx.reset_stats()
+        ctx.set_timing(True)
+        for _ in range(args.steps):
+            work.copy_from(pristine)
+            for b in buckets:
+                workers[0].process(work, b.first, b.count, b.low, b.num_vertices, collector=m.binding.SizeCollector())
+        ctx.set_timing(False)
+        kernel_stats = dict(ctx.stats())
+    triangles = sum(c.triangles for c in collectors) // max(args.steps, 1)
+    vertices = sum(c.vertices for c in collectors) // max(args.steps, 1)
+    external = sum(c.external for c in collectors) // max(args.steps, 1)
+    shipouts = sum(c.batches for c in collectors) // max(args.steps, 1)
+
+    # ---- algorithmic work (one instrumented, untimed pass on worker 0) ----
     counters = m.DeviceBuffer(ctx, array=np.zeros(3, np.uint64))
-    worker.set_mls_stats(counters)
+    w0 = workers[0]
+    before = w0.marching_counters()
+    w0.set_mls_stats(counters)
     work.copy_from(pristine)
-    corners = 0
+    corners = entries = 0
     for b in buckets:
-        worker.process(work, b.first, b.count, b.low, b.num_vertices, collector=m.binding.SizeCollector())
+        w0.process(work, b.first, b.count, b.low, b.num_vertices, collector=m.binding.SizeCollector())
+        entries += w0.tree_num_entries()
         corners += int(np.prod([-(-n // 8) * 8 for n in b.num_vertices]))
     ctx.synchronize()
     listed, tests, hits = (int(x) for x in counters.download(np.uint64))
-    worker.set_mls_stats(None)
-    sizes = sizes_box[0]
+    w0.set_mls_stats(None)
+    after = w0.marching_counters()
+    mc = {k: after[k] - before[k] for k in after}
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = world * voxels * args.steps / elapsed / 1e6
+    value = farm.throughput(total_voxels, elapsed)
     result = {
         "metric": "Mvoxels/s evaluated+triangulated",
         "value": round(value, 3),
@@ -149,56 +186,85 @@ def main():
             "voxels_per_step": voxels,
             "bucket_splats_total": len(bucketed),
             "mesh_memory_mb": args.mesh_memory_mb,
+            "device_workers": nworkers,
             "mls_variant": "culled" if args.variant == 0 else "basic",
             "per_rank": "own cloud per rank (seed offset = rank)",
-            "triangles_per_step": sizes.triangles // max(args.steps, 1),
-            "vertices_per_step": sizes.vertices // max(args.steps, 1),
-            "shipouts_per_step": sizes.batches // max(args.steps, 1),
+            "triangles_per_step": triangles,
+            "vertices_per_step": vertices,
+            "shipouts_per_step": shipouts,
             "host_setup_s": round(setup_s, 1),
         },
     }
 
-    # ---- roofline of the dominant kernel, processCorners ----
-    name = "kernel.mls.processCorners.time"
-    if name in kernel_stats and kernel_stats[name][1] > 0:
-        total_ms, launches = kernel_stats[name]
-        per_step_ms = total_ms / args.steps
-        # MLS bytes = 36*SigmaL + 4*V, flops = 10*512*SigmaL + 25*H  (per step, all buckets)
-        alg_bytes = 36 * listed + 4 * corners
-        alg_flops = 10 * 512 * listed + 25 * hits
-        done_flops = 10 * tests + 25 * hits          # distance tests actually executed after sub-block culling
-        achieved = alg_bytes / (per_step_ms * 1e-3) / 1e9
+    # ---- roofline: algorithmic bytes over HIP-event kernel time, per stage ----
+    if kernel_stats and not args.no_timing:
+        K = args.steps
+        T, O, Vw, C = 3 * triangles, mc["occupied"], vertices, voxels
+        sort_passes = 2       # 17 key bits at <= 10 bits per pass
+        models = {
+            # stat name: (kernel, algorithmic bytes per step)
+            "kernel.mls.processCorners.time": ("processCorners", 36 * listed + 4 * corners),
+            "kernel.octree.sort.time": ("sortHist+sortScatter (octree entries)", sort_passes * 20 * entries),
+            "kernel.octree.writeEntries.time": ("writeEntries (count+scan+write)", 3 * 16 * len(bucketed) + 8 * entries),
+            "kernel.octree.scan.time": ("countCommands+scan+writeSplatIds", 2 * 4 * entries + 8 * entries + 4 * entries),
+            "kernel.marching.generateElements.time": ("latticeTriangles", 4 * T + 16 * O + O),
+            "kernel.marching.compactVertices.time": ("latticeVertices", 12 * Vw + 8 * external + 8 * Vw),
+            "kernel.marching.countUniqueVertices.time": ("latticeMask", C + 8 * 12 * (corners // 64)),
+            "kernel.marching.genOccupied.time": ("cellCode+classify", 4 * corners + C + C),
+        }
+        stages = []
+        for stat, (kname, nbytes) in models.items():
+            if stat in kernel_stats and kernel_stats[stat][1] > 0:
+                ms = kernel_stats[stat][0] / K
+                stages.append({"stat": stat, "kernel": kname, "ms_per_step": round(ms, 3),
+                               "launches_per_step": kernel_stats[stat][1] // K,
+                               "algorithmic_bytes_per_step": int(nbytes),
+                               "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1)})
+        stages.sort(key=lambda s: -s["ms_per_step"])
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and stages:
             try:
                 tj = json.load(open(tpath))
-                traffic = tj.get("%s/%s" % (args.workload, args.dist), {}).get("processCorners_bytes_per_launch")
+                traffic = tj.get("%s/%s" % (args.workload, args.dist), {}).get(stages[0]["kernel"])
             except Exception:
                 traffic = None
-        result["roofline"] = {
-            "kernel": "processCorners",
-            "bound": "hbm",
-            "achieved": round(achieved, 2),
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5),
-            "traffic": traffic,
-            "launches_per_step": launches // args.steps,
-            "avg_launch_ms": round(total_ms / launches, 4),
-            "share_of_step": round(per_step_ms / ms_per_step, 3),
-            "algorithmic_bytes_per_step": alg_bytes,
-            "note": "processCorners is fp32-VALU/LDS bound, not HBM bound (SURVEY 8d); see valu",
-            "valu": {
-                "unit": "TFLOP/s",
-                "peak": FP32_VALU_PEAK_TFLOPS,
-                "reference_algorithm": round(alg_flops / (per_step_ms * 1e-3) / 1e12, 3),
-                "executed": round(done_flops / (per_step_ms * 1e-3) / 1e12, 3),
-                "frac_executed": round(done_flops / (per_step_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4),
+        single_ms = sum(v[0] for k, v in kernel_stats.items() if k == "device.compute") / K
+        if stages:
+            top = stages[0]
+            total_ms, launches = kernel_stats[top["stat"]]
+            result["roofline"] = {
+                "kernel": top["kernel"],
+                "bound": "hbm",
+                "achieved": top["achieved_GBps"],
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(top["achieved_GBps"] / HBM_PEAK_GBS, 5),
+                "traffic": traffic,
+                "avg_launch_ms": round(total_ms / launches, 4),
+                "launches_per_step": launches // K,
+                "algorithmic_bytes_per_launch": int(top["algorithmic_bytes_per_step"] // max(launches // K, 1)),
+                "share_of_kernel_time": round(top["ms_per_step"] / sum(s["ms_per_step"] for s in stages), 3),
+                "measured": "hipEvent pairs on the worker stream, %d single-worker passes after the timed region "
+                            "(%.1f ms per pass)" % (K, single_ms),
+                "stages": stages,
+            }
+        pc = "kernel.mls.processCorners.time"
+        if pc in kernel_stats and kernel_stats[pc][1] > 0:
+            ms = kernel_stats[pc][0] / K
+            # flops = 10*512*SigmaL + 25*H for the reference algorithm; "executed" counts the
+            # distance tests that survive sub-block culling
+            result["processCorners_valu"] = {
+                "unit": "TFLOP/s", "peak": FP32_VALU_PEAK_TFLOPS,
+                "reference_algorithm": round((10 * 512 * listed + 25 * hits) / (ms * 1e-3) / 1e12, 3),
+                "executed": round((10 * tests + 25 * hits) / (ms * 1e-3) / 1e12, 3),
+                "frac_executed": round((10 * tests + 25 * hits) / (ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4),
                 "sigma_L": listed, "tests": tests, "hits": hits, "corners": corners,
-            },
-        }
-        result["kernel_ms_per_step"] = {k: round(v[0] / args.steps, 3) for k, v in sorted(kernel_stats.items())}
+                "note": "fp32-VALU/LDS bound (SURVEY 8d), not an HBM kernel",
+            }
+        result["kernel_ms_per_step"] = {k: round(v[0] / K, 3) for k, v in sorted(kernel_stats.items())}
+        result["work_per_step"] = {"octree_entries": entries, "occupied_cells": O, "unwelded_vertices": mc["unwelded"],
+                                   "welded_vertices": Vw, "external_vertices": external, "indices": T}
 
     # ---- CPU baseline: the oracle ("port") on a bounded sample, rank 0 at N = 1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -232,6 +298,7 @@ def main():
 
     if rank == 0:
         print(json.dumps(result))
+    pool.shutdown()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -139,6 +139,8 @@ uint64_t mlsgpu_hip_tree_resource_usage(uint64_t maxLevels, uint64_t maxSplats);
 int mlsgpu_hip_tree_build(mlsgpu_tree *tree, mlsgpu_splat *dSplats, uint64_t firstSplat, uint64_t numSplats,
                           const uint32_t size[3], const int32_t offset[3], uint32_t subsamplingShift);
 void mlsgpu_hip_tree_clear_splats(mlsgpu_tree *tree);
+/* Measurement aid: (splat, node) entries of the last build (synchronises the stream). */
+int mlsgpu_hip_tree_num_entries(mlsgpu_tree *tree, uint64_t *out);
 const mlsgpu_splat *mlsgpu_hip_tree_splats(const mlsgpu_tree *tree);   /* getSplats   */
 const int32_t *mlsgpu_hip_tree_commands(const mlsgpu_tree *tree);      /* getCommands */
 const int32_t *mlsgpu_hip_tree_start(const mlsgpu_tree *tree);         /* getStart    */

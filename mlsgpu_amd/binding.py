@@ -108,6 +108,7 @@ def lib():
     sig("mlsgpu_hip_tree_resource_usage", u64, u64, u64)
     sig("mlsgpu_hip_tree_build", C.c_int, vp, vp, u64, u64, vp, vp, u32)
     sig("mlsgpu_hip_tree_clear_splats", None, vp)
+    sig("mlsgpu_hip_tree_num_entries", C.c_int, vp, P(u64))
     sig("mlsgpu_hip_tree_splats", vp, vp)
     sig("mlsgpu_hip_tree_commands", vp, vp)
     sig("mlsgpu_hip_tree_start", vp, vp)
@@ -539,6 +540,11 @@ class Worker:
         check(lib().mlsgpu_hip_marching_counters(lib().mlsgpu_hip_worker_marching(self.h), _p(out)))
         names = ["overflows", "shipouts", "nonempty", "occupied", "unwelded", "indices", "welded", "external"]
         return dict(zip(names, [int(x) for x in out]))
+
+    def tree_num_entries(self):
+        n = C.c_uint64()
+        check(lib().mlsgpu_hip_tree_num_entries(lib().mlsgpu_hip_worker_tree(self.h), C.byref(n)))
+        return n.value
 
     def tree_arrays(self):
         t = lib().mlsgpu_hip_worker_tree(self.h)

@@ -31,7 +31,7 @@ struct mlsgpu_tree
     uint32_t numLevels = 0;
     int32_t *dStart = nullptr, *dJumpPos = nullptr, *dCommands = nullptr;
     uint32_t *dKeysA = nullptr, *dKeysB = nullptr, *dValsA = nullptr, *dValsB = nullptr;
-    uint32_t *dHist = nullptr, *dTileSums = nullptr;
+    uint32_t *dHist = nullptr, *dTileSums = nullptr, *dNumEntries = nullptr;
     mlsgpu_splat *dSplats = nullptr;   /* borrowed between build and clear_splats */
 };
 
@@ -95,65 +95,103 @@ __device__ __forceinline__ int floorToInt(float v)
     return (int) f;
 }
 
-/* writeEntries, kernels/octree.cl:159-214.  One thread per splat; 8 (key, id) entries per splat written
- * as two 16-byte stores per array.  Replaces splat.w by 1/r^2 (:193). */
-__global__ __launch_bounds__(256) void writeEntriesKernel(uint32_t *keys, uint32_t *values, mlsgpu_splat *splats,
-                                                          int bx, int by, int bz, LevelOffsets levelOffsets,
-                                                          int minShift, int maxShift, uint32_t firstSplat,
-                                                          uint32_t numSplats)
+/* The per-splat part of writeEntries, kernels/octree.cl:159-214 (+prepare :79-90, goodEntry :100-110):
+ * the up-to-8 sort keys of one splat; returns the bit mask of the slots that hold a real entry
+ * (the reference writes UINT_MAX into the others). */
+struct EntryParams
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= numSplats)
-        return;
-    const uint32_t gid = i + firstSplat;
-    float4 *sp = reinterpret_cast<float4 *>(splats + gid);
-    const float4 pr = sp[0];
+    mlsgpu_splat *splats;
+    int bx, by, bz;
+    LevelOffsets levelOffsets;
+    int minShift, maxShift;
+    uint32_t firstSplat;
+};
+
+__device__ __forceinline__ uint32_t splatEntries(const EntryParams &P, const float4 pr, uint32_t k[8])
+{
     /* prepare, octree.cl:79-90 */
     const int lox = floorToInt(pr.x - pr.w), loy = floorToInt(pr.y - pr.w), loz = floorToInt(pr.z - pr.w);
     const int hix = floorToInt(pr.x + pr.w), hiy = floorToInt(pr.y + pr.w), hiz = floorToInt(pr.z + pr.w);
     int shift = levelShift(lox, loy, loz, hix, hiy, hiz);
-    shift = min(max(shift, minShift), maxShift);
-    const int ilx = max(lox - bx, 0) >> shift;
-    const int ily = max(loy - by, 0) >> shift;
-    const int ilz = max(loz - bz, 0) >> shift;
-
+    shift = min(max(shift, P.minShift), P.maxShift);
+    const int ilx = max(lox - P.bx, 0) >> shift;
+    const int ily = max(loy - P.by, 0) >> shift;
+    const int ilz = max(loz - P.bz, 0) >> shift;
     float radius2 = pr.w * pr.w;
-    reinterpret_cast<float *>(sp)[3] = 1.0f / radius2;
     radius2 *= 1.00001f;
-    const uint32_t levelOffset = levelOffsets.v[shift];
-    const int bound = 1 << (maxShift - shift);
-    uint32_t k[8];
+    const uint32_t levelOffset = P.levelOffsets.v[shift];
+    const int bound = 1 << (P.maxShift - shift);
+    uint32_t mask = 0;
 #pragma unroll
     for (int o = 0; o < 8; o++)
     {
         const int ax = ilx + (o & 1), ay = ily + ((o >> 1) & 1), az = ilz + (o >> 2);
         /* goodEntry, octree.cl:100-110; int arithmetic wraps like OpenCL's */
-        const int blx = (int) ((uint32_t) ax << shift) + bx, bhx = (int) ((uint32_t) (ax + 1) << shift) + bx;
-        const int bly = (int) ((uint32_t) ay << shift) + by, bhy = (int) ((uint32_t) (ay + 1) << shift) + by;
-        const int blz = (int) ((uint32_t) az << shift) + bz, bhz = (int) ((uint32_t) (az + 1) << shift) + bz;
+        const int blx = (int) ((uint32_t) ax << shift) + P.bx, bhx = (int) ((uint32_t) (ax + 1) << shift) + P.bx;
+        const int bly = (int) ((uint32_t) ay << shift) + P.by, bhy = (int) ((uint32_t) (ay + 1) << shift) + P.by;
+        const int blz = (int) ((uint32_t) az << shift) + P.bz, bhz = (int) ((uint32_t) (az + 1) << shift) + P.bz;
         bool isect = pointBoxDist2(pr.x, pr.y, pr.z, (float) blx, (float) bly, (float) blz,
                                    (float) bhx, (float) bhy, (float) bhz) < radius2;
         isect = isect && ax < bound && ay < bound && az < bound;
         /* inside the bounds the coordinates fit 10 bits (maxShift - shift <= 9 levels) */
-        k[o] = isect ? makeCode(ax, ay, az) + levelOffset : 0xFFFFFFFFu;
+        k[o] = makeCode(ax, ay, az) + levelOffset;
+        mask |= (isect ? 1u : 0u) << o;
     }
-    uint4 *kp = reinterpret_cast<uint4 *>(keys + (uint64_t) i * 8);
-    uint4 *vp = reinterpret_cast<uint4 *>(values + (uint64_t) i * 8);
-    kp[0] = make_uint4(k[0], k[1], k[2], k[3]);
-    kp[1] = make_uint4(k[4], k[5], k[6], k[7]);
-    vp[0] = make_uint4(gid, gid, gid, gid);
-    vp[1] = make_uint4(gid, gid, gid, gid);
+    return mask;
 }
+
+/*
+ * writeEntries as a compaction: the reference writes 8 (key, id) slots per splat and lets the UINT_MAX
+ * ones sort to the end, where writeSplatIds ignores them (kernels/octree.cl:263).  Here only the real
+ * entries are written, densely, in the same (splat, slot) order -- a stable sort of the survivors gives
+ * exactly the order the padded array would have had before its UINT_MAX tail, so `commands` and `start`
+ * are unchanged while sort, scan and writeSplatIds touch about half the data.
+ * Producer: number of real entries of splat i.  Consumer: writes them at the scanned position and
+ * replaces splat.w by 1/r^2 (:193).
+ */
+struct EntryCountIn
+{
+    EntryParams P;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const
+    {
+        const float4 pr = reinterpret_cast<const float4 *>(P.splats + (i + P.firstSplat))[0];
+        uint32_t k[8];
+        return (uint32_t) __popc(splatEntries(P, pr, k));
+    }
+};
+
+struct EntryWriteOut
+{
+    EntryParams P;
+    uint32_t *keys, *values;
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t pos, uint32_t) const
+    {
+        const uint32_t gid = (uint32_t) i + P.firstSplat;
+        float4 *sp = reinterpret_cast<float4 *>(P.splats + gid);
+        const float4 pr = sp[0];
+        uint32_t k[8];
+        const uint32_t mask = splatEntries(P, pr, k);
+        reinterpret_cast<float *>(sp)[3] = 1.0f / (pr.w * pr.w);
+#pragma unroll
+        for (int o = 0; o < 8; o++)
+            if (mask & (1u << o))
+            {
+                keys[pos] = k[o];
+                values[pos] = gid;
+                pos++;
+            }
+    }
+};
 
 /* countCommands (kernels/octree.cl:230-239) as the scan's producer.  The reference leaves the
  * last indicator unwritten; an exclusive scan never reads it, so any value serves. */
 struct IndicatorIn
 {
     const uint32_t *keys;
-    uint64_t n;
+    const uint32_t *n;          /* number of entries, on the device */
     __device__ __forceinline__ uint32_t operator()(uint64_t i) const
     {
-        if (i + 1 >= n)
+        if (i + 1 >= *n)
             return 1u;
         return keys[i] != keys[i + 1] ? 3u : 1u;
     }
@@ -164,7 +202,7 @@ struct SplatIdsOut
 {
     int32_t *commands, *start, *jumpPos;
     const uint32_t *keys, *ids;
-    uint64_t n;
+    const uint32_t *n;
     __device__ __forceinline__ void operator()(uint64_t pos, uint32_t cpos, uint32_t) const
     {
         const uint32_t curKey = keys[pos];
@@ -172,7 +210,7 @@ struct SplatIdsOut
         {
             commands[cpos] = (int32_t) ids[pos];
             const uint32_t prevKey = pos > 0 ? keys[pos - 1] : 0xFFFFFFFFu;
-            const uint32_t nextKey = pos < n - 1 ? keys[pos + 1] : 0xFFFFFFFFu;
+            const uint32_t nextKey = pos + 1 < *n ? keys[pos + 1] : 0xFFFFFFFFu;
             if (prevKey != curKey)
                 start[curKey] = (int32_t) (cpos - 1);
             if (curKey != nextKey)
@@ -303,6 +341,7 @@ MLSGPU_API int mlsgpu_hip_tree_create(mlsgpu_ctx *ctx, uint64_t maxLevels, uint6
     alloc((void **) &t->dValsB, entries * 4);
     alloc((void **) &t->dHist, histElems * 4);
     alloc((void **) &t->dTileSums, tileSums * 4);
+    alloc((void **) &t->dNumEntries, 4);
     if (rc != MLSGPU_OK)
     {
         mlsgpu_hip_tree_destroy(t);
@@ -319,7 +358,7 @@ MLSGPU_API void mlsgpu_hip_tree_destroy(mlsgpu_tree *t)
     hipSetDevice(t->ctx->device);
     hipFree(t->dStart); hipFree(t->dJumpPos); hipFree(t->dCommands);
     hipFree(t->dKeysA); hipFree(t->dKeysB); hipFree(t->dValsA); hipFree(t->dValsB);
-    hipFree(t->dHist); hipFree(t->dTileSums);
+    hipFree(t->dHist); hipFree(t->dTileSums); hipFree(t->dNumEntries);
     delete t;
 }
 
@@ -358,24 +397,37 @@ MLSGPU_API int mlsgpu_hip_tree_build(mlsgpu_tree *t, mlsgpu_splat *dSplats, uint
         HIP_CHECK(hipMemsetAsync(t->dJumpPos, 0xFF, (size_t) numStart * 4, ctx->stream));
         if (pend >= 0) ctx->endTiming(pend);
     }
-    const uint64_t numEntries = numSplats * 8;
+    const uint64_t maxEntries = numSplats * 8;
     if (numSplats > 0)
     {
-        LAUNCH(ctx, "kernel.octree.writeEntries.time", writeEntriesKernel, dim3(divUp(numSplats, 256)), dim3(256),
-               t->dKeysA, t->dValsA, dSplats, offset[0], offset[1], offset[2], lo, minShift, maxShift,
-               (uint32_t) firstSplat, (uint32_t) numSplats);
+        EntryParams P{dSplats, offset[0], offset[1], offset[2], lo, minShift, maxShift, (uint32_t) firstSplat};
+        /* writeEntries: count, scan, write compacted; the entry count stays on the device (t->dNumEntries) */
+        PROPAGATE((exclusiveScan<uint32_t>(ctx, "kernel.octree.writeEntries.time", EntryCountIn{P},
+                                           EntryWriteOut{P, t->dKeysA, t->dValsA}, numSplats, 0u,
+                                           t->dTileSums, t->dNumEntries)));
         SortResult<uint32_t> sorted;
         PROPAGATE(radixSort<uint32_t>(ctx, "kernel.octree.sort.time", t->dKeysA, t->dValsA, t->dKeysB, t->dValsB,
-                                      numEntries, (uint32_t) (3 * (maxShift - minShift) + 1), false,
-                                      t->dHist, t->dTileSums, &sorted));
+                                      maxEntries, (uint32_t) (3 * (maxShift - minShift) + 1), false,
+                                      t->dHist, t->dTileSums, &sorted, t->dNumEntries));
         /* countCommands + scan(seed 1) + writeSplatIds, src/splat_tree_cl.cpp:310-317 */
-        IndicatorIn in{sorted.keys, numEntries};
-        SplatIdsOut outF{t->dCommands, t->dStart, t->dJumpPos, sorted.keys, sorted.vals, numEntries};
-        PROPAGATE((exclusiveScan<uint32_t>(ctx, "kernel.octree.scan.time", in, outF, numEntries, 1u,
-                                           t->dTileSums, (uint32_t *) nullptr)));
+        IndicatorIn in{sorted.keys, t->dNumEntries};
+        SplatIdsOut outF{t->dCommands, t->dStart, t->dJumpPos, sorted.keys, sorted.vals, t->dNumEntries};
+        PROPAGATE((exclusiveScan<uint32_t>(ctx, "kernel.octree.scan.time", in, outF, maxEntries, 1u,
+                                           t->dTileSums, (uint32_t *) nullptr, t->dNumEntries)));
     }
     LAUNCH(ctx, "kernel.octree.writeStart.time", writeStartKernel, dim3(divUp(numStart, 256)), dim3(256),
            t->dStart, t->dCommands, (const int32_t *) t->dJumpPos, lo, minShift, maxShift, numStart);
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_tree_num_entries(mlsgpu_tree *t, uint64_t *out)
+{
+    REQUIRE(t != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(t->ctx->device));
+    uint32_t n = 0;
+    HIP_CHECK(hipMemcpyAsync(&n, t->dNumEntries, 4, hipMemcpyDeviceToHost, t->ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(t->ctx->stream));
+    *out = n;
     return MLSGPU_OK;
 }
 

@@ -65,8 +65,10 @@ __device__ __forceinline__ U3 readLaneT(U3 v, int lane)
 
 /* tileSums[b] = sum of in(i) over tile b */
 template<typename T, typename In>
-__global__ __launch_bounds__(PRIM_BLOCK) void scanReduceKernel(In in, T *tileSums, uint64_t n)
+__global__ __launch_bounds__(PRIM_BLOCK) void scanReduceKernel(In in, T *tileSums, uint64_t n, const uint32_t *nDev)
 {
+    if (nDev != nullptr && *nDev < n)
+        n = *nDev;      /* element count produced on the device; the grid covers the upper bound */
     __shared__ T waveTotals[PRIM_WAVES];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t base = (uint64_t) blockIdx.x * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
@@ -126,8 +128,10 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanTileSumsKernel(T *tileSums, ui
 
 /* out(i, exclusivePrefix(i), in(i)) for every i < n; tileSums already scanned */
 template<typename T, typename In, typename Out>
-__global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(In in, Out out, const T *tileSums, uint64_t n)
+__global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(In in, Out out, const T *tileSums, uint64_t n, const uint32_t *nDev)
 {
+    if (nDev != nullptr && *nDev < n)
+        n = *nDev;
     __shared__ T waveTotals[PRIM_WAVES];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t base = (uint64_t) blockIdx.x * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
@@ -166,31 +170,33 @@ static inline uint32_t scanTiles(uint64_t n) { return divUp(n, PRIM_TILE); }
 #ifdef __HIPCC__
 /* Phase 1: tile sums of in() scanned from `seed`; grand total (incl. seed) to *dTotal (may be null). */
 template<typename T, typename In>
-static int scanPhase1(mlsgpu_ctx *ctx, const char *statName, In in, uint64_t n, T seed, T *dTileSums, T *dTotal)
+static int scanPhase1(mlsgpu_ctx *ctx, const char *statName, In in, uint64_t n, T seed, T *dTileSums, T *dTotal,
+                      const uint32_t *nDev = nullptr)
 {
     const uint32_t tiles = scanTiles(n);
     if (tiles > 0)
-        LAUNCH(ctx, statName, (scanReduceKernel<T, In>), dim3(tiles), dim3(PRIM_BLOCK), in, dTileSums, n);
+        LAUNCH(ctx, statName, (scanReduceKernel<T, In>), dim3(tiles), dim3(PRIM_BLOCK), in, dTileSums, n, nDev);
     LAUNCH(ctx, statName, (scanTileSumsKernel<T>), dim3(1), dim3(PRIM_BLOCK), dTileSums, tiles, seed, dTotal);
     return MLSGPU_OK;
 }
 
 /* Phase 2: out(i, exclusivePrefix(i), in(i)) for all i, using the tile sums of phase 1. */
 template<typename T, typename In, typename Out>
-static int scanPhase2(mlsgpu_ctx *ctx, const char *statName, In in, Out out, uint64_t n, const T *dTileSums)
+static int scanPhase2(mlsgpu_ctx *ctx, const char *statName, In in, Out out, uint64_t n, const T *dTileSums,
+                      const uint32_t *nDev = nullptr)
 {
     const uint32_t tiles = scanTiles(n);
     if (tiles > 0)
-        LAUNCH(ctx, statName, (scanApplyKernel<T, In, Out>), dim3(tiles), dim3(PRIM_BLOCK), in, out, dTileSums, n);
+        LAUNCH(ctx, statName, (scanApplyKernel<T, In, Out>), dim3(tiles), dim3(PRIM_BLOCK), in, out, dTileSums, n, nDev);
     return MLSGPU_OK;
 }
 
 template<typename T, typename In, typename Out>
 static int exclusiveScan(mlsgpu_ctx *ctx, const char *statName, In in, Out out, uint64_t n, T seed,
-                         T *dTileSums, T *dTotal)
+                         T *dTileSums, T *dTotal, const uint32_t *nDev = nullptr)
 {
-    PROPAGATE((scanPhase1<T, In>(ctx, statName, in, n, seed, dTileSums, dTotal)));
-    return scanPhase2<T, In, Out>(ctx, statName, in, out, n, (const T *) dTileSums);
+    PROPAGATE((scanPhase1<T, In>(ctx, statName, in, n, seed, dTileSums, dTotal, nDev)));
+    return scanPhase2<T, In, Out>(ctx, statName, in, out, n, (const T *) dTileSums, nDev);
 }
 
 /* plain array in / array out functors */
@@ -211,8 +217,11 @@ struct ArrayOut
 
 template<typename K>
 __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(const K *keys, uint32_t *hist, uint64_t n,
-                                                             uint32_t shift, uint32_t digitBits, uint32_t numTiles)
+                                                             uint32_t shift, uint32_t digitBits, uint32_t numTiles,
+                                                             const uint32_t *nDev)
 {
+    if (nDev != nullptr && *nDev < n)
+        n = *nDev;
     __shared__ uint32_t bins[SORT_MAX_BINS];
     const uint32_t numBins = 1u << digitBits;
     const K mask = (K) (numBins - 1);
@@ -238,8 +247,11 @@ template<typename K, bool IOTA>
 __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn, const uint32_t *valsIn,
                                                                 K *keysOut, uint32_t *valsOut,
                                                                 const uint32_t *hist, uint64_t n,
-                                                                uint32_t shift, uint32_t digitBits, uint32_t numTiles)
+                                                                uint32_t shift, uint32_t digitBits, uint32_t numTiles,
+                                                                const uint32_t *nDev)
 {
+    if (nDev != nullptr && *nDev < n)
+        n = *nDev;
     __shared__ uint32_t waveBins[PRIM_WAVES][SORT_MAX_BINS];
     const uint32_t numBins = 1u << digitBits;
     const K mask = (K) (numBins - 1);
@@ -324,7 +336,7 @@ static inline uint64_t sortHistElems(uint64_t n) { return (uint64_t) SORT_MAX_BI
 template<typename K>
 static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *valsA, K *keysB, uint32_t *valsB,
                      uint64_t n, uint32_t bits, bool iota, uint32_t *dHist, uint32_t *dTileSums,
-                     SortResult<K> *result)
+                     SortResult<K> *result, const uint32_t *nDev = nullptr)
 {
     result->keys = keysA;
     result->vals = valsA;
@@ -343,15 +355,15 @@ static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *
         const uint32_t digitBits = (bits - shift) < perPass ? (bits - shift) : perPass;
         const uint64_t histN = ((uint64_t) 1 << digitBits) * tiles;
         LAUNCH(ctx, statName, (sortHistKernel<K>), dim3(tiles), dim3(PRIM_BLOCK),
-               (const K *) kin, dHist, n, shift, digitBits, tiles);
+               (const K *) kin, dHist, n, shift, digitBits, tiles, nDev);
         PROPAGATE((exclusiveScan<uint32_t>(ctx, statName, ArrayIn<uint32_t>{dHist}, ArrayOut<uint32_t>{dHist},
                                            histN, 0u, dTileSums, (uint32_t *) nullptr)));
         if (iota && p == 0)
             LAUNCH(ctx, statName, (sortScatterKernel<K, true>), dim3(tiles), dim3(PRIM_BLOCK),
-                   (const K *) kin, (const uint32_t *) vin, kout, vout, (const uint32_t *) dHist, n, shift, digitBits, tiles);
+                   (const K *) kin, (const uint32_t *) vin, kout, vout, (const uint32_t *) dHist, n, shift, digitBits, tiles, nDev);
         else
             LAUNCH(ctx, statName, (sortScatterKernel<K, false>), dim3(tiles), dim3(PRIM_BLOCK),
-                   (const K *) kin, (const uint32_t *) vin, kout, vout, (const uint32_t *) dHist, n, shift, digitBits, tiles);
+                   (const K *) kin, (const uint32_t *) vin, kout, vout, (const uint32_t *) dHist, n, shift, digitBits, tiles, nDev);
         shift += digitBits;
         K *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
