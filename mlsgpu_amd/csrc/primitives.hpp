@@ -242,7 +242,21 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(const K *keys, uint
         hist[(uint64_t) d * numTiles + blockIdx.x] = bins[d];
 }
 
-/* hist has been exclusively scanned over the (digit-major, tile-minor) sequence. */
+/* Largest digit a key type can be sorted by per pass: bounded by the LDS the scatter kernel needs
+ * (tile of keys + values, per-wave bins).  64 KB of static LDS per workgroup. */
+template<typename K> struct SortCaps { enum { MAX_DIGIT_BITS = sizeof(K) == 8 ? 9 : SORT_MAX_DIGIT_BITS }; };
+
+/*
+ * Scatter pass.  hist has been exclusively scanned over the (digit-major, tile-minor) sequence, so
+ * hist[d][tile] is where this tile's keys with digit d start in the output.
+ *   1. per-wave digit counts (LDS atomics);
+ *   2. tile-local start of every digit (block scan over the bins) and of every (wave, digit);
+ *   3. stable rank of each key among the keys of its wave with the same digit, by wave64 ballots
+ *      (one __ballot per digit bit gives the peer mask, mbcnt the rank), rounds in order: the key's
+ *      position inside the TILE-LOCALLY SORTED sequence;
+ *   4. the tile is assembled in that order in LDS and copied out by consecutive threads, so each
+ *      digit's run leaves as one contiguous, coalesced burst instead of 64 scattered dwords per store.
+ */
 template<typename K, bool IOTA>
 __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn, const uint32_t *valsIn,
                                                                 K *keysOut, uint32_t *valsOut,
@@ -250,9 +264,18 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn,
                                                                 uint32_t shift, uint32_t digitBits, uint32_t numTiles,
                                                                 const uint32_t *nDev)
 {
+    enum { BINS = 1 << SortCaps<K>::MAX_DIGIT_BITS };
+    __shared__ uint32_t waveBins[PRIM_WAVES][BINS];
+    __shared__ uint32_t tileBase[BINS];        /* global start of the digit minus its tile-local start */
+    __shared__ uint32_t waveTotals[PRIM_WAVES];
+    __shared__ K sKeys[PRIM_TILE];
+    __shared__ uint32_t sVals[PRIM_TILE];
     if (nDev != nullptr && *nDev < n)
         n = *nDev;
-    __shared__ uint32_t waveBins[PRIM_WAVES][SORT_MAX_BINS];
+    const uint64_t tileFirst = (uint64_t) blockIdx.x * PRIM_TILE;
+    if (tileFirst >= n)
+        return;
+    const uint32_t tileCount = (uint32_t) (n - tileFirst < PRIM_TILE ? n - tileFirst : PRIM_TILE);
     const uint32_t numBins = 1u << digitBits;
     const K mask = (K) (numBins - 1);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -263,7 +286,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn,
             waveBins[w][d] = 0;
     }
     __syncthreads();
-    const uint64_t base = (uint64_t) blockIdx.x * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
+    const uint64_t base = tileFirst + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
     K keys[PRIM_ITEMS];
 #pragma unroll
     for (int j = 0; j < PRIM_ITEMS; j++)
@@ -274,17 +297,36 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn,
             atomicAdd(&waveBins[wave][(uint32_t) ((keys[j] >> shift) & mask)], 1u);
     }
     __syncthreads();
-    /* per digit: global start of this tile, then waves in order */
-    for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
+    /* tile-local exclusive prefix over the digits: thread t owns the `per` consecutive bins from t * per */
     {
-        uint32_t run = hist[(uint64_t) d * numTiles + blockIdx.x];
+        const uint32_t per = numBins > PRIM_BLOCK ? numBins / PRIM_BLOCK : 1;
+        const uint32_t d0 = threadIdx.x * per;
+        uint32_t mine = 0;
+        if (d0 < numBins)
+            for (uint32_t k = 0; k < per; k++)
 #pragma unroll
-        for (int w = 0; w < PRIM_WAVES; w++)
-        {
-            uint32_t c = waveBins[w][d];
-            waveBins[w][d] = run;
-            run += c;
-        }
+                for (int w = 0; w < PRIM_WAVES; w++)
+                    mine += waveBins[w][d0 + k];
+        const uint32_t incl = waveInclusiveScan(mine);
+        if (lane == 63)
+            waveTotals[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - mine;
+        for (uint32_t w = 0; w < wave; w++)
+            run += waveTotals[w];
+        if (d0 < numBins)
+            for (uint32_t k = 0; k < per; k++)
+            {
+                const uint32_t d = d0 + k;
+                tileBase[d] = hist[(uint64_t) d * numTiles + blockIdx.x] - run;
+#pragma unroll
+                for (int w = 0; w < PRIM_WAVES; w++)
+                {
+                    const uint32_t c = waveBins[w][d];
+                    waveBins[w][d] = run;
+                    run += c;
+                }
+            }
     }
     __syncthreads();
     /* stable split of each round: rank among the lanes of the wave holding the same digit */
@@ -305,13 +347,21 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn,
         {
             const uint32_t rank = popcBelow(peers);
             const uint32_t dst = waveBins[wave][digit] + rank;
-            keysOut[dst] = keys[j];
-            valsOut[dst] = IOTA ? (uint32_t) i : valsIn[i];
+            sKeys[dst] = keys[j];
+            sVals[dst] = IOTA ? (uint32_t) i : valsIn[i];
             if (rank == 0)
                 waveBins[wave][digit] = dst + (uint32_t) __popcll(peers);
         }
         /* LDS operations of one wave complete in program order, so the next round sees the update */
         __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < tileCount; p += PRIM_BLOCK)
+    {
+        const K key = sKeys[p];
+        const uint32_t g = tileBase[(uint32_t) ((key >> shift) & mask)] + p;
+        keysOut[g] = key;
+        valsOut[g] = sVals[p];
     }
 }
 
@@ -323,7 +373,7 @@ struct SortResult
     uint32_t *vals;
 };
 
-static inline uint32_t sortPasses(uint32_t bits) { return (bits + SORT_MAX_DIGIT_BITS - 1) / SORT_MAX_DIGIT_BITS; }
+static inline uint32_t sortPasses(uint32_t bits, uint32_t maxDigitBits) { return (bits + maxDigitBits - 1) / maxDigitBits; }
 /* elements of uint32 needed for the histogram of a sort of n keys */
 static inline uint64_t sortHistElems(uint64_t n) { return (uint64_t) SORT_MAX_BINS * scanTiles(n); }
 
@@ -345,7 +395,7 @@ static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *
     const uint32_t tiles = scanTiles(n);
     if (bits == 0)
         bits = 1;    /* still run one pass so that iota values are materialised */
-    const uint32_t passes = sortPasses(bits);
+    const uint32_t passes = sortPasses(bits, SortCaps<K>::MAX_DIGIT_BITS);
     const uint32_t perPass = (bits + passes - 1) / passes;
     uint32_t shift = 0;
     K *kin = keysA, *kout = keysB;
