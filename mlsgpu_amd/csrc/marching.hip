@@ -237,18 +237,44 @@ struct CodeView
     }
 };
 
-__global__ __launch_bounds__(256) void cellCodeKernel(uint8_t *codes, FieldView F, uint32_t cw, uint32_t ch,
-                                                       uint32_t zFirst, uint32_t numCells)
+/* One wave per row of cells (fixed y, z): code bytes plus the row's (occupied, vertices, indices) totals.
+ * The row totals feed the swathe totals, the per-slice histogram and, in the lattice weld, each row's first
+ * cell / index slot -- a 256x smaller scan than one over cells. */
+__global__ __launch_bounds__(256) void cellCodeKernel(uint8_t *codes, U3 *rowCounts, FieldView F, uint32_t cw, uint32_t ch,
+                                                       uint32_t zFirst, uint32_t numRows, const uchar2 *countTable)
 {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= numCells)
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= numRows)
         return;
-    const uint32_t x = i % cw, r = i / cw, y = r % ch, z = r / ch + zFirst;
-    float iso[8];
-    loadIso(F, x, y, z, iso);
-    bool valid;
-    const uint32_t code = cellCode(iso, valid);
-    codes[i] = (valid && code != 255) ? (uint8_t) code : (uint8_t) 0;
+    const uint32_t y = row % ch, z = row / ch + zFirst;
+    U3 sum{0u, 0u, 0u};
+    for (uint32_t x0 = 0; x0 < cw; x0 += 64)
+    {
+        const uint32_t x = x0 + lane;
+        if (x < cw)
+        {
+            float iso[8];
+            loadIso(F, x, y, z, iso);
+            bool valid;
+            uint32_t code = cellCode(iso, valid);
+            if (!valid || code == 255)
+                code = 0;
+            codes[(uint64_t) row * cw + x] = (uint8_t) code;
+            if (code != 0)
+            {
+                const uchar2 c = countTable[code];
+                sum.a += 1;
+                sum.b += c.x;
+                sum.c += c.y;
+            }
+        }
+    }
+    sum.a = waveSum(sum.a);
+    sum.b = waveSum(sum.b);
+    sum.c = waveSum(sum.c);
+    if (lane == 0)
+        rowCounts[row] = sum;
 }
 
 /* ... step 2: the producer of the compaction scan */
@@ -291,34 +317,56 @@ struct CompactCellsOut
     }
 };
 
-/* per-slice (vertices, indices) histogram, only needed by the overflow path (src/marching.cpp:652-701) */
-__global__ __launch_bounds__(256) void sliceHistogramKernel(CodeView C, uint32_t zFirst,
-                                                            const uchar2 *countTable, uint2 *histogram)
+/* per-slice (vertices, indices) histogram, only needed by the overflow path (src/marching.cpp:652-701):
+ * one wave per slice sums that slice's row totals */
+__global__ __launch_bounds__(64) void sliceHistogramKernel(const U3 *rowCounts, uint32_t ch, uint32_t zFirst, uint32_t z0,
+                                                           uint2 *histogram)
 {
-    __shared__ uint32_t sv[4], si[4];
     const uint32_t z = zFirst + blockIdx.x;
     uint32_t v = 0, idx = 0;
-    const uint32_t cells = C.cw * C.ch;
-    for (uint32_t c = threadIdx.x; c < cells; c += 256)
+    for (uint32_t y = threadIdx.x; y < ch; y += 64)
     {
-        const uint32_t code = C.at(c % C.cw, c / C.cw, z);
-        if (code != 0)
-        {
-            const uchar2 n = countTable[code];
-            v += n.x;
-            idx += n.y;
-        }
+        const U3 c = rowCounts[(uint64_t) (z - z0) * ch + y];
+        v += c.b;
+        idx += c.c;
     }
     v = waveSum(v);
     idx = waveSum(idx);
-    if ((threadIdx.x & 63) == 0)
-    {
-        sv[threadIdx.x >> 6] = v;
-        si[threadIdx.x >> 6] = idx;
-    }
-    __syncthreads();
     if (threadIdx.x == 0)
-        histogram[z] = make_uint2(sv[0] + sv[1] + sv[2] + sv[3], si[0] + si[1] + si[2] + si[3]);
+        histogram[z] = make_uint2(v, idx);
+}
+
+/* Lattice weld: the occupied cells of the batch in cell-linear order with each cell's first index slot.
+ * One wave per row of cells; a row's first cell / index slot come from the exclusive scan of the row totals,
+ * positions inside the row from a ballot rank and a wave scan. */
+__global__ __launch_bounds__(256) void compactRowCellsKernel(const uint8_t *codes, uint32_t cw, uint32_t ch, uint32_t z0,
+                                                              uint32_t zFirst, const U3 *rowStarts, const uchar2 *countTable,
+                                                              uint2 *cells, uint2 *viStart, uint32_t numRows)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= numRows)
+        return;
+    const uint32_t y = r % ch, z = r / ch + zFirst;
+    const uint8_t *row = codes + ((uint64_t) (z - z0) * ch + y) * cw;
+    const U3 start = rowStarts[r];
+    uint32_t cellBase = start.a, indexBase = start.c;
+    for (uint32_t x0 = 0; x0 < cw; x0 += 64)
+    {
+        const uint32_t x = x0 + lane;
+        const uint32_t code = x < cw ? row[x] : 0u;
+        const uint32_t ni = code != 0 ? countTable[code].y : 0u;
+        const uint64_t occ = __ballot(code != 0);
+        const uint32_t incl = waveInclusiveScan(ni);
+        if (code != 0)
+        {
+            const uint32_t pos = cellBase + popcBelow(occ);
+            cells[pos] = make_uint2(x | (y << 16), z);
+            viStart[pos] = make_uint2(0u, indexBase + incl - ni);
+        }
+        cellBase += (uint32_t) __popcll(occ);
+        indexBase += readLane(incl, 63);
+    }
 }
 
 /* ScaleBiasFilter (kernels/scale_bias.cl:33-41) folded into vertex emission: v = fma(v, scale, bias).
@@ -563,11 +611,19 @@ __global__ void computeKeyTestKernel(uint32_t cx, uint32_t cy, uint32_t cz, uint
  * Rows are (z2, y2); each row is a bit mask over x2 plus per-word prefix counts, so an index is
  * rowStart[class] + wordPrefix + popcount -- three small L2-resident reads instead of a global sort.
  */
+/* one 64-point word of a row: existence bits + number of main-class vertices in the row's earlier words */
+struct LatWord
+{
+    uint64_t mask;
+    uint32_t prefix;
+    uint32_t pad;
+};
+
 struct Lattice
 {
-    uint64_t *mask;          /* [rows][nw] existence bits */
-    uint32_t *wordPrefix;    /* [rows][nw] main-class vertices in the preceding words of the row */
-    U3 *rowCounts;           /* [rows] per class; exclusive-scanned in place into row starts */
+    LatWord *words;          /* [rows][nw] */
+    U3 *rowCounts;           /* [rows] vertices per class; exclusive-scanned in place into per-class row starts */
+    uint4 *rowInfo;          /* [rows] after the scan: (first main-class index, first flagged index, bit0, row class) */
     const U3 *totals;        /* device: class totals after the scan */
     uint32_t nw;             /* 64-bit words per row */
     uint32_t rowsPerLayer;   /* 2H - 1 */
@@ -590,85 +646,173 @@ struct Lattice
             m |= 1ull << (topx & 63);
         return m;
     }
-    /* output index of the vertex at an existing half-lattice point */
+    /* output index of the vertex at an existing point, given its row's info record and its word */
+    __device__ __forceinline__ uint32_t indexFrom(const uint4 info, const LatWord wd, uint32_t x2) const
+    {
+        const uint64_t below = wd.mask & ((1ull << (x2 & 63)) - 1);
+        if (info.w == 2)
+            return info.x + wd.prefix + (uint32_t) __popcll(below);
+        if (x2 == 0)
+            return info.y;
+        if (x2 == topx)
+            return info.y + info.z;
+        return info.x + wd.prefix + (uint32_t) __popcll(below & ~columnMask(x2 >> 6));
+    }
+    /* two 16-byte loads per lookup, both L2-resident and shared by neighbouring cells */
     __device__ __forceinline__ uint32_t index(uint32_t x2, uint32_t y2, uint32_t z2) const
     {
         const uint32_t row = (z2 - z2First) * rowsPerLayer + y2;
-        const uint32_t rc = rowClass(y2, z2);
-        const U3 rs = rowCounts[row];
-        const U3 tot = *totals;
-        const uint32_t off2 = tot.a + tot.b;
-        const uint32_t w = x2 >> 6;
-        const uint64_t bits = mask[(uint64_t) row * nw + w];
-        const uint64_t below = bits & ((1ull << (x2 & 63)) - 1);
-        if (rc == 2)
-            return off2 + rs.c + wordPrefix[(uint64_t) row * nw + w] + (uint32_t) __popcll(below);
-        if (x2 == 0)
-            return off2 + rs.c;
-        if (x2 == topx)
-            return off2 + rs.c + (uint32_t) (mask[(uint64_t) row * nw] & 1);
-        const uint32_t base = rc == 0 ? rs.a : tot.a + rs.b;
-        return base + wordPrefix[(uint64_t) row * nw + w] + (uint32_t) __popcll(below & ~columnMask(w));
+        return indexFrom(rowInfo[row], words[(uint64_t) row * nw + (x2 >> 6)], x2);
     }
 };
 
-/* One wave per row: existence bits, per-word prefixes, per-class row totals. */
+/* spread the low 32 bits of v over the even bit positions of a 64-bit word */
+__device__ __forceinline__ uint64_t spreadBits(uint64_t v)
+{
+    v &= 0xFFFFFFFFull;
+    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
+    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    v = (v | (v << 2)) & 0x3333333333333333ull;
+    v = (v | (v << 1)) & 0x5555555555555555ull;
+    return v;
+}
+
+/* does a cell with this code (0 = not occupied) see different signs at its local corners a and b? */
+__device__ __forceinline__ uint32_t edgeBit(uint32_t code, uint32_t a, uint32_t b)
+{
+    return ((code >> a) ^ (code >> b)) & 1u;
+}
+
+/*
+ * Existence masks.  One wave per row of CORNERS (fixed y, z), lane = corner x.  A corner owns the seven
+ * edges towards +x, +y, +z, +xy, +xz, +yz, +xyz, i.e. the half-lattice points of four rows:
+ *   (z2, y2) = (2z, 2y): +x at x2 = 2x+1          (2z, 2y+1): +y at 2x, +xy at 2x+1
+ *              (2z+1, 2y): +z at 2x, +xz at 2x+1  (2z+1, 2y+1): +yz at 2x, +xyz at 2x+1
+ * An edge carries a vertex iff one of the occupied cells containing it sees a sign change along it; those
+ * cells are among the eight around the corner, whose code bytes are four loads per lane (cell x of the four
+ * adjacent cell rows) plus a lane shift for cell x-1.  Seven ballots give the rows' bits for 64 corners,
+ * interleaved (even/odd x2) into two 64-bit words per row on the scalar unit.
+ */
 __global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, uint32_t zCellFirst, uint32_t zCellLast,
-                                                         uint32_t numRows)
+                                                         uint32_t H, uint32_t numCornerRows)
 {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= numRows)
+    const uint32_t cr = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (cr >= numCornerRows)
         return;
-    const uint32_t z2 = row / L.rowsPerLayer + L.z2First, y2 = row % L.rowsPerLayer;
-    const uint32_t cz = z2 >> 1, pz = z2 & 1, cy = y2 >> 1, py = y2 & 1;
-    const uint32_t rc = L.rowClass(y2, z2);
-    uint32_t running = 0, nFlag = 0;
-    for (uint32_t w = 0; w < L.nw; w++)
+    const uint32_t y = cr % H, z = cr / H + zCellFirst;
+    const uint32_t W = L.cw + 1;
+    /* adjacent cell rows (y - dy, z - dz); a row outside the batch contributes no occupied cell */
+    bool rowOk[2][2];
+    const uint8_t *rowPtr[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+        for (int dz = 0; dz < 2; dz++)
+        {
+            const int cy = (int) y - dy, cz = (int) z - dz;
+            rowOk[dy][dz] = cy >= 0 && cy < (int) L.ch && cz >= (int) zCellFirst && cz < (int) zCellLast;
+            rowPtr[dy][dz] = C.codes + ((uint64_t) ((uint32_t) cz - C.z0) * C.ch + (uint32_t) cy) * C.cw;
+        }
+    /* the four half-lattice rows of this corner row: h = py | pz << 1 */
+    uint32_t rowId[4], rowCls[4], running[4], nFlag[4];
+    bool rowExists[4];
+#pragma unroll
+    for (int h = 0; h < 4; h++)
     {
-        const uint32_t x2 = w * 64 + lane;
-        const uint32_t cx = x2 >> 1, px = x2 & 1;
-        uint32_t exists = 0;
-        if (x2 <= L.topx && (px | py | pz))
+        const uint32_t y2 = 2 * y + (h & 1), z2 = 2 * z + (h >> 1);
+        rowExists[h] = y2 <= L.topy && z2 <= L.z2Last;
+        rowId[h] = (z2 - L.z2First) * L.rowsPerLayer + y2;
+        rowCls[h] = L.rowClass(y2, z2);
+        running[h] = nFlag[h] = 0;
+    }
+    uint32_t prev[2][2] = {{0, 0}, {0, 0}};
+    for (uint32_t x0 = 0; x0 < W; x0 += 64)
+    {
+        const uint32_t x = x0 + lane;
+        uint32_t c[2][2], m[2][2];
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (int dz = 0; dz < 2; dz++)
+            {
+                c[dy][dz] = (rowOk[dy][dz] && x < L.cw) ? rowPtr[dy][dz][x] : 0u;
+                const uint32_t up = __shfl_up(c[dy][dz], 1, 64);
+                m[dy][dz] = lane == 0 ? prev[dy][dz] : up;
+                prev[dy][dz] = readLane(c[dy][dz], 63);
+            }
+        /* edge from the corner = local corner (ox, oy, oz) of cell (x-ox, y-oy, z-oz); a = ox | oy<<1 | oz<<2 */
+        uint32_t ex = 0, ey = 0, ez = 0, exy = 0, exz = 0;
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+            for (int dz = 0; dz < 2; dz++)
+                ex |= edgeBit(c[dy][dz], (dy << 1) | (dz << 2), (dy << 1) | (dz << 2) | 1);
+#pragma unroll
+        for (int dz = 0; dz < 2; dz++)
         {
-            const uint32_t d = px | (py << 1) | (pz << 2);
-            /* cells containing the edge: along an axis the edge runs along, the owner's cell only;
-             * across, the owner's cell and the one before it */
-#pragma unroll
-            for (uint32_t oz = 0; oz < 2; oz++)
-#pragma unroll
-                for (uint32_t oy = 0; oy < 2; oy++)
-#pragma unroll
-                    for (uint32_t ox = 0; ox < 2; ox++)
-                    {
-                        if ((ox & px) | (oy & py) | (oz & pz))
-                            continue;
-                        const int ix = (int) cx - (int) ox, iy = (int) cy - (int) oy, iz = (int) cz - (int) oz;
-                        if (ix < 0 || iy < 0 || iz < (int) zCellFirst || ix >= (int) L.cw || iy >= (int) L.ch || iz >= (int) zCellLast)
-                            continue;
-                        const uint32_t code = C.at((uint32_t) ix, (uint32_t) iy, (uint32_t) iz);
-                        const uint32_t a = ox | (oy << 1) | (oz << 2);
-                        exists |= ((code >> a) ^ (code >> (a | d))) & 1u;
-                    }
+            ey |= edgeBit(c[0][dz], dz << 2, (dz << 2) | 2) | edgeBit(m[0][dz], 1 | (dz << 2), 1 | (dz << 2) | 2);
+            exy |= edgeBit(c[0][dz], dz << 2, (dz << 2) | 3);
         }
-        const uint64_t bits = __ballot(exists != 0);
-        const uint64_t cm = rc == 2 ? 0ull : L.columnMask(w);
-        if (lane == 0)
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
         {
-            L.mask[(uint64_t) row * L.nw + w] = bits;
-            L.wordPrefix[(uint64_t) row * L.nw + w] = running;
+            ez |= edgeBit(c[dy][0], dy << 1, (dy << 1) | 4) | edgeBit(m[dy][0], 1 | (dy << 1), 1 | (dy << 1) | 4);
+            exz |= edgeBit(c[dy][0], dy << 1, (dy << 1) | 5);
         }
-        running += (uint32_t) __popcll(bits & ~cm);
-        nFlag += (uint32_t) __popcll(bits & cm);
+        const uint32_t eyz = edgeBit(c[0][0], 0, 6) | edgeBit(m[0][0], 1, 7);
+        const uint32_t exyz = edgeBit(c[0][0], 0, 7);
+        const uint64_t even[4] = {0ull, __ballot(ey != 0), __ballot(ez != 0), __ballot(eyz != 0)};
+        const uint64_t odd[4] = {__ballot(ex != 0), __ballot(exy != 0), __ballot(exz != 0), __ballot(exyz != 0)};
+#pragma unroll
+        for (int h = 0; h < 4; h++)
+        {
+            if (!rowExists[h])
+                continue;
+#pragma unroll
+            for (int half = 0; half < 2; half++)
+            {
+                const uint32_t w = (x0 >> 6) * 2 + half;
+                if (w >= L.nw)
+                    continue;
+                const uint64_t bits = spreadBits(even[h] >> (32 * half)) | (spreadBits(odd[h] >> (32 * half)) << 1);
+                const uint64_t cm = rowCls[h] == 2 ? 0ull : L.columnMask(w);
+                if (lane == 0)
+                    L.words[(uint64_t) rowId[h] * L.nw + w] = LatWord{bits, running[h], 0u};
+                running[h] += (uint32_t) __popcll(bits & ~cm);
+                nFlag[h] += (uint32_t) __popcll(bits & cm);
+            }
+        }
     }
     if (lane == 0)
     {
-        U3 c{0u, 0u, 0u};
-        if (rc == 0) { c.a = running; c.c = nFlag; }
-        else if (rc == 1) { c.b = running; c.c = nFlag; }
-        else c.c = running;
-        L.rowCounts[row] = c;
+#pragma unroll
+        for (int h = 0; h < 4; h++)
+            if (rowExists[h])
+            {
+                U3 cnt{0u, 0u, 0u};
+                if (rowCls[h] == 0) { cnt.a = running[h]; cnt.c = nFlag[h]; }
+                else if (rowCls[h] == 1) { cnt.b = running[h]; cnt.c = nFlag[h]; }
+                else cnt.c = running[h];
+                L.rowCounts[rowId[h]] = cnt;
+            }
     }
+}
+
+/* After the scan of the row counts: one 16-byte record per row with everything a lookup needs. */
+__global__ __launch_bounds__(256) void latticeRowInfoKernel(Lattice L, uint32_t numRows)
+{
+    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= numRows)
+        return;
+    const uint32_t z2 = row / L.rowsPerLayer + L.z2First, y2 = row % L.rowsPerLayer;
+    const uint32_t rc = L.rowClass(y2, z2);
+    const U3 rs = L.rowCounts[row];
+    const U3 tot = *L.totals;
+    const uint32_t off2 = tot.a + tot.b;
+    const uint32_t mainBase = rc == 0 ? rs.a : (rc == 1 ? tot.a + rs.b : off2 + rs.c);
+    L.rowInfo[row] = make_uint4(mainBase, off2 + rs.c, (uint32_t) (L.words[(uint64_t) row * L.nw].mask & 1), rc);
 }
 
 /* One wave per row: positions (interp, kernels/marching.cl:130-138) and external keys of the existing points. */
@@ -682,31 +826,15 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lattice L, FieldVie
         return;
     const uint32_t z2 = row / L.rowsPerLayer + L.z2First, y2 = row % L.rowsPerLayer;
     const uint32_t cz = z2 >> 1, pz = z2 & 1, cy = y2 >> 1, py = y2 & 1;
-    const uint32_t rc = L.rowClass(y2, z2);
-    const U3 rs = L.rowCounts[row];
-    const U3 tot = *L.totals;
-    const uint32_t off2 = tot.a + tot.b;
-    const uint32_t mainBase = rc == 0 ? rs.a : (rc == 1 ? tot.a + rs.b : off2 + rs.c);
-    const uint32_t bit0 = (uint32_t) (L.mask[(uint64_t) row * L.nw] & 1);
+    const uint4 info = L.rowInfo[row];
     for (uint32_t w = 0; w < L.nw; w++)
     {
-        const uint64_t bits = L.mask[(uint64_t) row * L.nw + w];
-        if (!((bits >> lane) & 1))
+        const LatWord wd = L.words[(uint64_t) row * L.nw + w];
+        if (!((wd.mask >> lane) & 1))
             continue;
         const uint32_t x2 = w * 64 + lane;
-        const uint64_t below = bits & ((1ull << lane) - 1);
-        uint32_t idx;
-        uint32_t cls = rc;
-        if (rc != 2 && (x2 == 0 || x2 == L.topx))
-        {
-            cls = 2;
-            idx = off2 + rs.c + (x2 == 0 ? 0u : bit0);
-        }
-        else
-        {
-            const uint64_t cm = rc == 2 ? 0ull : L.columnMask(w);
-            idx = mainBase + L.wordPrefix[(uint64_t) row * L.nw + w] + (uint32_t) __popcll(below & ~cm);
-        }
+        const uint32_t idx = L.indexFrom(info, wd, x2);
+        const bool flagged = info.w != 0 || x2 == 0 || x2 == L.topx;    /* class 1 or 2: external */
         const uint32_t cx = x2 >> 1, px = x2 & 1;
         /* endpoint A = owner corner, B = A + (px,py,pz): A has the lower local corner id in every cell */
         const uint32_t rowA = cy + F.zStride * cz + (uint32_t) F.zBias;
@@ -726,7 +854,7 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lattice L, FieldVie
         outVertices[3 * (uint64_t) idx + 0] = vx;
         outVertices[3 * (uint64_t) idx + 1] = vy;
         outVertices[3 * (uint64_t) idx + 2] = vz;
-        if (cls != 0)
+        if (flagged)
             outKeys[idx] = (((uint64_t) z2 << (2 * KEY_AXIS_BITS)) | ((uint64_t) y2 << KEY_AXIS_BITS) | (uint64_t) x2) + keyOffset;
     }
 }
@@ -736,12 +864,16 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lattice L, FieldVie
  * compacted list, so their index ranges are one contiguous span of the output: it is assembled in LDS
  * and written with fully coalesced stores instead of 256 interleaved per-thread runs. */
 __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeView C, DevTables T, const uint2 *cells,
-                                                              const uint2 *viStart, uint32_t *indices, uint32_t numCells)
+                                                              const uint2 *viStart, uint32_t *indices,
+                                                              const U3 *batchTotals)
 {
     __shared__ uint32_t sIdx[256][MAX_CELL_VERTICES];
     __shared__ uint32_t sOut[256 * MAX_CELL_INDICES];
     __shared__ uint32_t sSpan;
+    const uint32_t numCells = batchTotals->a;           /* grid covers the host's count; the device value rules */
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x * blockDim.x >= numCells)
+        return;
     const uint32_t blockBase = viStart[blockIdx.x * blockDim.x].y;
     if (gid < numCells)
     {
@@ -816,8 +948,9 @@ struct mlsgpu_marching
 
     /* lattice weld (single-swathe buckets) */
     uint8_t *dCellCode = nullptr;
-    uint64_t *dLatMask = nullptr;
-    uint32_t *dLatPrefix = nullptr;
+    U3 *dRowCounts = nullptr, *dRowStarts = nullptr;   /* per row of cells of the swathe: (occupied, vertices, indices) */
+    LatWord *dLatWords = nullptr;
+    uint4 *dLatInfo = nullptr;
     U3 *dLatRows = nullptr;
     uint64_t latRowsMax = 0;
     uint32_t latWords = 0;
@@ -877,7 +1010,8 @@ uint64_t marchingSizes(uint32_t maxWidth, uint32_t maxHeight, uint32_t maxDepth,
     uint64_t bytes = *fieldRows * *imageWidth * 4;
     bytes += sc * 16 + sc;                          /* cells + viStart + cell codes */
     bytes += (uint64_t) scanTiles(std::max(sc, latRows)) * 12 + 12;    /* tile sums (U3) */
-    bytes += latRows * latWords * 12 + latRows * 12;                   /* lattice masks, prefixes, row counts */
+    bytes += latRows * latWords * 16 + latRows * 28;                   /* lattice words, row counts, row info */
+    bytes += (uint64_t) *swathe * (maxHeight - 1) * 24;                /* per cell-row counts and starts */
     if (legacy)
     {
         bytes += vs * 16;                           /* unwelded vertices */
@@ -953,8 +1087,10 @@ MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, ui
     m->latWords = (2 * maxWidth - 1 + 63) / 64;
     alloc((void **) &m->dTileSums3, ((uint64_t) scanTiles(std::max(sc, m->latRowsMax)) + 1) * sizeof(U3));
     alloc((void **) &m->dCellCode, sc);
-    alloc((void **) &m->dLatMask, m->latRowsMax * m->latWords * 8);
-    alloc((void **) &m->dLatPrefix, m->latRowsMax * m->latWords * 4);
+    alloc((void **) &m->dRowCounts, ((uint64_t) m->maxSwathe * (maxHeight - 1) + 1) * sizeof(U3));
+    alloc((void **) &m->dRowStarts, ((uint64_t) m->maxSwathe * (maxHeight - 1) + 1) * sizeof(U3));
+    alloc((void **) &m->dLatWords, m->latRowsMax * m->latWords * sizeof(LatWord));
+    alloc((void **) &m->dLatInfo, m->latRowsMax * sizeof(uint4));
     alloc((void **) &m->dLatRows, m->latRowsMax * sizeof(U3));
     if (m->legacyBuffers)
     {
@@ -1007,7 +1143,8 @@ MLSGPU_API void mlsgpu_hip_marching_destroy(mlsgpu_marching *m)
     hipFree(m->dVertices); hipFree(m->dKeysA); hipFree(m->dKeysB); hipFree(m->dValsA); hipFree(m->dValsB);
     hipFree(m->dIndices); hipFree(m->dIndexRemap); hipFree(m->dWelded); hipFree(m->dWeldedKeys);
     hipFree(m->dHist); hipFree(m->dTileSums); hipFree(m->dReadback);
-    hipFree(m->dCellCode); hipFree(m->dLatMask); hipFree(m->dLatPrefix); hipFree(m->dLatRows);
+    hipFree(m->dCellCode); hipFree(m->dRowCounts); hipFree(m->dRowStarts);
+    hipFree(m->dLatWords); hipFree(m->dLatInfo); hipFree(m->dLatRows);
     if (m->hReadback) hipHostFree(m->hReadback);
     if (m->hHistogram) hipHostFree(m->hHistogram);
     delete m;
@@ -1018,10 +1155,21 @@ MLSGPU_API void mlsgpu_hip_marching_destroy(mlsgpu_marching *m)
 int mlsgpu_marching::generateCells(const mlsgpu_swathe &sw, U3 *totals)
 {
     const CellRange R{sw.width - 1, sw.height - 1, sw.zFirst};
-    const uint64_t n = (uint64_t) R.cw * R.ch * (sw.zLast - sw.zFirst);
-    ClassifyIn in{codeView(sw), R, dCount};
-    PROPAGATE((scanPhase1<U3, ClassifyIn>(ctx, "kernel.marching.genOccupied.time", in, n, U3{0, 0, 0},
-                                          dTileSums3, &dReadback->totals)));
+    if (direct)
+    {
+        /* lattice weld: only the totals are needed now -- reduce the row totals of the (sub-)swathe */
+        const uint64_t rows = (uint64_t) R.ch * (sw.zLast - sw.zFirst);
+        const U3 *first = dRowCounts + (uint64_t) (sw.zFirst - codeZ0) * R.ch;
+        PROPAGATE((scanPhase1<U3, ArrayIn<U3> >(ctx, "kernel.marching.genOccupied.time", ArrayIn<U3>{first},
+                                                 R.cw > 0 ? rows : 0, U3{0, 0, 0}, dTileSums3, &dReadback->totals)));
+    }
+    else
+    {
+        const uint64_t n = (uint64_t) R.cw * R.ch * (sw.zLast - sw.zFirst);
+        ClassifyIn in{codeView(sw), R, dCount};
+        PROPAGATE((scanPhase1<U3, ClassifyIn>(ctx, "kernel.marching.genOccupied.time", in, n, U3{0, 0, 0},
+                                              dTileSums3, &dReadback->totals)));
+    }
     int pend = -1;
     if (ctx->timing) pend = ctx->beginTiming(ctx->statId("kernel.marching.readback.time"));
     HIP_CHECK(hipMemcpyAsync(&hReadback->totals, &dReadback->totals, sizeof(U3), hipMemcpyDeviceToHost, ctx->stream));
@@ -1034,8 +1182,8 @@ int mlsgpu_marching::generateCells(const mlsgpu_swathe &sw, U3 *totals)
 int mlsgpu_marching::sliceHistogram(const mlsgpu_swathe &sw)
 {
     const uint32_t slices = sw.zLast - sw.zFirst;
-    LAUNCH(ctx, "kernel.marching.genOccupied.time", sliceHistogramKernel, dim3(slices), dim3(256),
-           codeView(sw), sw.zFirst, (const uchar2 *) dCount, dHistogram);
+    LAUNCH(ctx, "kernel.marching.genOccupied.time", sliceHistogramKernel, dim3(slices), dim3(64),
+           (const U3 *) dRowCounts, sw.height - 1, sw.zFirst, codeZ0, dHistogram);
     HIP_CHECK(hipMemcpyAsync(hHistogram + sw.zFirst, dHistogram + sw.zFirst, (size_t) slices * 8,
                              hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -1063,11 +1211,11 @@ int mlsgpu_marching::weld(uint32_t nv, uint32_t zMax)
 int mlsgpu_marching::computeCodes(const mlsgpu_swathe &sw)
 {
     const uint32_t cw = sw.width - 1, ch = sw.height - 1;
-    const uint64_t n = (uint64_t) cw * ch * (sw.zLast - sw.zFirst);
+    const uint32_t rows = ch * (sw.zLast - sw.zFirst);
     codeZ0 = sw.zFirst;
-    if (n > 0)
-        LAUNCH(ctx, "kernel.marching.genOccupied.time", cellCodeKernel, dim3(divUp(n, 256)), dim3(256),
-               dCellCode, view(sw), cw, ch, sw.zFirst, (uint32_t) n);
+    if (rows > 0 && cw > 0)
+        LAUNCH(ctx, "kernel.marching.genOccupied.time", cellCodeKernel, dim3(divUp(rows, 4)), dim3(256),
+               dCellCode, dRowCounts, view(sw), cw, ch, sw.zFirst, rows, (const uchar2 *) dCount);
     return MLSGPU_OK;
 }
 
@@ -1096,9 +1244,9 @@ int mlsgpu_marching::shipOutLattice(const mlsgpu_swathe &sw, const uint32_t size
     (void) sizes;
     const uint32_t W = sw.width, H = sw.height;
     Lattice L;
-    L.mask = dLatMask;
-    L.wordPrefix = dLatPrefix;
+    L.words = dLatWords;
     L.rowCounts = dLatRows;
+    L.rowInfo = dLatInfo;
     L.totals = &dReadback->classTotals;
     L.nw = (2 * W - 1 + 63) / 64;
     L.rowsPerLayer = 2 * H - 1;
@@ -1111,27 +1259,32 @@ int mlsgpu_marching::shipOutLattice(const mlsgpu_swathe &sw, const uint32_t size
     const uint32_t numRows = (2 * (zMax - zTop) + 1) * L.rowsPerLayer;
     REQUIRE(numRows <= latRowsMax && L.nw <= latWords, MLSGPU_ERR_LENGTH);
     const CodeView C = codeView(sw);
-    const char *stat = "kernel.marching.compactVertices.time";
-    LAUNCH(ctx, "kernel.marching.countUniqueVertices.time", latticeMaskKernel, dim3(divUp(numRows, 4)), dim3(256),
-           L, C, zTop, zMax, numRows);
+    const uint32_t cornerRows = (zMax - zTop + 1) * H;
+    LAUNCH(ctx, "kernel.marching.countUniqueVertices.time", latticeMaskKernel, dim3(divUp(cornerRows, 4)), dim3(256),
+           L, C, zTop, zMax, H, cornerRows);
     PROPAGATE((exclusiveScan<U3>(ctx, "kernel.marching.scanUint.time", ArrayIn<U3>{dLatRows}, ArrayOut<U3>{dLatRows},
                                  numRows, U3{0, 0, 0}, dTileSums3, &dReadback->classTotals)));
+    LAUNCH(ctx, "kernel.marching.scanUint.time", latticeRowInfoKernel, dim3(divUp(numRows, 256)), dim3(256), L, numRows);
     const uint64_t keyOffsetL = ((uint64_t) keyOffset[2] << (2 * KEY_AXIS_BITS + 1))
         | ((uint64_t) keyOffset[1] << (KEY_AXIS_BITS + 1))
         | ((uint64_t) keyOffset[0] << 1);                                   /* src/marching.cpp:594-597 */
-    LAUNCH(ctx, stat, latticeVerticesKernel, dim3(divUp(numRows, 4)), dim3(256),
+    LAUNCH(ctx, "kernel.marching.compactVertices.time", latticeVerticesKernel, dim3(divUp(numRows, 4)), dim3(256),
            L, view(sw), dWelded, dWeldedKeys, keyOffset[0], keyOffset[1], keyOffset[2], keyOffsetL, transform, numRows);
-    /* compact the batch's occupied cells (cell-linear order) with their first index slot, then the triangles */
-    const CellRange R{W - 1, H - 1, zTop};
-    const uint64_t n = (uint64_t) R.cw * R.ch * (zMax - zTop);
-    ClassifyIn in{C, R, dCount};
-    CompactCellsOut outF{R, dCells, dViStart, 0u, 0u};
-    PROPAGATE((exclusiveScan<U3>(ctx, "kernel.marching.scanElements.time", in, outF, n, U3{0, 0, 0}, dTileSums3,
-                                 &dReadback->batchTotals)));
+    /* first cell / index slot of every row of cells of the batch, the compacted cells, then the triangles */
+    const uint32_t cellRows = (zMax - zTop) * L.ch;
+    const U3 *firstRow = dRowCounts + (uint64_t) (zTop - codeZ0) * L.ch;
+    PROPAGATE((exclusiveScan<U3>(ctx, "kernel.marching.scanElements.time", ArrayIn<U3>{firstRow}, ArrayOut<U3>{dRowStarts},
+                                 cellRows, U3{0, 0, 0}, dTileSums3, &dReadback->batchTotals)));
     const uint32_t cellsInBatch = bufferedCells;
-    if (cellsInBatch > 0)
+    if (cellRows > 0 && cellsInBatch > 0)
+    {
+        LAUNCH(ctx, "kernel.marching.scanElements.time", compactRowCellsKernel, dim3(divUp(cellRows, 4)), dim3(256),
+               (const uint8_t *) dCellCode, L.cw, L.ch, codeZ0, zTop, (const U3 *) dRowStarts, (const uchar2 *) dCount,
+               dCells, dViStart, cellRows);
         LAUNCH(ctx, "kernel.marching.generateElements.time", latticeTrianglesKernel, dim3(divUp(cellsInBatch, 256)), dim3(256),
-               L, C, devTables(), (const uint2 *) dCells, (const uint2 *) dViStart, dIndices, cellsInBatch);
+               L, C, devTables(), (const uint2 *) dCells, (const uint2 *) dViStart, dIndices,
+               (const U3 *) &dReadback->batchTotals);
+    }
     HIP_CHECK(hipMemcpyAsync(&hReadback->classTotals, &dReadback->classTotals, 2 * sizeof(U3), hipMemcpyDeviceToHost, ctx->stream));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     const U3 ct = hReadback->classTotals, bt = hReadback->batchTotals;
