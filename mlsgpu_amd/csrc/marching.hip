@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeVie
                                                               const U3 *batchTotals)
 {
     __shared__ uint32_t sIdx[256][MAX_CELL_VERTICES];
-    __shared__ uint32_t sOut[256 * MAX_CELL_INDICES];
+    __shared__ uint16_t sRef[256 * MAX_CELL_INDICES];   /* (thread << 4 | vertex slot): 18 KB instead of 36 KB of indices */
     __shared__ uint32_t sSpan;
     const uint32_t numCells = batchTotals->a;           /* grid covers the host's count; the device value rules */
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -889,14 +889,17 @@ __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeVie
         }
         const uint32_t local = viStart[gid].y - blockBase;
         for (uint32_t i = 0; i < ni; i++)
-            sOut[local + i] = sIdx[threadIdx.x][T.data[st.y + i]];
+            sRef[local + i] = (uint16_t) ((threadIdx.x << 4) | T.data[st.y + i]);
         if (gid == numCells - 1 || threadIdx.x == blockDim.x - 1)
             sSpan = local + ni;
     }
     __syncthreads();
     const uint32_t span = sSpan;
     for (uint32_t k = threadIdx.x; k < span; k += blockDim.x)
-        indices[blockBase + k] = sOut[k];
+    {
+        const uint32_t ref = sRef[k];
+        indices[blockBase + k] = sIdx[ref >> 4][ref & 15];
+    }
 }
 
 uint32_t bitsFor(uint32_t maxValue)

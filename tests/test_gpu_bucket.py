@@ -21,7 +21,7 @@ def run_gpu_bucket(ctx, cloud, first, count, low, nv, variant=0, **kw):
     return batches, w, buf
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 2])
 def test_cfg1_parity(ctx, variant):
     """BASELINE config 0: 64^3 grid, 50k splats on a sphere, one bucket: bit-identical to the oracle."""
     import mlsgpu_amd as m
@@ -71,6 +71,19 @@ def test_plane_shape_and_boundary_limit(ctx):
                        mesh_memory=63 * 63 * 2 * 872, shape=1, boundary_limit=1.5)
     assert_batches_equal(got, exp)
     assert sum(len(b["triangles"]) for b in got) > 0
+
+
+@pytest.mark.parametrize("variant", [0, 2])
+def test_dense_hits(ctx, variant):
+    """Large, dense splats: hundreds of hits per corner, so variant 2's 52-entry per-lane hit lists overflow and
+    are drained mid-round; the accumulation order, hence every bit of the result, must not change."""
+    from mlsgpu_amd import synth
+    cloud = synth.sphere_cloud(60_000, (32.0, 32.0, 32.0), 20.0, 5.0, 7.0, seed=4242)
+    got, _, _ = run_gpu_bucket(ctx, cloud, 0, len(cloud), (0, 0, 0), (64, 64, 64), variant=variant, max_cells=63)
+    exp, st = ob.bucket(cloud.copy(), 0, len(cloud), (64, 64, 64), (0, 0, 0), max_cells=63, max_swathe=64,
+                        mesh_memory=63 * 63 * 2 * 872)
+    assert st["hits"] > 100 * 64 ** 3
+    assert_batches_equal(got, exp)
 
 
 def test_empty_bucket(ctx):
@@ -124,7 +137,7 @@ def test_cfg2_full_size_properties(ctx):
     from mlsgpu_amd import synth
     cloud, g = synth.make_cloud("cfg2")
     digests = []
-    for variant in (0, 1, 0):
+    for variant in (0, 1, 2):
         w = m.Worker(ctx, len(cloud), max_cells=255)
         w.set_mls_variant(variant)
         buf = m.DeviceBuffer(ctx, array=cloud)
