@@ -42,7 +42,7 @@ def parse_args():
     p.add_argument("--scale", type=float, default=1.0, help="splat-count scale (debug only; 1.0 = BASELINE size)")
     p.add_argument("--mesh-memory-mb", type=int, default=4096, help="Marching mesh arena per worker")
     p.add_argument("--workers", type=int, default=2, help="device worker threads per GPU")
-    p.add_argument("--variant", type=int, default=0, help="MLS kernel variant: 0 culled, 1 basic")
+    p.add_argument("--variant", type=int, default=2, help="MLS kernel variant: 0 culled, 1 basic, 2 culled + hit lists")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-timing", action="store_true", help="do not time individual kernels with HIP events")
     return p.parse_args()
@@ -187,7 +187,7 @@ def main():
             "bucket_splats_total": len(bucketed),
             "mesh_memory_mb": args.mesh_memory_mb,
             "device_workers": nworkers,
-            "mls_variant": "culled" if args.variant == 0 else "basic",
+            "mls_variant": {0: "culled", 1: "basic", 2: "culled+hit-lists"}[args.variant],
             "per_rank": "own cloud per rank (seed offset = rank)",
             "triangles_per_step": triangles,
             "vertices_per_step": vertices,
@@ -221,16 +221,48 @@ def main():
                                "algorithmic_bytes_per_step": int(nbytes),
                                "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1)})
         stages.sort(key=lambda s: -s["ms_per_step"])
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath) and stages:
-            try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("%s/%s" % (args.workload, args.dist), {}).get(stages[0]["kernel"])
-            except Exception:
-                traffic = None
         single_ms = sum(v[0] for k, v in kernel_stats.items() if k == "device.compute") / K
-        if stages:
+        tj = {}
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath)).get("%s/%s" % (args.workload, args.dist), {})
+            except Exception:
+                tj = {}
+        for st in stages:
+            st["hbm_traffic_bytes_per_launch"] = tj.get(st["kernel"])
+        pc = "kernel.mls.processCorners.time"
+        if stages and stages[0]["stat"] == pc:
+            # Dominant kernel = processCorners: an fp32-VALU/LDS-bound kernel (>= 140 flop/B), so its
+            # roof is the fp32 rate.  MI355X's dense f32 MFMA peak equals its f32 vector peak (157.3 TFLOP/s,
+            # MI355X_MICROARCH.md); the kernel issues no MFMA, "mfma" here only names the compute roof.
+            total_ms, launches = kernel_stats[pc]
+            ms = total_ms / K
+            alg_flops = 10 * 512 * listed + 25 * hits          # SURVEY 8d per-bucket figure, summed over buckets
+            done_flops = 10 * tests + 25 * hits                # distance tests that survive sub-block culling
+            achieved = alg_flops / (ms * 1e-3) / 1e12
+            result["roofline"] = {
+                "kernel": "processCorners",
+                "bound": "mfma",
+                "achieved": round(achieved, 3),
+                "peak": FP32_VALU_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / FP32_VALU_PEAK_TFLOPS, 4),
+                "traffic": tj.get("processCorners"),
+                "avg_launch_ms": round(total_ms / launches, 4),
+                "launches_per_step": launches // K,
+                "algorithmic_flops_per_launch": int(alg_flops // max(launches // K, 1)),
+                "algorithmic": "SURVEY 8d: 10*512*SigmaL + 25*H flops of the reference's every-corner-tests-every-listed-"
+                               "splat loop; sub-block culling skips most of those tests, see executed_*",
+                "executed_TFLOPs": round(done_flops / (ms * 1e-3) / 1e12, 3),
+                "executed_frac": round(done_flops / (ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4),
+                "hbm_algorithmic_GBps": round((36 * listed + 4 * corners) / (ms * 1e-3) / 1e9, 1),
+                "sigma_L": listed, "tests": tests, "hits": hits, "corners": corners,
+                "share_of_kernel_time": round(stages[0]["ms_per_step"] / sum(s_["ms_per_step"] for s_ in stages), 3),
+                "measured": "hipEvent pairs on the worker stream, %d single-worker passes after the timed region "
+                            "(%.1f ms per pass)" % (K, single_ms),
+            }
+        elif stages:
             top = stages[0]
             total_ms, launches = kernel_stats[top["stat"]]
             result["roofline"] = {
@@ -240,28 +272,16 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(top["achieved_GBps"] / HBM_PEAK_GBS, 5),
-                "traffic": traffic,
+                "traffic": tj.get(top["kernel"]),
                 "avg_launch_ms": round(total_ms / launches, 4),
                 "launches_per_step": launches // K,
                 "algorithmic_bytes_per_launch": int(top["algorithmic_bytes_per_step"] // max(launches // K, 1)),
-                "share_of_kernel_time": round(top["ms_per_step"] / sum(s["ms_per_step"] for s in stages), 3),
+                "share_of_kernel_time": round(top["ms_per_step"] / sum(s_["ms_per_step"] for s_ in stages), 3),
                 "measured": "hipEvent pairs on the worker stream, %d single-worker passes after the timed region "
                             "(%.1f ms per pass)" % (K, single_ms),
-                "stages": stages,
             }
-        pc = "kernel.mls.processCorners.time"
-        if pc in kernel_stats and kernel_stats[pc][1] > 0:
-            ms = kernel_stats[pc][0] / K
-            # flops = 10*512*SigmaL + 25*H for the reference algorithm; "executed" counts the
-            # distance tests that survive sub-block culling
-            result["processCorners_valu"] = {
-                "unit": "TFLOP/s", "peak": FP32_VALU_PEAK_TFLOPS,
-                "reference_algorithm": round((10 * 512 * listed + 25 * hits) / (ms * 1e-3) / 1e12, 3),
-                "executed": round((10 * tests + 25 * hits) / (ms * 1e-3) / 1e12, 3),
-                "frac_executed": round((10 * tests + 25 * hits) / (ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4),
-                "sigma_L": listed, "tests": tests, "hits": hits, "corners": corners,
-                "note": "fp32-VALU/LDS bound (SURVEY 8d), not an HBM kernel",
-            }
+        if stages:
+            result["roofline"]["hbm_stages"] = stages
         result["kernel_ms_per_step"] = {k: round(v[0] / K, 3) for k, v in sorted(kernel_stats.items())}
         result["work_per_step"] = {"octree_entries": entries, "occupied_cells": O, "unwelded_vertices": mc["unwelded"],
                                    "welded_vertices": Vw, "external_vertices": external, "indices": T}
