@@ -59,11 +59,22 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # one process per GPU; MLSGPU_BENCH_BACKEND=gloo lets several ranks share one GPU (a single-GPU check of the
+    # N > 1 code path: the only collectives are a barrier and two scalar reductions, so RCCL is not essential)
+    backend = os.environ.get("MLSGPU_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and local_rank >= ndev:
+        raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, ndev))
+    local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    reduce_device = "cuda" if (dist is not None and backend == "nccl") else None
 
     import mlsgpu_amd as m
     from mlsgpu_amd import farm, synth
@@ -126,7 +137,7 @@ def main():
     if dist is not None:
         dist.barrier()
     # whole job: MAX of the elapsed time over ranks, SUM of the voxels (each rank ran `steps` passes of its cloud)
-    elapsed, total_voxels, _ = farm.combine(elapsed, voxels * args.steps, dist, "cuda" if dist is not None else None)
+    elapsed, total_voxels, _ = farm.combine(elapsed, voxels * args.steps, dist, reduce_device)
 
     # ---- per-kernel durations: the same `steps` passes once more on ONE worker with HIP events around every
     # launch.  Kept out of the headline region because with several workers the streams overlap and an event

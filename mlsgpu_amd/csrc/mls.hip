@@ -334,6 +334,7 @@ __global__ __launch_bounds__(512) void processCornersKernel(MlsArgs A)
  * here it runs max-hits-per-lane times at ~2/3 utilisation.  Results are bit-identical (same operations on
  * the same values in the same order per corner).
  */
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define LIST_STAGE 256
 #define LIST_CAP 52        /* bytes per lane; 13 dwords (odd) keeps the per-lane rows on different LDS banks */
 
@@ -373,22 +374,24 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
         /* accumulate this lane's listed hits, in list order, then empty the list */
         auto drain = [&]()
         {
+            /* Branch-free body: lanes whose list is exhausted re-read slot 0 (always staged) with weight 0,
+             * which leaves every sum bit-for-bit unchanged (fma(0, x, s) == s, s + 0 == s for finite x). */
             for (uint32_t j = 0; __any(j < cnt); j++)
             {
-                if (j < cnt)
-                {
-                    const uint32_t i = myList[j];
-                    const float4 pr = sPosRad[i];
-                    const float4 nq = sNormQ[i];
-                    const float px = pr.x - cx, py = pr.y - cy, pz = pr.z - cz;
-                    const float pp = dot3(px, py, pz, px, py, pz);
-                    const float d = pp * pr.w;
-                    float w = 1.0f - d;
-                    w *= w;
-                    w *= w;
-                    w *= nq.w;
-                    fitAdd(fit, w, px, py, pz, pp, nq.x, nq.y, nq.z);
-                }
+                const bool act = j < cnt;
+                const uint32_t i = act ? (uint32_t) myList[j] : 0u;
+                const float4 pr = sPosRad[i];
+                const float4 nq = sNormQ[i];
+                const float px = pr.x - cx, py = pr.y - cy, pz = pr.z - cz;
+                const float pp = dot3(px, py, pz, px, py, pz);
+                const float d = pp * pr.w;
+                float w = 1.0f - d;
+                w *= w;
+                w *= w;
+                w *= nq.w;
+                w = act ? w : 0.0f;
+                fitAdd(fit, w, px, py, pz, pp, nq.x, nq.y, nq.z);
+                fit.hits -= act ? 0u : 1u;      /* fitAdd counted it */
             }
             cnt = 0;
         };
@@ -444,23 +447,28 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
             {
                 const uint32_t m = sMask[g + lane];
                 uint64_t todo = __ballot((m >> wave) & 1u);
+                /* two relevant splats per iteration: the distance tests of both run as packed fp32
+                 * (v_pk_add / v_pk_mul / v_pk_fma), each component the same IEEE operation as the scalar form */
                 while (todo != 0)
                 {
-                    const int i = g + (int) __builtin_ctzll(todo);
+                    const int i0 = g + (int) __builtin_ctzll(todo);
                     todo &= todo - 1;
+                    const bool pair = todo != 0;
+                    const int i1 = pair ? g + (int) __builtin_ctzll(todo) : i0;
+                    todo &= todo - 1;           /* no-op when todo is already 0 */
                     if (STATS)
-                        nTests += 64;
-                    if (__any(cnt == LIST_CAP))
+                        nTests += pair ? 128 : 64;
+                    if (__any(cnt + 2 > LIST_CAP))
                         drain();
-                    const float4 pr = sPosRad[i];
-                    const float px = pr.x - cx, py = pr.y - cy, pz = pr.z - cz;
-                    const float pp = dot3(px, py, pz, px, py, pz);
-                    const float d = pp * pr.w;
-                    if (d < RADIUS_CUTOFF)
-                    {
-                        myList[cnt] = (uint8_t) i;
-                        cnt++;
-                    }
+                    const float4 a = sPosRad[i0], b = sPosRad[i1];
+                    const f32x2 px = f32x2{a.x, b.x} - cx, py = f32x2{a.y, b.y} - cy, pz = f32x2{a.z, b.z} - cz;
+                    const f32x2 pp = __builtin_elementwise_fma(px, px, __builtin_elementwise_fma(py, py, pz * pz));
+                    const f32x2 d = pp * f32x2{a.w, b.w};
+                    /* branch-free append: write the slot, keep it only if hit (the next append overwrites it) */
+                    myList[cnt] = (uint8_t) i0;
+                    cnt += d.x < RADIUS_CUTOFF ? 1u : 0u;
+                    myList[cnt] = (uint8_t) i1;
+                    cnt += (pair && d.y < RADIUS_CUTOFF) ? 1u : 0u;
                 }
             }
             drain();            /* the lists point into this round's staging buffers */
