@@ -44,6 +44,7 @@ def parse_args():
     p.add_argument("--workers", type=int, default=2, help="device worker threads per GPU")
     p.add_argument("--variant", type=int, default=2, help="MLS kernel variant: 0 culled, 1 basic, 2 culled + hit lists")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--no-stream", action="store_true", help="skip the PCIe-inclusive bucket-farm leg")
     p.add_argument("--no-timing", action="store_true", help="do not time individual kernels with HIP events")
     return p.parse_args()
 
@@ -296,6 +297,31 @@ def main():
         result["kernel_ms_per_step"] = {k: round(v[0] / K, 3) for k, v in sorted(kernel_stats.items())}
         result["work_per_step"] = {"octree_entries": entries, "occupied_cells": O, "unwelded_vertices": mc["unwelded"],
                                    "welded_vertices": Vw, "external_vertices": external, "indices": T}
+
+    # ---- PCIe-inclusive leg (never `value`): the same buckets from HOST memory through the bucket farm
+    # (pinned double-buffered staging, H2D on a copy stream, the same device workers), N = 1 only ----
+    if world == 1 and not args.no_stream:
+        del workers, work, pristine
+        farm_obj = m.BucketFarm([local_rank], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
+                                mesh_memory=args.mesh_memory_mb << 20)
+        views = [bucketed[b.first:b.first + b.count] for b in buckets]
+
+        def stream_pass():
+            for i, (b, v) in enumerate(zip(buckets, views)):
+                farm_obj.submit(v, b.low, b.num_vertices, i)
+            farm_obj.finish()
+        stream_pass()                                   # warm-up
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            stream_pass()
+        st_s = (time.perf_counter() - t0) / args.steps
+        result["pcie_inclusive"] = {
+            "value": round(voxels / st_s / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(st_s * 1e3, 3),
+            "h2d_GB_per_step": round(bucketed.nbytes / 1e9, 3),
+            "h2d_GBps_sustained": round(bucketed.nbytes / st_s / 1e9, 2),
+            "note": "host (pageable numpy) -> pinned staging -> H2D -> device workers; meshes stay in HBM",
+        }
+        farm_obj.close()
 
     # ---- CPU baseline: the oracle ("port") on a bounded sample, rank 0 at N = 1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -237,6 +237,43 @@ mlsgpu_tree *mlsgpu_hip_worker_tree(mlsgpu_worker *w);
 mlsgpu_mls *mlsgpu_hip_worker_mls(mlsgpu_worker *w);
 mlsgpu_marching *mlsgpu_hip_worker_marching(mlsgpu_worker *w);
 
+/* ---- bucket farm: CopyGroup + one DeviceWorkerGroup per GPU (src/workers.h:214-438, src/workers.cpp:87-418,
+ *      assembled by SlaveWorkers, src/mlsgpu_core.cpp:704-741).  The caller plays BucketLoader: it hands over
+ *      host splats of one bucket at a time (already in grid coordinates, see mlsgpu_hip_transform_splats);
+ *      the farm batches buckets into device items of at most maxBucketSplats splats (CopyGroupBase::Worker::
+ *      operator(), :377-418), stages each batch in pinned memory (two buffers, so filling the next batch
+ *      overlaps the copy of the previous one), picks the device whose group can take an item and has the most
+ *      unallocated splat capacity (flush(), :315-375), copies host->device on that device's copy stream and
+ *      queues the item; `workersPerDevice` threads per GPU (--device-threads) process the buckets of an item
+ *      with mlsgpu_hip_worker_process after waiting for the item's copy event. ---- */
+typedef struct mlsgpu_farm mlsgpu_farm;
+typedef struct mlsgpu_farm_config
+{
+    uint32_t numDevices;
+    const int32_t *devices;        /* device ordinals; NULL = 0 .. numDevices-1 */
+    uint32_t workersPerDevice;     /* default 1 */
+    uint32_t spare;                /* extra device items per GPU beyond one per worker; default 1 */
+    mlsgpu_worker_config worker;   /* maxBucketSplats is also the capacity of a device item */
+} mlsgpu_farm_config;
+/* Output functor with the chunk it belongs to (OutputGenerator, src/workers.h:225).  Called on the worker's
+ * thread; `ctx` is that worker's context (use it for mlsgpu_hip_mesh_read).  NULL: meshes are only counted. */
+typedef int (*mlsgpu_farm_output_fn)(void *user, int device, uint64_t chunkId, mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh);
+int mlsgpu_hip_farm_create(const mlsgpu_farm_config *cfg, mlsgpu_farm_output_fn output, void *user, mlsgpu_farm **out);
+void mlsgpu_hip_farm_destroy(mlsgpu_farm *farm);
+/* CopyGroup::get + push for one bucket: copies the splats into the pinned staging buffer (flushing the
+ * current batch first if they do not fit).  Blocks while every device item is in use. */
+int mlsgpu_hip_farm_submit(mlsgpu_farm *farm, const mlsgpu_splat *hSplats, uint64_t numSplats,
+                           const int32_t lowExtent[3], const uint32_t numVertices[3], uint64_t chunkId);
+/* Flushes the last batch and waits until every queued bucket has been processed; reports the first error. */
+int mlsgpu_hip_farm_finish(mlsgpu_farm *farm);
+/* out[0] buckets, [1] splats copied, [2] H2D bytes, [3] device items, [4] ship-outs, [5] vertices, [6] triangles,
+ * [7] external vertices; per device d: out[8 + d] = buckets processed there (up to 16 devices). */
+int mlsgpu_hip_farm_stats(mlsgpu_farm *farm, uint64_t out[24]);
+/* BucketLoader's world -> grid transform (src/bucket_loader.cpp:77-85, Grid::worldToVertex src/grid.cpp:99-106):
+ * position = (position - reference) * (1/spacing) - lowExtent, radius *= 1/spacing.  Host-side, in place. */
+void mlsgpu_hip_transform_splats(mlsgpu_splat *hSplats, uint64_t numSplats, const float reference[3], float spacing,
+                                 const int32_t gridLowExtent[3]);
+
 /* DeviceWorkerGroupBase::computeMaxSwathe, src/workers.cpp:169-182 */
 uint32_t mlsgpu_hip_compute_max_swathe(uint32_t yMax, uint32_t y, uint32_t yAlign, uint32_t zAlign);
 

@@ -60,6 +60,14 @@ class WorkerConfig(C.Structure):
                 ("gridOrigin", C.c_float * 3)]
 
 
+class FarmConfig(C.Structure):
+    _fields_ = [("numDevices", C.c_uint32), ("devices", C.POINTER(C.c_int32)), ("workersPerDevice", C.c_uint32),
+                ("spare", C.c_uint32), ("worker", WorkerConfig)]
+
+
+FARM_OUTPUT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(Mesh))
+
+
 def library_path():
     return os.path.join(_HERE, "libmlsgpu_hip.so")
 
@@ -144,6 +152,12 @@ def lib():
     sig("mlsgpu_hip_worker_mls", vp, vp)
     sig("mlsgpu_hip_worker_marching", vp, vp)
     sig("mlsgpu_hip_compute_max_swathe", u32, u32, u32, u32, u32)
+    sig("mlsgpu_hip_farm_create", C.c_int, P(FarmConfig), FARM_OUTPUT_FN, vp, P(vp))
+    sig("mlsgpu_hip_farm_destroy", None, vp)
+    sig("mlsgpu_hip_farm_submit", C.c_int, vp, vp, u64, vp, vp, u64)
+    sig("mlsgpu_hip_farm_finish", C.c_int, vp)
+    sig("mlsgpu_hip_farm_stats", C.c_int, vp, vp)
+    sig("mlsgpu_hip_transform_splats", None, vp, u64, vp, f32, vp)
     sig("mlsgpu_hip_test_make_code", C.c_int, vp, C.c_int, C.c_int, C.c_int, P(u32))
     sig("mlsgpu_hip_test_level_shift", C.c_int, vp, vp, vp, P(i32))
     sig("mlsgpu_hip_test_point_box_dist2", C.c_int, vp, vp, vp, vp, P(f32))
@@ -557,3 +571,93 @@ class Worker:
         if getattr(self, "h", None):
             lib().mlsgpu_hip_worker_destroy(self.h)
             self.h = None
+
+
+class _BorrowedContext:
+    """A worker's context handed to an output functor: valid only during the call."""
+
+    def __init__(self, h):
+        self.h = h
+
+    def synchronize(self):
+        check(lib().mlsgpu_hip_ctx_synchronize(self.h))
+
+
+class BucketFarm:
+    """CopyGroup + one DeviceWorkerGroup per GPU (include/mlsgpu_hip.h, "bucket farm")."""
+
+    def __init__(self, devices, max_bucket_splats, workers_per_device=1, spare=1, collect=False, **worker_kw):
+        cfg = FarmConfig()
+        cfg.numDevices = len(devices)
+        self._devs = (C.c_int32 * len(devices))(*devices)
+        cfg.devices = C.cast(self._devs, C.POINTER(C.c_int32))
+        cfg.workersPerDevice = workers_per_device
+        cfg.spare = spare
+        w = cfg.worker
+        w.maxBucketSplats = max_bucket_splats
+        w.maxCells = worker_kw.get("max_cells", 255)
+        w.meshMemory = worker_kw.get("mesh_memory", 0)
+        w.levels = worker_kw.get("levels", 6)
+        w.subsampling = worker_kw.get("subsampling", 3)
+        w.boundaryLimit = worker_kw.get("boundary_limit", 1.0)
+        w.shape = worker_kw.get("shape", SHAPE_SPHERE)
+        w.maxSwathe = worker_kw.get("max_swathe", 0)
+        w.gridSpacing = worker_kw.get("grid_spacing", 1.0)
+        for i, v in enumerate(worker_kw.get("grid_origin", (0, 0, 0))):
+            w.gridOrigin[i] = v
+        self.meshes = {}          # chunkId -> list of batches (collect=True)
+        self.error = None
+        import threading
+        self._lock = threading.Lock()
+
+        def cb(user, device, chunk, ctxh, meshp):
+            try:
+                batch = read_mesh(_BorrowedContext(ctxh), meshp.contents)
+                batch["device"] = device
+                with self._lock:
+                    self.meshes.setdefault(int(chunk), []).append(batch)
+                return 0
+            except Exception as e:   # never let an exception cross the C boundary
+                self.error = e
+                return 1
+        self._cb = FARM_OUTPUT_FN(cb) if collect else C.cast(None, FARM_OUTPUT_FN)
+        h = C.c_void_p()
+        check(lib().mlsgpu_hip_farm_create(C.byref(cfg), self._cb, None, C.byref(h)))
+        self.h = h
+
+    def submit(self, splats, low_extent, num_vertices, chunk_id):
+        splats = np.ascontiguousarray(splats)
+        check(lib().mlsgpu_hip_farm_submit(self.h, _p(splats), len(splats), _p(_i3(low_extent)), _p(_u3(num_vertices)),
+                                           chunk_id))
+
+    def finish(self):
+        rc = lib().mlsgpu_hip_farm_finish(self.h)
+        if self.error is not None:
+            raise self.error
+        check(rc)
+
+    def stats(self):
+        out = np.zeros(24, np.uint64)
+        check(lib().mlsgpu_hip_farm_stats(self.h, _p(out)))
+        names = ["buckets", "splats", "h2d_bytes", "items", "shipouts", "vertices", "triangles", "external"]
+        d = dict(zip(names, [int(x) for x in out[:8]]))
+        d["per_device"] = [int(x) for x in out[8:24]]
+        return d
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mlsgpu_hip_farm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def transform_splats(splats, reference, spacing, low_extent):
+    """BucketLoader's world -> grid transform, in place (src/bucket_loader.cpp:77-85)."""
+    assert splats.dtype == SPLAT_DTYPE and splats.flags.c_contiguous
+    lib().mlsgpu_hip_transform_splats(_p(splats), len(splats), _p(np.ascontiguousarray(reference, np.float32)),
+                                      spacing, _p(_i3(low_extent)))
