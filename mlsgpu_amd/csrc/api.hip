@@ -7,6 +7,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 
 using namespace mlsgpu;
@@ -102,8 +103,10 @@ MLSGPU_API int mlsgpu_hip_ctx_create(int device, void *stream, mlsgpu_ctx **out)
     HIP_CHECK(hipGetDeviceCount(&count));
     REQUIRE(device >= 0 && device < count, MLSGPU_ERR_INVALID);
     HIP_CHECK(hipSetDevice(device));
+    static std::atomic<uint64_t> nextSerial{1};
     mlsgpu_ctx *ctx = new mlsgpu_ctx;
     ctx->device = device;
+    ctx->serial = nextSerial++;
     if (stream != nullptr)
     {
         ctx->stream = static_cast<hipStream_t>(stream);

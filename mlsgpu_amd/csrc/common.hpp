@@ -65,6 +65,7 @@ struct PendingTiming
 struct mlsgpu_ctx
 {
     int device = 0;
+    uint64_t serial = 0;              /* unique per context: call sites cache stat ids against it, not the address */
     hipStream_t stream = nullptr;
     bool ownStream = false;
     bool timing = false;
@@ -87,10 +88,10 @@ namespace mlsgpu
 #define LAUNCH(ctx, statName, kernel, grid, block, ...)                                       \
     do {                                                                                      \
         static thread_local int statId__ = -1;                                                \
-        static thread_local mlsgpu_ctx *statCtx__ = nullptr;                                  \
+        static thread_local uint64_t statCtx__ = 0;                                           \
         int pend__ = -1;                                                                      \
         if ((ctx)->timing) {                                                                  \
-            if (statCtx__ != (ctx)) { statId__ = (ctx)->statId(statName); statCtx__ = (ctx); } \
+            if (statCtx__ != (ctx)->serial) { statId__ = (ctx)->statId(statName); statCtx__ = (ctx)->serial; } \
             pend__ = (ctx)->beginTiming(statId__);                                            \
         }                                                                                     \
         hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);               \

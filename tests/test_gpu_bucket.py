@@ -161,3 +161,45 @@ def test_cfg2_full_size_properties(ctx):
         digests.append(mesh_digest(batches))
         del w, buf
     assert digests[0] == digests[1] == digests[2]
+
+
+def test_cfg3_shape_scaled_cross_bucket_properties(ctx):
+    """BASELINE config 2's shape (512^3 grid, 27 buckets; "shells" cloud at 20 % of the splat count), with per-kernel
+    timing enabled on a context that outlives several workers.  Size-independent properties: the buckets tile
+    the grid, every external vertex that two buckets share has one key and bit-identical coordinates from both
+    sides, no key occurs more than 8 times, and the union of the meshes has no degenerate triangle."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import synth
+    cloud, g = synth.make_cloud("cfg3", dist="shells", scale=0.2)
+    allb, buckets = synth.bucketize(cloud, g, 255)
+    assert len(buckets) == 27 and sum(b.cells for b in buckets) == (g - 1) ** 3
+    ctx.set_timing(True)
+    w = m.Worker(ctx, max(b.count for b in buckets), max_cells=max(max(b.num_vertices) for b in buckets) - 1,
+                 mesh_memory=1 << 30)
+    buf = m.DeviceBuffer(ctx, array=allb)
+    keys, verts = [], []
+    tris = 0
+    for b in buckets:
+        for batch in w.process(buf, b.first, b.count, b.low, b.num_vertices):
+            ni = batch["num_internal"]
+            keys.append(batch["keys"][ni:])
+            verts.append(batch["vertices"][ni:])
+            t = batch["triangles"]
+            tris += len(t)
+            assert np.all(t[:, 0] != t[:, 1]) and np.all(t[:, 1] != t[:, 2]) and np.all(t[:, 0] != t[:, 2])
+            lo = np.array(b.low, np.float32)
+            hi = lo + np.array(b.num_vertices, np.float32) - 1
+            assert np.all(batch["vertices"] >= lo) and np.all(batch["vertices"] <= hi)
+    ctx.set_timing(False)
+    stats = ctx.stats()
+    assert stats["kernel.mls.processCorners.time"][1] == 27 and stats["kernel.mls.processCorners.time"][0] > 0
+    assert tris > 0
+    keys = np.concatenate(keys)
+    verts = np.concatenate(verts)
+    order = np.argsort(keys, kind="stable")
+    keys, verts = keys[order], verts[order].view(np.uint32)
+    same = keys[1:] == keys[:-1]
+    assert same.any()                                                   # buckets do share vertices
+    assert np.all(verts[1:][same] == verts[:-1][same])                  # ... and agree on them bit for bit
+    _, counts = np.unique(keys, return_counts=True)
+    assert counts.max() <= 8
