@@ -172,6 +172,8 @@ struct DevTables
     const ushort2 *start;    /* [257] */
     const uint8_t *data;     /* [8192] */
     const uint32_t *key;     /* [2432] kx | ky<<8 | kz<<16 */
+    const uint32_t *rec;     /* [256][16] per-code record for the lattice weld: words 0-1 = 6-bit keys (kx | ky<<2 | kz<<4) of
+                              * vertices 0..9, word 2 = vertices 10..12, word 3 = nv | ni << 8, words 4..12 = index bytes */
 };
 
 struct FieldView
@@ -880,16 +882,27 @@ __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeVie
         const uint2 cell = cells[gid];
         const uint32_t x = cell.x & 0xFFFFu, y = cell.x >> 16, z = cell.y;
         const uint32_t code = C.at(x, y, z);
-        const ushort2 st = T.start[code], en = T.start[code + 1];
-        const uint32_t nv = en.x - st.x, ni = en.y - st.y;
+        /* one 16-byte load gives the code's vertex keys and counts; its index list follows as aligned words */
+        const uint32_t *rec = T.rec + code * 16;
+        const uint4 r0 = *reinterpret_cast<const uint4 *>(rec);
+        const uint32_t nv = r0.w & 0xFFu, ni = r0.w >> 8;
+        const uint64_t klo = (uint64_t) r0.x | ((uint64_t) r0.y << 32);
         for (uint32_t i = 0; i < nv; i++)
         {
-            const uint32_t k = T.key[st.x + i];
-            sIdx[threadIdx.x][i] = L.index(2 * x + (k & 0xFF), 2 * y + ((k >> 8) & 0xFF), 2 * z + (k >> 16));
+            const uint32_t k = (i < 10 ? (uint32_t) (klo >> (6 * i)) : (r0.z >> (6 * (i - 10)))) & 63u;
+            sIdx[threadIdx.x][i] = L.index(2 * x + (k & 3), 2 * y + ((k >> 2) & 3), 2 * z + (k >> 4));
         }
         const uint32_t local = viStart[gid].y - blockBase;
-        for (uint32_t i = 0; i < ni; i++)
-            sRef[local + i] = (uint16_t) ((threadIdx.x << 4) | T.data[st.y + i]);
+        const uint32_t tidBits = threadIdx.x << 4;
+        for (uint32_t q = 0; 4 * q < ni; q++)
+        {
+            const uint32_t wd = rec[4 + q];
+            const uint32_t left = ni - 4 * q;
+            sRef[local + 4 * q] = (uint16_t) (tidBits | (wd & 0xFF));
+            if (left > 1) sRef[local + 4 * q + 1] = (uint16_t) (tidBits | ((wd >> 8) & 0xFF));
+            if (left > 2) sRef[local + 4 * q + 2] = (uint16_t) (tidBits | ((wd >> 16) & 0xFF));
+            if (left > 3) sRef[local + 4 * q + 3] = (uint16_t) (tidBits | (wd >> 24));
+        }
         if (gid == numCells - 1 || threadIdx.x == blockDim.x - 1)
             sSpan = local + ni;
     }
@@ -936,6 +949,7 @@ struct mlsgpu_marching
     ushort2 *dStart = nullptr;
     uint8_t *dData = nullptr;
     uint32_t *dKey = nullptr;
+    uint32_t *dCodeRec = nullptr;
     uint2 *dCells = nullptr, *dViStart = nullptr, *dHistogram = nullptr;
     U3 *dTileSums3 = nullptr;
     float4 *dVertices = nullptr;
@@ -974,7 +988,7 @@ struct mlsgpu_marching
 
     FieldView view(const mlsgpu_swathe &sw) const { return FieldView{dField, imageWidth, sw.zStride, sw.zBias}; }
     CodeView codeView(const mlsgpu_swathe &sw) const { return CodeView{dCellCode, sw.width - 1, sw.height - 1, codeZ0}; }
-    DevTables devTables() const { return DevTables{dCount, dStart, dData, dKey}; }
+    DevTables devTables() const { return DevTables{dCount, dStart, dData, dKey, dCodeRec}; }
 
     int generateCells(const mlsgpu_swathe &sw, U3 *totals);
     int sliceHistogram(const mlsgpu_swathe &sw);
@@ -1082,6 +1096,7 @@ MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, ui
     alloc((void **) &m->dStart, 257 * 4);
     alloc((void **) &m->dData, 8192);
     alloc((void **) &m->dKey, 2432 * 4);
+    alloc((void **) &m->dCodeRec, 256 * 16 * 4);
     alloc((void **) &m->dCells, sc * 8);
     alloc((void **) &m->dViStart, sc * 8);
     alloc((void **) &m->dHistogram, (uint64_t) maxDepth * 8);
@@ -1123,7 +1138,26 @@ MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, ui
     std::vector<uint32_t> packedKey(2432);
     for (int i = 0; i < 2432; i++)
         packedKey[i] = m->tables.key[3 * i] | (m->tables.key[3 * i + 1] << 8) | (m->tables.key[3 * i + 2] << 16);
+    std::vector<uint32_t> codeRec(256 * 16, 0u);
+    for (int c = 0; c < 256; c++)
+    {
+        const uint32_t sv = m->tables.start[c][0], si = m->tables.start[c][1];
+        const uint32_t nv = m->tables.count[c][0], ni = m->tables.count[c][1];
+        uint64_t klo = 0;
+        uint32_t khi = 0;
+        for (uint32_t i = 0; i < nv; i++)
+        {
+            const uint32_t *k3 = &m->tables.key[3 * (sv + i)];
+            const uint64_t k6 = k3[0] | (k3[1] << 2) | (k3[2] << 4);
+            if (i < 10) klo |= k6 << (6 * i); else khi |= (uint32_t) k6 << (6 * (i - 10));
+        }
+        uint32_t *rec = &codeRec[c * 16];
+        rec[0] = (uint32_t) klo; rec[1] = (uint32_t) (klo >> 32); rec[2] = khi; rec[3] = nv | (ni << 8);
+        for (uint32_t i = 0; i < ni; i++)
+            rec[4 + i / 4] |= (uint32_t) m->tables.data[si + i] << (8 * (i % 4));
+    }
     hipError_t e = hipMemcpy(m->dCount, m->tables.count, 512, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(m->dCodeRec, codeRec.data(), codeRec.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->dStart, m->tables.start, 257 * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->dData, m->tables.data.data(), 8192, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->dKey, packedKey.data(), 2432 * 4, hipMemcpyHostToDevice);
@@ -1141,7 +1175,7 @@ MLSGPU_API void mlsgpu_hip_marching_destroy(mlsgpu_marching *m)
     if (!m)
         return;
     hipSetDevice(m->ctx->device);
-    hipFree(m->dField); hipFree(m->dCount); hipFree(m->dStart); hipFree(m->dData); hipFree(m->dKey);
+    hipFree(m->dField); hipFree(m->dCount); hipFree(m->dStart); hipFree(m->dData); hipFree(m->dKey); hipFree(m->dCodeRec);
     hipFree(m->dCells); hipFree(m->dViStart); hipFree(m->dHistogram); hipFree(m->dTileSums3);
     hipFree(m->dVertices); hipFree(m->dKeysA); hipFree(m->dKeysB); hipFree(m->dValsA); hipFree(m->dValsB);
     hipFree(m->dIndices); hipFree(m->dIndexRemap); hipFree(m->dWelded); hipFree(m->dWeldedKeys);

@@ -32,6 +32,7 @@ struct mlsgpu_tree
     int32_t *dStart = nullptr, *dJumpPos = nullptr, *dCommands = nullptr;
     uint32_t *dKeysA = nullptr, *dKeysB = nullptr, *dValsA = nullptr, *dValsB = nullptr;
     uint32_t *dHist = nullptr, *dTileSums = nullptr, *dNumEntries = nullptr;
+    uint8_t *dSlotMasks = nullptr;      /* per splat: which of its 8 candidate slots are real entries */
     mlsgpu_splat *dSplats = nullptr;   /* borrowed between build and clear_splats */
 };
 
@@ -149,34 +150,54 @@ __device__ __forceinline__ uint32_t splatEntries(const EntryParams &P, const flo
  * Producer: number of real entries of splat i.  Consumer: writes them at the scanned position and
  * replaces splat.w by 1/r^2 (:193).
  */
-struct EntryCountIn
+struct EntryCountIn            /* phase 1: evaluates the splat, remembers which slots are real entries */
 {
     EntryParams P;
+    uint8_t *slotMasks;
     __device__ __forceinline__ uint32_t operator()(uint64_t i) const
     {
         const float4 pr = reinterpret_cast<const float4 *>(P.splats + (i + P.firstSplat))[0];
         uint32_t k[8];
-        return (uint32_t) __popc(splatEntries(P, pr, k));
+        const uint32_t mask = splatEntries(P, pr, k);
+        slotMasks[i] = (uint8_t) mask;
+        return (uint32_t) __popc(mask);
     }
+};
+
+struct EntryMaskIn             /* phase 2: the count again, from the remembered mask */
+{
+    const uint8_t *slotMasks;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return (uint32_t) __popc((uint32_t) slotMasks[i]); }
 };
 
 struct EntryWriteOut
 {
     EntryParams P;
+    const uint8_t *slotMasks;
     uint32_t *keys, *values;
     __device__ __forceinline__ void operator()(uint64_t i, uint32_t pos, uint32_t) const
     {
         const uint32_t gid = (uint32_t) i + P.firstSplat;
         float4 *sp = reinterpret_cast<float4 *>(P.splats + gid);
         const float4 pr = sp[0];
-        uint32_t k[8];
-        const uint32_t mask = splatEntries(P, pr, k);
         reinterpret_cast<float *>(sp)[3] = 1.0f / (pr.w * pr.w);
+        const uint32_t mask = slotMasks[i];
+        if (mask == 0)
+            return;
+        /* prepare (octree.cl:79-90) again for the node coordinates; the box tests are not repeated */
+        const int lox = floorToInt(pr.x - pr.w), loy = floorToInt(pr.y - pr.w), loz = floorToInt(pr.z - pr.w);
+        const int hix = floorToInt(pr.x + pr.w), hiy = floorToInt(pr.y + pr.w), hiz = floorToInt(pr.z + pr.w);
+        int shift = levelShift(lox, loy, loz, hix, hiy, hiz);
+        shift = min(max(shift, P.minShift), P.maxShift);
+        const int ilx = max(lox - P.bx, 0) >> shift;
+        const int ily = max(loy - P.by, 0) >> shift;
+        const int ilz = max(loz - P.bz, 0) >> shift;
+        const uint32_t levelOffset = P.levelOffsets.v[shift];
 #pragma unroll
         for (int o = 0; o < 8; o++)
             if (mask & (1u << o))
             {
-                keys[pos] = k[o];
+                keys[pos] = makeCode(ilx + (o & 1), ily + ((o >> 1) & 1), ilz + (o >> 2)) + levelOffset;
                 values[pos] = gid;
                 pos++;
             }
@@ -342,6 +363,7 @@ MLSGPU_API int mlsgpu_hip_tree_create(mlsgpu_ctx *ctx, uint64_t maxLevels, uint6
     alloc((void **) &t->dHist, histElems * 4);
     alloc((void **) &t->dTileSums, tileSums * 4);
     alloc((void **) &t->dNumEntries, 4);
+    alloc((void **) &t->dSlotMasks, maxSplats);
     if (rc != MLSGPU_OK)
     {
         mlsgpu_hip_tree_destroy(t);
@@ -358,7 +380,7 @@ MLSGPU_API void mlsgpu_hip_tree_destroy(mlsgpu_tree *t)
     hipSetDevice(t->ctx->device);
     hipFree(t->dStart); hipFree(t->dJumpPos); hipFree(t->dCommands);
     hipFree(t->dKeysA); hipFree(t->dKeysB); hipFree(t->dValsA); hipFree(t->dValsB);
-    hipFree(t->dHist); hipFree(t->dTileSums); hipFree(t->dNumEntries);
+    hipFree(t->dHist); hipFree(t->dTileSums); hipFree(t->dNumEntries); hipFree(t->dSlotMasks);
     delete t;
 }
 
@@ -402,9 +424,12 @@ MLSGPU_API int mlsgpu_hip_tree_build(mlsgpu_tree *t, mlsgpu_splat *dSplats, uint
     {
         EntryParams P{dSplats, offset[0], offset[1], offset[2], lo, minShift, maxShift, (uint32_t) firstSplat};
         /* writeEntries: count, scan, write compacted; the entry count stays on the device (t->dNumEntries) */
-        PROPAGATE((exclusiveScan<uint32_t>(ctx, "kernel.octree.writeEntries.time", EntryCountIn{P},
-                                           EntryWriteOut{P, t->dKeysA, t->dValsA}, numSplats, 0u,
-                                           t->dTileSums, t->dNumEntries)));
+        PROPAGATE((scanPhase1<uint32_t, EntryCountIn>(ctx, "kernel.octree.writeEntries.time", EntryCountIn{P, t->dSlotMasks},
+                                                      numSplats, 0u, t->dTileSums, t->dNumEntries)));
+        PROPAGATE((scanPhase2<uint32_t, EntryMaskIn, EntryWriteOut>(ctx, "kernel.octree.writeEntries.time",
+                                                                    EntryMaskIn{t->dSlotMasks},
+                                                                    EntryWriteOut{P, t->dSlotMasks, t->dKeysA, t->dValsA},
+                                                                    numSplats, (const uint32_t *) t->dTileSums)));
         SortResult<uint32_t> sorted;
         PROPAGATE(radixSort<uint32_t>(ctx, "kernel.octree.sort.time", t->dKeysA, t->dValsA, t->dKeysB, t->dValsB,
                                       maxEntries, (uint32_t) (3 * (maxShift - minShift) + 1), false,
