@@ -17,6 +17,8 @@
 
 #include "common.hpp"
 
+#include <cstdlib>
+
 namespace mlsgpu
 {
 
@@ -395,7 +397,14 @@ static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *
     const uint32_t tiles = scanTiles(n);
     if (bits == 0)
         bits = 1;    /* still run one pass so that iota values are materialised */
-    const uint32_t passes = sortPasses(bits, SortCaps<K>::MAX_DIGIT_BITS);
+    uint32_t maxDigit = SortCaps<K>::MAX_DIGIT_BITS;
+    if (const char *e = getenv("MLSGPU_HIP_SORT_DIGIT_BITS"))     /* tuning aid: narrower digits, more passes */
+    {
+        const uint32_t v = (uint32_t) atoi(e);
+        if (v >= 1 && v < maxDigit)
+            maxDigit = v;
+    }
+    const uint32_t passes = sortPasses(bits, maxDigit);
     const uint32_t perPass = (bits + passes - 1) / passes;
     uint32_t shift = 0;
     K *kin = keysA, *kout = keysB;
