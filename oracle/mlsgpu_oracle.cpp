@@ -46,7 +46,6 @@
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
-#include <parallel/algorithm>
 #endif
 
 #define ORC_API extern "C" __attribute__((visibility("default")))
@@ -226,8 +225,7 @@ static int treeBuild(Splat *splats, size_t firstSplat, size_t numSplats,
     std::vector<uint32_t> keys(numEntries);
     std::vector<uint32_t> values(numEntries);
 
-    /* writeEntries, kernels/octree.cl:159-214 (+prepare :79-90, goodEntry :100-110); splats are independent */
-#pragma omp parallel for schedule(static)
+    /* writeEntries, kernels/octree.cl:159-214 (+prepare :79-90, goodEntry :100-110) */
     for (size_t i = 0; i < numSplats; i++)
     {
         size_t gid = i + firstSplat;
@@ -851,15 +849,7 @@ public:
             viHistogram[2 * z] = viHistogram[2 * z + 1] = 0;
         cells.clear();
         viCount.clear();
-        /* slices are classified in parallel and concatenated in slice order: still cell-linear (z, y, x) */
-        const int nSlices = (int) (sw.zLast - sw.zFirst);
-        std::vector<std::vector<uint32_t> > sliceCells(std::max(nSlices, 0)), sliceCounts(std::max(nSlices, 0));
-#pragma omp parallel for schedule(dynamic, 1)
-        for (int zi = 0; zi < nSlices; zi++)
-        {
-            const uint32_t z = sw.zFirst + (uint32_t) zi;
-            std::vector<uint32_t> &sc = sliceCells[zi], &sv = sliceCounts[zi];
-            uint32_t hv = 0, hi = 0;
+        for (uint32_t z = sw.zFirst; z < sw.zLast; z++)
             for (uint32_t y = 0; y + 1 < sw.height; y++)
                 for (uint32_t x = 0; x + 1 < sw.width; x++)
                 {
@@ -876,21 +866,13 @@ public:
                     }
                     if (valid && code != 0 && code != 255)
                     {
-                        sc.push_back(x); sc.push_back(y); sc.push_back(z);
+                        cells.push_back(x); cells.push_back(y); cells.push_back(z);
                         uint32_t nv = tables.count[code][0], ni = tables.count[code][1];
-                        sv.push_back(nv); sv.push_back(ni);
-                        hv += nv;
-                        hi += ni;
+                        viCount.push_back(nv); viCount.push_back(ni);
+                        viHistogram[2 * z] += nv;
+                        viHistogram[2 * z + 1] += ni;
                     }
                 }
-            viHistogram[2 * z] = hv;
-            viHistogram[2 * z + 1] = hi;
-        }
-        for (int zi = 0; zi < nSlices; zi++)
-        {
-            cells.insert(cells.end(), sliceCells[zi].begin(), sliceCells[zi].end());
-            viCount.insert(viCount.end(), sliceCounts[zi].begin(), sliceCounts[zi].end());
-        }
         return cells.size() / 3;
     }
 
@@ -898,22 +880,9 @@ public:
     void generateElements(const Swathe &sw, size_t compacted, const uint32_t offsets[2],
                           const uint32_t gridOffset[3], const uint32_t top[3])
     {
-        /* scanElements (src/marching.cpp:721): each cell's first vertex / index slot, then cells are independent */
-        std::vector<uint32_t> vStart(compacted), iStart(compacted);
-        {
-            uint32_t v = offsets[0], i = offsets[1];
-            for (size_t gid = 0; gid < compacted; gid++)
-            {
-                vStart[gid] = v;
-                iStart[gid] = i;
-                v += viCount[2 * gid];
-                i += viCount[2 * gid + 1];
-            }
-        }
-#pragma omp parallel for schedule(static)
+        uint32_t vNext = offsets[0], iNext = offsets[1];
         for (size_t gid = 0; gid < compacted; gid++)
         {
-            const uint32_t vNext = vStart[gid], iNext = iStart[gid];
             const uint32_t cell[3] = {cells[3 * gid], cells[3 * gid + 1], cells[3 * gid + 2]};
             const uint32_t y0 = cell[2] * sw.zStride + sw.zBias + cell[1];
             const uint32_t y1 = y0 + sw.zStride;
@@ -945,6 +914,8 @@ public:
             }
             for (uint32_t i = 0; i < ni; i++)
                 indices[iNext + i] = vNext + tables.data[st[1] + i];
+            vNext += nv;
+            iNext += ni;
         }
     }
 
@@ -956,16 +927,10 @@ public:
         /* sortVertices: stable, all 64 bits (maxBits = 0), src/marching.cpp:572 */
         std::vector<uint32_t> order(nv);
         for (size_t i = 0; i < nv; i++) order[i] = (uint32_t) i;
-#ifdef _OPENMP
-        __gnu_parallel::stable_sort(order.begin(), order.end(),
-                                    [&](uint32_t a, uint32_t b) { return unweldedKeys[a] < unweldedKeys[b]; });
-#else
         std::stable_sort(order.begin(), order.end(),
                          [&](uint32_t a, uint32_t b) { return unweldedKeys[a] < unweldedKeys[b]; });
-#endif
         std::vector<uint64_t> sk(nv + 1);
         std::vector<float> sv(nv * 4);
-#pragma omp parallel for schedule(static)
         for (size_t i = 0; i < nv; i++)
         {
             sk[i] = unweldedKeys[order[i]];
@@ -994,7 +959,6 @@ public:
                         vertexUnique.data(), sv.data(), sk.data(), minExternalKey, keyOffsetL, nv);
         /* reindex, kernels/marching.cl:334-340 */
         std::vector<uint32_t> tri(ni + 1);
-#pragma omp parallel for schedule(static)
         for (size_t i = 0; i < ni; i++)
             tri[i] = indexRemap[indices[i]];
         stats.shipOuts++;
