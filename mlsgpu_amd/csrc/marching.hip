@@ -613,19 +613,28 @@ __global__ void computeKeyTestKernel(uint32_t cx, uint32_t cy, uint32_t cz, uint
  * Rows are (z2, y2); each row is a bit mask over x2 plus per-word prefix counts, so an index is
  * rowStart[class] + wordPrefix + popcount -- three small L2-resident reads instead of a global sort.
  */
-/* one 64-point word of a row: existence bits + number of main-class vertices in the row's earlier words */
+/* One 64-point word of a row, 16 bytes, everything a lookup needs in ONE load:
+ *   mask    existence bits of the row's MAIN class (all points of a class-2 row; a class-0/1 row without its two
+ *           class-2 columns x2 == 0 and x2 == top.x)
+ *   prefix  output index of the first main-class vertex of this word (row-relative until latticePatchKernel
+ *           adds the row's start)
+ *   flag    class-0/1 rows: output index of the row's first class-2 vertex, bit 31 = a vertex exists at x2 == 0,
+ *           bit 30 = one exists at x2 == top.x (latticeMaskKernel sets each bit in the word that holds the column;
+ *           latticePatchKernel copies both into every word of the row and adds the index) */
 struct LatWord
 {
     uint64_t mask;
     uint32_t prefix;
-    uint32_t pad;
+    uint32_t flag;
 };
+#define LAT_FLAG_X0 0x80000000u
+#define LAT_FLAG_TOP 0x40000000u
+#define LAT_FLAG_INDEX 0x3FFFFFFFu
 
 struct Lattice
 {
     LatWord *words;          /* [rows][nw] */
     U3 *rowCounts;           /* [rows] vertices per class; exclusive-scanned in place into per-class row starts */
-    uint4 *rowInfo;          /* [rows] after the scan: (first main-class index, first flagged index, bit0, row class) */
     const U3 *totals;        /* device: class totals after the scan */
     uint32_t nw;             /* 64-bit words per row */
     uint32_t rowsPerLayer;   /* 2H - 1 */
@@ -647,24 +656,6 @@ struct Lattice
         if (w == (topx >> 6))
             m |= 1ull << (topx & 63);
         return m;
-    }
-    /* output index of the vertex at an existing point, given its row's info record and its word */
-    __device__ __forceinline__ uint32_t indexFrom(const uint4 info, const LatWord wd, uint32_t x2) const
-    {
-        const uint64_t below = wd.mask & ((1ull << (x2 & 63)) - 1);
-        if (info.w == 2)
-            return info.x + wd.prefix + (uint32_t) __popcll(below);
-        if (x2 == 0)
-            return info.y;
-        if (x2 == topx)
-            return info.y + info.z;
-        return info.x + wd.prefix + (uint32_t) __popcll(below & ~columnMask(x2 >> 6));
-    }
-    /* two 16-byte loads per lookup, both L2-resident and shared by neighbouring cells */
-    __device__ __forceinline__ uint32_t index(uint32_t x2, uint32_t y2, uint32_t z2) const
-    {
-        const uint32_t row = (z2 - z2First) * rowsPerLayer + y2;
-        return indexFrom(rowInfo[row], words[(uint64_t) row * nw + (x2 >> 6)], x2);
     }
 };
 
@@ -730,16 +721,25 @@ __global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, 
         running[h] = nFlag[h] = 0;
     }
     uint32_t prev[2][2] = {{0, 0}, {0, 0}};
+    /* the code bytes of the next 64 corners are requested before this chunk's ballots, so the loop is not one
+     * memory latency per chunk */
+    uint32_t next[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+        for (int dz = 0; dz < 2; dz++)
+            next[dy][dz] = (rowOk[dy][dz] && lane < L.cw) ? rowPtr[dy][dz][lane] : 0u;
     for (uint32_t x0 = 0; x0 < W; x0 += 64)
     {
-        const uint32_t x = x0 + lane;
         uint32_t c[2][2], m[2][2];
 #pragma unroll
         for (int dy = 0; dy < 2; dy++)
 #pragma unroll
             for (int dz = 0; dz < 2; dz++)
             {
-                c[dy][dz] = (rowOk[dy][dz] && x < L.cw) ? rowPtr[dy][dz][x] : 0u;
+                c[dy][dz] = next[dy][dz];
+                const uint32_t xn = x0 + 64 + lane;
+                next[dy][dz] = (rowOk[dy][dz] && xn < L.cw) ? rowPtr[dy][dz][xn] : 0u;
                 const uint32_t up = __shfl_up(c[dy][dz], 1, 64);
                 m[dy][dz] = lane == 0 ? prev[dy][dz] : up;
                 prev[dy][dz] = readLane(c[dy][dz], 63);
@@ -780,10 +780,13 @@ __global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, 
                     continue;
                 const uint64_t bits = spreadBits(even[h] >> (32 * half)) | (spreadBits(odd[h] >> (32 * half)) << 1);
                 const uint64_t cm = rowCls[h] == 2 ? 0ull : L.columnMask(w);
+                const uint64_t col = bits & cm;
+                const uint64_t topBit = w == (L.topx >> 6) ? 1ull << (L.topx & 63) : 0ull;
+                const uint32_t colBits = ((w == 0 && (col & 1ull)) ? LAT_FLAG_X0 : 0u) | ((col & topBit) ? LAT_FLAG_TOP : 0u);
                 if (lane == 0)
-                    L.words[(uint64_t) rowId[h] * L.nw + w] = LatWord{bits, running[h], 0u};
+                    L.words[(uint64_t) rowId[h] * L.nw + w] = LatWord{bits & ~cm, running[h], colBits};
                 running[h] += (uint32_t) __popcll(bits & ~cm);
-                nFlag[h] += (uint32_t) __popcll(bits & cm);
+                nFlag[h] += (uint32_t) __popcll(col);
             }
         }
     }
@@ -802,69 +805,120 @@ __global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, 
     }
 }
 
-/* After the scan of the row counts: one 16-byte record per row with everything a lookup needs. */
-__global__ __launch_bounds__(256) void latticeRowInfoKernel(Lattice L, uint32_t numRows)
+/* After the scan of the row counts, one thread per word: make the word's prefix an absolute output index and
+ * give every word of a class-0/1 row the row's class-2 start and its two column bits. */
+__global__ __launch_bounds__(256) void latticePatchKernel(Lattice L, uint32_t numWords)
 {
-    const uint32_t row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= numRows)
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= numWords)
         return;
+    const uint32_t row = i / L.nw;
     const uint32_t z2 = row / L.rowsPerLayer + L.z2First, y2 = row % L.rowsPerLayer;
     const uint32_t rc = L.rowClass(y2, z2);
     const U3 rs = L.rowCounts[row];
     const U3 tot = *L.totals;
     const uint32_t off2 = tot.a + tot.b;
     const uint32_t mainBase = rc == 0 ? rs.a : (rc == 1 ? tot.a + rs.b : off2 + rs.c);
-    L.rowInfo[row] = make_uint4(mainBase, off2 + rs.c, (uint32_t) (L.words[(uint64_t) row * L.nw].mask & 1), rc);
+    /* bits 31 / 30 of word 0 / the top word keep their value through this kernel, so rows that straddle blocks are safe */
+    const uint32_t x0 = L.words[(uint64_t) row * L.nw].flag & LAT_FLAG_X0;
+    const uint32_t top = L.words[(uint64_t) row * L.nw + (L.topx >> 6)].flag & LAT_FLAG_TOP;
+    L.words[i].prefix += mainBase;
+    L.words[i].flag = (off2 + rs.c) | x0 | top;
 }
 
-/* One wave per row: positions (interp, kernels/marching.cl:130-138) and external keys of the existing points. */
+/* One wave per row: positions (interp, kernels/marching.cl:130-138) and external keys of the existing points.
+ * The row's words come through the scalar unit; the field values of up to four words are requested before the
+ * first is used (the kernel is bound by memory latency, not bytes). */
 __global__ __launch_bounds__(256) void latticeVerticesKernel(Lattice L, FieldView F, float *outVertices, uint64_t *outKeys,
                                                              uint32_t gox, uint32_t goy, uint32_t goz,
                                                              uint64_t keyOffset, VertexTransform X, uint32_t numRows)
 {
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint32_t row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row >= numRows)
         return;
     const uint32_t z2 = row / L.rowsPerLayer + L.z2First, y2 = row % L.rowsPerLayer;
     const uint32_t cz = z2 >> 1, pz = z2 & 1, cy = y2 >> 1, py = y2 & 1;
-    const uint4 info = L.rowInfo[row];
-    for (uint32_t w = 0; w < L.nw; w++)
+    const bool rowExternal = L.rowClass(y2, z2) != 0;
+    const bool rowFlagged = L.rowClass(y2, z2) == 2;
+    const uint32_t rowA = cy + F.zStride * cz + (uint32_t) F.zBias;
+    const uint32_t rowB = (cy + py) + F.zStride * (cz + pz) + (uint32_t) F.zBias;
+    const float *fieldA = F.field + (uint64_t) rowA * F.pitch;
+    const float *fieldB = F.field + (uint64_t) rowB * F.pitch;
+    const uint32_t px = lane & 1;
+    const LatWord *rowWords = L.words + (uint64_t) row * L.nw;
+    constexpr int G = 4;
+    for (uint32_t w0 = 0; w0 < L.nw; w0 += G)
     {
-        const LatWord wd = L.words[(uint64_t) row * L.nw + w];
-        if (!((wd.mask >> lane) & 1))
-            continue;
-        const uint32_t x2 = w * 64 + lane;
-        const uint32_t idx = L.indexFrom(info, wd, x2);
-        const bool flagged = info.w != 0 || x2 == 0 || x2 == L.topx;    /* class 1 or 2: external */
-        const uint32_t cx = x2 >> 1, px = x2 & 1;
-        /* endpoint A = owner corner, B = A + (px,py,pz): A has the lower local corner id in every cell */
-        const uint32_t rowA = cy + F.zStride * cz + (uint32_t) F.zBias;
-        const uint32_t rowB = (cy + py) + F.zStride * (cz + pz) + (uint32_t) F.zBias;
-        const float iso0 = F.at(cx, rowA), iso1 = F.at(cx + px, rowB);
-        const float inv = 1.0f / (iso0 - iso1);
-        const float t = iso0 * inv;
-        float vx = fmaf(t, (float) px, (float) (cx + gox));
-        float vy = fmaf(t, (float) py, (float) (cy + goy));
-        float vz = fmaf(t, (float) pz, (float) (cz + goz));
-        if (X.enabled)
+        LatWord wd[G];
+        float iso0[G], iso1[G];
+#pragma unroll
+        for (int j = 0; j < G; j++)
         {
-            vx = fmaf(vx, X.scale, X.bx);
-            vy = fmaf(vy, X.scale, X.by);
-            vz = fmaf(vz, X.scale, X.bz);
+            const uint32_t w = w0 + j < L.nw ? w0 + j : L.nw - 1;
+            wd[j] = rowWords[w];
+            /* every lane loads (clamped inside the row), so the loads do not wait on the masks */
+            const uint32_t cx = min(w * 32 + (lane >> 1), L.cw - px);
+            iso0[j] = fieldA[cx];
+            iso1[j] = fieldB[cx + px];
         }
-        outVertices[3 * (uint64_t) idx + 0] = vx;
-        outVertices[3 * (uint64_t) idx + 1] = vy;
-        outVertices[3 * (uint64_t) idx + 2] = vz;
-        if (flagged)
-            outKeys[idx] = (((uint64_t) z2 << (2 * KEY_AXIS_BITS)) | ((uint64_t) y2 << KEY_AXIS_BITS) | (uint64_t) x2) + keyOffset;
+#pragma unroll
+        for (int j = 0; j < G; j++)
+        {
+            if (w0 + j >= L.nw)
+                break;
+            const uint32_t x2 = (w0 + j) * 64 + lane;
+            uint64_t exists = wd[j].mask;
+            bool column = false;
+            uint32_t idx = wd[j].prefix + (uint32_t) __popcll(exists & ((1ull << lane) - 1));
+            if (!rowFlagged)
+            {
+                /* the row's two class-2 points are not in the mask */
+                if (x2 == 0 && (wd[j].flag & LAT_FLAG_X0))
+                {
+                    column = true;
+                    idx = wd[j].flag & LAT_FLAG_INDEX;
+                }
+                else if (x2 == L.topx && (wd[j].flag & LAT_FLAG_TOP))
+                {
+                    column = true;
+                    idx = (wd[j].flag & LAT_FLAG_INDEX) + (wd[j].flag >> 31);
+                }
+            }
+            if (!(((exists >> lane) & 1) || column))
+                continue;
+            const uint32_t cx = x2 >> 1;
+            /* endpoint A = owner corner, B = A + (px,py,pz): A has the lower local corner id in every cell */
+            const float inv = 1.0f / (iso0[j] - iso1[j]);
+            const float t = iso0[j] * inv;
+            float vx = fmaf(t, (float) px, (float) (cx + gox));
+            float vy = fmaf(t, (float) py, (float) (cy + goy));
+            float vz = fmaf(t, (float) pz, (float) (cz + goz));
+            if (X.enabled)
+            {
+                vx = fmaf(vx, X.scale, X.bx);
+                vy = fmaf(vy, X.scale, X.by);
+                vz = fmaf(vz, X.scale, X.bz);
+            }
+            outVertices[3 * (uint64_t) idx + 0] = vx;
+            outVertices[3 * (uint64_t) idx + 1] = vy;
+            outVertices[3 * (uint64_t) idx + 2] = vz;
+            if (rowExternal || column)
+                outKeys[idx] = (((uint64_t) z2 << (2 * KEY_AXIS_BITS)) | ((uint64_t) y2 << KEY_AXIS_BITS) | (uint64_t) x2) + keyOffset;
+        }
     }
 }
 
 /* One thread per occupied cell: look up the welded index of each of the cell's vertices, then emit its
- * triangles (the index half of generateElements + reindex).  A block's cells are consecutive in the
- * compacted list, so their index ranges are one contiguous span of the output: it is assembled in LDS
- * and written with fully coalesced stores instead of 256 interleaved per-thread runs. */
+ * triangles (the index half of generateElements + reindex).
+ *
+ * The cell's 19 possible vertices lie in 9 lattice rows (y2, z2) = (2y + 0..2, 2z + 0..2) at x2 = 2x + 0..2, and
+ * x2 = 2x + 2 still ranks inside the word of 2x (a full-word popcount when it is the next word's bit 0), so the
+ * lookup is nine independent 16-byte loads issued together, then 19 unrolled edge tests -- vertex slots follow
+ * edge ids (makeTables), so no per-code key table is needed.
+ *
+ * A block's cells are consecutive in the compacted list, so their index ranges are one contiguous span of the
+ * output: it is assembled in LDS and written with fully coalesced stores. */
 __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeView C, DevTables T, const uint2 *cells,
                                                               const uint2 *viStart, uint32_t *indices,
                                                               const U3 *batchTotals)
@@ -882,26 +936,53 @@ __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeVie
         const uint2 cell = cells[gid];
         const uint32_t x = cell.x & 0xFFFFu, y = cell.x >> 16, z = cell.y;
         const uint32_t code = C.at(x, y, z);
-        /* one 16-byte load gives the code's vertex keys and counts; its index list follows as aligned words */
-        const uint32_t *rec = T.rec + code * 16;
-        const uint4 r0 = *reinterpret_cast<const uint4 *>(rec);
-        const uint32_t nv = r0.w & 0xFFu, ni = r0.w >> 8;
-        const uint64_t klo = (uint64_t) r0.x | ((uint64_t) r0.y << 32);
-        for (uint32_t i = 0; i < nv; i++)
-        {
-            const uint32_t k = (i < 10 ? (uint32_t) (klo >> (6 * i)) : (r0.z >> (6 * (i - 10)))) & 63u;
-            sIdx[threadIdx.x][i] = L.index(2 * x + (k & 3), 2 * y + ((k >> 2) & 3), 2 * z + (k >> 4));
-        }
         const uint32_t local = viStart[gid].y - blockBase;
+        const uint32_t *rec = T.rec + code * 16;
+        const uint32_t ni = rec[3] >> 8;
+        /* the nine rows' words */
+        const uint32_t wIdx = (2 * x) >> 6, sh = (2 * x) & 63;
+        LatWord wd[9];
+        bool rowFlagged[9];
+#pragma unroll
+        for (int r = 0; r < 9; r++)
+        {
+            const uint32_t y2 = 2 * y + (r % 3), z2 = 2 * z + (r / 3);
+            const uint32_t row = (z2 - L.z2First) * L.rowsPerLayer + y2;
+            wd[r] = L.words[(uint64_t) row * L.nw + wIdx];
+            rowFlagged[r] = y2 == 0 || y2 == L.topy || z2 == L.z2First;
+        }
+        /* bits of the word below x2 = 2x + px */
+        uint64_t below[3];
+        below[0] = (1ull << sh) - 1;
+        below[1] = (2ull << sh) - 1;
+        below[2] = sh == 62 ? ~0ull : (4ull << sh) - 1;
+        const bool atX0 = x == 0, atTop = 2 * x + 2 == L.topx;
+        uint32_t slot = 0;
+#pragma unroll
+        for (int e = 0; e < NUM_EDGES; e++)
+        {
+            const int a = edgeIndices[e][0], b = edgeIndices[e][1];
+            const int px = (a & 1) + (b & 1), py = ((a >> 1) & 1) + ((b >> 1) & 1), pz = ((a >> 2) & 1) + ((b >> 2) & 1);
+            const int r = py + 3 * pz;
+            if (((code >> a) ^ (code >> b)) & 1u)
+            {
+                uint32_t idx = wd[r].prefix + (uint32_t) __popcll(wd[r].mask & below[px]);
+                if (px == 0 && atX0 && !rowFlagged[r])
+                    idx = wd[r].flag & LAT_FLAG_INDEX;
+                if (px == 2 && atTop && !rowFlagged[r])
+                    idx = (wd[r].flag & LAT_FLAG_INDEX) + (wd[r].flag >> 31);
+                sIdx[threadIdx.x][slot++] = idx;
+            }
+        }
         const uint32_t tidBits = threadIdx.x << 4;
         for (uint32_t q = 0; 4 * q < ni; q++)
         {
-            const uint32_t wd = rec[4 + q];
+            const uint32_t iw = rec[4 + q];
             const uint32_t left = ni - 4 * q;
-            sRef[local + 4 * q] = (uint16_t) (tidBits | (wd & 0xFF));
-            if (left > 1) sRef[local + 4 * q + 1] = (uint16_t) (tidBits | ((wd >> 8) & 0xFF));
-            if (left > 2) sRef[local + 4 * q + 2] = (uint16_t) (tidBits | ((wd >> 16) & 0xFF));
-            if (left > 3) sRef[local + 4 * q + 3] = (uint16_t) (tidBits | (wd >> 24));
+            sRef[local + 4 * q] = (uint16_t) (tidBits | (iw & 0xFF));
+            if (left > 1) sRef[local + 4 * q + 1] = (uint16_t) (tidBits | ((iw >> 8) & 0xFF));
+            if (left > 2) sRef[local + 4 * q + 2] = (uint16_t) (tidBits | ((iw >> 16) & 0xFF));
+            if (left > 3) sRef[local + 4 * q + 3] = (uint16_t) (tidBits | (iw >> 24));
         }
         if (gid == numCells - 1 || threadIdx.x == blockDim.x - 1)
             sSpan = local + ni;
@@ -967,7 +1048,6 @@ struct mlsgpu_marching
     uint8_t *dCellCode = nullptr;
     U3 *dRowCounts = nullptr, *dRowStarts = nullptr;   /* per row of cells of the swathe: (occupied, vertices, indices) */
     LatWord *dLatWords = nullptr;
-    uint4 *dLatInfo = nullptr;
     U3 *dLatRows = nullptr;
     uint64_t latRowsMax = 0;
     uint32_t latWords = 0;
@@ -1108,7 +1188,6 @@ MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, ui
     alloc((void **) &m->dRowCounts, ((uint64_t) m->maxSwathe * (maxHeight - 1) + 1) * sizeof(U3));
     alloc((void **) &m->dRowStarts, ((uint64_t) m->maxSwathe * (maxHeight - 1) + 1) * sizeof(U3));
     alloc((void **) &m->dLatWords, m->latRowsMax * m->latWords * sizeof(LatWord));
-    alloc((void **) &m->dLatInfo, m->latRowsMax * sizeof(uint4));
     alloc((void **) &m->dLatRows, m->latRowsMax * sizeof(U3));
     if (m->legacyBuffers)
     {
@@ -1181,7 +1260,7 @@ MLSGPU_API void mlsgpu_hip_marching_destroy(mlsgpu_marching *m)
     hipFree(m->dIndices); hipFree(m->dIndexRemap); hipFree(m->dWelded); hipFree(m->dWeldedKeys);
     hipFree(m->dHist); hipFree(m->dTileSums); hipFree(m->dReadback);
     hipFree(m->dCellCode); hipFree(m->dRowCounts); hipFree(m->dRowStarts);
-    hipFree(m->dLatWords); hipFree(m->dLatInfo); hipFree(m->dLatRows);
+    hipFree(m->dLatWords); hipFree(m->dLatRows);
     if (m->hReadback) hipHostFree(m->hReadback);
     if (m->hHistogram) hipHostFree(m->hHistogram);
     delete m;
@@ -1283,7 +1362,6 @@ int mlsgpu_marching::shipOutLattice(const mlsgpu_swathe &sw, const uint32_t size
     Lattice L;
     L.words = dLatWords;
     L.rowCounts = dLatRows;
-    L.rowInfo = dLatInfo;
     L.totals = &dReadback->classTotals;
     L.nw = (2 * W - 1 + 63) / 64;
     L.rowsPerLayer = 2 * H - 1;
@@ -1301,7 +1379,7 @@ int mlsgpu_marching::shipOutLattice(const mlsgpu_swathe &sw, const uint32_t size
            L, C, zTop, zMax, H, cornerRows);
     PROPAGATE((exclusiveScan<U3>(ctx, "kernel.marching.scanUint.time", ArrayIn<U3>{dLatRows}, ArrayOut<U3>{dLatRows},
                                  numRows, U3{0, 0, 0}, dTileSums3, &dReadback->classTotals)));
-    LAUNCH(ctx, "kernel.marching.scanUint.time", latticeRowInfoKernel, dim3(divUp(numRows, 256)), dim3(256), L, numRows);
+    LAUNCH(ctx, "kernel.marching.scanUint.time", latticePatchKernel, dim3(divUp(numRows * L.nw, 256)), dim3(256), L, numRows * L.nw);
     const uint64_t keyOffsetL = ((uint64_t) keyOffset[2] << (2 * KEY_AXIS_BITS + 1))
         | ((uint64_t) keyOffset[1] << (KEY_AXIS_BITS + 1))
         | ((uint64_t) keyOffset[0] << 1);                                   /* src/marching.cpp:594-597 */
