@@ -141,6 +141,15 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v)
     return v;
 }
 
+/* maximum over the wave, in every lane */
+__device__ __forceinline__ uint32_t waveMax(uint32_t v)
+{
+#pragma unroll
+    for (int d = WAVE / 2; d >= 1; d >>= 1)
+        v = max(v, (uint32_t) __shfl_xor(v, d, WAVE));
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 __device__ __forceinline__ uint32_t readLane(uint32_t v, int lane)
 {
     return __builtin_amdgcn_readlane(v, lane);

@@ -371,27 +371,44 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
         uint32_t cnt = 0;           /* entries in this lane's hit list */
         uint8_t *myList = sList[tid];
 
+        /* The eleven running sums, with the x/y components of sum(w p) and sum(w n) as register pairs: the
+         * pairs match how a staged splat arrives from LDS (float4 = two aligned pairs), so the accumulation is
+         * v_pk_fma_f32 without register shuffles.  Each component is the same IEEE operation as in fitAdd. */
+        f32x2 sWpxy = {0.0f, 0.0f}, sWnxy = {0.0f, 0.0f};
+        const f32x2 cxy = {cx, cy};
+
         /* accumulate this lane's listed hits, in list order, then empty the list */
         auto drain = [&]()
         {
-            /* Branch-free body: lanes whose list is exhausted re-read slot 0 (always staged) with weight 0,
-             * which leaves every sum bit-for-bit unchanged (fma(0, x, s) == s, s + 0 == s for finite x). */
-            for (uint32_t j = 0; __any(j < cnt); j++)
+            const uint32_t most = waveMax(cnt);
+            for (uint32_t j = 0; j < most; j++)
             {
-                const bool act = j < cnt;
-                const uint32_t i = act ? (uint32_t) myList[j] : 0u;
-                const float4 pr = sPosRad[i];
-                const float4 nq = sNormQ[i];
-                const float px = pr.x - cx, py = pr.y - cy, pz = pr.z - cz;
-                const float pp = dot3(px, py, pz, px, py, pz);
-                const float d = pp * pr.w;
-                float w = 1.0f - d;
-                w *= w;
-                w *= w;
-                w *= nq.w;
-                w = act ? w : 0.0f;
-                fitAdd(fit, w, px, py, pz, pp, nq.x, nq.y, nq.z);
-                fit.hits -= act ? 0u : 1u;      /* fitAdd counted it */
+                if (j < cnt)
+                {
+                    const uint32_t i = myList[j];
+                    const float4 pr = sPosRad[i];
+                    const float4 nq = sNormQ[i];
+                    const f32x2 pxy = f32x2{pr.x, pr.y} - cxy;
+                    const float pz = pr.z - cz;
+                    const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
+                    const float d = pp * pr.w;
+                    float w = 1.0f - d;
+                    w *= w;
+                    w *= w;
+                    w *= nq.w;
+                    const f32x2 ww = {w, w};
+                    const f32x2 nxy = {nq.x, nq.y};
+                    const f32x2 wnxy = ww * nxy;
+                    const float wnz = w * nq.z;
+                    fit.sumW = fit.sumW + w;
+                    sWpxy = __builtin_elementwise_fma(ww, pxy, sWpxy);
+                    fit.sumWpz = fmaf(w, pz, fit.sumWpz);
+                    sWnxy = __builtin_elementwise_fma(ww, nxy, sWnxy);
+                    fit.sumWnz = fmaf(w, nq.z, fit.sumWnz);
+                    fit.sumWpp = fmaf(w, pp, fit.sumWpp);
+                    fit.sumWpn = fit.sumWpn + fmaf(wnxy.x, pxy.x, fmaf(wnxy.y, pxy.y, wnz * pz));
+                    fit.hits++;
+                }
             }
             cnt = 0;
         };
@@ -474,6 +491,10 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
             drain();            /* the lists point into this round's staging buffers */
             __syncthreads();
         }
+        fit.sumWpx = sWpxy.x;
+        fit.sumWpy = sWpxy.y;
+        fit.sumWnx = sWnxy.x;
+        fit.sumWny = sWnxy.y;
         f = finishCorner<SHAPE>(fit, A.boundaryFactor);
         if (STATS)
         {
