@@ -368,8 +368,9 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
         Fit fit;
         fitInit(fit);
         unsigned long long nListed = 0, nTests = 0;
-        uint32_t cnt = 0;           /* entries in this lane's hit list */
-        uint8_t *myList = sList[tid];
+        uint8_t *const myList = sList[tid];
+        uint8_t *const listEnd = myList + LIST_CAP;
+        uint8_t *tail = myList;     /* one past this lane's last listed hit */
 
         /* The eleven running sums, with the x/y components of sum(w p) and sum(w n) as register pairs: the
          * pairs match how a staged splat arrives from LDS (float4 = two aligned pairs), so the accumulation is
@@ -380,6 +381,7 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
         /* accumulate this lane's listed hits, in list order, then empty the list */
         auto drain = [&]()
         {
+            const uint32_t cnt = (uint32_t) (tail - myList);
             const uint32_t most = waveMax(cnt);
             for (uint32_t j = 0; j < most; j++)
             {
@@ -410,7 +412,7 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
                     fit.hits++;
                 }
             }
-            cnt = 0;
+            tail = myList;
         };
 
         int32_t end = A.commands[pos++];
@@ -464,28 +466,31 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
             {
                 const uint32_t m = sMask[g + lane];
                 uint64_t todo = __ballot((m >> wave) & 1u);
-                /* two relevant splats per iteration: the distance tests of both run as packed fp32
-                 * (v_pk_add / v_pk_mul / v_pk_fma), each component the same IEEE operation as the scalar form */
+                /* up to four relevant splats between capacity checks; per splat the x/y differences are one
+                 * packed subtract on the pair as it arrives from LDS, the rest scalar -- the same IEEE operations
+                 * as dot3() in the basic kernel */
                 while (todo != 0)
                 {
-                    const int i0 = g + (int) __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    const bool pair = todo != 0;
-                    const int i1 = pair ? g + (int) __builtin_ctzll(todo) : i0;
-                    todo &= todo - 1;           /* no-op when todo is already 0 */
-                    if (STATS)
-                        nTests += pair ? 128 : 64;
-                    if (__any(cnt + 2 > LIST_CAP))
+                    if (__any(tail + 4 > listEnd))
                         drain();
-                    const float4 a = sPosRad[i0], b = sPosRad[i1];
-                    const f32x2 px = f32x2{a.x, b.x} - cx, py = f32x2{a.y, b.y} - cy, pz = f32x2{a.z, b.z} - cz;
-                    const f32x2 pp = __builtin_elementwise_fma(px, px, __builtin_elementwise_fma(py, py, pz * pz));
-                    const f32x2 d = pp * f32x2{a.w, b.w};
-                    /* branch-free append: write the slot, keep it only if hit (the next append overwrites it) */
-                    myList[cnt] = (uint8_t) i0;
-                    cnt += d.x < RADIUS_CUTOFF ? 1u : 0u;
-                    myList[cnt] = (uint8_t) i1;
-                    cnt += (pair && d.y < RADIUS_CUTOFF) ? 1u : 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                    {
+                        if (todo == 0)
+                            break;
+                        const int i = g + (int) __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        if (STATS)
+                            nTests += 64;
+                        const float4 a = sPosRad[i];
+                        const f32x2 pxy = f32x2{a.x, a.y} - cxy;
+                        const float pz = a.z - cz;
+                        const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
+                        const float d = pp * a.w;
+                        /* branch-free append: write the slot, keep it only if hit (the next append overwrites it) */
+                        *tail = (uint8_t) i;
+                        tail += d < RADIUS_CUTOFF ? 1 : 0;
+                    }
                 }
             }
             drain();            /* the lists point into this round's staging buffers */
