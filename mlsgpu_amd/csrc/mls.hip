@@ -368,9 +368,11 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
         Fit fit;
         fitInit(fit);
         unsigned long long nListed = 0, nTests = 0;
-        uint8_t *const myList = sList[tid];
-        uint8_t *const listEnd = myList + LIST_CAP;
-        uint8_t *tail = myList;     /* one past this lane's last listed hit */
+        /* the list is addressed by its 32-bit LDS offset so that the tail lives in one register */
+        typedef __attribute__((address_space(3))) uint8_t LdsByte;
+        LdsByte *const myList = (LdsByte *) sList[tid];
+        LdsByte *const listEnd = myList + LIST_CAP;
+        LdsByte *tail = myList;     /* one past this lane's last listed hit */
 
         /* The eleven running sums, with the x/y components of sum(w p) and sum(w n) as register pairs: the
          * pairs match how a staged splat arrives from LDS (float4 = two aligned pairs), so the accumulation is
@@ -383,6 +385,7 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
         {
             const uint32_t cnt = (uint32_t) (tail - myList);
             const uint32_t most = waveMax(cnt);
+            fit.hits += cnt;
             for (uint32_t j = 0; j < most; j++)
             {
                 if (j < cnt)
@@ -409,7 +412,6 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
                     fit.sumWnz = fmaf(w, nq.z, fit.sumWnz);
                     fit.sumWpp = fmaf(w, pp, fit.sumWpp);
                     fit.sumWpn = fit.sumWpn + fmaf(wnxy.x, pxy.x, fmaf(wnxy.y, pxy.y, wnz * pz));
-                    fit.hits++;
                 }
             }
             tail = myList;
@@ -490,6 +492,7 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
                         /* branch-free append: write the slot, keep it only if hit (the next append overwrites it) */
                         *tail = (uint8_t) i;
                         tail += d < RADIUS_CUTOFF ? 1 : 0;
+                        asm volatile("" : "+v"(tail));      /* keep the tail itself in a register, not base + count */
                     }
                 }
             }
