@@ -85,7 +85,10 @@ namespace mlsgpu
 {
 
 /* Launch a kernel on the context's stream, timing it under a reference stat name when enabled. */
-#define LAUNCH(ctx, statName, kernel, grid, block, ...)                                       \
+#define LAUNCH(ctx, statName, kernel, grid, block, ...) LAUNCH_LDS(ctx, statName, kernel, grid, block, 0, __VA_ARGS__)
+
+/* the same with `ldsBytes` of dynamic LDS on top of the kernel's static allocation */
+#define LAUNCH_LDS(ctx, statName, kernel, grid, block, ldsBytes, ...)                         \
     do {                                                                                      \
         static thread_local int statId__ = -1;                                                \
         static thread_local uint64_t statCtx__ = 0;                                           \
@@ -94,7 +97,7 @@ namespace mlsgpu
             if (statCtx__ != (ctx)->serial) { statId__ = (ctx)->statId(statName); statCtx__ = (ctx)->serial; } \
             pend__ = (ctx)->beginTiming(statId__);                                            \
         }                                                                                     \
-        hipLaunchKernelGGL(kernel, grid, block, 0, (ctx)->stream, __VA_ARGS__);               \
+        hipLaunchKernelGGL(kernel, grid, block, ldsBytes, (ctx)->stream, __VA_ARGS__);        \
         if (pend__ >= 0) (ctx)->endTiming(pend__);                                            \
         HIP_CHECK(hipGetLastError());                                                         \
     } while (0)
