@@ -22,8 +22,6 @@
  */
 #include "common.hpp"
 
-#include <cstdlib>
-
 using namespace mlsgpu;
 
 struct mlsgpu_tree;
@@ -477,33 +475,22 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
                 {
                     if (__any(tail + 4 > listEnd))
                         drain();
-                    /* pick the slots on the scalar unit, request all four splats, then test them */
-                    int slot[4];
-                    int have = 0;
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                     {
-                        slot[k] = g + (int) __builtin_ctzll(todo | (1ull << 63));
-                        have += todo != 0 ? 1 : 0;
-                        todo &= todo - 1;       /* stays 0 once empty */
-                    }
-                    float4 a[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                        a[k] = sPosRad[slot[k]];
-                    if (STATS)
-                        nTests += 64 * have;
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                    {
-                        if (k >= have)
+                        if (todo == 0)
                             break;
-                        const f32x2 pxy = f32x2{a[k].x, a[k].y} - cxy;
-                        const float pz = a[k].z - cz;
+                        const int i = g + (int) __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        if (STATS)
+                            nTests += 64;
+                        const float4 a = sPosRad[i];
+                        const f32x2 pxy = f32x2{a.x, a.y} - cxy;
+                        const float pz = a.z - cz;
                         const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
-                        const float d = pp * a[k].w;
+                        const float d = pp * a.w;
                         /* branch-free append: write the slot, keep it only if hit (the next append overwrites it) */
-                        *tail = (uint8_t) slot[k];
+                        *tail = (uint8_t) i;
                         tail += d < RADIUS_CUTOFF ? 1 : 0;
                         asm volatile("" : "+v"(tail));      /* keep the tail itself in a register, not base + count */
                     }
