@@ -659,18 +659,6 @@ struct Lattice
     }
 };
 
-/* spread the low 32 bits of v over the even bit positions of a 64-bit word */
-__device__ __forceinline__ uint64_t spreadBits(uint64_t v)
-{
-    v &= 0xFFFFFFFFull;
-    v = (v | (v << 16)) & 0x0000FFFF0000FFFFull;
-    v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
-    v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full;
-    v = (v | (v << 2)) & 0x3333333333333333ull;
-    v = (v | (v << 1)) & 0x5555555555555555ull;
-    return v;
-}
-
 /* does a cell with this code (0 = not occupied) see different signs at its local corners a and b? */
 __device__ __forceinline__ uint32_t edgeBit(uint32_t code, uint32_t a, uint32_t b)
 {
@@ -684,8 +672,8 @@ __device__ __forceinline__ uint32_t edgeBit(uint32_t code, uint32_t a, uint32_t 
  *              (2z+1, 2y): +z at 2x, +xz at 2x+1  (2z+1, 2y+1): +yz at 2x, +xyz at 2x+1
  * An edge carries a vertex iff one of the occupied cells containing it sees a sign change along it; those
  * cells are among the eight around the corner, whose code bytes are four loads per lane (cell x of the four
- * adjacent cell rows) plus a lane shift for cell x-1.  Seven ballots give the rows' bits for 64 corners,
- * interleaved (even/odd x2) into two 64-bit words per row on the scalar unit.
+ * adjacent cell rows) plus a lane shift for cell x-1.  The seven bits of 64 corners become the rows' words
+ * (even/odd x2 interleaved) through two lane permutations and one ballot per word.
  */
 __global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, uint32_t zCellFirst, uint32_t zCellLast,
                                                          uint32_t H, uint32_t numCornerRows)
@@ -765,8 +753,12 @@ __global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, 
         }
         const uint32_t eyz = edgeBit(c[0][0], 0, 6) | edgeBit(m[0][0], 1, 7);
         const uint32_t exyz = edgeBit(c[0][0], 0, 7);
-        const uint64_t even[4] = {0ull, __ballot(ey != 0), __ballot(ez != 0), __ballot(eyz != 0)};
-        const uint64_t odd[4] = {__ballot(ex != 0), __ballot(exy != 0), __ballot(exz != 0), __ballot(exyz != 0)};
+        /* Interleave (even x2 = 2x, odd x2 = 2x+1) by lane permutation instead of bit spreading: lane i of word
+         * `half` takes corner 32*half + i/2 and its even (i even) or odd (i odd) point, so one ballot per row and
+         * half IS the 64-bit word. */
+        const uint32_t pk = ex | (exy << 1) | (exz << 2) | (exyz << 3) | (ey << 5) | (ez << 6) | (eyz << 7);
+        const uint32_t from[2] = {(uint32_t) __shfl(pk, lane >> 1, 64), (uint32_t) __shfl(pk, 32 + (lane >> 1), 64)};
+        const uint32_t sel = (lane & 1) ? 0u : 4u;
 #pragma unroll
         for (int h = 0; h < 4; h++)
         {
@@ -778,7 +770,7 @@ __global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, 
                 const uint32_t w = (x0 >> 6) * 2 + half;
                 if (w >= L.nw)
                     continue;
-                const uint64_t bits = spreadBits(even[h] >> (32 * half)) | (spreadBits(odd[h] >> (32 * half)) << 1);
+                const uint64_t bits = __ballot((from[half] >> (sel + h)) & 1u);
                 const uint64_t cm = rowCls[h] == 2 ? 0ull : L.columnMask(w);
                 const uint64_t col = bits & cm;
                 const uint64_t topBit = w == (L.topx >> 6) ? 1ull << (L.topx & 63) : 0ull;
