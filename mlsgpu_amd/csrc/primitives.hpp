@@ -259,19 +259,20 @@ template<typename K> struct SortCaps { enum { MAX_DIGIT_BITS = sizeof(K) == 8 ? 
  *   4. the tile is assembled in that order in LDS and copied out by consecutive threads, so each
  *      digit's run leaves as one contiguous, coalesced burst instead of 64 scattered dwords per store.
  */
-template<typename K, bool IOTA>
+template<typename K, bool IOTA, int BIN_BITS>
 __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn, const uint32_t *valsIn,
                                                                 K *keysOut, uint32_t *valsOut,
                                                                 const uint32_t *hist, uint64_t n,
                                                                 uint32_t shift, uint32_t digitBits, uint32_t numTiles,
                                                                 const uint32_t *nDev)
 {
-    enum { BINS = 1 << SortCaps<K>::MAX_DIGIT_BITS };
+    enum { BINS = 1 << BIN_BITS };
     __shared__ uint32_t waveBins[PRIM_WAVES][BINS];
     __shared__ uint32_t tileBase[BINS];        /* global start of the digit minus its tile-local start */
     __shared__ uint32_t waveTotals[PRIM_WAVES];
-    __shared__ K sKeys[PRIM_TILE];
-    __shared__ uint32_t sVals[PRIM_TILE];
+    /* the tile is reordered in two phases through ONE buffer (keys, then values): half the LDS, twice the
+     * resident workgroups, which is what this latency-bound kernel needs */
+    __shared__ K sTile[PRIM_TILE];
     if (nDev != nullptr && *nDev < n)
         n = *nDev;
     const uint64_t tileFirst = (uint64_t) blockIdx.x * PRIM_TILE;
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn,
     }
     __syncthreads();
     /* stable split of each round: rank among the lanes of the wave holding the same digit */
+    uint32_t dst[PRIM_ITEMS];
 #pragma unroll
     for (int j = 0; j < PRIM_ITEMS; j++)
     {
@@ -345,25 +347,50 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn,
             const uint64_t m = __ballot(bit);
             peers &= bit ? m : ~m;
         }
+        dst[j] = 0;
         if (valid)
         {
             const uint32_t rank = popcBelow(peers);
-            const uint32_t dst = waveBins[wave][digit] + rank;
-            sKeys[dst] = keys[j];
-            sVals[dst] = IOTA ? (uint32_t) i : valsIn[i];
+            dst[j] = waveBins[wave][digit] + rank;
+            sTile[dst[j]] = keys[j];
             if (rank == 0)
-                waveBins[wave][digit] = dst + (uint32_t) __popcll(peers);
+                waveBins[wave][digit] = dst[j] + (uint32_t) __popcll(peers);
         }
         /* LDS operations of one wave complete in program order, so the next round sees the update */
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    for (uint32_t p = threadIdx.x; p < tileCount; p += PRIM_BLOCK)
+    /* keys leave in tile-sorted order: each digit's run is one contiguous, coalesced burst */
+    uint32_t out[PRIM_ITEMS];
+#pragma unroll
+    for (int k = 0; k < PRIM_ITEMS; k++)
     {
-        const K key = sKeys[p];
-        const uint32_t g = tileBase[(uint32_t) ((key >> shift) & mask)] + p;
-        keysOut[g] = key;
-        valsOut[g] = sVals[p];
+        const uint32_t p = threadIdx.x + k * PRIM_BLOCK;
+        out[k] = 0;
+        if (p < tileCount)
+        {
+            const K key = sTile[p];
+            out[k] = tileBase[(uint32_t) ((key >> shift) & mask)] + p;
+            keysOut[out[k]] = key;
+        }
+    }
+    __syncthreads();
+    /* the values take the same route through the same buffer */
+    uint32_t *sVals = reinterpret_cast<uint32_t *>(sTile);
+#pragma unroll
+    for (int j = 0; j < PRIM_ITEMS; j++)
+    {
+        const uint64_t i = base + (uint64_t) j * 64;
+        if (i < n)
+            sVals[dst[j]] = IOTA ? (uint32_t) i : valsIn[i];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PRIM_ITEMS; k++)
+    {
+        const uint32_t p = threadIdx.x + k * PRIM_BLOCK;
+        if (p < tileCount)
+            valsOut[out[k]] = sVals[p];
     }
 }
 
@@ -417,12 +444,15 @@ static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *
                (const K *) kin, dHist, n, shift, digitBits, tiles, nDev);
         PROPAGATE((exclusiveScan<uint32_t>(ctx, statName, ArrayIn<uint32_t>{dHist}, ArrayOut<uint32_t>{dHist},
                                            histN, 0u, dTileSums, (uint32_t *) nullptr)));
-        if (iota && p == 0)
-            LAUNCH(ctx, statName, (sortScatterKernel<K, true>), dim3(tiles), dim3(PRIM_BLOCK),
-                   (const K *) kin, (const uint32_t *) vin, kout, vout, (const uint32_t *) dHist, n, shift, digitBits, tiles, nDev);
-        else
-            LAUNCH(ctx, statName, (sortScatterKernel<K, false>), dim3(tiles), dim3(PRIM_BLOCK),
-                   (const K *) kin, (const uint32_t *) vin, kout, vout, (const uint32_t *) dHist, n, shift, digitBits, tiles, nDev);
+#define SORT_SCATTER(IOTA, BITS)                                                                                       \
+        LAUNCH(ctx, statName, (sortScatterKernel<K, IOTA, BITS>), dim3(tiles), dim3(PRIM_BLOCK), (const K *) kin,      \
+               (const uint32_t *) vin, kout, vout, (const uint32_t *) dHist, n, shift, digitBits, tiles, nDev)
+        /* the kernel's bin tables are sized for the digit in use: fewer bins, more resident workgroups */
+        const bool first = iota && p == 0;
+        if (digitBits <= 8) { if (first) SORT_SCATTER(true, 8); else SORT_SCATTER(false, 8); }
+        else if (digitBits <= 9) { if (first) SORT_SCATTER(true, 9); else SORT_SCATTER(false, 9); }
+        else { if (first) SORT_SCATTER(true, SortCaps<K>::MAX_DIGIT_BITS); else SORT_SCATTER(false, SortCaps<K>::MAX_DIGIT_BITS); }
+#undef SORT_SCATTER
         shift += digitBits;
         K *tk = kin; kin = kout; kout = tk;
         uint32_t *tv = vin; vin = vout; vout = tv;
