@@ -424,12 +424,9 @@ MLSGPU_API int mlsgpu_hip_tree_build(mlsgpu_tree *t, mlsgpu_splat *dSplats, uint
     {
         EntryParams P{dSplats, offset[0], offset[1], offset[2], lo, minShift, maxShift, (uint32_t) firstSplat};
         /* writeEntries: count, scan, write compacted; the entry count stays on the device (t->dNumEntries) */
-        PROPAGATE((scanPhase1<uint32_t, EntryCountIn>(ctx, "kernel.octree.writeEntries.time", EntryCountIn{P, t->dSlotMasks},
-                                                      numSplats, 0u, t->dTileSums, t->dNumEntries)));
-        PROPAGATE((scanPhase2<uint32_t, EntryMaskIn, EntryWriteOut>(ctx, "kernel.octree.writeEntries.time",
-                                                                    EntryMaskIn{t->dSlotMasks},
-                                                                    EntryWriteOut{P, t->dSlotMasks, t->dKeysA, t->dValsA},
-                                                                    numSplats, (const uint32_t *) t->dTileSums)));
+        PROPAGATE((exclusiveScan2<uint32_t, EntryCountIn, EntryMaskIn, EntryWriteOut>(
+            ctx, "kernel.octree.writeEntries.time", EntryCountIn{P, t->dSlotMasks}, EntryMaskIn{t->dSlotMasks},
+            EntryWriteOut{P, t->dSlotMasks, t->dKeysA, t->dValsA}, numSplats, 0u, t->dTileSums, t->dNumEntries)));
         SortResult<uint32_t> sorted;
         PROPAGATE(radixSort<uint32_t>(ctx, "kernel.octree.sort.time", t->dKeysA, t->dValsA, t->dKeysB, t->dValsB,
                                       maxEntries, (uint32_t) (3 * (maxShift - minShift) + 1), false,

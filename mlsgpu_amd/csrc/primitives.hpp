@@ -128,15 +128,32 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanTileSumsKernel(T *tileSums, ui
         *total = carry;
 }
 
-/* out(i, exclusivePrefix(i), in(i)) for every i < n; tileSums already scanned */
-template<typename T, typename In, typename Out>
-__global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(In in, Out out, const T *tileSums, uint64_t n, const uint32_t *nDev)
+/* out(i, exclusivePrefix(i), in(i)) for every i < n.
+ * FUSED = false: tileSums already hold each tile's exclusive prefix (scanTileSumsKernel ran).
+ * FUSED = true:  tileSums are the raw tile sums; every workgroup adds up its predecessors' itself (at most
+ *                SCAN_FUSED_MAX_TILES L2-resident values), which saves the single-workgroup launch in between;
+ *                the last workgroup writes the grand total. */
+template<typename T, typename In, typename Out, bool FUSED>
+__global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(In in, Out out, const T *tileSums, uint64_t n, const uint32_t *nDev,
+                                                              T seed, T *total)
 {
     if (nDev != nullptr && *nDev < n)
         n = *nDev;
     __shared__ T waveTotals[PRIM_WAVES];
+    __shared__ T wavePrefix[PRIM_WAVES];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t base = (uint64_t) blockIdx.x * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
+    /* the tile holding the last element (tile 0 of an empty scan) reports the total; later tiles are empty */
+    const uint32_t lastTile = n > 0 ? (uint32_t) ((n - 1) / PRIM_TILE) : 0u;
+    if (FUSED && blockIdx.x > lastTile)
+        return;
+    T before = zeroOf(T());
+    if (FUSED)
+    {
+        /* the predecessors' sums are requested first: their latency hides behind the tile's own loads */
+        for (uint32_t t = threadIdx.x; t < blockIdx.x; t += PRIM_BLOCK)
+            before = before + tileSums[t];
+    }
     T vals[PRIM_ITEMS];
     T excl[PRIM_ITEMS];
     T running = zeroOf(T());        /* wave-uniform: sum of the previous rounds of this wave */
@@ -149,10 +166,32 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(In in, Out out, co
         excl[j] = running + waveShiftUpT(incl);
         running = running + readLaneT(incl, 63);
     }
+    if (FUSED)
+    {
+        const T inclBefore = waveInclusiveScanT(before);
+        if (lane == 63)
+            wavePrefix[wave] = inclBefore;
+    }
     if (lane == 0)
         waveTotals[wave] = running;
     __syncthreads();
-    T before = tileSums[blockIdx.x];
+    if (FUSED)
+    {
+        before = seed;
+#pragma unroll
+        for (int w = 0; w < PRIM_WAVES; w++)
+            before = before + wavePrefix[w];
+        if (total != nullptr && blockIdx.x == lastTile && threadIdx.x == 0)
+        {
+            T all = before;
+#pragma unroll
+            for (int w = 0; w < PRIM_WAVES; w++)
+                all = all + waveTotals[w];
+            *total = all;
+        }
+    }
+    else
+        before = tileSums[blockIdx.x];
     for (uint32_t w = 0; w < wave; w++)
         before = before + waveTotals[w];
 #pragma unroll
@@ -189,16 +228,37 @@ static int scanPhase2(mlsgpu_ctx *ctx, const char *statName, In in, Out out, uin
 {
     const uint32_t tiles = scanTiles(n);
     if (tiles > 0)
-        LAUNCH(ctx, statName, (scanApplyKernel<T, In, Out>), dim3(tiles), dim3(PRIM_BLOCK), in, out, dTileSums, n, nDev);
+        LAUNCH(ctx, statName, (scanApplyKernel<T, In, Out, false>), dim3(tiles), dim3(PRIM_BLOCK), in, out, dTileSums, n, nDev,
+               zeroOf(T()), (T *) nullptr);
     return MLSGPU_OK;
+}
+
+/* largest scan (in tiles) whose workgroups add up their predecessors' tile sums themselves */
+#define SCAN_FUSED_MAX_TILES 4096u
+
+/* in1 feeds the tile sums, in2 the scan proper (they must agree; a first pass may cache what the second reads) */
+template<typename T, typename In1, typename In2, typename Out>
+static int exclusiveScan2(mlsgpu_ctx *ctx, const char *statName, In1 in1, In2 in2, Out out, uint64_t n, T seed,
+                          T *dTileSums, T *dTotal, const uint32_t *nDev = nullptr)
+{
+    const uint32_t tiles = scanTiles(n);
+    if (tiles > 0 && tiles <= SCAN_FUSED_MAX_TILES)
+    {
+        /* two launches: raw tile sums, then the scan proper */
+        LAUNCH(ctx, statName, (scanReduceKernel<T, In1>), dim3(tiles), dim3(PRIM_BLOCK), in1, dTileSums, n, nDev);
+        LAUNCH(ctx, statName, (scanApplyKernel<T, In2, Out, true>), dim3(tiles), dim3(PRIM_BLOCK), in2, out, (const T *) dTileSums,
+               n, nDev, seed, dTotal);
+        return MLSGPU_OK;
+    }
+    PROPAGATE((scanPhase1<T, In1>(ctx, statName, in1, n, seed, dTileSums, dTotal, nDev)));
+    return scanPhase2<T, In2, Out>(ctx, statName, in2, out, n, (const T *) dTileSums, nDev);
 }
 
 template<typename T, typename In, typename Out>
 static int exclusiveScan(mlsgpu_ctx *ctx, const char *statName, In in, Out out, uint64_t n, T seed,
                          T *dTileSums, T *dTotal, const uint32_t *nDev = nullptr)
 {
-    PROPAGATE((scanPhase1<T, In>(ctx, statName, in, n, seed, dTileSums, dTotal, nDev)));
-    return scanPhase2<T, In, Out>(ctx, statName, in, out, n, (const T *) dTileSums, nDev);
+    return exclusiveScan2<T, In, In, Out>(ctx, statName, in, in, out, n, seed, dTileSums, dTotal, nDev);
 }
 
 /* plain array in / array out functors */
