@@ -1,0 +1,139 @@
+#!/usr/bin/env python3
+"""Turns raw rocprofv3 output (gpurun_out/...) into the summaries committed under profiles/.
+
+    # on the GPU box (three separate runs; never --pmc together with a trace):
+    rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o run -- python3 bench.py --steps 2 --warmup 1 \
+        --no-cpu-baseline --no-stream --no-timing --workers 1
+    rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o run -- python3 bench.py --steps 1 --warmup 0 \
+        --no-cpu-baseline --no-stream --no-timing --workers 1
+    rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write -o run -- python3 bench.py --steps 1 --warmup 0 \
+        --no-cpu-baseline --no-stream --no-timing --workers 1
+    # here:
+    python tools/profile_summary.py stats gpurun_out/prof profiles/rNN_cfg3_kernel_stats.csv "<command line>"
+    python tools/profile_summary.py traffic gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/rNN_cfg3_pmc_hbm_traffic.csv
+
+`traffic` also rewrites profiles/traffic.json (HBM bytes per launch of the kernels bench.py reports).  FETCH_SIZE and
+WRITE_SIZE are in KiB; FETCH_SIZE under-reports 128-byte requests by 2x on gfx950 (MI355X_MICROARCH.md), which the
+1.7 GB device-to-device splat copy of every bench pass confirms (it reads as 0.49x its size), so reads are doubled.
+"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# kernels of the bench's per-stage table -> substring of the demangled kernel name
+TRACKED = {
+    "processCorners": "processCornersListKernel<0, false>",
+    "latticeTriangles": "latticeTrianglesKernel",
+    "latticeVertices": "latticeVerticesKernel",
+    "latticeMask": "latticeMaskKernel",
+    "sortScatter": "sortScatterKernel",
+    "sortHist": "sortHistKernel",
+    "cellCode": "cellCodeKernel",
+    "writeEntries": "EntryWriteOut",
+    "writeSplatIds": "SplatIdsOut",
+}
+
+
+def find(directory, suffix):
+    hits = glob.glob(os.path.join(directory, "**", "*" + suffix), recursive=True)
+    if not hits:
+        raise SystemExit("no *%s under %s" % (suffix, directory))
+    return sorted(hits)[-1]
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*$", "", name)
+
+
+def database(directory):
+    """rocprofv3's default output here is a rocpd SQLite file; --output-format csv gives the csv files instead"""
+    hits = glob.glob(os.path.join(directory, "**", "*_results.db"), recursive=True)
+    if not hits:
+        return None
+    import sqlite3
+    return sqlite3.connect(sorted(hits)[-1])
+
+
+def stats_rows(directory):
+    db = database(directory)
+    if db is None:
+        return list(csv.DictReader(open(find(directory, "kernel_stats.csv"))))
+    rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+                      "group by name order by sum(duration) desc").fetchall()
+    whole = sum(r[2] for r in rows)
+    return [dict(Name=r[0], Calls=r[1], TotalDurationNs=r[2], AverageNs="%.1f" % r[3], Percentage="%.4f" % (100.0 * r[2] / whole),
+                 MinNs=r[4], MaxNs=r[5]) for r in rows]
+
+
+def stats(directory, out, command):
+    rows = stats_rows(directory)
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- %s\n" % command)
+        f.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+        for r in rows:
+            f.write('"%s",%s,%s,%s,%s,%s,%s\n' % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
+                                                 r["Percentage"], r["MinNs"], r["MaxNs"]))
+    print("wrote", out, len(rows), "kernels")
+
+
+def counters(directory, counter):
+    total = defaultdict(float)
+    calls = defaultdict(int)
+    db = database(directory)
+    if db is not None:
+        for name, value in db.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+            total[short(name)] += float(value)
+            calls[short(name)] += 1
+        return total, calls
+    for r in csv.DictReader(open(find(directory, "counter_collection.csv"))):
+        if r["Counter_Name"] != counter:
+            continue
+        k = short(r["Kernel_Name"])
+        total[k] += float(r["Counter_Value"])
+        calls[k] += 1
+    return total, calls
+
+
+def traffic(fetch_dir, write_dir, out):
+    fetch, calls = counters(fetch_dir, "FETCH_SIZE")
+    write, wcalls = counters(write_dir, "WRITE_SIZE")
+    names = sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, 0) + write.get(k, 0)))
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes), bench.py --steps 1 --warmup 0 --workers 1\n")
+        f.write("# counters are in KiB; fetch bytes are 2 x FETCH_SIZE x 1024 (gfx950 correction, see tools/profile_summary.py)\n")
+        f.write("kernel,calls,FETCH_SIZE_KB_total,WRITE_SIZE_KB_total,fetch_bytes_per_launch_x2corrected,write_bytes_per_launch\n")
+        for k in names:
+            n = max(calls.get(k, 0), wcalls.get(k, 0), 1)
+            f.write('"%s",%d,%.1f,%.1f,%.0f,%.0f\n' % (k, n, fetch.get(k, 0), write.get(k, 0),
+                                                       2 * 1024 * fetch.get(k, 0) / n, 1024 * write.get(k, 0) / n))
+    per_launch = {}
+    for label, needle in TRACKED.items():
+        fk = [k for k in names if needle in k]
+        if not fk:
+            continue
+        n = sum(max(calls.get(k, 0), wcalls.get(k, 0)) for k in fk)
+        per_launch[label] = int((2 * 1024 * sum(fetch.get(k, 0) for k in fk) + 1024 * sum(write.get(k, 0) for k in fk)) / max(n, 1))
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    doc = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    doc["cfg3/uniform"] = per_launch
+    doc["_note"] = ("HBM bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 fetch correction), from "
+                    + os.path.relpath(out, ROOT))
+    json.dump(doc, open(tpath, "w"), indent=1)
+    print("wrote", out, "and", tpath, per_launch)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) >= 5 and sys.argv[1] == "stats":
+        stats(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif len(sys.argv) == 5 and sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3], sys.argv[4])
+    else:
+        raise SystemExit(__doc__)
