@@ -319,7 +319,7 @@ def main():
             "value": round(voxels / st_s / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(st_s * 1e3, 3),
             "h2d_GB_per_step": round(bucketed.nbytes / 1e9, 3),
             "h2d_GBps_sustained": round(bucketed.nbytes / st_s / 1e9, 2),
-            "note": "host (pageable numpy) -> pinned staging -> H2D -> device workers; meshes stay in HBM",
+            "note": "host (pageable numpy) -> pinned staging (4 copy threads) -> H2D -> device workers; meshes stay in HBM",
         }
         farm_obj.close()
 

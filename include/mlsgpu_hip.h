@@ -254,6 +254,7 @@ typedef struct mlsgpu_farm_config
     uint32_t workersPerDevice;     /* default 1 */
     uint32_t spare;                /* extra device items per GPU beyond one per worker; default 1 */
     mlsgpu_worker_config worker;   /* maxBucketSplats is also the capacity of a device item */
+    uint32_t copyThreads;          /* host threads mlsgpu_hip_farm_submit copies a bucket with; 0 = 4 */
 } mlsgpu_farm_config;
 /* Output functor with the chunk it belongs to (OutputGenerator, src/workers.h:225).  Called on the worker's
  * thread; `ctx` is that worker's context (use it for mlsgpu_hip_mesh_read).  NULL: meshes are only counted. */
@@ -264,6 +265,13 @@ void mlsgpu_hip_farm_destroy(mlsgpu_farm *farm);
  * current batch first if they do not fit).  Blocks while every device item is in use. */
 int mlsgpu_hip_farm_submit(mlsgpu_farm *farm, const mlsgpu_splat *hSplats, uint64_t numSplats,
                            const int32_t lowExtent[3], const uint32_t numVertices[3], uint64_t chunkId);
+/* The two halves of submit for a loader that writes splats straight into the staging buffer, as the reference's
+ * BucketLoader does (src/bucket_loader.cpp:56-128 fills the buffer CopyGroup::get returned, then pushes it):
+ * acquire returns room for numSplats splats in pinned memory (flushing the current batch first if they do not
+ * fit); push appends the bucket (at most the acquired number of splats) to the batch.  One acquire per push. */
+int mlsgpu_hip_farm_acquire(mlsgpu_farm *farm, uint64_t numSplats, mlsgpu_splat **out);
+int mlsgpu_hip_farm_push(mlsgpu_farm *farm, uint64_t numSplats, const int32_t lowExtent[3], const uint32_t numVertices[3],
+                         uint64_t chunkId);
 /* Flushes the last batch and waits until every queued bucket has been processed; reports the first error. */
 int mlsgpu_hip_farm_finish(mlsgpu_farm *farm);
 /* out[0] buckets, [1] splats copied, [2] H2D bytes, [3] device items, [4] ship-outs, [5] vertices, [6] triangles,

@@ -62,7 +62,7 @@ class WorkerConfig(C.Structure):
 
 class FarmConfig(C.Structure):
     _fields_ = [("numDevices", C.c_uint32), ("devices", C.POINTER(C.c_int32)), ("workersPerDevice", C.c_uint32),
-                ("spare", C.c_uint32), ("worker", WorkerConfig)]
+                ("spare", C.c_uint32), ("worker", WorkerConfig), ("copyThreads", C.c_uint32)]
 
 
 FARM_OUTPUT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(Mesh))
@@ -155,6 +155,8 @@ def lib():
     sig("mlsgpu_hip_farm_create", C.c_int, P(FarmConfig), FARM_OUTPUT_FN, vp, P(vp))
     sig("mlsgpu_hip_farm_destroy", None, vp)
     sig("mlsgpu_hip_farm_submit", C.c_int, vp, vp, u64, vp, vp, u64)
+    sig("mlsgpu_hip_farm_acquire", C.c_int, vp, u64, P(vp))
+    sig("mlsgpu_hip_farm_push", C.c_int, vp, u64, vp, vp, u64)
     sig("mlsgpu_hip_farm_finish", C.c_int, vp)
     sig("mlsgpu_hip_farm_stats", C.c_int, vp, vp)
     sig("mlsgpu_hip_transform_splats", None, vp, u64, vp, f32, vp)
@@ -629,6 +631,18 @@ class BucketFarm:
         splats = np.ascontiguousarray(splats)
         check(lib().mlsgpu_hip_farm_submit(self.h, _p(splats), len(splats), _p(_i3(low_extent)), _p(_u3(num_vertices)),
                                            chunk_id))
+
+    def acquire(self, num_splats):
+        """CopyGroup::get: a numpy view of pinned staging memory for one bucket; fill it, then push()."""
+        ptr = C.c_void_p()
+        check(lib().mlsgpu_hip_farm_acquire(self.h, num_splats, C.byref(ptr)))
+        if num_splats == 0:
+            return np.zeros(0, SPLAT_DTYPE)
+        buf = (C.c_char * (num_splats * SPLAT_DTYPE.itemsize)).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=SPLAT_DTYPE, count=num_splats)
+
+    def push(self, num_splats, low_extent, num_vertices, chunk_id):
+        check(lib().mlsgpu_hip_farm_push(self.h, num_splats, _p(_i3(low_extent)), _p(_u3(num_vertices)), chunk_id))
 
     def finish(self):
         rc = lib().mlsgpu_hip_farm_finish(self.h)

@@ -8,6 +8,7 @@
  */
 #include "common.hpp"
 
+#include <algorithm>
 #include <condition_variable>
 #include <deque>
 #include <memory>
@@ -75,6 +76,7 @@ struct Farm
     int cur = 0;
     std::vector<SubItem> bufferedItems;
     uint64_t bufferedSplats = 0;
+    uint64_t acquired = 0;          /* splats handed out by acquire and not pushed yet */
 
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
@@ -331,15 +333,25 @@ MLSGPU_API void mlsgpu_hip_farm_destroy(mlsgpu_farm *f)
 }
 
 /* CopyGroupBase::Worker::operator(), src/workers.cpp:377-418 */
-MLSGPU_API int mlsgpu_hip_farm_submit(mlsgpu_farm *f, const mlsgpu_splat *hSplats, uint64_t numSplats,
-                                      const int32_t lowExtent[3], const uint32_t numVertices[3], uint64_t chunkId)
+/* CopyGroup::get (src/workers.h:281-349 `get`): room for one bucket in the pinned staging buffer */
+MLSGPU_API int mlsgpu_hip_farm_acquire(mlsgpu_farm *f, uint64_t numSplats, mlsgpu_splat **out)
 {
-    REQUIRE(f != nullptr && lowExtent != nullptr && numVertices != nullptr, MLSGPU_ERR_INVALID);
-    REQUIRE(numSplats == 0 || hSplats != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(f != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
     REQUIRE(numSplats <= f->cfg.worker.maxBucketSplats, MLSGPU_ERR_LENGTH);
     if (f->bufferedSplats + numSplats > f->cfg.worker.maxBucketSplats)
         PROPAGATE(flushBatch(f));
-    std::memcpy(f->pinned[f->cur] + f->bufferedSplats, hSplats, numSplats * sizeof(mlsgpu_splat));
+    f->acquired = numSplats;
+    *out = f->pinned[f->cur] + f->bufferedSplats;
+    return MLSGPU_OK;
+}
+
+/* CopyGroup::push: the bucket written into the acquired space joins the current batch */
+MLSGPU_API int mlsgpu_hip_farm_push(mlsgpu_farm *f, uint64_t numSplats, const int32_t lowExtent[3],
+                                    const uint32_t numVertices[3], uint64_t chunkId)
+{
+    REQUIRE(f != nullptr && lowExtent != nullptr && numVertices != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(numSplats <= f->acquired, MLSGPU_ERR_LENGTH);
+    f->acquired = 0;
     SubItem sub;
     sub.chunkId = chunkId;
     for (int i = 0; i < 3; i++)
@@ -354,6 +366,42 @@ MLSGPU_API int mlsgpu_hip_farm_submit(mlsgpu_farm *f, const mlsgpu_splat *hSplat
     f->stats[0]++;
     f->stats[1] += numSplats;
     return MLSGPU_OK;
+}
+
+/* one host thread moves ~10 GB/s; a bucket of 2 M splats (64 MB) is split over a few so that staging keeps up
+ * with the PCIe link */
+static void parallelCopy(void *dst, const void *src, size_t bytes, unsigned threads)
+{
+    const size_t minChunk = size_t(4) << 20;
+    if (threads <= 1 || bytes < 2 * minChunk)
+    {
+        std::memcpy(dst, src, bytes);
+        return;
+    }
+    const size_t parts = std::min<size_t>(threads, bytes / minChunk);
+    const size_t chunk = (bytes / parts + 4095) & ~size_t(4095);
+    std::vector<std::thread> pool;
+    for (size_t p = 1; p < parts; p++)
+    {
+        const size_t off = p * chunk;
+        if (off >= bytes)
+            break;
+        pool.emplace_back([=] { std::memcpy((char *) dst + off, (const char *) src + off, std::min(chunk, bytes - off)); });
+    }
+    std::memcpy(dst, src, std::min(chunk, bytes));
+    for (std::thread &t : pool)
+        t.join();
+}
+
+MLSGPU_API int mlsgpu_hip_farm_submit(mlsgpu_farm *f, const mlsgpu_splat *hSplats, uint64_t numSplats,
+                                      const int32_t lowExtent[3], const uint32_t numVertices[3], uint64_t chunkId)
+{
+    REQUIRE(f != nullptr && lowExtent != nullptr && numVertices != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(numSplats == 0 || hSplats != nullptr, MLSGPU_ERR_INVALID);
+    mlsgpu_splat *dst = nullptr;
+    PROPAGATE(mlsgpu_hip_farm_acquire(f, numSplats, &dst));
+    parallelCopy(dst, hSplats, numSplats * sizeof(mlsgpu_splat), f->cfg.copyThreads == 0 ? 4u : f->cfg.copyThreads);
+    return mlsgpu_hip_farm_push(f, numSplats, lowExtent, numVertices, chunkId);
 }
 
 MLSGPU_API int mlsgpu_hip_farm_finish(mlsgpu_farm *f)

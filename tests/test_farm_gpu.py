@@ -34,7 +34,13 @@ def test_farm_matches_oracle(workers):
     cap = 3 * max(b.count for b in buckets) // 2          # room for more than one bucket per item
     farm = m.BucketFarm([0], cap, workers_per_device=workers, collect=True, max_cells=63)
     for i, b in enumerate(buckets):
-        farm.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, i)
+        if i % 2 == 0:
+            farm.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, i)
+        else:
+            # the loader's route (CopyGroup::get / push): write the bucket straight into pinned staging
+            room = farm.acquire(b.count)
+            room[:] = allb[b.first:b.first + b.count]
+            farm.push(b.count, b.low, b.num_vertices, i)
     farm.finish()
     st = farm.stats()
     assert st["buckets"] == 27 and st["splats"] == len(allb) and st["h2d_bytes"] == 32 * len(allb)
