@@ -88,8 +88,70 @@ def lib():
         L.orc_bucket.argtypes = [vp, u64, u64, vp, vp, u32, u32, f32, C.c_int, u32, u32, u64,
                                  OUTPUT_FN, vp, vp]
         L.orc_num_threads.restype = C.c_int
+        L.orc_bucket_partition.restype = C.c_int
+        L.orc_bucket_partition.argtypes = [vp, u64, vp, f32, vp, u64, u32, u32, u32, u64, BUCKET_LEAF_FN, vp, vp]
+        L.orc_splat_to_buckets.argtypes = [vp, vp, f32, vp, u32, vp, vp]
+        L.orc_for_each_node.restype = C.c_int
+        L.orc_for_each_node.argtypes = [vp, u32, vp, vp, C.c_int]
+        L.orc_node_child.argtypes = [vp, u32, vp]
+        L.orc_choose_micro_size.restype = u32
+        L.orc_choose_micro_size.argtypes = [vp, u64, u64, u64, u32]
         _lib = L
     return _lib
+
+
+BUCKET_LEAF_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_uint64), C.c_uint32, C.c_uint64,
+                             C.POINTER(C.c_uint64))
+
+
+class DensityError(RuntimeError):
+    """Bucket::DensityError, src/bucket.h:52-65"""
+    def __init__(self, cell_splats):
+        super().__init__("Too many splats covering one cell")
+        self.cell_splats = cell_splats
+
+
+def bucket_partition(splats, reference, spacing, extents, max_splats, max_cells, chunk_cells, micro_cells, max_split):
+    """Bucket::bucket: list of leaves dict(extents=(x0,x1,y0,y1,z0,z1), chunk, depth, ids) in callback order."""
+    assert splats.dtype == SPLAT_DTYPE and splats.flags.c_contiguous
+    leaves = []
+
+    def leaf(_user, ext, chunk, depth, n, ids):
+        leaves.append(dict(extents=tuple(int(ext[i]) for i in range(6)), chunk=tuple(int(chunk[i]) for i in range(3)),
+                           depth=int(depth), ids=np.ctypeslib.as_array(ids, shape=(n,)).copy() if n else np.zeros(0, np.uint64)))
+        return 0
+    cb = BUCKET_LEAF_FN(leaf)
+    ref = np.asarray(reference, np.float32)
+    ext = np.asarray(extents, np.int32).reshape(6)
+    cell = np.zeros(1, np.uint64)
+    rc = lib().orc_bucket_partition(_p(splats), len(splats), _p(ref), float(spacing), _p(ext), max_splats, max_cells,
+                                    chunk_cells, micro_cells, max_split, cb, None, _p(cell))
+    if rc == 1:
+        raise DensityError(int(cell[0]))
+    if rc != 0:
+        raise ValueError("orc_bucket_partition failed: %d" % rc)
+    return leaves
+
+
+def splat_to_buckets(splat, reference, spacing, extents, bucket_size):
+    s = np.zeros(1, SPLAT_DTYPE)
+    s[0] = splat
+    lower, upper = np.zeros(3, np.int64), np.zeros(3, np.int64)
+    lib().orc_splat_to_buckets(_p(s), _p(np.asarray(reference, np.float32)), float(spacing),
+                               _p(np.asarray(extents, np.int32).reshape(6)), bucket_size, _p(lower), _p(upper))
+    return lower, upper
+
+
+def for_each_node(dims, levels, inside):
+    out = np.zeros((4096, 4), np.uint32)
+    n = lib().orc_for_each_node(_p(np.asarray(dims, np.uint32)), levels, _p(np.asarray(inside, np.uint32)), _p(out), 4096)
+    return [tuple(int(v) for v in r) for r in out[:n]]
+
+
+def node_child(node, idx):
+    out = np.zeros(4, np.uint32)
+    lib().orc_node_child(_p(np.asarray(node, np.uint32)), idx, _p(out))
+    return tuple(int(v) for v in out)
 
 
 def _p(a):
