@@ -37,6 +37,7 @@ extern "C" {
 #define MLSGPU_ERR_HIP 3
 #define MLSGPU_ERR_NOMEM 4
 #define MLSGPU_ERR_CALLBACK 5
+#define MLSGPU_ERR_DENSITY 6   /* Bucket::DensityError, src/bucket.h:52-65 */
 
 /* struct Splat, src/splat.h:40-46 == kernels/octree.cl:32-36 (32 bytes, AoS).
  * After mlsgpu_hip_tree_build the radius slot holds 1/radius^2 (octree.cl:193). */
@@ -281,6 +282,44 @@ int mlsgpu_hip_farm_stats(mlsgpu_farm *farm, uint64_t out[24]);
  * position = (position - reference) * (1/spacing) - lowExtent, radius *= 1/spacing.  Host-side, in place. */
 void mlsgpu_hip_transform_splats(mlsgpu_splat *hSplats, uint64_t numSplats, const float reference[3], float spacing,
                                  const int32_t gridLowExtent[3]);
+
+/* ---- bucketing of a cloud that is resident in HBM: Bucket::bucket, src/bucket.h:116-180 ---- */
+typedef struct mlsgpu_grid          /* class Grid, src/grid.h: world = reference + spacing * vertex */
+{
+    float reference[3];
+    float spacing;
+    int32_t extents[6];             /* per axis [first, second): second - first cells, one more vertices */
+} mlsgpu_grid;
+typedef struct mlsgpu_bucket_params /* the arguments of Bucket::bucket, src/bucket.h:170-180 */
+{
+    uint64_t maxSplats;             /* --mem-bucket-splats / sizeof(Splat) */
+    uint32_t maxCells;              /* side of a bucket in cells: (1 << (levels + subsampling - 1)) - 1 */
+    uint32_t chunkCells;            /* output chunk alignment; 0 = none */
+    uint32_t microCells;            /* requested microblock side; 0 = heuristic (chooseMicroSize) */
+    uint64_t maxSplit;              /* maximum fan-out of one recursion level, >= 8 */
+} mlsgpu_bucket_params;
+typedef struct mlsgpu_bucket        /* what ProcessorType's callback receives, src/bucket.h:98-114 */
+{
+    int32_t extents[6];             /* the bucket's grid: same reference and spacing, these extents */
+    uint64_t chunk[3];              /* Recursion::chunk */
+    uint32_t depth;                 /* Recursion::depth */
+    uint64_t numSplats;
+    const uint32_t *dIds;           /* device: ids of the bucket's splats, ascending; valid during the callback */
+} mlsgpu_bucket;
+typedef int (*mlsgpu_bucket_fn)(void *user, mlsgpu_ctx *ctx, const mlsgpu_bucket *bucket);
+/* Splits `region` into buckets of at most maxCells cells per side and maxSplats splats and calls fn for each non-empty
+ * one, in the reference's order.  dSplats: all splats, world coordinates, on the device (non-finite ones are ignored
+ * as by the reference's splat sets).  MLSGPU_ERR_DENSITY if a single cell holds more than maxSplats splats
+ * (*cellSplats = how many).  The octree of counters of one level is dense here: at most 2^24 nodes. */
+int mlsgpu_hip_bucket(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, uint64_t numSplats, const mlsgpu_grid *region,
+                      const mlsgpu_bucket_params *params, mlsgpu_bucket_fn fn, void *user, uint64_t *cellSplats);
+/* BucketLoader (src/bucket_loader.cpp:77-85, Grid::worldToVertex src/grid.cpp:99-106) on the device:
+ * dOut[i] = splat dIds[i] (or i if dIds is NULL) in the vertex coordinates of fullGrid:
+ * (position - reference) / spacing - fullGrid.extents[first], radius / spacing.  dOut is what
+ * mlsgpu_hip_worker_process takes, with lowExtent = bucket.extents[first] - fullGrid.extents[first] and
+ * numVertices = bucket cells + 1 (the subGrid of src/bucket_loader.cpp:91-102). */
+int mlsgpu_hip_bucket_load(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, const uint32_t *dIds, uint64_t numSplats,
+                           const mlsgpu_grid *fullGrid, mlsgpu_splat *dOut);
 
 /* DeviceWorkerGroupBase::computeMaxSwathe, src/workers.cpp:169-182 */
 uint32_t mlsgpu_hip_compute_max_swathe(uint32_t yMax, uint32_t y, uint32_t yAlign, uint32_t zAlign);

@@ -28,6 +28,10 @@ class LengthError(MlsError, ValueError):
     """std::length_error in the reference."""
 
 
+class DensityError(MlsError, RuntimeError):
+    """Bucket::DensityError (src/bucket.h:52-65): more than maxSplats splats cover a single cell."""
+
+
 class HipError(MlsError, RuntimeError):
     """cl::Error in the reference."""
 
@@ -58,6 +62,23 @@ class WorkerConfig(C.Structure):
                 ("levels", C.c_uint32), ("subsampling", C.c_uint32), ("boundaryLimit", C.c_float),
                 ("shape", C.c_int), ("maxSwathe", C.c_uint32), ("gridSpacing", C.c_float),
                 ("gridOrigin", C.c_float * 3)]
+
+
+class GridStruct(C.Structure):
+    _fields_ = [("reference", C.c_float * 3), ("spacing", C.c_float), ("extents", C.c_int32 * 6)]
+
+
+class BucketParams(C.Structure):
+    _fields_ = [("maxSplats", C.c_uint64), ("maxCells", C.c_uint32), ("chunkCells", C.c_uint32), ("microCells", C.c_uint32),
+                ("maxSplit", C.c_uint64)]
+
+
+class BucketStruct(C.Structure):
+    _fields_ = [("extents", C.c_int32 * 6), ("chunk", C.c_uint64 * 3), ("depth", C.c_uint32), ("numSplats", C.c_uint64),
+                ("dIds", C.c_void_p)]
+
+
+BUCKET_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(BucketStruct))
 
 
 class FarmConfig(C.Structure):
@@ -160,6 +181,8 @@ def lib():
     sig("mlsgpu_hip_farm_finish", C.c_int, vp)
     sig("mlsgpu_hip_farm_stats", C.c_int, vp, vp)
     sig("mlsgpu_hip_transform_splats", None, vp, u64, vp, f32, vp)
+    sig("mlsgpu_hip_bucket", C.c_int, vp, vp, u64, P(GridStruct), P(BucketParams), BUCKET_FN, vp, P(u64))
+    sig("mlsgpu_hip_bucket_load", C.c_int, vp, vp, vp, u64, P(GridStruct), vp)
     sig("mlsgpu_hip_test_make_code", C.c_int, vp, C.c_int, C.c_int, C.c_int, P(u32))
     sig("mlsgpu_hip_test_level_shift", C.c_int, vp, vp, vp, P(i32))
     sig("mlsgpu_hip_test_point_box_dist2", C.c_int, vp, vp, vp, vp, P(f32))
@@ -173,7 +196,7 @@ def lib():
     return L
 
 
-_ERRORS = {1: InvalidArgument, 2: LengthError, 3: HipError, 4: HipError, 5: MlsError}
+_ERRORS = {1: InvalidArgument, 2: LengthError, 3: HipError, 4: HipError, 5: MlsError, 6: DensityError}
 
 
 def check(rc):
@@ -668,6 +691,65 @@ class BucketFarm:
             self.close()
         except Exception:
             pass
+
+
+def _grid_struct(reference, spacing, extents):
+    g = GridStruct()
+    for i in range(3):
+        g.reference[i] = float(reference[i])
+    g.spacing = float(spacing)
+    ext = np.asarray(extents, np.int64).reshape(6)
+    for i in range(6):
+        g.extents[i] = int(ext[i])
+    return g
+
+
+def bucket_cloud(ctx, d_splats, num_splats, reference, spacing, extents, max_splats, max_cells, chunk_cells=0,
+                 micro_cells=0, max_split=1 << 30, on_bucket=None):
+    """Bucket::bucket (src/bucket.h:170-180) over a cloud resident on the device.
+
+    on_bucket(leaf, d_ids_ptr) is called for every bucket while its id list is valid on the device; without it the
+    ids are copied to the host.  Returns the list of leaves dict(extents, chunk, depth, num_splats[, ids])."""
+    leaves = []
+    failure = []
+
+    def cb(_user, _ctx, b):
+        try:
+            b = b.contents
+            leaf = dict(extents=tuple(int(b.extents[i]) for i in range(6)), chunk=tuple(int(b.chunk[i]) for i in range(3)),
+                        depth=int(b.depth), num_splats=int(b.numSplats))
+            if on_bucket is not None:
+                on_bucket(leaf, b.dIds)
+            else:
+                ids = np.empty(leaf["num_splats"], np.uint32)
+                if len(ids):
+                    check(lib().mlsgpu_hip_memcpy_d2h(ctx.h, _p(ids), b.dIds, ids.nbytes, 0))
+                leaf["ids"] = ids
+            leaves.append(leaf)
+            return 0
+        except Exception as e:      # noqa: BLE001 - reported after the C call returns
+            failure.append(e)
+            return 1
+    fn = BUCKET_FN(cb)
+    g = _grid_struct(reference, spacing, extents)
+    p = BucketParams(max_splats, max_cells, chunk_cells, micro_cells, max_split)
+    cell = C.c_uint64(0)
+    rc = lib().mlsgpu_hip_bucket(ctx.h, d_splats.ptr if d_splats is not None else None, num_splats, C.byref(g), C.byref(p),
+                                 fn, None, C.byref(cell))
+    if failure:
+        raise failure[0]
+    if rc == 6:
+        e = DensityError("[6] " + lib().mlsgpu_hip_last_error().decode("utf-8", "replace"))
+        e.cell_splats = int(cell.value)
+        raise e
+    check(rc)
+    return leaves
+
+
+def bucket_load(ctx, d_splats, d_ids_ptr, num_splats, reference, spacing, extents, d_out):
+    """BucketLoader's gather + world -> full-grid vertex transform on the device (src/bucket_loader.cpp:77-85)."""
+    g = _grid_struct(reference, spacing, extents)
+    check(lib().mlsgpu_hip_bucket_load(ctx.h, d_splats.ptr, d_ids_ptr, num_splats, C.byref(g), d_out.ptr))
 
 
 def transform_splats(splats, reference, spacing, low_extent):

@@ -1,0 +1,578 @@
+/*
+ * Device-side bucketing: Bucket::bucket (src/bucket.h:116-180, src/bucket_impl.h:439-560, src/bucket.cpp:133-377)
+ * for a splat cloud that is resident in HBM -- row f2 of SURVEY.md section 8.
+ *
+ * The reference streams blobs of an out-of-core splat set twice per recursion level through one host thread
+ * (count into hash-mapped octree counters, then append id ranges to the chosen regions).  With 288 GB of HBM
+ * the whole cloud (32 B per splat) stays on the device, so each level is:
+ *   1. bucketCountKernel   every splat adds 1 to each octree node (all levels) its microblock range meets --
+ *                          the values the reference's delta-encoded counters hold after upsweepCounts;
+ *                          LDS-privatised when the dense octree fits (it does for the default 63-cell leaves);
+ *   2. host: pickNodes on the few hundred counters (same traversal order, so regions are numbered alike);
+ *   3. a scan whose producer counts the regions a splat joins ("once per node", bucket.cpp:291-301) and whose
+ *      consumer writes (region, splat id) pairs, a STABLE radix sort by region, and a boundary kernel:
+ *      every region's member list, ids ascending -- exactly the reference's subset;
+ *   4. recursion into each region (depth first, in region order) with its id list in place of all splats.
+ * Leaves are handed to the callback with their id list still on the device; mlsgpu_hip_bucket_load gathers
+ * them and transforms them into the full grid's vertex coordinates (BucketLoader, src/bucket_loader.cpp:77-85)
+ * ready for mlsgpu_hip_worker_process -- no host round trip of splat data at all.
+ */
+#include "common.hpp"
+#include "primitives.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+using namespace mlsgpu;
+
+namespace
+{
+
+enum { MAX_LEVELS = 32, LDS_NODES = 8192 };
+
+/* what a kernel needs to map a splat to the microblocks of one chunk's region */
+struct RegionView
+{
+    const mlsgpu_splat *splats;
+    const uint32_t *ids;        /* nullptr: splat i is splat i */
+    float ref[3];
+    float invSpacing;
+    int32_t first[3];           /* grid extents' lower ends (the grid being split, not the chunk) */
+    uint32_t microSize;
+    int32_t bias[3];            /* chunk coordinate * chunkRatio, in microblocks */
+    uint32_t dims[3];           /* microblocks of this chunk's region */
+
+    __device__ __forceinline__ uint32_t splatId(uint64_t i) const { return ids ? ids[i] : (uint32_t) i; }
+
+    /* splatToBuckets (src/splat_set.cpp:52-72, Grid::worldToCell src/grid.cpp:108-129) + BucketStateSet's chunk
+     * bias (bucket_impl.h:318-323) + BucketState::clamp (src/bucket.cpp:176-194) */
+    __device__ __forceinline__ bool range(uint32_t id, uint32_t lo[3], uint32_t hi[3]) const
+    {
+        const mlsgpu_splat s = splats[id];
+        if (!(isfinite(s.position[0]) && isfinite(s.position[1]) && isfinite(s.position[2]) && isfinite(s.radius)
+              && isfinite(s.normal[0]) && isfinite(s.normal[1]) && isfinite(s.normal[2]) && isfinite(s.quality)))
+            return false;       /* never enumerated by a splat set, src/splat_set.h:191 */
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+        {
+            const float loWorld = s.position[a] - s.radius, hiWorld = s.position[a] + s.radius;
+            const long long cl = (long long) floorf((loWorld - ref[a]) * invSpacing) - first[a];
+            const long long ch = (long long) floorf((hiWorld - ref[a]) * invSpacing) - first[a];
+            const long long m = (long long) microSize;
+            long long l = (cl >= 0 ? cl / m : -((-cl + m - 1) / m)) - bias[a];      /* divDown */
+            long long h = (ch >= 0 ? ch / m : -((-ch + m - 1) / m)) - bias[a];
+            if (l < 0) l = 0;
+            if (h >= (long long) dims[a]) h = (long long) dims[a] - 1;
+            if (l > h)
+                return false;
+            lo[a] = (uint32_t) l;
+            hi[a] = (uint32_t) h;
+        }
+        return true;
+    }
+};
+
+struct LevelLayout
+{
+    uint32_t levels;
+    uint32_t dims[MAX_LEVELS][3];
+    uint32_t offset[MAX_LEVELS + 1];
+};
+
+/* countSplats + upsweepCounts (src/bucket.cpp:161-174, 207-246) without the delta encoding */
+template<bool LDS>
+__global__ __launch_bounds__(256) void bucketCountKernel(RegionView V, LevelLayout L, uint32_t *counts, uint64_t n)
+{
+    __shared__ uint32_t local[LDS ? LDS_NODES : 1];
+    const uint32_t total = L.offset[L.levels];
+    if (LDS)
+    {
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x)
+            local[i] = 0;
+        __syncthreads();
+    }
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+    {
+        uint32_t lo[3], hi[3];
+        if (!V.range(V.splatId(i), lo, hi))
+            continue;
+        for (uint32_t l = 0; l < L.levels; l++)
+        {
+            const uint32_t dx = L.dims[l][0], dy = L.dims[l][1];
+            for (uint32_t z = lo[2] >> l; z <= (hi[2] >> l); z++)
+                for (uint32_t y = lo[1] >> l; y <= (hi[1] >> l); y++)
+                    for (uint32_t x = lo[0] >> l; x <= (hi[0] >> l); x++)
+                    {
+                        const uint32_t node = L.offset[l] + (z * dy + y) * dx + x;
+                        if (LDS)
+                            atomicAdd(&local[node], 1u);
+                        else
+                            atomicAdd(&counts[node], 1u);
+                    }
+        }
+    }
+    if (LDS)
+    {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x)
+            if (local[i] != 0)
+                atomicAdd(&counts[i], local[i]);
+    }
+}
+
+/* bucketSplats, src/bucket.cpp:271-302: table[microblock] = region id << 5 | node level */
+struct RegionCountIn
+{
+    RegionView V;
+    const uint32_t *table;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const
+    {
+        uint32_t lo[3], hi[3];
+        if (!V.range(V.splatId(i), lo, hi))
+            return 0;
+        uint32_t k = 0;
+        for (uint32_t x = lo[0]; x <= hi[0]; x++)
+            for (uint32_t y = lo[1]; y <= hi[1]; y++)
+                for (uint32_t z = lo[2]; z <= hi[2]; z++)
+                {
+                    const uint32_t t = table[(z * V.dims[1] + y) * V.dims[0] + x];
+                    const uint32_t mask = (1u << (t & 31u)) - 1;
+                    if ((x == lo[0] || (x & mask) == 0) && (y == lo[1] || (y & mask) == 0) && (z == lo[2] || (z & mask) == 0))
+                        k++;
+                }
+        return k;
+    }
+};
+
+struct RegionEmitOut
+{
+    RegionView V;
+    const uint32_t *table;
+    uint32_t *keys, *vals;
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t count) const
+    {
+        if (count == 0)
+            return;
+        const uint32_t id = V.splatId(i);
+        uint32_t lo[3], hi[3];
+        V.range(id, lo, hi);
+        for (uint32_t x = lo[0]; x <= hi[0]; x++)
+            for (uint32_t y = lo[1]; y <= hi[1]; y++)
+                for (uint32_t z = lo[2]; z <= hi[2]; z++)
+                {
+                    const uint32_t t = table[(z * V.dims[1] + y) * V.dims[0] + x];
+                    const uint32_t mask = (1u << (t & 31u)) - 1;
+                    if ((x == lo[0] || (x & mask) == 0) && (y == lo[1] || (y & mask) == 0) && (z == lo[2] || (z & mask) == 0))
+                    {
+                        keys[excl] = t >> 5;
+                        vals[excl] = id;
+                        excl++;
+                    }
+                }
+    }
+};
+
+/* first pair of every region in the region-sorted list (every region has at least one member) */
+__global__ void regionStartsKernel(const uint32_t *keys, uint64_t n, uint32_t *starts)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    if (i == 0 || keys[i] != keys[i - 1])
+        starts[keys[i]] = (uint32_t) i;
+}
+
+/* BucketLoader, src/bucket_loader.cpp:77-85 with Grid::worldToVertex (src/grid.cpp:99-106) */
+__global__ void bucketLoadKernel(const mlsgpu_splat *splats, const uint32_t *ids, uint64_t n, float rx, float ry, float rz,
+                                 float invSpacing, float lx, float ly, float lz, mlsgpu_splat *out)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    mlsgpu_splat s = splats[ids ? ids[i] : (uint32_t) i];
+    s.position[0] = (s.position[0] - rx) * invSpacing - lx;
+    s.position[1] = (s.position[1] - ry) * invSpacing - ly;
+    s.position[2] = (s.position[2] - rz) * invSpacing - lz;
+    s.radius *= invSpacing;
+    out[i] = s;
+}
+
+uint32_t bitsForCount(uint32_t count)
+{
+    uint32_t b = 1;
+    while (b < 32 && (count - 1) >> b)
+        b++;
+    return b;
+}
+
+uint64_t mulSat(uint64_t a, uint64_t b)
+{
+    if (a == 0 || b == 0)
+        return 0;
+    return a > UINT64_MAX / b ? UINT64_MAX : a * b;
+}
+
+/* chooseMicroSize, src/bucket.cpp:354-377 */
+uint32_t chooseMicroSize(const uint32_t dims[3], uint64_t maxSplit, uint64_t numSplats, uint64_t maxSplats, uint32_t maxCells)
+{
+    uint32_t microSize = 1;
+    auto blocks = [&]()
+    {
+        uint64_t b = 1;
+        for (int i = 0; i < 3; i++)
+            b = mulSat(b, divUp(dims[i], microSize));
+        return b;
+    };
+    uint64_t microBlocks = blocks();
+    const double target = 0.5 * std::min(std::min(dims[0], dims[1]), dims[2]) * std::sqrt((double) maxSplats / (double) numSplats);
+    while (microBlocks > maxSplit || (microBlocks > 8 && microSize < target * 0.5 && (uint64_t) microSize * 2 <= maxCells))
+    {
+        microSize *= 2;
+        microBlocks = blocks();
+    }
+    return microSize;
+}
+
+struct GridBox
+{
+    int32_t lo[3], hi[3];
+    uint32_t cells(int i) const { return (uint32_t) (hi[i] - lo[i]); }
+};
+
+/* device scratch of one recursion depth; a level's sorted member lists must outlive the recursion below it */
+struct DepthBuffers
+{
+    uint32_t *keysA = nullptr, *valsA = nullptr, *keysB = nullptr, *valsB = nullptr;
+    uint32_t *hist = nullptr, *tileSums = nullptr;
+    uint64_t pairCap = 0;
+    uint32_t *counts = nullptr, *table = nullptr, *starts = nullptr;
+    uint32_t nodeCap = 0, regionCap = 0;
+    uint32_t *total = nullptr;
+    uint32_t *scanSums = nullptr;
+    uint64_t scanCap = 0;
+    ~DepthBuffers()
+    {
+        hipFree(scanSums);
+        hipFree(keysA); hipFree(valsA); hipFree(keysB); hipFree(valsB); hipFree(hist); hipFree(tileSums);
+        hipFree(counts); hipFree(table); hipFree(starts); hipFree(total);
+    }
+};
+
+struct Bucketer
+{
+    mlsgpu_ctx *ctx;
+    const mlsgpu_splat *dSplats;
+    uint64_t numSplats;
+    mlsgpu_grid full;
+    mlsgpu_bucket_params P;
+    mlsgpu_bucket_fn fn;
+    void *user;
+    uint64_t cellSplats = 0;
+    std::vector<std::unique_ptr<DepthBuffers> > depthBufs;
+
+    int ensure(uint32_t **p, size_t elems)
+    {
+        hipFree(*p);
+        *p = nullptr;
+        HIP_CHECK(hipMalloc((void **) p, std::max<size_t>(elems, 1) * sizeof(uint32_t)));
+        return MLSGPU_OK;
+    }
+
+    int recurse(const uint32_t *dIds, uint64_t n, bool isSubset, const GridBox &grid, uint32_t chunkCells, uint32_t microCells,
+                uint32_t depth, const uint64_t chunkIn[3]);
+};
+
+/* bucketRecurse, src/bucket_impl.h:439-560 */
+int Bucketer::recurse(const uint32_t *dIds, uint64_t n, bool isSubset, const GridBox &grid, uint32_t chunkCells,
+                      uint32_t microCells, uint32_t depth, const uint64_t chunkIn[3])
+{
+    uint32_t cellDims[3];
+    for (int i = 0; i < 3; i++)
+        cellDims[i] = grid.cells(i);
+    const uint32_t maxCellDim = std::max(std::max(cellDims[0], cellDims[1]), cellDims[2]);
+    if (isSubset && n <= P.maxSplats && maxCellDim <= P.maxCells && (chunkCells == 0 || chunkCells >= maxCellDim))
+    {
+        mlsgpu_bucket b;
+        for (int i = 0; i < 3; i++)
+        {
+            b.extents[2 * i] = grid.lo[i];
+            b.extents[2 * i + 1] = grid.hi[i];
+            b.chunk[i] = chunkIn[i];
+        }
+        b.depth = depth;
+        b.numSplats = n;
+        b.dIds = dIds;
+        const int rc = fn(user, ctx, &b);
+        if (rc != 0)
+            return setError(MLSGPU_ERR_CALLBACK, "bucket callback failed with %d", rc);
+        return MLSGPU_OK;
+    }
+    if (maxCellDim == 1)
+    {
+        cellSplats = n;
+        return setError(MLSGPU_ERR_DENSITY, "Too many splats covering one cell (%llu)", (unsigned long long) n);
+    }
+    uint32_t microSize = microCells;
+    if (microSize == 0 || microSize > maxCellDim)
+        microSize = chooseMicroSize(cellDims, P.maxSplit, n, P.maxSplats, P.maxCells);
+    while (true)
+    {
+        uint64_t microBlocks = 1;
+        for (int i = 0; i < 3; i++)
+            microBlocks = mulSat(microBlocks, divUp(cellDims[i], microSize));
+        if (microBlocks <= P.maxSplit)
+            break;
+        microSize *= 2;
+    }
+    if (chunkCells == 0)
+        chunkCells = maxCellDim;
+    else
+        chunkCells = std::min(maxCellDim, chunkCells);
+    if (chunkCells > P.maxCells)
+    {
+        uint64_t grain = (uint64_t) P.maxCells / microSize * microSize;
+        if (grain == 0)
+            grain = microSize;
+        chunkCells = (uint32_t) ((chunkCells + grain - 1) / grain * grain);
+    }
+    else
+        chunkCells = roundUp(chunkCells, microSize);
+    uint32_t chunks[3];
+    for (int i = 0; i < 3; i++)
+        chunks[i] = divUp(cellDims[i], chunkCells);
+    uint32_t macroLevels = 1;
+    while (((uint64_t) microSize << (macroLevels - 1)) < chunkCells)
+        macroLevels++;
+    REQUIRE(macroLevels <= MAX_LEVELS, MLSGPU_ERR_LENGTH);
+    const uint32_t chunkRatio = chunkCells / microSize;
+
+    while (depthBufs.size() <= depth)
+        depthBufs.emplace_back(new DepthBuffers);
+    DepthBuffers &B = *depthBufs[depth];
+    if (B.total == nullptr)
+        PROPAGATE(ensure(&B.total, 2));
+
+    /* chunks x-major as the callbacks of bucket_impl.h:548-553; the chunks' states are independent */
+    for (uint32_t cx = 0; cx < chunks[0]; cx++)
+        for (uint32_t cy = 0; cy < chunks[1]; cy++)
+            for (uint32_t cz = 0; cz < chunks[2]; cz++)
+            {
+                const uint32_t cc[3] = {cx, cy, cz};
+                GridBox sub;            /* BucketStateSet, src/bucket.cpp:304-331 */
+                for (int i = 0; i < 3; i++)
+                {
+                    const int64_t off = (int64_t) cc[i] * chunkCells;
+                    sub.lo[i] = (int32_t) (grid.lo[i] + off);
+                    sub.hi[i] = (int32_t) std::min<int64_t>(grid.lo[i] + off + chunkCells, grid.hi[i]);
+                }
+                RegionView V;
+                V.splats = dSplats;
+                V.ids = dIds;
+                V.invSpacing = 1.0f / full.spacing;
+                V.microSize = microSize;
+                LevelLayout L;
+                L.levels = macroLevels;
+                for (int i = 0; i < 3; i++)
+                {
+                    V.ref[i] = full.reference[i];
+                    V.first[i] = grid.lo[i];
+                    V.bias[i] = (int32_t) (cc[i] * chunkRatio);
+                    V.dims[i] = divUp(sub.cells(i), microSize);
+                }
+                uint64_t totalNodes = 0;
+                for (uint32_t l = 0; l < macroLevels; l++)
+                {
+                    L.offset[l] = (uint32_t) totalNodes;
+                    uint64_t t = 1;
+                    for (int i = 0; i < 3; i++)
+                    {
+                        L.dims[l][i] = divUp(V.dims[i], (uint64_t) 1 << l);
+                        t *= L.dims[l][i];
+                    }
+                    totalNodes += t;
+                    REQUIRE(totalNodes <= (1u << 24), MLSGPU_ERR_LENGTH);      /* dense counters; the reference hashes */
+                }
+                L.offset[macroLevels] = (uint32_t) totalNodes;
+                const uint32_t n0 = V.dims[0] * V.dims[1] * V.dims[2];
+                if (B.nodeCap < totalNodes)
+                {
+                    PROPAGATE(ensure(&B.counts, totalNodes));
+                    PROPAGATE(ensure(&B.table, totalNodes));
+                    B.nodeCap = (uint32_t) totalNodes;
+                }
+                /* 1. counts */
+                HIP_CHECK(hipMemsetAsync(B.counts, 0, totalNodes * 4, ctx->stream));
+                if (n > 0)
+                {
+                    const uint32_t blocks = (uint32_t) std::min<uint64_t>(divUp(n, 256), 4096);
+                    if (totalNodes <= LDS_NODES)
+                        LAUNCH(ctx, "bucket.count.time", (bucketCountKernel<true>), dim3(blocks), dim3(256), V, L, B.counts, n);
+                    else
+                        LAUNCH(ctx, "bucket.count.time", (bucketCountKernel<false>), dim3(blocks), dim3(256), V, L, B.counts, n);
+                }
+                std::vector<uint32_t> counts(totalNodes);
+                HIP_CHECK(hipMemcpyAsync(counts.data(), B.counts, totalNodes * 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_CHECK(hipStreamSynchronize(ctx->stream));
+
+                /* 2. pickNodes (src/bucket.cpp:248-269, PickNodes :333-352): depth-first, children x fastest */
+                struct Region { uint32_t c[3]; uint32_t level; };
+                std::vector<Region> regions;
+                std::vector<uint32_t> table(n0, 0);
+                struct Frame { uint32_t c[3]; uint32_t level; };
+                std::vector<Frame> stack;
+                stack.push_back(Frame{{0, 0, 0}, macroLevels - 1});
+                while (!stack.empty())
+                {
+                    const Frame f = stack.back();
+                    stack.pop_back();
+                    const uint32_t count = counts[L.offset[f.level] + (f.c[2] * L.dims[f.level][1] + f.c[1]) * L.dims[f.level][0] + f.c[0]];
+                    if (count == 0)
+                        continue;
+                    if (f.level == 0 || (((uint64_t) microSize << f.level) <= P.maxCells && count <= P.maxSplats))
+                    {
+                        const uint32_t id = (uint32_t) regions.size();
+                        REQUIRE(id < (1u << 27), MLSGPU_ERR_LENGTH);
+                        regions.push_back(Region{{f.c[0], f.c[1], f.c[2]}, f.level});
+                        for (uint32_t z = f.c[2] << f.level; z < std::min(V.dims[2], (f.c[2] + 1) << f.level); z++)
+                            for (uint32_t y = f.c[1] << f.level; y < std::min(V.dims[1], (f.c[1] + 1) << f.level); y++)
+                                for (uint32_t x = f.c[0] << f.level; x < std::min(V.dims[0], (f.c[0] + 1) << f.level); x++)
+                                    table[(z * V.dims[1] + y) * V.dims[0] + x] = (id << 5) | f.level;
+                        continue;
+                    }
+                    for (int idx = 7; idx >= 0; idx--)     /* pushed in reverse so that child 0 is visited first */
+                    {
+                        const Frame ch{{f.c[0] * 2 + (idx & 1), f.c[1] * 2 + ((idx >> 1) & 1), f.c[2] * 2 + (uint32_t) (idx >> 2)}, f.level - 1};
+                        bool inside = true;
+                        for (int j = 0; j < 3; j++)
+                            if (((uint64_t) ch.c[j] << ch.level) >= V.dims[j])
+                                inside = false;
+                        if (inside)
+                            stack.push_back(ch);
+                    }
+                }
+                if (regions.empty())
+                    continue;
+                const uint32_t numRegions = (uint32_t) regions.size();
+                HIP_CHECK(hipMemcpyAsync(B.table, table.data(), (size_t) n0 * 4, hipMemcpyHostToDevice, ctx->stream));
+                if (B.regionCap < numRegions + 1)
+                {
+                    PROPAGATE(ensure(&B.starts, numRegions + 1));
+                    B.regionCap = numRegions + 1;
+                }
+
+                /* 3. member lists */
+                const RegionCountIn in{V, B.table};
+                if (B.scanCap < scanTiles(n))
+                {
+                    PROPAGATE(ensure(&B.scanSums, scanTiles(n)));
+                    B.scanCap = scanTiles(n);
+                }
+                uint32_t *tileSums = B.scanSums;
+                /* the pair total is needed before the pair buffers can be sized */
+                int rc = scanPhase1<uint32_t, RegionCountIn>(ctx, "bucket.members.time", in, n, 0u, tileSums, B.total);
+                uint32_t totalPairs = 0;
+                if (rc == MLSGPU_OK && hipMemcpyAsync(&totalPairs, B.total, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+                    rc = setError(MLSGPU_ERR_HIP, "bucket: readback failed");
+                if (rc == MLSGPU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
+                    rc = setError(MLSGPU_ERR_HIP, "bucket: synchronise failed");
+                if (rc == MLSGPU_OK && B.pairCap < totalPairs)
+                {
+                    const uint64_t cap = (uint64_t) totalPairs + totalPairs / 8 + 1024;
+                    rc = ensure(&B.keysA, cap);
+                    if (rc == MLSGPU_OK) rc = ensure(&B.valsA, cap);
+                    if (rc == MLSGPU_OK) rc = ensure(&B.keysB, cap);
+                    if (rc == MLSGPU_OK) rc = ensure(&B.valsB, cap);
+                    if (rc == MLSGPU_OK) rc = ensure(&B.hist, sortHistElems(cap));
+                    if (rc == MLSGPU_OK) rc = ensure(&B.tileSums, scanTiles(std::max<uint64_t>(sortHistElems(cap), cap)));
+                    B.pairCap = rc == MLSGPU_OK ? cap : 0;
+                }
+                if (rc == MLSGPU_OK)
+                    rc = scanPhase2<uint32_t, RegionCountIn, RegionEmitOut>(ctx, "bucket.members.time", in,
+                                                                           RegionEmitOut{V, B.table, B.keysA, B.valsA}, n,
+                                                                           (const uint32_t *) tileSums);
+                SortResult<uint32_t> sorted{B.keysA, B.valsA};
+                if (rc == MLSGPU_OK)
+                    rc = radixSort<uint32_t>(ctx, "bucket.members.time", B.keysA, B.valsA, B.keysB, B.valsB, totalPairs,
+                                             bitsForCount(numRegions), false, B.hist, B.tileSums, &sorted);
+                std::vector<uint32_t> starts(numRegions + 1, 0);
+                if (rc == MLSGPU_OK && totalPairs > 0)
+                {
+                    hipLaunchKernelGGL(regionStartsKernel, dim3(divUp(totalPairs, 256)), dim3(256), 0, ctx->stream,
+                                       (const uint32_t *) sorted.keys, (uint64_t) totalPairs, B.starts);
+                    if (hipMemcpyAsync(starts.data(), B.starts, (size_t) numRegions * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess
+                        || hipStreamSynchronize(ctx->stream) != hipSuccess)
+                        rc = setError(MLSGPU_ERR_HIP, "bucket: region starts failed");
+                }
+                PROPAGATE(rc);
+                starts[numRegions] = totalPairs;
+
+                /* 4. doCallbacks, src/bucket_impl.h:258-294 */
+                const uint64_t chunk[3] = {chunkIn[0] + cx, chunkIn[1] + cy, chunkIn[2] + cz};
+                const uint32_t *members = sorted.vals;
+                for (uint32_t r = 0; r < numRegions; r++)
+                {
+                    GridBox child;
+                    for (int i = 0; i < 3; i++)     /* Node::toCells clipped to the grid, src/bucket.cpp:113-122 */
+                    {
+                        const uint64_t lower = std::min<uint64_t>(((uint64_t) microSize * regions[r].c[i]) << regions[r].level, sub.cells(i));
+                        const uint64_t upper = std::min<uint64_t>((((uint64_t) microSize * regions[r].c[i]) << regions[r].level)
+                                                                  + ((uint64_t) microSize << regions[r].level), sub.cells(i));
+                        child.lo[i] = (int32_t) (sub.lo[i] + (int64_t) lower);
+                        child.hi[i] = (int32_t) (sub.lo[i] + (int64_t) upper);
+                    }
+                    PROPAGATE(recurse(members + starts[r], starts[r + 1] - starts[r], true, child, 0, 0, depth + 1, chunk));
+                }
+            }
+    return MLSGPU_OK;
+}
+
+} // namespace
+
+MLSGPU_API int mlsgpu_hip_bucket(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, uint64_t numSplats, const mlsgpu_grid *region,
+                                 const mlsgpu_bucket_params *params, mlsgpu_bucket_fn fn, void *user, uint64_t *cellSplats)
+{
+    REQUIRE(ctx != nullptr && region != nullptr && params != nullptr && fn != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(numSplats == 0 || dSplats != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(numSplats < (uint64_t(1) << 29), MLSGPU_ERR_LENGTH);     /* u32 ids; (region, id) pair counts stay below 2^32 */
+    REQUIRE(region->spacing > 0.0f && params->maxCells >= 1 && params->maxSplats >= 1 && params->maxSplit >= 8, MLSGPU_ERR_INVALID);
+    for (int i = 0; i < 3; i++)
+        REQUIRE(region->extents[2 * i] <= region->extents[2 * i + 1], MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    Bucketer b;
+    b.ctx = ctx;
+    b.dSplats = dSplats;
+    b.numSplats = numSplats;
+    b.full = *region;
+    b.P = *params;
+    b.fn = fn;
+    b.user = user;
+    GridBox g;
+    for (int i = 0; i < 3; i++)
+    {
+        g.lo[i] = region->extents[2 * i];
+        g.hi[i] = region->extents[2 * i + 1];
+    }
+    const uint64_t chunk[3] = {0, 0, 0};
+    /* the whole set is not a subset type: the top level always splits (bucket_impl.h:400-418) */
+    const int rc = b.recurse(nullptr, numSplats, false, g, params->chunkCells, params->microCells, 0, chunk);
+    if (cellSplats != nullptr)
+        *cellSplats = b.cellSplats;
+    hipStreamSynchronize(ctx->stream);
+    return rc;
+}
+
+MLSGPU_API int mlsgpu_hip_bucket_load(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, const uint32_t *dIds, uint64_t numSplats,
+                                      const mlsgpu_grid *fullGrid, mlsgpu_splat *dOut)
+{
+    REQUIRE(ctx != nullptr && fullGrid != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(numSplats == 0 || (dSplats != nullptr && dOut != nullptr), MLSGPU_ERR_INVALID);
+    REQUIRE(fullGrid->spacing > 0.0f, MLSGPU_ERR_INVALID);
+    if (numSplats == 0)
+        return MLSGPU_OK;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    LAUNCH(ctx, "bucket.load.time", bucketLoadKernel, dim3(divUp(numSplats, 256)), dim3(256), dSplats, dIds, numSplats,
+           fullGrid->reference[0], fullGrid->reference[1], fullGrid->reference[2], 1.0f / fullGrid->spacing,
+           (float) fullGrid->extents[0], (float) fullGrid->extents[2], (float) fullGrid->extents[4], dOut);
+    return MLSGPU_OK;
+}

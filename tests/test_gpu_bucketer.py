@@ -1,0 +1,132 @@
+"""HIP bucketer (mlsgpu_hip_bucket / mlsgpu_hip_bucket_load) against the bucketing oracle: identical leaves --
+extents, chunk, depth and member ids -- in the same order, on the reference's fixtures and random cases."""
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from bucket_checks import create_splats, validate_partition
+from test_oracle_bucket import GRID
+
+pytestmark = pytest.mark.gpu
+
+
+def both(splats, grid, max_splats, max_cells, chunk_cells, micro_cells, max_split):
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as b
+    ctx = m.Context(0)
+    dev = m.DeviceBuffer(ctx, array=splats) if len(splats) else None
+    try:
+        try:
+            exp = ob.bucket_partition(splats, grid["reference"], grid["spacing"], grid["extents"], max_splats, max_cells,
+                                      chunk_cells, micro_cells, max_split)
+        except ob.DensityError as e:
+            with pytest.raises(m.DensityError) as info:
+                b.bucket_cloud(ctx, dev, len(splats), grid["reference"], grid["spacing"], grid["extents"], max_splats,
+                               max_cells, chunk_cells, micro_cells, max_split)
+            assert info.value.cell_splats == e.cell_splats
+            return None, None
+        got = b.bucket_cloud(ctx, dev, len(splats), grid["reference"], grid["spacing"], grid["extents"], max_splats,
+                             max_cells, chunk_cells, micro_cells, max_split)
+    finally:
+        if dev is not None:
+            dev.free()
+        ctx.close()
+    assert len(got) == len(exp)
+    for g, e in zip(got, exp):
+        assert g["extents"] == e["extents"] and g["chunk"] == e["chunk"] and g["depth"] == e["depth"]
+        np.testing.assert_array_equal(g["ids"].astype(np.uint64), e["ids"])
+    return got, exp
+
+
+@pytest.mark.parametrize("args", [(5, 8, 0, 8, 1000000), (5, 8, 0, 8, 8), (15, 32, 0, 32, 1000000),
+                                  (20, 2 ** 31 - 1, 14, 8, 1000000), (1, 8, 0, 8, 1000000), (5, 8, 0, 0, 64)])
+def test_reference_fixture(args):
+    got, _ = both(create_splats(), GRID, *args)
+    if args == (5, 8, 0, 8, 1000000) or args == (5, 8, 0, 8, 8):
+        assert len(got) == 11                 # test/test_bucket.cpp:475,546
+    if args == (15, 32, 0, 32, 1000000):
+        assert len(got) == 1                  # test/test_bucket.cpp:508
+
+
+def test_empty_and_non_finite():
+    got, _ = both(np.zeros(0, ob.SPLAT_DTYPE), GRID, 5, 8, 0, 8, 1000000)
+    assert got == []
+    bad = create_splats()
+    bad["position"][3, 1] = np.nan
+    bad["quality"][7] = np.inf
+    got, _ = both(bad, GRID, 5, 8, 0, 8, 1000000)
+    validate_partition(bad, GRID, got, 5, 8, 0)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random(seed):
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(1, 20000))
+    max_split = int(rng.integers(64, 1001))
+    max_cells = int(rng.integers(40, 101))
+    chunk_cells = int(rng.integers(80, 514)) if rng.random() < 0.5 else 0
+    max_splats = int(rng.integers(20, 10001))
+    micro = [max_cells, 0, int(rng.integers(1, max_cells + 1))][seed % 3]
+    spacing = float(np.float32(rng.uniform(0.25, 2.5)))
+    splats = np.zeros(n, ob.SPLAT_DTYPE)
+    lo = rng.uniform(-100, 1, 3)
+    hi = rng.uniform(20, 100, 3)
+    splats["position"] = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
+    splats["radius"] = rng.uniform(0.01, rng.uniform(0.25, 10.0), n).astype(np.float32)
+    splats["normal"] = 1.0
+    inv = np.float32(1.0) / np.float32(spacing)
+    ref = (float(np.float32(rng.uniform(-5, 5))), 0.0, float(np.float32(rng.uniform(-5, 5))))
+    lows = np.floor((splats["position"] - splats["radius"][:, None] - np.float32(ref)) * inv).min(axis=0).astype(np.int64)
+    highs = np.floor((splats["position"] + splats["radius"][:, None] - np.float32(ref)) * inv).max(axis=0).astype(np.int64)
+    shrink = int(seed % 4 == 3) * 7           # some grids cut splats off at the border
+    grid = dict(reference=ref, spacing=spacing,
+                extents=(lows[0] + shrink, highs[0] + 1 - shrink, lows[1], highs[1] + 1, lows[2] + shrink, highs[2] + 1))
+    got, exp = both(splats, grid, max_splats, max_cells, chunk_cells, micro, max_split)
+    if got is not None and shrink == 0:
+        validate_partition(splats, grid, got, max_splats, max_cells, 0)
+
+
+def test_cloud_to_meshes_without_leaving_the_device():
+    """bucket -> load -> worker for every leaf equals the oracle run on the oracle's partition."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as b, synth
+    cloud = synth.shells_cloud(150_000, 95.0, 16.0, 1.5, 2.5, seed=77)       # grid coordinates 0..191
+    spacing, ref = np.float32(0.02), np.array([-1.5, 0.25, 3.0], np.float32)
+    world = cloud.copy()
+    world["position"] = world["position"] * spacing + ref                      # a world-space cloud
+    world["radius"] = world["radius"] * spacing
+    extents = (-3, 188, 2, 193, 0, 191)                                        # the full grid does not start at vertex 0
+    world["position"] += (np.array(extents[0::2], np.float32) * spacing)
+    max_cells, max_splats = 63, 40000
+    exp = ob.bucket_partition(world, ref, spacing, extents, max_splats, max_cells, 0, 16, 1 << 30)
+    ctx = m.Context(0)
+    dev = m.DeviceBuffer(ctx, array=world)
+    worker = m.Worker(ctx, max_splats, max_cells=max_cells)
+    staged = m.DeviceBuffer(ctx, nbytes=max_splats * 32)
+    results = []
+
+    def on_bucket(leaf, d_ids):
+        low = [leaf["extents"][2 * i] - extents[2 * i] for i in range(3)]     # subGrid, src/bucket_loader.cpp:91-102
+        nv = [leaf["extents"][2 * i + 1] - leaf["extents"][2 * i] + 1 for i in range(3)]
+        b.bucket_load(ctx, dev, d_ids, leaf["num_splats"], ref, spacing, extents, staged)
+        loaded = staged.download(m.SPLAT_DTYPE, leaf["num_splats"])
+        results.append((loaded, worker.process(staged, 0, leaf["num_splats"], low, nv)))
+    got = b.bucket_cloud(ctx, dev, len(world), ref, spacing, extents, max_splats, max_cells, 0, 16, 1 << 30, on_bucket=on_bucket)
+    assert len(got) == len(exp) > 8
+    total = 0
+    for leaf, e, (loaded, batches) in zip(got, exp, results):
+        assert leaf["extents"] == e["extents"] and leaf["num_splats"] == len(e["ids"])
+        low = [e["extents"][2 * i] - extents[2 * i] for i in range(3)]
+        nv = [e["extents"][2 * i + 1] - e["extents"][2 * i] + 1 for i in range(3)]
+        host = world[e["ids"].astype(np.int64)].copy()
+        b.transform_splats(host, ref, float(spacing), extents[0::2])           # the host loader's transform
+        np.testing.assert_array_equal(loaded.view(np.uint32), host.view(np.uint32))
+        ref_batches, _ = ob.bucket(host, 0, len(host), nv, low, max_cells=max_cells)
+        assert len(batches) == len(ref_batches)
+        for g, r in zip(batches, ref_batches):
+            np.testing.assert_array_equal(g["vertices"].view(np.uint32), r["vertices"].view(np.uint32))
+            np.testing.assert_array_equal(g["triangles"], r["triangles"])
+            total += len(g["triangles"])
+    assert total > 100000
+    del worker
+    ctx.close()
