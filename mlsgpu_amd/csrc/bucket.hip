@@ -537,7 +537,7 @@ MLSGPU_API int mlsgpu_hip_bucket(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, u
     REQUIRE(numSplats < (uint64_t(1) << 29), MLSGPU_ERR_LENGTH);     /* u32 ids; (region, id) pair counts stay below 2^32 */
     REQUIRE(region->spacing > 0.0f && params->maxCells >= 1 && params->maxSplats >= 1 && params->maxSplit >= 8, MLSGPU_ERR_INVALID);
     for (int i = 0; i < 3; i++)
-        REQUIRE(region->extents[2 * i] <= region->extents[2 * i + 1], MLSGPU_ERR_INVALID);
+        REQUIRE(region->extents[2 * i] < region->extents[2 * i + 1], MLSGPU_ERR_INVALID);   /* at least one cell per axis */
     HIP_CHECK(hipSetDevice(ctx->device));
     Bucketer b;
     b.ctx = ctx;

@@ -399,6 +399,9 @@ ORC_API int orc_bucket_partition(const void *splats, uint64_t n, const float ref
                                  LeafFn leaf, void *user, uint64_t *cellSplats)
 {
     Run run{static_cast<const Splat *>(splats), leaf, user, 0, 0};
+    for (int i = 0; i < 3; i++)
+        if (extents[2 * i] >= extents[2 * i + 1])
+            return 3;       /* the reference divides by zero on a region without cells */
     Grid g;
     for (int i = 0; i < 3; i++)
     {

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 import oracle_binding as ob
-from bucket_checks import create_splats, validate_partition
+from bucket_checks import create_splats, random_case, validate_partition
 from test_oracle_bucket import GRID
 
 pytestmark = pytest.mark.gpu
@@ -60,30 +60,20 @@ def test_empty_and_non_finite():
 
 @pytest.mark.parametrize("seed", range(30))
 def test_random(seed):
-    rng = np.random.default_rng(1000 + seed)
-    n = int(rng.integers(1, 20000))
-    max_split = int(rng.integers(64, 1001))
-    max_cells = int(rng.integers(40, 101))
-    chunk_cells = int(rng.integers(80, 514)) if rng.random() < 0.5 else 0
-    max_splats = int(rng.integers(20, 10001))
-    micro = [max_cells, 0, int(rng.integers(1, max_cells + 1))][seed % 3]
-    spacing = float(np.float32(rng.uniform(0.25, 2.5)))
-    splats = np.zeros(n, ob.SPLAT_DTYPE)
-    lo = rng.uniform(-100, 1, 3)
-    hi = rng.uniform(20, 100, 3)
-    splats["position"] = rng.uniform(lo, hi, (n, 3)).astype(np.float32)
-    splats["radius"] = rng.uniform(0.01, rng.uniform(0.25, 10.0), n).astype(np.float32)
-    splats["normal"] = 1.0
-    inv = np.float32(1.0) / np.float32(spacing)
-    ref = (float(np.float32(rng.uniform(-5, 5))), 0.0, float(np.float32(rng.uniform(-5, 5))))
-    lows = np.floor((splats["position"] - splats["radius"][:, None] - np.float32(ref)) * inv).min(axis=0).astype(np.int64)
-    highs = np.floor((splats["position"] + splats["radius"][:, None] - np.float32(ref)) * inv).max(axis=0).astype(np.int64)
-    shrink = int(seed % 4 == 3) * 7           # some grids cut splats off at the border
-    grid = dict(reference=ref, spacing=spacing,
-                extents=(lows[0] + shrink, highs[0] + 1 - shrink, lows[1], highs[1] + 1, lows[2] + shrink, highs[2] + 1))
-    got, exp = both(splats, grid, max_splats, max_cells, chunk_cells, micro, max_split)
-    if got is not None and shrink == 0:
-        validate_partition(splats, grid, got, max_splats, max_cells, 0)
+    splats, grid, p = random_case(seed)
+    got, exp = both(splats, grid, p["max_splats"], p["max_cells"], p["chunk_cells"], p["micro_cells"], p["max_split"])
+    if got is not None:
+        validate_partition(splats, grid, got, p["max_splats"], p["max_cells"], 0, strict=seed % 4 != 3)
+
+
+def test_rejects_an_empty_region():
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as b
+    ctx = m.Context(0)
+    dev = m.DeviceBuffer(ctx, array=create_splats())
+    with pytest.raises(m.InvalidArgument):
+        b.bucket_cloud(ctx, dev, 13, (0, 0, 0), 1.0, (0, 10, 5, 5, 0, 10), 5, 8)
+    ctx.close()
 
 
 def test_cloud_to_meshes_without_leaving_the_device():

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import oracle_binding as ob
-from bucket_checks import create_splats, make_splat, validate_partition
+from bucket_checks import create_splats, make_splat, random_case, validate_partition
 
 
 def test_node_child():
@@ -139,3 +139,19 @@ def test_random(seed):
     except ob.DensityError:
         return
     validate_partition(splats, grid, leaves, max_splats, max_cells, 0)
+
+
+@pytest.mark.parametrize("seed", range(30))
+def test_random_general(seed):
+    """The cases the HIP bucketer is compared on (non-zero reference, other microblock requests, clipped grids)."""
+    splats, grid, p = random_case(seed)
+    try:
+        leaves = run(splats, p["max_splats"], p["max_cells"], p["chunk_cells"], p["micro_cells"], p["max_split"], grid)
+    except ob.DensityError:
+        return
+    validate_partition(splats, grid, leaves, p["max_splats"], p["max_cells"], 0, strict=seed % 4 != 3)
+
+
+def test_rejects_an_empty_region():
+    with pytest.raises(ValueError):
+        run(create_splats(), 5, 8, 0, 8, 1000, dict(GRID, extents=(0, 10, 5, 5, 0, 10)))
