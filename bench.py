@@ -45,6 +45,7 @@ def parse_args():
     p.add_argument("--variant", type=int, default=2, help="MLS kernel variant: 0 culled, 1 basic, 2 culled + hit lists")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-stream", action="store_true", help="skip the PCIe-inclusive bucket-farm leg")
+    p.add_argument("--no-partition", action="store_true", help="skip the device-bucketer leg (reference partition)")
     p.add_argument("--no-timing", action="store_true", help="do not time individual kernels with HIP events")
     return p.parse_args()
 
@@ -85,7 +86,6 @@ def main():
     cloud, grid = synth.make_cloud(args.workload, args.dist, scale=args.scale, seed_offset=rank)
     bucketed, buckets = synth.bucketize(cloud, grid, 255)
     n_splats = len(cloud)
-    del cloud
     voxels = sum(b.cells for b in buckets)
     max_count = max(b.count for b in buckets)
     max_cells = max(max(b.num_vertices) for b in buckets) - 1
@@ -297,6 +297,53 @@ def main():
         result["kernel_ms_per_step"] = {k: round(v[0] / K, 3) for k, v in sorted(kernel_stats.items())}
         result["work_per_step"] = {"octree_entries": entries, "occupied_cells": O, "unwelded_vertices": mc["unwelded"],
                                    "welded_vertices": Vw, "external_vertices": external, "indices": T}
+
+    # ---- device-bucketer leg (never `value`): the RAW cloud resident in HBM, partitioned on the device exactly as
+    # the reference's Bucket::bucket would with its defaults (255-cell buckets, 63-cell microblocks, 2 097 152 splats,
+    # src/mlsgpu_core.cpp:112-132,655-678), each leaf gathered + transformed on the device and run through a worker ----
+    if world == 1 and not args.no_partition:
+        from mlsgpu_amd import binding as mb
+        raw = m.DeviceBuffer(ctx, array=cloud)
+        ext = (0, grid - 1, 0, grid - 1, 0, grid - 1)
+        bp = dict(max_splats=2097152, max_cells=255, chunk_cells=0, micro_cells=63, max_split=1 << 30)
+        leaves = mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=lambda leaf, ids: None, **bp)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=lambda leaf, ids: None, **bp)
+        ctx.synchronize()
+        part_s = (time.perf_counter() - t0) / args.steps
+        pmax = max(l["num_splats"] for l in leaves)
+        pcells = max(max(l["extents"][2 * i + 1] - l["extents"][2 * i] for i in range(3)) for l in leaves)
+        pworker = m.Worker(ctx, pmax, max_cells=pcells, mesh_memory=args.mesh_memory_mb << 20)
+        pworker.set_mls_variant(args.variant)
+        staged = m.DeviceBuffer(ctx, nbytes=pmax * 32)
+        pcol = m.binding.SizeCollector()
+
+        def leaf_work(leaf, d_ids):
+            low = leaf["extents"][0::2]
+            nv = [leaf["extents"][2 * i + 1] - leaf["extents"][2 * i] + 1 for i in range(3)]
+            mb.bucket_load(ctx, raw, d_ids, leaf["num_splats"], (0.0, 0.0, 0.0), 1.0, ext, staged)
+            pworker.process(staged, 0, leaf["num_splats"], low, nv, collector=pcol)
+        mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=leaf_work, **bp)      # warm-up
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=leaf_work, **bp)
+        ctx.synchronize()
+        pipe_s = (time.perf_counter() - t0) / args.steps
+        pvox = sum((l["extents"][1] - l["extents"][0]) * (l["extents"][3] - l["extents"][2]) * (l["extents"][5] - l["extents"][4])
+                   for l in leaves)
+        result["device_partition"] = {
+            "buckets": len(leaves), "bucket_splats_total": int(sum(l["num_splats"] for l in leaves)),
+            "max_bucket_cells": int(pcells), "bucketing_ms": round(part_s * 1e3, 3),
+            "bucketing_msplats_per_s": round(n_splats / part_s / 1e6, 1),
+            "pipeline_ms_per_step": round(pipe_s * 1e3, 3), "pipeline_mvoxels_per_s": round(pvox / pipe_s / 1e6, 3),
+            "note": "raw cloud resident in HBM -> mlsgpu_hip_bucket (reference partition) -> mlsgpu_hip_bucket_load -> one "
+                    "device worker; bucketing is inside the pipeline time",
+        }
+        del pworker, staged, raw
+    del cloud
 
     # ---- PCIe-inclusive leg (never `value`): the same buckets from HOST memory through the bucket farm
     # (pinned double-buffered staging, H2D on a copy stream, the same device workers), N = 1 only ----
