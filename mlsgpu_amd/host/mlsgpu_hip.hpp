@@ -17,6 +17,7 @@
 #include <cstdint>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <mutex>
@@ -484,6 +485,89 @@ private:
     std::vector<std::thread> threads;
     std::exception_ptr workerError;
 };
+
+/**
+ * Bucket::bucket (src/bucket.h:116-180) for a cloud that is resident on the device, and the device half of
+ * BucketLoader (src/bucket_loader.cpp:77-102).  The processor receives the bucket's grid, recursion state and its
+ * splat ids (device memory, ascending, valid during the call) where the reference's receives a splat subset.
+ */
+namespace Bucket
+{
+
+typedef mlsgpu_grid Grid;                   // src/grid.h: reference, spacing, per-axis [first, second) extents
+typedef mlsgpu_bucket Bin;                  // extents, Recursion::chunk / depth, numSplats, dIds
+
+/// Bucket::DensityError, src/bucket.h:52-65
+class DensityError : public std::runtime_error
+{
+    std::uint64_t cellSplats;
+public:
+    explicit DensityError(std::uint64_t cellSplats)
+        : std::runtime_error("Too many splats covering one cell"), cellSplats(cellSplats) {}
+    std::uint64_t getCellSplats() const { return cellSplats; }
+};
+
+typedef std::function<void(const Bin &)> Processor;
+
+namespace detail
+{
+struct Thunk
+{
+    const Processor *process;
+    std::exception_ptr error;
+    static int call(void *user, mlsgpu_ctx *, const mlsgpu_bucket *b)
+    {
+        Thunk *self = static_cast<Thunk *>(user);
+        try
+        {
+            (*self->process)(*b);
+            return 0;
+        }
+        catch (...)
+        {
+            self->error = std::current_exception();
+            return 1;
+        }
+    }
+};
+} // namespace detail
+
+inline void bucket(const Context &ctx, const Buffer<Splat> &splats, std::uint64_t numSplats, const Grid &region,
+                   std::uint64_t maxSplats, std::uint32_t maxCells, std::uint32_t chunkCells, std::uint32_t microCells,
+                   std::uint64_t maxSplit, const Processor &process)
+{
+    mlsgpu_bucket_params p;
+    p.maxSplats = maxSplats;
+    p.maxCells = maxCells;
+    p.chunkCells = chunkCells;
+    p.microCells = microCells;
+    p.maxSplit = maxSplit;
+    detail::Thunk thunk{&process, std::exception_ptr()};
+    std::uint64_t cellSplats = 0;
+    const int rc = mlsgpu_hip_bucket(ctx.get(), splats.get(), numSplats, &region, &p, &detail::Thunk::call, &thunk, &cellSplats);
+    if (thunk.error)
+        std::rethrow_exception(thunk.error);
+    if (rc == MLSGPU_ERR_DENSITY)
+        throw DensityError(cellSplats);
+    check(rc);
+}
+
+/// Gathers a bin's splats into `out` in the full grid's vertex coordinates and returns the sub-grid the worker needs
+/// (BucketLoader::operator(), src/bucket_loader.cpp:77-102).
+inline BucketGrid load(const Context &ctx, const Buffer<Splat> &splats, const Bin &bin, const Grid &fullGrid,
+                       const Buffer<Splat> &out)
+{
+    check(mlsgpu_hip_bucket_load(ctx.get(), splats.get(), bin.dIds, bin.numSplats, &fullGrid, out.get()));
+    BucketGrid g;
+    for (int i = 0; i < 3; i++)
+    {
+        g.low[i] = bin.extents[2 * i] - fullGrid.extents[2 * i];
+        g.numVertices[i] = (std::uint32_t) (bin.extents[2 * i + 1] - bin.extents[2 * i] + 1);
+    }
+    return g;
+}
+
+} // namespace Bucket
 
 } // namespace hip
 } // namespace mlsgpu

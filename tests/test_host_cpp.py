@@ -8,11 +8,11 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def build_example(tmp_path):
-    exe = str(tmp_path / "host_bucket")
+def build_example(tmp_path, name="host_bucket"):
+    exe = str(tmp_path / name)
     libdir = os.path.join(ROOT, "mlsgpu_amd")
     cmd = ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-O1", "-I", ROOT,
-           os.path.join(ROOT, "examples", "host_bucket.cpp"), "-o", exe,
+           os.path.join(ROOT, "examples", name + ".cpp"), "-o", exe,
            "-L" + libdir, "-lmlsgpu_hip", "-Wl,-rpath," + libdir, "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib",
            "-pthread"]
     subprocess.check_call(cmd)
@@ -23,6 +23,7 @@ def test_host_header_compiles_and_links(tmp_path):
     """SplatTreeCL / MlsFunctor / Marching / DeviceWorkerGroup over the C-ABI: compiles warning-free and links."""
     exe = build_example(tmp_path)
     assert os.path.exists(exe)
+    assert os.path.exists(build_example(tmp_path, "host_partition"))
 
 
 @pytest.mark.gpu
@@ -66,3 +67,28 @@ def test_device_worker_group_matches_oracle(tmp_path):
             np.testing.assert_array_equal(tris, e["triangles"])
             np.testing.assert_array_equal(keys, e["keys"][ni:])
     assert nonempty > 0
+
+
+@pytest.mark.gpu
+def test_cpp_bucket_matches_oracle(tmp_path):
+    """mlsgpu::hip::Bucket::bucket from C++: the same bins as the oracle, DensityError included."""
+    import oracle_binding as ob
+    from bucket_checks import random_case
+    exe = build_example(tmp_path, "host_partition")
+    for seed in (1, 4, 11):
+        splats, grid, p = random_case(seed)
+        splats.tofile(str(tmp_path / "cloud.bin"))
+        args = [exe, str(tmp_path / "cloud.bin")] + [repr(float(v)) for v in grid["reference"]] + [repr(grid["spacing"])] \
+            + [str(int(v)) for v in grid["extents"]] \
+            + [str(p[k]) for k in ("max_splats", "max_cells", "chunk_cells", "micro_cells", "max_split")]
+        out = subprocess.check_output(args, timeout=300).decode().split("\n")
+        try:
+            exp = ob.bucket_partition(splats, grid["reference"], grid["spacing"], grid["extents"], p["max_splats"],
+                                      p["max_cells"], p["chunk_cells"], p["micro_cells"], p["max_split"])
+        except ob.DensityError as e:
+            assert out[0] == "density %d" % e.cell_splats
+            continue
+        assert out[len(exp)] == "bins %d" % len(exp)
+        for line, e in zip(out, exp):
+            want = list(e["extents"]) + list(e["chunk"]) + [e["depth"], len(e["ids"]), int(e["ids"].sum())]
+            assert [int(v) for v in line.split()] == want
