@@ -321,6 +321,34 @@ int mlsgpu_hip_bucket(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, uint64_t num
 int mlsgpu_hip_bucket_load(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, const uint32_t *dIds, uint64_t numSplats,
                            const mlsgpu_grid *fullGrid, mlsgpu_splat *dOut);
 
+/* ---- mesh sink for meshes that stay in HBM: OOCMesher's weld / components / prune / per-chunk output,
+ *      src/mesher.h:203-330, src/mesher.cpp:220-852 ---- */
+typedef struct mlsgpu_mesher mlsgpu_mesher;
+int mlsgpu_hip_mesher_create(mlsgpu_ctx *ctx, mlsgpu_mesher **out);
+void mlsgpu_hip_mesher_destroy(mlsgpu_mesher *mesher);
+/* MesherBase::setPruneThreshold: components with fewer vertices than uint64(total * threshold) are dropped */
+int mlsgpu_hip_mesher_set_prune_threshold(mlsgpu_mesher *mesher, double threshold);
+/* MesherBase::InputFunctor for a DeviceKeyMesh: appends a copy of the mesh (device to device, on `from`'s stream, which
+ * is synchronised before returning: Marching reuses the mesh).  Thread safe; `from` is the calling worker's context on
+ * the mesher's device.  The blocks of one chunk must arrive contiguously ("chunks must be in order", src/mesher.h:190-193);
+ * blocks within a chunk in any order. */
+int mlsgpu_hip_mesher_add(mlsgpu_mesher *mesher, mlsgpu_ctx *from, uint64_t chunkId, const mlsgpu_mesh *mesh);
+/* What MesherBase::write does before it writes files: weld by key, components, prune.  *numChunks = chunks that have
+ * triangles (no output is produced for the others, src/mesher.cpp:820). */
+int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *mesher, uint32_t *numChunks);
+/* Output chunk i (arrival order): packed float3 vertices and uint3 triangles on the device, indices relative to the
+ * chunk's first vertex.  A vertex shared by two chunks is in both (externalRemap is per chunk, src/mesher.cpp:538-567).
+ * Valid until the next finalize / destroy. */
+int mlsgpu_hip_mesher_chunk(mlsgpu_mesher *mesher, uint32_t i, uint64_t *chunkId, uint64_t *numVertices, uint64_t *numTriangles,
+                            const float **dVertices, const uint32_t **dTriangles);
+/* getStatistics (src/mesher.cpp:491-536): out[0] welded vertices, [1] threshold, [2] components, [3] kept components,
+ * [4] kept vertices (each welded vertex once), [5] kept triangles, [6] vertices added, [7] triangles added */
+int mlsgpu_hip_mesher_stats(mlsgpu_mesher *mesher, uint64_t out[8]);
+/* FastPly::Writer's file from host memory (src/fast_ply.cpp:443-521): binary little endian, header padded to 4 bytes,
+ * float32 x y z, faces as uint8 3 + 3 x uint32 */
+int mlsgpu_hip_write_ply(const char *path, const float *vertices, uint64_t numVertices, const uint32_t *triangles,
+                         uint64_t numTriangles, const char *const *comments, uint32_t numComments);
+
 /* DeviceWorkerGroupBase::computeMaxSwathe, src/workers.cpp:169-182 */
 uint32_t mlsgpu_hip_compute_max_swathe(uint32_t yMax, uint32_t y, uint32_t yAlign, uint32_t zAlign);
 

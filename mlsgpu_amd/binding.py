@@ -181,6 +181,14 @@ def lib():
     sig("mlsgpu_hip_farm_finish", C.c_int, vp)
     sig("mlsgpu_hip_farm_stats", C.c_int, vp, vp)
     sig("mlsgpu_hip_transform_splats", None, vp, u64, vp, f32, vp)
+    sig("mlsgpu_hip_mesher_create", C.c_int, vp, P(vp))
+    sig("mlsgpu_hip_mesher_destroy", None, vp)
+    sig("mlsgpu_hip_mesher_set_prune_threshold", C.c_int, vp, C.c_double)
+    sig("mlsgpu_hip_mesher_add", C.c_int, vp, vp, u64, vp)
+    sig("mlsgpu_hip_mesher_finalize", C.c_int, vp, P(u32))
+    sig("mlsgpu_hip_mesher_chunk", C.c_int, vp, u32, P(u64), P(u64), P(u64), P(vp), P(vp))
+    sig("mlsgpu_hip_mesher_stats", C.c_int, vp, vp)
+    sig("mlsgpu_hip_write_ply", C.c_int, C.c_char_p, vp, u64, vp, u64, vp, u32)
     sig("mlsgpu_hip_bucket", C.c_int, vp, vp, u64, P(GridStruct), P(BucketParams), BUCKET_FN, vp, P(u64))
     sig("mlsgpu_hip_bucket_load", C.c_int, vp, vp, vp, u64, P(GridStruct), vp)
     sig("mlsgpu_hip_test_make_code", C.c_int, vp, C.c_int, C.c_int, C.c_int, P(u32))
@@ -448,6 +456,108 @@ class SizeCollector:
             self.batches += 1
             return 0
         self.cb = OUTPUT_FN(cb)
+
+
+class Mesher:
+    """Device-resident mesh sink: OOCMesher's weld / components / prune / chunks (src/mesher.h:203-330)."""
+
+    def __init__(self, ctx, prune_threshold=0.0):
+        self.ctx = ctx
+        h = C.c_void_p()
+        check(lib().mlsgpu_hip_mesher_create(ctx.h, C.byref(h)))
+        self.h = h
+        if prune_threshold:
+            self.set_prune_threshold(prune_threshold)
+
+    def set_prune_threshold(self, threshold):
+        check(lib().mlsgpu_hip_mesher_set_prune_threshold(self.h, float(threshold)))
+
+    def add_device(self, from_ctx, chunk_id, mesh_ptr):
+        check(lib().mlsgpu_hip_mesher_add(self.h, from_ctx.h, chunk_id, mesh_ptr))
+
+    def add(self, chunk_id, vertices, num_internal, keys, triangles, ctx=None):
+        """Adds a host mesh (tests): uploads it as a DeviceKeyMesh first; keys are the external vertices' keys."""
+        ctx = ctx or self.ctx
+        vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+        triangles = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        all_keys = np.zeros(len(vertices), np.uint64)
+        all_keys[num_internal:] = np.asarray(keys, np.uint64)
+        bufs = [DeviceBuffer(ctx, array=a) if a.size else None for a in (vertices, triangles, all_keys)]
+        mesh = Mesh(bufs[0].ptr if bufs[0] else None, bufs[1].ptr if bufs[1] else None, bufs[2].ptr if bufs[2] else None,
+                    len(vertices), len(triangles), num_internal)
+        try:
+            check(lib().mlsgpu_hip_mesher_add(self.h, ctx.h, chunk_id, C.byref(mesh)))
+        finally:
+            for b in bufs:
+                if b is not None:
+                    b.free()
+
+    def collector(self, from_ctx, chunk_id):
+        """An output functor for Worker.process / Marching.generate that feeds this mesher."""
+        return MesherCollector(self, from_ctx, chunk_id)
+
+    def finalize(self):
+        n = C.c_uint32(0)
+        check(lib().mlsgpu_hip_mesher_finalize(self.h, C.byref(n)))
+        return n.value
+
+    def chunk(self, i, download=True):
+        cid, nv, nt = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        pv, pt = C.c_void_p(), C.c_void_p()
+        check(lib().mlsgpu_hip_mesher_chunk(self.h, i, C.byref(cid), C.byref(nv), C.byref(nt), C.byref(pv), C.byref(pt)))
+        out = dict(chunk=cid.value, num_vertices=nv.value, num_triangles=nt.value, d_vertices=pv.value, d_triangles=pt.value)
+        if download:
+            v = np.empty((nv.value, 3), np.float32)
+            t = np.empty((nt.value, 3), np.uint32)
+            if v.size:
+                check(lib().mlsgpu_hip_memcpy_d2h(self.ctx.h, _p(v), pv.value, v.nbytes, 0))
+            if t.size:
+                check(lib().mlsgpu_hip_memcpy_d2h(self.ctx.h, _p(t), pt.value, t.nbytes, 0))
+            out["vertices"], out["triangles"] = v, t
+        return out
+
+    def stats(self):
+        out = np.zeros(8, np.uint64)
+        check(lib().mlsgpu_hip_mesher_stats(self.h, _p(out)))
+        names = ["total_vertices", "threshold", "components", "kept_components", "kept_vertices", "kept_triangles",
+                 "vertices_added", "triangles_added"]
+        return dict(zip(names, [int(x) for x in out]))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mlsgpu_hip_mesher_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MesherCollector:
+    def __init__(self, mesher, from_ctx, chunk_id):
+        self.error = None
+        self.batches = 0
+
+        def cb(user, stream, meshp):
+            try:
+                mesher.add_device(from_ctx, chunk_id, meshp)
+                self.batches += 1
+                return 0
+            except Exception as e:      # noqa: BLE001
+                self.error = e
+                return 1
+        self.cb = OUTPUT_FN(cb)
+
+
+def write_ply(path, vertices, triangles, comments=()):
+    """FastPly::Writer's file (src/fast_ply.cpp:443-521)."""
+    vertices = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+    triangles = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+    arr = (C.c_char_p * max(len(comments), 1))(*[c.encode("ascii") for c in comments])
+    check(lib().mlsgpu_hip_write_ply(str(path).encode(), _p(vertices), len(vertices), _p(triangles), len(triangles),
+                                     arr, len(comments)))
 
 
 class Marching:

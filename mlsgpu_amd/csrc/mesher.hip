@@ -1,0 +1,677 @@
+/*
+ * Device-side mesh sink: what OOCMesher (src/mesher.cpp) does with the meshes Marching ships out -- weld of
+ * external vertices by 64-bit key across buckets, connected components, pruning of components below a fraction
+ * of the total vertex count, one output mesh per chunk -- for meshes that stay RESIDENT IN HBM.  Row f3 of
+ * SURVEY.md section 8.
+ *
+ * The reference copies every ship-out to the host, runs a union-find per block plus a hash map of keys on ONE
+ * mesher thread, spills to temporary files and re-reads them to write the PLY (src/mesher.cpp:220-469,763-852);
+ * its manual names that thread as the scaling limit (doc/mlsgpu-user-manual.xml:508-511).  Here add() is a
+ * device-to-device append of the DeviceKeyMesh into arenas (288 GB: the 13.5 GB mesh of the cfg3 noise cloud fits
+ * many times) and finalize() is a handful of passes:
+ *   1. externals: stable radix sort of (key, slot) -- blocks arrive grouped by chunk, so equal keys end up ordered
+ *      by chunk; the first vertex of a key run is the vertex's identity for components (updateClumpKeyMap,
+ *      :286-311), the first of a (key, chunk) run its identity in that chunk's file (externalRemap, :538-567);
+ *   2. components: lock-free union-find over the triangles' two edges (computeLocalComponents uses the same two,
+ *      :228-235) with CAS hooking, then full path compression;
+ *   3. component sizes (each welded vertex once), the prune threshold uint64(total * threshold) and the
+ *      keep test `>=` of getStatistics (:491-536);
+ *   4. two scans compact the kept vertices and triangles; a chunk's indices are relative to its first vertex.
+ * Output order is (chunk, block arrival, vertex / triangle order inside the block); the reference's differs
+ * (clump order, reorder buffer) and its own tests compare up to isomorphism (test/test_mesher.cpp:401-460).
+ */
+#include "common.hpp"
+#include "primitives.hpp"
+
+#include <algorithm>
+#include <mutex>
+
+using namespace mlsgpu;
+
+namespace
+{
+
+struct MeshRecord
+{
+    uint64_t chunk;
+    uint32_t vBase, nv, nInternal;
+    uint64_t tBase, nt;
+    uint32_t eBase;
+};
+
+/* per block, on the device: what the finalize kernels look up by binary search over tBase / vBase */
+struct BlockTable
+{
+    const uint64_t *tBase;      /* [blocks + 1] */
+    const uint32_t *vBase;      /* [blocks + 1] */
+    const uint32_t *chunkOf;    /* [blocks] dense chunk index */
+    const uint32_t *chunkVStart;/* [chunks + 1] output vertex index where the chunk starts (after the vertex scan) */
+    uint32_t blocks;
+
+    __device__ __forceinline__ uint32_t blockOfTriangle(uint64_t t) const
+    {
+        uint32_t lo = 0, hi = blocks;           /* last block with tBase <= t */
+        while (hi - lo > 1)
+        {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (tBase[mid] <= t) lo = mid; else hi = mid;
+        }
+        return lo;
+    }
+};
+
+__global__ void rebaseTrianglesKernel(uint32_t *tri, uint64_t n3, uint32_t base)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n3)
+        tri[i] += base;
+}
+
+__global__ void iotaKernel(uint32_t *a, uint64_t n)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        a[i] = (uint32_t) i;
+}
+
+/* externals sorted by key (ties in arrival = chunk order): identities of every external vertex */
+__global__ void externalRepsKernel(const uint64_t *keys, const uint32_t *slots, const uint32_t *extGid, const uint32_t *extChunk,
+                                   uint64_t n, uint32_t *compRep, uint32_t *outRep)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint64_t key = keys[i];
+    const uint32_t chunk = extChunk[slots[i]];
+    uint64_t c = i, o = i;
+    /* runs are as long as the number of blocks that share the vertex (at most 8 for bucket corners) */
+    while (c > 0 && keys[c - 1] == key)
+        c--;
+    while (o > 0 && keys[o - 1] == key && extChunk[slots[o - 1]] == chunk)
+        o--;
+    const uint32_t g = extGid[slots[i]];
+    compRep[g] = extGid[slots[c]];
+    outRep[g] = extGid[slots[o]];
+}
+
+/* parent[] is read while other workgroups hook roots: the loads must come from the coherence point (a line cached
+ * in this CU's vector L1 would never show the new parent and the retry loop below would not end) */
+__device__ __forceinline__ uint32_t loadParent(const uint32_t *parent, uint32_t v)
+{
+    return __hip_atomic_load(&parent[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint32_t findRoot(const uint32_t *parent, uint32_t v)
+{
+    uint32_t p = loadParent(parent, v);
+    while (p != v)
+    {
+        v = p;
+        p = loadParent(parent, v);
+    }
+    return v;
+}
+
+/* union of the endpoints of two edges per triangle (the third is redundant, src/mesher.cpp:231-234) */
+__global__ void unionKernel(const uint32_t *tri, uint64_t nt, const uint32_t *compRep, uint32_t *parent, uint32_t *failed)
+{
+    const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nt)
+        return;
+    const uint32_t v[3] = {compRep[tri[3 * t]], compRep[tri[3 * t + 1]], compRep[tri[3 * t + 2]]};
+#pragma unroll
+    for (int e = 0; e < 2; e++)
+    {
+        uint32_t a = v[e], b = v[e + 1];
+        for (uint32_t attempt = 0;; attempt++)
+        {
+            if (attempt == (1u << 20))      /* cannot happen; a bound instead of a hung GPU if it ever does */
+            {
+                *failed = 1;
+                break;
+            }
+            a = findRoot(parent, a);
+            b = findRoot(parent, b);
+            if (a == b)
+                break;
+            if (a < b)
+            {
+                const uint32_t s = a; a = b; b = s;
+            }
+            /* hook the larger root under the smaller; retry if someone re-parented it first */
+            if (atomicCAS(&parent[a], a, b) == a)
+                break;
+        }
+    }
+}
+
+__global__ void compressKernel(uint32_t *parent, const uint32_t *compRep, uint64_t n, uint32_t *root)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        root[i] = findRoot(parent, compRep[i]);
+}
+
+/* vertices of a component: every welded vertex once.  Neighbouring vertices mostly share their component (a noise
+ * cloud is ONE component of hundreds of millions of vertices), so a wave adds once per distinct root it holds. */
+__global__ void componentSizeKernel(const uint32_t *compRep, const uint32_t *root, uint64_t n, uint32_t *size)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const bool counts = i < n && compRep[i] == (uint32_t) i;
+    const uint32_t mine = counts ? root[i] : 0u;
+    uint64_t todo = __ballot(counts);
+    while (todo != 0)
+    {
+        const uint32_t r = readLane(mine, (int) __builtin_ctzll(todo));
+        const uint64_t same = __ballot(counts && mine == r) & todo;
+        if (laneId() == (uint32_t) __builtin_ctzll(same))
+            atomicAdd(&size[r], (uint32_t) __popcll(same));
+        todo &= ~same;
+    }
+}
+
+/* [0] welded vertices, [1] components, [2] kept components, [3] kept vertices */
+__global__ void componentStatsKernel(const uint32_t *compRep, const uint32_t *root, const uint32_t *size, uint64_t n,
+                                     uint64_t threshold, unsigned long long *stats, int pass)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    if (pass == 0)
+    {
+        const uint64_t reps = __ballot(compRep[i] == (uint32_t) i);
+        if (reps != 0 && laneId() == (uint32_t) __builtin_ctzll(reps))
+            atomicAdd(&stats[0], (unsigned long long) __popcll(reps));
+    }
+    else if (root[i] == (uint32_t) i && compRep[i] == (uint32_t) i)
+    {
+        atomicAdd(&stats[1], 1ull);
+        if (size[i] >= threshold)
+        {
+            atomicAdd(&stats[2], 1ull);
+            atomicAdd(&stats[3], (unsigned long long) size[i]);
+        }
+    }
+}
+
+struct KeepVertexIn
+{
+    const uint32_t *outRep, *root, *size;
+    uint64_t threshold;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const
+    {
+        return (outRep[i] == (uint32_t) i && size[root[i]] >= threshold) ? 1u : 0u;
+    }
+};
+
+struct VertexOut
+{
+    const float *vertices;
+    float *out;
+    uint32_t *index;
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t keep) const
+    {
+        index[i] = excl;
+        if (keep)
+        {
+            out[3 * (uint64_t) excl + 0] = vertices[3 * i + 0];
+            out[3 * (uint64_t) excl + 1] = vertices[3 * i + 1];
+            out[3 * (uint64_t) excl + 2] = vertices[3 * i + 2];
+        }
+    }
+};
+
+struct KeepTriangleIn
+{
+    const uint32_t *tri, *root, *size;
+    uint64_t threshold;
+    __device__ __forceinline__ uint32_t operator()(uint64_t t) const
+    {
+        return size[root[tri[3 * t]]] >= threshold ? 1u : 0u;
+    }
+};
+
+struct TriangleOut
+{
+    const uint32_t *tri, *outRep, *vIndex;
+    BlockTable B;
+    uint32_t *out;
+    __device__ __forceinline__ void operator()(uint64_t t, uint32_t excl, uint32_t keep) const
+    {
+        if (!keep)
+            return;
+        const uint32_t first = B.chunkVStart[B.chunkOf[B.blockOfTriangle(t)]];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            out[3 * (uint64_t) excl + j] = vIndex[outRep[tri[3 * t + j]]] - first;
+    }
+};
+
+struct TriangleOutIdx
+{
+    TriangleOut inner;
+    uint32_t *tIndex;
+    __device__ __forceinline__ void operator()(uint64_t t, uint32_t excl, uint32_t keep) const
+    {
+        tIndex[t] = excl;
+        inner(t, excl, keep);
+    }
+};
+
+__global__ void gatherU32Kernel(const uint32_t *src, const uint64_t *at, uint32_t n, uint64_t limit, uint32_t last, uint32_t *dst)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        dst[i] = at[i] < limit ? src[at[i]] : last;
+}
+
+template<typename T>
+struct Arena
+{
+    T *ptr = nullptr;
+    uint64_t used = 0, cap = 0;
+
+    int reserve(mlsgpu_ctx *ctx, uint64_t need)
+    {
+        if (need <= cap)
+            return MLSGPU_OK;
+        const uint64_t newCap = std::max<uint64_t>(need, cap + cap / 2 + 1024);
+        T *np = nullptr;
+        HIP_CHECK(hipMalloc((void **) &np, newCap * sizeof(T)));
+        if (used > 0)
+        {
+            hipError_t e = hipMemcpyAsync(np, ptr, used * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess)
+            {
+                hipFree(np);
+                return setError(MLSGPU_ERR_HIP, "mesher: arena move failed: %s", hipGetErrorString(e));
+            }
+        }
+        hipFree(ptr);
+        ptr = np;
+        cap = newCap;
+        return MLSGPU_OK;
+    }
+    ~Arena() { hipFree(ptr); }
+};
+
+} // namespace
+
+struct mlsgpu_mesher
+{
+    mlsgpu_ctx *ctx = nullptr;
+    std::mutex mutex;
+    double pruneThreshold = 0.0;
+    Arena<float> vertices;          /* 3 per vertex */
+    Arena<uint32_t> triangles;      /* 3 per triangle, global vertex ids */
+    Arena<uint64_t> extKeys;
+    Arena<uint32_t> extGid, extChunk;
+    std::vector<MeshRecord> blocks;
+    std::vector<uint64_t> chunkIds;             /* dense index -> caller's id, arrival order */
+    bool finalized = false;
+    /* results */
+    float *outVertices = nullptr;
+    uint32_t *outTriangles = nullptr;
+    std::vector<uint64_t> chunkVStart, chunkTStart;     /* [chunks + 1] */
+    std::vector<uint32_t> outChunks;                    /* dense chunk indices that have triangles */
+    uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    void dropResults()
+    {
+        hipFree(outVertices);
+        hipFree(outTriangles);
+        outVertices = nullptr;
+        outTriangles = nullptr;
+        finalized = false;
+    }
+    ~mlsgpu_mesher() { dropResults(); }
+};
+
+MLSGPU_API int mlsgpu_hip_mesher_create(mlsgpu_ctx *ctx, mlsgpu_mesher **out)
+{
+    REQUIRE(ctx != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    mlsgpu_mesher *m = new mlsgpu_mesher;
+    m->ctx = ctx;
+    *out = m;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API void mlsgpu_hip_mesher_destroy(mlsgpu_mesher *m) { delete m; }
+
+MLSGPU_API int mlsgpu_hip_mesher_set_prune_threshold(mlsgpu_mesher *m, double threshold)
+{
+    REQUIRE(m != nullptr && threshold >= 0.0 && threshold <= 1.0, MLSGPU_ERR_INVALID);
+    m->pruneThreshold = threshold;
+    return MLSGPU_OK;
+}
+
+/* MesherBase::InputFunctor (src/mesher.h:204-210) for a mesh that is still on the device */
+MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_t chunkId, const mlsgpu_mesh *mesh)
+{
+    REQUIRE(m != nullptr && from != nullptr && mesh != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(from->device == m->ctx->device, MLSGPU_ERR_INVALID);
+    REQUIRE(mesh->numInternalVertices <= mesh->numVertices, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    REQUIRE(!m->finalized, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(from->device));
+    /* chunks must arrive in order (src/mesher.h:190-193): a chunk is one contiguous run of blocks */
+    uint32_t chunk;
+    if (!m->chunkIds.empty() && m->chunkIds.back() == chunkId)
+        chunk = (uint32_t) m->chunkIds.size() - 1;
+    else
+    {
+        REQUIRE(std::find(m->chunkIds.begin(), m->chunkIds.end(), chunkId) == m->chunkIds.end(), MLSGPU_ERR_INVALID);
+        chunk = (uint32_t) m->chunkIds.size();
+        m->chunkIds.push_back(chunkId);
+    }
+    const uint64_t nv = mesh->numVertices, nt = mesh->numTriangles, ne = nv - mesh->numInternalVertices;
+    REQUIRE(m->vertices.used / 3 + nv < (uint64_t(1) << 32), MLSGPU_ERR_LENGTH);
+    /* the arenas may move: everything queued on the mesher's own stream has completed (reserve synchronises) */
+    PROPAGATE(m->vertices.reserve(from, m->vertices.used + 3 * nv));
+    PROPAGATE(m->triangles.reserve(from, m->triangles.used + 3 * nt));
+    PROPAGATE(m->extKeys.reserve(from, m->extKeys.used + ne));
+    PROPAGATE(m->extGid.reserve(from, m->extGid.used + ne));
+    PROPAGATE(m->extChunk.reserve(from, m->extChunk.used + ne));
+    MeshRecord r;
+    r.chunk = chunk;
+    r.vBase = (uint32_t) (m->vertices.used / 3);
+    r.nv = (uint32_t) nv;
+    r.nInternal = (uint32_t) mesh->numInternalVertices;
+    r.tBase = m->triangles.used / 3;
+    r.nt = nt;
+    r.eBase = (uint32_t) m->extKeys.used;
+    if (nv > 0)
+        HIP_CHECK(hipMemcpyAsync(m->vertices.ptr + m->vertices.used, mesh->dVertices, 3 * nv * sizeof(float),
+                                 hipMemcpyDeviceToDevice, from->stream));
+    if (nt > 0)
+    {
+        HIP_CHECK(hipMemcpyAsync(m->triangles.ptr + m->triangles.used, mesh->dTriangles, 3 * nt * sizeof(uint32_t),
+                                 hipMemcpyDeviceToDevice, from->stream));
+        hipLaunchKernelGGL(rebaseTrianglesKernel, dim3(divUp(3 * nt, 256)), dim3(256), 0, from->stream,
+                           m->triangles.ptr + m->triangles.used, 3 * nt, r.vBase);
+    }
+    if (ne > 0)
+    {
+        HIP_CHECK(hipMemcpyAsync(m->extKeys.ptr + m->extKeys.used, mesh->dVertexKeys + mesh->numInternalVertices,
+                                 ne * sizeof(uint64_t), hipMemcpyDeviceToDevice, from->stream));
+        std::vector<uint32_t> gid(ne), ch(ne, chunk);
+        for (uint64_t j = 0; j < ne; j++)
+            gid[j] = r.vBase + r.nInternal + (uint32_t) j;
+        HIP_CHECK(hipMemcpyAsync(m->extGid.ptr + m->extGid.used, gid.data(), ne * 4, hipMemcpyHostToDevice, from->stream));
+        HIP_CHECK(hipMemcpyAsync(m->extChunk.ptr + m->extChunk.used, ch.data(), ne * 4, hipMemcpyHostToDevice, from->stream));
+    }
+    /* the mesh is Marching's and is reused for the next ship-out: the copies must have left it */
+    HIP_CHECK(hipStreamSynchronize(from->stream));
+    m->vertices.used += 3 * nv;
+    m->triangles.used += 3 * nt;
+    m->extKeys.used += ne;
+    m->extGid.used += ne;
+    m->extChunk.used += ne;
+    m->blocks.push_back(r);
+    return MLSGPU_OK;
+}
+
+namespace
+{
+template<typename T>
+int devAlloc(T **p, uint64_t n)
+{
+    *p = nullptr;
+    HIP_CHECK(hipMalloc((void **) p, std::max<uint64_t>(n, 1) * sizeof(T)));
+    return MLSGPU_OK;
+}
+
+struct Scratch
+{
+    std::vector<void *> ptrs;
+    template<typename T> int get(T **p, uint64_t n)
+    {
+        PROPAGATE(devAlloc(p, n));
+        ptrs.push_back(*p);
+        return MLSGPU_OK;
+    }
+    ~Scratch()
+    {
+        for (void *p : ptrs)
+            hipFree(p);
+    }
+};
+} // namespace
+
+/* MesherBase::write's finalisation (src/mesher.cpp:763-852) up to the point where files are written */
+MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
+{
+    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    mlsgpu_ctx *ctx = m->ctx;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    m->dropResults();
+    const uint64_t nv = m->vertices.used / 3, nt = m->triangles.used / 3, ne = m->extKeys.used;
+    const uint32_t nb = (uint32_t) m->blocks.size(), nc = (uint32_t) m->chunkIds.size();
+    m->chunkVStart.assign(nc + 1, 0);
+    m->chunkTStart.assign(nc + 1, 0);
+    m->outChunks.clear();
+    std::fill(m->stats, m->stats + 8, 0);
+    if (nv == 0 || nt == 0)
+    {
+        m->finalized = true;
+        if (numChunks)
+            *numChunks = 0;
+        return MLSGPU_OK;
+    }
+    Scratch S;
+    uint32_t *compRep, *outRep, *parent, *root, *size, *vIndex;
+    PROPAGATE(S.get(&compRep, nv));
+    PROPAGATE(S.get(&outRep, nv));
+    PROPAGATE(S.get(&parent, nv));
+    PROPAGATE(S.get(&root, nv));
+    PROPAGATE(S.get(&size, nv));
+    PROPAGATE(S.get(&vIndex, nv));
+    const dim3 B(256);
+    LAUNCH(ctx, "mesher.weld.time", iotaKernel, dim3(divUp(nv, 256)), B, compRep, nv);
+    LAUNCH(ctx, "mesher.weld.time", iotaKernel, dim3(divUp(nv, 256)), B, outRep, nv);
+    LAUNCH(ctx, "mesher.weld.time", iotaKernel, dim3(divUp(nv, 256)), B, parent, nv);
+    HIP_CHECK(hipMemsetAsync(size, 0, nv * 4, ctx->stream));
+
+    /* 1. weld */
+    if (ne > 0)
+    {
+        uint64_t *keysA, *keysB;
+        uint32_t *slotsA, *slotsB, *hist, *tileSums;
+        PROPAGATE(S.get(&keysA, ne));
+        PROPAGATE(S.get(&keysB, ne));
+        PROPAGATE(S.get(&slotsA, ne));
+        PROPAGATE(S.get(&slotsB, ne));
+        PROPAGATE(S.get(&hist, sortHistElems(ne)));
+        PROPAGATE(S.get(&tileSums, scanTiles(std::max<uint64_t>(sortHistElems(ne), ne))));
+        HIP_CHECK(hipMemcpyAsync(keysA, m->extKeys.ptr, ne * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        SortResult<uint64_t> sorted;
+        PROPAGATE(radixSort<uint64_t>(ctx, "mesher.weld.time", keysA, slotsA, keysB, slotsB, ne, 64, true, hist, tileSums, &sorted));
+        LAUNCH(ctx, "mesher.weld.time", externalRepsKernel, dim3(divUp(ne, 256)), B, (const uint64_t *) sorted.keys,
+               (const uint32_t *) sorted.vals, (const uint32_t *) m->extGid.ptr, (const uint32_t *) m->extChunk.ptr, ne, compRep, outRep);
+    }
+
+    /* 2. components */
+    uint32_t *dFailed;
+    PROPAGATE(S.get(&dFailed, 1));
+    HIP_CHECK(hipMemsetAsync(dFailed, 0, 4, ctx->stream));
+    LAUNCH(ctx, "mesher.components.time", unionKernel, dim3(divUp(nt, 256)), B, (const uint32_t *) m->triangles.ptr, nt,
+           (const uint32_t *) compRep, parent, dFailed);
+    LAUNCH(ctx, "mesher.components.time", compressKernel, dim3(divUp(nv, 256)), B, parent, (const uint32_t *) compRep, nv, root);
+    LAUNCH(ctx, "mesher.components.time", componentSizeKernel, dim3(divUp(nv, 256)), B, (const uint32_t *) compRep,
+           (const uint32_t *) root, nv, size);
+
+    /* 3. prune threshold, src/mesher.cpp:498-527 */
+    unsigned long long *dStats;
+    PROPAGATE(S.get(&dStats, 4));
+    HIP_CHECK(hipMemsetAsync(dStats, 0, 32, ctx->stream));
+    LAUNCH(ctx, "mesher.components.time", componentStatsKernel, dim3(divUp(nv, 256)), B, (const uint32_t *) compRep,
+           (const uint32_t *) root, (const uint32_t *) size, nv, (uint64_t) 0, dStats, 0);
+    unsigned long long hStats[4];
+    uint32_t hFailed = 0;
+    HIP_CHECK(hipMemcpyAsync(hStats, dStats, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(&hFailed, dFailed, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (hFailed != 0)
+        return setError(MLSGPU_ERR_HIP, "mesher: component union did not converge");
+    const uint64_t totalVertices = hStats[0];
+    const uint64_t threshold = (uint64_t) ((double) totalVertices * m->pruneThreshold);
+    LAUNCH(ctx, "mesher.components.time", componentStatsKernel, dim3(divUp(nv, 256)), B, (const uint32_t *) compRep,
+           (const uint32_t *) root, (const uint32_t *) size, nv, threshold, dStats, 1);
+
+    /* 4. output */
+    std::vector<uint64_t> tBase(nb + 1), chunkFirstV(nc + 1), chunkFirstT(nc + 1);
+    std::vector<uint32_t> vBase(nb + 1), chunkOf(nb);
+    for (uint32_t b = 0; b < nb; b++)
+    {
+        tBase[b] = m->blocks[b].tBase;
+        vBase[b] = m->blocks[b].vBase;
+        chunkOf[b] = (uint32_t) m->blocks[b].chunk;
+    }
+    tBase[nb] = nt;
+    vBase[nb] = (uint32_t) nv;
+    for (uint32_t c = 0, b = 0; c <= nc; c++)
+    {
+        while (b < nb && chunkOf[b] < c)
+            b++;
+        chunkFirstV[c] = b < nb ? vBase[b] : nv;
+        chunkFirstT[c] = b < nb ? tBase[b] : nt;
+    }
+    uint64_t *dTBase, *dAt;
+    uint32_t *dVBase, *dChunkOf, *dChunkVStart, *dChunkTStart, *dTotals, *tileSums;
+    PROPAGATE(S.get(&dTBase, nb + 1));
+    PROPAGATE(S.get(&dVBase, nb + 1));
+    PROPAGATE(S.get(&dChunkOf, nb));
+    PROPAGATE(S.get(&dChunkVStart, nc + 1));
+    PROPAGATE(S.get(&dChunkTStart, nc + 1));
+    PROPAGATE(S.get(&dAt, nc + 1));
+    PROPAGATE(S.get(&dTotals, 2));
+    PROPAGATE(S.get(&tileSums, scanTiles(std::max(nv, nt))));
+    HIP_CHECK(hipMemcpyAsync(dTBase, tBase.data(), (nb + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(dVBase, vBase.data(), (nb + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(dChunkOf, chunkOf.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
+
+    /* vertices: the scan's size is not known before it ran; the output is sized for every vertex and trimmed by count */
+    HIP_CHECK(hipMalloc((void **) &m->outVertices, std::max<uint64_t>(3 * nv, 1) * sizeof(float)));
+    const KeepVertexIn keepV{outRep, root, size, threshold};
+    PROPAGATE((exclusiveScan<uint32_t>(ctx, "mesher.output.time", keepV, VertexOut{m->vertices.ptr, m->outVertices, vIndex},
+                                       nv, 0u, tileSums, dTotals)));
+    HIP_CHECK(hipMemcpyAsync(dAt, chunkFirstV.data(), (nc + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH(ctx, "mesher.output.time", gatherU32Kernel, dim3(divUp(nc + 1, 256)), B, (const uint32_t *) vIndex,
+           (const uint64_t *) dAt, nc + 1, nv, 0u, dChunkVStart);
+    /* the entry for "one past the last vertex" is the scan total */
+    std::vector<uint32_t> hV(nc + 1), hT(nc + 1);
+    uint32_t totals[2] = {0, 0};
+    HIP_CHECK(hipMemcpyAsync(hV.data(), dChunkVStart, (nc + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(&totals[0], dTotals, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t c = 0; c <= nc; c++)
+        if (chunkFirstV[c] >= nv)
+            hV[c] = totals[0];
+    HIP_CHECK(hipMemcpyAsync(dChunkVStart, hV.data(), (nc + 1) * 4, hipMemcpyHostToDevice, ctx->stream));
+
+    /* triangles */
+    uint32_t *tIndex;
+    PROPAGATE(S.get(&tIndex, nt));
+    HIP_CHECK(hipMalloc((void **) &m->outTriangles, std::max<uint64_t>(3 * nt, 1) * sizeof(uint32_t)));
+    const BlockTable T{dTBase, dVBase, dChunkOf, dChunkVStart, nb};
+    const KeepTriangleIn keepT{m->triangles.ptr, root, size, threshold};
+    PROPAGATE((exclusiveScan<uint32_t>(ctx, "mesher.output.time", keepT,
+                                       TriangleOutIdx{TriangleOut{m->triangles.ptr, outRep, vIndex, T, m->outTriangles}, tIndex},
+                                       nt, 0u, tileSums, dTotals + 1)));
+    HIP_CHECK(hipMemcpyAsync(dAt, chunkFirstT.data(), (nc + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    LAUNCH(ctx, "mesher.output.time", gatherU32Kernel, dim3(divUp(nc + 1, 256)), B, (const uint32_t *) tIndex,
+           (const uint64_t *) dAt, nc + 1, nt, 0u, dChunkTStart);
+    HIP_CHECK(hipMemcpyAsync(hT.data(), dChunkTStart, (nc + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(&totals[1], dTotals + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipMemcpyAsync(hStats, dStats, 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (uint32_t c = 0; c <= nc; c++)
+    {
+        if (chunkFirstT[c] >= nt)
+            hT[c] = totals[1];
+        m->chunkVStart[c] = hV[c];
+        m->chunkTStart[c] = hT[c];
+    }
+    for (uint32_t c = 0; c < nc; c++)
+        if (m->chunkTStart[c + 1] > m->chunkTStart[c])      /* no output for a chunk without triangles, :820 */
+            m->outChunks.push_back(c);
+    m->stats[0] = totalVertices;
+    m->stats[1] = threshold;
+    m->stats[2] = hStats[1];
+    m->stats[3] = hStats[2];
+    m->stats[4] = hStats[3];
+    m->stats[5] = totals[1];
+    m->stats[6] = nv;
+    m->stats[7] = nt;
+    m->finalized = true;
+    if (numChunks)
+        *numChunks = (uint32_t) m->outChunks.size();
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_mesher_chunk(mlsgpu_mesher *m, uint32_t i, uint64_t *chunkId, uint64_t *numVertices,
+                                       uint64_t *numTriangles, const float **dVertices, const uint32_t **dTriangles)
+{
+    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(m->finalized && i < m->outChunks.size(), MLSGPU_ERR_INVALID);
+    const uint32_t c = m->outChunks[i];
+    if (chunkId) *chunkId = m->chunkIds[c];
+    if (numVertices) *numVertices = m->chunkVStart[c + 1] - m->chunkVStart[c];
+    if (numTriangles) *numTriangles = m->chunkTStart[c + 1] - m->chunkTStart[c];
+    if (dVertices) *dVertices = m->outVertices + 3 * m->chunkVStart[c];
+    if (dTriangles) *dTriangles = m->outTriangles + 3 * m->chunkTStart[c];
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_mesher_stats(mlsgpu_mesher *m, uint64_t out[8])
+{
+    REQUIRE(m != nullptr && out != nullptr && m->finalized, MLSGPU_ERR_INVALID);
+    std::copy(m->stats, m->stats + 8, out);
+    return MLSGPU_OK;
+}
+
+/* FastPly::Writer's file (src/fast_ply.cpp:443-521): header padded to a multiple of 4, float32 x y z per vertex,
+ * uint8 3 + 3 x uint32 per face; host memory in, one file out */
+MLSGPU_API int mlsgpu_hip_write_ply(const char *path, const float *vertices, uint64_t numVertices, const uint32_t *triangles,
+                                    uint64_t numTriangles, const char *const *comments, uint32_t numComments)
+{
+    REQUIRE(path != nullptr && (numVertices == 0 || vertices != nullptr) && (numTriangles == 0 || triangles != nullptr),
+            MLSGPU_ERR_INVALID);
+    std::string head = "ply\nformat binary_little_endian 1.0\n";
+    for (uint32_t i = 0; i < numComments; i++)
+        head += std::string("comment ") + comments[i] + "\n";
+    head += "element vertex " + std::to_string(numVertices) + "\nproperty float32 x\nproperty float32 y\nproperty float32 z\n";
+    head += "element face " + std::to_string(numTriangles) + "\nproperty list uint8 uint32 vertex_indices\ncomment padding:";
+    size_t size = head.size() + 12;
+    while (size % 4 != 0)
+    {
+        head += 'X';
+        size++;
+    }
+    head += "\nend_header\n";
+    FILE *f = std::fopen(path, "wb");
+    if (f == nullptr)
+        return setError(MLSGPU_ERR_INVALID, "cannot open %s for writing", path);
+    bool ok = std::fwrite(head.data(), 1, head.size(), f) == head.size();
+    ok = ok && std::fwrite(vertices, 12, numVertices, f) == numVertices;
+    std::vector<unsigned char> faces;
+    const uint64_t batch = 1 << 20;
+    for (uint64_t first = 0; ok && first < numTriangles; first += batch)
+    {
+        const uint64_t n = std::min(batch, numTriangles - first);
+        faces.resize(13 * n);
+        for (uint64_t i = 0; i < n; i++)
+        {
+            faces[13 * i] = 3;
+            std::memcpy(&faces[13 * i + 1], triangles + 3 * (first + i), 12);
+        }
+        ok = std::fwrite(faces.data(), 13, n, f) == n;
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    if (!ok)
+        return setError(MLSGPU_ERR_INVALID, "writing %s failed", path);
+    return MLSGPU_OK;
+}

@@ -1,0 +1,142 @@
+"""HIP mesh sink (mlsgpu_hip_mesher_*) against the reference's mesher vectors and the oracle, up to isomorphism --
+the comparison the reference's own tests make (test/test_mesher.cpp:401-460)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import mesher_oracle as mo  # noqa: E402
+from mesher_cases import CASES  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def chunk_number(chunk, seen):
+    return seen.setdefault(chunk, len(seen))
+
+
+def run_hip(meshes, prune=0.0):
+    import mlsgpu_amd as m
+    ctx = m.Context(0)
+    mesher = m.Mesher(ctx, prune)
+    seen = {}
+    for mesh in meshes:
+        mesher.add(chunk_number(mesh["chunk"], seen), mesh["vertices"], mesh["num_internal"], mesh["keys"], mesh["triangles"])
+    n = mesher.finalize()
+    out = [mesher.chunk(i) for i in range(n)]
+    stats = mesher.stats()
+    mesher.close()
+    ctx.close()
+    back = {v: k for k, v in seen.items()}
+    return [(back[c["chunk"]], c["vertices"], c["triangles"]) for c in out], stats
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reference_case(name):
+    case = CASES[name]
+    out, stats = run_hip(case["meshes"], case.get("prune", 0.0))
+    assert [c for c, _, _ in out] == [c for c, _, _ in case["expected"]]
+    for (_, v, t), (_, ev, et) in zip(out, case["expected"]):
+        assert mo.isomorphic(v, t, ev, et), name
+    for k, val in case.get("stats", {}).items():
+        assert stats[k] == val
+
+
+def test_block_order_does_not_matter():
+    case = CASES["weld"]
+    out, _ = run_hip(case["meshes"][::-1])
+    (_, v, t), (_, ev, et) = out[0], case["expected"][0]
+    assert mo.isomorphic(v, t, ev, et)
+
+
+def test_chunks_must_be_contiguous():
+    import mlsgpu_amd as m
+    ctx = m.Context(0)
+    mesher = m.Mesher(ctx)
+    a = CASES["simple"]["meshes"][0]
+    mesher.add(0, a["vertices"], a["num_internal"], a["keys"], a["triangles"])
+    mesher.add(1, a["vertices"], a["num_internal"], a["keys"], a["triangles"])
+    with pytest.raises(m.InvalidArgument):
+        mesher.add(0, a["vertices"], a["num_internal"], a["keys"], a["triangles"])
+    mesher.close()
+    ctx.close()
+
+
+def random_meshes(seed, blocks=12, chunks=3):
+    """Blocks of a triangulated grid sheet cut into strips: vertices on the cuts are external with a shared key;
+    a few small islands test pruning.  Positions are unique per welded vertex."""
+    rng = np.random.default_rng(seed)
+    width, height = 40, 6 * blocks
+    meshes = []
+    for b in range(blocks):
+        y0, y1 = 6 * b, 6 * (b + 1)                       # rows y0..y1 inclusive; rows y0 and y1 are shared
+        gaps = rng.random((y1 - y0, width - 1)) < 0.15    # missing quads break the sheet into components
+        ids = -np.ones((y1 - y0 + 1, width), np.int64)
+        tris = []
+        for y in range(y0, y1):
+            for x in range(width - 1):
+                if gaps[y - y0, x]:
+                    continue
+                quad = [(y, x), (y, x + 1), (y + 1, x + 1), (y + 1, x)]
+                tris.append([quad[0], quad[1], quad[2]])
+                tris.append([quad[0], quad[2], quad[3]])
+        used = sorted({p for t in tris for p in t})
+        internal = [p for p in used if p[0] not in (y0, y1)]
+        external = [p for p in used if p[0] in (y0, y1)]
+        order = {p: i for i, p in enumerate(internal + external)}
+        verts = np.array([[p[1], p[0], (p[0] * 7 + p[1] * 3) % 5] for p in internal + external], np.float32).reshape(-1, 3)
+        keys = np.array([(p[0] << 21) | p[1] | (1 << 63) for p in external], np.uint64)
+        t = np.array([[order[p] for p in tri] for tri in tris], np.uint32).reshape(-1, 3)
+        meshes.append(dict(chunk=b * chunks // blocks, vertices=verts, num_internal=len(internal), keys=keys, triangles=t))
+    return meshes
+
+
+@pytest.mark.parametrize("seed,prune", [(1, 0.0), (2, 0.01), (3, 0.05), (4, 0.3)])
+def test_random_sheets_match_oracle(seed, prune):
+    meshes = random_meshes(seed)
+    exp, exp_stats = mo.mesh_sink(meshes, prune)
+    out, stats = run_hip(meshes, prune)
+    for k in ("total_vertices", "threshold", "components", "kept_components", "kept_vertices", "kept_triangles"):
+        assert stats[k] == exp_stats[k], k
+    assert [c for c, _, _ in out] == [c for c, _, _ in exp]
+    for (_, v, t), (_, ev, et) in zip(out, exp):
+        assert mo.isomorphic(v, t, ev, et)
+
+
+def test_worker_meshes_weld_into_a_closed_surface(tmp_path):
+    """27 buckets of a shells cloud through workers into the mesher: the welded result equals the oracle sink fed with
+    the oracle's bucket meshes, external vertices are shared (fewer vertices than the sum), and the PLY round-trips."""
+    import mlsgpu_amd as m
+    import oracle_binding as ob
+    from mlsgpu_amd import binding as b, synth
+    cloud = synth.shells_cloud(120_000, 95.0, 16.0, 1.5, 2.5, seed=321)
+    allb, buckets = synth.bucketize(cloud, 96, 32)
+    ctx = m.Context(0)
+    dev = m.DeviceBuffer(ctx, array=allb)
+    worker = m.Worker(ctx, max(bk.count for bk in buckets), max_cells=63)
+    mesher = m.Mesher(ctx, 0.02)
+    for bk in buckets:
+        worker.process(dev, bk.first, bk.count, bk.low, bk.num_vertices, collector=mesher.collector(ctx, 0))
+    assert mesher.finalize() == 1
+    got = mesher.chunk(0)
+    stats = mesher.stats()
+    ref = allb.copy()
+    meshes = []
+    for bk in buckets:
+        batches, _ = ob.bucket(ref, bk.first, bk.count, bk.num_vertices, bk.low, max_cells=63)
+        for g in batches:
+            meshes.append(dict(chunk=0, vertices=g["vertices"], num_internal=g["num_internal"],
+                               keys=g["keys"][g["num_internal"]:], triangles=g["triangles"]))
+    exp, exp_stats = mo.mesh_sink(meshes, 0.02)
+    for k in ("total_vertices", "threshold", "components", "kept_components", "kept_vertices", "kept_triangles"):
+        assert stats[k] == exp_stats[k], k
+    assert stats["total_vertices"] < stats["vertices_added"]            # shared vertices were welded
+    assert mo.isomorphic(got["vertices"], got["triangles"], exp[0][1], exp[0][2])
+    path = tmp_path / "out.ply"
+    b.write_ply(path, got["vertices"], got["triangles"], ["mlsgpu version: test"])
+    assert open(path, "rb").read() == mo.ply_bytes(got["vertices"], got["triangles"], ["mlsgpu version: test"])
+    mesher.close()
+    del worker
+    ctx.close()
