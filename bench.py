@@ -46,6 +46,7 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-stream", action="store_true", help="skip the PCIe-inclusive bucket-farm leg")
     p.add_argument("--no-partition", action="store_true", help="skip the device-bucketer leg (reference partition)")
+    p.add_argument("--no-sink", action="store_true", help="skip the device mesh-sink leg (weld / components / prune)")
     p.add_argument("--no-timing", action="store_true", help="do not time individual kernels with HIP events")
     return p.parse_args()
 
@@ -297,6 +298,32 @@ def main():
         result["kernel_ms_per_step"] = {k: round(v[0] / K, 3) for k, v in sorted(kernel_stats.items())}
         result["work_per_step"] = {"octree_entries": entries, "occupied_cells": O, "unwelded_vertices": mc["unwelded"],
                                    "welded_vertices": Vw, "external_vertices": external, "indices": T}
+
+    # ---- mesh-sink leg (never `value`): every ship-out of one pass appended to the device mesher (d2d), then
+    # finalize = weld by key across buckets + connected components + prune (--fit-prune default 0.02) + compaction ----
+    if world == 1 and not args.no_sink:
+        sink = m.Mesher(ctx, 0.02)
+        work.copy_from(pristine)
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for b in buckets:
+            workers[0].process(work, b.first, b.count, b.low, b.num_vertices, collector=sink.collector(ctxs[0], 0))
+        ctxs[0].synchronize()
+        add_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        nchunks = sink.finalize()
+        ctx.synchronize()
+        fin_s = time.perf_counter() - t0
+        st = sink.stats()
+        result["mesh_sink"] = {
+            "pass_with_appends_ms": round(add_s * 1e3, 3), "finalize_ms": round(fin_s * 1e3, 3),
+            "finalize_mvertices_per_s": round(st["vertices_added"] / fin_s / 1e6, 1), "chunks": nchunks,
+            "vertices_added": st["vertices_added"], "triangles_added": st["triangles_added"],
+            "welded_vertices": st["total_vertices"], "components": st["components"], "kept_components": st["kept_components"],
+            "kept_vertices": st["kept_vertices"], "kept_triangles": st["kept_triangles"],
+            "note": "one worker; meshes never leave HBM; finalize = key sort + union-find + sizes + two compaction scans",
+        }
+        sink.close()
 
     # ---- device-bucketer leg (never `value`): the RAW cloud resident in HBM, partitioned on the device exactly as
     # the reference's Bucket::bucket would with its defaults (255-cell buckets, 63-cell microblocks, 2 097 152 splats,
