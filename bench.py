@@ -303,6 +303,7 @@ def main():
     # finalize = weld by key across buckets + connected components + prune (--fit-prune default 0.02) + compaction ----
     if world == 1 and not args.no_sink:
         sink = m.Mesher(ctx, 0.02)
+        sink.reserve(mc["welded"] + 1024, mc["indices"] // 3 + 1024, mc["external"] + 1024)   # counts of the stats pass
         work.copy_from(pristine)
         ctx.synchronize()
         t0 = time.perf_counter()

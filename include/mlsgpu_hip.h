@@ -328,6 +328,9 @@ int mlsgpu_hip_mesher_create(mlsgpu_ctx *ctx, mlsgpu_mesher **out);
 void mlsgpu_hip_mesher_destroy(mlsgpu_mesher *mesher);
 /* MesherBase::setPruneThreshold: components with fewer vertices than uint64(total * threshold) are dropped */
 int mlsgpu_hip_mesher_set_prune_threshold(mlsgpu_mesher *mesher, double threshold);
+/* Optional: room for this many vertices / triangles / external vertices in total (the arenas grow by reallocation
+ * otherwise). */
+int mlsgpu_hip_mesher_reserve(mlsgpu_mesher *mesher, uint64_t numVertices, uint64_t numTriangles, uint64_t numExternal);
 /* MesherBase::InputFunctor for a DeviceKeyMesh: appends a copy of the mesh (device to device, on `from`'s stream, which
  * is synchronised before returning: Marching reuses the mesh).  Thread safe; `from` is the calling worker's context on
  * the mesher's device.  The blocks of one chunk must arrive contiguously ("chunks must be in order", src/mesher.h:190-193);

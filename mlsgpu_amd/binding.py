@@ -185,6 +185,7 @@ def lib():
     sig("mlsgpu_hip_mesher_destroy", None, vp)
     sig("mlsgpu_hip_mesher_set_prune_threshold", C.c_int, vp, C.c_double)
     sig("mlsgpu_hip_mesher_add", C.c_int, vp, vp, u64, vp)
+    sig("mlsgpu_hip_mesher_reserve", C.c_int, vp, u64, u64, u64)
     sig("mlsgpu_hip_mesher_finalize", C.c_int, vp, P(u32))
     sig("mlsgpu_hip_mesher_chunk", C.c_int, vp, u32, P(u64), P(u64), P(u64), P(vp), P(vp))
     sig("mlsgpu_hip_mesher_stats", C.c_int, vp, vp)
@@ -471,6 +472,9 @@ class Mesher:
 
     def set_prune_threshold(self, threshold):
         check(lib().mlsgpu_hip_mesher_set_prune_threshold(self.h, float(threshold)))
+
+    def reserve(self, num_vertices, num_triangles, num_external):
+        check(lib().mlsgpu_hip_mesher_reserve(self.h, num_vertices, num_triangles, num_external))
 
     def add_device(self, from_ctx, chunk_id, mesh_ptr):
         check(lib().mlsgpu_hip_mesher_add(self.h, from_ctx.h, chunk_id, mesh_ptr))

@@ -67,6 +67,16 @@ __global__ void rebaseTrianglesKernel(uint32_t *tri, uint64_t n3, uint32_t base)
         tri[i] += base;
 }
 
+__global__ void fillExternalsKernel(uint32_t *gid, uint32_t *chunk, uint64_t n, uint32_t firstGid, uint32_t chunkIndex)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+    {
+        gid[i] = firstGid + (uint32_t) i;
+        chunk[i] = chunkIndex;
+    }
+}
+
 __global__ void iotaKernel(uint32_t *a, uint64_t n)
 {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,44 +163,74 @@ __global__ void compressKernel(uint32_t *parent, const uint32_t *compRep, uint64
 }
 
 /* vertices of a component: every welded vertex once.  Neighbouring vertices mostly share their component (a noise
- * cloud is ONE component of hundreds of millions of vertices), so a wave adds once per distinct root it holds. */
-__global__ void componentSizeKernel(const uint32_t *compRep, const uint32_t *root, uint64_t n, uint32_t *size)
+ * cloud is ONE component of hundreds of millions of vertices, and 6 million same-address atomics take 67 ms), so each
+ * wave walks a contiguous span and keeps one pending (root, count) in registers; it only touches memory when the root
+ * changes. */
+#define SIZE_SPAN 64        /* steps of 64 vertices per wave */
+__global__ __launch_bounds__(256) void componentSizeKernel(const uint32_t *compRep, const uint32_t *root, uint64_t n, uint32_t *size)
 {
-    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    const bool counts = i < n && compRep[i] == (uint32_t) i;
-    const uint32_t mine = counts ? root[i] : 0u;
-    uint64_t todo = __ballot(counts);
-    while (todo != 0)
+    const uint64_t wave = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t first = wave * (64 * SIZE_SPAN);
+    uint32_t pendingRoot = 0, pendingCount = 0;         /* wave-uniform */
+    for (uint32_t s = 0; s < SIZE_SPAN; s++)
     {
-        const uint32_t r = readLane(mine, (int) __builtin_ctzll(todo));
-        const uint64_t same = __ballot(counts && mine == r) & todo;
-        if (laneId() == (uint32_t) __builtin_ctzll(same))
-            atomicAdd(&size[r], (uint32_t) __popcll(same));
-        todo &= ~same;
+        const uint64_t i = first + (uint64_t) s * 64 + laneId();
+        if (first + (uint64_t) s * 64 >= n)
+            break;
+        const bool counts = i < n && compRep[i] == (uint32_t) i;
+        const uint32_t mine = counts ? root[i] : 0u;
+        uint64_t todo = __ballot(counts);
+        while (todo != 0)
+        {
+            const uint32_t r = readLane(mine, (int) __builtin_ctzll(todo));
+            const uint64_t same = __ballot(counts && mine == r) & todo;
+            const uint32_t c = (uint32_t) __popcll(same);
+            if (pendingCount != 0 && r != pendingRoot)
+            {
+                if (laneId() == 0)
+                    atomicAdd(&size[pendingRoot], pendingCount);
+                pendingCount = 0;
+            }
+            pendingRoot = r;
+            pendingCount += c;
+            todo &= ~same;
+        }
     }
+    if (pendingCount != 0 && laneId() == 0)
+        atomicAdd(&size[pendingRoot], pendingCount);
 }
 
 /* [0] welded vertices, [1] components, [2] kept components, [3] kept vertices */
-__global__ void componentStatsKernel(const uint32_t *compRep, const uint32_t *root, const uint32_t *size, uint64_t n,
-                                     uint64_t threshold, unsigned long long *stats, int pass)
+__global__ __launch_bounds__(256) void componentStatsKernel(const uint32_t *compRep, const uint32_t *root, const uint32_t *size,
+                                                           uint64_t n, uint64_t threshold, unsigned long long *stats, int pass)
 {
-    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n)
-        return;
-    if (pass == 0)
+    /* grid-stride with per-thread sums, one atomic per wave at the end */
+    unsigned long long reps = 0, comps = 0, kept = 0, keptV = 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
     {
-        const uint64_t reps = __ballot(compRep[i] == (uint32_t) i);
-        if (reps != 0 && laneId() == (uint32_t) __builtin_ctzll(reps))
-            atomicAdd(&stats[0], (unsigned long long) __popcll(reps));
-    }
-    else if (root[i] == (uint32_t) i && compRep[i] == (uint32_t) i)
-    {
-        atomicAdd(&stats[1], 1ull);
-        if (size[i] >= threshold)
+        const bool rep = compRep[i] == (uint32_t) i;
+        if (pass == 0)
+            reps += rep ? 1 : 0;
+        else if (rep && root[i] == (uint32_t) i)
         {
-            atomicAdd(&stats[2], 1ull);
-            atomicAdd(&stats[3], (unsigned long long) size[i]);
+            comps++;
+            if (size[i] >= threshold)
+            {
+                kept++;
+                keptV += size[i];
+            }
         }
+    }
+    const unsigned long long vals[4] = {reps, comps, kept, keptV};
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        unsigned long long v = vals[k];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+            v += __shfl_xor(v, d, 64);
+        if (laneId() == 0 && v != 0)
+            atomicAdd(&stats[k], v);
     }
 }
 
@@ -347,6 +387,20 @@ MLSGPU_API int mlsgpu_hip_mesher_set_prune_threshold(mlsgpu_mesher *m, double th
     return MLSGPU_OK;
 }
 
+/* room for the whole job up front: an arena that has to grow is reallocated and copied */
+MLSGPU_API int mlsgpu_hip_mesher_reserve(mlsgpu_mesher *m, uint64_t numVertices, uint64_t numTriangles, uint64_t numExternal)
+{
+    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    HIP_CHECK(hipSetDevice(m->ctx->device));
+    PROPAGATE(m->vertices.reserve(m->ctx, 3 * numVertices));
+    PROPAGATE(m->triangles.reserve(m->ctx, 3 * numTriangles));
+    PROPAGATE(m->extKeys.reserve(m->ctx, numExternal));
+    PROPAGATE(m->extGid.reserve(m->ctx, numExternal));
+    PROPAGATE(m->extChunk.reserve(m->ctx, numExternal));
+    return MLSGPU_OK;
+}
+
 /* MesherBase::InputFunctor (src/mesher.h:204-210) for a mesh that is still on the device */
 MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_t chunkId, const mlsgpu_mesh *mesh)
 {
@@ -396,11 +450,8 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
     {
         HIP_CHECK(hipMemcpyAsync(m->extKeys.ptr + m->extKeys.used, mesh->dVertexKeys + mesh->numInternalVertices,
                                  ne * sizeof(uint64_t), hipMemcpyDeviceToDevice, from->stream));
-        std::vector<uint32_t> gid(ne), ch(ne, chunk);
-        for (uint64_t j = 0; j < ne; j++)
-            gid[j] = r.vBase + r.nInternal + (uint32_t) j;
-        HIP_CHECK(hipMemcpyAsync(m->extGid.ptr + m->extGid.used, gid.data(), ne * 4, hipMemcpyHostToDevice, from->stream));
-        HIP_CHECK(hipMemcpyAsync(m->extChunk.ptr + m->extChunk.used, ch.data(), ne * 4, hipMemcpyHostToDevice, from->stream));
+        hipLaunchKernelGGL(fillExternalsKernel, dim3(divUp(ne, 256)), dim3(256), 0, from->stream,
+                           m->extGid.ptr + m->extGid.used, m->extChunk.ptr + m->extChunk.used, ne, r.vBase + r.nInternal, chunk);
     }
     /* the mesh is Marching's and is reused for the next ship-out: the copies must have left it */
     HIP_CHECK(hipStreamSynchronize(from->stream));
@@ -500,14 +551,15 @@ MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
     LAUNCH(ctx, "mesher.components.time", unionKernel, dim3(divUp(nt, 256)), B, (const uint32_t *) m->triangles.ptr, nt,
            (const uint32_t *) compRep, parent, dFailed);
     LAUNCH(ctx, "mesher.components.time", compressKernel, dim3(divUp(nv, 256)), B, parent, (const uint32_t *) compRep, nv, root);
-    LAUNCH(ctx, "mesher.components.time", componentSizeKernel, dim3(divUp(nv, 256)), B, (const uint32_t *) compRep,
-           (const uint32_t *) root, nv, size);
+    LAUNCH(ctx, "mesher.components.time", componentSizeKernel, dim3(divUp(divUp(nv, 64 * SIZE_SPAN), 4)), B,
+           (const uint32_t *) compRep, (const uint32_t *) root, nv, size);
 
     /* 3. prune threshold, src/mesher.cpp:498-527 */
     unsigned long long *dStats;
     PROPAGATE(S.get(&dStats, 4));
     HIP_CHECK(hipMemsetAsync(dStats, 0, 32, ctx->stream));
-    LAUNCH(ctx, "mesher.components.time", componentStatsKernel, dim3(divUp(nv, 256)), B, (const uint32_t *) compRep,
+    const dim3 statsGrid((uint32_t) std::min<uint64_t>(divUp(nv, 256), 8192));
+    LAUNCH(ctx, "mesher.components.time", componentStatsKernel, statsGrid, B, (const uint32_t *) compRep,
            (const uint32_t *) root, (const uint32_t *) size, nv, (uint64_t) 0, dStats, 0);
     unsigned long long hStats[4];
     uint32_t hFailed = 0;
@@ -518,7 +570,7 @@ MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
         return setError(MLSGPU_ERR_HIP, "mesher: component union did not converge");
     const uint64_t totalVertices = hStats[0];
     const uint64_t threshold = (uint64_t) ((double) totalVertices * m->pruneThreshold);
-    LAUNCH(ctx, "mesher.components.time", componentStatsKernel, dim3(divUp(nv, 256)), B, (const uint32_t *) compRep,
+    LAUNCH(ctx, "mesher.components.time", componentStatsKernel, statsGrid, B, (const uint32_t *) compRep,
            (const uint32_t *) root, (const uint32_t *) size, nv, threshold, dStats, 1);
 
     /* 4. output */
