@@ -339,6 +339,39 @@ struct Arena
 
 } // namespace
 
+namespace
+{
+/* bump allocator over a slab the mesher keeps between calls: allocating and freeing tens of GB of scratch costs
+ * several times the kernels that use it */
+struct Scratch
+{
+    char *base;
+    uint64_t cap, used = 0;
+    Scratch(void *base, uint64_t cap) : base(static_cast<char *>(base)), cap(cap) {}
+    template<typename T> int get(T **p, uint64_t n)
+    {
+        const uint64_t bytes = (std::max<uint64_t>(n, 1) * sizeof(T) + 255) & ~uint64_t(255);
+        if (used + bytes > cap)
+            return setError(MLSGPU_ERR_NOMEM, "mesher: scratch slab too small (%llu of %llu bytes used, %llu more wanted)",
+                            (unsigned long long) used, (unsigned long long) cap, (unsigned long long) bytes);
+        *p = reinterpret_cast<T *>(base + used);
+        used += bytes;
+        return MLSGPU_OK;
+    }
+};
+
+uint64_t scratchBytes(uint64_t nv, uint64_t nt, uint64_t ne, uint64_t nb, uint64_t nc)
+{
+    auto al = [](uint64_t b) { return (std::max<uint64_t>(b, 1) + 255) & ~uint64_t(255); };
+    uint64_t total = 6 * al(nv * 4) + al(nt * 4);                                   /* per-vertex arrays, tIndex */
+    total += 2 * al(ne * 8) + 2 * al(ne * 4) + al(sortHistElems(ne) * 4)            /* key sort */
+        + al(scanTiles(std::max<uint64_t>(sortHistElems(ne), ne)) * 4);
+    total += al(scanTiles(std::max(nv, nt)) * 4);                                   /* scans */
+    total += 2 * al((nb + 1) * 8) + 2 * al((nb + 1) * 4) + 3 * al((nc + 1) * 8) + 8 * 256;
+    return total + (1 << 20);
+}
+} // namespace
+
 struct mlsgpu_mesher
 {
     mlsgpu_ctx *ctx = nullptr;
@@ -358,15 +391,49 @@ struct mlsgpu_mesher
     std::vector<uint32_t> outChunks;                    /* dense chunk indices that have triangles */
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    void dropResults()
+    /* kept between finalize calls; grown on demand (or up front by reserve) */
+    void *slab = nullptr;
+    uint64_t slabCap = 0;
+    uint64_t outVCap = 0, outTCap = 0;
+
+    int ensureSlab(uint64_t bytes)
+    {
+        if (bytes <= slabCap)
+            return MLSGPU_OK;
+        hipFree(slab);
+        slab = nullptr;
+        slabCap = 0;
+        HIP_CHECK(hipMalloc(&slab, bytes));
+        slabCap = bytes;
+        return MLSGPU_OK;
+    }
+    int ensureOutputs(uint64_t nv, uint64_t nt)
+    {
+        if (outVCap < nv)
+        {
+            hipFree(outVertices);
+            outVertices = nullptr;
+            outVCap = 0;
+            HIP_CHECK(hipMalloc((void **) &outVertices, std::max<uint64_t>(3 * nv, 1) * sizeof(float)));
+            outVCap = nv;
+        }
+        if (outTCap < nt)
+        {
+            hipFree(outTriangles);
+            outTriangles = nullptr;
+            outTCap = 0;
+            HIP_CHECK(hipMalloc((void **) &outTriangles, std::max<uint64_t>(3 * nt, 1) * sizeof(uint32_t)));
+            outTCap = nt;
+        }
+        return MLSGPU_OK;
+    }
+    void dropResults() { finalized = false; }
+    ~mlsgpu_mesher()
     {
         hipFree(outVertices);
         hipFree(outTriangles);
-        outVertices = nullptr;
-        outTriangles = nullptr;
-        finalized = false;
+        hipFree(slab);
     }
-    ~mlsgpu_mesher() { dropResults(); }
 };
 
 MLSGPU_API int mlsgpu_hip_mesher_create(mlsgpu_ctx *ctx, mlsgpu_mesher **out)
@@ -398,6 +465,9 @@ MLSGPU_API int mlsgpu_hip_mesher_reserve(mlsgpu_mesher *m, uint64_t numVertices,
     PROPAGATE(m->extKeys.reserve(m->ctx, numExternal));
     PROPAGATE(m->extGid.reserve(m->ctx, numExternal));
     PROPAGATE(m->extChunk.reserve(m->ctx, numExternal));
+    /* finalize's scratch and outputs too (a few hundred blocks and chunks are assumed; finalize grows it otherwise) */
+    PROPAGATE(m->ensureSlab(scratchBytes(numVertices, numTriangles, numExternal, 4096, 4096)));
+    PROPAGATE(m->ensureOutputs(numVertices, numTriangles));
     return MLSGPU_OK;
 }
 
@@ -464,32 +534,6 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
     return MLSGPU_OK;
 }
 
-namespace
-{
-template<typename T>
-int devAlloc(T **p, uint64_t n)
-{
-    *p = nullptr;
-    HIP_CHECK(hipMalloc((void **) p, std::max<uint64_t>(n, 1) * sizeof(T)));
-    return MLSGPU_OK;
-}
-
-struct Scratch
-{
-    std::vector<void *> ptrs;
-    template<typename T> int get(T **p, uint64_t n)
-    {
-        PROPAGATE(devAlloc(p, n));
-        ptrs.push_back(*p);
-        return MLSGPU_OK;
-    }
-    ~Scratch()
-    {
-        for (void *p : ptrs)
-            hipFree(p);
-    }
-};
-} // namespace
 
 /* MesherBase::write's finalisation (src/mesher.cpp:763-852) up to the point where files are written */
 MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
@@ -512,7 +556,9 @@ MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
             *numChunks = 0;
         return MLSGPU_OK;
     }
-    Scratch S;
+    PROPAGATE(m->ensureSlab(scratchBytes(nv, nt, ne, nb, nc)));
+    PROPAGATE(m->ensureOutputs(nv, nt));
+    Scratch S(m->slab, m->slabCap);
     uint32_t *compRep, *outRep, *parent, *root, *size, *vIndex;
     PROPAGATE(S.get(&compRep, nv));
     PROPAGATE(S.get(&outRep, nv));
@@ -606,7 +652,6 @@ MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
     HIP_CHECK(hipMemcpyAsync(dChunkOf, chunkOf.data(), nb * 4, hipMemcpyHostToDevice, ctx->stream));
 
     /* vertices: the scan's size is not known before it ran; the output is sized for every vertex and trimmed by count */
-    HIP_CHECK(hipMalloc((void **) &m->outVertices, std::max<uint64_t>(3 * nv, 1) * sizeof(float)));
     const KeepVertexIn keepV{outRep, root, size, threshold};
     PROPAGATE((exclusiveScan<uint32_t>(ctx, "mesher.output.time", keepV, VertexOut{m->vertices.ptr, m->outVertices, vIndex},
                                        nv, 0u, tileSums, dTotals)));
@@ -627,7 +672,6 @@ MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
     /* triangles */
     uint32_t *tIndex;
     PROPAGATE(S.get(&tIndex, nt));
-    HIP_CHECK(hipMalloc((void **) &m->outTriangles, std::max<uint64_t>(3 * nt, 1) * sizeof(uint32_t)));
     const BlockTable T{dTBase, dVBase, dChunkOf, dChunkVStart, nb};
     const KeepTriangleIn keepT{m->triangles.ptr, root, size, threshold};
     PROPAGATE((exclusiveScan<uint32_t>(ctx, "mesher.output.time", keepT,
