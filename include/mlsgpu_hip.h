@@ -38,6 +38,7 @@ extern "C" {
 #define MLSGPU_ERR_NOMEM 4
 #define MLSGPU_ERR_CALLBACK 5
 #define MLSGPU_ERR_DENSITY 6   /* Bucket::DensityError, src/bucket.h:52-65 */
+#define MLSGPU_ERR_FORMAT 7    /* FastPly::FormatError, src/fast_ply.h:60-75 */
 
 /* struct Splat, src/splat.h:40-46 == kernels/octree.cl:32-36 (32 bytes, AoS).
  * After mlsgpu_hip_tree_build the radius slot holds 1/radius^2 (octree.cl:193). */
@@ -351,6 +352,19 @@ int mlsgpu_hip_mesher_stats(mlsgpu_mesher *mesher, uint64_t out[8]);
  * float32 x y z, faces as uint8 3 + 3 x uint32 */
 int mlsgpu_hip_write_ply(const char *path, const float *vertices, uint64_t numVertices, const uint32_t *triangles,
                          uint64_t numTriangles, const char *const *comments, uint32_t numComments);
+
+/* ---- splat input: FastPly::Reader, src/fast_ply.h:77-262; host only ---- */
+typedef struct mlsgpu_ply_reader mlsgpu_ply_reader;
+/* Opens a binary PLY file of splats (float32 x y z nx ny nz radius among the vertex properties) and checks its header;
+ * MLSGPU_ERR_FORMAT with the reference's message otherwise.  radius' = min(radius, maxRadius) * smooth,
+ * quality = 1 / radius'^2 (Reader::decode, src/fast_ply.cpp:334-350). */
+int mlsgpu_hip_ply_open(const char *path, float smooth, float maxRadius, mlsgpu_ply_reader **out);
+void mlsgpu_hip_ply_close(mlsgpu_ply_reader *reader);
+uint64_t mlsgpu_hip_ply_size(const mlsgpu_ply_reader *reader);
+/* out[0] vertex size in bytes, [1] vertex count, [2] header size, [3..9] byte offsets of x y z nx ny nz radius */
+int mlsgpu_hip_ply_layout(const mlsgpu_ply_reader *reader, uint64_t out[10]);
+/* Reader::Handle::read: splats [first, first + count) into host memory (e.g. what mlsgpu_hip_farm_acquire returned) */
+int mlsgpu_hip_ply_read(mlsgpu_ply_reader *reader, uint64_t first, uint64_t count, mlsgpu_splat *out);
 
 /* DeviceWorkerGroupBase::computeMaxSwathe, src/workers.cpp:169-182 */
 uint32_t mlsgpu_hip_compute_max_swathe(uint32_t yMax, uint32_t y, uint32_t yAlign, uint32_t zAlign);

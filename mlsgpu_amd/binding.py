@@ -28,6 +28,10 @@ class LengthError(MlsError, ValueError):
     """std::length_error in the reference."""
 
 
+class FormatError(MlsError, ValueError):
+    """FastPly::FormatError, src/fast_ply.h:60-75."""
+
+
 class DensityError(MlsError, RuntimeError):
     """Bucket::DensityError (src/bucket.h:52-65): more than maxSplats splats cover a single cell."""
 
@@ -181,6 +185,11 @@ def lib():
     sig("mlsgpu_hip_farm_finish", C.c_int, vp)
     sig("mlsgpu_hip_farm_stats", C.c_int, vp, vp)
     sig("mlsgpu_hip_transform_splats", None, vp, u64, vp, f32, vp)
+    sig("mlsgpu_hip_ply_open", C.c_int, C.c_char_p, f32, f32, P(vp))
+    sig("mlsgpu_hip_ply_close", None, vp)
+    sig("mlsgpu_hip_ply_size", u64, vp)
+    sig("mlsgpu_hip_ply_layout", C.c_int, vp, vp)
+    sig("mlsgpu_hip_ply_read", C.c_int, vp, u64, u64, vp)
     sig("mlsgpu_hip_mesher_create", C.c_int, vp, P(vp))
     sig("mlsgpu_hip_mesher_destroy", None, vp)
     sig("mlsgpu_hip_mesher_set_prune_threshold", C.c_int, vp, C.c_double)
@@ -205,7 +214,7 @@ def lib():
     return L
 
 
-_ERRORS = {1: InvalidArgument, 2: LengthError, 3: HipError, 4: HipError, 5: MlsError, 6: DensityError}
+_ERRORS = {1: InvalidArgument, 2: LengthError, 3: HipError, 4: HipError, 5: MlsError, 6: DensityError, 7: FormatError}
 
 
 def check(rc):
@@ -553,6 +562,44 @@ class MesherCollector:
                 self.error = e
                 return 1
         self.cb = OUTPUT_FN(cb)
+
+
+class PlyReader:
+    """FastPly::Reader, src/fast_ply.h:77-262."""
+
+    def __init__(self, path, smooth=1.0, max_radius=float("inf")):
+        h = C.c_void_p()
+        check(lib().mlsgpu_hip_ply_open(str(path).encode(), smooth, max_radius, C.byref(h)))
+        self.h = h
+
+    def __len__(self):
+        return int(lib().mlsgpu_hip_ply_size(self.h))
+
+    def layout(self):
+        out = np.zeros(10, np.uint64)
+        check(lib().mlsgpu_hip_ply_layout(self.h, _p(out)))
+        names = ["vertex_size", "vertex_count", "header_size", "x", "y", "z", "nx", "ny", "nz", "radius"]
+        return dict(zip(names, [int(v) for v in out]))
+
+    def read(self, first=0, count=None, out=None):
+        if count is None:
+            count = len(self) - first
+        if out is None:
+            out = np.zeros(count, SPLAT_DTYPE)
+        assert out.dtype == SPLAT_DTYPE and out.flags.c_contiguous and len(out) >= count
+        check(lib().mlsgpu_hip_ply_read(self.h, first, count, _p(out)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mlsgpu_hip_ply_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def write_ply(path, vertices, triangles, comments=()):

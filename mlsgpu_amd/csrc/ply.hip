@@ -1,0 +1,268 @@
+/*
+ * Splat input from PLY files: FastPly::Reader (src/fast_ply.h:77-262, src/fast_ply.cpp:66-350) -- row f4 of
+ * SURVEY.md section 8, host side only (no device code in this file).
+ *
+ * Accepts what the reference accepts: binary PLY in the CPU's byte order, version 1.0, `vertex` as the first
+ * element with float32 properties x y z nx ny nz radius in any order and at any offset among other scalar
+ * properties; lists in the vertex element are rejected.  A splat's radius is min(radius, maxRadius) * smooth and
+ * its quality 1 / radius^2 (Reader::decode, :334-350).  Errors carry the reference's FormatError texts.
+ */
+#include "common.hpp"
+
+#include <cstdio>
+#include <algorithm>
+#include <fstream>
+#include <memory>
+#include <sstream>
+
+using namespace mlsgpu;
+
+namespace
+{
+
+enum FieldType { INT8, UINT8, INT16, UINT16, INT32, UINT32, FLOAT32, FLOAT64, BAD_TYPE };
+
+FieldType parseType(const std::string &t)
+{
+    if (t == "int8" || t == "char") return INT8;
+    if (t == "uint8" || t == "uchar") return UINT8;
+    if (t == "int16") return INT16;
+    if (t == "uint16") return UINT16;
+    if (t == "int32" || t == "int") return INT32;
+    if (t == "uint32" || t == "uint") return UINT32;
+    if (t == "float32" || t == "float") return FLOAT32;
+    if (t == "float64") return FLOAT64;
+    return BAD_TYPE;
+}
+
+uint64_t fieldSize(FieldType f)
+{
+    switch (f)
+    {
+    case INT8: case UINT8: return 1;
+    case INT16: case UINT16: return 2;
+    case INT32: case UINT32: case FLOAT32: return 4;
+    default: return 8;
+    }
+}
+
+enum { X, Y, Z, NX, NY, NZ, RADIUS, NUM_PROPERTIES };
+
+} // namespace
+
+struct mlsgpu_ply_reader
+{
+    std::string path;
+    std::ifstream in;
+    float smooth = 1.0f, maxRadius = 0.0f;
+    uint64_t vertexSize = 0, vertexCount = 0, headerSize = 0;
+    uint64_t offsets[NUM_PROPERTIES] = {0, 0, 0, 0, 0, 0, 0};
+    std::vector<char> buffer;
+};
+
+namespace
+{
+
+int formatError(const mlsgpu_ply_reader &r, const std::string &what)
+{
+    return setError(MLSGPU_ERR_FORMAT, "%s: %s", r.path.c_str(), what.c_str());
+}
+
+/* Reader::readHeader, src/fast_ply.cpp:180-330 */
+int readHeader(mlsgpu_ply_reader &r)
+{
+    static const char *const names[NUM_PROPERTIES] = {"x", "y", "z", "nx", "ny", "nz", "radius"};
+    bool have[NUM_PROPERTIES] = {false, false, false, false, false, false, false};
+    uint64_t elements = 0;
+    bool haveFormat = false;
+    std::string line;
+    auto getLine = [&]() -> bool { return (bool) std::getline(r.in, line); };
+    if (!getLine() || line != "ply")
+        return formatError(r, "PLY signature missing");
+    while (true)
+    {
+        if (!getLine())
+            return formatError(r, "End of file in PLY header");
+        std::istringstream split(line);
+        std::vector<std::string> tokens;
+        for (std::string t; split >> t;)
+            tokens.push_back(t);
+        if (tokens.empty())
+            continue;
+        if (tokens[0] == "end_header")
+            break;
+        if (tokens[0] == "format")
+        {
+            if (tokens.size() != 3)
+                return formatError(r, "Malformed format line");
+            if (tokens[1] == "ascii")
+                return formatError(r, "PLY ASCII format not supported");
+            if (tokens[1] == "binary_big_endian")
+                return formatError(r, "PLY big endian format not supported on this CPU");
+            if (tokens[1] != "binary_little_endian")
+                return formatError(r, "Unknown PLY format " + tokens[1]);
+            if (tokens[2] != "1.0")
+                return formatError(r, "Unknown PLY version " + tokens[2]);
+            haveFormat = true;
+        }
+        else if (tokens[0] == "element")
+        {
+            if (tokens.size() != 3)
+                return formatError(r, "Malformed element line");
+            /* boost::lexical_cast<size_type>: decimal digits only, no overflow */
+            const std::string &c = tokens[2];
+            uint64_t count = 0;
+            bool ok = !c.empty();
+            for (char ch : c)
+            {
+                if (ch < '0' || ch > '9' || count > (UINT64_MAX - (uint64_t) (ch - '0')) / 10)
+                {
+                    ok = false;
+                    break;
+                }
+                count = count * 10 + (uint64_t) (ch - '0');
+            }
+            if (!ok)
+                return formatError(r, "Malformed element line or too many elements");
+            if (elements == 0)
+            {
+                if (tokens[1] != "vertex")
+                    return formatError(r, "First element is not vertex");
+                r.vertexCount = count;
+            }
+            elements++;
+        }
+        else if (tokens[0] == "property")
+        {
+            if (tokens.size() < 3)
+                return formatError(r, "Malformed property line");
+            bool isList = false;
+            FieldType valueType;
+            std::string name;
+            if (tokens[1] == "list")
+            {
+                if (tokens.size() != 5)
+                    return formatError(r, "Malformed property line");
+                isList = true;
+                const FieldType lengthType = parseType(tokens[2]);
+                valueType = parseType(tokens[3]);
+                if (lengthType == BAD_TYPE)
+                    return formatError(r, "Unknown type `" + tokens[2] + "'");
+                if (valueType == BAD_TYPE)
+                    return formatError(r, "Unknown type `" + tokens[3] + "'");
+                if (lengthType == FLOAT32 || lengthType == FLOAT64)
+                    return formatError(r, "List cannot have floating-point count");
+                name = tokens[4];
+            }
+            else
+            {
+                if (tokens.size() != 3)
+                    return formatError(r, "Malformed property line");
+                valueType = parseType(tokens[1]);
+                if (valueType == BAD_TYPE)
+                    return formatError(r, "Unknown type `" + tokens[1] + "'");
+                name = tokens[2];
+            }
+            if (elements == 0)
+                return formatError(r, "Property `" + name + "' appears before any element declaration");
+            if (elements == 1)
+            {
+                if (isList)
+                    return formatError(r, "Lists in a vertex are not supported");
+                for (int i = 0; i < NUM_PROPERTIES; i++)
+                    if (name == names[i])
+                    {
+                        if (have[i])
+                            return formatError(r, "Duplicate property " + name);
+                        if (valueType != FLOAT32)
+                            return formatError(r, "Property " + name + " must be FLOAT32");
+                        have[i] = true;
+                        r.offsets[i] = r.vertexSize;
+                        break;
+                    }
+                r.vertexSize += fieldSize(valueType);
+            }
+        }
+        /* other header lines (comment, obj_info, ...) are skipped, as by the reference's reader */
+    }
+    if (!haveFormat)
+        return formatError(r, "No format line found");
+    if (elements < 1)
+        return formatError(r, "No elements found");
+    for (int i = 0; i < NUM_PROPERTIES; i++)
+        if (!have[i])
+            return formatError(r, std::string("Property ") + names[i] + " not found");
+    r.headerSize = (uint64_t) r.in.tellg();
+    return MLSGPU_OK;
+}
+
+} // namespace
+
+MLSGPU_API int mlsgpu_hip_ply_open(const char *path, float smooth, float maxRadius, mlsgpu_ply_reader **out)
+{
+    REQUIRE(path != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    std::unique_ptr<mlsgpu_ply_reader> r(new mlsgpu_ply_reader);
+    r->path = path;
+    r->smooth = smooth;
+    r->maxRadius = maxRadius;
+    r->in.open(path, std::ios::in | std::ios::binary);
+    if (!r->in)
+        return setError(MLSGPU_ERR_INVALID, "%s: could not open file", path);
+    PROPAGATE(readHeader(*r));
+    /* "File is too small to contain its vertices", src/fast_ply.cpp:352-372 */
+    r->in.seekg(0, std::ios::end);
+    const uint64_t fileSize = (uint64_t) r->in.tellg();
+    if (r->vertexSize != 0 && (fileSize - r->headerSize) / r->vertexSize < r->vertexCount)
+        return setError(MLSGPU_ERR_FORMAT, "%s: File is too small to contain its vertices", path);
+    *out = r.release();
+    return MLSGPU_OK;
+}
+
+MLSGPU_API void mlsgpu_hip_ply_close(mlsgpu_ply_reader *r) { delete r; }
+
+MLSGPU_API uint64_t mlsgpu_hip_ply_size(const mlsgpu_ply_reader *r) { return r ? r->vertexCount : 0; }
+
+MLSGPU_API int mlsgpu_hip_ply_layout(const mlsgpu_ply_reader *r, uint64_t out[10])
+{
+    REQUIRE(r != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    out[0] = r->vertexSize;
+    out[1] = r->vertexCount;
+    out[2] = r->headerSize;
+    for (int i = 0; i < NUM_PROPERTIES; i++)
+        out[3 + i] = r->offsets[i];
+    return MLSGPU_OK;
+}
+
+/* Reader::Handle::read + Reader::decode, src/fast_ply.cpp:334-350, 374-400 */
+MLSGPU_API int mlsgpu_hip_ply_read(mlsgpu_ply_reader *r, uint64_t first, uint64_t count, mlsgpu_splat *out)
+{
+    REQUIRE(r != nullptr && (count == 0 || out != nullptr), MLSGPU_ERR_INVALID);
+    REQUIRE(first <= r->vertexCount && count <= r->vertexCount - first, MLSGPU_ERR_LENGTH);     /* std::out_of_range */
+    const uint64_t batch = 1 << 16;
+    r->buffer.resize((size_t) (std::min(batch, std::max<uint64_t>(count, 1)) * r->vertexSize));
+    for (uint64_t done = 0; done < count; done += batch)
+    {
+        const uint64_t n = std::min(batch, count - done);
+        r->in.clear();
+        r->in.seekg((std::streamoff) (r->headerSize + (first + done) * r->vertexSize));
+        r->in.read(r->buffer.data(), (std::streamsize) (n * r->vertexSize));
+        if ((uint64_t) r->in.gcount() != n * r->vertexSize)
+            return setError(MLSGPU_ERR_FORMAT, "%s: short read", r->path.c_str());
+        for (uint64_t i = 0; i < n; i++)
+        {
+            const char *v = r->buffer.data() + i * r->vertexSize;
+            mlsgpu_splat &s = out[done + i];
+            std::memcpy(&s.position[0], v + r->offsets[X], 4);
+            std::memcpy(&s.position[1], v + r->offsets[Y], 4);
+            std::memcpy(&s.position[2], v + r->offsets[Z], 4);
+            std::memcpy(&s.radius, v + r->offsets[RADIUS], 4);
+            std::memcpy(&s.normal[0], v + r->offsets[NX], 4);
+            std::memcpy(&s.normal[1], v + r->offsets[NY], 4);
+            std::memcpy(&s.normal[2], v + r->offsets[NZ], 4);
+            s.radius = std::min(s.radius, r->maxRadius);
+            s.radius *= r->smooth;
+            s.quality = (float) (1.0 / (s.radius * s.radius));       /* double 1.0 / float product, as the reference */
+        }
+    }
+    return MLSGPU_OK;
+}

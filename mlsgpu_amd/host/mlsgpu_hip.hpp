@@ -487,6 +487,63 @@ private:
 };
 
 /**
+ * MesherBase / OOCMesher (src/mesher.h:203-420) for meshes that stay on the device: functor() gives the
+ * Marching::OutputFunctor that appends a ship-out, write() welds, prunes and writes one PLY per non-empty chunk.
+ * One pass (numPasses() == 1).  The namer maps a chunk id to a file name (TrivialNamer / ChunkNamer, :136-182).
+ */
+class DeviceMesher
+{
+    mlsgpu_mesher *h;
+    const Context *ctx;
+    DeviceMesher(const DeviceMesher &);
+    DeviceMesher &operator=(const DeviceMesher &);
+public:
+    typedef std::function<std::string(std::uint64_t chunkId)> Namer;
+
+    explicit DeviceMesher(const Context &ctx) : h(NULL), ctx(&ctx) { check(mlsgpu_hip_mesher_create(ctx.get(), &h)); }
+    ~DeviceMesher() { mlsgpu_hip_mesher_destroy(h); }
+    unsigned int numPasses() const { return 1; }
+    void setPruneThreshold(double threshold) { check(mlsgpu_hip_mesher_set_prune_threshold(h, threshold)); }
+    void reserve(std::uint64_t vertices, std::uint64_t triangles, std::uint64_t external)
+    {
+        check(mlsgpu_hip_mesher_reserve(h, vertices, triangles, external));
+    }
+    /// The output functor of one chunk for the worker that owns `from` (thread safe across workers).
+    Marching::OutputFunctor functor(const Context &from, std::uint64_t chunkId)
+    {
+        mlsgpu_mesher *mesher = h;
+        mlsgpu_ctx *fromCtx = from.get();
+        return [mesher, fromCtx, chunkId](void *, const DeviceKeyMesh &mesh) { check(mlsgpu_hip_mesher_add(mesher, fromCtx, chunkId, &mesh)); };
+    }
+    /// MesherBase::write: returns the number of files written.
+    std::size_t write(const Namer &namer, const std::vector<std::string> &comments = std::vector<std::string>())
+    {
+        std::uint32_t chunks = 0;
+        check(mlsgpu_hip_mesher_finalize(h, &chunks));
+        std::vector<const char *> cstr;
+        for (const std::string &c : comments)
+            cstr.push_back(c.c_str());
+        std::vector<float> vertices;
+        std::vector<std::uint32_t> triangles;
+        for (std::uint32_t i = 0; i < chunks; i++)
+        {
+            std::uint64_t id, nv, nt;
+            const float *dV;
+            const std::uint32_t *dT;
+            check(mlsgpu_hip_mesher_chunk(h, i, &id, &nv, &nt, &dV, &dT));
+            vertices.resize(3 * nv);
+            triangles.resize(3 * nt);
+            check(mlsgpu_hip_memcpy_d2h(ctx->get(), vertices.data(), dV, vertices.size() * sizeof(float), 0));
+            check(mlsgpu_hip_memcpy_d2h(ctx->get(), triangles.data(), dT, triangles.size() * sizeof(std::uint32_t), 0));
+            check(mlsgpu_hip_write_ply(namer(id).c_str(), vertices.data(), nv, triangles.data(), nt,
+                                       cstr.empty() ? NULL : cstr.data(), (std::uint32_t) cstr.size()));
+        }
+        return chunks;
+    }
+    void getStatistics(std::uint64_t out[8]) const { check(mlsgpu_hip_mesher_stats(h, out)); }
+};
+
+/**
  * Bucket::bucket (src/bucket.h:116-180) for a cloud that is resident on the device, and the device half of
  * BucketLoader (src/bucket_loader.cpp:77-102).  The processor receives the bucket's grid, recursion state and its
  * splat ids (device memory, ascending, valid during the call) where the reference's receives a splat subset.

@@ -1,0 +1,118 @@
+"""FastPly::Reader / Writer over the C-ABI (host code, no GPU needed): the reference's reader and writer tests,
+test/test_fast_ply.cpp:202-535, 576-690."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import mesher_oracle as mo  # noqa: E402
+
+HEAD = "ply\nformat binary_little_endian 1.0\n"
+SEVEN = "".join("property float32 %s\n" % n for n in ("x", "y", "z", "nx", "ny", "nz", "radius"))
+
+
+def reader(tmp_path, content, smooth=1.0, max_radius=float("inf"), payload=256):
+    import mlsgpu_amd as m
+    path = tmp_path / "test_fast_ply.ply"
+    if isinstance(content, str):
+        content = content.encode("ascii") + b"\0" * payload
+    path.write_bytes(content)
+    return m.binding.PlyReader(path, smooth, max_radius)
+
+
+BAD = {   # test/test_fast_ply.cpp:202-401 (the ones the reader's code rejects; `foo` header lines are skipped like comments)
+    "empty": "",
+    "signature": "ply no not really",
+    "format_format": "ply\nformat binary_little_endiannotreally 1.0\nelement vertex 1\nend_header\n",
+    "format_version": "ply\nformat binary_little_endian 1.01\nelement vertex 1\nend_header\n",
+    "format_length": "ply\nformat\nelement vertex 1\nend_header\n",
+    "element_count": HEAD + "element vertex -1\nend_header\n",
+    "element_overflow": HEAD + "element vertex 123456789012345678901234567890\nend_header\n",
+    "element_hex": HEAD + "element vertex 0xDEADBEEF\nend_header\n",
+    "element_length": HEAD + "element\nend_header\n",
+    "property_length": HEAD + "element vertex 0\nproperty int int int x\nend_header\n",
+    "property_list_length": HEAD + "element vertex 0\nproperty list int x\nend_header\n",
+    "property_list_type": HEAD + "element vertex 0\nproperty list float int x\nend_header\n",
+    "property_type": HEAD + "element vertex 0\nproperty int1 x\nend_header\n",
+    "property_line": HEAD + "element vertex 0\nproperty int\nend_header\n",
+    "early_property": HEAD + "property int x\nelement vertex 0\nend_header\n",
+    "duplicate_property": HEAD + "element vertex 0\nproperty float x\nproperty float x\nend_header\n",
+    "missing_end": HEAD + "element vertex 0\nproperty int x\n",
+    "list_in_vertex": HEAD + "element vertex 5\n" + SEVEN + "property list uint8 int32 foo\nend_header\n",
+    "not_float": HEAD + "element vertex 5\n" + SEVEN.replace("float32 radius", "int32 radius") + "end_header\n",
+    "ascii": "ply\nformat ascii 1.0\nelement vertex 5\n" + SEVEN + "end_header\n",
+    "format_missing": "ply\nelement vertex 5\n" + SEVEN + "end_header\n",
+    "missing_property": HEAD + "element vertex 5\n" + SEVEN.replace("property float32 nz\n", "") + "end_header\n",
+}
+
+
+@pytest.mark.parametrize("name", sorted(BAD))
+def test_rejects(tmp_path, name):
+    import mlsgpu_amd as m
+    with pytest.raises(m.FormatError):
+        reader(tmp_path, BAD[name])
+
+
+def test_short_file(tmp_path):
+    import mlsgpu_amd as m
+    head = HEAD + "element vertex 5\n" + SEVEN + "property uint8 foo\nend_header\n"
+    with pytest.raises(m.FormatError):
+        reader(tmp_path, head, payload=29 * 5 - 1)            # test/test_fast_ply.cpp:310-330
+    assert len(reader(tmp_path, head, payload=29 * 5)) == 5
+
+
+def test_header_layout(tmp_path):
+    # test/test_fast_ply.cpp:403-432
+    head = HEAD + "element vertex 5\nproperty float32 z\nproperty float32 y\nproperty float32 x\nproperty int16 bar\n" \
+        "property float32 nx\nproperty float32 ny\nproperty float32 nz\nproperty float32 radius\nproperty uint8 foo\nend_header\n"
+    lay = reader(tmp_path, head).layout()
+    assert lay == dict(vertex_size=31, vertex_count=5, header_size=len(head), x=8, y=4, z=0, nx=14, ny=18, nz=22, radius=26)
+
+
+def setup_read(n):
+    # test/test_fast_ply.cpp:434-458
+    data = (np.arange(n, dtype=np.float32)[:, None] * 100.0 + np.arange(7, dtype=np.float32)[None, :]).astype("<f4")
+    head = HEAD + "element vertex %d\n" % n + "".join("property float32 %s\n" % p for p in ("y", "z", "x", "nx", "ny", "nz", "radius")) \
+        + "end_header\n"
+    return head.encode("ascii") + data.tobytes()
+
+
+def test_read(tmp_path):
+    # test/test_fast_ply.cpp:460-492: smooth 2, maxRadius 250
+    r = reader(tmp_path, setup_read(5), 2.0, 250.0)
+    out = r.read(1, 3)
+    for k, s in enumerate(out):
+        pos = k + 1
+        assert tuple(s["position"]) == (pos * 100.0 + 2.0, pos * 100.0 + 0.0, pos * 100.0 + 1.0)
+        assert tuple(s["normal"]) == (pos * 100.0 + 3.0, pos * 100.0 + 4.0, pos * 100.0 + 5.0)
+        radius = np.float32(2.0) * np.float32(min(250.0, pos * 100.0 + 6.0))
+        assert s["radius"] == radius
+        assert s["quality"] == np.float32(1.0 / (np.float64(radius) * np.float64(radius)))
+    assert len(r.read(2, 0)) == 0                              # testReadZero
+    import mlsgpu_amd as m
+    with pytest.raises(m.LengthError):
+        r.read(1, 6)                                           # std::out_of_range in the reference
+
+
+def test_comments_and_other_elements_are_skipped(tmp_path):
+    head = "ply\nformat binary_little_endian 1.0\ncomment made by a scanner\nobj_info x\nelement vertex 2\n" + SEVEN \
+        + "element face 0\nproperty list uint8 uint32 vertex_indices\nend_header\n"
+    data = np.arange(14, dtype="<f4") + 1
+    out = reader(tmp_path, head.encode("ascii") + data.tobytes()).read()
+    assert tuple(out[1]["position"]) == (8.0, 9.0, 10.0) and out[1]["radius"] == 14.0
+
+
+def test_writer_matches_the_reference_layout(tmp_path):
+    # FastPly::Writer, test/test_fast_ply.cpp:582-646: header text, padding, 12-byte vertices, 13-byte faces
+    import mlsgpu_amd as m
+    v = np.array([[1, 2, 3], [4, 5, 6], [7, 8, 9], [10, 11, 12], [13, 14, 15]], np.float32)
+    t = np.array([[0, 1, 2], [0, 2, 3], [3, 2, 4]], np.uint32)
+    path = tmp_path / "w.ply"
+    m.binding.write_ply(path, v, t, ["Example comment", "Another"])
+    raw = path.read_bytes()
+    assert raw == mo.ply_bytes(v, t, ["Example comment", "Another"])
+    head = raw[:raw.index(b"end_header\n") + 11]
+    assert len(head) % 4 == 0 and b"comment Example comment\ncomment Another\nelement vertex 5\n" in head
+    assert len(raw) == len(head) + 5 * 12 + 3 * 13
