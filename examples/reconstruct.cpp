@@ -1,0 +1,120 @@
+/*
+ * PLY of splats in, PLY mesh out, everything between on the device: the in-core shape of the reference's main
+ * pipeline (src/mlsgpu_core.cpp:560-760: load -> bounding grid -> Bucket::bucket -> BucketLoader -> device worker ->
+ * mesher -> FastPly::Writer) with this repository's pieces:
+ *   FastPly::Reader      mlsgpu_hip_ply_*            (host)
+ *   bounding grid        mlsgpu_hip_bounding_grid    (device reduction)
+ *   Bucket::bucket       mlsgpu::hip::Bucket::bucket (device)
+ *   BucketLoader         mlsgpu::hip::Bucket::load   (device gather + transform)
+ *   DeviceWorkerGroup    mlsgpu_hip_worker_*         (octree, MLS, marching, scale/bias)
+ *   OOCMesher            mlsgpu::hip::DeviceMesher   (device weld / components / prune), FastPly::Writer on the host
+ *
+ * usage: reconstruct <in.ply> <out.ply> <spacing> [smooth=4] [levels=6] [subsampling=3] [prune=0.02] [maxSplats=2097152]
+ * (defaults as src/mlsgpu_core.cpp:86-135: --fit-smooth 4, --levels 6, --subsampling 3, --fit-prune 0.02)
+ */
+#include <cstdio>
+#include <cstdlib>
+#include <iostream>
+#include <limits>
+#include <vector>
+
+#include "../mlsgpu_amd/host/mlsgpu_hip.hpp"
+
+using namespace mlsgpu::hip;
+
+int main(int argc, char **argv)
+{
+    if (argc < 4)
+    {
+        std::cerr << "usage: reconstruct in.ply out.ply spacing [smooth] [levels] [subsampling] [prune] [maxSplats]\n";
+        return 2;
+    }
+    const float spacing = (float) atof(argv[3]);
+    const float smooth = argc > 4 ? (float) atof(argv[4]) : 4.0f;
+    const unsigned levels = argc > 5 ? (unsigned) atoi(argv[5]) : 6;
+    const unsigned subsampling = argc > 6 ? (unsigned) atoi(argv[6]) : 3;
+    const double prune = argc > 7 ? atof(argv[7]) : 0.02;
+    const std::uint64_t maxSplats = argc > 8 ? strtoull(argv[8], NULL, 10) : 2097152;
+    const std::uint32_t maxCells = (1u << (levels + subsampling - 1)) - 1;        // src/mlsgpu_core.cpp:672-673
+    const std::uint32_t microCells = std::min<std::uint32_t>(63, maxCells);          // --leaf-cells 63, :113,674
+    try
+    {
+        mlsgpu_ply_reader *reader = NULL;
+        check(mlsgpu_hip_ply_open(argv[1], smooth, std::numeric_limits<float>::infinity(), &reader));
+        std::vector<Splat> host(mlsgpu_hip_ply_size(reader));
+        check(mlsgpu_hip_ply_read(reader, 0, host.size(), host.data()));
+        mlsgpu_hip_ply_close(reader);
+        if (host.empty())
+        {
+            std::cerr << "no splats\n";
+            return 1;
+        }
+
+        Context ctx(0);
+        Buffer<Splat> cloud(ctx, host.size());
+        cloud.write(host.data(), host.size());
+        Bucket::Grid grid;
+        check(mlsgpu_hip_bounding_grid(ctx.get(), cloud.get(), host.size(), spacing, microCells, &grid));
+
+        mlsgpu_worker_config cfg;
+        std::memset(&cfg, 0, sizeof(cfg));
+        cfg.maxBucketSplats = maxSplats;
+        cfg.maxCells = maxCells;
+        cfg.levels = levels;
+        cfg.subsampling = subsampling;
+        cfg.boundaryLimit = 1.0f;
+        cfg.shape = MLSGPU_SHAPE_SPHERE;
+        cfg.gridSpacing = spacing;                             // ScaleBiasFilter: vertex * spacing + grid.getVertex(0,0,0)
+        for (int i = 0; i < 3; i++)
+            cfg.gridOrigin[i] = grid.reference[i] + spacing * (float) grid.extents[2 * i];
+        mlsgpu_worker *worker = NULL;
+        check(mlsgpu_hip_worker_create(ctx.get(), &cfg, &worker));
+
+        Buffer<Splat> staged(ctx, maxSplats);
+        DeviceMesher mesher(ctx);
+        mesher.setPruneThreshold(prune);
+        std::size_t bins = 0;
+        struct Sink
+        {
+            DeviceMesher *mesher;
+            const Context *ctx;
+            static int call(void *user, void *, const mlsgpu_mesh *mesh)
+            {
+                Sink *self = static_cast<Sink *>(user);
+                try
+                {
+                    self->mesher->functor(*self->ctx, 0)(NULL, *static_cast<const DeviceKeyMesh *>(mesh));
+                    return 0;
+                }
+                catch (std::exception &e)
+                {
+                    std::cerr << e.what() << "\n";
+                    return 1;
+                }
+            }
+        } sink{&mesher, &ctx};
+        Bucket::bucket(ctx, cloud, host.size(), grid, maxSplats, maxCells, 0, microCells, std::uint64_t(1) << 30,
+                       [&](const Bucket::Bin &bin)
+        {
+            const BucketGrid sub = Bucket::load(ctx, cloud, bin, grid, staged);
+            check(mlsgpu_hip_worker_process(worker, staged.get(), 0, bin.numSplats, sub.low, sub.numVertices, &Sink::call, &sink));
+            bins++;
+        });
+        const std::string outName = argv[2];
+        const std::size_t files = mesher.write([&](std::uint64_t) { return outName; },
+                                               std::vector<std::string>(1, "mlsgpu-hip example: reconstruct"));
+        std::uint64_t st[8];
+        mesher.getStatistics(st);
+        std::printf("splats %zu grid %d..%d %d..%d %d..%d bins %zu files %zu vertices %llu triangles %llu components %llu kept %llu\n",
+                    host.size(), grid.extents[0], grid.extents[1], grid.extents[2], grid.extents[3], grid.extents[4],
+                    grid.extents[5], bins, files, (unsigned long long) st[4], (unsigned long long) st[5],
+                    (unsigned long long) st[2], (unsigned long long) st[3]);
+        mlsgpu_hip_worker_destroy(worker);
+    }
+    catch (std::exception &e)
+    {
+        std::cerr << "error: " << e.what() << "\n";
+        return 1;
+    }
+    return 0;
+}

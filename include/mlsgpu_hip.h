@@ -314,6 +314,11 @@ typedef int (*mlsgpu_bucket_fn)(void *user, mlsgpu_ctx *ctx, const mlsgpu_bucket
  * (*cellSplats = how many).  The octree of counters of one level is dense here: at most 2^24 nodes. */
 int mlsgpu_hip_bucket(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, uint64_t numSplats, const mlsgpu_grid *region,
                       const mlsgpu_bucket_params *params, mlsgpu_bucket_fn fn, void *user, uint64_t *cellSplats);
+/* FastBlobSet::makeBoundingGrid (src/splat_set_impl.h:770-811): the grid the reference reconstructs on -- reference 0,
+ * extents floor(min(p - r) / spacing) rounded down to a multiple of bucketSize, and ceil(max(p + r) / spacing) -- from a
+ * min / max reduction over the finite splats on the device. */
+int mlsgpu_hip_bounding_grid(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, uint64_t numSplats, float spacing,
+                             uint32_t bucketSize, mlsgpu_grid *out);
 /* BucketLoader (src/bucket_loader.cpp:77-85, Grid::worldToVertex src/grid.cpp:99-106) on the device:
  * dOut[i] = splat dIds[i] (or i if dIds is NULL) in the vertex coordinates of fullGrid:
  * (position - reference) / spacing - fullGrid.extents[first], radius / spacing.  dOut is what

@@ -201,6 +201,7 @@ def lib():
     sig("mlsgpu_hip_write_ply", C.c_int, C.c_char_p, vp, u64, vp, u64, vp, u32)
     sig("mlsgpu_hip_bucket", C.c_int, vp, vp, u64, P(GridStruct), P(BucketParams), BUCKET_FN, vp, P(u64))
     sig("mlsgpu_hip_bucket_load", C.c_int, vp, vp, vp, u64, P(GridStruct), vp)
+    sig("mlsgpu_hip_bounding_grid", C.c_int, vp, vp, u64, f32, u32, P(GridStruct))
     sig("mlsgpu_hip_test_make_code", C.c_int, vp, C.c_int, C.c_int, C.c_int, P(u32))
     sig("mlsgpu_hip_test_level_shift", C.c_int, vp, vp, vp, P(i32))
     sig("mlsgpu_hip_test_point_box_dist2", C.c_int, vp, vp, vp, vp, P(f32))
@@ -905,6 +906,13 @@ def bucket_cloud(ctx, d_splats, num_splats, reference, spacing, extents, max_spl
         raise e
     check(rc)
     return leaves
+
+
+def bounding_grid(ctx, d_splats, num_splats, spacing, bucket_size):
+    """FastBlobSet::makeBoundingGrid (src/splat_set_impl.h:770-811): (reference, spacing, extents)."""
+    g = GridStruct()
+    check(lib().mlsgpu_hip_bounding_grid(ctx.h, d_splats.ptr, num_splats, spacing, bucket_size, C.byref(g)))
+    return tuple(g.reference), float(g.spacing), tuple(int(v) for v in g.extents)
 
 
 def bucket_load(ctx, d_splats, d_ids_ptr, num_splats, reference, spacing, extents, d_out):

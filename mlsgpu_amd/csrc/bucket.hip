@@ -198,6 +198,50 @@ __global__ void bucketLoadKernel(const mlsgpu_splat *splats, const uint32_t *ids
     out[i] = s;
 }
 
+/* detail::Bbox of the finite splats (src/splat_set_impl.h:495-512): per-workgroup min of position - radius and max of
+ * position + radius; the host folds the partial results (min / max are exact in any order) */
+__global__ __launch_bounds__(256) void bboxKernel(const mlsgpu_splat *splats, uint64_t n, float *partial)
+{
+    __shared__ float sMin[3][4], sMax[3][4];
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+    {
+        const mlsgpu_splat s = splats[i];
+        if (!(isfinite(s.position[0]) && isfinite(s.position[1]) && isfinite(s.position[2]) && isfinite(s.radius)
+              && isfinite(s.normal[0]) && isfinite(s.normal[1]) && isfinite(s.normal[2]) && isfinite(s.quality)))
+            continue;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+        {
+            lo[a] = fminf(lo[a], s.position[a] - s.radius);
+            hi[a] = fmaxf(hi[a], s.position[a] + s.radius);
+        }
+    }
+    const uint32_t wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+    {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1)
+        {
+            lo[a] = fminf(lo[a], __shfl_xor(lo[a], d, 64));
+            hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], d, 64));
+        }
+        if (laneId() == 0)
+        {
+            sMin[a][wave] = lo[a];
+            sMax[a][wave] = hi[a];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3)
+    {
+        const int a = threadIdx.x;
+        partial[blockIdx.x * 6 + a] = fminf(fminf(sMin[a][0], sMin[a][1]), fminf(sMin[a][2], sMin[a][3]));
+        partial[blockIdx.x * 6 + 3 + a] = fmaxf(fmaxf(sMax[a][0], sMax[a][1]), fmaxf(sMax[a][2], sMax[a][3]));
+    }
+}
+
 uint32_t bitsForCount(uint32_t count)
 {
     uint32_t b = 1;
@@ -560,6 +604,47 @@ MLSGPU_API int mlsgpu_hip_bucket(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, u
         *cellSplats = b.cellSplats;
     hipStreamSynchronize(ctx->stream);
     return rc;
+}
+
+/* FastBlobSet::makeBoundingGrid, src/splat_set_impl.h:770-811 */
+MLSGPU_API int mlsgpu_hip_bounding_grid(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, uint64_t numSplats, float spacing,
+                                        uint32_t bucketSize, mlsgpu_grid *out)
+{
+    REQUIRE(ctx != nullptr && out != nullptr && (numSplats == 0 || dSplats != nullptr), MLSGPU_ERR_INVALID);
+    REQUIRE(spacing > 0.0f && bucketSize >= 1, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const uint32_t blocks = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(divUp(numSplats, 256), 2048));
+    float *dPartial = nullptr;
+    HIP_CHECK(hipMalloc((void **) &dPartial, (size_t) blocks * 6 * sizeof(float)));
+    std::vector<float> partial((size_t) blocks * 6);
+    hipLaunchKernelGGL(bboxKernel, dim3(blocks), dim3(256), 0, ctx->stream, dSplats, numSplats, dPartial);
+    hipError_t e = hipMemcpyAsync(partial.data(), dPartial, partial.size() * sizeof(float), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess)
+        e = hipStreamSynchronize(ctx->stream);
+    hipFree(dPartial);
+    if (e != hipSuccess)
+        return setError(MLSGPU_ERR_HIP, "bounding grid: %s", hipGetErrorString(e));
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (uint32_t b = 0; b < blocks; b++)
+        for (int a = 0; a < 3; a++)
+        {
+            lo[a] = std::min(lo[a], partial[(size_t) b * 6 + a]);
+            hi[a] = std::max(hi[a], partial[(size_t) b * 6 + 3 + a]);
+        }
+    if (lo[0] > hi[0])
+        return setError(MLSGPU_ERR_INVALID, "Must be at least one splat");        /* std::runtime_error, :773-774 */
+    for (int a = 0; a < 3; a++)
+    {
+        out->reference[a] = 0.0f;
+        int64_t l = (int64_t) std::floor(lo[a] / spacing);
+        const int64_t h = (int64_t) std::ceil(hi[a] / spacing);
+        const int64_t b = (int64_t) bucketSize;
+        l = (l >= 0 ? l / b : -((-l + b - 1) / b)) * b;       /* the lower extent is a multiple of the bucket size */
+        out->extents[2 * a] = (int32_t) l;
+        out->extents[2 * a + 1] = (int32_t) h;
+    }
+    out->spacing = spacing;
+    return MLSGPU_OK;
 }
 
 MLSGPU_API int mlsgpu_hip_bucket_load(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, const uint32_t *dIds, uint64_t numSplats,

@@ -24,6 +24,7 @@ def test_host_header_compiles_and_links(tmp_path):
     exe = build_example(tmp_path)
     assert os.path.exists(exe)
     assert os.path.exists(build_example(tmp_path, "host_partition"))
+    assert os.path.exists(build_example(tmp_path, "reconstruct"))
 
 
 @pytest.mark.gpu
@@ -92,3 +93,71 @@ def test_cpp_bucket_matches_oracle(tmp_path):
         for line, e in zip(out, exp):
             want = list(e["extents"]) + list(e["chunk"]) + [e["depth"], len(e["ids"]), int(e["ids"].sum())]
             assert [int(v) for v in line.split()] == want
+
+
+def parse_ply_mesh(path):
+    raw = open(path, "rb").read()
+    head_end = raw.index(b"end_header\n") + 11
+    head = raw[:head_end].decode("ascii").split("\n")
+    nv = int([l for l in head if l.startswith("element vertex")][0].split()[2])
+    nt = int([l for l in head if l.startswith("element face")][0].split()[2])
+    v = np.frombuffer(raw, "<f4", 3 * nv, head_end).reshape(nv, 3)
+    faces = np.frombuffer(raw, np.dtype([("n", np.uint8), ("i", "<u4", 3)]), nt, head_end + 12 * nv)
+    assert (faces["n"] == 3).all()
+    return v, faces["i"]
+
+
+@pytest.mark.gpu
+def test_reconstruct_ply_to_ply(tmp_path):
+    """examples/reconstruct: a PLY of splats in, a welded and pruned PLY mesh out; the result equals the oracle chain
+    (bucketing oracle -> per-bucket oracle -> mesh-sink oracle) up to vertex / triangle order."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mesher_oracle as mo
+    import oracle_binding as ob
+    from mlsgpu_amd import synth
+    exe = build_example(tmp_path, "reconstruct")
+    cloud = synth.shells_cloud(60_000, 63.0, 16.0, 1.5, 2.5, seed=5)          # grid units
+    spacing = np.float32(0.5)
+    world = cloud.copy()
+    world["position"] = world["position"] * spacing + np.float32(3.0)
+    world["radius"] = world["radius"] * spacing
+    rows = np.zeros(len(world), np.dtype([("p", "<f4", 3), ("n", "<f4", 3), ("r", "<f4")]))
+    rows["p"], rows["n"], rows["r"] = world["position"], world["normal"], world["radius"]
+    head = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % len(rows) \
+        + "".join("property float32 %s\n" % n for n in ("x", "y", "z", "nx", "ny", "nz", "radius")) + "end_header\n"
+    (tmp_path / "in.ply").write_bytes(head.encode("ascii") + rows.tobytes())
+    smooth, levels, subsampling, prune, max_splats = 1.5, 4, 3, 0.02, 30000
+    out = subprocess.check_output([exe, str(tmp_path / "in.ply"), str(tmp_path / "out.ply"), repr(float(spacing)), str(smooth),
+                                   str(levels), str(subsampling), str(prune), str(max_splats)], timeout=600).decode()
+    assert "files 1" in out, out
+    got_v, got_t = parse_ply_mesh(tmp_path / "out.ply")
+
+    # the same chain with the oracles
+    splats = world.copy()
+    splats["radius"] = np.minimum(splats["radius"], np.float32(np.inf)) * np.float32(smooth)
+    splats["quality"] = (1.0 / (splats["radius"].astype(np.float64) ** 2)).astype(np.float32)
+    max_cells = (1 << (levels + subsampling - 1)) - 1
+    micro = min(63, max_cells)
+    lo = np.floor((splats["position"] - splats["radius"][:, None]).min(axis=0) / spacing).astype(np.int64) // micro * micro
+    hi = np.ceil((splats["position"] + splats["radius"][:, None]).max(axis=0) / spacing).astype(np.int64)
+    extents = (lo[0], hi[0], lo[1], hi[1], lo[2], hi[2])
+    leaves = ob.bucket_partition(splats, (0, 0, 0), float(spacing), extents, max_splats, max_cells, 0, micro, 1 << 30)
+    meshes = []
+    for leaf in leaves:
+        low = [leaf["extents"][2 * i] - extents[2 * i] for i in range(3)]
+        nv = [leaf["extents"][2 * i + 1] - leaf["extents"][2 * i] + 1 for i in range(3)]
+        local = splats[leaf["ids"].astype(np.int64)].copy()
+        inv = np.float32(1.0) / spacing
+        local["position"] = (local["position"] - np.float32(0.0)) * inv - np.array(extents[0::2], np.float32)
+        local["radius"] = local["radius"] * inv
+        batches, _ = ob.bucket(local, 0, len(local), nv, low, levels=levels, subsampling=subsampling, max_cells=max_cells)
+        for g in batches:
+            origin = np.float32(0.0) + spacing * np.array(extents[0::2], np.float32)
+            verts = np.ascontiguousarray(g["vertices"], np.float32).copy()
+            ob.lib().orc_scale_bias(ob._p(verts), len(verts), float(spacing), float(origin[0]), float(origin[1]), float(origin[2]))
+            meshes.append(dict(chunk=0, vertices=verts, num_internal=g["num_internal"],
+                               keys=g["keys"][g["num_internal"]:], triangles=g["triangles"]))
+    exp, stats = mo.mesh_sink(meshes, prune)
+    assert len(exp) == 1 and len(got_t) == stats["kept_triangles"] > 10000
+    assert mo.isomorphic(got_v, got_t, exp[0][1], exp[0][2])
