@@ -136,7 +136,8 @@ def test_reconstruct_ply_to_ply(tmp_path):
     # the same chain with the oracles
     splats = world.copy()
     splats["radius"] = np.minimum(splats["radius"], np.float32(np.inf)) * np.float32(smooth)
-    splats["quality"] = (1.0 / (splats["radius"].astype(np.float64) ** 2)).astype(np.float32)
+    # Reader::decode: 1.0 / (radius * radius) with the product in float and the division in double
+    splats["quality"] = (1.0 / (splats["radius"] * splats["radius"]).astype(np.float64)).astype(np.float32)
     max_cells = (1 << (levels + subsampling - 1)) - 1
     micro = min(63, max_cells)
     lo = np.floor((splats["position"] - splats["radius"][:, None]).min(axis=0) / spacing).astype(np.int64) // micro * micro

@@ -89,7 +89,7 @@ def test_read(tmp_path):
         assert tuple(s["normal"]) == (pos * 100.0 + 3.0, pos * 100.0 + 4.0, pos * 100.0 + 5.0)
         radius = np.float32(2.0) * np.float32(min(250.0, pos * 100.0 + 6.0))
         assert s["radius"] == radius
-        assert s["quality"] == np.float32(1.0 / (np.float64(radius) * np.float64(radius)))
+        assert s["quality"] == np.float32(1.0 / np.float64(radius * radius))       # float product, double division
     assert len(r.read(2, 0)) == 0                              # testReadZero
     import mlsgpu_amd as m
     with pytest.raises(m.LengthError):
