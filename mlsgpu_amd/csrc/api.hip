@@ -132,6 +132,7 @@ MLSGPU_API void mlsgpu_hip_ctx_destroy(mlsgpu_ctx *ctx)
         return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    ctx->scratchCache.clear();
     for (const PendingTiming &p : ctx->pending)
     {
         hipEventDestroy(p.start);

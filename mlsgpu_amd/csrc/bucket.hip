@@ -313,7 +313,8 @@ struct Bucketer
     mlsgpu_bucket_fn fn;
     void *user;
     uint64_t cellSplats = 0;
-    std::vector<std::unique_ptr<DepthBuffers> > depthBufs;
+    typedef std::vector<std::unique_ptr<DepthBuffers> > DepthList;
+    DepthList *depthList = nullptr;     /* lives in the context's scratch cache: allocating ~1 GB per call costs more than the kernels */
 
     int ensure(uint32_t **p, size_t elems)
     {
@@ -391,9 +392,9 @@ int Bucketer::recurse(const uint32_t *dIds, uint64_t n, bool isSubset, const Gri
     REQUIRE(macroLevels <= MAX_LEVELS, MLSGPU_ERR_LENGTH);
     const uint32_t chunkRatio = chunkCells / microSize;
 
-    while (depthBufs.size() <= depth)
-        depthBufs.emplace_back(new DepthBuffers);
-    DepthBuffers &B = *depthBufs[depth];
+    while (depthList->size() <= depth)
+        depthList->emplace_back(new DepthBuffers);
+    DepthBuffers &B = *(*depthList)[depth];
     if (B.total == nullptr)
         PROPAGATE(ensure(&B.total, 2));
 
@@ -583,7 +584,11 @@ MLSGPU_API int mlsgpu_hip_bucket(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, u
     for (int i = 0; i < 3; i++)
         REQUIRE(region->extents[2 * i] < region->extents[2 * i + 1], MLSGPU_ERR_INVALID);   /* at least one cell per axis */
     HIP_CHECK(hipSetDevice(ctx->device));
+    std::shared_ptr<void> &cached = ctx->scratchCache["bucket"];
+    if (!cached)
+        cached = std::shared_ptr<void>(new Bucketer::DepthList, [](void *p) { delete static_cast<Bucketer::DepthList *>(p); });
     Bucketer b;
+    b.depthList = static_cast<Bucketer::DepthList *>(cached.get());
     b.ctx = ctx;
     b.dSplats = dSplats;
     b.numSplats = numSplats;

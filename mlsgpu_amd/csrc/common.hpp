@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -74,6 +75,9 @@ struct mlsgpu_ctx
     std::vector<mlsgpu::Stat> stats;
     std::vector<mlsgpu::PendingTiming> pending;
     std::vector<hipEvent_t> eventPool;
+    /* device scratch that entry points without an object of their own (mlsgpu_hip_bucket) keep between calls;
+     * released with the context */
+    std::map<std::string, std::shared_ptr<void> > scratchCache;
 
     int statId(const char *name);
     int beginTiming(int id);          /* returns index into pending or -1 */
