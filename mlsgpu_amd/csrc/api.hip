@@ -5,7 +5,6 @@
  * SplatTreeCL, one MlsFunctor, one Marching and a ScaleBiasFilter in front of the output functor.
  */
 #include "common.hpp"
-#include "primitives.hpp"
 
 #include <algorithm>
 #include <atomic>
@@ -153,7 +152,7 @@ MLSGPU_API int mlsgpu_hip_ctx_synchronize(mlsgpu_ctx *ctx)
     REQUIRE(ctx != nullptr, MLSGPU_ERR_INVALID);
     HIP_CHECK(hipSetDevice(ctx->device));
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    return scanCheck(ctx);
+    return MLSGPU_OK;
 }
 
 MLSGPU_API int mlsgpu_hip_malloc(mlsgpu_ctx *ctx, size_t bytes, void **dptr)

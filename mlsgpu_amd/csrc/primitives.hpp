@@ -128,15 +128,32 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanTileSumsKernel(T *tileSums, ui
         *total = carry;
 }
 
-/* out(i, exclusivePrefix(i), in(i)) for every i < n; tileSums already hold each tile's exclusive prefix */
-template<typename T, typename In, typename Out>
-__global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(In in, Out out, const T *tileSums, uint64_t n, const uint32_t *nDev)
+/* out(i, exclusivePrefix(i), in(i)) for every i < n.
+ * FUSED = false: tileSums already hold each tile's exclusive prefix (scanTileSumsKernel ran).
+ * FUSED = true:  tileSums are the raw tile sums; every workgroup adds up its predecessors' itself (at most
+ *                SCAN_FUSED_MAX_TILES L2-resident values), which saves the single-workgroup launch in between;
+ *                the last workgroup writes the grand total. */
+template<typename T, typename In, typename Out, bool FUSED>
+__global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(In in, Out out, const T *tileSums, uint64_t n, const uint32_t *nDev,
+                                                              T seed, T *total)
 {
     if (nDev != nullptr && *nDev < n)
         n = *nDev;
     __shared__ T waveTotals[PRIM_WAVES];
+    __shared__ T wavePrefix[PRIM_WAVES];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t base = (uint64_t) blockIdx.x * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
+    /* the tile holding the last element (tile 0 of an empty scan) reports the total; later tiles are empty */
+    const uint32_t lastTile = n > 0 ? (uint32_t) ((n - 1) / PRIM_TILE) : 0u;
+    if (FUSED && blockIdx.x > lastTile)
+        return;
+    T before = zeroOf(T());
+    if (FUSED)
+    {
+        /* the predecessors' sums are requested first: their latency hides behind the tile's own loads */
+        for (uint32_t t = threadIdx.x; t < blockIdx.x; t += PRIM_BLOCK)
+            before = before + tileSums[t];
+    }
     T vals[PRIM_ITEMS];
     T excl[PRIM_ITEMS];
     T running = zeroOf(T());        /* wave-uniform: sum of the previous rounds of this wave */
@@ -149,164 +166,38 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(In in, Out out, co
         excl[j] = running + waveShiftUpT(incl);
         running = running + readLaneT(incl, 63);
     }
+    if (FUSED)
+    {
+        const T inclBefore = waveInclusiveScanT(before);
+        if (lane == 63)
+            wavePrefix[wave] = inclBefore;
+    }
     if (lane == 0)
         waveTotals[wave] = running;
     __syncthreads();
-    T before = tileSums[blockIdx.x];
+    if (FUSED)
+    {
+        before = seed;
+#pragma unroll
+        for (int w = 0; w < PRIM_WAVES; w++)
+            before = before + wavePrefix[w];
+        if (total != nullptr && blockIdx.x == lastTile && threadIdx.x == 0)
+        {
+            T all = before;
+#pragma unroll
+            for (int w = 0; w < PRIM_WAVES; w++)
+                all = all + waveTotals[w];
+            *total = all;
+        }
+    }
+    else
+        before = tileSums[blockIdx.x];
     for (uint32_t w = 0; w < wave; w++)
         before = before + waveTotals[w];
 #pragma unroll
     for (int j = 0; j < PRIM_ITEMS; j++)
     {
         uint64_t i = base + (uint64_t) j * 64;
-        if (i < n)
-            out(i, before + excl[j], vals[j]);
-    }
-}
-
-/* ------------------------------------------------------------------ single-pass scan (decoupled look-back)
- *
- * One launch, the input read once.  A workgroup takes the next tile by ticket (so every predecessor is already
- * running), scans it locally, PUBLISHES the tile's aggregate, adds up its predecessors' aggregates until it meets one
- * that has published an inclusive prefix, then publishes its own prefix (Merrill & Garland, "Single-pass parallel
- * prefix scan with decoupled look-back").  A descriptor is ONE 64-bit word -- value in the low half, (epoch << 2 |
- * state) in the high half -- written and read with relaxed agent-scope atomics, so no fences are needed and words of
- * an earlier scan (other epoch) read as "not yet published" without clearing the buffer.  A U3 scan is three
- * independent chains over the same tiles.  Waiting is bounded: a workgroup that gives up sets *failed (checked at the
- * context's next synchronisation) instead of hanging the GPU.
- */
-enum { SCAN_INVALID = 0, SCAN_AGGREGATE = 1, SCAN_PREFIX = 2 };
-
-__device__ __forceinline__ int scanComponents(uint32_t) { return 1; }
-__device__ __forceinline__ int scanComponents(U3) { return 3; }
-__device__ __forceinline__ uint32_t scanGet(uint32_t v, int) { return v; }
-__device__ __forceinline__ uint32_t scanGet(const U3 &v, int c) { return c == 0 ? v.a : (c == 1 ? v.b : v.c); }
-__device__ __forceinline__ void scanSet(uint32_t &v, int, uint32_t x) { v = x; }
-__device__ __forceinline__ void scanSet(U3 &v, int c, uint32_t x) { if (c == 0) v.a = x; else if (c == 1) v.b = x; else v.c = x; }
-
-__device__ __forceinline__ void scanPublish(uint64_t *desc, uint32_t epoch, uint32_t state, uint32_t value)
-{
-    __hip_atomic_store(desc, ((uint64_t) ((epoch << 2) | state) << 32) | value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-/* exclusive prefix of `tile` for one component chain; called by the whole of wave 0 */
-__device__ __forceinline__ uint32_t scanLookBack(const uint64_t *desc, uint32_t stride, uint32_t tile, uint32_t epoch, uint32_t *failed)
-{
-    const uint32_t lane = laneId();
-    uint32_t acc = 0;
-    int64_t first = (int64_t) tile - 1;         /* nearest predecessor looked at by lane 0 */
-    uint32_t spins = 0;
-    while (true)
-    {
-        const int64_t pred = first - lane;
-        uint32_t state = SCAN_PREFIX, value = 0;    /* lanes before tile 0 read as an empty prefix */
-        if (pred >= 0)
-        {
-            const uint64_t d = __hip_atomic_load(&desc[(uint64_t) pred * stride], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t tag = (uint32_t) (d >> 32);
-            state = (tag >> 2) == epoch ? (tag & 3u) : (uint32_t) SCAN_INVALID;
-            value = (uint32_t) d;
-        }
-        const uint64_t prefixes = __ballot(state == SCAN_PREFIX);
-        const uint64_t invalid = __ballot(state == SCAN_INVALID);
-        const uint32_t stop = prefixes != 0 ? (uint32_t) __builtin_ctzll(prefixes) : 64u;   /* nearest published prefix */
-        const uint64_t needed = stop >= 63 ? ~0ull : ((2ull << stop) - 1);                   /* lanes 0 .. stop */
-        if (invalid & needed)
-        {
-            if (++spins > (1u << 22))
-            {
-                if (lane == 0)
-                    *failed = 1;
-                return acc;
-            }
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-        }
-        acc += waveSum(lane <= stop ? value : 0u);
-        if (stop < 64)
-            return acc;
-        first -= 64;
-    }
-}
-
-template<typename T, typename In, typename Out>
-__global__ __launch_bounds__(PRIM_BLOCK) void scanOnePassKernel(In in, Out out, uint64_t n, const uint32_t *nDev, T seed, T *total,
-                                                                uint64_t *desc, uint32_t *ticket, uint32_t epoch, uint32_t *failed)
-{
-    if (nDev != nullptr && *nDev < n)
-        n = *nDev;
-    __shared__ uint32_t sTile;
-    __shared__ T sPrefix;
-    __shared__ T waveTotals[PRIM_WAVES];
-    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0)
-    {
-        sTile = atomicAdd(ticket, 1u);
-        if (sTile == gridDim.x - 1)
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    /* every ticket is taken */
-    }
-    __syncthreads();
-    const uint32_t tile = sTile;
-    const int C = scanComponents(T());
-    const uint64_t base = (uint64_t) tile * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
-    T vals[PRIM_ITEMS];
-    T excl[PRIM_ITEMS];
-    T running = zeroOf(T());
-#pragma unroll
-    for (int j = 0; j < PRIM_ITEMS; j++)
-    {
-        const uint64_t i = base + (uint64_t) j * 64;
-        vals[j] = i < n ? in(i) : zeroOf(T());
-        const T incl = waveInclusiveScanT(vals[j]);
-        excl[j] = running + waveShiftUpT(incl);
-        running = running + readLaneT(incl, 63);
-    }
-    if (lane == 0)
-        waveTotals[wave] = running;
-    __syncthreads();
-    if (wave == 0)
-    {
-        T sum = waveTotals[0];
-#pragma unroll
-        for (int w = 1; w < PRIM_WAVES; w++)
-            sum = sum + waveTotals[w];
-        T prefix = seed;
-        if (tile == 0)
-        {
-            if (lane == 0)
-                for (int c = 0; c < C; c++)
-                    scanPublish(&desc[c], epoch, SCAN_PREFIX, scanGet(seed, c) + scanGet(sum, c));
-        }
-        else
-        {
-            if (lane == 0)
-                for (int c = 0; c < C; c++)
-                    scanPublish(&desc[(uint64_t) tile * C + c], epoch, SCAN_AGGREGATE, scanGet(sum, c));
-            for (int c = 0; c < C; c++)
-            {
-                const uint32_t before = scanLookBack(desc + c, (uint32_t) C, tile, epoch, failed);
-                scanSet(prefix, c, before);
-                if (lane == 0)
-                    scanPublish(&desc[(uint64_t) tile * C + c], epoch, SCAN_PREFIX, before + scanGet(sum, c));
-            }
-        }
-        if (lane == 0)
-        {
-            sPrefix = prefix;
-            /* the tile holding the last element (tile 0 of an empty scan) reports the total; later tiles are empty */
-            const uint32_t lastTile = n > 0 ? (uint32_t) ((n - 1) / PRIM_TILE) : 0u;
-            if (total != nullptr && tile == lastTile)
-                *total = prefix + sum;
-        }
-    }
-    __syncthreads();
-    T before = sPrefix;
-    for (uint32_t w = 0; w < wave; w++)
-        before = before + waveTotals[w];
-#pragma unroll
-    for (int j = 0; j < PRIM_ITEMS; j++)
-    {
-        const uint64_t i = base + (uint64_t) j * 64;
         if (i < n)
             out(i, before + excl[j], vals[j]);
     }
@@ -337,96 +228,26 @@ static int scanPhase2(mlsgpu_ctx *ctx, const char *statName, In in, Out out, uin
 {
     const uint32_t tiles = scanTiles(n);
     if (tiles > 0)
-        LAUNCH(ctx, statName, (scanApplyKernel<T, In, Out>), dim3(tiles), dim3(PRIM_BLOCK), in, out, dTileSums, n, nDev);
+        LAUNCH(ctx, statName, (scanApplyKernel<T, In, Out, false>), dim3(tiles), dim3(PRIM_BLOCK), in, out, dTileSums, n, nDev,
+               zeroOf(T()), (T *) nullptr);
     return MLSGPU_OK;
 }
 
 /* largest scan (in tiles) whose workgroups add up their predecessors' tile sums themselves */
-/* descriptors, ticket and failure flag of the single-pass scans of one context (its scans are stream-ordered) */
-struct ScanState
-{
-    uint64_t *desc = nullptr;
-    uint64_t capWords = 0;
-    uint32_t *ticket = nullptr;     /* [0] ticket, [1] failed */
-    uint32_t epoch = 0;
-    ~ScanState()
-    {
-        hipFree(desc);
-        hipFree(ticket);
-    }
-};
+#define SCAN_FUSED_MAX_TILES 4096u
 
-static int scanState(mlsgpu_ctx *ctx, uint64_t words, ScanState **out)
-{
-    std::shared_ptr<void> &cached = ctx->scratchCache["scan"];
-    if (!cached)
-        cached = std::shared_ptr<void>(new ScanState, [](void *p) { delete static_cast<ScanState *>(p); });
-    ScanState *st = static_cast<ScanState *>(cached.get());
-    if (st->ticket == nullptr)
-    {
-        HIP_CHECK(hipMalloc((void **) &st->ticket, 2 * sizeof(uint32_t)));
-        HIP_CHECK(hipMemsetAsync(st->ticket, 0, 2 * sizeof(uint32_t), ctx->stream));
-    }
-    if (st->capWords < words)
-    {
-        /* earlier scans on this stream may still be running: the old buffer is released by hipFree after they finish */
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        hipFree(st->desc);
-        st->desc = nullptr;
-        st->capWords = 0;
-        const uint64_t cap = std::max<uint64_t>(words + words / 2, 4096);
-        HIP_CHECK(hipMalloc((void **) &st->desc, cap * sizeof(uint64_t)));
-        HIP_CHECK(hipMemsetAsync(st->desc, 0, cap * sizeof(uint64_t), ctx->stream));
-        st->capWords = cap;
-    }
-    *out = st;
-    return MLSGPU_OK;
-}
-
-/* MLSGPU_ERR_HIP if a look-back of an earlier scan on this context gave up (never observed; see scanLookBack) */
-static inline int scanCheck(mlsgpu_ctx *ctx)
-{
-    auto it = ctx->scratchCache.find("scan");
-    if (it == ctx->scratchCache.end())
-        return MLSGPU_OK;
-    ScanState *st = static_cast<ScanState *>(it->second.get());
-    if (st->ticket == nullptr)
-        return MLSGPU_OK;
-    uint32_t failed = 0;
-    /* on the context's own stream: a null-stream copy would wait for every other worker's stream too */
-    HIP_CHECK(hipMemcpyAsync(&failed, st->ticket + 1, 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (failed != 0)
-        return setError(MLSGPU_ERR_HIP, "single-pass scan: look-back gave up");
-    return MLSGPU_OK;
-}
-
-/* in1 is what the scan reads (once); in2 is the same values for a second reader and is only used by the three-launch
- * form that very large scans fall back to */
+/* in1 feeds the tile sums, in2 the scan proper (they must agree; a first pass may cache what the second reads) */
 template<typename T, typename In1, typename In2, typename Out>
 static int exclusiveScan2(mlsgpu_ctx *ctx, const char *statName, In1 in1, In2 in2, Out out, uint64_t n, T seed,
                           T *dTileSums, T *dTotal, const uint32_t *nDev = nullptr)
 {
     const uint32_t tiles = scanTiles(n);
-    if (tiles == 0)
+    if (tiles > 0 && tiles <= SCAN_FUSED_MAX_TILES)
     {
-        if (dTotal != nullptr)
-            HIP_CHECK(hipMemcpyAsync(dTotal, &seed, sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-        return MLSGPU_OK;
-    }
-    if (tiles <= (1u << 24))
-    {
-        ScanState *st = nullptr;
-        PROPAGATE(scanState(ctx, (uint64_t) tiles * (sizeof(T) / 4), &st));
-        st->epoch = (st->epoch + 1) & 0x3FFFFFFFu;
-        if (st->epoch == 0)
-        {
-            /* the epoch wrapped: forget every descriptor once */
-            HIP_CHECK(hipMemsetAsync(st->desc, 0, st->capWords * sizeof(uint64_t), ctx->stream));
-            st->epoch = 1;
-        }
-        LAUNCH(ctx, statName, (scanOnePassKernel<T, In1, Out>), dim3(tiles), dim3(PRIM_BLOCK), in1, out, n, nDev, seed, dTotal,
-               st->desc, st->ticket, st->epoch, st->ticket + 1);
+        /* two launches: raw tile sums, then the scan proper */
+        LAUNCH(ctx, statName, (scanReduceKernel<T, In1>), dim3(tiles), dim3(PRIM_BLOCK), in1, dTileSums, n, nDev);
+        LAUNCH(ctx, statName, (scanApplyKernel<T, In2, Out, true>), dim3(tiles), dim3(PRIM_BLOCK), in2, out, (const T *) dTileSums,
+               n, nDev, seed, dTotal);
         return MLSGPU_OK;
     }
     PROPAGATE((scanPhase1<T, In1>(ctx, statName, in1, n, seed, dTileSums, dTotal, nDev)));
