@@ -46,6 +46,8 @@ def parse_args():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-stream", action="store_true", help="skip the PCIe-inclusive bucket-farm leg")
     p.add_argument("--no-partition", action="store_true", help="skip the device-bucketer leg (reference partition)")
+    p.add_argument("--partition-max-splats", type=int, default=2097152,
+                   help="bucket capacity of the device-bucketer leg (reference default 64 MiB / 32 B)")
     p.add_argument("--no-sink", action="store_true", help="skip the device mesh-sink leg (weld / components / prune)")
     p.add_argument("--no-timing", action="store_true", help="do not time individual kernels with HIP events")
     return p.parse_args()
@@ -333,7 +335,7 @@ def main():
         from mlsgpu_amd import binding as mb
         raw = m.DeviceBuffer(ctx, array=cloud)
         ext = (0, grid - 1, 0, grid - 1, 0, grid - 1)
-        bp = dict(max_splats=2097152, max_cells=255, chunk_cells=0, micro_cells=63, max_split=1 << 30)
+        bp = dict(max_splats=args.partition_max_splats, max_cells=255, chunk_cells=0, micro_cells=63, max_split=1 << 30)
         leaves = mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=lambda leaf, ids: None, **bp)
         ctx.synchronize()
         t0 = time.perf_counter()
