@@ -70,3 +70,32 @@ def test_synth_is_counter_based():
     allb, buckets = synth.bucketize(s, g, 127)
     assert len(buckets) == 27 and sum(b.count for b in buckets) == len(allb)
     assert sum(b.cells for b in buckets) == 255 ** 3
+
+
+def test_struct_layouts_match_the_header(tmp_path):
+    """The header compiles as plain C, and every struct the ctypes binding mirrors has the C compiler's size and
+    field offsets (a1: mlsgpu_splat is the reference's 32-byte Splat, src/splat.h:40-46)."""
+    import ctypes as C
+    import subprocess
+    from mlsgpu_amd import binding as b
+    pairs = [("mlsgpu_mesh", b.Mesh), ("mlsgpu_swathe", b.Swathe), ("mlsgpu_worker_config", b.WorkerConfig),
+             ("mlsgpu_farm_config", b.FarmConfig), ("mlsgpu_grid", b.GridStruct), ("mlsgpu_bucket_params", b.BucketParams),
+             ("mlsgpu_bucket", b.BucketStruct), ("mlsgpu_generator", b.Generator)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mlsgpu_hip.h"', 'int main(void) {',
+             'printf("mlsgpu_splat %zu %zu %zu %zu %zu\\n", sizeof(mlsgpu_splat), offsetof(mlsgpu_splat, position), '
+             'offsetof(mlsgpu_splat, radius), offsetof(mlsgpu_splat, normal), offsetof(mlsgpu_splat, quality));']
+    for cname, cls in pairs:
+        fmt = " ".join(["%zu"] * (1 + len(cls._fields_)))
+        args = ", ".join(["sizeof(%s)" % cname] + ["offsetof(%s, %s)" % (cname, f[0]) for f in cls._fields_])
+        lines.append('printf("%s %s\\n", %s);' % (cname, fmt, args))
+    lines += ["return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    out = dict((l.split()[0], [int(v) for v in l.split()[1:]]) for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    assert out["mlsgpu_splat"] == [32, 0, 12, 16, 28]
+    assert b.SPLAT_DTYPE.itemsize == 32 and [b.SPLAT_DTYPE.fields[n][1] for n in ("position", "radius", "normal", "quality")] == [0, 12, 16, 28]
+    for cname, cls in pairs:
+        want = [C.sizeof(cls)] + [getattr(cls, f[0]).offset for f in cls._fields_]
+        assert out[cname] == want, cname
