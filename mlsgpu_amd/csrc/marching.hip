@@ -675,8 +675,8 @@ __device__ __forceinline__ uint32_t edgeBit(uint32_t code, uint32_t a, uint32_t 
  * adjacent cell rows) plus a lane shift for cell x-1.  The seven bits of 64 corners become the rows' words
  * (even/odd x2 interleaved) through two lane permutations and one ballot per word.
  */
-__global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, uint32_t zCellFirst, uint32_t zCellLast,
-                                                         uint32_t H, uint32_t numCornerRows)
+__global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, const U3 *cellRowCounts, uint32_t zCellFirst,
+                                                         uint32_t zCellLast, uint32_t H, uint32_t numCornerRows)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t cr = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -707,6 +707,29 @@ __global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, 
         rowId[h] = (z2 - L.z2First) * L.rowsPerLayer + y2;
         rowCls[h] = L.rowClass(y2, z2);
         running[h] = nFlag[h] = 0;
+    }
+    /* Surface-like data leaves most of a bucket empty: if none of the adjacent cell rows holds an occupied cell (their
+     * totals come from cellCodeKernel) the four rows are all zeros, written by 16-byte stores of the first lanes. */
+    uint32_t occupied = 0;
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+        for (int dz = 0; dz < 2; dz++)
+            if (rowOk[dy][dz])
+                occupied += cellRowCounts[(uint64_t) ((uint32_t) ((int) z - dz) - C.z0) * C.ch + (uint32_t) ((int) y - dy)].a;
+    if (occupied == 0)
+    {
+#pragma unroll
+        for (int h = 0; h < 4; h++)
+        {
+            if (!rowExists[h])
+                continue;
+            for (uint32_t w = lane; w < L.nw; w += 64)
+                L.words[(uint64_t) rowId[h] * L.nw + w] = LatWord{0ull, 0u, 0u};
+            if (lane == 0)
+                L.rowCounts[rowId[h]] = U3{0u, 0u, 0u};
+        }
+        return;
     }
     uint32_t prev[2][2] = {{0, 0}, {0, 0}};
     /* the code bytes of the next 64 corners are requested before this chunk's ballots, so the loop is not one
@@ -844,11 +867,19 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lattice L, FieldVie
     {
         LatWord wd[G];
         float iso0[G], iso1[G];
+        uint64_t any = 0;
+#pragma unroll
+        for (int j = 0; j < G; j++)
+        {
+            wd[j] = rowWords[w0 + j < L.nw ? w0 + j : L.nw - 1];
+            any |= wd[j].mask | (uint64_t) (wd[j].flag & (LAT_FLAG_X0 | LAT_FLAG_TOP));
+        }
+        if (any == 0)
+            continue;       /* nothing in these words: most rows of a surface-like bucket */
 #pragma unroll
         for (int j = 0; j < G; j++)
         {
             const uint32_t w = w0 + j < L.nw ? w0 + j : L.nw - 1;
-            wd[j] = rowWords[w];
             /* every lane loads (clamped inside the row), so the loads do not wait on the masks */
             const uint32_t cx = min(w * 32 + (lane >> 1), L.cw - px);
             iso0[j] = fieldA[cx];
@@ -1368,7 +1399,7 @@ int mlsgpu_marching::shipOutLattice(const mlsgpu_swathe &sw, const uint32_t size
     const CodeView C = codeView(sw);
     const uint32_t cornerRows = (zMax - zTop + 1) * H;
     LAUNCH(ctx, "kernel.marching.countUniqueVertices.time", latticeMaskKernel, dim3(divUp(cornerRows, 4)), dim3(256),
-           L, C, zTop, zMax, H, cornerRows);
+           L, C, (const U3 *) dRowCounts, zTop, zMax, H, cornerRows);
     PROPAGATE((exclusiveScan<U3>(ctx, "kernel.marching.scanUint.time", ArrayIn<U3>{dLatRows}, ArrayOut<U3>{dLatRows},
                                  numRows, U3{0, 0, 0}, dTileSums3, &dReadback->classTotals)));
     LAUNCH(ctx, "kernel.marching.scanUint.time", latticePatchKernel, dim3(divUp(numRows * L.nw, 256)), dim3(256), L, numRows * L.nw);
