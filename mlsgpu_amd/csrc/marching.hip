@@ -867,20 +867,13 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lattice L, FieldVie
     {
         LatWord wd[G];
         float iso0[G], iso1[G];
-        uint64_t any = 0;
-#pragma unroll
-        for (int j = 0; j < G; j++)
-        {
-            wd[j] = rowWords[w0 + j < L.nw ? w0 + j : L.nw - 1];
-            any |= wd[j].mask | (uint64_t) (wd[j].flag & (LAT_FLAG_X0 | LAT_FLAG_TOP));
-        }
-        if (any == 0)
-            continue;       /* nothing in these words: most rows of a surface-like bucket */
 #pragma unroll
         for (int j = 0; j < G; j++)
         {
             const uint32_t w = w0 + j < L.nw ? w0 + j : L.nw - 1;
-            /* every lane loads (clamped inside the row), so the loads do not wait on the masks */
+            wd[j] = rowWords[w];
+            /* every lane loads (clamped inside the row), so the loads do not wait on the masks; checking the words for
+             * emptiness first was measured: -7 % on surface-like data, +8 % on the noise cloud (exposed latency) */
             const uint32_t cx = min(w * 32 + (lane >> 1), L.cw - px);
             iso0[j] = fieldA[cx];
             iso1[j] = fieldB[cx + px];
