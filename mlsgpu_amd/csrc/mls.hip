@@ -22,6 +22,8 @@
  */
 #include "common.hpp"
 
+#include <cstdlib>
+
 using namespace mlsgpu;
 
 struct mlsgpu_tree;
@@ -180,20 +182,34 @@ struct MlsArgs
     uint32_t zFirst;
     uint32_t blocksX, blocksY, blocksZ;
     float boundaryFactor;
+    uint32_t xcdChunk;           /* see xcdRemap */
     unsigned long long *stats;   /* [0] listed splats, [1] (corner, splat) distance tests, [2] hits */
 };
 
 /*
- * Workgroup -> block mapping.  Workgroups are dealt round-robin to the 8 XCDs (each with its own
- * L2), so consecutive ids land on different XCDs.  Remap so that each XCD walks one contiguous
- * run of blocks in x-fastest order: neighbouring blocks share most of their splat lists, which
- * then hit in that XCD's L2.  (Speed only; any mapping gives the same result.)
+ * Workgroup -> block mapping.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive
+ * ids land on different XCDs.  Neighbouring blocks share most of their splat lists, so small runs of `chunk` consecutive
+ * blocks are kept on one XCD -- but the runs are dealt round-robin: giving each XCD one contiguous eighth of the bucket
+ * (chunk = 0, the first version) leaves XCDs idle on surface-like data, where the eighths hold very different amounts
+ * of surface.  (Speed only; any mapping gives the same result.)
  */
-__device__ __forceinline__ uint32_t xcdRemap(uint32_t id, uint32_t n)
+__device__ __forceinline__ uint32_t xcdRemap(uint32_t id, uint32_t n, uint32_t chunk)
 {
-    const uint32_t q = n / 8, r = n % 8;
-    const uint32_t xcd = id % 8, k = id / 8;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    if (chunk == 0)
+    {
+        /* one contiguous eighth of the blocks per XCD */
+        const uint32_t q = n / 8, r = n % 8;
+        const uint32_t xcd = id % 8, k = id / 8;
+        return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    /* `chunk` consecutive blocks per XCD, chunks dealt round-robin: neighbours still share an L2, and an XCD no longer
+     * owns one slab of the bucket (on surface-like data the slabs hold very different amounts of work) */
+    const uint32_t super = 8 * chunk;
+    const uint32_t full = n / super * super;
+    if (id >= full)
+        return id;
+    const uint32_t g = id / super, j = id % super;
+    return g * super + (j % 8) * chunk + j / 8;
 }
 
 template<int SHAPE, bool CULL, bool STATS>
@@ -204,7 +220,7 @@ __global__ __launch_bounds__(512) void processCornersKernel(MlsArgs A)
     __shared__ uint32_t sMask[STAGE];
 
     const uint32_t nBlocks = A.blocksX * A.blocksY * A.blocksZ;
-    const uint32_t bid = xcdRemap(blockIdx.x, nBlocks);
+    const uint32_t bid = xcdRemap(blockIdx.x, nBlocks, A.xcdChunk);
     const uint32_t gx = bid % A.blocksX, gy = (bid / A.blocksX) % A.blocksY, gz = bid / (A.blocksX * A.blocksY);
     const int wx = (int) (gx * 8), wy = (int) (gy * 8), wz = (int) (gz * 8 + A.zFirst);
     /* makeCode(wid) >> startShift (kernels/mls.cl:318) == makeCode(wid >> subsampling): Morton digits are independent */
@@ -347,7 +363,7 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
     __shared__ uint8_t sList[512][LIST_CAP];
 
     const uint32_t nBlocks = A.blocksX * A.blocksY * A.blocksZ;
-    const uint32_t bid = xcdRemap(blockIdx.x, nBlocks);
+    const uint32_t bid = xcdRemap(blockIdx.x, nBlocks, A.xcdChunk);
     const uint32_t gx = bid % A.blocksX, gy = (bid / A.blocksX) % A.blocksY, gz = bid / (A.blocksX * A.blocksY);
     const int wx = (int) (gx * 8), wy = (int) (gy * 8), wz = (int) (gz * 8 + A.zFirst);
     const uint32_t sub = A.startShift / 3;
@@ -623,6 +639,9 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
     A.blocksY = height / 8;
     A.blocksZ = blocksZ;
     A.boundaryFactor = m->boundaryFactor;
+    /* measured on cfg3: 1..16 are equal within noise; one contiguous eighth per XCD (0) costs 24 % on the shells cloud */
+    static const uint32_t xcdChunk = getenv("MLSGPU_HIP_MLS_XCD_CHUNK") ? (uint32_t) atoi(getenv("MLSGPU_HIP_MLS_XCD_CHUNK")) : 4u;
+    A.xcdChunk = xcdChunk;
     const dim3 grid(A.blocksX * A.blocksY * A.blocksZ), block(512);
     const char *stat = "kernel.mls.processCorners.time";      /* src/mls.cpp:57 */
     A.stats = m->dStats;
