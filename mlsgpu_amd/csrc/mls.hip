@@ -188,7 +188,7 @@ struct MlsArgs
 
 /*
  * Workgroup -> block mapping.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive
- * ids land on different XCDs.  Neighbouring blocks share most of their splat lists, so small runs of `chunk` consecutive
+ * ids land on different XCDs.  Neighbouring blocks share most of their splat lists, so runs of `chunk` consecutive
  * blocks are kept on one XCD -- but the runs are dealt round-robin: giving each XCD one contiguous eighth of the bucket
  * (chunk = 0, the first version) leaves XCDs idle on surface-like data, where the eighths hold very different amounts
  * of surface.  (Speed only; any mapping gives the same result.)
@@ -639,8 +639,10 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
     A.blocksY = height / 8;
     A.blocksZ = blocksZ;
     A.boundaryFactor = m->boundaryFactor;
-    /* measured on cfg3: 1..16 are equal within noise; one contiguous eighth per XCD (0) costs 24 % on the shells cloud */
-    static const uint32_t xcdChunk = getenv("MLSGPU_HIP_MLS_XCD_CHUNK") ? (uint32_t) atoi(getenv("MLSGPU_HIP_MLS_XCD_CHUNK")) : 4u;
+    /* measured on cfg3 (ms per step shells / noise cloud, HBM fetch per launch on the noise cloud):
+     *   one contiguous eighth per XCD 12.5 / 10.6, 424 MB;  runs of 4: 9.5 / 10.5, 700 MB;  16: 9.5 / 10.5, 624 MB;
+     *   64: 9.9 / 10.5, 402 MB;  128: 10.1 / 10.5.  64 keeps the L2 locality and most of the balance. */
+    static const uint32_t xcdChunk = getenv("MLSGPU_HIP_MLS_XCD_CHUNK") ? (uint32_t) atoi(getenv("MLSGPU_HIP_MLS_XCD_CHUNK")) : 64u;
     A.xcdChunk = xcdChunk;
     const dim3 grid(A.blocksX * A.blocksY * A.blocksZ), block(512);
     const char *stat = "kernel.mls.processCorners.time";      /* src/mls.cpp:57 */
