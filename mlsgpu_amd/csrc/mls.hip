@@ -641,8 +641,10 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
     A.boundaryFactor = m->boundaryFactor;
     /* measured on cfg3 (ms per step shells / noise cloud, HBM fetch per launch on the noise cloud):
      *   one contiguous eighth per XCD 12.5 / 10.6, 424 MB;  runs of 4: 9.5 / 10.5, 700 MB;  16: 9.5 / 10.5, 624 MB;
-     *   64: 9.9 / 10.5, 402 MB;  128: 10.1 / 10.5.  64 keeps the L2 locality and most of the balance. */
-    static const uint32_t xcdChunk = getenv("MLSGPU_HIP_MLS_XCD_CHUNK") ? (uint32_t) atoi(getenv("MLSGPU_HIP_MLS_XCD_CHUNK")) : 64u;
+     *   64: 10.2 / 10.5, 402 MB;  128: 10.1 / 10.5.  Long runs keep a hot list in ONE L2, which then limits the heavy
+     *   blocks of surface-like data; short runs re-fetch it into several L2s (more HBM traffic, more L2 bandwidth).
+     *   The kernel is not HBM-bound, so the faster setting wins. */
+    static const uint32_t xcdChunk = getenv("MLSGPU_HIP_MLS_XCD_CHUNK") ? (uint32_t) atoi(getenv("MLSGPU_HIP_MLS_XCD_CHUNK")) : 16u;
     A.xcdChunk = xcdChunk;
     const dim3 grid(A.blocksX * A.blocksY * A.blocksZ), block(512);
     const char *stat = "kernel.mls.processCorners.time";      /* src/mls.cpp:57 */
