@@ -136,8 +136,9 @@ int mlsgpu_hip_tree_create(mlsgpu_ctx *ctx, uint64_t maxLevels, uint64_t maxSpla
 void mlsgpu_hip_tree_destroy(mlsgpu_tree *tree);
 /* SplatTreeCL::resourceUsage: device bytes a tree of this capacity allocates. */
 uint64_t mlsgpu_hip_tree_resource_usage(uint64_t maxLevels, uint64_t maxSplats);
-/* SplatTreeCL::enqueueBuild, src/splat_tree_cl.cpp:269-335.  Pure enqueue.  Borrows dSplats until
- * mlsgpu_hip_tree_clear_splats and MUTATES it (radius -> 1/radius^2). */
+/* SplatTreeCL::enqueueBuild, src/splat_tree_cl.cpp:269-335.  Enqueues on the context's stream, with one stream
+ * synchronisation inside (the entry count sizes the sort); the tree is complete in stream order on return.  Borrows
+ * dSplats until mlsgpu_hip_tree_clear_splats and MUTATES it (radius -> 1/radius^2). */
 int mlsgpu_hip_tree_build(mlsgpu_tree *tree, mlsgpu_splat *dSplats, uint64_t firstSplat, uint64_t numSplats,
                           const uint32_t size[3], const int32_t offset[3], uint32_t subsamplingShift);
 void mlsgpu_hip_tree_clear_splats(mlsgpu_tree *tree);
