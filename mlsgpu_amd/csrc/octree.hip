@@ -419,7 +419,6 @@ MLSGPU_API int mlsgpu_hip_tree_build(mlsgpu_tree *t, mlsgpu_splat *dSplats, uint
         HIP_CHECK(hipMemsetAsync(t->dJumpPos, 0xFF, (size_t) numStart * 4, ctx->stream));
         if (pend >= 0) ctx->endTiming(pend);
     }
-    const uint64_t maxEntries = numSplats * 8;
     if (numSplats > 0)
     {
         EntryParams P{dSplats, offset[0], offset[1], offset[2], lo, minShift, maxShift, (uint32_t) firstSplat};
