@@ -41,7 +41,7 @@ def parse_args():
     p.add_argument("--dist", default="uniform", choices=["uniform", "shells"])
     p.add_argument("--scale", type=float, default=1.0, help="splat-count scale (debug only; 1.0 = BASELINE size)")
     p.add_argument("--mesh-memory-mb", type=int, default=4096, help="Marching mesh arena per worker")
-    p.add_argument("--workers", type=int, default=2, help="device worker threads per GPU")
+    p.add_argument("--workers", type=int, default=4, help="device worker threads per GPU (measured 2..4: +0..6 %)")
     p.add_argument("--variant", type=int, default=2, help="MLS kernel variant: 0 culled, 1 basic, 2 culled + hit lists")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-stream", action="store_true", help="skip the PCIe-inclusive bucket-farm leg")
