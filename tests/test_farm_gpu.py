@@ -75,3 +75,32 @@ def test_farm_rejects_oversized_bucket_and_reports_worker_errors():
     with pytest.raises(m.LengthError):
         farm.finish()
     farm.close()
+
+
+@pytest.mark.gpu
+def test_farm_dispatches_over_device_groups():
+    """Two DeviceWorkerGroups (here both on GPU 0, as a one-GPU stand-in for two GPUs): the copy thread sends each item to
+    the group with the most unallocated capacity (src/workers.cpp:320-351), both groups get work, and every chunk's
+    meshes are the oracle's whichever group produced them."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import synth
+    cloud = synth.shells_cloud(120_000, 95.0, 16.0, 1.5, 2.5, seed=99)
+    allb, buckets = synth.bucketize(cloud, 96, 32)
+    cap = max(b.count for b in buckets)
+    farm = m.BucketFarm([0, 0], cap, workers_per_device=1, collect=True, max_cells=63)
+    for i, b in enumerate(buckets):
+        farm.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, i)
+    farm.finish()
+    st = farm.stats()
+    assert st["buckets"] == 27 and st["per_device"][0] + st["per_device"][1] == 27
+    assert st["per_device"][0] > 0 and st["per_device"][1] > 0
+    ref = allb.copy()
+    for i, b in enumerate(buckets):
+        exp, _ = ob.bucket(ref, b.first, b.count, b.num_vertices, b.low, max_cells=63, max_swathe=64,
+                           mesh_memory=63 * 63 * 2 * 872)
+        got = farm.meshes.get(i, [])
+        assert len(got) == len(exp), i
+        for g, e in zip(got, exp):
+            np.testing.assert_array_equal(g["vertices"].view(np.uint32), e["vertices"].view(np.uint32))
+            np.testing.assert_array_equal(g["triangles"], e["triangles"])
+    farm.close()
