@@ -345,45 +345,21 @@ def main():
         part_s = (time.perf_counter() - t0) / args.steps
         pmax = max(l["num_splats"] for l in leaves)
         pcells = max(max(l["extents"][2 * i + 1] - l["extents"][2 * i] for i in range(3)) for l in leaves)
-        # the bucketer's callback loads a leaf into a free staging slot (device gather + transform) and hands it to one
-        # of `nworkers` device workers, each with its own context / stream, as the farm does for host buckets
-        import queue
-        pctxs = [m.Context(local_rank) for _ in range(nworkers)]
-        pworkers = [m.Worker(c, pmax, max_cells=pcells, mesh_memory=args.mesh_memory_mb << 20) for c in pctxs]
-        for w in pworkers:
-            w.set_mls_variant(args.variant)
-        slots = [m.DeviceBuffer(ctx, nbytes=pmax * 32) for _ in range(nworkers + 1)]
-        free_slots, free_workers = queue.Queue(), queue.Queue()
-        for i in range(len(slots)):
-            free_slots.put(i)
-        for i in range(nworkers):
-            free_workers.put(i)
-        pcols = [m.binding.SizeCollector() for _ in range(nworkers)]
-        ppool = ThreadPoolExecutor(nworkers)
-        pending = []
-
-        def run_leaf(slot, n, low, nv):
-            k = free_workers.get()
-            try:
-                pworkers[k].process(slots[slot], 0, n, low, nv, collector=pcols[k])
-                pctxs[k].synchronize()
-            finally:
-                free_workers.put(k)
-                free_slots.put(slot)
+        # the bucketer's callback hands every leaf to the bucket farm's device path (gather + transform kernel into a
+        # device item, then the farm's worker threads), as CopyGroup does with host buckets
+        pfarm = m.BucketFarm([local_rank], pmax, workers_per_device=nworkers, spare=1, max_cells=pcells,
+                             mesh_memory=args.mesh_memory_mb << 20)
+        leaf_no = [0]
 
         def leaf_work(leaf, d_ids):
             low = leaf["extents"][0::2]
             nv = [leaf["extents"][2 * i + 1] - leaf["extents"][2 * i] + 1 for i in range(3)]
-            slot = free_slots.get()
-            mb.bucket_load(ctx, raw, d_ids, leaf["num_splats"], (0.0, 0.0, 0.0), 1.0, ext, slots[slot])
-            ctx.synchronize()                       # the slot is complete and the id list may be reused
-            pending.append(ppool.submit(run_leaf, slot, leaf["num_splats"], low, nv))
+            pfarm.submit_device(local_rank, raw, d_ids, leaf["num_splats"], (0.0, 0.0, 0.0), 1.0, ext, low, nv, leaf_no[0])
+            leaf_no[0] += 1
 
         def partition_pass():
             mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=leaf_work, **bp)
-            for f in pending:
-                f.result()
-            del pending[:]
+            pfarm.finish()
         partition_pass()                            # warm-up
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -397,11 +373,11 @@ def main():
             "bucketing_msplats_per_s": round(n_splats / part_s / 1e6, 1),
             "pipeline_ms_per_step": round(pipe_s * 1e3, 3), "pipeline_mvoxels_per_s": round(pvox / pipe_s / 1e6, 3),
             "device_workers": nworkers,
-            "note": "raw cloud resident in HBM -> mlsgpu_hip_bucket (reference partition) -> mlsgpu_hip_bucket_load -> "
-                    "device workers; bucketing is inside the pipeline time",
+            "note": "raw cloud resident in HBM -> mlsgpu_hip_bucket (reference partition) -> mlsgpu_hip_farm_submit_device "
+                    "(device gather + transform) -> the farm's device workers; bucketing is inside the pipeline time",
         }
-        ppool.shutdown()
-        del pworkers, slots, raw
+        pfarm.close()
+        del raw
     del cloud
 
     # ---- PCIe-inclusive leg (never `value`): the same buckets from HOST memory through the bucket farm

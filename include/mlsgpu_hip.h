@@ -328,6 +328,14 @@ int mlsgpu_hip_bounding_grid(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, uint6
 int mlsgpu_hip_bucket_load(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, const uint32_t *dIds, uint64_t numSplats,
                            const mlsgpu_grid *fullGrid, mlsgpu_splat *dOut);
 
+/* A bucket whose splats are already on GPU `device` (one of the farm's), e.g. from mlsgpu_hip_bucket's callback: the
+ * device item is filled by mlsgpu_hip_bucket_load (gather of dIds + transform into fullGrid's vertex coordinates) on the
+ * group's copy stream -- no host copy.  dIds may be reused when the call returns.  lowExtent / numVertices as for
+ * mlsgpu_hip_worker_process.  */
+int mlsgpu_hip_farm_submit_device(mlsgpu_farm *farm, int device, const mlsgpu_splat *dSplats, const uint32_t *dIds,
+                                  uint64_t numSplats, const mlsgpu_grid *fullGrid, const int32_t lowExtent[3],
+                                  const uint32_t numVertices[3], uint64_t chunkId);
+
 /* ---- mesh sink for meshes that stay in HBM: OOCMesher's weld / components / prune / per-chunk output,
  *      src/mesher.h:203-330, src/mesher.cpp:220-852 ---- */
 typedef struct mlsgpu_mesher mlsgpu_mesher;

@@ -182,6 +182,7 @@ def lib():
     sig("mlsgpu_hip_farm_submit", C.c_int, vp, vp, u64, vp, vp, u64)
     sig("mlsgpu_hip_farm_acquire", C.c_int, vp, u64, P(vp))
     sig("mlsgpu_hip_farm_push", C.c_int, vp, u64, vp, vp, u64)
+    sig("mlsgpu_hip_farm_submit_device", C.c_int, vp, C.c_int, vp, vp, u64, P(GridStruct), vp, vp, u64)
     sig("mlsgpu_hip_farm_finish", C.c_int, vp)
     sig("mlsgpu_hip_farm_stats", C.c_int, vp, vp)
     sig("mlsgpu_hip_transform_splats", None, vp, u64, vp, f32, vp)
@@ -828,6 +829,13 @@ class BucketFarm:
 
     def push(self, num_splats, low_extent, num_vertices, chunk_id):
         check(lib().mlsgpu_hip_farm_push(self.h, num_splats, _p(_i3(low_extent)), _p(_u3(num_vertices)), chunk_id))
+
+    def submit_device(self, device, d_splats, d_ids_ptr, num_splats, reference, spacing, extents, low_extent, num_vertices,
+                      chunk_id):
+        """A bucket whose splats are on the device already (the bucketer's callback): loaded by a device kernel."""
+        g = _grid_struct(reference, spacing, extents)
+        check(lib().mlsgpu_hip_farm_submit_device(self.h, device, d_splats.ptr, d_ids_ptr, num_splats, C.byref(g),
+                                                  _p(_i3(low_extent)), _p(_u3(num_vertices)), chunk_id))
 
     def finish(self):
         rc = lib().mlsgpu_hip_farm_finish(self.h)

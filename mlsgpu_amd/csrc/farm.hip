@@ -46,6 +46,7 @@ struct DeviceGroup               /* DeviceWorkerGroup, src/workers.h:214-350 */
     int device = 0;
     uint32_t index = 0;
     hipStream_t copyStream = nullptr;
+    mlsgpu_ctx *copyCtx = nullptr;       /* the copy stream as a context, for device-side loads */
     std::vector<std::unique_ptr<WorkItem> > items;
     std::deque<WorkItem *> pool;         /* itemPool */
     std::deque<WorkItem *> queue;        /* pushed, not yet taken by a worker */
@@ -278,6 +279,8 @@ MLSGPU_API int mlsgpu_hip_farm_create(const mlsgpu_farm_config *cfg, mlsgpu_farm
         g->index = d;
         if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking) != hipSuccess)
             rc = setError(MLSGPU_ERR_HIP, "farm: cannot create the copy stream on device %d", dev);
+        if (rc == MLSGPU_OK)
+            rc = mlsgpu_hip_ctx_create(dev, g->copyStream, &g->copyCtx);
         const uint32_t nItems = f->cfg.workersPerDevice + f->cfg.spare;
         for (uint32_t i = 0; i < nItems && rc == MLSGPU_OK; i++)
         {
@@ -322,6 +325,7 @@ MLSGPU_API void mlsgpu_hip_farm_destroy(mlsgpu_farm *f)
             hipFree(item->dSplats);
             if (item->copyEvent) hipEventDestroy(item->copyEvent);
         }
+        if (g->copyCtx) mlsgpu_hip_ctx_destroy(g->copyCtx);
         if (g->copyStream) hipStreamDestroy(g->copyStream);
     }
     for (int b = 0; b < 2; b++)
@@ -402,6 +406,83 @@ MLSGPU_API int mlsgpu_hip_farm_submit(mlsgpu_farm *f, const mlsgpu_splat *hSplat
     PROPAGATE(mlsgpu_hip_farm_acquire(f, numSplats, &dst));
     parallelCopy(dst, hSplats, numSplats * sizeof(mlsgpu_splat), f->cfg.copyThreads == 0 ? 4u : f->cfg.copyThreads);
     return mlsgpu_hip_farm_push(f, numSplats, lowExtent, numVertices, chunkId);
+}
+
+/* A bucket whose splats are already on `device` (the device bucketer's callback): the item is filled by the gather +
+ * transform kernel of mlsgpu_hip_bucket_load on the group's copy stream instead of a host-to-device copy. */
+MLSGPU_API int mlsgpu_hip_farm_submit_device(mlsgpu_farm *f, int device, const mlsgpu_splat *dSplats, const uint32_t *dIds,
+                                             uint64_t numSplats, const mlsgpu_grid *fullGrid, const int32_t lowExtent[3],
+                                             const uint32_t numVertices[3], uint64_t chunkId)
+{
+    REQUIRE(f != nullptr && fullGrid != nullptr && lowExtent != nullptr && numVertices != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(numSplats == 0 || dSplats != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(numSplats <= f->cfg.worker.maxBucketSplats, MLSGPU_ERR_LENGTH);
+    PROPAGATE(flushBatch(f));           /* host buckets submitted earlier keep their place in the order */
+    DeviceGroup *out = nullptr;
+    WorkItem *item = nullptr;
+    {
+        std::unique_lock<std::mutex> l(f->mutex);
+        bool known = false;
+        for (auto &g : f->groups)
+            known = known || g->device == device;
+        REQUIRE(known, MLSGPU_ERR_INVALID);
+        for (;;)
+        {
+            if (f->error != MLSGPU_OK)
+                return setError(f->error, "%s", f->errorText.c_str());
+            uint64_t best = 0;
+            for (auto &g : f->groups)
+                if (g->device == device && !g->pool.empty() && g->unallocated >= best)
+                {
+                    best = g->unallocated;
+                    out = g.get();
+                }
+            if (out != nullptr)
+                break;
+            f->popCond.wait(l);
+        }
+        item = out->pool.front();
+        out->pool.pop_front();
+        out->unallocated -= numSplats;
+        f->inFlightItems++;
+    }
+    SubItem sub;
+    sub.chunkId = chunkId;
+    for (int i = 0; i < 3; i++)
+    {
+        sub.low[i] = lowExtent[i];
+        sub.numVertices[i] = numVertices[i];
+    }
+    sub.firstSplat = 0;
+    sub.numSplats = numSplats;
+    item->subItems.assign(1, sub);
+    item->numSplats = numSplats;
+    int rc = mlsgpu_hip_bucket_load(out->copyCtx, dSplats, dIds, numSplats, fullGrid, item->dSplats);
+    if (rc == MLSGPU_OK && hipEventRecord(item->copyEvent, out->copyStream) != hipSuccess)
+        rc = setError(MLSGPU_ERR_HIP, "farm: cannot record the load event");
+    /* the id list belongs to the caller (the bucketer reuses it after its callback returns) */
+    if (rc == MLSGPU_OK && hipStreamSynchronize(out->copyStream) != hipSuccess)
+        rc = setError(MLSGPU_ERR_HIP, "farm: the device-side load failed");
+    {
+        std::lock_guard<std::mutex> l(f->mutex);
+        if (rc != MLSGPU_OK)
+        {
+            item->subItems.clear();
+            out->pool.push_back(item);
+            out->unallocated += numSplats;
+            f->inFlightItems--;
+        }
+        else
+        {
+            f->stats[0]++;
+            f->stats[1] += numSplats;
+            f->stats[3]++;
+            out->queue.push_back(item);
+        }
+    }
+    if (rc == MLSGPU_OK)
+        f->queueCond.notify_all();
+    return rc;
 }
 
 MLSGPU_API int mlsgpu_hip_farm_finish(mlsgpu_farm *f)

@@ -120,3 +120,47 @@ def test_cloud_to_meshes_without_leaving_the_device():
     assert total > 100000
     del worker
     ctx.close()
+
+
+def test_bucketer_feeds_the_farm_on_the_device():
+    """mlsgpu_hip_bucket -> mlsgpu_hip_farm_submit_device -> two worker threads: every leaf's meshes equal the oracle's
+    for that leaf (chunk id = leaf number), with no host copy of splat data."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as b, synth
+    cloud = synth.shells_cloud(150_000, 95.0, 16.0, 1.5, 2.5, seed=78)
+    spacing, ref = np.float32(0.05), np.array([2.0, -1.0, 0.5], np.float32)
+    world = cloud.copy()
+    world["position"] = world["position"] * spacing + ref
+    world["radius"] = world["radius"] * spacing
+    extents = (0, 191, 0, 191, 0, 191)
+    max_cells, max_splats = 63, 40000
+    exp = ob.bucket_partition(world, ref, spacing, extents, max_splats, max_cells, 0, 16, 1 << 30)
+    ctx = m.Context(0)
+    dev = m.DeviceBuffer(ctx, array=world)
+    farm = m.BucketFarm([0], max_splats, workers_per_device=2, collect=True, max_cells=max_cells)
+    count = [0]
+
+    def on_bucket(leaf, d_ids):
+        low = [leaf["extents"][2 * i] - extents[2 * i] for i in range(3)]
+        nv = [leaf["extents"][2 * i + 1] - leaf["extents"][2 * i] + 1 for i in range(3)]
+        farm.submit_device(0, dev, d_ids, leaf["num_splats"], ref, spacing, extents, low, nv, count[0])
+        count[0] += 1
+    got = b.bucket_cloud(ctx, dev, len(world), ref, spacing, extents, max_splats, max_cells, 0, 16, 1 << 30, on_bucket=on_bucket)
+    farm.finish()
+    assert len(got) == len(exp) == farm.stats()["buckets"]
+    nonempty = 0
+    for i, e in enumerate(exp):
+        low = [e["extents"][2 * k] - extents[2 * k] for k in range(3)]
+        nv = [e["extents"][2 * k + 1] - e["extents"][2 * k] + 1 for k in range(3)]
+        host = world[e["ids"].astype(np.int64)].copy()
+        b.transform_splats(host, ref, float(spacing), extents[0::2])
+        ref_batches, _ = ob.bucket(host, 0, len(host), nv, low, max_cells=max_cells)
+        batches = farm.meshes.get(i, [])
+        assert len(batches) == len(ref_batches)
+        for g, r in zip(batches, ref_batches):
+            np.testing.assert_array_equal(g["vertices"].view(np.uint32), r["vertices"].view(np.uint32))
+            np.testing.assert_array_equal(g["triangles"], r["triangles"])
+            nonempty += len(g["triangles"]) > 0
+    assert nonempty > 8
+    farm.close()
+    ctx.close()
