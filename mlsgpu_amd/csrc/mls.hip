@@ -35,7 +35,7 @@ struct mlsgpu_mls
 {
     mlsgpu_ctx *ctx = nullptr;
     int shape = MLSGPU_SHAPE_SPHERE;
-    int variant = 0;
+    int variant = 2;             /* culled + hit lists: the fastest on both BASELINE clouds; 0 and 1 stay selectable */
     const mlsgpu_splat *dSplats = nullptr;
     const int32_t *dCommands = nullptr;
     const int32_t *dStart = nullptr;
