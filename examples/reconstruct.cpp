@@ -5,8 +5,8 @@
  *   FastPly::Reader      mlsgpu_hip_ply_*            (host)
  *   bounding grid        mlsgpu_hip_bounding_grid    (device reduction)
  *   Bucket::bucket       mlsgpu::hip::Bucket::bucket (device)
- *   BucketLoader         mlsgpu::hip::Bucket::load   (device gather + transform)
- *   DeviceWorkerGroup    mlsgpu_hip_worker_*         (octree, MLS, marching, scale/bias)
+ *   BucketLoader + CopyGroup + DeviceWorkerGroup   mlsgpu_hip_farm_submit_device (device gather + transform into a
+ *                        device item, then four worker threads: octree, MLS, marching, scale/bias)
  *   OOCMesher            mlsgpu::hip::DeviceMesher   (device weld / components / prune), FastPly::Writer on the host
  *
  * usage: reconstruct <in.ply> <out.ply> <spacing> [smooth=4] [levels=6] [subsampling=3] [prune=0.02] [maxSplats=2097152]
@@ -56,8 +56,12 @@ int main(int argc, char **argv)
         Bucket::Grid grid;
         check(mlsgpu_hip_bounding_grid(ctx.get(), cloud.get(), host.size(), spacing, microCells, &grid));
 
-        mlsgpu_worker_config cfg;
-        std::memset(&cfg, 0, sizeof(cfg));
+        mlsgpu_farm_config fcfg;
+        std::memset(&fcfg, 0, sizeof(fcfg));
+        fcfg.numDevices = 1;
+        fcfg.workersPerDevice = 4;                              // --device-threads
+        fcfg.spare = 1;
+        mlsgpu_worker_config &cfg = fcfg.worker;
         cfg.maxBucketSplats = maxSplats;
         cfg.maxCells = maxCells;
         cfg.levels = levels;
@@ -67,39 +71,43 @@ int main(int argc, char **argv)
         cfg.gridSpacing = spacing;                             // ScaleBiasFilter: vertex * spacing + grid.getVertex(0,0,0)
         for (int i = 0; i < 3; i++)
             cfg.gridOrigin[i] = grid.reference[i] + spacing * (float) grid.extents[2 * i];
-        mlsgpu_worker *worker = NULL;
-        check(mlsgpu_hip_worker_create(ctx.get(), &cfg, &worker));
 
-        Buffer<Splat> staged(ctx, maxSplats);
         DeviceMesher mesher(ctx);
         mesher.setPruneThreshold(prune);
-        std::size_t bins = 0;
+        // the farm's output functor (OutputGenerator of src/workers.h:225): every ship-out goes to the device mesher
         struct Sink
         {
-            DeviceMesher *mesher;
-            const Context *ctx;
-            static int call(void *user, void *, const mlsgpu_mesh *mesh)
+            static int call(void *user, int, std::uint64_t, mlsgpu_ctx *workerCtx, const mlsgpu_mesh *mesh)
             {
-                Sink *self = static_cast<Sink *>(user);
-                try
-                {
-                    self->mesher->functor(*self->ctx, 0)(NULL, *static_cast<const DeviceKeyMesh *>(mesh));
-                    return 0;
-                }
-                catch (std::exception &e)
-                {
-                    std::cerr << e.what() << "\n";
-                    return 1;
-                }
+                return mlsgpu_hip_mesher_add(static_cast<DeviceMesher *>(user)->get(), workerCtx, 0, mesh);
             }
-        } sink{&mesher, &ctx};
-        Bucket::bucket(ctx, cloud, host.size(), grid, maxSplats, maxCells, 0, microCells, std::uint64_t(1) << 30,
-                       [&](const Bucket::Bin &bin)
+        };
+        mlsgpu_farm *farm = NULL;
+        check(mlsgpu_hip_farm_create(&fcfg, &Sink::call, &mesher, &farm));
+        std::size_t bins = 0;
+        try
         {
-            const BucketGrid sub = Bucket::load(ctx, cloud, bin, grid, staged);
-            check(mlsgpu_hip_worker_process(worker, staged.get(), 0, bin.numSplats, sub.low, sub.numVertices, &Sink::call, &sink));
-            bins++;
-        });
+            Bucket::bucket(ctx, cloud, host.size(), grid, maxSplats, maxCells, 0, microCells, std::uint64_t(1) << 30,
+                           [&](const Bucket::Bin &bin)
+            {
+                std::int32_t low[3];
+                std::uint32_t nv[3];
+                for (int i = 0; i < 3; i++)
+                {
+                    low[i] = bin.extents[2 * i] - grid.extents[2 * i];
+                    nv[i] = (std::uint32_t) (bin.extents[2 * i + 1] - bin.extents[2 * i] + 1);
+                }
+                check(mlsgpu_hip_farm_submit_device(farm, 0, cloud.get(), bin.dIds, bin.numSplats, &grid, low, nv, bins));
+                bins++;
+            });
+            check(mlsgpu_hip_farm_finish(farm));
+        }
+        catch (...)
+        {
+            mlsgpu_hip_farm_destroy(farm);
+            throw;
+        }
+        mlsgpu_hip_farm_destroy(farm);
         const std::string outName = argv[2];
         const std::size_t files = mesher.write([&](std::uint64_t) { return outName; },
                                                std::vector<std::string>(1, "mlsgpu-hip example: reconstruct"));
@@ -109,7 +117,6 @@ int main(int argc, char **argv)
                     host.size(), grid.extents[0], grid.extents[1], grid.extents[2], grid.extents[3], grid.extents[4],
                     grid.extents[5], bins, files, (unsigned long long) st[4], (unsigned long long) st[5],
                     (unsigned long long) st[2], (unsigned long long) st[3]);
-        mlsgpu_hip_worker_destroy(worker);
     }
     catch (std::exception &e)
     {

@@ -502,6 +502,7 @@ public:
 
     explicit DeviceMesher(const Context &ctx) : h(NULL), ctx(&ctx) { check(mlsgpu_hip_mesher_create(ctx.get(), &h)); }
     ~DeviceMesher() { mlsgpu_hip_mesher_destroy(h); }
+    mlsgpu_mesher *get() const { return h; }
     unsigned int numPasses() const { return 1; }
     void setPruneThreshold(double threshold) { check(mlsgpu_hip_mesher_set_prune_threshold(h, threshold)); }
     void reserve(std::uint64_t vertices, std::uint64_t triangles, std::uint64_t external)
