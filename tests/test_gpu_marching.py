@@ -183,3 +183,37 @@ def test_scale_bias(ctx):
     np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
     empty = m.binding.Mesh(None, None, None, 0, 0, 0)
     m.binding.check(m.lib().mlsgpu_hip_scale_bias(ctx.h, C.byref(empty), 3.0, 10.0, -20.0, 30.0))
+
+
+def noise_fn(seed, hole_rate):
+    """A hash-noise field with NaN holes: every cube code, every lattice word boundary, cells dropped by isValid."""
+    def fn(x, y, z):
+        h = (x.astype(np.uint64) * np.uint64(73856093)) ^ (y.astype(np.uint64) * np.uint64(19349663)) \
+            ^ (np.uint64(z) * np.uint64(83492791)) ^ np.uint64(seed * 2654435761)
+        h = (h * np.uint64(0x9E3779B97F4A7C15)) >> np.uint64(40)
+        v = (h.astype(np.float64) / float(1 << 24) - 0.5).astype(np.float32)
+        v = np.where(v == 0, np.float32(0.25), v)
+        holes = ((h >> np.uint64(7)) % np.uint64(1000)) < np.uint64(int(hole_rate * 1000))
+        return np.where(holes, np.float32(np.nan), v)
+    return fn
+
+
+@pytest.mark.parametrize("size,swathe,weld", [((97, 35, 41), 48, "lattice"), ((131, 67, 9), 16, "lattice"), ((33, 129, 20), 24, "lattice"),
+                                               ((97, 35, 41), 16, "sort"), ((2, 2, 2), 8, "lattice"), ((65, 3, 2), 8, "lattice")])
+def test_noise_fields_with_holes(ctx, size, swathe, weld, monkeypatch):
+    """Random fields (every code, NaN holes) on ragged sizes around the 32-cell word boundaries of the lattice weld."""
+    import mlsgpu_amd as m
+    if weld == "sort":
+        monkeypatch.setenv("MLSGPU_HIP_WELD", "sort")
+    fn = noise_fn(sum(size), 0.03)
+    alignment = (8, 8, 8)
+    mw, mh, md = size[0] + 3, size[1] + 2, size[2] + 5
+    for mesh_memory in ((mw - 1) * (mh - 1) * 872 * 400, (mw - 1) * (mh - 1) * 872 * 2):
+        mc = m.Marching(ctx, mw, mh, md, swathe, mesh_memory, alignment)
+        got = mc.generate(m.binding.HostGenerator(ctx, fn, alignment), size, (7, 0, 3))
+        oracle = ob.MarchingOracle(mw, mh, md, swathe, mesh_memory, alignment)
+        exp = oracle.generate(host_generator(fn), size, (7, 0, 3))
+        assert_batches_equal(got, exp)
+        st, cnt = oracle.stats(), mc.counters()
+        for k in ("shipouts", "overflows", "occupied", "unwelded", "indices", "welded", "external"):
+            assert st[k] == cnt[k], k
