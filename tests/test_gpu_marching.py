@@ -199,7 +199,7 @@ def noise_fn(seed, hole_rate):
 
 
 @pytest.mark.parametrize("size,swathe,weld", [((97, 35, 41), 48, "lattice"), ((131, 67, 9), 16, "lattice"), ((33, 129, 20), 24, "lattice"),
-                                               ((97, 35, 41), 16, "sort"), ((2, 2, 2), 8, "lattice"), ((65, 3, 2), 8, "lattice")])
+                                               ((97, 35, 41), 16, "sort"), ((9, 10, 11), 16, "lattice"), ((65, 9, 10), 16, "lattice")])
 def test_noise_fields_with_holes(ctx, size, swathe, weld, monkeypatch):
     """Random fields (every code, NaN holes) on ragged sizes around the 32-cell word boundaries of the lattice weld."""
     import mlsgpu_amd as m
