@@ -297,6 +297,17 @@ def main():
             }
         if stages:
             result["roofline"]["hbm_stages"] = stages
+        if tj and "roofline" in result:
+            # whole-pipeline HBM rate: measured PMC traffic per launch (profiles/traffic.json) x launches per
+            # step of every tracked kernel, over the step time of the timed region
+            per_bucket = {"processCorners": 1, "latticeTriangles": 1, "latticeVertices": 1, "latticeMask": 1, "cellCode": 1,
+                          "writeEntries": 1, "writeSplatIds": 1, "sortScatter": sort_passes, "sortHist": sort_passes}
+            moved = sum(tj[k] * n * len(buckets) for k, n in per_bucket.items() if k in tj)
+            result["roofline"]["pipeline_hbm"] = {
+                "traffic_bytes_per_step": int(moved), "achieved_GBps": round(moved / (ms_per_step * 1e-3) / 1e9, 1),
+                "peak_GBps": HBM_PEAK_GBS, "frac": round(moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                "note": "PMC traffic of the tracked kernels (over 95 % of kernel time) / step time with %d device workers; "
+                        "the step is bound by processCorners' fp32/LDS work and by latency, not by HBM" % nworkers}
         result["kernel_ms_per_step"] = {k: round(v[0] / K, 3) for k, v in sorted(kernel_stats.items())}
         result["work_per_step"] = {"octree_entries": entries, "occupied_cells": O, "unwelded_vertices": mc["unwelded"],
                                    "welded_vertices": Vw, "external_vertices": external, "indices": T}
