@@ -306,7 +306,7 @@ def main():
             result["roofline"]["pipeline_hbm"] = {
                 "traffic_bytes_per_step": int(moved), "achieved_GBps": round(moved / (ms_per_step * 1e-3) / 1e9, 1),
                 "peak_GBps": HBM_PEAK_GBS, "frac": round(moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "PMC traffic of the tracked kernels (over 95 % of kernel time) / step time with %d device workers; "
+                "note": "PMC traffic of the tracked kernels (over 95 %% of kernel time) / step time with %d device workers; "
                         "the step is bound by processCorners' fp32/LDS work and by latency, not by HBM" % nworkers}
         result["kernel_ms_per_step"] = {k: round(v[0] / K, 3) for k, v in sorted(kernel_stats.items())}
         result["work_per_step"] = {"octree_entries": entries, "occupied_cells": O, "unwelded_vertices": mc["unwelded"],
