@@ -380,6 +380,11 @@ uint64_t mlsgpu_hip_ply_size(const mlsgpu_ply_reader *reader);
 int mlsgpu_hip_ply_layout(const mlsgpu_ply_reader *reader, uint64_t out[10]);
 /* Reader::Handle::read: splats [first, first + count) into host memory (e.g. what mlsgpu_hip_farm_acquire returned) */
 int mlsgpu_hip_ply_read(mlsgpu_ply_reader *reader, uint64_t first, uint64_t count, mlsgpu_splat *out);
+/* File -> device memory, decode (hostThreads host threads, 0 = 4) overlapped with the host-to-device copies through two
+ * pinned 64 MiB buffers on ctx's stream; returns when dOut[0 .. count) is complete.  What the reference's reader
+ * threads + async I/O do for its out-of-core splat sets (src/splat_set.h:389-700), for inputs that fit in HBM. */
+int mlsgpu_hip_ply_load(mlsgpu_ply_reader *reader, mlsgpu_ctx *ctx, uint64_t first, uint64_t count, mlsgpu_splat *dOut,
+                        uint32_t hostThreads);
 
 /* DeviceWorkerGroupBase::computeMaxSwathe, src/workers.cpp:169-182 */
 uint32_t mlsgpu_hip_compute_max_swathe(uint32_t yMax, uint32_t y, uint32_t yAlign, uint32_t zAlign);

@@ -191,6 +191,7 @@ def lib():
     sig("mlsgpu_hip_ply_size", u64, vp)
     sig("mlsgpu_hip_ply_layout", C.c_int, vp, vp)
     sig("mlsgpu_hip_ply_read", C.c_int, vp, u64, u64, vp)
+    sig("mlsgpu_hip_ply_load", C.c_int, vp, vp, u64, u64, vp, u32)
     sig("mlsgpu_hip_mesher_create", C.c_int, vp, P(vp))
     sig("mlsgpu_hip_mesher_destroy", None, vp)
     sig("mlsgpu_hip_mesher_set_prune_threshold", C.c_int, vp, C.c_double)
@@ -591,6 +592,13 @@ class PlyReader:
         assert out.dtype == SPLAT_DTYPE and out.flags.c_contiguous and len(out) >= count
         check(lib().mlsgpu_hip_ply_read(self.h, first, count, _p(out)))
         return out
+
+    def load(self, ctx, d_out, first=0, count=None, host_threads=0):
+        """File -> device buffer (decode overlapped with the H2D copies)."""
+        if count is None:
+            count = len(self) - first
+        assert d_out.nbytes >= count * SPLAT_DTYPE.itemsize
+        check(lib().mlsgpu_hip_ply_load(self.h, ctx.h, first, count, d_out.ptr, host_threads))
 
     def close(self):
         if getattr(self, "h", None):

@@ -14,6 +14,7 @@
 #include <fstream>
 #include <memory>
 #include <sstream>
+#include <thread>
 
 using namespace mlsgpu;
 
@@ -265,4 +266,87 @@ MLSGPU_API int mlsgpu_hip_ply_read(mlsgpu_ply_reader *r, uint64_t first, uint64_
         }
     }
     return MLSGPU_OK;
+}
+
+namespace
+{
+
+/* decode `count` vertices starting at `first` into out, on `threads` host threads (each with its own file handle) */
+int decodeParallel(mlsgpu_ply_reader *r, uint64_t first, uint64_t count, mlsgpu_splat *out, unsigned threads)
+{
+    if (threads <= 1 || count < 65536)
+        return mlsgpu_hip_ply_read(r, first, count, out);
+    std::vector<std::thread> pool;
+    std::vector<int> rc(threads, MLSGPU_OK);
+    std::vector<std::string> msg(threads);
+    const uint64_t per = (count + threads - 1) / threads;
+    for (unsigned t = 0; t < threads; t++)
+    {
+        const uint64_t lo = std::min<uint64_t>(count, t * per), hi = std::min<uint64_t>(count, lo + per);
+        if (lo == hi)
+            continue;
+        pool.emplace_back([=, &rc, &msg]
+        {
+            mlsgpu_ply_reader *mine = nullptr;
+            rc[t] = mlsgpu_hip_ply_open(r->path.c_str(), r->smooth, r->maxRadius, &mine);
+            if (rc[t] == MLSGPU_OK)
+                rc[t] = mlsgpu_hip_ply_read(mine, first + lo, hi - lo, out + lo);
+            if (rc[t] != MLSGPU_OK)
+                msg[t] = mlsgpu_hip_last_error();
+            mlsgpu_hip_ply_close(mine);
+        });
+    }
+    for (std::thread &t : pool)
+        t.join();
+    for (unsigned t = 0; t < threads; t++)
+        if (rc[t] != MLSGPU_OK)
+            return setError(rc[t], "%s", msg[t].c_str());
+    return MLSGPU_OK;
+}
+
+} // namespace
+
+/* File -> device without a host copy of the whole cloud: the role of the reference's reader threads and async I/O
+ * (src/splat_set.h:389-700, src/async_io.h) for inputs that fit in HBM.  Two pinned buffers: the host threads decode
+ * batch k + 1 from the file while batch k travels over PCIe on the context's stream. */
+MLSGPU_API int mlsgpu_hip_ply_load(mlsgpu_ply_reader *r, mlsgpu_ctx *ctx, uint64_t first, uint64_t count, mlsgpu_splat *dOut,
+                                   uint32_t hostThreads)
+{
+    REQUIRE(r != nullptr && ctx != nullptr && (count == 0 || dOut != nullptr), MLSGPU_ERR_INVALID);
+    REQUIRE(first <= r->vertexCount && count <= r->vertexCount - first, MLSGPU_ERR_LENGTH);
+    if (count == 0)
+        return MLSGPU_OK;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const uint64_t batch = std::min<uint64_t>(count, uint64_t(1) << 21);        /* 64 MiB of splats */
+    mlsgpu_splat *pinned[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int rc = MLSGPU_OK;
+    for (int b = 0; b < 2 && rc == MLSGPU_OK; b++)
+        if (hipHostMalloc((void **) &pinned[b], batch * sizeof(mlsgpu_splat)) != hipSuccess
+            || hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess)
+            rc = setError(MLSGPU_ERR_NOMEM, "ply load: cannot allocate the pinned buffers");
+    bool busy[2] = {false, false};
+    int cur = 0;
+    for (uint64_t at = 0; at < count && rc == MLSGPU_OK; at += batch)
+    {
+        const uint64_t n = std::min(batch, count - at);
+        if (busy[cur] && hipEventSynchronize(done[cur]) != hipSuccess)
+            rc = setError(MLSGPU_ERR_HIP, "ply load: waiting for the previous copy failed");
+        if (rc == MLSGPU_OK)
+            rc = decodeParallel(r, first + at, n, pinned[cur], hostThreads == 0 ? 4u : hostThreads);
+        if (rc == MLSGPU_OK
+            && (hipMemcpyAsync(dOut + at, pinned[cur], n * sizeof(mlsgpu_splat), hipMemcpyHostToDevice, ctx->stream) != hipSuccess
+                || hipEventRecord(done[cur], ctx->stream) != hipSuccess))
+            rc = setError(MLSGPU_ERR_HIP, "ply load: the host-to-device copy failed");
+        busy[cur] = true;
+        cur ^= 1;
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == MLSGPU_OK)
+        rc = setError(MLSGPU_ERR_HIP, "ply load: synchronise failed");
+    for (int b = 0; b < 2; b++)
+    {
+        if (pinned[b]) hipHostFree(pinned[b]);
+        if (done[b]) hipEventDestroy(done[b]);
+    }
+    return rc;
 }
