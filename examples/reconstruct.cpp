@@ -2,7 +2,7 @@
  * PLY of splats in, PLY mesh out, everything between on the device: the in-core shape of the reference's main
  * pipeline (src/mlsgpu_core.cpp:560-760: load -> bounding grid -> Bucket::bucket -> BucketLoader -> device worker ->
  * mesher -> FastPly::Writer) with this repository's pieces:
- *   FastPly::Reader      mlsgpu_hip_ply_*            (host)
+ *   FastPly::Reader      mlsgpu_hip_ply_open / _load (host threads decode while batches travel to the device)
  *   bounding grid        mlsgpu_hip_bounding_grid    (device reduction)
  *   Bucket::bucket       mlsgpu::hip::Bucket::bucket (device)
  *   BucketLoader + CopyGroup + DeviceWorkerGroup   mlsgpu_hip_farm_submit_device (device gather + transform into a
@@ -41,20 +41,21 @@ int main(int argc, char **argv)
     {
         mlsgpu_ply_reader *reader = NULL;
         check(mlsgpu_hip_ply_open(argv[1], smooth, std::numeric_limits<float>::infinity(), &reader));
-        std::vector<Splat> host(mlsgpu_hip_ply_size(reader));
-        check(mlsgpu_hip_ply_read(reader, 0, host.size(), host.data()));
-        mlsgpu_hip_ply_close(reader);
-        if (host.empty())
+        const std::uint64_t numSplats = mlsgpu_hip_ply_size(reader);
+        if (numSplats == 0)
         {
             std::cerr << "no splats\n";
+            mlsgpu_hip_ply_close(reader);
             return 1;
         }
-
         Context ctx(0);
-        Buffer<Splat> cloud(ctx, host.size());
-        cloud.write(host.data(), host.size());
+        Buffer<Splat> cloud(ctx, numSplats);
+        // file -> HBM: threaded decode overlapped with the host-to-device copies, no host copy of the whole cloud
+        const int loaded = mlsgpu_hip_ply_load(reader, ctx.get(), 0, numSplats, cloud.get(), 0);
+        mlsgpu_hip_ply_close(reader);
+        check(loaded);
         Bucket::Grid grid;
-        check(mlsgpu_hip_bounding_grid(ctx.get(), cloud.get(), host.size(), spacing, microCells, &grid));
+        check(mlsgpu_hip_bounding_grid(ctx.get(), cloud.get(), numSplats, spacing, microCells, &grid));
 
         mlsgpu_farm_config fcfg;
         std::memset(&fcfg, 0, sizeof(fcfg));
@@ -87,7 +88,7 @@ int main(int argc, char **argv)
         std::size_t bins = 0;
         try
         {
-            Bucket::bucket(ctx, cloud, host.size(), grid, maxSplats, maxCells, 0, microCells, std::uint64_t(1) << 30,
+            Bucket::bucket(ctx, cloud, numSplats, grid, maxSplats, maxCells, 0, microCells, std::uint64_t(1) << 30,
                            [&](const Bucket::Bin &bin)
             {
                 std::int32_t low[3];
@@ -113,8 +114,8 @@ int main(int argc, char **argv)
                                                std::vector<std::string>(1, "mlsgpu-hip example: reconstruct"));
         std::uint64_t st[8];
         mesher.getStatistics(st);
-        std::printf("splats %zu grid %d..%d %d..%d %d..%d bins %zu files %zu vertices %llu triangles %llu components %llu kept %llu\n",
-                    host.size(), grid.extents[0], grid.extents[1], grid.extents[2], grid.extents[3], grid.extents[4],
+        std::printf("splats %llu grid %d..%d %d..%d %d..%d bins %zu files %zu vertices %llu triangles %llu components %llu kept %llu\n",
+                    (unsigned long long) numSplats, grid.extents[0], grid.extents[1], grid.extents[2], grid.extents[3], grid.extents[4],
                     grid.extents[5], bins, files, (unsigned long long) st[4], (unsigned long long) st[5],
                     (unsigned long long) st[2], (unsigned long long) st[3]);
     }
