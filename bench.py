@@ -319,10 +319,13 @@ def main():
         sink.reserve(mc["welded"] + 1024, mc["indices"] // 3 + 1024, mc["external"] + 1024)   # counts of the stats pass
         work.copy_from(pristine)
         ctx.synchronize()
+        def sink_share(k):
+            col = sink.collector(ctxs[k], 0)
+            for b in farm.worker_share(buckets, k, nworkers):
+                workers[k].process(work, b.first, b.count, b.low, b.num_vertices, collector=col)
+            ctxs[k].synchronize()
         t0 = time.perf_counter()
-        for b in buckets:
-            workers[0].process(work, b.first, b.count, b.low, b.num_vertices, collector=sink.collector(ctxs[0], 0))
-        ctxs[0].synchronize()
+        list(pool.map(sink_share, range(nworkers)))
         add_s = time.perf_counter() - t0
         t0 = time.perf_counter()
         nchunks = sink.finalize()
@@ -335,7 +338,8 @@ def main():
             "vertices_added": st["vertices_added"], "triangles_added": st["triangles_added"],
             "welded_vertices": st["total_vertices"], "components": st["components"], "kept_components": st["kept_components"],
             "kept_vertices": st["kept_vertices"], "kept_triangles": st["kept_triangles"],
-            "note": "one worker; meshes never leave HBM; finalize = key sort + union-find + sizes + two compaction scans",
+            "device_workers": nworkers,
+            "note": "meshes never leave HBM; finalize = key sort + union-find + sizes + two compaction scans",
         }
         sink.close()
 
