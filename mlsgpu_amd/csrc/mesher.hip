@@ -111,32 +111,13 @@ __device__ __forceinline__ uint32_t loadParent(const uint32_t *parent, uint32_t 
     return __hip_atomic_load(&parent[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-/* Root of v while other workgroups are hooking.  A parent only ever changes from "itself" to a smaller vertex of the
- * same set, so a stale cached value is still an ancestor: the chain is followed with ordinary (cached) loads and only
- * an apparent root is confirmed at the coherence point. */
 __device__ __forceinline__ uint32_t findRoot(const uint32_t *parent, uint32_t v)
 {
-    while (true)
-    {
-        uint32_t p = parent[v];
-        if (p == v)
-        {
-            p = loadParent(parent, v);
-            if (p == v)
-                return v;
-        }
-        v = p;
-    }
-}
-
-/* the same after the union kernel has finished: nothing changes any more */
-__device__ __forceinline__ uint32_t findRootFinal(const uint32_t *parent, uint32_t v)
-{
-    uint32_t p = parent[v];
+    uint32_t p = loadParent(parent, v);
     while (p != v)
     {
         v = p;
-        p = parent[v];
+        p = loadParent(parent, v);
     }
     return v;
 }
@@ -178,7 +159,7 @@ __global__ void compressKernel(uint32_t *parent, const uint32_t *compRep, uint64
 {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n)
-        root[i] = findRootFinal(parent, compRep[i]);
+        root[i] = findRoot(parent, compRep[i]);
 }
 
 /* vertices of a component: every welded vertex once.  Neighbouring vertices mostly share their component (a noise
