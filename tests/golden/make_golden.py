@@ -68,12 +68,45 @@ def run_case(spec):
     )
 
 
+def partition_case():
+    """Bucket::bucket oracle on a seeded cloud: leaves as extents + SHA-256 of the member ids."""
+    from bucket_checks import random_case
+    splats, grid, p = random_case(4)
+    leaves = ob_module().bucket_partition(splats, grid["reference"], grid["spacing"], grid["extents"], p["max_splats"],
+                                          p["max_cells"], p["chunk_cells"], p["micro_cells"], p["max_split"])
+    h = hashlib.sha256()
+    for leaf in leaves:
+        h.update(np.asarray(leaf["extents"], np.int64).tobytes())
+        h.update(np.asarray(leaf["chunk"], np.uint64).tobytes())
+        h.update(np.ascontiguousarray(leaf["ids"], np.uint64).tobytes())
+    return dict(leaves=len(leaves), members=int(sum(len(l["ids"]) for l in leaves)), digest=h.hexdigest(),
+                first_extents=[int(v) for v in leaves[0]["extents"]])
+
+
+def sink_case():
+    """Mesh-sink oracle on the reference's prune fixture: statistics and canonical mesh digest."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "oracle"))
+    import mesher_oracle as mo
+    from mesher_cases import CASES as MC
+    out, stats = mo.mesh_sink(MC["prune"]["meshes"], MC["prune"]["prune"])
+    v, t = mo.canonical(out[0][1], out[0][2])
+    h = hashlib.sha256(np.ascontiguousarray(v).tobytes() + np.ascontiguousarray(t, np.int64).tobytes())
+    return dict(stats=stats, vertices=len(v), triangles=len(t), digest=h.hexdigest())
+
+
+def ob_module():
+    import oracle_binding as ob
+    return ob
+
+
 def main():
     out = {name: run_case(spec) for name, spec in sorted(CASES.items())}
+    out["_partition_random4"] = partition_case()
+    out["_sink_prune"] = sink_case()
     with open(os.path.join(HERE, "oracle_golden.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
         f.write("\n")
-    print(json.dumps({k: (v["digest"][:16], v["vertices"], v["triangles"]) for k, v in out.items()}, indent=1))
+    print(json.dumps({k: (v["digest"][:16], v.get("vertices"), v.get("triangles")) for k, v in out.items()}, indent=1))
 
 
 if __name__ == "__main__":

@@ -38,3 +38,8 @@ def test_hip_matches_golden(name):
     assert make_golden.digest_batches(batches) == gold["digest"]
     del w
     ctx.close()
+
+
+def test_partition_and_sink_oracles_reproduce_golden():
+    assert make_golden.partition_case() == GOLDEN["_partition_random4"]
+    assert make_golden.sink_case() == GOLDEN["_sink_prune"]
