@@ -342,6 +342,23 @@ def main():
             "note": "meshes never leave HBM; finalize = key sort + union-find + sizes + two compaction scans",
         }
         sink.close()
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import mesher_oracle as mo
+            b = buckets[len(buckets) // 2]
+            work.copy_from(pristine)
+            ctx.synchronize()
+            got = workers[0].process(work, b.first, b.count, b.low, b.num_vertices)          # ship-outs copied to the host
+            meshes = [dict(chunk=0, vertices=g["vertices"], num_internal=g["num_internal"], keys=g["keys"][g["num_internal"]:],
+                           triangles=g["triangles"]) for g in got]
+            t0 = time.perf_counter()
+            _, ost = mo.mesh_sink(meshes, 0.02)
+            cpu_s = time.perf_counter() - t0
+            nvs = sum(len(g["vertices"]) for g in got)
+            result["mesh_sink"]["cpu_oracle"] = {
+                "mvertices_per_s": round(nvs / cpu_s / 1e6, 2), "cores": 1, "kind": "port",
+                "sample": "the ship-outs of one of the %d buckets (%d vertices), %.1f s of the numpy/scipy mesh-sink oracle"
+                          % (len(buckets), nvs, cpu_s)}
 
     # ---- device-bucketer leg (never `value`): the RAW cloud resident in HBM, partitioned on the device exactly as
     # the reference's Bucket::bucket would with its defaults (255-cell buckets, 63-cell microblocks, 2 097 152 splats,
@@ -391,6 +408,18 @@ def main():
             "note": "raw cloud resident in HBM -> mlsgpu_hip_bucket (reference partition) -> mlsgpu_hip_farm_submit_device "
                     "(device gather + transform) -> the farm's device workers; bucketing is inside the pipeline time",
         }
+        if not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_binding as ob
+            sample = np.ascontiguousarray(cloud[::10])
+            t0 = time.perf_counter()
+            cpu_leaves = ob.bucket_partition(sample, (0.0, 0.0, 0.0), 1.0, ext, bp["max_splats"] // 10, bp["max_cells"],
+                                             bp["chunk_cells"], bp["micro_cells"], bp["max_split"])
+            cpu_s = time.perf_counter() - t0
+            result["device_partition"]["cpu_oracle"] = {
+                "msplats_per_s": round(len(sample) / cpu_s / 1e6, 2), "cores": 1, "kind": "port", "buckets": len(cpu_leaves),
+                "sample": "every 10th splat (%d) with a tenth of the bucket capacity, %.1f s of the single-threaded "
+                          "bucketing oracle (the reference's bucketing is single-threaded too)" % (len(sample), cpu_s)}
         pfarm.close()
         del raw
     del cloud
