@@ -940,7 +940,7 @@ __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeVie
                                                               const U3 *batchTotals)
 {
     __shared__ uint32_t sIdx[256][MAX_CELL_VERTICES];
-    __shared__ uint16_t sRef[256 * MAX_CELL_INDICES];   /* (thread << 4 | vertex slot): 18 KB instead of 36 KB of indices */
+    __shared__ uint16_t sRef[256 * MAX_CELL_INDICES];   /* thread * 13 + vertex slot: 18 KB instead of 36 KB of indices */
     __shared__ uint32_t sSpan;
     const uint32_t numCells = batchTotals->a;           /* grid covers the host's count; the device value rules */
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -990,15 +990,16 @@ __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeVie
                 sIdx[threadIdx.x][slot++] = idx;
             }
         }
-        const uint32_t tidBits = threadIdx.x << 4;
+        /* a reference is the word index of the vertex's welded index inside sIdx: one LDS read resolves it */
+        const uint32_t first = threadIdx.x * MAX_CELL_VERTICES;
         for (uint32_t q = 0; 4 * q < ni; q++)
         {
             const uint32_t iw = rec[4 + q];
             const uint32_t left = ni - 4 * q;
-            sRef[local + 4 * q] = (uint16_t) (tidBits | (iw & 0xFF));
-            if (left > 1) sRef[local + 4 * q + 1] = (uint16_t) (tidBits | ((iw >> 8) & 0xFF));
-            if (left > 2) sRef[local + 4 * q + 2] = (uint16_t) (tidBits | ((iw >> 16) & 0xFF));
-            if (left > 3) sRef[local + 4 * q + 3] = (uint16_t) (tidBits | (iw >> 24));
+            sRef[local + 4 * q] = (uint16_t) (first + (iw & 0xFF));
+            if (left > 1) sRef[local + 4 * q + 1] = (uint16_t) (first + ((iw >> 8) & 0xFF));
+            if (left > 2) sRef[local + 4 * q + 2] = (uint16_t) (first + ((iw >> 16) & 0xFF));
+            if (left > 3) sRef[local + 4 * q + 3] = (uint16_t) (first + (iw >> 24));
         }
         if (gid == numCells - 1 || threadIdx.x == blockDim.x - 1)
             sSpan = local + ni;
@@ -1007,8 +1008,7 @@ __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeVie
     const uint32_t span = sSpan;
     for (uint32_t k = threadIdx.x; k < span; k += blockDim.x)
     {
-        const uint32_t ref = sRef[k];
-        indices[blockBase + k] = sIdx[ref >> 4][ref & 15];
+        indices[blockBase + k] = (&sIdx[0][0])[sRef[k]];
     }
 }
 
