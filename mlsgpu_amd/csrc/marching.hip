@@ -254,10 +254,18 @@ __global__ __launch_bounds__(256) void cellCodeKernel(uint8_t *codes, U3 *rowCou
     for (uint32_t x0 = 0; x0 < cw; x0 += 64)
     {
         const uint32_t x = x0 + lane;
+        /* corner x of the four corner rows of this cell row; corner x + 1 is the next lane's (lane 63 loads its own) */
+        const uint32_t r0 = y + F.zStride * z + (uint32_t) F.zBias, r1 = r0 + F.zStride;
+        const uint32_t xc = min(x, cw);
+        const float a0 = F.at(xc, r0), a1 = F.at(xc, r0 + 1), a2 = F.at(xc, r1), a3 = F.at(xc, r1 + 1);
+        float b0 = __shfl_down(a0, 1, 64), b1 = __shfl_down(a1, 1, 64), b2 = __shfl_down(a2, 1, 64), b3 = __shfl_down(a3, 1, 64);
+        if (lane == 63 && x < cw)
+        {
+            b0 = F.at(x + 1, r0); b1 = F.at(x + 1, r0 + 1); b2 = F.at(x + 1, r1); b3 = F.at(x + 1, r1 + 1);
+        }
         if (x < cw)
         {
-            float iso[8];
-            loadIso(F, x, y, z, iso);
+            const float iso[8] = {a0, b0, a1, b1, a2, b2, a3, b3};       /* loadIso's order, kernels/marching.cl:95-107 */
             bool valid;
             uint32_t code = cellCode(iso, valid);
             if (!valid || code == 255)
