@@ -164,3 +164,31 @@ def test_bucketer_feeds_the_farm_on_the_device():
     assert nonempty > 8
     farm.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_bounding_grid(seed):
+    """FastBlobSet::makeBoundingGrid (src/splat_set_impl.h:770-811): floor(min(p - r) / spacing) rounded down to a
+    multiple of the bucket size, ceil(max(p + r) / spacing); non-finite splats do not count."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as b
+    rng = np.random.default_rng(seed)
+    n = 100_003
+    s = np.zeros(n, ob.SPLAT_DTYPE)
+    s["position"] = rng.uniform(-37.0, 91.0, (n, 3)).astype(np.float32)
+    s["radius"] = rng.uniform(0.01, 3.0, n).astype(np.float32)
+    s["normal"] = 1.0
+    s["position"][5] = (1e9, np.nan, 0.0)              # ignored
+    s["radius"][77] = np.inf                           # ignored
+    spacing, bucket = np.float32(0.37), 7 + seed
+    ok = np.isfinite(s["position"]).all(axis=1) & np.isfinite(s["radius"])
+    lo = np.floor((s["position"][ok] - s["radius"][ok, None]).min(axis=0) / spacing).astype(np.int64) // bucket * bucket
+    hi = np.ceil((s["position"][ok] + s["radius"][ok, None]).max(axis=0) / spacing).astype(np.int64)
+    ctx = m.Context(0)
+    dev = m.DeviceBuffer(ctx, array=s)
+    ref, sp, ext = b.bounding_grid(ctx, dev, n, float(spacing), bucket)
+    assert ref == (0.0, 0.0, 0.0) and sp == float(spacing)
+    assert ext == (lo[0], hi[0], lo[1], hi[1], lo[2], hi[2])
+    with pytest.raises(m.InvalidArgument):
+        b.bounding_grid(ctx, m.DeviceBuffer(ctx, array=s[5:6]), 1, float(spacing), bucket)     # "Must be at least one splat"
+    ctx.close()
