@@ -281,6 +281,32 @@ int mlsgpu_hip_farm_finish(mlsgpu_farm *farm);
 /* out[0] buckets, [1] splats copied, [2] H2D bytes, [3] device items, [4] ship-outs, [5] vertices, [6] triangles,
  * [7] external vertices; per device d: out[8 + d] = buckets processed there (up to 16 devices). */
 int mlsgpu_hip_farm_stats(mlsgpu_farm *farm, uint64_t out[24]);
+
+/* HostKeyMesh, src/mesh.h:125-179: a ship-out in host memory -- keys of the EXTERNAL vertices only (they are the last
+ * numVertices - numInternalVertices vertices), packed float xyz, uint32 index triplets. */
+typedef struct mlsgpu_host_mesh
+{
+    const uint64_t *vertexKeys;
+    const float *vertices;
+    const uint32_t *triangles;
+    uint64_t numVertices;
+    uint64_t numTriangles;
+    uint64_t numInternalVertices;
+} mlsgpu_host_mesh;
+/* MesherBase::InputFunctor (src/mesher.h:204-210) as the reference's device workers feed it: called on the farm's ONE
+ * mesher thread (MesherGroup, src/workers.cpp:47-85), meshes in the order the ship-outs happened; `mesh` points into
+ * the farm's pinned circular buffer and is valid until the functor returns. */
+typedef int (*mlsgpu_farm_host_output_fn)(void *user, int device, uint64_t chunkId, const mlsgpu_host_mesh *mesh);
+/* Routes every ship-out to the host as the reference does (OutputGeneratorBuilder::Functor, src/workers.h:488-509):
+ * room in a pinned circular buffer of ringBytes (MesherGroup::meshBuffer, --mem-mesh; the worker blocks while it is
+ * full), enqueueReadMesh (src/mesh.cpp:62-102) asynchronously on the worker's stream -- the worker goes on with the
+ * next bucket -- and `fn` on the mesher thread once the reads have completed.  fn may be NULL (meshes are read back and
+ * dropped).  Works for any number of GPUs: this is the path that brings buckets of different devices to ONE welder
+ * (mlsgpu_hip_host_mesher_*).  Call before the first bucket is submitted; a device-side output functor given to
+ * mlsgpu_hip_farm_create still runs first.  A ship-out larger than ringBytes is MLSGPU_ERR_LENGTH. */
+int mlsgpu_hip_farm_set_host_output(mlsgpu_farm *farm, uint64_t ringBytes, mlsgpu_farm_host_output_fn fn, void *user);
+/* out[0] meshes read back, [1] bytes, [2] times a worker waited for ring space, [3] largest mesh in bytes */
+int mlsgpu_hip_farm_host_stats(mlsgpu_farm *farm, uint64_t out[4]);
 /* BucketLoader's world -> grid transform (src/bucket_loader.cpp:77-85, Grid::worldToVertex src/grid.cpp:99-106):
  * position = (position - reference) * (1/spacing) - lowExtent, radius *= 1/spacing.  Host-side, in place. */
 void mlsgpu_hip_transform_splats(mlsgpu_splat *hSplats, uint64_t numSplats, const float reference[3], float spacing,
@@ -330,9 +356,11 @@ int mlsgpu_hip_bucket_load(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, const u
                            const mlsgpu_grid *fullGrid, mlsgpu_splat *dOut);
 
 /* A bucket whose splats are already on GPU `device` (one of the farm's), e.g. from mlsgpu_hip_bucket's callback: the
- * device item is filled by mlsgpu_hip_bucket_load (gather of dIds + transform into fullGrid's vertex coordinates) on the
- * group's copy stream -- no host copy.  dIds may be reused when the call returns.  lowExtent / numVertices as for
- * mlsgpu_hip_worker_process.  */
+ * device item is filled by mlsgpu_hip_bucket_load (gather of dIds + transform into fullGrid's vertex coordinates) --
+ * no host copy.  Like a host bucket it goes to the device group with the most unallocated capacity
+ * (src/workers.cpp:320-351), `device`'s own on a tie: for another GPU the gather runs on `device` and the item is
+ * filled by a peer copy, so a cloud resident on one GPU feeds all of them.  dIds may be reused when the call returns.
+ * lowExtent / numVertices as for mlsgpu_hip_worker_process.  */
 int mlsgpu_hip_farm_submit_device(mlsgpu_farm *farm, int device, const mlsgpu_splat *dSplats, const uint32_t *dIds,
                                   uint64_t numSplats, const mlsgpu_grid *fullGrid, const int32_t lowExtent[3],
                                   const uint32_t numVertices[3], uint64_t chunkId);
@@ -348,9 +376,10 @@ int mlsgpu_hip_mesher_set_prune_threshold(mlsgpu_mesher *mesher, double threshol
  * otherwise). */
 int mlsgpu_hip_mesher_reserve(mlsgpu_mesher *mesher, uint64_t numVertices, uint64_t numTriangles, uint64_t numExternal);
 /* MesherBase::InputFunctor for a DeviceKeyMesh: appends a copy of the mesh (device to device, on `from`'s stream, which
- * is synchronised before returning: Marching reuses the mesh).  Thread safe; `from` is the calling worker's context on
- * the mesher's device.  The blocks of one chunk must arrive contiguously ("chunks must be in order", src/mesher.h:190-193);
- * blocks within a chunk in any order. */
+ * is synchronised before returning: Marching reuses the mesh).  Thread safe; `from` is the calling worker's context, on
+ * the mesher's device or on ANOTHER GPU (then the append is a peer copy over the fabric: several GPUs' buckets welded
+ * in one GPU's HBM).  Blocks may arrive in any order, chunk ids interleaved (OOCMesher::add indexes chunks[chunkId.gen]
+ * and accepts any arrival order too); output chunks are in order of first arrival. */
 int mlsgpu_hip_mesher_add(mlsgpu_mesher *mesher, mlsgpu_ctx *from, uint64_t chunkId, const mlsgpu_mesh *mesh);
 /* What MesherBase::write does before it writes files: weld by key, components, prune.  *numChunks = chunks that have
  * triangles (no output is produced for the others, src/mesher.cpp:820). */
@@ -363,6 +392,28 @@ int mlsgpu_hip_mesher_chunk(mlsgpu_mesher *mesher, uint32_t i, uint64_t *chunkId
 /* getStatistics (src/mesher.cpp:491-536): out[0] welded vertices, [1] threshold, [2] components, [3] kept components,
  * [4] kept vertices (each welded vertex once), [5] kept triangles, [6] vertices added, [7] triangles added */
 int mlsgpu_hip_mesher_stats(mlsgpu_mesher *mesher, uint64_t out[8]);
+/* ---- host mesh sink: OOCMesher's weld as the reference runs it, on the host (src/mesher.cpp:220-469, north_star:
+ *      "welding stays on host").  add() is MesherBase::InputFunctor: local components of the block by union-find over
+ *      two edges per triangle (computeLocalComponents, :220-236), clumps merged across blocks through the external
+ *      keys (updateClumpKeyMap, :286-311); finalize() applies the prune rule of getStatistics (:491-536) and lays out
+ *      one mesh per chunk in which a key appears once (externalRemap, :538-567).  Meshes of ANY device can be added --
+ *      it is the cross-GPU welder behind mlsgpu_hip_farm_set_host_output.  In memory: no temporary files, no reorder
+ *      buffer; chunk ids may arrive interleaved.  add() is serialised by an internal mutex. ---- */
+typedef struct mlsgpu_host_mesher mlsgpu_host_mesher;
+int mlsgpu_hip_host_mesher_create(mlsgpu_host_mesher **out);
+void mlsgpu_hip_host_mesher_destroy(mlsgpu_host_mesher *mesher);
+int mlsgpu_hip_host_mesher_set_prune_threshold(mlsgpu_host_mesher *mesher, double threshold);
+int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *mesher, uint64_t chunkId, const mlsgpu_host_mesh *mesh);
+/* a mlsgpu_farm_host_output_fn whose `user` is the mlsgpu_host_mesher */
+int mlsgpu_hip_host_mesher_farm_output(void *mesher, int device, uint64_t chunkId, const mlsgpu_host_mesh *mesh);
+int mlsgpu_hip_host_mesher_finalize(mlsgpu_host_mesher *mesher, uint32_t *numChunks);
+/* Output chunk i (chunks in order of first arrival, those without triangles skipped): host pointers, valid until the
+ * next add / finalize / destroy; indices relative to the chunk's first vertex. */
+int mlsgpu_hip_host_mesher_chunk(mlsgpu_host_mesher *mesher, uint32_t i, uint64_t *chunkId, uint64_t *numVertices,
+                                 uint64_t *numTriangles, const float **vertices, const uint32_t **triangles);
+/* as mlsgpu_hip_mesher_stats */
+int mlsgpu_hip_host_mesher_stats(mlsgpu_host_mesher *mesher, uint64_t out[8]);
+
 /* FastPly::Writer's file from host memory (src/fast_ply.cpp:443-521): binary little endian, header padded to 4 bytes,
  * float32 x y z, faces as uint8 3 + 3 x uint32 */
 int mlsgpu_hip_write_ply(const char *path, const float *vertices, uint64_t numVertices, const uint32_t *triangles,

@@ -5,8 +5,8 @@ classes in ``mlsgpu_amd/host`` that mirror the reference's call surface.  This P
 a thin ctypes binding of the same C-ABI, used by the tests and by bench.py.  There is no CPU
 fallback: importing :mod:`mlsgpu_amd.binding` without the built library raises.
 """
-from .binding import (BucketFarm, Context, DensityError, DeviceBuffer, FormatError, HipError, InvalidArgument, LengthError, Marching, Mesher, MlsError,
+from .binding import (BucketFarm, Context, DensityError, DeviceBuffer, FormatError, HipError, HostMesher, InvalidArgument, LengthError, Marching, Mesher, MlsError,
                       MlsFunctor, SPLAT_DTYPE, SplatTree, Swathe, Worker, WorkerConfig, lib, library_path)
 
-__all__ = ["BucketFarm", "Context", "DensityError", "DeviceBuffer", "FormatError", "HipError", "InvalidArgument", "LengthError", "Marching", "Mesher", "MlsError",
+__all__ = ["BucketFarm", "Context", "DensityError", "DeviceBuffer", "FormatError", "HipError", "HostMesher", "InvalidArgument", "LengthError", "Marching", "Mesher", "MlsError",
            "MlsFunctor", "SPLAT_DTYPE", "SplatTree", "Swathe", "Worker", "WorkerConfig", "lib", "library_path"]

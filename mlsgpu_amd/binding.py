@@ -56,6 +56,12 @@ ENQUEUE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64
 OUTPUT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(Mesh))
 
 
+class HostMesh(C.Structure):
+    """HostKeyMesh, src/mesh.h:125-179 (mlsgpu_host_mesh)."""
+    _fields_ = [("vertexKeys", C.c_void_p), ("vertices", C.c_void_p), ("triangles", C.c_void_p),
+                ("numVertices", C.c_uint64), ("numTriangles", C.c_uint64), ("numInternalVertices", C.c_uint64)]
+
+
 class Generator(C.Structure):
     """Marching::Generator, src/marching.h:204-253."""
     _fields_ = [("alignment", C.c_uint32 * 3), ("enqueue", ENQUEUE_FN), ("user", C.c_void_p)]
@@ -91,6 +97,7 @@ class FarmConfig(C.Structure):
 
 
 FARM_OUTPUT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(Mesh))
+FARM_HOST_OUTPUT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.POINTER(HostMesh))
 
 
 def library_path():
@@ -185,6 +192,15 @@ def lib():
     sig("mlsgpu_hip_farm_submit_device", C.c_int, vp, C.c_int, vp, vp, u64, P(GridStruct), vp, vp, u64)
     sig("mlsgpu_hip_farm_finish", C.c_int, vp)
     sig("mlsgpu_hip_farm_stats", C.c_int, vp, vp)
+    sig("mlsgpu_hip_farm_set_host_output", C.c_int, vp, u64, vp, vp)
+    sig("mlsgpu_hip_farm_host_stats", C.c_int, vp, vp)
+    sig("mlsgpu_hip_host_mesher_create", C.c_int, P(vp))
+    sig("mlsgpu_hip_host_mesher_destroy", None, vp)
+    sig("mlsgpu_hip_host_mesher_set_prune_threshold", C.c_int, vp, C.c_double)
+    sig("mlsgpu_hip_host_mesher_add", C.c_int, vp, u64, P(HostMesh))
+    sig("mlsgpu_hip_host_mesher_finalize", C.c_int, vp, P(u32))
+    sig("mlsgpu_hip_host_mesher_chunk", C.c_int, vp, u32, P(u64), P(u64), P(u64), P(vp), P(vp))
+    sig("mlsgpu_hip_host_mesher_stats", C.c_int, vp, vp)
     sig("mlsgpu_hip_transform_splats", None, vp, u64, vp, f32, vp)
     sig("mlsgpu_hip_ply_open", C.c_int, C.c_char_p, f32, f32, P(vp))
     sig("mlsgpu_hip_ply_close", None, vp)
@@ -290,8 +306,13 @@ class Context:
 class DeviceBuffer:
     """A device allocation (cl::Buffer)."""
 
-    def __init__(self, ctx, nbytes=0, array=None, fill=None):
+    def __init__(self, ctx, nbytes=0, array=None, fill=None, borrow=None):
         self.ctx = ctx
+        self.owned = borrow is None
+        if borrow is not None:
+            # memory that someone else owns (e.g. a torch tensor's data_ptr() on the same device); never freed here
+            self.ptr, self.nbytes = int(borrow), int(nbytes)
+            return
         if array is not None:
             array = np.ascontiguousarray(array)
             nbytes = array.nbytes
@@ -324,9 +345,9 @@ class DeviceBuffer:
         check(lib().mlsgpu_hip_memcpy_d2d(self.ctx.h, self.ptr, other.ptr, self.nbytes if nbytes is None else nbytes))
 
     def free(self):
-        if self.ptr:
+        if self.ptr and self.owned:
             lib().mlsgpu_hip_free(self.ctx.h, self.ptr)
-            self.ptr = None
+        self.ptr = None
 
     def __del__(self):
         try:
@@ -565,6 +586,77 @@ class MesherCollector:
                 self.error = e
                 return 1
         self.cb = OUTPUT_FN(cb)
+
+
+def host_mesh_arrays(hm):
+    """numpy COPIES of a mlsgpu_host_mesh (the memory behind it is only valid during the callback)."""
+    nv, nt, ni = int(hm.numVertices), int(hm.numTriangles), int(hm.numInternalVertices)
+
+    def view(ptr, dtype, count):
+        if count == 0:
+            return np.zeros(0, dtype)
+        buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr)
+        return np.frombuffer(buf, dtype=dtype, count=count).copy()
+    keys = np.zeros(nv, np.uint64)
+    keys[ni:] = view(hm.vertexKeys, np.uint64, nv - ni)
+    return dict(vertices=view(hm.vertices, np.float32, 3 * nv).reshape(nv, 3), keys=keys,
+                triangles=view(hm.triangles, np.uint32, 3 * nt).reshape(nt, 3), num_internal=ni)
+
+
+class HostMesher:
+    """OOCMesher's weld on the host (src/mesher.cpp:220-469), in memory: the cross-GPU welder behind
+    BucketFarm.set_host_output (include/mlsgpu_hip.h, "host mesh sink")."""
+
+    def __init__(self, prune_threshold=0.0):
+        h = C.c_void_p()
+        check(lib().mlsgpu_hip_host_mesher_create(C.byref(h)))
+        self.h = h
+        check(lib().mlsgpu_hip_host_mesher_set_prune_threshold(self.h, prune_threshold))
+
+    def add(self, chunk_id, vertices, num_internal, keys, triangles):
+        """keys: the external vertices' keys (len(vertices) - num_internal of them)."""
+        v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        k = np.ascontiguousarray(keys, np.uint64)
+        assert len(k) == len(v) - num_internal
+        hm = HostMesh(k.ctypes.data, v.ctypes.data, t.ctypes.data, len(v), len(t), num_internal)
+        check(lib().mlsgpu_hip_host_mesher_add(self.h, chunk_id, C.byref(hm)))
+
+    def finalize(self):
+        n = C.c_uint32()
+        check(lib().mlsgpu_hip_host_mesher_finalize(self.h, C.byref(n)))
+        return n.value
+
+    def chunk(self, i):
+        cid, nv, nt = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        pv, pt = C.c_void_p(), C.c_void_p()
+        check(lib().mlsgpu_hip_host_mesher_chunk(self.h, i, C.byref(cid), C.byref(nv), C.byref(nt), C.byref(pv), C.byref(pt)))
+
+        def view(ptr, dtype, count):
+            if count == 0:
+                return np.zeros(0, dtype)
+            buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(ptr.value)
+            return np.frombuffer(buf, dtype=dtype, count=count).copy()
+        return (int(cid.value), view(pv, np.float32, 3 * nv.value).reshape(-1, 3),
+                view(pt, np.uint32, 3 * nt.value).reshape(-1, 3))
+
+    def stats(self):
+        out = np.zeros(8, np.uint64)
+        check(lib().mlsgpu_hip_host_mesher_stats(self.h, _p(out)))
+        names = ["total_vertices", "threshold", "components", "kept_components", "kept_vertices", "kept_triangles",
+                 "vertices_added", "triangles_added"]
+        return dict(zip(names, [int(x) for x in out]))
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mlsgpu_hip_host_mesher_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PlyReader:
@@ -844,6 +936,33 @@ class BucketFarm:
         g = _grid_struct(reference, spacing, extents)
         check(lib().mlsgpu_hip_farm_submit_device(self.h, device, d_splats.ptr, d_ids_ptr, num_splats, C.byref(g),
                                                   _p(_i3(low_extent)), _p(_u3(num_vertices)), chunk_id))
+
+    def set_host_output(self, ring_bytes, sink=None):
+        """Every ship-out is read back through a pinned circular buffer of `ring_bytes` and handed to ONE mesher thread
+        (OutputGeneratorBuilder::Functor + MesherGroup, src/workers.h:488-509, src/workers.cpp:47-85).  `sink`: None
+        (read back and dropped), a HostMesher (welded on the host, in C++), or a callable(device, chunk_id, batch) that
+        receives numpy copies."""
+        self._host_sink = sink
+        fn, user = None, None
+        if isinstance(sink, HostMesher):
+            fn = C.cast(lib().mlsgpu_hip_host_mesher_farm_output, C.c_void_p)
+            user = sink.h
+        elif sink is not None:
+            def cb(_user, device, chunk, hm):
+                try:
+                    sink(device, int(chunk), host_mesh_arrays(hm.contents))
+                    return 0
+                except Exception as e:   # never let an exception cross the C boundary
+                    self.error = e
+                    return 1
+            self._host_cb = FARM_HOST_OUTPUT_FN(cb)
+            fn = C.cast(self._host_cb, C.c_void_p)
+        check(lib().mlsgpu_hip_farm_set_host_output(self.h, ring_bytes, fn, user))
+
+    def host_stats(self):
+        out = np.zeros(4, np.uint64)
+        check(lib().mlsgpu_hip_farm_host_stats(self.h, _p(out)))
+        return dict(zip(["meshes", "bytes", "ring_waits", "largest_mesh_bytes"], [int(x) for x in out]))
 
     def finish(self):
         rc = lib().mlsgpu_hip_farm_finish(self.h)

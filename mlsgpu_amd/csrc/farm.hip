@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
 #include <deque>
 #include <memory>
 #include <mutex>
@@ -53,6 +54,20 @@ struct DeviceGroup               /* DeviceWorkerGroup, src/workers.h:214-350 */
     uint64_t unallocated = 0;
     uint64_t bucketsDone = 0;
     std::vector<std::thread> threads;
+    std::vector<hipEvent_t> eventPool;   /* read-back events of this device (guarded by the farm's mutex) */
+    mlsgpu_splat *peerScratch = nullptr; /* a bucket gathered here before it is peer-copied to another GPU's item */
+};
+
+/* One ship-out on its way to the host: OutputGeneratorBuilder::Functor's MesherGroup::WorkItem, src/workers.h:488-509 */
+struct HostSlot
+{
+    uint64_t offset = 0, bytes = 0;      /* the slot's bytes in the ring, padding at the wrap included in `bytes` */
+    int device = 0;
+    uint64_t chunkId = 0;
+    mlsgpu_host_mesh mesh;
+    hipEvent_t done = nullptr;
+    DeviceGroup *group = nullptr;
+    bool ready = false;                  /* the reads and `done` have been enqueued */
 };
 
 struct Farm
@@ -61,25 +76,47 @@ struct Farm
     mlsgpu_farm_output_fn output = nullptr;
     void *user = nullptr;
     std::vector<std::unique_ptr<DeviceGroup> > groups;
-    std::mutex mutex;                    /* guards pools, queues, counters, error */
+    std::mutex mutex;                    /* guards pools, queues, counters, error, the host ring */
     std::condition_variable popCond;     /* an item went back to some pool (popCondition in the reference) */
     std::condition_variable queueCond;   /* an item was pushed / stopping */
-    std::condition_variable idleCond;    /* a bucket finished */
+    std::condition_variable idleCond;    /* a bucket finished / a host mesh was consumed */
     bool stopping = false;
     int error = MLSGPU_OK;
     std::string errorText;
     uint64_t inFlightItems = 0;
 
-    /* staging (CopyGroupBase::Worker: pinned + bufferedItems + bufferedSplats) */
-    mlsgpu_splat *pinned[2] = {nullptr, nullptr};
-    hipEvent_t pinnedFree[2] = {nullptr, nullptr};   /* the copy out of this buffer has completed */
-    bool pinnedBusy[2] = {false, false};
-    int cur = 0;
+    /* staging (CopyGroupBase::Worker: pinned + bufferedItems + bufferedSplats).  A ring of numDevices + 1 (at least
+     * two) portable pinned buffers: while one is being filled, one copy per GPU can be in flight, each on its own
+     * device's copy stream (the reference has one buffer and waits for its copy, src/workers.cpp:367-372).  A buffer
+     * is free again once the copy event of the item it was sent to has completed; that event was created on the
+     * item's device, so no event is ever recorded on another device's stream. */
+    struct Staging
+    {
+        mlsgpu_splat *ptr = nullptr;
+        hipEvent_t busy = nullptr;       /* WorkItem::copyEvent of the last copy out of this buffer, or null */
+    };
+    std::vector<Staging> staging;
+    size_t cur = 0;
     std::vector<SubItem> bufferedItems;
     uint64_t bufferedSplats = 0;
     uint64_t acquired = 0;          /* splats handed out by acquire and not pushed yet */
 
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    /* host output: ship-outs are read back asynchronously on the worker's stream into a pinned circular buffer
+     * (MesherGroup::meshBuffer, --mem-mesh) and consumed in arrival order by ONE mesher thread
+     * (MesherGroup, src/workers.cpp:47-85). */
+    bool hostOutput = false;
+    mlsgpu_farm_host_output_fn hostFn = nullptr;
+    void *hostUser = nullptr;
+    char *ring = nullptr;
+    uint64_t ringBytes = 0, ringHead = 0, ringUsed = 0;   /* in use: the ringUsed bytes that end at ringHead */
+    std::deque<HostSlot *> hostQueue;
+    std::condition_variable hostCond;    /* a slot became ready / stopping */
+    std::condition_variable ringCond;    /* ring space was released */
+    std::thread mesherThread;
+    uint32_t liveWorkers = 0;            /* the mesher thread outlives every thread that can still queue a slot */
+    uint64_t hostStats[4] = {0, 0, 0, 0};   /* meshes, bytes read back, waits for ring space, largest mesh */
 
     void fail(int code, const char *text)
     {
@@ -93,6 +130,8 @@ struct Farm
         queueCond.notify_all();
         popCond.notify_all();
         idleCond.notify_all();
+        hostCond.notify_all();
+        ringCond.notify_all();
     }
 };
 
@@ -111,6 +150,86 @@ struct OutputThunk
     uint64_t chunkId;
 };
 
+/* The ship-out goes to the host: room in the circular buffer (blocking while it is full, as
+ * CircularBuffer::allocate does), enqueueReadMesh on the worker's own stream, an event behind the reads.  The
+ * worker does not wait: Marching's next kernels are behind the reads in stream order, and the mesher thread waits
+ * for the event (MesherGroup's verticesEvent / vertexKeysEvent / trianglesEvent). */
+int hostReadBack(OutputThunk *t, const mlsgpu_mesh *mesh)
+{
+    Farm *f = t->farm;
+    const uint64_t need = (mlsgpu_hip_mesh_host_bytes(mesh) + 63) & ~uint64_t(63);
+    if (need > f->ringBytes)
+        return setError(MLSGPU_ERR_LENGTH, "farm: a ship-out of %llu bytes does not fit the host mesh buffer of %llu",
+                        (unsigned long long) need, (unsigned long long) f->ringBytes);
+    std::unique_ptr<HostSlot> slot(new HostSlot);
+    HostSlot *s = slot.get();
+    {
+        std::unique_lock<std::mutex> l(f->mutex);
+        bool waited = false;
+        for (;;)
+        {
+            if (f->error != MLSGPU_OK)
+                return setError(f->error, "%s", f->errorText.c_str());
+            /* contiguous room at the head, or after wrapping (the skipped tail end is charged to this slot) */
+            const uint64_t toEnd = f->ringBytes - f->ringHead;
+            const uint64_t pad = need <= toEnd ? 0 : toEnd;
+            if (f->ringUsed + pad + need <= f->ringBytes)
+            {
+                s->offset = pad ? 0 : f->ringHead;
+                s->bytes = pad + need;
+                f->ringHead = (s->offset + need) % f->ringBytes;
+                f->ringUsed += s->bytes;
+                break;
+            }
+            if (!waited)
+                f->hostStats[2]++;
+            waited = true;
+            f->ringCond.wait(l);
+        }
+        if (!t->group->eventPool.empty())
+        {
+            s->done = t->group->eventPool.back();
+            t->group->eventPool.pop_back();
+        }
+        s->device = t->group->device;
+        s->group = t->group;
+        s->chunkId = t->chunkId;
+        f->hostQueue.push_back(slot.release());         /* arrival order = allocation order = release order */
+        f->hostStats[0]++;
+        f->hostStats[1] += need;
+        f->hostStats[3] = std::max(f->hostStats[3], need);
+    }
+    int rc = MLSGPU_OK;
+    hipStream_t stream = static_cast<hipStream_t>(mlsgpu_hip_ctx_stream(t->ctx));
+    if (s->done == nullptr && hipEventCreateWithFlags(&s->done, hipEventDisableTiming) != hipSuccess)
+        rc = setError(MLSGPU_ERR_HIP, "farm: cannot create a read-back event");
+    char *blob = f->ring + s->offset;
+    const uint64_t ne = mesh->numVertices - mesh->numInternalVertices;
+    s->mesh.vertexKeys = reinterpret_cast<const uint64_t *>(blob);
+    s->mesh.vertices = reinterpret_cast<const float *>(blob + 8 * ne);
+    s->mesh.triangles = reinterpret_cast<const uint32_t *>(blob + 8 * ne + 12 * mesh->numVertices);
+    s->mesh.numVertices = mesh->numVertices;
+    s->mesh.numTriangles = mesh->numTriangles;
+    s->mesh.numInternalVertices = mesh->numInternalVertices;
+    if (rc == MLSGPU_OK)
+        rc = mlsgpu_hip_mesh_read(t->ctx, mesh, blob, 1);
+    if (rc == MLSGPU_OK && hipEventRecord(s->done, stream) != hipSuccess)
+        rc = setError(MLSGPU_ERR_HIP, "farm: cannot record a read-back event");
+    if (rc != MLSGPU_OK)
+    {
+        /* the slot stays queued (the ring is released in order); the mesher thread drops it once the farm has failed */
+        const std::string text = mlsgpu_hip_last_error();
+        f->fail(rc, text.c_str());
+        hipStreamSynchronize(stream);                    /* nothing may still be writing into the ring */
+    }
+    {
+        std::lock_guard<std::mutex> l(f->mutex);
+        s->ready = true;
+    }
+    f->hostCond.notify_all();
+    return rc;
+}
+
 int outputThunk(void *user, void *stream, const mlsgpu_mesh *mesh)
 {
     (void) stream;
@@ -123,8 +242,58 @@ int outputThunk(void *user, void *stream, const mlsgpu_mesh *mesh)
         t->farm->stats[7] += mesh->numVertices - mesh->numInternalVertices;
     }
     if (t->farm->output != nullptr)
-        return t->farm->output(t->farm->user, t->group->device, t->chunkId, t->ctx, mesh);
+        PROPAGATE(t->farm->output(t->farm->user, t->group->device, t->chunkId, t->ctx, mesh));
+    if (t->farm->hostOutput)
+        return hostReadBack(t, mesh);
     return 0;
+}
+
+/* MesherGroupBase::Worker::operator(), src/workers.cpp:47-52: wait for the reads, hand the mesh to the consumer,
+ * give the memory back to the circular buffer */
+void mesherMain(Farm *f)
+{
+    for (;;)
+    {
+        HostSlot *s = nullptr;
+        {
+            std::unique_lock<std::mutex> l(f->mutex);
+            f->hostCond.wait(l, [&] { return (!f->hostQueue.empty() && f->hostQueue.front()->ready)
+                                             || (f->stopping && f->liveWorkers == 0 && f->hostQueue.empty()); });
+            if (f->hostQueue.empty())
+                break;
+            s = f->hostQueue.front();
+        }
+        int rc = MLSGPU_OK;
+        bool failed;
+        {
+            std::lock_guard<std::mutex> l(f->mutex);
+            failed = f->error != MLSGPU_OK;
+        }
+        if (s->done != nullptr && hipEventSynchronize(s->done) != hipSuccess && !failed)
+        {
+            rc = MLSGPU_ERR_HIP;
+            f->fail(rc, "farm: waiting for a mesh read-back failed");
+            failed = true;
+        }
+        if (!failed && f->hostFn != nullptr)
+        {
+            rc = f->hostFn(f->hostUser, s->device, s->chunkId, &s->mesh);
+            if (rc != MLSGPU_OK)
+                f->fail(MLSGPU_ERR_CALLBACK, "farm: the host output functor reported an error");
+        }
+        {
+            std::lock_guard<std::mutex> l(f->mutex);
+            f->hostQueue.pop_front();
+            f->ringUsed -= s->bytes;                    /* slots are released in allocation order */
+            if (f->ringUsed == 0)
+                f->ringHead = 0;
+            if (s->done != nullptr)
+                s->group->eventPool.push_back(s->done);
+        }
+        delete s;
+        f->ringCond.notify_all();
+        f->idleCond.notify_all();
+    }
 }
 
 /* DeviceWorkerGroupBase::Worker::operator(), src/workers.cpp:232-286 */
@@ -139,7 +308,7 @@ void workerMain(Farm *farm, DeviceGroup *g)
     {
         farm->fail(rc, mlsgpu_hip_last_error());
         if (ctx) mlsgpu_hip_ctx_destroy(ctx);
-        return;
+        ctx = nullptr;
     }
     for (;;)
     {
@@ -152,11 +321,21 @@ void workerMain(Farm *farm, DeviceGroup *g)
             item = g->queue.front();
             g->queue.pop_front();
         }
+        /* after a failure the queued items are only handed back, so that finish() and destroy() never wait for them */
+        bool run = ctx != nullptr;
+        {
+            std::lock_guard<std::mutex> l(farm->mutex);
+            run = run && farm->error == MLSGPU_OK;
+        }
         /* wait[0] = work.copyEvent (src/workers.cpp:268) */
-        hipError_t e = hipStreamWaitEvent(static_cast<hipStream_t>(mlsgpu_hip_ctx_stream(ctx)), item->copyEvent, 0);
-        if (e != hipSuccess)
-            farm->fail(MLSGPU_ERR_HIP, hipGetErrorString(e));
-        for (size_t i = 0; i < item->subItems.size() && e == hipSuccess; i++)
+        hipError_t e = hipSuccess;
+        if (run)
+        {
+            e = hipStreamWaitEvent(static_cast<hipStream_t>(mlsgpu_hip_ctx_stream(ctx)), item->copyEvent, 0);
+            if (e != hipSuccess)
+                farm->fail(MLSGPU_ERR_HIP, hipGetErrorString(e));
+        }
+        for (size_t i = 0; run && i < item->subItems.size() && e == hipSuccess; i++)
         {
             const SubItem &sub = item->subItems[i];
             OutputThunk thunk = {farm, g, ctx, sub.chunkId};
@@ -181,8 +360,49 @@ void workerMain(Farm *farm, DeviceGroup *g)
             farm->idleCond.notify_all();
         }
     }
-    mlsgpu_hip_worker_destroy(worker);
-    mlsgpu_hip_ctx_destroy(ctx);
+    if (ctx != nullptr)
+    {
+        mlsgpu_hip_ctx_synchronize(ctx);             /* read-backs still in flight use this stream */
+        mlsgpu_hip_worker_destroy(worker);
+        mlsgpu_hip_ctx_destroy(ctx);
+    }
+    {
+        std::lock_guard<std::mutex> l(farm->mutex);
+        farm->liveWorkers--;
+    }
+    farm->hostCond.notify_all();
+}
+
+/* a failure between taking an item from a pool and queueing it: the item goes back, the accounting is undone and the
+ * farm is marked failed, so that finish() reports the error instead of waiting for an item that will never be done */
+int abandonItem(Farm *f, DeviceGroup *g, WorkItem *item, uint64_t splats, int rc)
+{
+    const std::string text = mlsgpu_hip_last_error();
+    {
+        std::lock_guard<std::mutex> l(f->mutex);
+        item->subItems.clear();
+        g->pool.push_back(item);
+        g->unallocated += splats;
+        f->inFlightItems--;
+    }
+    f->fail(rc, text.c_str());
+    return setError(rc, "%s", text.c_str());
+}
+
+/* among the groups that can take an item now, the one with the most unallocated capacity (flush, src/workers.cpp:
+ * 320-351); `prefer` >= 0 breaks ties in favour of that device.  Called with the mutex held; null if none. */
+DeviceGroup *pickGroup(Farm *f, int prefer)
+{
+    DeviceGroup *out = nullptr;
+    uint64_t best = 0;
+    for (auto &g : f->groups)
+        if (!g->pool.empty()
+            && (out == nullptr || g->unallocated > best || (g->unallocated == best && g->device == prefer && out->device != prefer)))
+        {
+            best = g->unallocated;
+            out = g.get();
+        }
+    return out;
 }
 
 /* CopyGroupBase::Worker::flush, src/workers.cpp:315-375 */
@@ -198,14 +418,7 @@ int flushBatch(Farm *f)
         {
             if (f->error != MLSGPU_OK)
                 return setError(f->error, "%s", f->errorText.c_str());
-            /* among the devices that can take an item now, the one with the most unallocated capacity */
-            uint64_t best = 0;
-            for (auto &g : f->groups)
-                if (!g->pool.empty() && g->unallocated >= best)
-                {
-                    best = g->unallocated;
-                    out = g.get();
-                }
+            out = pickGroup(f, -1);
             if (out != nullptr)
                 break;
             f->popCond.wait(l);
@@ -215,28 +428,43 @@ int flushBatch(Farm *f)
         out->unallocated -= f->bufferedSplats;
         f->inFlightItems++;
     }
+    const uint64_t splats = f->bufferedSplats;
     item->subItems.swap(f->bufferedItems);
-    item->numSplats = f->bufferedSplats;
-    HIP_CHECK(hipSetDevice(out->device));
-    HIP_CHECK(hipMemcpyAsync(item->dSplats, f->pinned[f->cur], f->bufferedSplats * sizeof(mlsgpu_splat),
-                             hipMemcpyHostToDevice, out->copyStream));
-    HIP_CHECK(hipEventRecord(item->copyEvent, out->copyStream));
-    /* the staging buffer is free again once this copy is done; the other buffer is filled meanwhile */
-    HIP_CHECK(hipEventRecord(f->pinnedFree[f->cur], out->copyStream));
-    f->pinnedBusy[f->cur] = true;
+    item->numSplats = splats;
+    f->bufferedItems.clear();
+    f->bufferedSplats = 0;
+    Farm::Staging &st = f->staging[f->cur];
+    hipError_t e = hipSetDevice(out->device);
+    if (e == hipSuccess)
+        e = hipMemcpyAsync(item->dSplats, st.ptr, splats * sizeof(mlsgpu_splat), hipMemcpyHostToDevice, out->copyStream);
+    if (e == hipSuccess)
+        e = hipEventRecord(item->copyEvent, out->copyStream);
+    if (e != hipSuccess)
+    {
+        setError(MLSGPU_ERR_HIP, "farm: host-to-device copy to device %d failed: %s", out->device, hipGetErrorString(e));
+        hipStreamSynchronize(out->copyStream);
+        return abandonItem(f, out, item, splats, MLSGPU_ERR_HIP);
+    }
+    st.busy = item->copyEvent;          /* this buffer is free again once that copy is done */
     {
         std::lock_guard<std::mutex> l(f->mutex);
-        f->stats[2] += f->bufferedSplats * sizeof(mlsgpu_splat);
+        f->stats[2] += splats * sizeof(mlsgpu_splat);
         f->stats[3]++;
         out->queue.push_back(item);                 /* DeviceWorkerGroup::push */
     }
     f->queueCond.notify_all();
-    f->bufferedSplats = 0;
-    f->cur ^= 1;
-    if (f->pinnedBusy[f->cur])
+    /* fill the next buffer of the ring meanwhile; it may still be the source of an older copy */
+    f->cur = (f->cur + 1) % f->staging.size();
+    Farm::Staging &next = f->staging[f->cur];
+    if (next.busy != nullptr)
     {
-        HIP_CHECK(hipEventSynchronize(f->pinnedFree[f->cur]));     /* copyEvent.wait(), src/workers.cpp:367-372 */
-        f->pinnedBusy[f->cur] = false;
+        e = hipEventSynchronize(next.busy);         /* copyEvent.wait(), src/workers.cpp:367-372 */
+        next.busy = nullptr;
+        if (e != hipSuccess)
+        {
+            f->fail(MLSGPU_ERR_HIP, hipGetErrorString(e));
+            return setError(MLSGPU_ERR_HIP, "farm: waiting for a staging buffer failed: %s", hipGetErrorString(e));
+        }
     }
     return MLSGPU_OK;
 }
@@ -259,12 +487,10 @@ MLSGPU_API int mlsgpu_hip_farm_create(const mlsgpu_farm_config *cfg, mlsgpu_farm
     f->user = user;
     const uint64_t cap = cfg->worker.maxBucketSplats;
     int rc = MLSGPU_OK;
-    for (int b = 0; b < 2 && rc == MLSGPU_OK; b++)
-    {
-        if (hipHostMalloc((void **) &f->pinned[b], cap * sizeof(mlsgpu_splat)) != hipSuccess
-            || hipEventCreateWithFlags(&f->pinnedFree[b], hipEventDisableTiming) != hipSuccess)
+    f->staging.resize(std::max<uint32_t>(2, cfg->numDevices + 1));
+    for (size_t b = 0; b < f->staging.size() && rc == MLSGPU_OK; b++)
+        if (hipHostMalloc((void **) &f->staging[b].ptr, cap * sizeof(mlsgpu_splat), hipHostMallocPortable) != hipSuccess)
             rc = setError(MLSGPU_ERR_NOMEM, "farm: cannot allocate pinned staging of %llu splats", (unsigned long long) cap);
-    }
     for (uint32_t d = 0; d < cfg->numDevices && rc == MLSGPU_OK; d++)
     {
         const int dev = cfg->devices ? cfg->devices[d] : (int) d;
@@ -277,6 +503,7 @@ MLSGPU_API int mlsgpu_hip_farm_create(const mlsgpu_farm_config *cfg, mlsgpu_farm
         g->farm = f;
         g->device = dev;
         g->index = d;
+        /* everything below belongs to `dev`: streams, events and items are created with it current */
         if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking) != hipSuccess)
             rc = setError(MLSGPU_ERR_HIP, "farm: cannot create the copy stream on device %d", dev);
         if (rc == MLSGPU_OK)
@@ -299,10 +526,27 @@ MLSGPU_API int mlsgpu_hip_farm_create(const mlsgpu_farm_config *cfg, mlsgpu_farm
         mlsgpu_hip_farm_destroy(f);
         return rc;
     }
+    f->liveWorkers = (uint32_t) f->groups.size() * f->cfg.workersPerDevice;
     for (auto &g : f->groups)
         for (uint32_t w = 0; w < f->cfg.workersPerDevice; w++)
             g->threads.push_back(std::thread(workerMain, static_cast<Farm *>(f), g.get()));
     *out = f;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_farm_set_host_output(mlsgpu_farm *f, uint64_t ringBytes, mlsgpu_farm_host_output_fn fn, void *user)
+{
+    REQUIRE(f != nullptr && ringBytes >= 4096, MLSGPU_ERR_INVALID);
+    REQUIRE(!f->hostOutput, MLSGPU_ERR_INVALID);
+    REQUIRE(f->stats[0] == 0, MLSGPU_ERR_INVALID);          /* before the first bucket */
+    ringBytes = (ringBytes + 63) & ~uint64_t(63);
+    if (hipHostMalloc((void **) &f->ring, ringBytes, hipHostMallocPortable) != hipSuccess)
+        return setError(MLSGPU_ERR_NOMEM, "farm: cannot allocate %llu bytes of pinned mesh buffer", (unsigned long long) ringBytes);
+    f->ringBytes = ringBytes;
+    f->hostFn = fn;
+    f->hostUser = user;
+    f->mesherThread = std::thread(mesherMain, static_cast<Farm *>(f));
+    f->hostOutput = true;
     return MLSGPU_OK;
 }
 
@@ -315,24 +559,30 @@ MLSGPU_API void mlsgpu_hip_farm_destroy(mlsgpu_farm *f)
         f->stopping = true;
     }
     f->queueCond.notify_all();
+    f->hostCond.notify_all();
     for (auto &g : f->groups)
-    {
         for (auto &t : g->threads)
             t.join();
+    f->hostCond.notify_all();
+    if (f->mesherThread.joinable())
+        f->mesherThread.join();
+    for (auto &g : f->groups)
+    {
         hipSetDevice(g->device);
         for (auto &item : g->items)
         {
             hipFree(item->dSplats);
             if (item->copyEvent) hipEventDestroy(item->copyEvent);
         }
+        for (hipEvent_t e : g->eventPool)
+            hipEventDestroy(e);
+        hipFree(g->peerScratch);
         if (g->copyCtx) mlsgpu_hip_ctx_destroy(g->copyCtx);
         if (g->copyStream) hipStreamDestroy(g->copyStream);
     }
-    for (int b = 0; b < 2; b++)
-    {
-        if (f->pinned[b]) hipHostFree(f->pinned[b]);
-        if (f->pinnedFree[b]) hipEventDestroy(f->pinnedFree[b]);
-    }
+    for (auto &st : f->staging)
+        if (st.ptr) hipHostFree(st.ptr);
+    if (f->ring) hipHostFree(f->ring);
     delete f;
 }
 
@@ -345,7 +595,7 @@ MLSGPU_API int mlsgpu_hip_farm_acquire(mlsgpu_farm *f, uint64_t numSplats, mlsgp
     if (f->bufferedSplats + numSplats > f->cfg.worker.maxBucketSplats)
         PROPAGATE(flushBatch(f));
     f->acquired = numSplats;
-    *out = f->pinned[f->cur] + f->bufferedSplats;
+    *out = f->staging[f->cur].ptr + f->bufferedSplats;
     return MLSGPU_OK;
 }
 
@@ -408,8 +658,11 @@ MLSGPU_API int mlsgpu_hip_farm_submit(mlsgpu_farm *f, const mlsgpu_splat *hSplat
     return mlsgpu_hip_farm_push(f, numSplats, lowExtent, numVertices, chunkId);
 }
 
-/* A bucket whose splats are already on `device` (the device bucketer's callback): the item is filled by the gather +
- * transform kernel of mlsgpu_hip_bucket_load on the group's copy stream instead of a host-to-device copy. */
+/* A bucket whose splats are already on GPU `device` (the device bucketer's callback): the item is filled by the gather +
+ * transform kernel of mlsgpu_hip_bucket_load instead of a host-to-device copy.  The bucket goes to the group with the
+ * most unallocated capacity, like a host bucket (flush, src/workers.cpp:320-351), `device`'s own group on a tie.  On
+ * the same GPU the kernel writes straight into the item; for another GPU it writes into a scratch buffer on `device`
+ * and the item is filled by a peer copy on the target's copy stream (xGMI), so one resident cloud feeds every GPU. */
 MLSGPU_API int mlsgpu_hip_farm_submit_device(mlsgpu_farm *f, int device, const mlsgpu_splat *dSplats, const uint32_t *dIds,
                                              uint64_t numSplats, const mlsgpu_grid *fullGrid, const int32_t lowExtent[3],
                                              const uint32_t numVertices[3], uint64_t chunkId)
@@ -418,25 +671,19 @@ MLSGPU_API int mlsgpu_hip_farm_submit_device(mlsgpu_farm *f, int device, const m
     REQUIRE(numSplats == 0 || dSplats != nullptr, MLSGPU_ERR_INVALID);
     REQUIRE(numSplats <= f->cfg.worker.maxBucketSplats, MLSGPU_ERR_LENGTH);
     PROPAGATE(flushBatch(f));           /* host buckets submitted earlier keep their place in the order */
-    DeviceGroup *out = nullptr;
+    DeviceGroup *out = nullptr, *src = nullptr;
     WorkItem *item = nullptr;
     {
         std::unique_lock<std::mutex> l(f->mutex);
-        bool known = false;
         for (auto &g : f->groups)
-            known = known || g->device == device;
-        REQUIRE(known, MLSGPU_ERR_INVALID);
+            if (g->device == device && src == nullptr)
+                src = g.get();
+        REQUIRE(src != nullptr, MLSGPU_ERR_INVALID);
         for (;;)
         {
             if (f->error != MLSGPU_OK)
                 return setError(f->error, "%s", f->errorText.c_str());
-            uint64_t best = 0;
-            for (auto &g : f->groups)
-                if (g->device == device && !g->pool.empty() && g->unallocated >= best)
-                {
-                    best = g->unallocated;
-                    out = g.get();
-                }
+            out = pickGroup(f, device);
             if (out != nullptr)
                 break;
             f->popCond.wait(l);
@@ -457,31 +704,52 @@ MLSGPU_API int mlsgpu_hip_farm_submit_device(mlsgpu_farm *f, int device, const m
     sub.numSplats = numSplats;
     item->subItems.assign(1, sub);
     item->numSplats = numSplats;
-    int rc = mlsgpu_hip_bucket_load(out->copyCtx, dSplats, dIds, numSplats, fullGrid, item->dSplats);
-    if (rc == MLSGPU_OK && hipEventRecord(item->copyEvent, out->copyStream) != hipSuccess)
-        rc = setError(MLSGPU_ERR_HIP, "farm: cannot record the load event");
-    /* the id list belongs to the caller (the bucketer reuses it after its callback returns) */
-    if (rc == MLSGPU_OK && hipStreamSynchronize(out->copyStream) != hipSuccess)
-        rc = setError(MLSGPU_ERR_HIP, "farm: the device-side load failed");
+    static const bool forcePeer = getenv("MLSGPU_HIP_FARM_FORCE_PEER") != nullptr;   /* tests: the peer route on one GPU */
+    int rc = MLSGPU_OK;
+    if (out->device == device && !forcePeer)
+    {
+        rc = mlsgpu_hip_bucket_load(out->copyCtx, dSplats, dIds, numSplats, fullGrid, item->dSplats);
+        if (rc == MLSGPU_OK && hipEventRecord(item->copyEvent, out->copyStream) != hipSuccess)
+            rc = setError(MLSGPU_ERR_HIP, "farm: cannot record the load event");
+        /* the id list belongs to the caller (the bucketer reuses it after its callback returns) */
+        if (rc == MLSGPU_OK && hipStreamSynchronize(out->copyStream) != hipSuccess)
+            rc = setError(MLSGPU_ERR_HIP, "farm: the device-side load failed");
+    }
+    else
+    {
+        /* gather + transform where the cloud lives, then device-to-device over the fabric */
+        if (src->peerScratch == nullptr
+            && (hipSetDevice(device) != hipSuccess
+                || hipMalloc((void **) &src->peerScratch, f->cfg.worker.maxBucketSplats * sizeof(mlsgpu_splat)) != hipSuccess))
+            rc = setError(MLSGPU_ERR_NOMEM, "farm: cannot allocate the peer scratch on device %d", device);
+        if (rc == MLSGPU_OK)
+            rc = mlsgpu_hip_bucket_load(src->copyCtx, dSplats, dIds, numSplats, fullGrid, src->peerScratch);
+        if (rc == MLSGPU_OK && hipStreamSynchronize(src->copyStream) != hipSuccess)
+            rc = setError(MLSGPU_ERR_HIP, "farm: the device-side load failed");
+        hipError_t e = hipSuccess;
+        if (rc == MLSGPU_OK)
+            e = hipSetDevice(out->device);
+        if (rc == MLSGPU_OK && e == hipSuccess && numSplats > 0)
+            e = hipMemcpyPeerAsync(item->dSplats, out->device, src->peerScratch, device, numSplats * sizeof(mlsgpu_splat),
+                                   out->copyStream);
+        if (rc == MLSGPU_OK && e == hipSuccess)
+            e = hipEventRecord(item->copyEvent, out->copyStream);
+        /* the scratch is reused by the next bucket */
+        if (rc == MLSGPU_OK && e == hipSuccess)
+            e = hipStreamSynchronize(out->copyStream);
+        if (rc == MLSGPU_OK && e != hipSuccess)
+            rc = setError(MLSGPU_ERR_HIP, "farm: peer copy %d -> %d failed: %s", device, out->device, hipGetErrorString(e));
+    }
+    if (rc != MLSGPU_OK)
+        return abandonItem(f, out, item, numSplats, rc);
     {
         std::lock_guard<std::mutex> l(f->mutex);
-        if (rc != MLSGPU_OK)
-        {
-            item->subItems.clear();
-            out->pool.push_back(item);
-            out->unallocated += numSplats;
-            f->inFlightItems--;
-        }
-        else
-        {
-            f->stats[0]++;
-            f->stats[1] += numSplats;
-            f->stats[3]++;
-            out->queue.push_back(item);
-        }
+        f->stats[0]++;
+        f->stats[1] += numSplats;
+        f->stats[3]++;
+        out->queue.push_back(item);
     }
-    if (rc == MLSGPU_OK)
-        f->queueCond.notify_all();
+    f->queueCond.notify_all();
     return rc;
 }
 
@@ -490,7 +758,7 @@ MLSGPU_API int mlsgpu_hip_farm_finish(mlsgpu_farm *f)
     REQUIRE(f != nullptr, MLSGPU_ERR_INVALID);
     PROPAGATE(flushBatch(f));
     std::unique_lock<std::mutex> l(f->mutex);
-    f->idleCond.wait(l, [&] { return f->inFlightItems == 0 || f->error != MLSGPU_OK; });
+    f->idleCond.wait(l, [&] { return (f->inFlightItems == 0 && f->hostQueue.empty()) || f->error != MLSGPU_OK; });
     if (f->error != MLSGPU_OK)
         return setError(f->error, "%s", f->errorText.c_str());
     return MLSGPU_OK;
@@ -505,6 +773,15 @@ MLSGPU_API int mlsgpu_hip_farm_stats(mlsgpu_farm *f, uint64_t out[24])
         out[i] = f->stats[i];
     for (size_t d = 0; d < f->groups.size() && d < 16; d++)
         out[8 + d] = f->groups[d]->bucketsDone;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_farm_host_stats(mlsgpu_farm *f, uint64_t out[4])
+{
+    REQUIRE(f != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> l(f->mutex);
+    for (int i = 0; i < 4; i++)
+        out[i] = f->hostStats[i];
     return MLSGPU_OK;
 }
 

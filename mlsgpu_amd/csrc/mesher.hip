@@ -24,6 +24,7 @@
 #include "primitives.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 using namespace mlsgpu;
@@ -311,7 +312,8 @@ struct Arena
     T *ptr = nullptr;
     uint64_t used = 0, cap = 0;
 
-    int reserve(mlsgpu_ctx *ctx, uint64_t need)
+    /* the mesher's device must be current; `stream` is one of its streams */
+    int reserve(hipStream_t stream, uint64_t need)
     {
         if (need <= cap)
             return MLSGPU_OK;
@@ -320,9 +322,9 @@ struct Arena
         HIP_CHECK(hipMalloc((void **) &np, newCap * sizeof(T)));
         if (used > 0)
         {
-            hipError_t e = hipMemcpyAsync(np, ptr, used * sizeof(T), hipMemcpyDeviceToDevice, ctx->stream);
+            hipError_t e = hipMemcpyAsync(np, ptr, used * sizeof(T), hipMemcpyDeviceToDevice, stream);
             if (e == hipSuccess)
-                e = hipStreamSynchronize(ctx->stream);
+                e = hipStreamSynchronize(stream);
             if (e != hipSuccess)
             {
                 hipFree(np);
@@ -427,12 +429,23 @@ struct mlsgpu_mesher
         }
         return MLSGPU_OK;
     }
+    /* a stream of the mesher's own: add() is called from worker threads whose contexts (and devices) differ, and the
+     * mesher's context belongs to the thread that finalizes; everything on it runs under the mutex */
+    hipStream_t addStream = nullptr;
+    int ensureAddStream()
+    {
+        if (addStream == nullptr)
+            HIP_CHECK(hipStreamCreateWithFlags(&addStream, hipStreamNonBlocking));
+        return MLSGPU_OK;
+    }
+    int regroupByChunk();
     void dropResults() { finalized = false; }
     ~mlsgpu_mesher()
     {
         hipFree(outVertices);
         hipFree(outTriangles);
         hipFree(slab);
+        if (addStream) hipStreamDestroy(addStream);
     }
 };
 
@@ -460,44 +473,44 @@ MLSGPU_API int mlsgpu_hip_mesher_reserve(mlsgpu_mesher *m, uint64_t numVertices,
     REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
     std::lock_guard<std::mutex> lock(m->mutex);
     HIP_CHECK(hipSetDevice(m->ctx->device));
-    PROPAGATE(m->vertices.reserve(m->ctx, 3 * numVertices));
-    PROPAGATE(m->triangles.reserve(m->ctx, 3 * numTriangles));
-    PROPAGATE(m->extKeys.reserve(m->ctx, numExternal));
-    PROPAGATE(m->extGid.reserve(m->ctx, numExternal));
-    PROPAGATE(m->extChunk.reserve(m->ctx, numExternal));
+    PROPAGATE(m->ensureAddStream());
+    PROPAGATE(m->vertices.reserve(m->addStream, 3 * numVertices));
+    PROPAGATE(m->triangles.reserve(m->addStream, 3 * numTriangles));
+    PROPAGATE(m->extKeys.reserve(m->addStream, numExternal));
+    PROPAGATE(m->extGid.reserve(m->addStream, numExternal));
+    PROPAGATE(m->extChunk.reserve(m->addStream, numExternal));
     /* finalize's scratch and outputs too (a few hundred blocks and chunks are assumed; finalize grows it otherwise) */
     PROPAGATE(m->ensureSlab(scratchBytes(numVertices, numTriangles, numExternal, 4096, 4096)));
     PROPAGATE(m->ensureOutputs(numVertices, numTriangles));
     return MLSGPU_OK;
 }
 
-/* MesherBase::InputFunctor (src/mesher.h:204-210) for a mesh that is still on the device */
+/* MesherBase::InputFunctor (src/mesher.h:204-210) for a mesh that is still on a device */
 MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_t chunkId, const mlsgpu_mesh *mesh)
 {
     REQUIRE(m != nullptr && from != nullptr && mesh != nullptr, MLSGPU_ERR_INVALID);
-    REQUIRE(from->device == m->ctx->device, MLSGPU_ERR_INVALID);
     REQUIRE(mesh->numInternalVertices <= mesh->numVertices, MLSGPU_ERR_INVALID);
     std::lock_guard<std::mutex> lock(m->mutex);
     REQUIRE(!m->finalized, MLSGPU_ERR_INVALID);
-    HIP_CHECK(hipSetDevice(from->device));
-    /* chunks must arrive in order (src/mesher.h:190-193): a chunk is one contiguous run of blocks */
-    uint32_t chunk;
-    if (!m->chunkIds.empty() && m->chunkIds.back() == chunkId)
-        chunk = (uint32_t) m->chunkIds.size() - 1;
-    else
-    {
-        REQUIRE(std::find(m->chunkIds.begin(), m->chunkIds.end(), chunkId) == m->chunkIds.end(), MLSGPU_ERR_INVALID);
-        chunk = (uint32_t) m->chunkIds.size();
+    const int home = m->ctx->device;
+    static const bool forcePeer = getenv("MLSGPU_HIP_MESHER_FORCE_PEER") != nullptr;    /* tests: the peer route on one GPU */
+    const bool peer = from->device != home || forcePeer;
+    HIP_CHECK(hipSetDevice(home));
+    PROPAGATE(m->ensureAddStream());
+    /* OOCMesher::add indexes chunks[chunkId.gen] (src/mesher.cpp:380-384): any arrival order; dense index = first arrival */
+    uint32_t chunk = 0;
+    while (chunk < m->chunkIds.size() && m->chunkIds[chunk] != chunkId)
+        chunk++;
+    if (chunk == m->chunkIds.size())
         m->chunkIds.push_back(chunkId);
-    }
     const uint64_t nv = mesh->numVertices, nt = mesh->numTriangles, ne = nv - mesh->numInternalVertices;
     REQUIRE(m->vertices.used / 3 + nv < (uint64_t(1) << 32), MLSGPU_ERR_LENGTH);
-    /* the arenas may move: everything queued on the mesher's own stream has completed (reserve synchronises) */
-    PROPAGATE(m->vertices.reserve(from, m->vertices.used + 3 * nv));
-    PROPAGATE(m->triangles.reserve(from, m->triangles.used + 3 * nt));
-    PROPAGATE(m->extKeys.reserve(from, m->extKeys.used + ne));
-    PROPAGATE(m->extGid.reserve(from, m->extGid.used + ne));
-    PROPAGATE(m->extChunk.reserve(from, m->extChunk.used + ne));
+    /* the arenas may move: every earlier append has completed (each add synchronises before it returns) */
+    PROPAGATE(m->vertices.reserve(m->addStream, m->vertices.used + 3 * nv));
+    PROPAGATE(m->triangles.reserve(m->addStream, m->triangles.used + 3 * nt));
+    PROPAGATE(m->extKeys.reserve(m->addStream, m->extKeys.used + ne));
+    PROPAGATE(m->extGid.reserve(m->addStream, m->extGid.used + ne));
+    PROPAGATE(m->extChunk.reserve(m->addStream, m->extChunk.used + ne));
     MeshRecord r;
     r.chunk = chunk;
     r.vBase = (uint32_t) (m->vertices.used / 3);
@@ -506,31 +519,108 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
     r.tBase = m->triangles.used / 3;
     r.nt = nt;
     r.eBase = (uint32_t) m->extKeys.used;
-    if (nv > 0)
-        HIP_CHECK(hipMemcpyAsync(m->vertices.ptr + m->vertices.used, mesh->dVertices, 3 * nv * sizeof(float),
-                                 hipMemcpyDeviceToDevice, from->stream));
+    /* the copies run on the producing worker's stream, behind the kernels that made the mesh; from another GPU they are
+     * peer copies over the fabric.  The index fix-ups run on the mesher's device, after the copies. */
+    HIP_CHECK(hipSetDevice(from->device));
+    auto append = [&](void *dst, const void *src, size_t bytes) -> hipError_t
+    {
+        if (bytes == 0)
+            return hipSuccess;
+        return peer ? hipMemcpyPeerAsync(dst, home, src, from->device, bytes, from->stream)
+                    : hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, from->stream);
+    };
+    HIP_CHECK(append(m->vertices.ptr + m->vertices.used, mesh->dVertices, 3 * nv * sizeof(float)));
+    HIP_CHECK(append(m->triangles.ptr + m->triangles.used, mesh->dTriangles, 3 * nt * sizeof(uint32_t)));
+    HIP_CHECK(append(m->extKeys.ptr + m->extKeys.used, mesh->dVertexKeys + mesh->numInternalVertices, ne * sizeof(uint64_t)));
+    hipStream_t fix = from->stream;
+    if (peer)
+    {
+        HIP_CHECK(hipStreamSynchronize(from->stream));
+        HIP_CHECK(hipSetDevice(home));
+        fix = m->addStream;
+    }
     if (nt > 0)
-    {
-        HIP_CHECK(hipMemcpyAsync(m->triangles.ptr + m->triangles.used, mesh->dTriangles, 3 * nt * sizeof(uint32_t),
-                                 hipMemcpyDeviceToDevice, from->stream));
-        hipLaunchKernelGGL(rebaseTrianglesKernel, dim3(divUp(3 * nt, 256)), dim3(256), 0, from->stream,
+        hipLaunchKernelGGL(rebaseTrianglesKernel, dim3(divUp(3 * nt, 256)), dim3(256), 0, fix,
                            m->triangles.ptr + m->triangles.used, 3 * nt, r.vBase);
-    }
     if (ne > 0)
-    {
-        HIP_CHECK(hipMemcpyAsync(m->extKeys.ptr + m->extKeys.used, mesh->dVertexKeys + mesh->numInternalVertices,
-                                 ne * sizeof(uint64_t), hipMemcpyDeviceToDevice, from->stream));
-        hipLaunchKernelGGL(fillExternalsKernel, dim3(divUp(ne, 256)), dim3(256), 0, from->stream,
+        hipLaunchKernelGGL(fillExternalsKernel, dim3(divUp(ne, 256)), dim3(256), 0, fix,
                            m->extGid.ptr + m->extGid.used, m->extChunk.ptr + m->extChunk.used, ne, r.vBase + r.nInternal, chunk);
-    }
+    HIP_CHECK(hipGetLastError());
     /* the mesh is Marching's and is reused for the next ship-out: the copies must have left it */
-    HIP_CHECK(hipStreamSynchronize(from->stream));
+    HIP_CHECK(hipStreamSynchronize(fix));
     m->vertices.used += 3 * nv;
     m->triangles.used += 3 * nt;
     m->extKeys.used += ne;
     m->extGid.used += ne;
     m->extChunk.used += ne;
     m->blocks.push_back(r);
+    return MLSGPU_OK;
+}
+
+/* finalize wants the blocks of a chunk adjacent in the arenas (output order is arena order, and equal keys must sort by
+ * chunk).  With several workers and several chunks they arrive interleaved: move the blocks into (chunk by first
+ * arrival, arrival) order -- device-to-device copies into fresh arenas, vertex ids shifted by the block's move. */
+int mlsgpu_mesher::regroupByChunk()
+{
+    bool grouped = true;
+    for (size_t b = 1; b < blocks.size(); b++)
+        grouped = grouped && blocks[b - 1].chunk <= blocks[b].chunk;
+    if (grouped)
+        return MLSGPU_OK;
+    std::vector<uint32_t> order(blocks.size());
+    for (uint32_t i = 0; i < order.size(); i++)
+        order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return blocks[a].chunk < blocks[b].chunk; });
+    PROPAGATE(ensureAddStream());
+    Arena<float> nVertices;
+    Arena<uint32_t> nTriangles, nGid, nChunk;
+    Arena<uint64_t> nKeys;
+    PROPAGATE(nVertices.reserve(addStream, std::max<uint64_t>(vertices.cap, 1)));
+    PROPAGATE(nTriangles.reserve(addStream, std::max<uint64_t>(triangles.cap, 1)));
+    PROPAGATE(nKeys.reserve(addStream, std::max<uint64_t>(extKeys.cap, 1)));
+    PROPAGATE(nGid.reserve(addStream, std::max<uint64_t>(extGid.cap, 1)));
+    PROPAGATE(nChunk.reserve(addStream, std::max<uint64_t>(extChunk.cap, 1)));
+    std::vector<MeshRecord> moved;
+    for (uint32_t idx : order)
+    {
+        const MeshRecord &o = blocks[idx];
+        MeshRecord r = o;
+        r.vBase = (uint32_t) (nVertices.used / 3);
+        r.tBase = nTriangles.used / 3;
+        r.eBase = (uint32_t) nKeys.used;
+        const uint64_t ne = o.nv - o.nInternal;
+        if (o.nv > 0)
+            HIP_CHECK(hipMemcpyAsync(nVertices.ptr + nVertices.used, vertices.ptr + 3 * (uint64_t) o.vBase, 3 * (uint64_t) o.nv * sizeof(float),
+                                     hipMemcpyDeviceToDevice, addStream));
+        if (o.nt > 0)
+        {
+            HIP_CHECK(hipMemcpyAsync(nTriangles.ptr + nTriangles.used, triangles.ptr + 3 * o.tBase, 3 * o.nt * sizeof(uint32_t),
+                                     hipMemcpyDeviceToDevice, addStream));
+            hipLaunchKernelGGL(rebaseTrianglesKernel, dim3(divUp(3 * o.nt, 256)), dim3(256), 0, addStream,
+                               nTriangles.ptr + nTriangles.used, 3 * o.nt, r.vBase - o.vBase);      /* modulo 2^32 */
+        }
+        if (ne > 0)
+        {
+            HIP_CHECK(hipMemcpyAsync(nKeys.ptr + nKeys.used, extKeys.ptr + o.eBase, ne * sizeof(uint64_t), hipMemcpyDeviceToDevice,
+                                     addStream));
+            hipLaunchKernelGGL(fillExternalsKernel, dim3(divUp(ne, 256)), dim3(256), 0, addStream, nGid.ptr + nGid.used,
+                               nChunk.ptr + nChunk.used, ne, r.vBase + r.nInternal, (uint32_t) r.chunk);
+        }
+        nVertices.used += 3 * (uint64_t) o.nv;
+        nTriangles.used += 3 * o.nt;
+        nKeys.used += ne;
+        nGid.used += ne;
+        nChunk.used += ne;
+        moved.push_back(r);
+    }
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipStreamSynchronize(addStream));
+    std::swap(vertices.ptr, nVertices.ptr);   std::swap(vertices.cap, nVertices.cap);
+    std::swap(triangles.ptr, nTriangles.ptr); std::swap(triangles.cap, nTriangles.cap);
+    std::swap(extKeys.ptr, nKeys.ptr);        std::swap(extKeys.cap, nKeys.cap);
+    std::swap(extGid.ptr, nGid.ptr);          std::swap(extGid.cap, nGid.cap);
+    std::swap(extChunk.ptr, nChunk.ptr);      std::swap(extChunk.cap, nChunk.cap);
+    blocks.swap(moved);
     return MLSGPU_OK;
 }
 
@@ -543,6 +633,7 @@ MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
     mlsgpu_ctx *ctx = m->ctx;
     HIP_CHECK(hipSetDevice(ctx->device));
     m->dropResults();
+    PROPAGATE(m->regroupByChunk());
     const uint64_t nv = m->vertices.used / 3, nt = m->triangles.used / 3, ne = m->extKeys.used;
     const uint32_t nb = (uint32_t) m->blocks.size(), nc = (uint32_t) m->chunkIds.size();
     m->chunkVStart.assign(nc + 1, 0);

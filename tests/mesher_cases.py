@@ -83,3 +83,32 @@ CASES["chunk"] = dict(                                                    # test
             mesh((2, 4, 1), I2, X2, K2, T2), mesh((3, 9, 1), I3, X3, K3, T3)],
     expected=[((0, 0, 1), arr(I0), tri(T0)), ((1, 1, 1), arr(X1), tri(T1)),
               ((2, 4, 1), arr(I2 + X2), tri(T2)), ((3, 9, 1), arr(I3 + X3), tri(T3))])
+
+
+def random_meshes(seed, blocks=12, chunks=3):
+    """Blocks of a triangulated grid sheet cut into strips: vertices on the cuts are external with a shared key;
+    a few small islands test pruning.  Positions are unique per welded vertex."""
+    rng = np.random.default_rng(seed)
+    width, height = 40, 6 * blocks
+    meshes = []
+    for b in range(blocks):
+        y0, y1 = 6 * b, 6 * (b + 1)                       # rows y0..y1 inclusive; rows y0 and y1 are shared
+        gaps = rng.random((y1 - y0, width - 1)) < 0.15    # missing quads break the sheet into components
+        ids = -np.ones((y1 - y0 + 1, width), np.int64)
+        tris = []
+        for y in range(y0, y1):
+            for x in range(width - 1):
+                if gaps[y - y0, x]:
+                    continue
+                quad = [(y, x), (y, x + 1), (y + 1, x + 1), (y + 1, x)]
+                tris.append([quad[0], quad[1], quad[2]])
+                tris.append([quad[0], quad[2], quad[3]])
+        used = sorted({p for t in tris for p in t})
+        internal = [p for p in used if p[0] not in (y0, y1)]
+        external = [p for p in used if p[0] in (y0, y1)]
+        order = {p: i for i, p in enumerate(internal + external)}
+        verts = np.array([[p[1], p[0], (p[0] * 7 + p[1] * 3) % 5] for p in internal + external], np.float32).reshape(-1, 3)
+        keys = np.array([(p[0] << 21) | p[1] | (1 << 63) for p in external], np.uint64)
+        t = np.array([[order[p] for p in tri] for tri in tris], np.uint32).reshape(-1, 3)
+        meshes.append(dict(chunk=b * chunks // blocks, vertices=verts, num_internal=len(internal), keys=keys, triangles=t))
+    return meshes

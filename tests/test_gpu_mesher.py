@@ -8,7 +8,7 @@ import pytest
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
 import mesher_oracle as mo  # noqa: E402
-from mesher_cases import CASES  # noqa: E402
+from mesher_cases import CASES, random_meshes  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -51,46 +51,30 @@ def test_block_order_does_not_matter():
     assert mo.isomorphic(v, t, ev, et)
 
 
-def test_chunks_must_be_contiguous():
-    import mlsgpu_amd as m
-    ctx = m.Context(0)
-    mesher = m.Mesher(ctx)
-    a = CASES["simple"]["meshes"][0]
-    mesher.add(0, a["vertices"], a["num_internal"], a["keys"], a["triangles"])
-    mesher.add(1, a["vertices"], a["num_internal"], a["keys"], a["triangles"])
-    with pytest.raises(m.InvalidArgument):
-        mesher.add(0, a["vertices"], a["num_internal"], a["keys"], a["triangles"])
-    mesher.close()
-    ctx.close()
+def test_chunks_may_arrive_interleaved():
+    """Two workers and several chunks deliver blocks of different chunks interleaved; OOCMesher::add accepts any order
+    (it indexes chunks[chunkId.gen], src/mesher.cpp:380-384).  Output chunks are in order of first arrival."""
+    meshes = random_meshes(7, blocks=12, chunks=3)
+    order = [0, 4, 8, 1, 5, 9, 2, 10, 6, 3, 7, 11]            # chunks 0,1,2,0,1,2,...
+    mixed = [meshes[i] for i in order]
+    exp, exp_stats = mo.mesh_sink(mixed, 0.02)
+    out, stats = run_hip(mixed, 0.02)
+    for k in ("total_vertices", "threshold", "components", "kept_components", "kept_vertices", "kept_triangles"):
+        assert stats[k] == exp_stats[k], k
+    assert [c for c, _, _ in out] == [c for c, _, _ in exp] == [0, 1, 2]
+    for (_, v, t), (_, ev, et) in zip(out, exp):
+        assert mo.isomorphic(v, t, ev, et)
 
 
-def random_meshes(seed, blocks=12, chunks=3):
-    """Blocks of a triangulated grid sheet cut into strips: vertices on the cuts are external with a shared key;
-    a few small islands test pruning.  Positions are unique per welded vertex."""
-    rng = np.random.default_rng(seed)
-    width, height = 40, 6 * blocks
-    meshes = []
-    for b in range(blocks):
-        y0, y1 = 6 * b, 6 * (b + 1)                       # rows y0..y1 inclusive; rows y0 and y1 are shared
-        gaps = rng.random((y1 - y0, width - 1)) < 0.15    # missing quads break the sheet into components
-        ids = -np.ones((y1 - y0 + 1, width), np.int64)
-        tris = []
-        for y in range(y0, y1):
-            for x in range(width - 1):
-                if gaps[y - y0, x]:
-                    continue
-                quad = [(y, x), (y, x + 1), (y + 1, x + 1), (y + 1, x)]
-                tris.append([quad[0], quad[1], quad[2]])
-                tris.append([quad[0], quad[2], quad[3]])
-        used = sorted({p for t in tris for p in t})
-        internal = [p for p in used if p[0] not in (y0, y1)]
-        external = [p for p in used if p[0] in (y0, y1)]
-        order = {p: i for i, p in enumerate(internal + external)}
-        verts = np.array([[p[1], p[0], (p[0] * 7 + p[1] * 3) % 5] for p in internal + external], np.float32).reshape(-1, 3)
-        keys = np.array([(p[0] << 21) | p[1] | (1 << 63) for p in external], np.uint64)
-        t = np.array([[order[p] for p in tri] for tri in tris], np.uint32).reshape(-1, 3)
-        meshes.append(dict(chunk=b * chunks // blocks, vertices=verts, num_internal=len(internal), keys=keys, triangles=t))
-    return meshes
+def test_peer_route_appends(monkeypatch):
+    """The cross-GPU append (peer copies on the producer's stream, index fix-ups on the mesher's device) forced on one
+    GPU: same result as the local route."""
+    import subprocess
+    code = ("import os,sys; sys.path[:0]=[%r,%r,%r]; os.environ['MLSGPU_HIP_MESHER_FORCE_PEER']='1';"
+            "import test_gpu_mesher as t; t.test_random_sheets_match_oracle(2, 0.01); t.test_chunks_may_arrive_interleaved()"
+            % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+               os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")))
+    subprocess.check_call([sys.executable, "-c", code])
 
 
 @pytest.mark.parametrize("seed,prune", [(1, 0.0), (2, 0.01), (3, 0.05), (4, 0.3)])

@@ -1,0 +1,84 @@
+"""Host mesh sink (mlsgpu_hip_host_mesher_*: OOCMesher's weld on the host, the cross-GPU welder behind the farm's
+host output) against the reference's mesher vectors and the oracle, up to isomorphism -- the comparison the reference's
+own tests make (test/test_mesher.cpp:401-460).  Host code: runs without a GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import mesher_oracle as mo  # noqa: E402
+from mesher_cases import CASES, random_meshes  # noqa: E402
+
+
+def run_host(meshes, prune=0.0):
+    import mlsgpu_amd as m
+    mesher = m.HostMesher(prune)
+    seen = {}
+    for mesh in meshes:
+        mesher.add(seen.setdefault(mesh["chunk"], len(seen)), mesh["vertices"], mesh["num_internal"], mesh["keys"],
+                   mesh["triangles"])
+    n = mesher.finalize()
+    out = [mesher.chunk(i) for i in range(n)]
+    stats = mesher.stats()
+    mesher.close()
+    back = {v: k for k, v in seen.items()}
+    return [(back[c], v, t) for c, v, t in out], stats
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_reference_case(name):
+    case = CASES[name]
+    out, stats = run_host(case["meshes"], case.get("prune", 0.0))
+    assert [c for c, _, _ in out] == [c for c, _, _ in case["expected"]]
+    for (_, v, t), (_, ev, et) in zip(out, case["expected"]):
+        assert mo.isomorphic(v, t, ev, et), name
+    for k, val in case.get("stats", {}).items():
+        assert stats[k] == val
+
+
+def test_block_order_does_not_matter():
+    # test/test_mesher.cpp:497-525 adds the blocks in reverse on the second pass
+    case = CASES["weld"]
+    out, _ = run_host(case["meshes"][::-1])
+    (_, v, t), (_, ev, et) = out[0], case["expected"][0]
+    assert mo.isomorphic(v, t, ev, et)
+
+
+@pytest.mark.parametrize("seed,prune", [(1, 0.0), (2, 0.01), (3, 0.05), (4, 0.3)])
+def test_random_sheets_match_oracle(seed, prune):
+    meshes = random_meshes(seed)
+    exp, exp_stats = mo.mesh_sink(meshes, prune)
+    out, stats = run_host(meshes, prune)
+    for k in ("total_vertices", "threshold", "components", "kept_components", "kept_vertices", "kept_triangles"):
+        assert stats[k] == exp_stats[k], k
+    assert [c for c, _, _ in out] == [c for c, _, _ in exp]
+    for (_, v, t), (_, ev, et) in zip(out, exp):
+        assert mo.isomorphic(v, t, ev, et)
+
+
+def test_interleaved_chunks_and_empty_blocks():
+    meshes = random_meshes(7, blocks=12, chunks=3)
+    mixed = [meshes[i] for i in [0, 4, 8, 1, 5, 9, 2, 10, 6, 3, 7, 11]]
+    empty = dict(chunk=1, vertices=np.zeros((0, 3), np.float32), num_internal=0, keys=np.zeros(0, np.uint64),
+                 triangles=np.zeros((0, 3), np.uint32))
+    mixed.insert(5, empty)
+    exp, exp_stats = mo.mesh_sink(mixed, 0.02)
+    out, stats = run_host(mixed, 0.02)
+    for k in ("total_vertices", "threshold", "components", "kept_components", "kept_vertices", "kept_triangles"):
+        assert stats[k] == exp_stats[k], k
+    assert [c for c, _, _ in out] == [c for c, _, _ in exp] == [0, 1, 2]
+    for (_, v, t), (_, ev, et) in zip(out, exp):
+        assert mo.isomorphic(v, t, ev, et)
+
+
+def test_argument_checks():
+    import mlsgpu_amd as m
+    mesher = m.HostMesher()
+    with pytest.raises(m.InvalidArgument):
+        mesher.add(0, np.zeros((2, 3), np.float32), 2, np.zeros(0, np.uint64), np.array([[0, 1, 2]], np.uint32))   # index out of range
+    with pytest.raises(m.InvalidArgument):
+        mesher.stats()                       # not finalized
+    with pytest.raises(m.InvalidArgument):
+        m.HostMesher(1.5)
