@@ -1,25 +1,39 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mvoxels/s evaluated + triangulated by the per-bucket device pipeline.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-One "step" is one pass of the hot path (octree build -> MLS corner evaluation -> marching tetrahedra
-with welding -> scale/bias) over every bucket of one synthetic splat cloud whose splats are already
-resident in HBM.  At N = 1 the workload is BASELINE.json configs[2] (512^3 grid, 50 M uniform-random
-splats, multi-bucket stream), the configuration the north_star target is quoted on; with N > 1 every
-rank streams its own cloud of the same shape (weak scaling, no data-path collective: buckets are
-independent, cross-bucket welding is host work in the reference).
+One "step" is one pass of the hot path (octree build -> MLS corner evaluation -> marching tetrahedra with welding ->
+scale/bias) over every bucket of ONE synthetic splat cloud whose splats are already resident in HBM.
 
-Per GPU, `--workers` device worker threads (default 2, the reference's --device-threads,
-src/mlsgpu_core.cpp:114) each own a stream, an octree, an MLS functor and a Marching instance and take
-alternate buckets, so one worker's host synchronisations overlap the other's kernels.
+N = 1   BASELINE.json configs[2]: 512^3 grid, 50 M uniform-random splats, 27 buckets -- the configuration the
+        north_star target is quoted on.
+N > 1   ONE sharded cloud: BASELINE.json configs[3] (1024^3 grid, 200 M uniform-random splats) cut into z-slabs of
+        128 corner slices, one slab of 25 buckets (<= 205 x 205 x 128 cells) per GPU; at N = 8 the slabs are the
+        whole of cfg4, at N = 2 / 4 the first N slabs of the same cloud.  One process per GPU (RANK / LOCAL_RANK /
+        WORLD_SIZE from torch.distributed.run); every rank generates the cloud in its own HBM and keeps the splats of
+        its slab (with halo).  No data-path collective: buckets are independent; torch.distributed
+        carries the barrier and the reductions of the timing.  Per-GPU work is fixed (about 134 M voxels, as in
+        cfg3): "scaling": "weak".
+        `python bench.py --gpus N` without a launcher starts the N ranks itself (fresh child processes, before this
+        process has touched a GPU) and exits with their status.
 
-Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+Per GPU, `--workers` device worker threads (the reference's --device-threads, src/mlsgpu_core.cpp:114) each own a stream,
+an octree, an MLS functor and a Marching instance and take alternate buckets, so one worker's host synchronisations
+overlap another's kernels.
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").  Beside the headline it carries: the roofline of the
+dominant kernel (durations measured live with HIP events on the worker's stream), a digest of every mesh the pipeline
+produced (checked against the value pinned in tests/test_gpu_configs.py for the default workload), the
+transfer-inclusive figures of SURVEY.md 8(d) (host splats in -> last mesh byte out) on both synthetic distributions, the
+device mesh sink, the reference partition, and the CPU baseline (the oracle, parallel over buckets on the host cores).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -29,66 +43,281 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
-FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (= dense f32 MFMA rate)
+FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (counts packed FMA: 2 flops x 2 per lane per clock)
+SLAB = 128                     # corner slices per GPU of the N > 1 workload
+# digest of the meshes of the default N = 1 workload (cfg3 uniform), pinned in tests/test_gpu_configs.py as well
+CFG3_UNIFORM_DIGEST = None
 
 
 def parse_args():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
-    p.add_argument("--steps", type=int, default=3)
-    p.add_argument("--warmup", type=int, default=1)
-    p.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3"])
+    p.add_argument("--steps", type=int, default=200, help="timed passes (default: about 5 s of timed region at N = 1)")
+    p.add_argument("--warmup", type=int, default=5)
+    p.add_argument("--workload", default="auto", choices=["auto", "cfg2", "cfg3", "cfg4slab"],
+                   help="auto: cfg3 at N = 1, the cfg4 slab family at N > 1; cfg4slab runs one slab of cfg4 at N = 1")
     p.add_argument("--dist", default="uniform", choices=["uniform", "shells"])
     p.add_argument("--scale", type=float, default=1.0, help="splat-count scale (debug only; 1.0 = BASELINE size)")
     p.add_argument("--mesh-memory-mb", type=int, default=4096, help="Marching mesh arena per worker")
     p.add_argument("--workers", type=int, default=4, help="device worker threads per GPU (measured 2..4: +0..6 %)")
     p.add_argument("--variant", type=int, default=2, help="MLS kernel variant: 0 culled, 1 basic, 2 culled + hit lists")
+    p.add_argument("--leg-steps", type=int, default=3, help="passes of every secondary leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-stream", action="store_true", help="skip the PCIe-inclusive bucket-farm leg")
+    p.add_argument("--no-transfer", action="store_true", help="skip the transfer-inclusive legs (SURVEY 8d timed region)")
+    p.add_argument("--no-shells", action="store_true", help="skip the D1 (shells) secondary measurement")
     p.add_argument("--no-partition", action="store_true", help="skip the device-bucketer leg (reference partition)")
     p.add_argument("--partition-max-splats", type=int, default=2097152,
                    help="bucket capacity of the device-bucketer leg (reference default 64 MiB / 32 B)")
     p.add_argument("--no-sink", action="store_true", help="skip the device mesh-sink leg (weld / components / prune)")
     p.add_argument("--no-timing", action="store_true", help="do not time individual kernels with HIP events")
+    p.add_argument("--headline-only", action="store_true", help="only the timed region and the roofline")
     return p.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks the way the driver does.  Nothing in this process has
+    touched a GPU yet (device_count does not initialise HIP on this image), and the children are fresh processes."""
+    import socket
+
+    import torch
+    have = torch.cuda.device_count()
+    if have < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible; refusing to report an %d-GPU number from fewer "
+                         "devices" % (args.gpus, have, args.gpus))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+# ---------------------------------------------------------------------------------------------------- workloads
+
+def build_workload(args, rank, world, device):
+    """The rank's buckets, generated in HBM.  Returns a dict: bucketed (torch (n, 8) f32), buckets, voxels (this rank),
+    n_splats (cloud splats this rank accounts for), text, cloud (the raw cloud tensor or None), grid."""
+    import torch
+
+    from mlsgpu_amd import synth
+    name = args.workload
+    if name == "auto":
+        name = "cfg3" if world == 1 else "cfg4slab"
+    if world > 1 and name != "cfg4slab":
+        raise SystemExit("N > 1 runs the sharded cfg4 slab family only")
+    if name in ("cfg2", "cfg3"):
+        cloud, g = synth.make_cloud_device(name, device, scale=args.scale, dist=args.dist)
+        boxes = synth.grid_buckets((g, g, g), 255)
+        bucketed, buckets = synth.bucketize_device(cloud, boxes)
+        text = ("%s: %d^3 grid, %d splats (%s), %d buckets of <= %d cells per side, octree+MLS+MC end-to-end"
+                % (name, g, len(cloud), args.dist, len(buckets), max(max(b.num_vertices) for b in buckets) - 1))
+        return dict(bucketed=bucketed, buckets=buckets, n_splats=len(cloud), text=text, cloud=cloud, grid=(g, g, g),
+                    name=name, all_buckets=len(buckets))
+    # cfg4 slab family: the cfg4 cloud, the first `world` slabs of SLAB corner slices, slab r = rank r's 25 buckets
+    if args.dist != "uniform":
+        raise SystemExit("the cfg4 slab family is defined on the uniform cloud")
+    cloud, g = synth.make_cloud_device("cfg4", device, scale=args.scale)
+    dims = (g, g, SLAB * world)
+    boxes = synth.grid_buckets(dims, 255, runs=(0, 0, world))
+    per = len(boxes) // world
+    assert per * world == len(boxes)
+    bucketed, buckets = synth.bucketize_device(cloud, boxes[rank * per:(rank + 1) * per])
+    # splats this rank accounts for in Msplats/s: centres inside its slab (the halo copies are not counted twice)
+    z0 = buckets[0].low[2]
+    z1 = z0 + buckets[0].num_vertices[2] - 1
+    zc = cloud[:, 2]
+    inside = (zc >= float(z0)) & ((zc <= float(z1)) if rank == world - 1 else (zc < float(z1)))
+    mine = int(inside.sum().item())
+    del inside
+    text = ("cfg4 slab family: cfg4's cloud (1024^3 grid, %d uniform splats), grid %d x %d x %d = %d slab(s) of %d corner "
+            "slices, %d buckets of <= %d x %d x %d cells per slab, one slab per GPU%s"
+            % (len(cloud), dims[0], dims[1], dims[2], world, SLAB, per, buckets[0].num_vertices[0] - 1,
+               buckets[0].num_vertices[1] - 1, max(b.num_vertices[2] for b in buckets) - 1,
+               " (= BASELINE configs[3] in full)" if world * SLAB == g else ""))
+    del zc
+    return dict(bucketed=bucketed, buckets=buckets, n_splats=mine, text=text, cloud=None, grid=dims, name="cfg4slab",
+                all_buckets=len(boxes))
+
+
+# ---------------------------------------------------------------------------------------------------- legs
+
+def cpu_baseline(bucketed_host, buckets, max_cells, budget_s=20.0):
+    """The CPU baseline: the oracle (oracle/, "port") on the host cores, PARALLEL OVER BUCKETS like the GPU farm -- one
+    single-threaded worker process per core, each with one bucket of the same cloud, all started together; throughput =
+    cells of all those buckets / wall time until the last one finishes.  The oracle is rebuilt here with -O3
+    -march=native for this machine's CPU when a compiler is present."""
+    cores = os.cpu_count() or 1
+    try:
+        import psutil
+        mem_gb = psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        mem_gb = 64.0
+    lib = os.path.join(ROOT, "oracle", "liboracle_native.so")
+    built = subprocess.call(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "native"],
+                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL) == 0 and os.path.exists(lib)
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.pop("MLSGPU_ORACLE_LIB", None)
+    if built:
+        env["MLSGPU_ORACLE_LIB"] = lib
+    # one bucket per worker; a worker needs about 1.5 GB (field, octree, mesh arenas of the reference's defaults)
+    nproc = int(max(1, min(cores, mem_gb / 2.0)))
+    order = sorted(range(len(buckets)), key=lambda i: abs(i - len(buckets) // 2))
+    tmp = tempfile.mkdtemp(prefix="mlsgpu_cpu_")
+    go = os.path.join(tmp, "go")
+    procs = []
+    for w in range(nproc):
+        b = buckets[order[w % len(buckets)]]
+        job = os.path.join(tmp, "job%d.npz" % w)
+        np.savez(job, splats=bucketed_host[b.first:b.first + b.count],
+                 buckets=np.array([[0, b.count] + list(b.low) + list(b.num_vertices)], np.int64), max_cells=max_cells)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tools", "cpu_bucket_worker.py"), job, go],
+                                      stdout=subprocess.PIPE, env=env))
+    deadline = time.time() + 120
+    while time.time() < deadline and sum(1 for f in os.listdir(tmp) if ".ready." in f) < nproc:
+        time.sleep(0.05)
+    t0 = time.time()
+    open(go, "w").close()
+    outs = []
+    for p in procs:
+        line = p.communicate()[0].decode().strip().splitlines()
+        if p.returncode == 0 and line:
+            outs.append(json.loads(line[-1]))
+    wall = max(o["t_end"] for o in outs) - t0 if outs else float("nan")
+    for f in os.listdir(tmp):
+        os.remove(os.path.join(tmp, f))
+    os.rmdir(tmp)
+    if not outs:
+        return None
+    cells = sum(o["cells"] for o in outs)
+    busy = sum(o["seconds"] for o in outs) / (wall * cores)
+    flops = sum(10 * 512 * o["listed"] + 25 * o["hits"] for o in outs)
+    return {
+        "value": round(cells / wall / 1e6, 4), "unit": "Mvoxels/s", "cores": len(outs), "kind": "port",
+        "sample": "%d buckets of the same cloud (centre outwards, %d distinct), one single-threaded oracle process per "
+                  "bucket, all started together on a %d-thread host: %d cells, %d splats, %.1f s wall until the last "
+                  "finished (%.1f s of work per bucket on average)"
+                  % (len(outs), min(len(outs), len(buckets)), cores, cells, sum(o["splats"] for o in outs), wall,
+                     sum(o["seconds"] for o in outs) / len(outs)),
+        "host_threads": cores, "cores_busy_frac": round(busy, 3),
+        "build": "-O3 -march=native on this host" if built else "portable -O2 -mavx2 build (no compiler run here)",
+        "stage_cpu_seconds": {"octree": round(sum(o["tree_s"] for o in outs), 2),
+                              "processCorners": round(sum(o["mls_s"] for o in outs), 2),
+                              "marching": round(sum(o["marching_s"] for o in outs), 2)},
+        "processCorners_GFLOPs": round(flops / max(sum(o["mls_s"] for o in outs), 1e-9) * len(outs) / 1e9 / len(outs), 2),
+        "processCorners_GFLOPs_per_core": round(flops / max(sum(o["mls_s"] for o in outs), 1e-9) / 1e9, 3),
+    }
+
+
+def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_cells, voxels, steps, with_sink=True):
+    """SURVEY 8(d)'s timed region: host splats of every bucket in -> last byte of mesh back in host memory.
+    route "shipouts": every ship-out read back asynchronously through the farm's pinned circular buffer, overlapped with
+    the next buckets (the reference's route, src/workers.h:488-509, src/mesh.cpp:62-102);
+    route "device_sink": ship-outs appended to the device mesher, weld / components / prune in HBM, ONE read-back."""
+    out = {}
+    views = [bucketed_host[b.first:b.first + b.count] for b in buckets]
+    nworkers = max(1, min(args.workers, len(buckets)))
+    farm = m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
+                        mesh_memory=args.mesh_memory_mb << 20)
+    farm.set_host_output(6 << 30, None)
+
+    def stream_pass():
+        for i, (b, v) in enumerate(zip(buckets, views)):
+            farm.submit(v, b.low, b.num_vertices, i)
+        farm.finish()
+    stream_pass()
+    before = farm.host_stats()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        stream_pass()
+    dt = (time.perf_counter() - t0) / steps
+    hs = farm.host_stats()
+    d2h = (hs["bytes"] - before["bytes"]) / steps
+    out["shipouts"] = {
+        "value": round(voxels / dt / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(dt * 1e3, 3),
+        "h2d_GB_per_step": round(bucketed_host.nbytes / 1e9, 3), "d2h_GB_per_step": round(d2h / 1e9, 3),
+        "link_GBps": round((bucketed_host.nbytes + d2h) / dt / 1e9, 2), "ring_waits": hs["ring_waits"] - before["ring_waits"],
+        "note": "pageable host splats -> pinned staging (4 copy threads) -> H2D -> %d device workers -> every ship-out "
+                "read back through a 6 GiB pinned circular buffer, consumed (dropped) by the farm's mesher thread" % nworkers}
+    farm.close()
+    if not with_sink:
+        return out
+    # route 2: the device sink, one final D2H of the welded, pruned mesh
+    ctx = m.Context(device_index)
+    sink = m.Mesher(ctx, 0.02)
+    farm = m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
+                        mesh_memory=args.mesh_memory_mb << 20, sink=sink)
+
+    def sink_pass(keep=None):
+        for i, (b, v) in enumerate(zip(buckets, views)):
+            farm.submit(v, b.low, b.num_vertices, 0)
+        farm.finish()
+        n = sink.finalize()
+        got = [sink.chunk(i, download=False) for i in range(n)]
+        nbytes = 0
+        for c in got:
+            nbytes += m.binding.download_into_pinned(ctx, c, keep)
+        ctx.synchronize()
+        sink.reset()
+        return nbytes
+    pinned = m.binding.PinnedBuffer(1)
+    nbytes = sink_pass(pinned)                 # warm-up; sizes the pinned landing buffer
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        nbytes = sink_pass(pinned)
+    dt = (time.perf_counter() - t0) / steps
+    out["device_sink"] = {
+        "value": round(voxels / dt / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(dt * 1e3, 3),
+        "h2d_GB_per_step": round(bucketed_host.nbytes / 1e9, 3), "d2h_GB_per_step": round(nbytes / 1e9, 3),
+        "note": "host splats -> farm -> ship-outs appended in HBM -> weld + components + prune (0.02) on the device -> "
+                "ONE read-back of the final mesh into pinned memory"}
+    pinned.free()
+    farm.close()
+    sink.close()
+    ctx.close()
+    return out
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d: refusing to report a number for a different device count"
+                         % (args.gpus, world))
 
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # one process per GPU; MLSGPU_BENCH_BACKEND=gloo lets several ranks share one GPU (a single-GPU check of the
-    # N > 1 code path: the only collectives are a barrier and two scalar reductions, so RCCL is not essential)
+    # N > 1 code path: the only collectives are a barrier and reductions of scalars, so RCCL is not essential)
     backend = os.environ.get("MLSGPU_BENCH_BACKEND", "nccl")
     ndev = torch.cuda.device_count()
     if backend == "nccl" and local_rank >= ndev:
         raise SystemExit("LOCAL_RANK %d but only %d GPU(s) visible" % (local_rank, ndev))
     local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
     reduce_device = "cuda" if (dist is not None and backend == "nccl") else None
 
     import mlsgpu_amd as m
-    from mlsgpu_amd import farm, synth
+    from mlsgpu_amd import farm
 
-    # ---- workload (host side, untimed) ----
+    # ---- workload (generated in HBM, untimed) ----
     t0 = time.time()
-    cloud, grid = synth.make_cloud(args.workload, args.dist, scale=args.scale, seed_offset=rank)
-    bucketed, buckets = synth.bucketize(cloud, grid, 255)
-    n_splats = len(cloud)
+    W = build_workload(args, rank, world, device)
+    torch.cuda.synchronize()
+    bucketed_t, buckets = W["bucketed"], W["buckets"]
     voxels = sum(b.cells for b in buckets)
     max_count = max(b.count for b in buckets)
     max_cells = max(max(b.num_vertices) for b in buckets) - 1
@@ -97,8 +326,9 @@ def main():
     nworkers = max(1, min(args.workers, len(buckets)))
     ctxs = [m.Context(local_rank) for _ in range(nworkers)]
     ctx = ctxs[0]
-    pristine = m.DeviceBuffer(ctx, array=bucketed)
-    work = m.DeviceBuffer(ctx, nbytes=bucketed.nbytes)
+    nbytes = bucketed_t.numel() * 4
+    pristine = m.DeviceBuffer(ctx, nbytes=nbytes, borrow=bucketed_t.data_ptr())
+    work = m.DeviceBuffer(ctx, nbytes=nbytes)
     workers = [m.Worker(c, max_count, max_cells=max_cells, mesh_memory=args.mesh_memory_mb << 20) for c in ctxs]
     for w in workers:
         w.set_mls_variant(args.variant)
@@ -137,21 +367,30 @@ def main():
     for c in ctxs:
         c.synchronize()
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    own_elapsed = time.perf_counter() - t0
     if dist is not None:
         dist.barrier()
-    # whole job: MAX of the elapsed time over ranks, SUM of the voxels (each rank ran `steps` passes of its cloud)
-    elapsed, total_voxels, _ = farm.combine(elapsed, voxels * args.steps, dist, reduce_device)
+    # whole job: MAX of the elapsed time over ranks, SUM of the voxels (each rank ran `steps` passes over its buckets)
+    elapsed, total_voxels, _ = farm.combine(own_elapsed, voxels * args.steps, dist, reduce_device)
+    per_rank = None
+    total_splats = W["n_splats"]
+    if dist is not None:
+        t = torch.zeros((world, 4), dtype=torch.float64, device=reduce_device)
+        t[rank, 0], t[rank, 1], t[rank, 2], t[rank, 3] = own_elapsed, len(buckets), voxels, W["n_splats"]
+        dist.all_reduce(t)
+        per_rank = t.cpu().numpy()
+        total_splats = int(per_rank[:, 3].sum())
 
-    # ---- per-kernel durations: the same `steps` passes once more on ONE worker with HIP events around every
-    # launch.  Kept out of the headline region because with several workers the streams overlap and an event
-    # pair then measures a kernel sharing the GPU, not the kernel; single-worker durations are what the
-    # roofline divides by (and what `rocprofv3 --kernel-trace --stats ... --workers 1` reports). ----
+    # ---- per-kernel durations: passes on ONE worker with HIP events around every launch.  Kept out of the headline
+    # region because with several workers the streams overlap and an event pair then measures a kernel sharing the GPU,
+    # not the kernel; single-worker durations are what the roofline divides by (and what `rocprofv3 --kernel-trace
+    # --stats ... --workers 1` reports). ----
     kernel_stats = {}
+    ksteps = max(1, min(args.steps, 10))
     if not args.no_timing:
         ctx.reset_stats()
         ctx.set_timing(True)
-        for _ in range(args.steps):
+        for _ in range(ksteps):
             work.copy_from(pristine)
             for b in buckets:
                 workers[0].process(work, b.first, b.count, b.low, b.num_vertices, collector=m.binding.SizeCollector())
@@ -162,15 +401,16 @@ def main():
     external = sum(c.external for c in collectors) // max(args.steps, 1)
     shipouts = sum(c.batches for c in collectors) // max(args.steps, 1)
 
-    # ---- algorithmic work (one instrumented, untimed pass on worker 0) ----
+    # ---- algorithmic work + output digest (one instrumented, untimed pass on worker 0) ----
     counters = m.DeviceBuffer(ctx, array=np.zeros(3, np.uint64))
     w0 = workers[0]
     before = w0.marching_counters()
     w0.set_mls_stats(counters)
     work.copy_from(pristine)
     corners = entries = 0
+    check = m.binding.ChecksumCollector(ctx)
     for b in buckets:
-        w0.process(work, b.first, b.count, b.low, b.num_vertices, collector=m.binding.SizeCollector())
+        w0.process(work, b.first, b.count, b.low, b.num_vertices, collector=check)
         entries += w0.tree_num_entries()
         corners += int(np.prod([-(-n // 8) * 8 for n in b.num_vertices]))
     ctx.synchronize()
@@ -178,6 +418,10 @@ def main():
     w0.set_mls_stats(None)
     after = w0.marching_counters()
     mc = {k: after[k] - before[k] for k in after}
+    digest = check.digest()
+    if check.vertices != vertices or check.triangles != triangles:
+        raise SystemExit("the timed passes produced %d vertices / %d triangles per step, the checked pass %d / %d"
+                         % (vertices, triangles, check.vertices, check.triangles))
 
     ms_per_step = elapsed / args.steps * 1e3
     value = farm.throughput(total_voxels, elapsed)
@@ -194,71 +438,99 @@ def main():
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
-        "msplats_per_s": round(world * n_splats * args.steps / elapsed / 1e6, 3),
+        "msplats_per_s": round(total_splats * args.steps / elapsed / 1e6, 3),
+        "timed_region_s": round(elapsed, 3),
         "config": {
-            "workload": "%s: %d^3 grid, %d splats (%s), %d buckets of <= %d cells per side, octree+MLS+MC end-to-end"
-                        % (args.workload, grid, n_splats, args.dist, len(buckets), max_cells),
-            "voxels_per_step": voxels,
-            "bucket_splats_total": len(bucketed),
+            "workload": W["text"],
+            "voxels_per_step": int(total_voxels // args.steps),
+            "bucket_splats_total": int(bucketed_t.shape[0]),
             "mesh_memory_mb": args.mesh_memory_mb,
             "device_workers": nworkers,
             "mls_variant": {0: "culled", 1: "basic", 2: "culled+hit-lists"}[args.variant],
-            "per_rank": "own cloud per rank (seed offset = rank)",
+            "sharding": "one process per GPU, rank r owns z-slab r (25 buckets); no data-path collective" if world > 1
+                        else "single GPU",
             "triangles_per_step": triangles,
             "vertices_per_step": vertices,
             "shipouts_per_step": shipouts,
-            "host_setup_s": round(setup_s, 1),
+            "setup_s": round(setup_s, 1),
         },
+        "output_digest": {
+            "rank0_digest": digest, "batches": check.batches,
+            "what": "sha256/16 over (sizes, vertex / triangle / external-key checksums) of every ship-out of one pass of rank "
+                    "0's buckets, computed on the device (mlsgpu_hip_mesh_checksum)"},
     }
+    if W["name"] == "cfg3" and args.dist == "uniform" and args.scale == 1.0 and CFG3_UNIFORM_DIGEST is not None:
+        result["output_digest"]["expected"] = CFG3_UNIFORM_DIGEST
+        result["output_digest"]["ok"] = digest == CFG3_UNIFORM_DIGEST
+        if digest != CFG3_UNIFORM_DIGEST:
+            raise SystemExit("output digest %s differs from the pinned %s: the timed pipeline did not produce the meshes "
+                             "the parity tests check" % (digest, CFG3_UNIFORM_DIGEST))
+    if per_rank is not None:
+        result["per_rank"] = {
+            "buckets": [int(x) for x in per_rank[:, 1]],
+            "ms_per_step": [round(x / args.steps * 1e3, 3) for x in per_rank[:, 0]],
+            "mvoxels_per_s": [round(v * args.steps / e / 1e6, 1) for e, v in zip(per_rank[:, 0], per_rank[:, 2])],
+            "note": "every rank is one GPU working on its own slab; value = sum of voxels / slowest rank's time"}
 
     # ---- roofline: algorithmic bytes over HIP-event kernel time, per stage ----
     if kernel_stats and not args.no_timing:
-        K = args.steps
+        K = ksteps
         T, O, Vw, C = 3 * triangles, mc["occupied"], vertices, voxels
         sort_passes = 2       # 17 key bits at <= 10 bits per pass
+        nb_splats = int(bucketed_t.shape[0])
         models = {
             # stat name: (kernel, algorithmic bytes per step)
             "kernel.mls.processCorners.time": ("processCorners", 36 * listed + 4 * corners),
             "kernel.octree.sort.time": ("sortHist+sortScatter (octree entries)", sort_passes * 20 * entries),
-            "kernel.octree.writeEntries.time": ("writeEntries (count+scan+write)", 3 * 16 * len(bucketed) + 8 * entries),
+            "kernel.octree.writeEntries.time": ("writeEntries (count+scan+write)", 3 * 16 * nb_splats + 8 * entries),
             "kernel.octree.scan.time": ("countCommands+scan+writeSplatIds", 2 * 4 * entries + 8 * entries + 4 * entries),
             "kernel.marching.generateElements.time": ("latticeTriangles", 4 * T + 16 * O + O),
             "kernel.marching.compactVertices.time": ("latticeVertices", 12 * Vw + 8 * external + 8 * Vw),
             "kernel.marching.countUniqueVertices.time": ("latticeMask", C + 8 * 12 * (corners // 64)),
             "kernel.marching.genOccupied.time": ("cellCode+classify", 4 * corners + C + C),
         }
-        stages = []
-        for stat, (kname, nbytes) in models.items():
-            if stat in kernel_stats and kernel_stats[stat][1] > 0:
-                ms = kernel_stats[stat][0] / K
-                stages.append({"stat": stat, "kernel": kname, "ms_per_step": round(ms, 3),
-                               "launches_per_step": kernel_stats[stat][1] // K,
-                               "algorithmic_bytes_per_step": int(nbytes),
-                               "achieved_GBps": round(nbytes / (ms * 1e-3) / 1e9, 1)})
-        stages.sort(key=lambda s: -s["ms_per_step"])
-        single_ms = sum(v[0] for k, v in kernel_stats.items() if k == "device.compute") / K
         tj = {}
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath)).get("%s/%s" % (args.workload, args.dist), {})
+                tj = json.load(open(tpath)).get("%s/%s" % (W["name"], args.dist), {})
             except Exception:
                 tj = {}
-        for st in stages:
-            st["hbm_traffic_bytes_per_launch"] = tj.get(st["kernel"])
+        traffic_of = {"processCorners": ["processCorners"], "latticeTriangles": ["latticeTriangles"],
+                      "latticeVertices": ["latticeVertices"], "latticeMask": ["latticeMask"],
+                      "cellCode+classify": ["cellCode"], "writeEntries (count+scan+write)": ["writeEntries"],
+                      "countCommands+scan+writeSplatIds": ["writeSplatIds"],
+                      "sortHist+sortScatter (octree entries)": ["sortHist", "sortScatter"]}
+        stages = []
+        for stat, (kname, nb) in models.items():
+            if stat in kernel_stats and kernel_stats[stat][1] > 0:
+                ms = kernel_stats[stat][0] / K
+                per_launch = [tj.get(k) for k in traffic_of.get(kname, [])]
+                stages.append({"stat": stat, "kernel": kname, "ms_per_step": round(ms, 3),
+                               "launches_per_step": kernel_stats[stat][1] // K,
+                               "algorithmic_bytes_per_step": int(nb),
+                               "achieved_GBps": round(nb / (ms * 1e-3) / 1e9, 1),
+                               "hbm_frac": round(nb / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "hbm_traffic_bytes_per_launch": (sum(per_launch) if per_launch and all(v is not None for v in per_launch)
+                                                                else None)})
+        stages.sort(key=lambda s: -s["ms_per_step"])
+        single_ms = sum(v[0] for k, v in kernel_stats.items() if k == "device.compute") / K
         pc = "kernel.mls.processCorners.time"
+        measured = ("hipEvent pairs on the worker's stream, %d single-worker passes after the timed region (%.1f ms per pass)"
+                    % (K, single_ms))
         if stages and stages[0]["stat"] == pc:
-            # Dominant kernel = processCorners: an fp32-VALU/LDS-bound kernel (>= 140 flop/B), so its
-            # roof is the fp32 rate.  MI355X's dense f32 MFMA peak equals its f32 vector peak (157.3 TFLOP/s,
-            # MI355X_MICROARCH.md); the kernel issues no MFMA, "mfma" here only names the compute roof.
+            # Dominant kernel = processCorners: fp32 VALU + LDS work (>= 140 flop/B); no MFMA is issued (no dense
+            # contraction).  `achieved` counts the flops the kernel EXECUTES (10 per lane-test that survives sub-block culling,
+            # 25 per hit) against the fp32 vector peak, which counts packed FMAs.  The reference algorithm's count (every
+            # corner tests every listed splat) is given beside it as algorithmic_equiv_*.
             total_ms, launches = kernel_stats[pc]
             ms = total_ms / K
             alg_flops = 10 * 512 * listed + 25 * hits          # SURVEY 8d per-bucket figure, summed over buckets
-            done_flops = 10 * tests + 25 * hits                # distance tests that survive sub-block culling
-            achieved = alg_flops / (ms * 1e-3) / 1e12
+            done_flops = 10 * tests + 25 * hits
+            achieved = done_flops / (ms * 1e-3) / 1e12
             result["roofline"] = {
                 "kernel": "processCorners",
-                "bound": "mfma",
+                "bound": "valu_fp32",
                 "achieved": round(achieved, 3),
                 "peak": FP32_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
@@ -266,16 +538,17 @@ def main():
                 "traffic": tj.get("processCorners"),
                 "avg_launch_ms": round(total_ms / launches, 4),
                 "launches_per_step": launches // K,
-                "algorithmic_flops_per_launch": int(alg_flops // max(launches // K, 1)),
-                "algorithmic": "SURVEY 8d: 10*512*SigmaL + 25*H flops of the reference's every-corner-tests-every-listed-"
-                               "splat loop; sub-block culling skips most of those tests, see executed_*",
-                "executed_TFLOPs": round(done_flops / (ms * 1e-3) / 1e12, 3),
-                "executed_frac": round(done_flops / (ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4),
+                "executed_flops_per_launch": int(done_flops // max(launches // K, 1)),
+                "executed": "10 flops per (corner, splat) lane-test executed + 25 per hit; the tests of lanes outside the support "
+                            "are executed work, the culled ones are not counted",
+                "algorithmic_equiv_TFLOPs": round(alg_flops / (ms * 1e-3) / 1e12, 3),
+                "algorithmic_equiv_frac": round(alg_flops / (ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4),
+                "algorithmic_equiv": "SURVEY 8d: 10*512*SigmaL + 25*H flops of the reference's every-corner-tests-every-listed-"
+                                     "splat loop, most of which sub-block culling never executes",
                 "hbm_algorithmic_GBps": round((36 * listed + 4 * corners) / (ms * 1e-3) / 1e9, 1),
                 "sigma_L": listed, "tests": tests, "hits": hits, "corners": corners,
                 "share_of_kernel_time": round(stages[0]["ms_per_step"] / sum(s_["ms_per_step"] for s_ in stages), 3),
-                "measured": "hipEvent pairs on the worker stream, %d single-worker passes after the timed region "
-                            "(%.1f ms per pass)" % (K, single_ms),
+                "measured": measured,
             }
         elif stages:
             top = stages[0]
@@ -287,38 +560,40 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(top["achieved_GBps"] / HBM_PEAK_GBS, 5),
-                "traffic": tj.get(top["kernel"]),
+                "traffic": top["hbm_traffic_bytes_per_launch"],
                 "avg_launch_ms": round(total_ms / launches, 4),
                 "launches_per_step": launches // K,
                 "algorithmic_bytes_per_launch": int(top["algorithmic_bytes_per_step"] // max(launches // K, 1)),
                 "share_of_kernel_time": round(top["ms_per_step"] / sum(s_["ms_per_step"] for s_ in stages), 3),
-                "measured": "hipEvent pairs on the worker stream, %d single-worker passes after the timed region "
-                            "(%.1f ms per pass)" % (K, single_ms),
+                "measured": measured,
             }
         if stages:
             result["roofline"]["hbm_stages"] = stages
+            result["roofline"]["traffic_source"] = ("profiles/traffic.json: rocprofv3 --pmc passes of this commit's kernels, "
+                                                    "corrected as MI355X_MICROARCH.md prescribes (tools/profile_summary.py)")
         if tj and "roofline" in result:
-            # whole-pipeline HBM rate: measured PMC traffic per launch (profiles/traffic.json) x launches per
-            # step of every tracked kernel, over the step time of the timed region
             per_bucket = {"processCorners": 1, "latticeTriangles": 1, "latticeVertices": 1, "latticeMask": 1, "cellCode": 1,
                           "writeEntries": 1, "writeSplatIds": 1, "sortScatter": sort_passes, "sortHist": sort_passes}
             moved = sum(tj[k] * n * len(buckets) for k, n in per_bucket.items() if k in tj)
             result["roofline"]["pipeline_hbm"] = {
                 "traffic_bytes_per_step": int(moved), "achieved_GBps": round(moved / (ms_per_step * 1e-3) / 1e9, 1),
                 "peak_GBps": HBM_PEAK_GBS, "frac": round(moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                "note": "PMC traffic of the tracked kernels (over 95 %% of kernel time) / step time with %d device workers; "
-                        "the step is bound by processCorners' fp32/LDS work and by latency, not by HBM" % nworkers}
+                "note": "PMC traffic of the tracked kernels / step time with %d device workers" % nworkers}
         result["kernel_ms_per_step"] = {k: round(v[0] / K, 3) for k, v in sorted(kernel_stats.items())}
         result["work_per_step"] = {"octree_entries": entries, "occupied_cells": O, "unwelded_vertices": mc["unwelded"],
                                    "welded_vertices": Vw, "external_vertices": external, "indices": T}
 
+    secondary = world == 1 and not args.headline_only
+    L = max(1, args.leg_steps)
+
     # ---- mesh-sink leg (never `value`): every ship-out of one pass appended to the device mesher (d2d), then
     # finalize = weld by key across buckets + connected components + prune (--fit-prune default 0.02) + compaction ----
-    if world == 1 and not args.no_sink:
+    if secondary and not args.no_sink:
         sink = m.Mesher(ctx, 0.02)
         sink.reserve(mc["welded"] + 1024, mc["indices"] // 3 + 1024, mc["external"] + 1024)   # counts of the stats pass
         work.copy_from(pristine)
         ctx.synchronize()
+
         def sink_share(k):
             col = sink.collector(ctxs[k], 0)
             for b in farm.worker_share(buckets, k, nworkers):
@@ -342,39 +617,24 @@ def main():
             "note": "meshes never leave HBM; finalize = key sort + union-find + sizes + two compaction scans",
         }
         sink.close()
-        if not args.no_cpu_baseline:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import mesher_oracle as mo
-            b = buckets[len(buckets) // 2]
-            work.copy_from(pristine)
-            ctx.synchronize()
-            got = workers[0].process(work, b.first, b.count, b.low, b.num_vertices)          # ship-outs copied to the host
-            meshes = [dict(chunk=0, vertices=g["vertices"], num_internal=g["num_internal"], keys=g["keys"][g["num_internal"]:],
-                           triangles=g["triangles"]) for g in got]
-            t0 = time.perf_counter()
-            _, ost = mo.mesh_sink(meshes, 0.02)
-            cpu_s = time.perf_counter() - t0
-            nvs = sum(len(g["vertices"]) for g in got)
-            result["mesh_sink"]["cpu_oracle"] = {
-                "mvertices_per_s": round(nvs / cpu_s / 1e6, 2), "cores": 1, "kind": "port",
-                "sample": "the ship-outs of one of the %d buckets (%d vertices), %.1f s of the numpy/scipy mesh-sink oracle"
-                          % (len(buckets), nvs, cpu_s)}
 
     # ---- device-bucketer leg (never `value`): the RAW cloud resident in HBM, partitioned on the device exactly as
     # the reference's Bucket::bucket would with its defaults (255-cell buckets, 63-cell microblocks, 2 097 152 splats,
     # src/mlsgpu_core.cpp:112-132,655-678), each leaf gathered + transformed on the device and run through a worker ----
-    if world == 1 and not args.no_partition:
+    if secondary and not args.no_partition and W["cloud"] is not None:
         from mlsgpu_amd import binding as mb
-        raw = m.DeviceBuffer(ctx, array=cloud)
+        grid = W["grid"][0]
+        n_splats = W["n_splats"]
+        raw = m.DeviceBuffer(ctx, nbytes=W["cloud"].numel() * 4, borrow=W["cloud"].data_ptr())
         ext = (0, grid - 1, 0, grid - 1, 0, grid - 1)
         bp = dict(max_splats=args.partition_max_splats, max_cells=255, chunk_cells=0, micro_cells=63, max_split=1 << 30)
         leaves = mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=lambda leaf, ids: None, **bp)
         ctx.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(L):
             mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=lambda leaf, ids: None, **bp)
         ctx.synchronize()
-        part_s = (time.perf_counter() - t0) / args.steps
+        part_s = (time.perf_counter() - t0) / L
         pmax = max(l["num_splats"] for l in leaves)
         pcells = max(max(l["extents"][2 * i + 1] - l["extents"][2 * i] for i in range(3)) for l in leaves)
         # the bucketer's callback hands every leaf to the bucket farm's device path (gather + transform kernel into a
@@ -394,9 +654,9 @@ def main():
             pfarm.finish()
         partition_pass()                            # warm-up
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(L):
             partition_pass()
-        pipe_s = (time.perf_counter() - t0) / args.steps
+        pipe_s = (time.perf_counter() - t0) / L
         pvox = sum((l["extents"][1] - l["extents"][0]) * (l["extents"][3] - l["extents"][2]) * (l["extents"][5] - l["extents"][4])
                    for l in leaves)
         result["device_partition"] = {
@@ -408,76 +668,71 @@ def main():
             "note": "raw cloud resident in HBM -> mlsgpu_hip_bucket (reference partition) -> mlsgpu_hip_farm_submit_device "
                     "(device gather + transform) -> the farm's device workers; bucketing is inside the pipeline time",
         }
-        if not args.no_cpu_baseline:
-            sys.path.insert(0, os.path.join(ROOT, "tests"))
-            import oracle_binding as ob
-            sample = np.ascontiguousarray(cloud[::10])
-            t0 = time.perf_counter()
-            cpu_leaves = ob.bucket_partition(sample, (0.0, 0.0, 0.0), 1.0, ext, bp["max_splats"] // 10, bp["max_cells"],
-                                             bp["chunk_cells"], bp["micro_cells"], bp["max_split"])
-            cpu_s = time.perf_counter() - t0
-            result["device_partition"]["cpu_oracle"] = {
-                "msplats_per_s": round(len(sample) / cpu_s / 1e6, 2), "cores": 1, "kind": "port", "buckets": len(cpu_leaves),
-                "sample": "every 10th splat (%d) with a tenth of the bucket capacity, %.1f s of the single-threaded "
-                          "bucketing oracle (the reference's bucketing is single-threaded too)" % (len(sample), cpu_s)}
         pfarm.close()
         del raw
-    del cloud
+    W["cloud"] = None
 
-    # ---- PCIe-inclusive leg (never `value`): the same buckets from HOST memory through the bucket farm
-    # (pinned double-buffered staging, H2D on a copy stream, the same device workers), N = 1 only ----
-    if world == 1 and not args.no_stream:
-        del workers, work, pristine
-        farm_obj = m.BucketFarm([local_rank], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
-                                mesh_memory=args.mesh_memory_mb << 20)
-        views = [bucketed[b.first:b.first + b.count] for b in buckets]
+    # the remaining legs start from HOST memory: one copy of the bucketed splats
+    bucketed_host = None
+    if secondary and (not args.no_transfer or not args.no_cpu_baseline):
+        bucketed_host = bucketed_t.cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
+    del workers, work, pristine, bucketed_t, W
+    torch.cuda.empty_cache()
 
-        def stream_pass():
-            for i, (b, v) in enumerate(zip(buckets, views)):
-                farm_obj.submit(v, b.low, b.num_vertices, i)
-            farm_obj.finish()
-        stream_pass()                                   # warm-up
+    # ---- transfer-inclusive legs (never `value`): SURVEY 8(d)'s region, host splats in -> last mesh byte out ----
+    if secondary and not args.no_transfer:
+        result["transfer_inclusive"] = transfer_legs(m, args, local_rank, bucketed_host, buckets, max_count, max_cells, voxels, L)
+        result["transfer_inclusive"]["distribution"] = args.dist
+
+    # ---- D1 ("shells", SURVEY 8d: report both): resident rate and the same transfer-inclusive legs ----
+    if secondary and not args.no_shells and args.dist == "uniform" and args.workload in ("auto", "cfg3"):
+        from mlsgpu_amd import synth
+        cloud, g = synth.make_cloud_device("cfg3", device, scale=args.scale, dist="shells")
+        sb_t, sbuckets = synth.bucketize_device(cloud, synth.grid_buckets((g, g, g), 255))
+        del cloud
+        torch.cuda.synchronize()
+        smax = max(b.count for b in sbuckets)
+        scells = max(max(b.num_vertices) for b in sbuckets) - 1
+        svox = sum(b.cells for b in sbuckets)
+        sprist = m.DeviceBuffer(ctx, nbytes=sb_t.numel() * 4, borrow=sb_t.data_ptr())
+        swork = m.DeviceBuffer(ctx, nbytes=sb_t.numel() * 4)
+        sworkers = [m.Worker(c, smax, max_cells=scells, mesh_memory=args.mesh_memory_mb << 20) for c in ctxs]
+        scol = [m.binding.SizeCollector() for _ in range(nworkers)]
+
+        def s_share(k):
+            for b in farm.worker_share(sbuckets, k, nworkers):
+                sworkers[k].process(swork, b.first, b.count, b.low, b.num_vertices, collector=scol[k])
+            ctxs[k].synchronize()
+
+        def s_step():
+            swork.copy_from(sprist)
+            ctx.synchronize()
+            list(pool.map(s_share, range(nworkers)))
+        for _ in range(2):
+            s_step()
+        ssteps = max(10, min(args.steps, 50))
+        scol[:] = [m.binding.SizeCollector() for _ in range(nworkers)]
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            stream_pass()
-        st_s = (time.perf_counter() - t0) / args.steps
-        result["pcie_inclusive"] = {
-            "value": round(voxels / st_s / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(st_s * 1e3, 3),
-            "h2d_GB_per_step": round(bucketed.nbytes / 1e9, 3),
-            "h2d_GBps_sustained": round(bucketed.nbytes / st_s / 1e9, 2),
-            "note": "host (pageable numpy) -> pinned staging (4 copy threads) -> H2D -> device workers; meshes stay in HBM",
-        }
-        farm_obj.close()
+        for _ in range(ssteps):
+            s_step()
+        s_dt = (time.perf_counter() - t0) / ssteps
+        shells = {"value": round(svox / s_dt / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(s_dt * 1e3, 3), "steps": ssteps,
+                  "workload": "cfg3 grid, %d splats on concentric shells (D1 of SURVEY 8d), %d buckets" % (int(50_000_000 * args.scale), len(sbuckets)),
+                  "triangles_per_step": sum(c.triangles for c in scol) // ssteps,
+                  "vertices_per_step": sum(c.vertices for c in scol) // ssteps}
+        sb_host = sb_t.cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1) if not args.no_transfer else None
+        del sworkers, swork, sprist, sb_t
+        torch.cuda.empty_cache()
+        if not args.no_transfer:
+            shells["transfer_inclusive"] = transfer_legs(m, args, local_rank, sb_host, sbuckets, smax, scells, svox, L)
+        result["shells"] = shells
 
-    # ---- CPU baseline: the oracle ("port") on a bounded sample, rank 0 at N = 1 only ----
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import oracle_binding as ob
-        # Sample: buckets of the same cloud, centre outwards, until about 12 s of CPU work (at least one).
-        order = sorted(range(len(buckets)), key=lambda i: abs(i - len(buckets) // 2))
-        cpu_s, cells, nspl, used = 0.0, 0, 0, 0
-        for i in order:
-            sample = buckets[i]
-            spl = bucketed[sample.first:sample.first + sample.count].copy()
-            t0 = time.perf_counter()
-            # the reference's own defaults: 24-slice swathes, (maxCells^2 * 2) cells of mesh memory
-            ob.bucket(spl, 0, len(spl), sample.num_vertices, sample.low, max_cells=max_cells)
-            cpu_s += time.perf_counter() - t0
-            cells += sample.cells
-            nspl += len(spl)
-            used += 1
-            if cpu_s > 12.0:
-                break
-        result["cpu_baseline"] = {
-            "value": round(cells / cpu_s / 1e6, 4),
-            "unit": "Mvoxels/s",
-            "cores": ob.lib().orc_num_threads(),
-            "kind": "port",
-            "sample": "%d of the %d buckets of the same cloud (centre outwards): %d cells, %d splats, %.1f s of "
-                      "the OpenMP oracle on %d threads" % (used, len(buckets), cells, nspl, cpu_s,
-                                                          ob.lib().orc_num_threads()),
-        }
-        result["speedup_vs_cpu"] = round(value / result["cpu_baseline"]["value"], 1)
+    # ---- CPU baseline: the oracle ("port") parallel over buckets on the host cores, rank 0 at N = 1 only ----
+    if rank == 0 and secondary and not args.no_cpu_baseline:
+        cb = cpu_baseline(bucketed_host, buckets, max_cells)
+        if cb is not None:
+            result["cpu_baseline"] = cb
+            result["gpu_over_cpu"] = round(value / cb["value"], 1)
 
     if rank == 0:
         print(json.dumps(result))

@@ -211,6 +211,10 @@ uint64_t mlsgpu_hip_mesh_host_bytes(const mlsgpu_mesh *mesh);
 /* enqueueReadMesh into a HostKeyMesh blob [extKeys u64][vertices 3xf32][triangles 3xu32]
  * (src/mesh.cpp:51-102).  hostBlob must be 8-byte aligned.  async != 0: caller synchronises. */
 int mlsgpu_hip_mesh_read(mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh, void *hostBlob, int async);
+/* Measurement aid (bench.py and the full-size tests check the meshes a timed pass produced without copying gigabytes
+ * to the host): out[0..2] = for the vertex words, the triangle indices and the external keys (as 32-bit words) the
+ * sum of word[i] * (2 i + 1) modulo 2^64.  Synchronises the stream. */
+int mlsgpu_hip_mesh_checksum(mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh, uint64_t out[3]);
 /* ScaleBiasFilter, src/mesh_filter.cpp:69-113 + kernels/scale_bias.cl:33-41: in place. */
 int mlsgpu_hip_scale_bias(mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh, float scale, float bx, float by, float bz);
 
@@ -381,6 +385,11 @@ int mlsgpu_hip_mesher_reserve(mlsgpu_mesher *mesher, uint64_t numVertices, uint6
  * in one GPU's HBM).  Blocks may arrive in any order, chunk ids interleaved (OOCMesher::add indexes chunks[chunkId.gen]
  * and accepts any arrival order too); output chunks are in order of first arrival. */
 int mlsgpu_hip_mesher_add(mlsgpu_mesher *mesher, mlsgpu_ctx *from, uint64_t chunkId, const mlsgpu_mesh *mesh);
+/* a mlsgpu_farm_output_fn whose `user` is the mlsgpu_mesher: give it to mlsgpu_hip_farm_create and the farm's device
+ * workers (of any of its GPUs) append their ship-outs to the device sink */
+int mlsgpu_hip_mesher_farm_output(void *mesher, int device, uint64_t chunkId, mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh);
+/* Empties the mesher for the next job; arenas, scratch and outputs keep their capacity. */
+int mlsgpu_hip_mesher_reset(mlsgpu_mesher *mesher);
 /* What MesherBase::write does before it writes files: weld by key, components, prune.  *numChunks = chunks that have
  * triangles (no output is produced for the others, src/mesher.cpp:820). */
 int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *mesher, uint32_t *numChunks);

@@ -176,6 +176,7 @@ def lib():
     sig("mlsgpu_hip_mesh_host_bytes", u64, P(Mesh))
     sig("mlsgpu_hip_mesh_read", C.c_int, vp, P(Mesh), vp, C.c_int)
     sig("mlsgpu_hip_scale_bias", C.c_int, vp, P(Mesh), f32, f32, f32, f32)
+    sig("mlsgpu_hip_mesh_checksum", C.c_int, vp, P(Mesh), vp)
     sig("mlsgpu_hip_worker_create", C.c_int, vp, P(WorkerConfig), P(vp))
     sig("mlsgpu_hip_worker_destroy", None, vp)
     sig("mlsgpu_hip_worker_resource_usage", u64, P(WorkerConfig))
@@ -198,6 +199,7 @@ def lib():
     sig("mlsgpu_hip_host_mesher_destroy", None, vp)
     sig("mlsgpu_hip_host_mesher_set_prune_threshold", C.c_int, vp, C.c_double)
     sig("mlsgpu_hip_host_mesher_add", C.c_int, vp, u64, P(HostMesh))
+    sig("mlsgpu_hip_host_mesher_farm_output", C.c_int, vp, C.c_int, u64, P(HostMesh))
     sig("mlsgpu_hip_host_mesher_finalize", C.c_int, vp, P(u32))
     sig("mlsgpu_hip_host_mesher_chunk", C.c_int, vp, u32, P(u64), P(u64), P(u64), P(vp), P(vp))
     sig("mlsgpu_hip_host_mesher_stats", C.c_int, vp, vp)
@@ -213,6 +215,8 @@ def lib():
     sig("mlsgpu_hip_mesher_set_prune_threshold", C.c_int, vp, C.c_double)
     sig("mlsgpu_hip_mesher_add", C.c_int, vp, vp, u64, vp)
     sig("mlsgpu_hip_mesher_reserve", C.c_int, vp, u64, u64, u64)
+    sig("mlsgpu_hip_mesher_farm_output", C.c_int, vp, C.c_int, u64, vp, P(Mesh))
+    sig("mlsgpu_hip_mesher_reset", C.c_int, vp)
     sig("mlsgpu_hip_mesher_finalize", C.c_int, vp, P(u32))
     sig("mlsgpu_hip_mesher_chunk", C.c_int, vp, u32, P(u64), P(u64), P(u64), P(vp), P(vp))
     sig("mlsgpu_hip_mesher_stats", C.c_int, vp, vp)
@@ -356,6 +360,47 @@ class DeviceBuffer:
             pass
 
 
+class PinnedBuffer:
+    """Page-locked host memory (CLH::PinnedMemory, src/clh.h:334-477) that grows on demand."""
+
+    def __init__(self, nbytes):
+        self.ptr, self.nbytes = None, 0
+        self.ensure(nbytes)
+
+    def ensure(self, nbytes):
+        if nbytes <= self.nbytes:
+            return
+        self.free()
+        p = C.c_void_p()
+        check(lib().mlsgpu_hip_host_alloc(int(nbytes), C.byref(p)))
+        self.ptr, self.nbytes = p.value, int(nbytes)
+
+    def free(self):
+        if self.ptr:
+            lib().mlsgpu_hip_host_free(self.ptr)
+        self.ptr, self.nbytes = None, 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def download_into_pinned(ctx, chunk, pinned):
+    """Reads a device chunk of Mesher.chunk(i, download=False) into `pinned` (vertices then triangles), asynchronously
+    on ctx's stream; returns the bytes.  The caller synchronises."""
+    nv, nt = 12 * chunk["num_vertices"], 12 * chunk["num_triangles"]
+    if nv + nt > pinned.nbytes:
+        ctx.synchronize()
+        pinned.ensure(int((nv + nt) * 1.1) + 4096)
+    if nv:
+        check(lib().mlsgpu_hip_memcpy_d2h(ctx.h, pinned.ptr, chunk["d_vertices"], nv, 1))
+    if nt:
+        check(lib().mlsgpu_hip_memcpy_d2h(ctx.h, pinned.ptr + nv, chunk["d_triangles"], nt, 1))
+    return nv + nt
+
+
 def download_ptr(ctx, ptr, dtype, count):
     out = np.empty(count, np.dtype(dtype))
     if count:
@@ -492,6 +537,83 @@ class SizeCollector:
         self.cb = OUTPUT_FN(cb)
 
 
+def words_checksum(words):
+    """The host twin of mlsgpu_hip_mesh_checksum for one array: sum of word[i] * (2 i + 1) modulo 2^64."""
+    w = np.ascontiguousarray(words).view(np.uint32).ravel().astype(np.uint64)
+    with np.errstate(over="ignore"):
+        return int((w * (np.arange(len(w), dtype=np.uint64) * np.uint64(2) + np.uint64(1))).sum(dtype=np.uint64))
+
+
+def batch_checksum(batch):
+    """(vertices, triangles, external keys) checksums of a host batch, as mlsgpu_hip_mesh_checksum computes them."""
+    ni = batch["num_internal"]
+    return (words_checksum(batch["vertices"]), words_checksum(batch["triangles"]), words_checksum(batch["keys"][ni:]))
+
+
+class ChecksumCollector:
+    """An output functor that folds every ship-out into a digest on the device (nothing is copied to the host):
+    sizes plus the three checksums of every batch, combined in ship-out order."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.vertices = self.triangles = self.external = self.batches = 0
+        self.sums = []
+        self.error = None
+
+        def cb(user, stream, meshp):
+            try:
+                mm = meshp.contents
+                out = np.zeros(3, np.uint64)
+                check(lib().mlsgpu_hip_mesh_checksum(ctx.h, meshp, _p(out)))
+                self.sums.append((int(mm.numVertices), int(mm.numTriangles), int(mm.numInternalVertices)) + tuple(int(x) for x in out))
+                self.vertices += mm.numVertices
+                self.triangles += mm.numTriangles
+                self.external += mm.numVertices - mm.numInternalVertices
+                self.batches += 1
+                return 0
+            except Exception as e:   # never let an exception cross the C boundary
+                self.error = e
+                return 1
+        self.cb = OUTPUT_FN(cb)
+
+    def digest(self):
+        return digest_of_sums(self.sums)
+
+
+class ExternalCollector(ChecksumCollector):
+    """ChecksumCollector that also copies every batch's EXTERNAL vertices and their keys to the host (a few percent of
+    a mesh): what a cross-bucket weld check needs at sizes where whole meshes are too big to read back."""
+
+    def __init__(self, ctx):
+        super().__init__(ctx)
+        self.ext_keys, self.ext_vertices = [], []
+        inner = self.cb
+
+        def cb(user, stream, meshp):
+            rc = inner(user, stream, meshp)
+            if rc != 0:
+                return rc
+            try:
+                mm = meshp.contents
+                ni, ne = int(mm.numInternalVertices), int(mm.numVertices - mm.numInternalVertices)
+                if ne:
+                    self.ext_keys.append(download_ptr(ctx, mm.dVertexKeys + 8 * ni, np.uint64, ne))
+                    self.ext_vertices.append(download_ptr(ctx, mm.dVertices + 12 * ni, np.float32, 3 * ne).reshape(-1, 3))
+                return 0
+            except Exception as e:
+                self.error = e
+                return 1
+        self.cb = OUTPUT_FN(cb)
+
+
+def digest_of_sums(sums):
+    import hashlib
+    h = hashlib.sha256()
+    for rec in sums:
+        h.update(np.array(rec, np.uint64).tobytes())
+    return h.hexdigest()[:16]
+
+
 class Mesher:
     """Device-resident mesh sink: OOCMesher's weld / components / prune / chunks (src/mesher.h:203-330)."""
 
@@ -532,6 +654,9 @@ class Mesher:
     def collector(self, from_ctx, chunk_id):
         """An output functor for Worker.process / Marching.generate that feeds this mesher."""
         return MesherCollector(self, from_ctx, chunk_id)
+
+    def reset(self):
+        check(lib().mlsgpu_hip_mesher_reset(self.h))
 
     def finalize(self):
         n = C.c_uint32(0)
@@ -874,7 +999,7 @@ class _BorrowedContext:
 class BucketFarm:
     """CopyGroup + one DeviceWorkerGroup per GPU (include/mlsgpu_hip.h, "bucket farm")."""
 
-    def __init__(self, devices, max_bucket_splats, workers_per_device=1, spare=1, collect=False, **worker_kw):
+    def __init__(self, devices, max_bucket_splats, workers_per_device=1, spare=1, collect=False, sink=None, **worker_kw):
         cfg = FarmConfig()
         cfg.numDevices = len(devices)
         self._devs = (C.c_int32 * len(devices))(*devices)
@@ -909,8 +1034,15 @@ class BucketFarm:
                 self.error = e
                 return 1
         self._cb = FARM_OUTPUT_FN(cb) if collect else C.cast(None, FARM_OUTPUT_FN)
+        user = None
+        if sink is not None:
+            # a device Mesher: the workers append their ship-outs to it, in C (mlsgpu_hip_mesher_farm_output)
+            assert not collect
+            self._sink = sink
+            self._cb = C.cast(lib().mlsgpu_hip_mesher_farm_output, FARM_OUTPUT_FN)
+            user = sink.h
         h = C.c_void_p()
-        check(lib().mlsgpu_hip_farm_create(C.byref(cfg), self._cb, None, C.byref(h)))
+        check(lib().mlsgpu_hip_farm_create(C.byref(cfg), self._cb, user, C.byref(h)))
         self.h = h
 
     def submit(self, splats, low_extent, num_vertices, chunk_id):

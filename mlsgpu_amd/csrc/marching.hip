@@ -1741,6 +1741,51 @@ MLSGPU_API int mlsgpu_hip_mesh_read(mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh, vo
     return MLSGPU_OK;
 }
 
+/* Measurement aid: sum over the 32-bit words w[i] of an array of w[i] * (2 i + 1), modulo 2^64 -- sensitive to
+ * values and to their order; partial sums per wave, one atomic per wave. */
+namespace
+{
+__global__ __launch_bounds__(256) void checksumKernel(const uint32_t *words, uint64_t n, unsigned long long *out)
+{
+    unsigned long long acc = 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+        acc += (unsigned long long) words[i] * (2 * i + 1);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        acc += __shfl_xor(acc, d, 64);
+    if (laneId() == 0 && acc != 0)
+        atomicAdd(out, acc);
+}
+} // namespace
+
+MLSGPU_API int mlsgpu_hip_mesh_checksum(mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh, uint64_t out[3])
+{
+    REQUIRE(ctx != nullptr && mesh != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(mesh->numInternalVertices <= mesh->numVertices, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    auto it = ctx->scratchCache.find("mesh.checksum");
+    if (it == ctx->scratchCache.end())
+    {
+        void *d = nullptr;
+        HIP_CHECK(hipMalloc(&d, 24));
+        it = ctx->scratchCache.emplace("mesh.checksum", std::shared_ptr<void>(d, [](void *p) { hipFree(p); })).first;
+    }
+    unsigned long long *d = static_cast<unsigned long long *>(it->second.get());
+    HIP_CHECK(hipMemsetAsync(d, 0, 24, ctx->stream));
+    const uint64_t numExt = mesh->numVertices - mesh->numInternalVertices;
+    const struct { const void *p; uint64_t words; } parts[3] = {
+        {mesh->dVertices, 3 * mesh->numVertices}, {mesh->dTriangles, 3 * mesh->numTriangles},
+        {mesh->dVertexKeys + mesh->numInternalVertices, 2 * numExt}};
+    for (int k = 0; k < 3; k++)
+        if (parts[k].words > 0)
+            hipLaunchKernelGGL(checksumKernel, dim3((uint32_t) std::min<uint64_t>(divUp(parts[k].words, 256), 4096)), dim3(256), 0,
+                               ctx->stream, static_cast<const uint32_t *>(parts[k].p), parts[k].words, d + k);
+    HIP_CHECK(hipGetLastError());
+    HIP_CHECK(hipMemcpyAsync(out, d, 24, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MLSGPU_OK;
+}
+
 MLSGPU_API int mlsgpu_hip_scale_bias(mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh, float scale, float bx, float by, float bz)
 {
     REQUIRE(ctx != nullptr && mesh != nullptr, MLSGPU_ERR_INVALID);

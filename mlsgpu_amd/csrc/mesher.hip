@@ -557,6 +557,27 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
     return MLSGPU_OK;
 }
 
+/* a mlsgpu_farm_output_fn whose `user` is the mesher: the farm's device workers append their ship-outs */
+MLSGPU_API int mlsgpu_hip_mesher_farm_output(void *mesher, int device, uint64_t chunkId, mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh)
+{
+    (void) device;
+    return mlsgpu_hip_mesher_add(static_cast<mlsgpu_mesher *>(mesher), ctx, chunkId, mesh);
+}
+
+/* empties the mesher (arenas, scratch and outputs keep their capacity): the next job starts from nothing */
+MLSGPU_API int mlsgpu_hip_mesher_reset(mlsgpu_mesher *m)
+{
+    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    m->vertices.used = m->triangles.used = 0;
+    m->extKeys.used = m->extGid.used = m->extChunk.used = 0;
+    m->blocks.clear();
+    m->chunkIds.clear();
+    m->outChunks.clear();
+    m->finalized = false;
+    return MLSGPU_OK;
+}
+
 /* finalize wants the blocks of a chunk adjacent in the arenas (output order is arena order, and equal keys must sort by
  * chunk).  With several workers and several chunks they arrive interleaved: move the blocks into (chunk by first
  * arrival, arrival) order -- device-to-device copies into fresh arenas, vertex ids shifted by the block's move. */

@@ -49,7 +49,7 @@ def sphere_cloud(n, center, big_radius, r_lo, r_hi, seed, first=0):
 
 def uniform_cloud(n, extent, r_lo, r_hi, seed, first=0, chunk=4_000_000):
     """D2 of SURVEY 8d: position ~ U[0, extent)^3, radius ~ U(r_lo, r_hi), normal = normalize(p - centre),
-    quality = 1 / r^2."""
+    quality = 1 / r^2.  (uniform_cloud_device generates the same bits on a GPU.)"""
     s = np.zeros(n, SPLAT_DTYPE)
     c = 0.5 * extent
     for lo in range(0, n, chunk):
@@ -97,12 +97,161 @@ CONFIGS = {
 }
 
 
+def cloud_seed(cfg, seed_offset=0):
+    return SEED_BASE + int(cfg[3:]) + (seed_offset << 8)
+
+
+def _i64(v):
+    """A 64-bit pattern as the signed value torch's int64 holds."""
+    v &= 0xFFFFFFFFFFFFFFFF
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def uniform_cloud_device(n, extent, r_lo, r_hi, seed, device, first=0, chunk=16_000_000):
+    """uniform_cloud on a torch device (bench.py and the full-size tests generate 50 M - 200 M splats in HBM instead
+    of on the host): the same counter-based splitmix64 stream and the same float64 -> float32 arithmetic, operation
+    for operation, so the result is bit-identical to the numpy generator (tests/test_synth.py checks it).  Returns an
+    (n, 8) float32 tensor laid out as SPLAT_DTYPE.  torch is plumbing here -- it only fills input buffers."""
+    import torch
+    out = torch.empty((n, 8), dtype=torch.float32, device=device)
+    golden, m1, m2 = _i64(0x9E3779B97F4A7C15), _i64(0xBF58476D1CE4E5B9), _i64(0x94D049BB133111EB)
+
+    def lsr(z, k):                                   # logical shift right of the 64-bit pattern
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    def mix(z):
+        z = (z ^ lsr(z, 30)) * m1
+        z = (z ^ lsr(z, 27)) * m2
+        return z ^ lsr(z, 31)
+    c = 0.5 * extent
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        ids = torch.arange(first + lo, first + lo + m, dtype=torch.int64, device=device)
+        u = []
+        for j in range(4):
+            ctr = ids * 8 + (j + 1)
+            z = mix(ctr * golden + _i64(seed))
+            u.append(lsr(z, 11).to(torch.float64) * (1.0 / 9007199254740992.0))
+        p = [u[a] * extent for a in range(3)]
+        d = [pa - c for pa in p]
+        ln = torch.sqrt((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2])
+        ln = torch.where(ln == 0, torch.ones_like(ln), ln)
+        r = r_lo + (r_hi - r_lo) * u[3]
+        v = out[lo:lo + m]
+        for a in range(3):
+            v[:, a] = p[a].to(torch.float32)
+            v[:, 4 + a] = (d[a] / ln).to(torch.float32)
+        v[:, 3] = r.to(torch.float32)
+        v[:, 7] = (1.0 / (r * r)).to(torch.float32)
+    return out
+
+
+def shells_cloud_device(n, extent, spacing, r_lo, r_hi, seed, device, first=0, chunk=16_000_000):
+    """shells_cloud on a torch device.  Same stream and formulas; cos / sin of the device's float64 library may differ
+    from numpy's in the last place, so this is the same distribution, not guaranteed the same bits (bench.py only)."""
+    import math
+
+    import torch
+    out = torch.empty((n, 8), dtype=torch.float32, device=device)
+    golden, m1, m2 = _i64(0x9E3779B97F4A7C15), _i64(0xBF58476D1CE4E5B9), _i64(0x94D049BB133111EB)
+
+    def lsr(z, k):
+        return (z >> k) & ((1 << (64 - k)) - 1)
+
+    def mix(z):
+        z = (z ^ lsr(z, 30)) * m1
+        z = (z ^ lsr(z, 27)) * m2
+        return z ^ lsr(z, 31)
+    kmax = max(int((0.5 * extent - 4) // spacing), 1)
+    w = np.arange(1, kmax + 1, dtype=np.float64) ** 2
+    cdf = torch.tensor(np.cumsum(w) / w.sum(), dtype=torch.float64, device=device)
+    for lo in range(0, n, chunk):
+        m = min(chunk, n - lo)
+        ids = torch.arange(first + lo, first + lo + m, dtype=torch.int64, device=device)
+        u = []
+        for j in range(5):
+            z = mix((ids * 8 + (j + 1)) * golden + _i64(seed))
+            u.append(lsr(z, 11).to(torch.float64) * (1.0 / 9007199254740992.0))
+        k = (torch.searchsorted(cdf, u[4], right=True) + 1).to(torch.float64)
+        zz = 2.0 * u[0] - 1.0
+        t = (2.0 * u[1] - 1.0) * math.pi
+        xy = torch.sqrt(1.0 - zz * zz)
+        nrm = [torch.cos(t) * xy, torch.sin(t) * xy, zz]
+        v = out[lo:lo + m]
+        for a in range(3):
+            v[:, 4 + a] = nrm[a].to(torch.float32)
+            v[:, a] = (0.5 * extent + nrm[a] * (spacing * k)).to(torch.float32)
+        v[:, 3] = (r_lo + (r_hi - r_lo) * u[2]).to(torch.float32)
+        v[:, 7] = (1.0 - u[3]).to(torch.float32)
+    return out
+
+
+def make_cloud_device(cfg, device, scale=1.0, seed_offset=0, dist="uniform"):
+    """make_cloud(cfg, "uniform") generated on `device`; returns ((n, 8) float32 tensor, grid corners per side)."""
+    c = CONFIGS[cfg]
+    g = c["grid"]
+    n = max(int(c["splats"] * scale), 1)
+    if dist == "shells":
+        return shells_cloud_device(n, float(g - 1), 16.0, 1.0, 2.0, cloud_seed(cfg, seed_offset), device), g
+    return uniform_cloud_device(n, float(g - 1), 2.0, 3.0, cloud_seed(cfg, seed_offset), device), g
+
+
+def grid_buckets(dims, max_cells=255, runs=None):
+    """The fixed spatial split of bucketize() for a grid of `dims` corners per axis: [(low, num_vertices)] in z-major,
+    x-fastest order.  runs[a] overrides the number of runs along axis a."""
+    per_axis = []
+    for a in range(3):
+        cells = dims[a] - 1
+        if runs is not None and runs[a]:
+            base, extra = divmod(cells, runs[a])
+            lo, r = 0, []
+            for i in range(runs[a]):
+                k = base + (1 if i < extra else 0)
+                r.append((lo, lo + k))
+                lo += k
+            assert max(h - l for l, h in r) <= max_cells
+            per_axis.append(r)
+        else:
+            per_axis.append(split_axis(cells, max_cells))
+    out = []
+    for (z0, z1) in per_axis[2]:
+        for (y0, y1) in per_axis[1]:
+            for (x0, x1) in per_axis[0]:
+                out.append(((x0, y0, z0), (x1 - x0 + 1, y1 - y0 + 1, z1 - z0 + 1)))
+    return out
+
+
+def bucketize_device(cloud, boxes):
+    """bucketize() for a cloud resident on a torch device and an explicit list of boxes [(low, num_vertices)] (a
+    rank's share of grid_buckets): every box receives, in global order, all splats whose bounding box [p - r, p + r]
+    meets its vertex range.  Returns ((total, 8) float32 tensor, [Bucket])."""
+    import torch
+    pos, rad = cloud[:, 0:3], cloud[:, 3:4]
+    lo, hi = pos - rad, pos + rad
+    cache = {}
+
+    def axis_mask(a, r0, r1):
+        key = (a, r0, r1)
+        if key not in cache:
+            cache[key] = (hi[:, a] >= r0) & (lo[:, a] <= r1)
+        return cache[key]
+    pieces, buckets, first = [], [], 0
+    for low, nv in boxes:
+        m = axis_mask(2, low[2], low[2] + nv[2] - 1) & axis_mask(1, low[1], low[1] + nv[1] - 1) \
+            & axis_mask(0, low[0], low[0] + nv[0] - 1)
+        idx = torch.nonzero(m).squeeze(1)
+        pieces.append(cloud.index_select(0, idx))
+        buckets.append(Bucket(tuple(low), tuple(nv), first, int(idx.numel())))
+        first += int(idx.numel())
+    return (torch.cat(pieces) if pieces else cloud[:0]), buckets
+
+
 def make_cloud(cfg, dist="uniform", scale=1.0, seed_offset=0):
     """Cloud of a BASELINE config.  `scale` < 1 shrinks the splat count (tests); the grid stays."""
     c = CONFIGS[cfg]
     g = c["grid"]
     n = max(int(c["splats"] * scale), 1)
-    seed = SEED_BASE + int(cfg[3:]) + (seed_offset << 8)
+    seed = cloud_seed(cfg, seed_offset)
     if cfg == "cfg1":
         return sphere_cloud(n, (32.0, 32.0, 32.0), 24.0, 1.0, 2.0, seed), g
     if dist == "uniform":

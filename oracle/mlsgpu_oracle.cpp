@@ -1100,13 +1100,16 @@ struct MlsGenerator
     float boundaryFactor;
     int shape;
     MlsStats stats;
+    double seconds = 0.0;       /* wall time spent in processCorners (bench.py's cpu_baseline reports it per stage) */
 };
 
 static void mlsGeneratorFn(void *user, float *field, size_t pitch, const Swathe *sw)
 {
     MlsGenerator *g = (MlsGenerator *) user;
+    const double t0 = omp_get_wtime();
     processCorners(field, pitch, g->splats, g->commands, g->start, g->startShift, g->offset,
                    *sw, g->boundaryFactor, g->shape, &g->stats);
+    g->seconds += omp_get_wtime() - t0;
 }
 
 /* src/mls.cpp:137-144 */
@@ -1273,7 +1276,8 @@ ORC_API void orc_marching_copy_slice(orc_marching *m, float *image, uint64_t pit
 /*
  * splats: mutated (radius -> 1/r^2) exactly like the device buffer.
  * size = numVertices of the bucket grid; offset = keyOffset = low extents.
- * stats (optional, 16 u64): [0]=Sigma L, [1]=H, [2..8]=MarchingStats, [9]=numCommands
+ * stats (optional, 16 u64): [0]=Sigma L, [1]=H, [2..8]=MarchingStats, [9]=numCommands,
+ * [10..12] = microseconds of wall time in the octree build, in processCorners, in marching (generate minus MLS)
  */
 ORC_API int orc_bucket(void *splats, uint64_t firstSplat, uint64_t numSplats,
                        const uint32_t size[3], const int32_t offset[3],
@@ -1286,8 +1290,10 @@ ORC_API int orc_bucket(void *splats, uint64_t firstSplat, uint64_t numSplats,
     for (int i = 0; i < 3; i++)
         expanded[i] = roundUp(size[i], wgs[i]);
     TreeResult tree;
+    const double tTree = omp_get_wtime();
     if (treeBuild((Splat *) splats, firstSplat, numSplats, expanded, offset, subsampling, levels, tree) != 0)
         return 1;
+    const double treeSeconds = omp_get_wtime() - tTree;
     MlsGenerator gen;
     gen.splats = (const Splat *) splats;
     gen.commands = tree.commands.data();
@@ -1301,10 +1307,15 @@ ORC_API int orc_bucket(void *splats, uint64_t firstSplat, uint64_t numSplats,
     if (m.init(maxCells + 1, maxCells + 1, maxCells + 1, maxSwathe, meshMemory, wgs) != 0)
         return 2;
     uint32_t keyOffset[3] = {(uint32_t) offset[0], (uint32_t) offset[1], (uint32_t) offset[2]};
+    const double tGen = omp_get_wtime();
     if (m.generate(mlsGeneratorFn, &gen, out, outUser, size, keyOffset) != 0)
         return 3;
+    const double genSeconds = omp_get_wtime() - tGen;
     if (stats)
     {
+        stats[10] += (uint64_t) (treeSeconds * 1e6);
+        stats[11] += (uint64_t) (gen.seconds * 1e6);
+        stats[12] += (uint64_t) ((genSeconds - gen.seconds) * 1e6);
         stats[0] += gen.stats.listed;
         stats[1] += gen.stats.hits;
         const uint64_t *ms = (const uint64_t *) &m.stats;

@@ -11,7 +11,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-LIB_PATH = os.path.join(ORACLE_DIR, "liboracle.so")
+# MLSGPU_ORACLE_LIB selects another build of the same sources (bench.py's cpu_baseline: liboracle_native.so, built with
+# -O3 -march=native on the machine that times it)
+LIB_PATH = os.environ.get("MLSGPU_ORACLE_LIB") or os.path.join(ORACLE_DIR, "liboracle.so")
 
 SPLAT_DTYPE = np.dtype([("position", np.float32, 3), ("radius", np.float32),
                         ("normal", np.float32, 3), ("quality", np.float32)])
@@ -29,6 +31,8 @@ class Swathe(C.Structure):
 
 def build():
     src = os.path.join(ORACLE_DIR, "mlsgpu_oracle.cpp")
+    if os.environ.get("MLSGPU_ORACLE_LIB"):
+        return
     if (not os.path.exists(LIB_PATH)
             or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(LIB_PATH))):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
@@ -270,5 +274,5 @@ def bucket(splats, first, num, size, offset, levels=6, subsampling=3, boundary_l
     if rc != 0:
         raise ValueError("orc_bucket failed: %d" % rc)
     names = ["listed", "hits", "occupied", "unwelded", "indices", "welded", "external", "shipouts",
-             "overflows", "commands"]
-    return out.batches, dict(zip(names, [int(x) for x in stats[:10]]))
+             "overflows", "commands", "tree_us", "mls_us", "marching_us"]
+    return out.batches, dict(zip(names, [int(x) for x in stats[:13]]))

@@ -104,3 +104,143 @@ def test_farm_dispatches_over_device_groups():
             np.testing.assert_array_equal(g["vertices"].view(np.uint32), e["vertices"].view(np.uint32))
             np.testing.assert_array_equal(g["triangles"], e["triangles"])
     farm.close()
+
+
+def _oracle_meshes(allb, buckets, chunk_of=lambda i: 0):
+    ref = allb.copy()
+    meshes = []
+    for i, b in enumerate(buckets):
+        batches, _ = ob.bucket(ref, b.first, b.count, b.num_vertices, b.low, max_cells=63, max_swathe=64,
+                               mesh_memory=63 * 63 * 2 * 872)
+        for g in batches:
+            meshes.append(dict(chunk=chunk_of(i), vertices=g["vertices"], num_internal=g["num_internal"],
+                               keys=g["keys"][g["num_internal"]:], triangles=g["triangles"]))
+    return meshes
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ring_kb", [256, 65536])
+def test_farm_host_output_welds_across_device_groups(ring_kb):
+    """The reference's route for several GPUs: every device group's ship-outs are read back through the pinned circular
+    buffer (OutputGeneratorBuilder::Functor, src/workers.h:488-509) and welded by ONE host mesher
+    (src/mesher.cpp:220-469).  Two groups (both on GPU 0 here), two chunks whose blocks arrive interleaved; a 256 KB ring
+    makes the workers wait for the mesher thread and wraps many times.  The result equals the oracle sink fed with the
+    oracle's bucket meshes."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import mesher_oracle as mo
+    import mlsgpu_amd as m
+    from mlsgpu_amd import synth
+    cloud = synth.shells_cloud(120_000, 95.0, 16.0, 1.5, 2.5, seed=321)
+    allb, buckets = synth.bucketize(cloud, 96, 32)
+    cap = max(b.count for b in buckets)
+    welder = m.HostMesher(0.02)
+    farm = m.BucketFarm([0, 0], cap, workers_per_device=2, max_cells=63)
+    farm.set_host_output(ring_kb << 10, welder)
+    chunk_of = lambda i: i % 2                                      # noqa: E731
+    for i, b in enumerate(buckets):
+        farm.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, chunk_of(i))
+    farm.finish()
+    st, hs = farm.stats(), farm.host_stats()
+    assert st["per_device"][0] > 0 and st["per_device"][1] > 0
+    assert hs["meshes"] == st["shipouts"] and hs["bytes"] > 0
+    if ring_kb == 256:
+        assert hs["bytes"] > 4 * (ring_kb << 10)                    # the ring wrapped
+    farm.close()
+    n = welder.finalize()
+    stats = welder.stats()
+    exp, exp_stats = mo.mesh_sink(_oracle_meshes(allb, buckets, chunk_of), 0.02)
+    for k in ("total_vertices", "threshold", "components", "kept_components", "kept_vertices", "kept_triangles"):
+        assert stats[k] == exp_stats[k], k
+    got = sorted((welder.chunk(i) for i in range(n)), key=lambda c: c[0])
+    assert [c for c, _, _ in got] == sorted(c for c, _, _ in exp)
+    for (c, v, t), (ec, ev, et) in zip(got, sorted(exp, key=lambda c: c[0])):
+        assert mo.isomorphic(v, t, ev, et)
+    welder.close()
+
+
+@pytest.mark.gpu
+def test_farm_host_output_python_sink_and_oversized_mesh():
+    import mlsgpu_amd as m
+    from mlsgpu_amd import synth
+    cloud = synth.shells_cloud(120_000, 95.0, 16.0, 1.5, 2.5, seed=321)
+    allb, buckets = synth.bucketize(cloud, 96, 32)
+    cap = max(b.count for b in buckets)
+    got = {}
+    farm = m.BucketFarm([0], cap, workers_per_device=2, max_cells=63)
+    farm.set_host_output(8 << 20, lambda device, chunk, batch: got.setdefault(chunk, []).append(batch))
+    for i, b in enumerate(buckets):
+        farm.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, i)
+    farm.finish()
+    farm.close()
+    ref = allb.copy()
+    for i, b in enumerate(buckets):
+        exp, _ = ob.bucket(ref, b.first, b.count, b.num_vertices, b.low, max_cells=63, max_swathe=64,
+                           mesh_memory=63 * 63 * 2 * 872)
+        assert len(got.get(i, [])) == len(exp), i
+        for g, e in zip(got.get(i, []), exp):
+            assert g["num_internal"] == e["num_internal"]
+            np.testing.assert_array_equal(g["vertices"].view(np.uint32), e["vertices"].view(np.uint32))
+            np.testing.assert_array_equal(g["triangles"], e["triangles"])
+            np.testing.assert_array_equal(g["keys"][g["num_internal"]:], e["keys"][e["num_internal"]:])
+    # a ship-out that does not fit the ring is an error, reported by finish, not a hang
+    farm = m.BucketFarm([0], cap, max_cells=63)
+    farm.set_host_output(4096, None)
+    b = max(buckets, key=lambda b: b.count)
+    farm.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, 0)
+    with pytest.raises(m.LengthError):
+        farm.finish()
+    farm.close()
+
+
+@pytest.mark.gpu
+def test_device_sink_behind_the_farm_and_peer_routes():
+    """Ship-outs appended to the device mesher by the farm's workers in C (mlsgpu_hip_mesher_farm_output), two chunks
+    interleaved over two device groups; then the same with the cross-GPU routes forced on one GPU: buckets gathered on the
+    cloud's device and peer-copied into the item (mlsgpu_hip_farm_submit_device), ship-outs peer-copied into the mesher."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+sys.path[:0] = [%r, %r, %r]
+import numpy as np
+import mesher_oracle as mo
+import oracle_binding as ob
+import mlsgpu_amd as m
+from mlsgpu_amd import binding as mb, synth
+from test_farm_gpu import _oracle_meshes
+cloud = synth.shells_cloud(120_000, 95.0, 16.0, 1.5, 2.5, seed=321)
+allb, buckets = synth.bucketize(cloud, 96, 32)
+cap = max(b.count for b in buckets)
+ctx = m.Context(0)
+sink = m.Mesher(ctx, 0.02)
+farm = m.BucketFarm([0, 0], cap, workers_per_device=2, max_cells=63, sink=sink)
+raw = m.DeviceBuffer(ctx, array=allb)
+ext = (0, 95, 0, 95, 0, 95)
+for i, b in enumerate(buckets):
+    if i %% 3 == 0:
+        farm.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, i %% 2)
+    else:
+        ids = m.DeviceBuffer(ctx, array=np.arange(b.first, b.first + b.count, dtype=np.uint32))
+        farm.submit_device(0, raw, ids.ptr, b.count, (0.0, 0.0, 0.0), 1.0, ext, b.low, b.num_vertices, i %% 2)
+farm.finish()
+assert min(farm.stats()["per_device"][:2]) > 0
+farm.close()
+n = sink.finalize()
+stats = sink.stats()
+exp, exp_stats = mo.mesh_sink(_oracle_meshes(allb, buckets, lambda i: i %% 2), 0.02)
+for k in ("total_vertices", "threshold", "components", "kept_components", "kept_vertices", "kept_triangles"):
+    assert stats[k] == exp_stats[k], k
+got = sorted((sink.chunk(i) for i in range(n)), key=lambda c: c["chunk"])
+for c, (ec, ev, et) in zip(got, sorted(exp, key=lambda c: c[0])):
+    assert c["chunk"] == ec and mo.isomorphic(c["vertices"], c["triangles"], ev, et)
+sink.reset()
+assert sink.finalize() == 0
+print("ok")
+""" % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+       os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    for env in ({}, {"MLSGPU_HIP_FARM_FORCE_PEER": "1", "MLSGPU_HIP_MESHER_FORCE_PEER": "1"}):
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr

@@ -1,0 +1,189 @@
+"""The BASELINE.json configurations that only fit a GPU, at full size (cfg3) or full shape (cfg4), under -m gpu.
+
+cfg3  512^3 grid, 50 M uniform splats, 27 buckets: the cloud bench.py times.  Oracle bit-parity on three buckets (corner,
+      face, centre), size-independent properties on all 27 (bucket tiling, cross-bucket agreement of shared vertices bit
+      for bit, key multiplicity), and the totals + digest that bench.py prints for its timed passes, pinned in
+      tests/golden/cfg3_uniform.json.
+cfg4  1024^3 grid cut 8 ways: the multi-device bucket farm with eight device groups (all on GPU 0 here: a one-GPU box
+      stands in for eight GPUs; on an 8-GPU node pass MLSGPU_TEST_DEVICES=0,1,...,7), ship-outs read back through the
+      pinned circular buffer into the host welder; splat count reduced, oracle parity on sampled buckets, and the Euler
+      characteristic of the welded shells as the whole-job check.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from gpu_common import assert_batches_equal, ctx  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg3_uniform.json")
+
+
+def test_device_generators_match_numpy():
+    """The clouds bench.py and the tests below generate in HBM are the numpy clouds of mlsgpu_amd.synth, bit for bit."""
+    import torch
+    from mlsgpu_amd import synth
+    dev = torch.device("cuda", 0)
+    ref, g = synth.make_cloud("cfg3", scale=0.01)
+    got, _ = synth.make_cloud_device("cfg3", dev, scale=0.01)
+    np.testing.assert_array_equal(got.cpu().numpy().view(np.uint32).ravel(), ref.view(np.uint32).ravel())
+    allb, buckets = synth.bucketize(ref, g, 255)
+    gb, gbuckets = synth.bucketize_device(got, synth.grid_buckets((g, g, g), 255))
+    np.testing.assert_array_equal(gb.cpu().numpy().view(np.uint32).ravel(), allb.view(np.uint32).ravel())
+    assert [(b.low, b.num_vertices, b.first, b.count) for b in gbuckets] == \
+        [(b.low, b.num_vertices, b.first, b.count) for b in buckets]
+    # the tail of the full-size cloud is the same stream
+    tail = synth.uniform_cloud_device(1000, 511.0, 2.0, 3.0, synth.cloud_seed("cfg3"), dev, first=49_999_000)
+    exp = synth.uniform_cloud(1000, 511.0, 2.0, 3.0, synth.cloud_seed("cfg3"), first=49_999_000)
+    np.testing.assert_array_equal(tail.cpu().numpy().view(np.uint32).ravel(), exp.view(np.uint32).ravel())
+
+
+def test_mesh_checksum_matches_host(ctx):
+    """mlsgpu_hip_mesh_checksum (the digest bench.py prints) against the same sums computed from the copied-back mesh."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as mb, synth
+    cloud, g = synth.make_cloud("cfg1")
+    w = m.Worker(ctx, len(cloud), max_cells=63)
+    buf = m.DeviceBuffer(ctx, array=cloud)
+    batches = w.process(buf, 0, len(cloud), (0, 0, 0), (g, g, g))
+    buf.upload(cloud)
+    col = w.process(buf, 0, len(cloud), (0, 0, 0), (g, g, g), collector=mb.ChecksumCollector(ctx))
+    assert col.batches == len(batches) >= 1
+    for b, rec in zip(batches, col.sums):
+        assert rec[:3] == (len(b["vertices"]), len(b["triangles"]), b["num_internal"])
+        assert rec[3:] == mb.batch_checksum(b)
+    exp, _ = ob.bucket(cloud.copy(), 0, len(cloud), (g, g, g), (0, 0, 0), max_cells=63, max_swathe=64,
+                       mesh_memory=63 * 63 * 2 * 872)
+    sums = [(len(b["vertices"]), len(b["triangles"]), b["num_internal"]) + mb.batch_checksum(b) for b in exp]
+    assert mb.digest_of_sums(sums) == col.digest()          # the oracle's meshes have the digest the device computed
+
+
+def test_cfg3_full_size(ctx):
+    import torch
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as mb, synth
+    dev = torch.device("cuda", 0)
+    cloud, g = synth.make_cloud_device("cfg3", dev)
+    assert len(cloud) == 50_000_000 and g == 512
+    bucketed, buckets = synth.bucketize_device(cloud, synth.grid_buckets((g, g, g), 255))
+    del cloud
+    torch.cuda.synchronize()
+    assert len(buckets) == 27 and sum(b.cells for b in buckets) == (g - 1) ** 3
+    max_cells = max(max(b.num_vertices) for b in buckets) - 1
+    max_count = max(b.count for b in buckets)
+    nbytes = bucketed.numel() * 4
+    pristine = m.DeviceBuffer(ctx, nbytes=nbytes, borrow=bucketed.data_ptr())
+    work = m.DeviceBuffer(ctx, nbytes=nbytes)
+
+    # ---- all 27 buckets with bench.py's settings: totals, digest, cross-bucket agreement ----
+    w = m.Worker(ctx, max_count, max_cells=max_cells, mesh_memory=4096 << 20)
+    work.copy_from(pristine)
+    col = mb.ExternalCollector(ctx)
+    for b in buckets:
+        w.process(work, b.first, b.count, b.low, b.num_vertices, collector=col)
+    cnt = w.marching_counters()
+    assert cnt["welded"] == col.vertices and cnt["indices"] == 3 * col.triangles
+    keys = np.concatenate(col.ext_keys)
+    verts = np.concatenate(col.ext_vertices).view(np.uint32)
+    order = np.argsort(keys, kind="stable")
+    keys, verts = keys[order], verts[order]
+    same = keys[1:] == keys[:-1]
+    assert same.sum() > 1_000_000                                       # buckets share millions of face vertices
+    assert np.all(verts[1:][same] == verts[:-1][same])                  # ... and agree on every one, bit for bit
+    _, counts = np.unique(keys, return_counts=True)
+    assert counts.max() <= 8
+    got = dict(triangles=int(col.triangles), vertices=int(col.vertices), external=int(col.external), shipouts=col.batches,
+               digest=col.digest())
+    if os.environ.get("MLSGPU_WRITE_GOLDEN"):
+        out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "cfg3_uniform.json")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        json.dump(got, open(out, "w"), indent=1)
+    exp = json.load(open(GOLDEN))
+    assert got == {k: exp[k] for k in got}, (got, exp)
+
+    # ---- oracle bit-parity on a corner, a face and the centre bucket (2 M splats, 170^3 cells each) ----
+    del w
+    mm = 1 << 30
+    w = m.Worker(ctx, max_count, max_cells=max_cells, mesh_memory=mm)
+    for i in (0, 4, 13):
+        b = buckets[i]
+        host = bucketed[b.first:b.first + b.count].cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
+        work.copy_from(pristine)
+        batches = w.process(work, b.first, b.count, b.low, b.num_vertices)
+        exp_b, st = ob.bucket(host, 0, b.count, b.num_vertices, b.low, max_cells=max_cells, max_swathe=max_cells + 1,
+                              mesh_memory=mm)
+        assert st["shipouts"] == len(batches) >= 1
+        assert_batches_equal(batches, exp_b)
+        del batches, exp_b
+
+
+def farm_devices(n):
+    env = os.environ.get("MLSGPU_TEST_DEVICES")
+    if env:
+        devs = [int(x) for x in env.split(",")]
+        assert len(devs) == n
+        return devs
+    return [0] * n
+
+
+def test_cfg4_shape_eight_device_groups():
+    """cfg4's shape: 1024^3 grid, 125 buckets, EIGHT device groups behind one copy thread, every ship-out read back into
+    the host welder.  Splats: 8 M on seven concentric shells (a surface instead of cfg4's noise, so that the result has
+    a topology to check; the oracle finishes sampled buckets in seconds)."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import synth
+    g = 1024
+    cloud = synth.shells_cloud(8_000_000, float(g - 1), 64.0, 2.5, 3.5, seed=4444)
+    allb, buckets = synth.bucketize(cloud, g, 255)
+    assert len(buckets) == 125
+    max_cells = max(max(b.num_vertices) for b in buckets) - 1
+    cap = max(b.count for b in buckets)
+    devices = farm_devices(8)
+    welder = m.HostMesher(0.001)
+    farm = m.BucketFarm(devices, cap, workers_per_device=1, spare=1, max_cells=max_cells, mesh_memory=256 << 20)
+    farm.set_host_output(64 << 20, welder)        # a small ring: workers wait for the mesher thread now and then
+    for i, b in enumerate(buckets):
+        room = farm.acquire(b.count)               # the loader's route: straight into pinned staging
+        room[:] = allb[b.first:b.first + b.count]
+        farm.push(b.count, b.low, b.num_vertices, 0)
+    farm.finish()
+    st = farm.stats()
+    hs = farm.host_stats()
+    assert st["buckets"] == 125 and sum(st["per_device"][:8]) == 125
+    assert min(st["per_device"][:8]) > 0                                   # every device group got work
+    assert hs["meshes"] == st["shipouts"] > 0
+    farm.close()
+    assert welder.finalize() == 1
+    ws = welder.stats()
+    _, v, t = welder.chunk(0)
+    # seven closed spheres: welded across 125 buckets / 8 device groups, V - E + F = 2 each with E = 3F/2
+    assert ws["kept_components"] == 7 and ws["components"] >= 7
+    assert ws["total_vertices"] < ws["vertices_added"]
+    assert len(v) == ws["kept_vertices"] and len(t) == ws["kept_triangles"]
+    assert 2 * len(v) - len(t) == 4 * 7
+    edges = np.sort(np.concatenate([t[:, [0, 1]], t[:, [1, 2]], t[:, [2, 0]]]).astype(np.int64), axis=1)
+    _, ecount = np.unique(edges[:, 0] * len(v) + edges[:, 1], return_counts=True)
+    assert np.all(ecount == 2)                                             # every edge has exactly two triangles
+    # oracle parity where the oracle is quick: the buckets with the fewest splats that still produce a mesh
+    ctx = m.Context(devices[0])
+    w = m.Worker(ctx, cap, max_cells=max_cells, mesh_memory=256 << 20)
+    buf = m.DeviceBuffer(ctx, array=allb)
+    ref = allb.copy()
+    done = 0
+    for b in sorted(buckets, key=lambda b: b.count):
+        if b.count < 2000:
+            continue
+        batches = w.process(buf, b.first, b.count, b.low, b.num_vertices)
+        exp, _ = ob.bucket(ref, b.first, b.count, b.num_vertices, b.low, max_cells=max_cells, max_swathe=max_cells + 1,
+                           mesh_memory=256 << 20)
+        assert_batches_equal(batches, exp)
+        done += 1 if batches else 0
+        if done == 3:
+            break
+    assert done == 3
+    del w, buf
+    ctx.close()
+    welder.close()
