@@ -60,7 +60,7 @@ def parse_args():
     p.add_argument("--scale", type=float, default=1.0, help="splat-count scale (debug only; 1.0 = BASELINE size)")
     p.add_argument("--mesh-memory-mb", type=int, default=4096, help="Marching mesh arena per worker")
     p.add_argument("--workers", type=int, default=4, help="device worker threads per GPU (measured 2..4: +0..6 %)")
-    p.add_argument("--variant", type=int, default=2, help="MLS kernel variant: 0 culled, 1 basic, 2 culled + hit lists, 3 scalar-fed")
+    p.add_argument("--variant", type=int, default=2, help="MLS kernel variant: 0 culled, 1 basic, 2 culled + hit lists")
     p.add_argument("--leg-steps", type=int, default=3, help="passes of every secondary leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-transfer", action="store_true", help="skip the transfer-inclusive legs (SURVEY 8d timed region)")
@@ -469,7 +469,7 @@ def main():
             "bucket_splats_total": int(bucketed_t.shape[0]),
             "mesh_memory_mb": args.mesh_memory_mb,
             "device_workers": nworkers,
-            "mls_variant": {0: "culled", 1: "basic", 2: "culled+hit-lists", 3: "culled+hit-lists, scalar-fed tests"}[args.variant],
+            "mls_variant": {0: "culled", 1: "basic", 2: "culled+hit-lists"}[args.variant],
             "sharding": "one process per GPU, rank r owns z-slab r (25 buckets); no data-path collective" if world > 1
                         else "single GPU",
             "triangles_per_step": triangles,

@@ -446,6 +446,27 @@ int mlsgpu_hip_ply_read(mlsgpu_ply_reader *reader, uint64_t first, uint64_t coun
 int mlsgpu_hip_ply_load(mlsgpu_ply_reader *reader, mlsgpu_ctx *ctx, uint64_t first, uint64_t count, mlsgpu_splat *dOut,
                         uint32_t hostThreads);
 
+/* ---- SplatSet::FileSet, src/splat_set.h:383-700: several PLY files read as ONE splat sequence
+ *      (file after file; the reference packs the file number into the upper bits of its splat ids, here ids are
+ *      positions in the concatenation). ---- */
+typedef struct mlsgpu_fileset mlsgpu_fileset;
+int mlsgpu_hip_fileset_create(float smooth, float maxRadius, mlsgpu_fileset **out);
+void mlsgpu_hip_fileset_destroy(mlsgpu_fileset *files);
+/* FileSet::addFile: the header is parsed and checked now (MLSGPU_ERR_FORMAT as mlsgpu_hip_ply_open) */
+int mlsgpu_hip_fileset_add_file(mlsgpu_fileset *files, const char *path);
+uint64_t mlsgpu_hip_fileset_num_files(const mlsgpu_fileset *files);
+uint64_t mlsgpu_hip_fileset_num_splats(const mlsgpu_fileset *files);     /* FileSet::maxSplats */
+/* FileSet::setBufferSize (default 32 MiB): the host memory a load may hold, whatever the size of the files */
+int mlsgpu_hip_fileset_set_buffer_size(mlsgpu_fileset *files, uint64_t bytes);
+/* splats [first, first + count) of the sequence into host memory (e.g. what mlsgpu_hip_farm_acquire returned) */
+int mlsgpu_hip_fileset_read(mlsgpu_fileset *files, uint64_t first, uint64_t count, mlsgpu_splat *out);
+/* The same range into DEVICE memory with bounded host memory: `readerThreads` host threads (0 = 4; the reference's
+ * ReaderThread, src/splat_set.h:560-700) decode consecutive chunks into the quarters of one pinned buffer of the set's
+ * buffer size while earlier chunks travel to the GPU on ctx's stream (the role of src/async_io.h:95-140 + CopyGroup for
+ * clouds that fit in HBM: 10^9 splats are 32 GB of 288).  Returns when dOut[0 .. count) is complete. */
+int mlsgpu_hip_fileset_load(mlsgpu_fileset *files, mlsgpu_ctx *ctx, uint64_t first, uint64_t count, mlsgpu_splat *dOut,
+                            uint32_t readerThreads);
+
 /* DeviceWorkerGroupBase::computeMaxSwathe, src/workers.cpp:169-182 */
 uint32_t mlsgpu_hip_compute_max_swathe(uint32_t yMax, uint32_t y, uint32_t yAlign, uint32_t zAlign);
 

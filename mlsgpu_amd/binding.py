@@ -210,6 +210,14 @@ def lib():
     sig("mlsgpu_hip_ply_layout", C.c_int, vp, vp)
     sig("mlsgpu_hip_ply_read", C.c_int, vp, u64, u64, vp)
     sig("mlsgpu_hip_ply_load", C.c_int, vp, vp, u64, u64, vp, u32)
+    sig("mlsgpu_hip_fileset_create", C.c_int, f32, f32, P(vp))
+    sig("mlsgpu_hip_fileset_destroy", None, vp)
+    sig("mlsgpu_hip_fileset_add_file", C.c_int, vp, C.c_char_p)
+    sig("mlsgpu_hip_fileset_num_files", u64, vp)
+    sig("mlsgpu_hip_fileset_num_splats", u64, vp)
+    sig("mlsgpu_hip_fileset_set_buffer_size", C.c_int, vp, u64)
+    sig("mlsgpu_hip_fileset_read", C.c_int, vp, u64, u64, vp)
+    sig("mlsgpu_hip_fileset_load", C.c_int, vp, vp, u64, u64, vp, u32)
     sig("mlsgpu_hip_mesher_create", C.c_int, vp, P(vp))
     sig("mlsgpu_hip_mesher_destroy", None, vp)
     sig("mlsgpu_hip_mesher_set_prune_threshold", C.c_int, vp, C.c_double)
@@ -820,6 +828,48 @@ class PlyReader:
     def close(self):
         if getattr(self, "h", None):
             lib().mlsgpu_hip_ply_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FileSet:
+    """SplatSet::FileSet (src/splat_set.h:383-700): several PLY files read as one splat sequence."""
+
+    def __init__(self, paths=(), smooth=1.0, max_radius=float("inf"), buffer_size=None):
+        h = C.c_void_p()
+        check(lib().mlsgpu_hip_fileset_create(smooth, max_radius, C.byref(h)))
+        self.h = h
+        for p in paths:
+            self.add_file(p)
+        if buffer_size is not None:
+            check(lib().mlsgpu_hip_fileset_set_buffer_size(self.h, buffer_size))
+
+    def add_file(self, path):
+        check(lib().mlsgpu_hip_fileset_add_file(self.h, str(path).encode()))
+
+    def __len__(self):
+        return int(lib().mlsgpu_hip_fileset_num_splats(self.h))
+
+    def read(self, first=0, count=None, out=None):
+        count = len(self) - first if count is None else count
+        if out is None:
+            out = np.empty(count, SPLAT_DTYPE)
+        check(lib().mlsgpu_hip_fileset_read(self.h, first, count, _p(out)))
+        return out
+
+    def load(self, ctx, d_out, first=0, count=None, reader_threads=0):
+        count = len(self) - first if count is None else count
+        check(lib().mlsgpu_hip_fileset_load(self.h, ctx.h, first, count, d_out.ptr, reader_threads))
+        return count
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mlsgpu_hip_fileset_destroy(self.h)
             self.h = None
 
     def __del__(self):

@@ -354,21 +354,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define LIST_STAGE 256
 #define LIST_CAP 52        /* bytes per lane; 13 dwords (odd) keeps the per-lane rows on different LDS banks */
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef const f32x4 __attribute__((address_space(4))) *ConstFloat4Ptr;
-
-template<int SHAPE, bool STATS, bool SCALAR>
+template<int SHAPE, bool STATS>
 __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
 {
     __shared__ float4 sPosRad[LIST_STAGE];
     __shared__ float4 sNormQ[LIST_STAGE];
     __shared__ uint32_t sMask[LIST_STAGE];
-    __shared__ uint32_t sId[SCALAR ? LIST_STAGE : 1];
     __shared__ uint8_t sList[512][LIST_CAP];
-    /* SCALAR: the splat a wave tests is the same in all 64 lanes, so its record can come through the scalar data cache
-     * (s_load_dwordx4 from the splat array, L2-resident since the staging loads) into SGPRs instead of a 16-byte
-     * broadcast read that costs the LDS pipe four cycles per test.  The array is read-only in this kernel. */
-    const ConstFloat4Ptr cSplats = (ConstFloat4Ptr) (uintptr_t) A.splats;
 
     const uint32_t nBlocks = A.blocksX * A.blocksY * A.blocksZ;
     const uint32_t bid = xcdRemap(blockIdx.x, nBlocks, A.xcdChunk);
@@ -456,8 +448,6 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
                     const float4 nq = A.splats[2 * (int64_t) mine + 1];
                     sPosRad[tid] = pr;
                     sNormQ[tid] = nq;
-                    if (SCALAR)
-                        sId[tid] = (uint32_t) mine;
                     float d[3][2];
                     const float p[3] = {pr.x, pr.y, pr.z};
                     const float b[3] = {bx0, by0, bz0};
@@ -494,66 +484,31 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
             {
                 const uint32_t m = sMask[g + lane];
                 uint64_t todo = __ballot((m >> wave) & 1u);
-                uint32_t vid = 0;
-                if (SCALAR)
-                    vid = sId[g + lane];        /* entries beyond `staged` are never selected */
-                /* one distance test + branch-free append (write the slot, keep it only if hit: the next append
-                 * overwrites it) */
-                auto testOne = [&](const f32x4 a, const int i)
-                {
-                    if (STATS)
-                        nTests += 64;
-                    const f32x2 pxy = f32x2{a.x, a.y} - cxy;
-                    const float pz = a.z - cz;
-                    const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
-                    const float d = pp * a.w;
-                    *tail = (uint8_t) i;
-                    tail += d < RADIUS_CUTOFF ? 1 : 0;
-                    asm volatile("" : "+v"(tail));      /* keep the tail itself in a register, not base + count */
-                };
+                /* up to four relevant splats between capacity checks; per splat the x/y differences are one
+                 * packed subtract on the pair as it arrives from LDS, the rest scalar -- the same IEEE operations
+                 * as dot3() in the basic kernel */
                 while (todo != 0)
                 {
                     if (__any(tail + 4 > listEnd))
                         drain();
-                    if (SCALAR)
-                    {
-                        /* the next (up to) four relevant splats: their ids from the lanes that staged them, four
-                         * scalar loads in flight, then the tests; slots past the end repeat the first splat, unused */
-                        const int l0 = (int) __builtin_ctzll(todo);
-                        todo &= todo - 1;
-                        const int l1 = todo ? (int) __builtin_ctzll(todo) : l0;
-                        const bool h1 = todo != 0;
-                        todo &= todo - 1;
-                        const int l2 = todo ? (int) __builtin_ctzll(todo) : l0;
-                        const bool h2 = todo != 0;
-                        todo &= todo - 1;
-                        const int l3 = todo ? (int) __builtin_ctzll(todo) : l0;
-                        const bool h3 = todo != 0;
-                        todo &= todo - 1;
-                        const f32x4 a0 = cSplats[2 * (uint64_t) __builtin_amdgcn_readlane(vid, l0)];
-                        const f32x4 a1 = cSplats[2 * (uint64_t) __builtin_amdgcn_readlane(vid, l1)];
-                        const f32x4 a2 = cSplats[2 * (uint64_t) __builtin_amdgcn_readlane(vid, l2)];
-                        const f32x4 a3 = cSplats[2 * (uint64_t) __builtin_amdgcn_readlane(vid, l3)];
-                        testOne(a0, g + l0);
-                        if (h1) testOne(a1, g + l1);
-                        if (h2) testOne(a2, g + l2);
-                        if (h3) testOne(a3, g + l3);
-                    }
-                    else
-                    {
-                        /* up to four relevant splats between capacity checks; per splat the x/y differences are one
-                         * packed subtract on the pair as it arrives from LDS, the rest scalar -- the same IEEE
-                         * operations as dot3() in the basic kernel */
 #pragma unroll
-                        for (int k = 0; k < 4; k++)
-                        {
-                            if (todo == 0)
-                                break;
-                            const int i = g + (int) __builtin_ctzll(todo);
-                            todo &= todo - 1;
-                            const float4 q = sPosRad[i];
-                            testOne(f32x4{q.x, q.y, q.z, q.w}, i);
-                        }
+                    for (int k = 0; k < 4; k++)
+                    {
+                        if (todo == 0)
+                            break;
+                        const int i = g + (int) __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        if (STATS)
+                            nTests += 64;
+                        const float4 a = sPosRad[i];
+                        const f32x2 pxy = f32x2{a.x, a.y} - cxy;
+                        const float pz = a.z - cz;
+                        const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
+                        const float d = pp * a.w;
+                        /* branch-free append: write the slot, keep it only if hit (the next append overwrites it) */
+                        *tail = (uint8_t) i;
+                        tail += d < RADIUS_CUTOFF ? 1 : 0;
+                        asm volatile("" : "+v"(tail));      /* keep the tail itself in a register, not base + count */
                     }
                 }
             }
@@ -634,7 +589,7 @@ MLSGPU_API int mlsgpu_hip_mls_set_boundary_limit(mlsgpu_mls *m, float limit)
 
 MLSGPU_API int mlsgpu_hip_mls_set_variant(mlsgpu_mls *m, int variant)
 {
-    REQUIRE(m != nullptr && variant >= 0 && variant <= 3, MLSGPU_ERR_INVALID);
+    REQUIRE(m != nullptr && variant >= 0 && variant <= 2, MLSGPU_ERR_INVALID);
     m->variant = variant;
     return MLSGPU_OK;
 }
@@ -695,10 +650,9 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
     const char *stat = "kernel.mls.processCorners.time";      /* src/mls.cpp:57 */
     A.stats = m->dStats;
 #define MLS_LAUNCH(SHAPE, CULL, STATS) LAUNCH(ctx, stat, (processCornersKernel<SHAPE, CULL, STATS>), grid, block, A)
-#define MLS_LAUNCH_LIST(SHAPE, STATS) do { if (m->variant == 3) LAUNCH(ctx, stat, (processCornersListKernel<SHAPE, STATS, true>), grid, block, A); \
-                                           else LAUNCH(ctx, stat, (processCornersListKernel<SHAPE, STATS, false>), grid, block, A); } while (0)
+#define MLS_LAUNCH_LIST(SHAPE, STATS) LAUNCH(ctx, stat, (processCornersListKernel<SHAPE, STATS>), grid, block, A)
     const bool sphere = m->shape == MLSGPU_SHAPE_SPHERE, cull = m->variant == 0;
-    if (m->variant >= 2)
+    if (m->variant == 2)
     {
         if (m->dStats != nullptr) { if (sphere) MLS_LAUNCH_LIST(MLSGPU_SHAPE_SPHERE, true); else MLS_LAUNCH_LIST(MLSGPU_SHAPE_PLANE, true); }
         else { if (sphere) MLS_LAUNCH_LIST(MLSGPU_SHAPE_SPHERE, false); else MLS_LAUNCH_LIST(MLSGPU_SHAPE_PLANE, false); }

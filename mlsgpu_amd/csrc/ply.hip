@@ -350,3 +350,215 @@ MLSGPU_API int mlsgpu_hip_ply_load(mlsgpu_ply_reader *r, mlsgpu_ctx *ctx, uint64
     }
     return rc;
 }
+
+/* ------------------------------------------------------------------ SplatSet::FileSet, src/splat_set.h:383-700 */
+
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+
+struct mlsgpu_fileset
+{
+    float smooth = 1.0f, maxRadius = 0.0f;
+    std::vector<std::string> paths;
+    std::vector<uint64_t> first;            /* first[i] = linear id of file i's first splat; first[n] = total */
+    uint64_t bufferSize = 32u << 20;        /* FileSet::DEFAULT_BUFFER_SIZE, src/splat_set.h:461 */
+};
+
+MLSGPU_API int mlsgpu_hip_fileset_create(float smooth, float maxRadius, mlsgpu_fileset **out)
+{
+    REQUIRE(out != nullptr, MLSGPU_ERR_INVALID);
+    mlsgpu_fileset *f = new mlsgpu_fileset;
+    f->smooth = smooth;
+    f->maxRadius = maxRadius;
+    f->first.push_back(0);
+    *out = f;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API void mlsgpu_hip_fileset_destroy(mlsgpu_fileset *f) { delete f; }
+
+/* FileSet::addFile, src/splat_set_impl.h: the header is checked now, the file is re-opened by whoever reads it */
+MLSGPU_API int mlsgpu_hip_fileset_add_file(mlsgpu_fileset *f, const char *path)
+{
+    REQUIRE(f != nullptr && path != nullptr, MLSGPU_ERR_INVALID);
+    mlsgpu_ply_reader *r = nullptr;
+    PROPAGATE(mlsgpu_hip_ply_open(path, f->smooth, f->maxRadius, &r));
+    const uint64_t n = r->vertexCount;
+    mlsgpu_hip_ply_close(r);
+    f->paths.push_back(path);
+    f->first.push_back(f->first.back() + n);
+    return MLSGPU_OK;
+}
+
+MLSGPU_API uint64_t mlsgpu_hip_fileset_num_files(const mlsgpu_fileset *f) { return f ? f->paths.size() : 0; }
+MLSGPU_API uint64_t mlsgpu_hip_fileset_num_splats(const mlsgpu_fileset *f) { return f ? f->first.back() : 0; }
+
+/* FileSet::setBufferSize, src/splat_set.h:505-515: the memory a stream may pin; a quarter of it per read */
+MLSGPU_API int mlsgpu_hip_fileset_set_buffer_size(mlsgpu_fileset *f, uint64_t bytes)
+{
+    REQUIRE(f != nullptr && bytes >= 4 * sizeof(mlsgpu_splat), MLSGPU_ERR_INVALID);
+    f->bufferSize = bytes;
+    return MLSGPU_OK;
+}
+
+namespace
+{
+
+/* splats [first, first + count) of the concatenation, file by file (FileRangeIterator: ranges "always within a single
+ * file", src/splat_set.h:399-420); `readers` caches one open reader per file for the calling thread */
+int filesetRead(const mlsgpu_fileset *f, std::vector<mlsgpu_ply_reader *> &readers, uint64_t first, uint64_t count,
+                mlsgpu_splat *out)
+{
+    size_t file = std::upper_bound(f->first.begin(), f->first.end(), first) - f->first.begin() - 1;
+    while (count > 0)
+    {
+        while (file + 1 < f->first.size() && f->first[file + 1] <= first)
+            file++;
+        const uint64_t inFile = first - f->first[file];
+        const uint64_t n = std::min(count, f->first[file + 1] - first);
+        if (readers[file] == nullptr)
+            PROPAGATE(mlsgpu_hip_ply_open(f->paths[file].c_str(), f->smooth, f->maxRadius, &readers[file]));
+        PROPAGATE(mlsgpu_hip_ply_read(readers[file], inFile, n, out));
+        out += n;
+        first += n;
+        count -= n;
+    }
+    return MLSGPU_OK;
+}
+
+void closeAll(std::vector<mlsgpu_ply_reader *> &readers)
+{
+    for (mlsgpu_ply_reader *r : readers)
+        mlsgpu_hip_ply_close(r);
+}
+
+} // namespace
+
+MLSGPU_API int mlsgpu_hip_fileset_read(mlsgpu_fileset *f, uint64_t first, uint64_t count, mlsgpu_splat *out)
+{
+    REQUIRE(f != nullptr && (count == 0 || out != nullptr), MLSGPU_ERR_INVALID);
+    REQUIRE(first <= f->first.back() && count <= f->first.back() - first, MLSGPU_ERR_LENGTH);
+    std::vector<mlsgpu_ply_reader *> readers(f->paths.size(), nullptr);
+    const int rc = filesetRead(f, readers, first, count, out);
+    closeAll(readers);
+    return rc;
+}
+
+/*
+ * Files -> device memory with bounded host memory: what the reference's ReaderThread + circular buffer + async I/O do
+ * for its out-of-core splat sets (src/splat_set.h:560-700, src/async_io.h:95-140), for clouds that fit in HBM (one
+ * billion splats are 32 GB of 288).  `readerThreads` host threads (0 = 4) decode consecutive chunks of bufferSize / 4
+ * bytes, each into its own quarter of ONE pinned buffer of bufferSize bytes; the calling thread sends every finished
+ * chunk to dOut on ctx's stream, and a quarter is reused once its copy has completed -- file reads, decoding and PCIe
+ * overlap, and the host never holds more than bufferSize bytes of the cloud however many files of whatever size.
+ */
+MLSGPU_API int mlsgpu_hip_fileset_load(mlsgpu_fileset *f, mlsgpu_ctx *ctx, uint64_t first, uint64_t count, mlsgpu_splat *dOut,
+                                       uint32_t readerThreads)
+{
+    REQUIRE(f != nullptr && ctx != nullptr && (count == 0 || dOut != nullptr), MLSGPU_ERR_INVALID);
+    REQUIRE(first <= f->first.back() && count <= f->first.back() - first, MLSGPU_ERR_LENGTH);
+    if (count == 0)
+        return MLSGPU_OK;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    enum { SLOTS = 4 };
+    const uint64_t chunk = std::max<uint64_t>(1, f->bufferSize / SLOTS / sizeof(mlsgpu_splat));
+    const uint64_t jobs = (count + chunk - 1) / chunk;
+    const uint32_t threads = (uint32_t) std::min<uint64_t>(std::min<uint32_t>(readerThreads == 0 ? 4u : readerThreads, SLOTS), jobs);
+    mlsgpu_splat *pinned = nullptr;
+    if (hipHostMalloc((void **) &pinned, SLOTS * chunk * sizeof(mlsgpu_splat)) != hipSuccess)
+        return setError(MLSGPU_ERR_NOMEM, "fileset load: cannot pin %llu bytes", (unsigned long long) (SLOTS * chunk * sizeof(mlsgpu_splat)));
+    hipEvent_t copied[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    int rc = MLSGPU_OK;
+    for (int s = 0; s < SLOTS && rc == MLSGPU_OK; s++)
+        if (hipEventCreateWithFlags(&copied[s], hipEventDisableTiming) != hipSuccess)
+            rc = setError(MLSGPU_ERR_HIP, "fileset load: cannot create an event");
+
+    std::mutex mutex;
+    std::condition_variable cond;
+    std::vector<char> ready(jobs, 0);           /* job decoded into its slot */
+    uint64_t issued = 0;                         /* jobs whose copy has been enqueued (by the calling thread, in order) */
+    std::atomic<uint64_t> next(0);
+    int failed = MLSGPU_OK;
+    std::string failText;
+
+    auto readerMain = [&]()
+    {
+        std::vector<mlsgpu_ply_reader *> readers(f->paths.size(), nullptr);
+        for (;;)
+        {
+            const uint64_t j = next.fetch_add(1);
+            if (j >= jobs)
+                break;
+            {
+                /* slot j % SLOTS is free once the copy of job j - SLOTS has been enqueued and has completed */
+                std::unique_lock<std::mutex> l(mutex);
+                cond.wait(l, [&] { return failed != MLSGPU_OK || j < SLOTS || issued > j - SLOTS; });
+                if (failed != MLSGPU_OK)
+                    break;
+            }
+            int r = MLSGPU_OK;
+            if (j >= SLOTS && hipEventSynchronize(copied[j % SLOTS]) != hipSuccess)
+                r = setError(MLSGPU_ERR_HIP, "fileset load: waiting for a copy failed");
+            const uint64_t at = j * chunk, n = std::min(chunk, count - at);
+            if (r == MLSGPU_OK)
+                r = filesetRead(f, readers, first + at, n, pinned + (j % SLOTS) * chunk);
+            std::lock_guard<std::mutex> l(mutex);
+            if (r != MLSGPU_OK && failed == MLSGPU_OK)
+            {
+                failed = r;
+                failText = mlsgpu_hip_last_error();
+            }
+            ready[j] = 1;
+            cond.notify_all();
+            if (r != MLSGPU_OK)
+                break;
+        }
+        closeAll(readers);
+    };
+    std::vector<std::thread> pool;
+    if (rc == MLSGPU_OK)
+        for (uint32_t t = 0; t < threads; t++)
+            pool.emplace_back(readerMain);
+    for (uint64_t j = 0; j < jobs && rc == MLSGPU_OK; j++)
+    {
+        {
+            std::unique_lock<std::mutex> l(mutex);
+            cond.wait(l, [&] { return failed != MLSGPU_OK || ready[j]; });
+            if (failed != MLSGPU_OK)
+                break;
+        }
+        const uint64_t at = j * chunk, n = std::min(chunk, count - at);
+        hipError_t e = hipMemcpyAsync(dOut + at, pinned + (j % SLOTS) * chunk, n * sizeof(mlsgpu_splat), hipMemcpyHostToDevice,
+                                      ctx->stream);
+        if (e == hipSuccess)
+            e = hipEventRecord(copied[j % SLOTS], ctx->stream);
+        std::lock_guard<std::mutex> l(mutex);
+        if (e != hipSuccess && failed == MLSGPU_OK)
+        {
+            failed = MLSGPU_ERR_HIP;
+            failText = std::string("fileset load: the host-to-device copy failed: ") + hipGetErrorString(e);
+        }
+        issued = j + 1;
+        cond.notify_all();
+    }
+    {
+        std::lock_guard<std::mutex> l(mutex);
+        if (rc != MLSGPU_OK && failed == MLSGPU_OK)
+            failed = rc;
+        cond.notify_all();
+    }
+    for (std::thread &t : pool)
+        t.join();
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && failed == MLSGPU_OK)
+    {
+        failed = MLSGPU_ERR_HIP;
+        failText = "fileset load: synchronise failed";
+    }
+    for (int s = 0; s < SLOTS; s++)
+        if (copied[s]) hipEventDestroy(copied[s]);
+    hipHostFree(pinned);
+    if (failed != MLSGPU_OK)
+        return setError(failed, "%s", failText.empty() ? mlsgpu_hip_last_error() : failText.c_str());
+    return MLSGPU_OK;
+}
