@@ -159,8 +159,14 @@ int hostReadBack(OutputThunk *t, const mlsgpu_mesh *mesh)
     Farm *f = t->farm;
     const uint64_t need = (mlsgpu_hip_mesh_host_bytes(mesh) + 63) & ~uint64_t(63);
     if (need > f->ringBytes)
-        return setError(MLSGPU_ERR_LENGTH, "farm: a ship-out of %llu bytes does not fit the host mesh buffer of %llu",
-                        (unsigned long long) need, (unsigned long long) f->ringBytes);
+    {
+        /* the first error is the one finish() reports (Marching only says "the output functor failed") */
+        char text[160];
+        snprintf(text, sizeof(text), "farm: a ship-out of %llu bytes does not fit the host mesh buffer of %llu bytes",
+                 (unsigned long long) need, (unsigned long long) f->ringBytes);
+        f->fail(MLSGPU_ERR_LENGTH, text);
+        return setError(MLSGPU_ERR_LENGTH, "%s", text);
+    }
     std::unique_ptr<HostSlot> slot(new HostSlot);
     HostSlot *s = slot.get();
     {
