@@ -422,6 +422,18 @@ int mlsgpu_hip_host_mesher_chunk(mlsgpu_host_mesher *mesher, uint32_t i, uint64_
                                  uint64_t *numTriangles, const float **vertices, const uint32_t **triangles);
 /* as mlsgpu_hip_mesher_stats */
 int mlsgpu_hip_host_mesher_stats(mlsgpu_host_mesher *mesher, uint64_t out[8]);
+/* Several meshers, one job (one process per GPU, each welding its own buckets; the reference's MPI build gathers every
+ * ship-out on one rank instead, src/mlsgpu_mpi.cpp).  Components that cross rank boundaries and the prune threshold need
+ * the other ranks' clumps: boundary() sizes and boundary_read() exports every external key this mesher has seen (sorted)
+ * with the ROOT clump holding its vertex, and the vertex / triangle counts of every root clump (0 for the others).  The
+ * caller unites clumps that share a key across meshers (a vertex seen by r meshers was counted r times), applies the
+ * prune rule of getStatistics (src/mesher.cpp:491-536) to the merged counts and hands the verdict per root clump back
+ * to finalize_with().  mlsgpu_amd/dist_sink.py does this over torch.distributed. */
+int mlsgpu_hip_host_mesher_boundary(mlsgpu_host_mesher *mesher, uint64_t *numKeys, uint64_t *numClumps);
+int mlsgpu_hip_host_mesher_boundary_read(mlsgpu_host_mesher *mesher, uint64_t *keys, uint32_t *keyClump,
+                                         uint64_t *clumpVertices, uint64_t *clumpTriangles);
+int mlsgpu_hip_host_mesher_finalize_with(mlsgpu_host_mesher *mesher, const uint8_t *keepClump, uint64_t numClumps,
+                                         uint32_t *numChunks);
 
 /* FastPly::Writer's file from host memory (src/fast_ply.cpp:443-521): binary little endian, header padded to 4 bytes,
  * float32 x y z, faces as uint8 3 + 3 x uint32 */

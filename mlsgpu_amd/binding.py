@@ -201,6 +201,9 @@ def lib():
     sig("mlsgpu_hip_host_mesher_add", C.c_int, vp, u64, P(HostMesh))
     sig("mlsgpu_hip_host_mesher_farm_output", C.c_int, vp, C.c_int, u64, P(HostMesh))
     sig("mlsgpu_hip_host_mesher_finalize", C.c_int, vp, P(u32))
+    sig("mlsgpu_hip_host_mesher_boundary", C.c_int, vp, P(u64), P(u64))
+    sig("mlsgpu_hip_host_mesher_boundary_read", C.c_int, vp, vp, vp, vp, vp)
+    sig("mlsgpu_hip_host_mesher_finalize_with", C.c_int, vp, vp, u64, P(u32))
     sig("mlsgpu_hip_host_mesher_chunk", C.c_int, vp, u32, P(u64), P(u64), P(u64), P(vp), P(vp))
     sig("mlsgpu_hip_host_mesher_stats", C.c_int, vp, vp)
     sig("mlsgpu_hip_transform_splats", None, vp, u64, vp, f32, vp)
@@ -758,6 +761,21 @@ class HostMesher:
     def finalize(self):
         n = C.c_uint32()
         check(lib().mlsgpu_hip_host_mesher_finalize(self.h, C.byref(n)))
+        return n.value
+
+    def boundary(self):
+        """(keys, key_clump, clump_vertices, clump_triangles): what a cross-rank merge needs (dist_sink.global_prune)."""
+        nk, nc = C.c_uint64(), C.c_uint64()
+        check(lib().mlsgpu_hip_host_mesher_boundary(self.h, C.byref(nk), C.byref(nc)))
+        keys, kc = np.zeros(nk.value, np.uint64), np.zeros(nk.value, np.uint32)
+        cv, ct = np.zeros(nc.value, np.uint64), np.zeros(nc.value, np.uint64)
+        check(lib().mlsgpu_hip_host_mesher_boundary_read(self.h, _p(keys), _p(kc), _p(cv), _p(ct)))
+        return keys, kc, cv, ct
+
+    def finalize_with(self, keep_clump):
+        keep = np.ascontiguousarray(keep_clump, np.uint8)
+        n = C.c_uint32()
+        check(lib().mlsgpu_hip_host_mesher_finalize_with(self.h, _p(keep), len(keep), C.byref(n)))
         return n.value
 
     def chunk(self, i):

@@ -203,13 +203,13 @@ MLSGPU_API int mlsgpu_hip_host_mesher_farm_output(void *mesher, int device, uint
     return mlsgpu_hip_host_mesher_add(static_cast<mlsgpu_host_mesher *>(mesher), chunkId, mesh);
 }
 
-MLSGPU_API int mlsgpu_hip_host_mesher_finalize(mlsgpu_host_mesher *m, uint32_t *numChunks)
+/* keepClump == nullptr: the prune rule on this mesher's own counts (getStatistics, src/mesher.cpp:491-536);
+ * otherwise keepClump[root clump] decides (the caller merged the clumps of several meshers, see
+ * mlsgpu_hip_host_mesher_boundary) */
+static int finalizeWith(mlsgpu_host_mesher *m, const uint8_t *keepClump, uint32_t *numChunks)
 {
-    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
-    std::lock_guard<std::mutex> lock(m->mutex);
     const uint64_t nv = m->vertices.size() / 3, nt = m->triangles.size() / 3;
     const uint32_t nc = (uint32_t) m->chunkIds.size();
-    /* getStatistics, src/mesher.cpp:491-536 */
     uint64_t total = 0, components = 0;
     for (size_t c = 0; c < m->clumps.size(); c++)
         if (m->clumps[c].parent < 0)
@@ -218,9 +218,10 @@ MLSGPU_API int mlsgpu_hip_host_mesher_finalize(mlsgpu_host_mesher *m, uint32_t *
             components++;
         }
     const uint64_t threshold = (uint64_t) ((double) total * m->pruneThreshold);
+    auto kept = [&](uint32_t root) { return keepClump ? keepClump[root] != 0 : m->clumps[root].vertices >= threshold; };
     uint64_t keptComponents = 0, keptVertices = 0, keptTriangles = 0;
     for (size_t c = 0; c < m->clumps.size(); c++)
-        if (m->clumps[c].parent < 0 && m->clumps[c].vertices >= threshold)
+        if (m->clumps[c].parent < 0 && kept((uint32_t) c))
         {
             keptComponents++;
             keptVertices += m->clumps[c].vertices;
@@ -254,7 +255,7 @@ MLSGPU_API int mlsgpu_hip_host_mesher_finalize(mlsgpu_host_mesher *m, uint32_t *
             for (uint64_t i = 0; i < b.nv; i++)
             {
                 const uint32_t root = m->clumpRoot(m->clumpOf[b.vBase + i]);
-                if (m->clumps[root].vertices < threshold)
+                if (!kept(root))
                     continue;
                 if (i >= b.nInternal)
                 {
@@ -297,6 +298,59 @@ MLSGPU_API int mlsgpu_hip_host_mesher_finalize(mlsgpu_host_mesher *m, uint32_t *
     if (numChunks)
         *numChunks = (uint32_t) m->outChunks.size();
     return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_host_mesher_finalize(mlsgpu_host_mesher *m, uint32_t *numChunks)
+{
+    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    return finalizeWith(m, nullptr, numChunks);
+}
+
+/* ---- several meshers, one job (one process per GPU: every rank welds its own buckets; components that cross rank
+ *      boundaries and the prune threshold need the other ranks' clumps).  boundary() exports what the merge needs:
+ *      every external key this mesher has seen with the ROOT clump that holds its vertex, and the vertex / triangle
+ *      counts of every root clump.  The caller unites clumps that share a key across meshers (a vertex seen by r
+ *      meshers was counted r times), applies the prune rule to the merged counts and hands the verdict back to
+ *      finalize_with().  mlsgpu_amd/dist_sink.py does this over torch.distributed. ---- */
+MLSGPU_API int mlsgpu_hip_host_mesher_boundary(mlsgpu_host_mesher *m, uint64_t *numKeys, uint64_t *numClumps)
+{
+    REQUIRE(m != nullptr && numKeys != nullptr && numClumps != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    *numKeys = m->clumpIdMap.size();
+    *numClumps = m->clumps.size();
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_host_mesher_boundary_read(mlsgpu_host_mesher *m, uint64_t *keys, uint32_t *keyClump,
+                                                    uint64_t *clumpVertices, uint64_t *clumpTriangles)
+{
+    REQUIRE(m != nullptr && keys != nullptr && keyClump != nullptr && clumpVertices != nullptr && clumpTriangles != nullptr,
+            MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    std::vector<std::pair<uint64_t, uint32_t> > sorted(m->clumpIdMap.begin(), m->clumpIdMap.end());
+    std::sort(sorted.begin(), sorted.end());        /* by key: the same order on every rank, whatever the hash map did */
+    for (size_t i = 0; i < sorted.size(); i++)
+    {
+        keys[i] = sorted[i].first;
+        keyClump[i] = m->clumpRoot(sorted[i].second);
+    }
+    for (size_t c = 0; c < m->clumps.size(); c++)
+    {
+        const bool root = m->clumps[c].parent < 0;
+        clumpVertices[c] = root ? m->clumps[c].vertices : 0;
+        clumpTriangles[c] = root ? m->clumps[c].triangles : 0;
+    }
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_host_mesher_finalize_with(mlsgpu_host_mesher *m, const uint8_t *keepClump, uint64_t numClumps,
+                                                    uint32_t *numChunks)
+{
+    REQUIRE(m != nullptr && keepClump != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    REQUIRE(numClumps == m->clumps.size(), MLSGPU_ERR_LENGTH);
+    return finalizeWith(m, keepClump, numChunks);
 }
 
 MLSGPU_API int mlsgpu_hip_host_mesher_chunk(mlsgpu_host_mesher *m, uint32_t i, uint64_t *chunkId, uint64_t *numVertices,

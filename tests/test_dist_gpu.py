@@ -1,0 +1,105 @@
+"""The one-process-per-GPU path on real devices: two ranks (sharing GPU 0 on a one-GPU box, gloo for the exchange), each
+running ITS share of one cloud's buckets through its own bucket farm, host read-back and HostMesher, then the one
+all-gather of dist_sink.global_prune; and bench.py's N > 1 mode launched the way the driver launches it."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+RANK_CODE = r"""
+import os, sys
+sys.path[:0] = [%(tests)r, %(root)r, %(oracle)r]
+import numpy as np
+import torch                      # before the HIP library (tests/conftest.py)
+import torch.distributed as dist
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+import mesher_oracle as mo
+import oracle_binding as ob
+import mlsgpu_amd as m
+from mlsgpu_amd import dist_sink, farm, synth
+ndev = torch.cuda.device_count()
+cloud = synth.shells_cloud(120_000, 95.0, 16.0, 1.5, 2.5, seed=321)
+cloud = np.concatenate([cloud, synth.sphere_cloud(600, (10.0, 10.0, 10.0), 4.0, 1.0, 1.5, seed=3)])
+allb, buckets = synth.bucketize(cloud, 96, 32)
+mine = farm.rank_share(list(range(len(buckets))), rank, world)
+welder = m.HostMesher(0.02)
+f = m.BucketFarm([rank %% ndev], max(b.count for b in buckets), workers_per_device=2, max_cells=63)
+f.set_host_output(8 << 20, welder)
+for i in mine:
+    b = buckets[i]
+    f.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, rank)
+f.finish()
+f.close()
+n, stats = dist_sink.global_prune(welder, 0.02, dist)
+ok = True
+if rank == 0:
+    ref = allb.copy()
+    everything = []
+    for i, b in enumerate(buckets):
+        owner = next(r for r in range(world) if i in farm.rank_share(list(range(len(buckets))), r, world))
+        batches, _ = ob.bucket(ref, b.first, b.count, b.num_vertices, b.low, max_cells=63, max_swathe=64,
+                               mesh_memory=63 * 63 * 2 * 872)
+        for g in batches:
+            ni = g["num_internal"]
+            everything.append(dict(chunk=owner, vertices=g["vertices"], num_internal=ni, keys=g["keys"][ni:], triangles=g["triangles"]))
+    exp, exp_stats = mo.mesh_sink(everything, 0.02)
+    ok = all(stats[k] == exp_stats[k] for k in exp_stats) and stats["kept_components"] < stats["components"]
+    _, v, t = welder.chunk(0)
+    ev, et = [(v_, t_) for c, v_, t_ in exp if c == 0][0]
+    ok = ok and n == 1 and mo.isomorphic(v, t, ev, et)
+flag = torch.tensor([1 if ok else 0])
+dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+dist.destroy_process_group()
+sys.exit(0 if int(flag.item()) == 1 else 3)
+"""
+
+
+def _launch(n, args, env=None):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port())] + args
+    return subprocess.run(cmd, env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=900)
+
+
+def test_two_ranks_weld_one_cloud(tmp_path):
+    script = tmp_path / "rank.py"
+    script.write_text(RANK_CODE % dict(tests=os.path.join(ROOT, "tests"), root=ROOT, oracle=os.path.join(ROOT, "oracle")))
+    out = _launch(2, [str(script)])
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_bench_two_ranks_one_sharded_cloud():
+    """bench.py as the driver starts it for N = 2 (here both ranks on GPU 0, gloo): the cfg4 slab family at 2 %% of the
+    splat count; the line reports two ranks with 25 buckets each of ONE cloud, and refuses a mismatching --gpus."""
+    env = {"MLSGPU_BENCH_BACKEND": "gloo"}
+    out = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1",
+                      "--no-timing"], env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["per_rank"]["buckets"] == [25, 25]
+    assert d["config"]["voxels_per_step"] == 1023 * 1023 * 255
+    assert "cfg4" in d["config"]["workload"] and d["value"] > 0
+    # without a launcher bench.py starts the ranks itself; with a launcher of the wrong size it refuses
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "1",
+                          "--warmup", "0", "--no-timing"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 2
+    out = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--scale", "0.02", "--steps", "1", "--warmup", "0"], env)
+    assert out.returncode != 0 and "does not match WORLD_SIZE" in (out.stdout + out.stderr)

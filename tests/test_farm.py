@@ -58,6 +58,76 @@ def test_two_rank_gloo_farm():
     assert cmin0 == cmax0 == 1                    # rank_share is a partition
 
 
+def _sink_rank_main(rank, world, port, out):
+    """One rank of the distributed mesh sink: its share of ONE cloud's buckets (farm.rank_share) -> meshes (the CPU oracle
+    stands in for the GPU pipeline here) -> this rank's HostMesher -> dist_sink.global_prune over gloo."""
+    import sys
+    import numpy as np
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        here = os.path.dirname(os.path.abspath(__file__))
+        sys.path[:0] = [here, os.path.join(os.path.dirname(here), "oracle")]
+        import mesher_oracle as mo
+        import oracle_binding as ob
+        import mlsgpu_amd as m
+        from mlsgpu_amd import dist_sink, farm, synth
+        cloud = synth.shells_cloud(60_000, 63.0, 12.0, 1.5, 2.5, seed=77)
+        cloud = np.concatenate([cloud, synth.sphere_cloud(400, (8.0, 8.0, 8.0), 3.0, 1.0, 1.5, seed=3)])   # an island to prune
+        allb, buckets = synth.bucketize(cloud, 64, 21)
+        assert len(buckets) == 27
+        mine = farm.rank_share(list(range(len(buckets))), rank, world)
+        welder = m.HostMesher(0.05)
+        ref = allb.copy()
+        everything = []
+        for i, b in enumerate(buckets):
+            batches, _ = ob.bucket(ref, b.first, b.count, b.num_vertices, b.low, max_cells=63, max_swathe=64,
+                                   mesh_memory=63 * 63 * 2 * 872)
+            owner = next(r for r in range(world) if i in farm.rank_share(list(range(len(buckets))), r, world))
+            for g in batches:
+                ni = g["num_internal"]
+                everything.append(dict(chunk=owner, vertices=g["vertices"], num_internal=ni, keys=g["keys"][ni:],
+                                       triangles=g["triangles"]))
+                if i in mine:
+                    welder.add(rank, g["vertices"], ni, g["keys"][ni:], g["triangles"])
+        n, stats = dist_sink.global_prune(welder, 0.05, dist)
+        exp, exp_stats = mo.mesh_sink(everything, 0.05)           # the whole job in one process, one chunk per rank
+        ok = all(stats[k] == exp_stats[k] for k in exp_stats)
+        exp_mine = [(v, t) for c, v, t in exp if c == rank]
+        if exp_mine:
+            _, v, t = welder.chunk(0)
+            ok = ok and n == 1 and mo.isomorphic(v, t, *exp_mine[0])
+        else:
+            ok = ok and n == 0
+        out.put((rank, ok, stats["components"], stats["kept_components"], stats["total_vertices"],
+                 sum(len(mm["vertices"]) for mm in everything)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_distributed_sink():
+    """The N > 1 mesh sink on CPU: two gloo ranks, each welding its share of one cloud's 27 buckets, one all-gather of
+    the boundary; components crossing the rank seam are united, the island falls under the global threshold, and every
+    rank's output equals the single-process oracle's chunk for it."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sink_rank_main, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert res[0][2:] == res[1][2:]                 # both ranks computed the same whole-job statistics
+    assert res[0][3] < res[0][2]                    # something was pruned
+    assert res[0][4] < res[0][5]                    # shared vertices were counted once
+
+
 def test_shares():
     from mlsgpu_amd import farm
     items = list(range(27))
