@@ -304,13 +304,49 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(const K *keys, uint
         hist[(uint64_t) d * numTiles + blockIdx.x] = bins[d];
 }
 
+/* hist[d][0 .. numTiles) -> its exclusive prefix along the tiles, in place; digitTotals[d] = the digit's count.  One
+ * workgroup per digit: the whole scan of a pass's histogram is this ONE small launch (the scatter kernel turns the 2^bits
+ * digit totals into digit bases itself), where a generic scan of the 2^bits x numTiles array took two. */
+template<typename T>    /* T = uint32_t; a template only so that the header can be included by several translation units */
+__global__ __launch_bounds__(PRIM_BLOCK) void sortDigitScanKernel(T *hist, T *digitTotals, uint32_t numTiles)
+{
+    __shared__ T waveTotals[PRIM_WAVES];
+    T *row = hist + (uint64_t) blockIdx.x * numTiles;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < numTiles; base += PRIM_BLOCK)
+    {
+        const uint32_t i = base + threadIdx.x;
+        const uint32_t v = i < numTiles ? row[i] : 0u;
+        const uint32_t incl = waveInclusiveScan(v);
+        if (lane == 63)
+            waveTotals[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry, all = carry;
+#pragma unroll
+        for (uint32_t w = 0; w < PRIM_WAVES; w++)
+        {
+            if (w < wave)
+                before += waveTotals[w];
+            all += waveTotals[w];
+        }
+        if (i < numTiles)
+            row[i] = before + incl - v;
+        carry = all;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        digitTotals[blockIdx.x] = carry;
+}
+
 /* Largest digit a key type can be sorted by per pass: bounded by the LDS the scatter kernel needs
  * (tile of keys + values, per-wave bins).  64 KB of static LDS per workgroup. */
 template<typename K> struct SortCaps { enum { MAX_DIGIT_BITS = sizeof(K) == 8 ? 9 : SORT_MAX_DIGIT_BITS }; };
 
 /*
- * Scatter pass.  hist has been exclusively scanned over the (digit-major, tile-minor) sequence, so
- * hist[d][tile] is where this tile's keys with digit d start in the output.
+ * Scatter pass.  hist[d][tile] = keys with digit d in the tiles before this one (sortDigitScanKernel), digitTotals[d] =
+ * keys with digit d: the digit's base is the exclusive prefix of the totals, computed here by every workgroup (2^bits
+ * values from L2), so hist[d][tile] + base[d] is where this tile's keys with digit d start in the output.
  *   1. per-wave digit counts (LDS atomics);
  *   2. tile-local start of every digit (block scan over the bins) and of every (wave, digit);
  *   3. stable rank of each key among the keys of its wave with the same digit, by wave64 ballots
@@ -322,14 +358,14 @@ template<typename K> struct SortCaps { enum { MAX_DIGIT_BITS = sizeof(K) == 8 ? 
 template<typename K, bool IOTA, int BIN_BITS>
 __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn, const uint32_t *valsIn,
                                                                 K *keysOut, uint32_t *valsOut,
-                                                                const uint32_t *hist, uint64_t n,
-                                                                uint32_t shift, uint32_t digitBits, uint32_t numTiles,
-                                                                const uint32_t *nDev)
+                                                                const uint32_t *hist, const uint32_t *digitTotals,
+                                                                uint64_t n, uint32_t shift, uint32_t digitBits,
+                                                                uint32_t numTiles, const uint32_t *nDev)
 {
     enum { BINS = 1 << BIN_BITS };
     __shared__ uint32_t waveBins[PRIM_WAVES][BINS];
     __shared__ uint32_t tileBase[BINS];        /* global start of the digit minus its tile-local start */
-    __shared__ uint32_t waveTotals[PRIM_WAVES];
+    __shared__ uint32_t waveTotals[PRIM_WAVES], waveTotalsAll[PRIM_WAVES];
     /* the tile is reordered in two phases through ONE buffer (keys, then values): half the LDS, twice the
      * resident workgroups, which is what this latency-bound kernel needs */
     __shared__ K sTile[PRIM_TILE];
@@ -364,24 +400,34 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn,
     {
         const uint32_t per = numBins > PRIM_BLOCK ? numBins / PRIM_BLOCK : 1;
         const uint32_t d0 = threadIdx.x * per;
-        uint32_t mine = 0;
+        uint32_t mine = 0, mineAll = 0;         /* this tile's / the whole input's keys in my bins */
         if (d0 < numBins)
             for (uint32_t k = 0; k < per; k++)
+            {
+                mineAll += digitTotals[d0 + k];
 #pragma unroll
                 for (int w = 0; w < PRIM_WAVES; w++)
                     mine += waveBins[w][d0 + k];
-        const uint32_t incl = waveInclusiveScan(mine);
+            }
+        const uint32_t incl = waveInclusiveScan(mine), inclAll = waveInclusiveScan(mineAll);
         if (lane == 63)
+        {
             waveTotals[wave] = incl;
+            waveTotalsAll[wave] = inclAll;
+        }
         __syncthreads();
-        uint32_t run = incl - mine;
+        uint32_t run = incl - mine, base = inclAll - mineAll;
         for (uint32_t w = 0; w < wave; w++)
+        {
             run += waveTotals[w];
+            base += waveTotalsAll[w];
+        }
         if (d0 < numBins)
             for (uint32_t k = 0; k < per; k++)
             {
                 const uint32_t d = d0 + k;
-                tileBase[d] = hist[(uint64_t) d * numTiles + blockIdx.x] - run;
+                tileBase[d] = base + hist[(uint64_t) d * numTiles + blockIdx.x] - run;
+                base += digitTotals[d];
 #pragma unroll
                 for (int w = 0; w < PRIM_WAVES; w++)
                 {
@@ -463,14 +509,15 @@ struct SortResult
 };
 
 static inline uint32_t sortPasses(uint32_t bits, uint32_t maxDigitBits) { return (bits + maxDigitBits - 1) / maxDigitBits; }
-/* elements of uint32 needed for the histogram of a sort of n keys */
-static inline uint64_t sortHistElems(uint64_t n) { return (uint64_t) SORT_MAX_BINS * scanTiles(n); }
+/* elements of uint32 needed for the histogram of a sort of n keys: 2^bits x tiles counters and, behind them, the 2^bits
+ * digit totals of the pass */
+static inline uint64_t sortHistElems(uint64_t n) { return (uint64_t) SORT_MAX_BINS * ((uint64_t) scanTiles(n) + 1); }
 
 /*
  * Sorts (keysA, valsA)[0..n) stably by key bits [0, bits).  keysB/valsB are same-sized temporaries
  * (the reference aliases its sort temporaries onto other buffers the same way,
  * src/splat_tree_cl.cpp:129, src/marching.cpp:405).  iota: values are 0..n-1 and valsA is not read.
- * dHist: sortHistElems(n) uint32; dTileSums: scanTiles(sortHistElems(n)) uint32.
+ * dHist: sortHistElems(n) uint32; dTileSums: not used any more (kept for the call sites' sake).
  */
 template<typename K>
 static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *valsA, K *keysB, uint32_t *valsB,
@@ -482,6 +529,8 @@ static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *
     if (n == 0)
         return MLSGPU_OK;
     const uint32_t tiles = scanTiles(n);
+    (void) dTileSums;
+    uint32_t *const dDigitTotals = dHist + (uint64_t) SORT_MAX_BINS * tiles;
     if (bits == 0)
         bits = 1;    /* still run one pass so that iota values are materialised */
     uint32_t maxDigit = SortCaps<K>::MAX_DIGIT_BITS;
@@ -499,14 +548,13 @@ static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *
     for (uint32_t p = 0; p < passes; p++)
     {
         const uint32_t digitBits = (bits - shift) < perPass ? (bits - shift) : perPass;
-        const uint64_t histN = ((uint64_t) 1 << digitBits) * tiles;
         LAUNCH(ctx, statName, (sortHistKernel<K>), dim3(tiles), dim3(PRIM_BLOCK),
                (const K *) kin, dHist, n, shift, digitBits, tiles, nDev);
-        PROPAGATE((exclusiveScan<uint32_t>(ctx, statName, ArrayIn<uint32_t>{dHist}, ArrayOut<uint32_t>{dHist},
-                                           histN, 0u, dTileSums, (uint32_t *) nullptr)));
+        LAUNCH(ctx, statName, (sortDigitScanKernel<uint32_t>), dim3(1u << digitBits), dim3(PRIM_BLOCK), dHist, dDigitTotals, tiles);
 #define SORT_SCATTER(IOTA, BITS)                                                                                       \
         LAUNCH(ctx, statName, (sortScatterKernel<K, IOTA, BITS>), dim3(tiles), dim3(PRIM_BLOCK), (const K *) kin,      \
-               (const uint32_t *) vin, kout, vout, (const uint32_t *) dHist, n, shift, digitBits, tiles, nDev)
+               (const uint32_t *) vin, kout, vout, (const uint32_t *) dHist, (const uint32_t *) dDigitTotals, n, shift,\
+               digitBits, tiles, nDev)
         /* the kernel's bin tables are sized for the digit in use: fewer bins, more resident workgroups */
         const bool first = iota && p == 0;
         if (digitBits <= 8) { if (first) SORT_SCATTER(true, 8); else SORT_SCATTER(false, 8); }
