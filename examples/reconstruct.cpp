@@ -1,68 +1,99 @@
 /*
- * PLY of splats in, PLY mesh out, everything between on the device: the in-core shape of the reference's main
- * pipeline (src/mlsgpu_core.cpp:560-760: load -> bounding grid -> Bucket::bucket -> BucketLoader -> device worker ->
- * mesher -> FastPly::Writer) with this repository's pieces:
- *   FastPly::Reader      mlsgpu_hip_ply_open / _load (host threads decode while batches travel to the device)
- *   bounding grid        mlsgpu_hip_bounding_grid    (device reduction)
- *   Bucket::bucket       mlsgpu::hip::Bucket::bucket (device)
- *   BucketLoader + CopyGroup + DeviceWorkerGroup   mlsgpu_hip_farm_submit_device (device gather + transform into a
- *                        device item, then four worker threads: octree, MLS, marching, scale/bias)
- *   OOCMesher            mlsgpu::hip::DeviceMesher   (device weld / components / prune), FastPly::Writer on the host
+ * PLY files of splats in, PLY mesh out, everything between on the device(s): the shape of the reference's main pipeline
+ * (src/mlsgpu_core.cpp:560-760: load -> bounding grid -> Bucket::bucket -> BucketLoader -> device workers -> mesher ->
+ * FastPly::Writer) with this repository's pieces:
+ *   SplatSet::FileSet    mlsgpu::hip::FileSet         (several files, reader threads, bounded pinned memory, H2D overlap)
+ *   bounding grid        mlsgpu_hip_bounding_grid     (device reduction)
+ *   Bucket::bucket       mlsgpu::hip::Bucket::bucket  (device)
+ *   BucketLoader + CopyGroup + DeviceWorkerGroup      mlsgpu::hip::BucketFarm::submitDevice (device gather + transform
+ *                        into a device item of the least-loaded GPU -- a peer copy when that is another GPU -- then four
+ *                        worker threads per GPU: octree, MLS, marching, scale/bias)
+ *   OOCMesher            --weld device: mlsgpu::hip::DeviceMesher (ship-outs appended in one GPU's HBM, weld / components /
+ *                        prune there); --weld host: every ship-out read back through the pinned circular buffer and welded
+ *                        by mlsgpu::hip::OOCMesher on the mesher thread (the reference's route)
  *
- * usage: reconstruct <in.ply> <out.ply> <spacing> [smooth=4] [levels=6] [subsampling=3] [prune=0.02] [maxSplats=2097152]
+ * usage: reconstruct [--devices 0,1,...] [--weld device|host] [--buffer BYTES] <in.ply> [more.ply ...] <out.ply>
+ *                    <spacing> [smooth=4] [levels=6] [subsampling=3] [prune=0.02] [maxSplats=2097152]
  * (defaults as src/mlsgpu_core.cpp:86-135: --fit-smooth 4, --levels 6, --subsampling 3, --fit-prune 0.02)
  */
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
 #include <limits>
+#include <sstream>
 #include <vector>
 
 #include "../mlsgpu_amd/host/mlsgpu_hip.hpp"
 
 using namespace mlsgpu::hip;
 
+static bool isPly(const std::string &a) { return a.size() > 4 && a.compare(a.size() - 4, 4, ".ply") == 0; }
+
 int main(int argc, char **argv)
 {
-    if (argc < 4)
+    std::vector<std::int32_t> devices(1, 0);
+    bool hostWeld = false;
+    std::uint64_t bufferBytes = 0;
+    std::vector<std::string> plys, rest;
+    for (int i = 1; i < argc; i++)
     {
-        std::cerr << "usage: reconstruct in.ply out.ply spacing [smooth] [levels] [subsampling] [prune] [maxSplats]\n";
+        const std::string a = argv[i];
+        if (a == "--devices" && i + 1 < argc)
+        {
+            devices.clear();
+            std::istringstream ss(argv[++i]);
+            std::string tok;
+            while (std::getline(ss, tok, ','))
+                devices.push_back(atoi(tok.c_str()));
+        }
+        else if (a == "--weld" && i + 1 < argc)
+            hostWeld = std::string(argv[++i]) == "host";
+        else if (a == "--buffer" && i + 1 < argc)
+            bufferBytes = strtoull(argv[++i], NULL, 10);
+        else if (rest.empty() && isPly(a))
+            plys.push_back(a);
+        else
+            rest.push_back(a);
+    }
+    if (plys.size() < 2 || rest.empty() || devices.empty())
+    {
+        std::cerr << "usage: reconstruct [--devices 0,1] [--weld device|host] [--buffer BYTES] in.ply [more.ply ...] out.ply "
+                     "spacing [smooth] [levels] [subsampling] [prune] [maxSplats]\n";
         return 2;
     }
-    const float spacing = (float) atof(argv[3]);
-    const float smooth = argc > 4 ? (float) atof(argv[4]) : 4.0f;
-    const unsigned levels = argc > 5 ? (unsigned) atoi(argv[5]) : 6;
-    const unsigned subsampling = argc > 6 ? (unsigned) atoi(argv[6]) : 3;
-    const double prune = argc > 7 ? atof(argv[7]) : 0.02;
-    const std::uint64_t maxSplats = argc > 8 ? strtoull(argv[8], NULL, 10) : 2097152;
+    const std::string outName = plys.back();
+    plys.pop_back();
+    const float spacing = (float) atof(rest[0].c_str());
+    const float smooth = rest.size() > 1 ? (float) atof(rest[1].c_str()) : 4.0f;
+    const unsigned levels = rest.size() > 2 ? (unsigned) atoi(rest[2].c_str()) : 6;
+    const unsigned subsampling = rest.size() > 3 ? (unsigned) atoi(rest[3].c_str()) : 3;
+    const double prune = rest.size() > 4 ? atof(rest[4].c_str()) : 0.02;
+    const std::uint64_t maxSplats = rest.size() > 5 ? strtoull(rest[5].c_str(), NULL, 10) : 2097152;
     const std::uint32_t maxCells = (1u << (levels + subsampling - 1)) - 1;        // src/mlsgpu_core.cpp:672-673
     const std::uint32_t microCells = std::min<std::uint32_t>(63, maxCells);          // --leaf-cells 63, :113,674
     try
     {
-        mlsgpu_ply_reader *reader = NULL;
-        check(mlsgpu_hip_ply_open(argv[1], smooth, std::numeric_limits<float>::infinity(), &reader));
-        const std::uint64_t numSplats = mlsgpu_hip_ply_size(reader);
+        FileSet files(smooth, std::numeric_limits<float>::infinity());
+        for (const std::string &p : plys)
+            files.addFile(p);
+        if (bufferBytes)
+            files.setBufferSize(bufferBytes);
+        const std::uint64_t numSplats = files.maxSplats();
         if (numSplats == 0)
         {
             std::cerr << "no splats\n";
-            mlsgpu_hip_ply_close(reader);
             return 1;
         }
-        Context ctx(0);
+        const int home = devices[0];                            // the cloud (and the device sink) live on the first GPU
+        Context ctx(home);
         Buffer<Splat> cloud(ctx, numSplats);
-        // file -> HBM: threaded decode overlapped with the host-to-device copies, no host copy of the whole cloud
-        const int loaded = mlsgpu_hip_ply_load(reader, ctx.get(), 0, numSplats, cloud.get(), 0);
-        mlsgpu_hip_ply_close(reader);
-        check(loaded);
+        // files -> HBM: reader threads decode into pinned quarters while earlier chunks travel; no host copy of the cloud
+        files.load(ctx, cloud, 0, numSplats);
         Bucket::Grid grid;
         check(mlsgpu_hip_bounding_grid(ctx.get(), cloud.get(), numSplats, spacing, microCells, &grid));
 
-        mlsgpu_farm_config fcfg;
-        std::memset(&fcfg, 0, sizeof(fcfg));
-        fcfg.numDevices = 1;
-        fcfg.workersPerDevice = 4;                              // --device-threads
-        fcfg.spare = 1;
-        mlsgpu_worker_config &cfg = fcfg.worker;
+        mlsgpu_worker_config cfg;
+        std::memset(&cfg, 0, sizeof(cfg));
         cfg.maxBucketSplats = maxSplats;
         cfg.maxCells = maxCells;
         cfg.levels = levels;
@@ -73,51 +104,41 @@ int main(int argc, char **argv)
         for (int i = 0; i < 3; i++)
             cfg.gridOrigin[i] = grid.reference[i] + spacing * (float) grid.extents[2 * i];
 
-        DeviceMesher mesher(ctx);
-        mesher.setPruneThreshold(prune);
-        // the farm's output functor (OutputGenerator of src/workers.h:225): every ship-out goes to the device mesher
-        struct Sink
+        DeviceMesher deviceMesher(ctx);
+        deviceMesher.setPruneThreshold(prune);
+        OOCMesher hostMesher;
+        hostMesher.setPruneThreshold(prune);
+        std::size_t bins = 0, written = 0;
+        std::uint64_t st[8];
         {
-            static int call(void *user, int, std::uint64_t, mlsgpu_ctx *workerCtx, const mlsgpu_mesh *mesh)
-            {
-                return mlsgpu_hip_mesher_add(static_cast<DeviceMesher *>(user)->get(), workerCtx, 0, mesh);
-            }
-        };
-        mlsgpu_farm *farm = NULL;
-        check(mlsgpu_hip_farm_create(&fcfg, &Sink::call, &mesher, &farm));
-        std::size_t bins = 0;
-        try
-        {
+            BucketFarm farm(devices, cfg, 4 /* --device-threads */, 1, hostWeld ? NULL : &deviceMesher);
+            if (hostWeld)
+                farm.setHostOutput(std::uint64_t(512) << 20 /* --mem-mesh */, hostMesher);
             Bucket::bucket(ctx, cloud, numSplats, grid, maxSplats, maxCells, 0, microCells, std::uint64_t(1) << 30,
                            [&](const Bucket::Bin &bin)
             {
-                std::int32_t low[3];
-                std::uint32_t nv[3];
-                for (int i = 0; i < 3; i++)
-                {
-                    low[i] = bin.extents[2 * i] - grid.extents[2 * i];
-                    nv[i] = (std::uint32_t) (bin.extents[2 * i + 1] - bin.extents[2 * i] + 1);
-                }
-                check(mlsgpu_hip_farm_submit_device(farm, 0, cloud.get(), bin.dIds, bin.numSplats, &grid, low, nv, bins));
+                farm.submitDevice(home, cloud, bin, grid, 0);
                 bins++;
             });
-            check(mlsgpu_hip_farm_finish(farm));
+            farm.finish();
         }
-        catch (...)
+        const std::vector<std::string> comments(1, "mlsgpu-hip example: reconstruct");
+        if (hostWeld)
         {
-            mlsgpu_hip_farm_destroy(farm);
-            throw;
+            written = hostMesher.write([&](std::uint64_t) { return outName; }, comments);
+            hostMesher.getStatistics(st);
         }
-        mlsgpu_hip_farm_destroy(farm);
-        const std::string outName = argv[2];
-        const std::size_t files = mesher.write([&](std::uint64_t) { return outName; },
-                                               std::vector<std::string>(1, "mlsgpu-hip example: reconstruct"));
-        std::uint64_t st[8];
-        mesher.getStatistics(st);
-        std::printf("splats %llu grid %d..%d %d..%d %d..%d bins %zu files %zu vertices %llu triangles %llu components %llu kept %llu\n",
-                    (unsigned long long) numSplats, grid.extents[0], grid.extents[1], grid.extents[2], grid.extents[3], grid.extents[4],
-                    grid.extents[5], bins, files, (unsigned long long) st[4], (unsigned long long) st[5],
-                    (unsigned long long) st[2], (unsigned long long) st[3]);
+        else
+        {
+            written = deviceMesher.write([&](std::uint64_t) { return outName; }, comments);
+            deviceMesher.getStatistics(st);
+        }
+        std::printf("files in %zu splats %llu grid %d..%d %d..%d %d..%d bins %zu devices %zu weld %s files %zu vertices %llu "
+                    "triangles %llu components %llu kept %llu\n",
+                    plys.size(), (unsigned long long) numSplats, grid.extents[0], grid.extents[1], grid.extents[2],
+                    grid.extents[3], grid.extents[4], grid.extents[5], bins, devices.size(), hostWeld ? "host" : "device",
+                    written, (unsigned long long) st[4], (unsigned long long) st[5], (unsigned long long) st[2],
+                    (unsigned long long) st[3]);
     }
     catch (std::exception &e)
     {

@@ -650,7 +650,10 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
     const char *stat = "kernel.mls.processCorners.time";      /* src/mls.cpp:57 */
     A.stats = m->dStats;
 #define MLS_LAUNCH(SHAPE, CULL, STATS) LAUNCH(ctx, stat, (processCornersKernel<SHAPE, CULL, STATS>), grid, block, A)
-#define MLS_LAUNCH_LIST(SHAPE, STATS) LAUNCH(ctx, stat, (processCornersListKernel<SHAPE, STATS>), grid, block, A)
+    /* tuning aid: dynamic LDS that the kernel never touches lowers its occupancy (3 workgroups per CU from 8 KB, 2 from
+     * 20 KB), leaving wave slots to the memory-bound kernels of the other device workers */
+    static const uint32_t ldsPad = getenv("MLSGPU_HIP_MLS_LDS_PAD") ? (uint32_t) atoi(getenv("MLSGPU_HIP_MLS_LDS_PAD")) : 0u;
+#define MLS_LAUNCH_LIST(SHAPE, STATS) LAUNCH_LDS(ctx, stat, (processCornersListKernel<SHAPE, STATS>), grid, block, ldsPad, A)
     const bool sphere = m->shape == MLSGPU_SHAPE_SPHERE, cull = m->variant == 0;
     if (m->variant == 2)
     {

@@ -545,6 +545,123 @@ public:
 };
 
 /**
+ * OOCMesher (src/mesher.h:331-420, src/mesher.cpp:220-469) in host memory: the reference's weld, run where the reference
+ * runs it.  add() is MesherBase::InputFunctor for a HostKeyMesh; meshes of any GPU may be added (it is what
+ * BucketFarm::setHostOutput feeds from its mesher thread).  write() welds, prunes and writes one PLY per non-empty
+ * chunk, like DeviceMesher::write.
+ */
+class OOCMesher
+{
+    mlsgpu_host_mesher *h;
+    OOCMesher(const OOCMesher &);
+    OOCMesher &operator=(const OOCMesher &);
+public:
+    typedef std::function<std::string(std::uint64_t chunkId)> Namer;
+    OOCMesher() : h(NULL) { check(mlsgpu_hip_host_mesher_create(&h)); }
+    ~OOCMesher() { mlsgpu_hip_host_mesher_destroy(h); }
+    mlsgpu_host_mesher *get() const { return h; }
+    void setPruneThreshold(double t) { check(mlsgpu_hip_host_mesher_set_prune_threshold(h, t)); }
+    void add(std::uint64_t chunkId, const mlsgpu_host_mesh &mesh) { check(mlsgpu_hip_host_mesher_add(h, chunkId, &mesh)); }
+    std::size_t write(const Namer &namer, const std::vector<std::string> &comments = std::vector<std::string>())
+    {
+        std::uint32_t chunks = 0;
+        check(mlsgpu_hip_host_mesher_finalize(h, &chunks));
+        std::vector<const char *> cstr;
+        for (const std::string &c : comments)
+            cstr.push_back(c.c_str());
+        for (std::uint32_t i = 0; i < chunks; i++)
+        {
+            std::uint64_t id, nv, nt;
+            const float *v;
+            const std::uint32_t *t;
+            check(mlsgpu_hip_host_mesher_chunk(h, i, &id, &nv, &nt, &v, &t));
+            check(mlsgpu_hip_write_ply(namer(id).c_str(), v, nv, t, nt, cstr.empty() ? NULL : cstr.data(),
+                                       (std::uint32_t) cstr.size()));
+        }
+        return chunks;
+    }
+    void getStatistics(std::uint64_t out[8]) const { check(mlsgpu_hip_host_mesher_stats(h, out)); }
+};
+
+/**
+ * SplatSet::FileSet (src/splat_set.h:383-700): several PLY files read as one splat sequence; load() is the bounded-memory
+ * route into HBM (reader threads + pinned quarters + H2D overlap).
+ */
+class FileSet
+{
+    mlsgpu_fileset *h;
+    FileSet(const FileSet &);
+    FileSet &operator=(const FileSet &);
+public:
+    FileSet(float smooth, float maxRadius) : h(NULL) { check(mlsgpu_hip_fileset_create(smooth, maxRadius, &h)); }
+    ~FileSet() { mlsgpu_hip_fileset_destroy(h); }
+    void addFile(const std::string &path) { check(mlsgpu_hip_fileset_add_file(h, path.c_str())); }
+    void setBufferSize(std::uint64_t bytes) { check(mlsgpu_hip_fileset_set_buffer_size(h, bytes)); }
+    std::uint64_t maxSplats() const { return mlsgpu_hip_fileset_num_splats(h); }
+    void read(std::uint64_t first, std::uint64_t count, Splat *out) { check(mlsgpu_hip_fileset_read(h, first, count, out)); }
+    void load(const Context &ctx, const Buffer<Splat> &out, std::uint64_t first, std::uint64_t count, unsigned readerThreads = 0)
+    {
+        check(mlsgpu_hip_fileset_load(h, ctx.get(), first, count, out.get(), readerThreads));
+    }
+};
+
+/**
+ * CopyGroup + one DeviceWorkerGroup per GPU inside the library (mlsgpu_hip_farm_*; src/workers.h:214-438,
+ * src/mlsgpu_core.cpp:704-741).  Ship-outs go to a DeviceMesher (appended in HBM, by peer copy from other GPUs) or, with
+ * setHostOutput, through the pinned circular buffer to an OOCMesher on the farm's mesher thread (the reference's route,
+ * src/workers.h:488-509).
+ */
+class BucketFarm
+{
+    mlsgpu_farm *h;
+    BucketFarm(const BucketFarm &);
+    BucketFarm &operator=(const BucketFarm &);
+public:
+    BucketFarm(const std::vector<std::int32_t> &devices, const mlsgpu_worker_config &worker, unsigned workersPerDevice,
+               unsigned spare, DeviceMesher *deviceSink = NULL) : h(NULL)
+    {
+        mlsgpu_farm_config cfg;
+        std::memset(&cfg, 0, sizeof(cfg));
+        cfg.numDevices = (std::uint32_t) devices.size();
+        cfg.devices = devices.data();
+        cfg.workersPerDevice = workersPerDevice;
+        cfg.spare = spare;
+        cfg.worker = worker;
+        check(mlsgpu_hip_farm_create(&cfg, deviceSink ? &mlsgpu_hip_mesher_farm_output : NULL,
+                                     deviceSink ? deviceSink->get() : NULL, &h));
+    }
+    ~BucketFarm() { mlsgpu_hip_farm_destroy(h); }
+    mlsgpu_farm *get() const { return h; }
+    void setHostOutput(std::uint64_t ringBytes, OOCMesher &mesher)
+    {
+        check(mlsgpu_hip_farm_set_host_output(h, ringBytes, &mlsgpu_hip_host_mesher_farm_output, mesher.get()));
+    }
+    Splat *acquire(std::uint64_t numSplats)                                 // CopyGroup::get
+    {
+        Splat *p = NULL;
+        check(mlsgpu_hip_farm_acquire(h, numSplats, &p));
+        return p;
+    }
+    void push(std::uint64_t numSplats, const BucketGrid &grid, std::uint64_t chunkId)     // CopyGroup::push
+    {
+        check(mlsgpu_hip_farm_push(h, numSplats, grid.low, grid.numVertices, chunkId));
+    }
+    void submitDevice(int device, const Buffer<Splat> &cloud, const mlsgpu_bucket &bin, const mlsgpu_grid &fullGrid,
+                      std::uint64_t chunkId)
+    {
+        BucketGrid g;
+        for (int i = 0; i < 3; i++)
+        {
+            g.low[i] = bin.extents[2 * i] - fullGrid.extents[2 * i];
+            g.numVertices[i] = (std::uint32_t) (bin.extents[2 * i + 1] - bin.extents[2 * i] + 1);
+        }
+        check(mlsgpu_hip_farm_submit_device(h, device, cloud.get(), bin.dIds, bin.numSplats, &fullGrid, g.low, g.numVertices,
+                                            chunkId));
+    }
+    void finish() { check(mlsgpu_hip_farm_finish(h)); }
+};
+
+/**
  * Bucket::bucket (src/bucket.h:116-180) for a cloud that is resident on the device, and the device half of
  * BucketLoader (src/bucket_loader.cpp:77-102).  The processor receives the bucket's grid, recursion state and its
  * splat ids (device memory, ascending, valid during the call) where the reference's receives a splat subset.

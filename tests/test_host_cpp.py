@@ -124,14 +124,28 @@ def test_reconstruct_ply_to_ply(tmp_path):
     world["radius"] = world["radius"] * spacing
     rows = np.zeros(len(world), np.dtype([("p", "<f4", 3), ("n", "<f4", 3), ("r", "<f4")]))
     rows["p"], rows["n"], rows["r"] = world["position"], world["normal"], world["radius"]
-    head = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % len(rows) \
-        + "".join("property float32 %s\n" % n for n in ("x", "y", "z", "nx", "ny", "nz", "radius")) + "end_header\n"
-    (tmp_path / "in.ply").write_bytes(head.encode("ascii") + rows.tobytes())
+    # three input files of unequal size (SplatSet::FileSet), read through a 64 KiB pinned buffer
+    cuts = [0, 25_000, 25_001, len(rows)]
+    names = []
+    for k in range(3):
+        part = rows[cuts[k]:cuts[k + 1]]
+        head = "ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % len(part) \
+            + "".join("property float32 %s\n" % n for n in ("x", "y", "z", "nx", "ny", "nz", "radius")) + "end_header\n"
+        (tmp_path / ("in%d.ply" % k)).write_bytes(head.encode("ascii") + part.tobytes())
+        names.append(str(tmp_path / ("in%d.ply" % k)))
     smooth, levels, subsampling, prune, max_splats = 1.5, 4, 3, 0.02, 30000
-    out = subprocess.check_output([exe, str(tmp_path / "in.ply"), str(tmp_path / "out.ply"), repr(float(spacing)), str(smooth),
-                                   str(levels), str(subsampling), str(prune), str(max_splats)], timeout=600).decode()
-    assert "files 1" in out, out
-    got_v, got_t = parse_ply_mesh(tmp_path / "out.ply")
+    tail = [repr(float(spacing)), str(smooth), str(levels), str(subsampling), str(prune), str(max_splats)]
+    meshes_out = {}
+    for weld, devices in (("device", "0"), ("device", "0,0,0"), ("host", "0,0")):
+        out_ply = tmp_path / ("out_%s_%d.ply" % (weld, len(devices)))
+        env = dict(os.environ)
+        if devices == "0,0,0":
+            env.update(MLSGPU_HIP_FARM_FORCE_PEER="1", MLSGPU_HIP_MESHER_FORCE_PEER="1")      # the cross-GPU routes
+        out = subprocess.check_output([exe, "--devices", devices, "--weld", weld, "--buffer", "65536"] + names
+                                      + [str(out_ply)] + tail, timeout=600, env=env).decode()
+        assert "files in 3" in out and "files 1" in out and "weld " + weld in out, out
+        meshes_out[(weld, devices)] = parse_ply_mesh(out_ply)
+    got_v, got_t = meshes_out[("device", "0")]
 
     # the same chain with the oracles
     splats = world.copy()
@@ -161,4 +175,5 @@ def test_reconstruct_ply_to_ply(tmp_path):
                                keys=g["keys"][g["num_internal"]:], triangles=g["triangles"]))
     exp, stats = mo.mesh_sink(meshes, prune)
     assert len(exp) == 1 and len(got_t) == stats["kept_triangles"] > 10000
-    assert mo.isomorphic(got_v, got_t, exp[0][1], exp[0][2])
+    for key, (v, t) in meshes_out.items():          # one GPU, three device groups over the peer routes, host weld: one mesh
+        assert mo.isomorphic(v, t, exp[0][1], exp[0][2]), key
