@@ -45,8 +45,12 @@ import numpy as np  # noqa: E402
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (counts packed FMA: 2 flops x 2 per lane per clock)
 SLAB = 128                     # corner slices per GPU of the N > 1 workload
-# digest of the meshes of the default N = 1 workload (cfg3 uniform), pinned in tests/test_gpu_configs.py as well
-CFG3_UNIFORM_DIGEST = None
+# digest of the meshes of the default N = 1 workload (cfg3 uniform): the value tests/test_gpu_configs.py pins next to
+# oracle bit-parity on three of the 27 buckets (a data fixture, tests/golden/cfg3_uniform.json)
+try:
+    CFG3_UNIFORM_DIGEST = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg3_uniform.json")))["digest"]
+except Exception:   # noqa: BLE001 - the fixture is optional for the benchmark
+    CFG3_UNIFORM_DIGEST = None
 
 
 def parse_args():
