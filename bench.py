@@ -499,7 +499,12 @@ def main():
             "buckets": [int(x) for x in per_rank[:, 1]],
             "ms_per_step": [round(x / args.steps * 1e3, 3) for x in per_rank[:, 0]],
             "mvoxels_per_s": [round(v * args.steps / e / 1e6, 1) for e, v in zip(per_rank[:, 0], per_rank[:, 2])],
-            "note": "every rank is one GPU working on its own slab; value = sum of voxels / slowest rank's time"}
+            "note": "every rank is one GPU working on its own slab; value = sum of voxels / slowest rank's time",
+            "reading_the_scaling_curve": "the N = 1 point of the driver's curve is cfg3 (0.37 splats per voxel); the N > 1 "
+                                         "points are slabs of cfg4 (0.19 splats per voxel, the density BASELINE names), a lighter "
+                                         "cloud per voxel: ONE slab on ONE GPU runs at 8299 Mvoxels/s "
+                                         "(profiles/r02_bench_cfg4slab_n1.json, `python bench.py --workload cfg4slab`), which is the "
+                                         "per-GPU rate to hold the N > 1 values against"}
 
     # ---- roofline: algorithmic bytes over HIP-event kernel time, per stage ----
     if kernel_stats and not args.no_timing:
