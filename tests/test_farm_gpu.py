@@ -244,3 +244,51 @@ print("ok")
     for env in ({}, {"MLSGPU_HIP_FARM_FORCE_PEER": "1", "MLSGPU_HIP_MESHER_FORCE_PEER": "1"}):
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True)
         assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_farm_on_two_real_devices():
+    """the farm with its device groups on DIFFERENT GPUs (staging events belong to the item's device; a
+    bucket resident on GPU 0 reaches GPU 1's group by a peer copy; ship-outs of both GPUs are welded by the host welder and,
+    separately, appended by peer copy to GPU 0's device sink).  Skipped on a one-GPU box; the same routes run there with
+    both groups on GPU 0 (tests above)."""
+    import os
+    import sys
+    import mlsgpu_amd as m
+    count = m.binding.C.c_int(0)
+    m.binding.check(m.lib().mlsgpu_hip_device_count(m.binding.C.byref(count)))
+    if count.value < 2:
+        pytest.skip("needs two GPUs")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import mesher_oracle as mo
+    from mlsgpu_amd import synth
+    cloud = synth.shells_cloud(120_000, 95.0, 16.0, 1.5, 2.5, seed=321)
+    allb, buckets = synth.bucketize(cloud, 96, 32)
+    cap = max(b.count for b in buckets)
+    exp, exp_stats = mo.mesh_sink(_oracle_meshes(allb, buckets), 0.02)
+    ctx = m.Context(0)
+    raw = m.DeviceBuffer(ctx, array=allb)
+    for route in ("host", "device"):
+        welder = m.HostMesher(0.02) if route == "host" else m.Mesher(ctx, 0.02)
+        farm = m.BucketFarm([0, 1], cap, workers_per_device=2, max_cells=63, sink=None if route == "host" else welder)
+        if route == "host":
+            farm.set_host_output(16 << 20, welder)
+        for i, b in enumerate(buckets):
+            if i % 2 == 0:
+                farm.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, 0)
+            else:
+                ids = m.DeviceBuffer(ctx, array=np.arange(b.first, b.first + b.count, dtype=np.uint32))
+                farm.submit_device(0, raw, ids.ptr, b.count, (0.0, 0.0, 0.0), 1.0, (0, 95, 0, 95, 0, 95), b.low, b.num_vertices, 0)
+        farm.finish()
+        st = farm.stats()
+        assert st["per_device"][0] > 0 and st["per_device"][1] > 0
+        farm.close()
+        assert welder.finalize() == 1
+        stats = welder.stats()
+        for k in ("total_vertices", "threshold", "components", "kept_components", "kept_vertices", "kept_triangles"):
+            assert stats[k] == exp_stats[k], (route, k)
+        got = welder.chunk(0)
+        v, t = (got[1], got[2]) if route == "host" else (got["vertices"], got["triangles"])
+        assert mo.isomorphic(v, t, exp[0][1], exp[0][2]), route
+        welder.close()
+    ctx.close()
