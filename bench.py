@@ -479,6 +479,7 @@ def main():
             "triangles_per_step": triangles,
             "vertices_per_step": vertices,
             "shipouts_per_step": shipouts,
+            "counts_cover": "the whole cloud" if world == 1 else "rank 0's slab (bucket_splats_total, triangles, vertices, ship-outs)",
             "setup_s": round(setup_s, 1),
         },
         "output_digest": {
