@@ -363,18 +363,18 @@ def main():
     collectors = [m.binding.SizeCollector() for _ in range(nworkers)]
 
     def run_share(k):
-        # worker k takes buckets k, k + nworkers, ... (ctypes releases the GIL inside the library)
-        w, col = workers[k], collectors[k]
+        # worker k takes buckets k, k + nworkers, ... (ctypes releases the GIL inside the library).
+        # The octree build overwrites splat.w with 1/r^2 (kernels/octree.cl:193), so every bucket starts from a fresh
+        # copy of its resident splats: a device-to-device copy ON THE WORKER'S STREAM, standing where the reference has the
+        # host-to-device copy of the work item (src/workers.cpp:356-361), overlapping the other workers' kernels exactly as
+        # that copy overlaps them.  It is inside the timed region.
+        w, col, c = workers[k], collectors[k], ctxs[k]
         for b in farm.worker_share(buckets, k, nworkers):
+            m.binding.check(m.lib().mlsgpu_hip_memcpy_d2d(c.h, work.ptr + 32 * b.first, pristine.ptr + 32 * b.first, 32 * b.count))
             w.process(work, b.first, b.count, b.low, b.num_vertices, collector=col)
-        ctxs[k].synchronize()
+        c.synchronize()
 
     def step():
-        # The octree build overwrites splat.w with 1/r^2 (kernels/octree.cl:193), so each pass starts from a
-        # fresh copy of the resident splats: a device-to-device copy standing where the reference has its
-        # host-to-device copy (src/workers.cpp:356-361).  It is inside the timed region.
-        work.copy_from(pristine)
-        ctx.synchronize()
         list(pool.map(run_share, range(nworkers)))
 
     def barrier():
