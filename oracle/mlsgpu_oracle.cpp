@@ -410,6 +410,24 @@ static inline void fitSphere(const SphereFit &sf, Sphere &out)
     out.b2 = dot3(b, b);
 }
 
+/* half_rsqrt(b2), kernels/mls.cl:406.  OpenCL leaves its error implementation-defined (at most 8192 ulp); oracle and HIP path
+ * use the exactly rounded 1/sqrt.  To MEASURE what that substitution can do to a mesh, orc_set_rsqrt_bits(n) makes this
+ * function keep only n mantissa bits of the result (n = 11: what a half-precision reciprocal square root delivers;
+ * 0 = exact, the default) -- tests/test_oracle_mls.py compares the two meshes. */
+static int g_rsqrtBits = 0;
+static inline float rsqrtModel(float x)
+{
+    float r = 1.0f / sqrtf(x);
+    if (g_rsqrtBits > 0 && g_rsqrtBits < 23 && std::isfinite(r))
+    {
+        uint32_t u;
+        std::memcpy(&u, &r, 4);
+        u &= ~((1u << (23 - g_rsqrtBits)) - 1u);
+        std::memcpy(&r, &u, 4);
+    }
+    return r;
+}
+
 /* kernels/mls.cl:237-248 */
 static inline float solveQuadratic(float a, float b, float c)
 {
@@ -445,7 +463,7 @@ static inline float finishCorner(const SphereFit &fit, int shape, float boundary
             {
                 float rhs = (fit.sumWpp - 2 * dot3(fit.sumWp, a) + fit.sumW * aa);
                 if (sphere.qDen > boundaryFactor * rhs)
-                    f = -dot3(sphere.b, a) * (1.0f / sqrtf(sphere.b2));
+                    f = -dot3(sphere.b, a) * rsqrtModel(sphere.b2);
             }
         }
         else
@@ -1324,6 +1342,8 @@ ORC_API int orc_bucket(void *splats, uint64_t firstSplat, uint64_t numSplats,
     }
     return 0;
 }
+
+ORC_API void orc_set_rsqrt_bits(int bits) { g_rsqrtBits = bits; }
 
 ORC_API int orc_num_threads(void)
 {

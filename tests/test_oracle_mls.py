@@ -178,3 +178,28 @@ def test_boundary_factor():
     bs = math.sqrt(6.0) * 512 / (693 * math.pi)
     assert abs(ob.lib().orc_boundary_factor(1.0) - (1 - bs * bs)) < 1e-6
     assert ob.lib().orc_boundary_factor(0.0) == 1.0
+
+
+def test_half_rsqrt_substitution_moves_vertices_not_topology():
+    """The one arithmetic substitution whose size the reference leaves open: `half_rsqrt` (kernels/mls.cl:406, error
+    implementation-defined) is an exactly rounded 1/sqrt in the oracle and the HIP path.  It scales |f| and never its
+    sign, so which cells are occupied, every triangle and every vertex key are unchanged; vertices move along their grid
+    edges.  Measured here with the result cut to 11 mantissa bits (a half-precision reciprocal square root): identical
+    topology, vertices within 1e-3 cells -- the "stated float tolerance + identical topology" of the north star."""
+    from mlsgpu_amd import synth
+    cloud, g = synth.make_cloud("cfg1")
+    kw = dict(max_cells=63, max_swathe=64, mesh_memory=63 * 63 * 2 * 872)
+    exact, _ = ob.bucket(cloud.copy(), 0, len(cloud), (g, g, g), (0, 0, 0), **kw)
+    try:
+        ob.lib().orc_set_rsqrt_bits(11)
+        rough, _ = ob.bucket(cloud.copy(), 0, len(cloud), (g, g, g), (0, 0, 0), **kw)
+    finally:
+        ob.lib().orc_set_rsqrt_bits(0)
+    assert len(exact) == len(rough) >= 1
+    worst = 0.0
+    for a, b in zip(exact, rough):
+        assert a["num_internal"] == b["num_internal"]
+        np.testing.assert_array_equal(a["triangles"], b["triangles"])
+        np.testing.assert_array_equal(a["keys"], b["keys"])
+        worst = max(worst, float(np.abs(a["vertices"] - b["vertices"]).max()))
+    assert 0.0 < worst < 1e-3, worst
