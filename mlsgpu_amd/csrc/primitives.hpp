@@ -26,9 +26,15 @@ enum
 {
     PRIM_BLOCK = 256,                       /* threads per block (4 waves) */
     PRIM_WAVES = PRIM_BLOCK / 64,
-    PRIM_ITEMS = 16,                        /* rounds of 64 contiguous elements per wave */
+    PRIM_ITEMS = 8,                         /* rounds of 64 contiguous elements per wave */
     PRIM_TILE = PRIM_BLOCK * PRIM_ITEMS,    /* elements per block */
     PRIM_WAVE_SPAN = 64 * PRIM_ITEMS,       /* contiguous elements per wave */
+    /* the sort's tiles are twice the scans': measured on cfg3 (ms per step) scans 2048 / sort 4096 elements per workgroup:
+     * writeEntries 2.08, octree.scan 1.41, marching scans 1.12, octree.sort 4.2; all at 4096: 2.41, 1.76, 1.45, 4.2; all at
+     * 2048: sort 4.35 */
+    SORT_ITEMS = 16,
+    SORT_TILE = PRIM_BLOCK * SORT_ITEMS,
+    SORT_WAVE_SPAN = 64 * SORT_ITEMS,
     SORT_MAX_DIGIT_BITS = 10,
     SORT_MAX_BINS = 1 << SORT_MAX_DIGIT_BITS
 };
@@ -291,9 +297,9 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(const K *keys, uint
         bins[d] = 0;
     __syncthreads();
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t base = (uint64_t) blockIdx.x * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
+    const uint64_t base = (uint64_t) blockIdx.x * SORT_TILE + (uint64_t) wave * SORT_WAVE_SPAN + lane;
 #pragma unroll 4
-    for (int j = 0; j < PRIM_ITEMS; j++)
+    for (int j = 0; j < SORT_ITEMS; j++)
     {
         uint64_t i = base + (uint64_t) j * 64;
         if (i < n)
@@ -368,13 +374,13 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn,
     __shared__ uint32_t waveTotals[PRIM_WAVES], waveTotalsAll[PRIM_WAVES];
     /* the tile is reordered in two phases through ONE buffer (keys, then values): half the LDS, twice the
      * resident workgroups, which is what this latency-bound kernel needs */
-    __shared__ K sTile[PRIM_TILE];
+    __shared__ K sTile[SORT_TILE];
     if (nDev != nullptr && *nDev < n)
         n = *nDev;
-    const uint64_t tileFirst = (uint64_t) blockIdx.x * PRIM_TILE;
+    const uint64_t tileFirst = (uint64_t) blockIdx.x * SORT_TILE;
     if (tileFirst >= n)
         return;
-    const uint32_t tileCount = (uint32_t) (n - tileFirst < PRIM_TILE ? n - tileFirst : PRIM_TILE);
+    const uint32_t tileCount = (uint32_t) (n - tileFirst < SORT_TILE ? n - tileFirst : SORT_TILE);
     const uint32_t numBins = 1u << digitBits;
     const K mask = (K) (numBins - 1);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -385,10 +391,10 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn,
             waveBins[w][d] = 0;
     }
     __syncthreads();
-    const uint64_t base = tileFirst + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
-    K keys[PRIM_ITEMS];
+    const uint64_t base = tileFirst + (uint64_t) wave * SORT_WAVE_SPAN + lane;
+    K keys[SORT_ITEMS];
 #pragma unroll
-    for (int j = 0; j < PRIM_ITEMS; j++)
+    for (int j = 0; j < SORT_ITEMS; j++)
     {
         uint64_t i = base + (uint64_t) j * 64;
         keys[j] = i < n ? keysIn[i] : (K) 0;
@@ -439,9 +445,9 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn,
     }
     __syncthreads();
     /* stable split of each round: rank among the lanes of the wave holding the same digit */
-    uint32_t dst[PRIM_ITEMS];
+    uint32_t dst[SORT_ITEMS];
 #pragma unroll
-    for (int j = 0; j < PRIM_ITEMS; j++)
+    for (int j = 0; j < SORT_ITEMS; j++)
     {
         const uint64_t i = base + (uint64_t) j * 64;
         const bool valid = i < n;
@@ -467,9 +473,9 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn,
     }
     __syncthreads();
     /* keys leave in tile-sorted order: each digit's run is one contiguous, coalesced burst */
-    uint32_t out[PRIM_ITEMS];
+    uint32_t out[SORT_ITEMS];
 #pragma unroll
-    for (int k = 0; k < PRIM_ITEMS; k++)
+    for (int k = 0; k < SORT_ITEMS; k++)
     {
         const uint32_t p = threadIdx.x + k * PRIM_BLOCK;
         out[k] = 0;
@@ -484,7 +490,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn,
     /* the values take the same route through the same buffer */
     uint32_t *sVals = reinterpret_cast<uint32_t *>(sTile);
 #pragma unroll
-    for (int j = 0; j < PRIM_ITEMS; j++)
+    for (int j = 0; j < SORT_ITEMS; j++)
     {
         const uint64_t i = base + (uint64_t) j * 64;
         if (i < n)
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn,
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < PRIM_ITEMS; k++)
+    for (int k = 0; k < SORT_ITEMS; k++)
     {
         const uint32_t p = threadIdx.x + k * PRIM_BLOCK;
         if (p < tileCount)
@@ -511,7 +517,8 @@ struct SortResult
 static inline uint32_t sortPasses(uint32_t bits, uint32_t maxDigitBits) { return (bits + maxDigitBits - 1) / maxDigitBits; }
 /* elements of uint32 needed for the histogram of a sort of n keys: 2^bits x tiles counters and, behind them, the 2^bits
  * digit totals of the pass */
-static inline uint64_t sortHistElems(uint64_t n) { return (uint64_t) SORT_MAX_BINS * ((uint64_t) scanTiles(n) + 1); }
+static inline uint32_t sortTiles(uint64_t n) { return divUp(n, SORT_TILE); }
+static inline uint64_t sortHistElems(uint64_t n) { return (uint64_t) SORT_MAX_BINS * ((uint64_t) sortTiles(n) + 1); }
 
 /*
  * Sorts (keysA, valsA)[0..n) stably by key bits [0, bits).  keysB/valsB are same-sized temporaries
@@ -528,7 +535,7 @@ static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *
     result->vals = valsA;
     if (n == 0)
         return MLSGPU_OK;
-    const uint32_t tiles = scanTiles(n);
+    const uint32_t tiles = sortTiles(n);
     (void) dTileSums;
     uint32_t *const dDigitTotals = dHist + (uint64_t) SORT_MAX_BINS * tiles;
     if (bits == 0)
