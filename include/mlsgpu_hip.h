@@ -390,6 +390,16 @@ int mlsgpu_hip_mesher_add(mlsgpu_mesher *mesher, mlsgpu_ctx *from, uint64_t chun
 int mlsgpu_hip_mesher_farm_output(void *mesher, int device, uint64_t chunkId, mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh);
 /* Empties the mesher for the next job; arenas, scratch and outputs keep their capacity. */
 int mlsgpu_hip_mesher_reset(mlsgpu_mesher *mesher);
+/* Several meshers, one job (one process per GPU, every rank's meshes in its own HBM): the device sink's counterpart of
+ * mlsgpu_hip_host_mesher_boundary / _boundary_read / _finalize_with below.  boundary() welds and labels what has been
+ * added and exports every distinct external key with the (densely numbered) component that holds its vertex, and the
+ * vertex / triangle count of every component; finalize_with() produces the output with the caller's verdict per component
+ * in place of the prune rule.  No add between the two calls.  mlsgpu_amd/dist_sink.py merges the exports of all ranks in
+ * one all-gather. */
+int mlsgpu_hip_mesher_boundary(mlsgpu_mesher *mesher, uint64_t *numKeys, uint64_t *numRoots);
+int mlsgpu_hip_mesher_boundary_read(mlsgpu_mesher *mesher, uint64_t *keys, uint32_t *keyRoot, uint64_t *rootVertices,
+                                    uint64_t *rootTriangles);
+int mlsgpu_hip_mesher_finalize_with(mlsgpu_mesher *mesher, const uint8_t *keepRoot, uint64_t numRoots, uint32_t *numChunks);
 /* What MesherBase::write does before it writes files: weld by key, components, prune.  *numChunks = chunks that have
  * triangles (no output is produced for the others, src/mesher.cpp:820). */
 int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *mesher, uint32_t *numChunks);

@@ -228,6 +228,9 @@ def lib():
     sig("mlsgpu_hip_mesher_reserve", C.c_int, vp, u64, u64, u64)
     sig("mlsgpu_hip_mesher_farm_output", C.c_int, vp, C.c_int, u64, vp, P(Mesh))
     sig("mlsgpu_hip_mesher_reset", C.c_int, vp)
+    sig("mlsgpu_hip_mesher_boundary", C.c_int, vp, P(u64), P(u64))
+    sig("mlsgpu_hip_mesher_boundary_read", C.c_int, vp, vp, vp, vp, vp)
+    sig("mlsgpu_hip_mesher_finalize_with", C.c_int, vp, vp, u64, P(u32))
     sig("mlsgpu_hip_mesher_finalize", C.c_int, vp, P(u32))
     sig("mlsgpu_hip_mesher_chunk", C.c_int, vp, u32, P(u64), P(u64), P(u64), P(vp), P(vp))
     sig("mlsgpu_hip_mesher_stats", C.c_int, vp, vp)
@@ -668,6 +671,22 @@ class Mesher:
 
     def reset(self):
         check(lib().mlsgpu_hip_mesher_reset(self.h))
+
+    def boundary(self):
+        """(keys, key_root, root_vertices, root_triangles) of what has been added: what a cross-rank merge needs
+        (dist_sink.global_prune); the meshes stay in HBM."""
+        nk, nr = C.c_uint64(), C.c_uint64()
+        check(lib().mlsgpu_hip_mesher_boundary(self.h, C.byref(nk), C.byref(nr)))
+        keys, kr = np.zeros(nk.value, np.uint64), np.zeros(nk.value, np.uint32)
+        rv, rt = np.zeros(nr.value, np.uint64), np.zeros(nr.value, np.uint64)
+        check(lib().mlsgpu_hip_mesher_boundary_read(self.h, _p(keys), _p(kr), _p(rv), _p(rt)))
+        return keys, kr, rv, rt
+
+    def finalize_with(self, keep_root):
+        keep = np.ascontiguousarray(keep_root, np.uint8)
+        n = C.c_uint32(0)
+        check(lib().mlsgpu_hip_mesher_finalize_with(self.h, _p(keep), len(keep), C.byref(n)))
+        return n.value
 
     def finalize(self):
         n = C.c_uint32(0)

@@ -306,6 +306,99 @@ __global__ void gatherU32Kernel(const uint32_t *src, const uint64_t *at, uint32_
         dst[i] = at[i] < limit ? src[at[i]] : last;
 }
 
+/* ---- boundary export for several meshers, one job (see mlsgpu_hip_mesher_boundary) ---- */
+
+/* the roots of the components, densely numbered in vertex order */
+struct IsRootIn
+{
+    const uint32_t *compRep, *root;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const
+    {
+        return (compRep[i] == (uint32_t) i && root[i] == (uint32_t) i) ? 1u : 0u;
+    }
+};
+struct RootOut
+{
+    uint32_t *rootId, *denseOf;
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t isRoot) const
+    {
+        denseOf[i] = excl;
+        if (isRoot)
+            rootId[excl] = (uint32_t) i;
+    }
+};
+
+/* triangles per component, by the span trick of componentSizeKernel (a noise cloud is one component) */
+__global__ __launch_bounds__(256) void componentTrianglesKernel(const uint32_t *tri, const uint32_t *root, const uint32_t *denseOf,
+                                                                uint64_t nt, uint32_t *count)
+{
+    const uint64_t wave = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t first = wave * (64 * SIZE_SPAN);
+    uint32_t pendingRoot = 0, pendingCount = 0;
+    for (uint32_t s = 0; s < SIZE_SPAN; s++)
+    {
+        const uint64_t t = first + (uint64_t) s * 64 + laneId();
+        if (first + (uint64_t) s * 64 >= nt)
+            break;
+        const bool counts = t < nt;
+        const uint32_t mine = counts ? denseOf[root[tri[3 * t]]] : 0u;
+        uint64_t todo = __ballot(counts);
+        while (todo != 0)
+        {
+            const uint32_t r = readLane(mine, (int) __builtin_ctzll(todo));
+            const uint64_t same = __ballot(counts && mine == r) & todo;
+            if (pendingCount != 0 && r != pendingRoot)
+            {
+                if (laneId() == 0)
+                    atomicAdd(&count[pendingRoot], pendingCount);
+                pendingCount = 0;
+            }
+            pendingRoot = r;
+            pendingCount += (uint32_t) __popcll(same);
+            todo &= ~same;
+        }
+    }
+    if (pendingCount != 0 && laneId() == 0)
+        atomicAdd(&count[pendingRoot], pendingCount);
+}
+
+__global__ void gatherSizesKernel(const uint32_t *rootId, const uint32_t *size, uint32_t n, uint32_t *out)
+{
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n)
+        out[d] = size[rootId[d]];
+}
+
+/* every distinct external key (the keys are sorted) with the dense root of its vertex */
+struct FirstOfRunIn
+{
+    const uint64_t *keys;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return (i == 0 || keys[i - 1] != keys[i]) ? 1u : 0u; }
+};
+struct KeyRootOut
+{
+    const uint64_t *keys;
+    const uint32_t *slots, *extGid, *root, *denseOf;
+    uint64_t *keyOut;
+    uint32_t *rootOut;
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t first) const
+    {
+        if (first)
+        {
+            keyOut[excl] = keys[i];
+            rootOut[excl] = denseOf[root[extGid[slots[i]]]];
+        }
+    }
+};
+
+/* the caller's verdict per dense root becomes the "size" the output pass tests against a threshold of 1 */
+__global__ void applyVerdictKernel(const uint32_t *rootId, const uint8_t *keep, uint32_t n, uint32_t *size)
+{
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n)
+        size[rootId[d]] = keep[d] ? 0xFFFFFFFFu : 0u;
+}
+
 template<typename T>
 struct Arena
 {
@@ -370,6 +463,7 @@ uint64_t scratchBytes(uint64_t nv, uint64_t nt, uint64_t ne, uint64_t nb, uint64
         + al(scanTiles(std::max<uint64_t>(sortHistElems(ne), ne)) * 4);
     total += al(scanTiles(std::max(nv, nt)) * 4);                                   /* scans */
     total += 2 * al((nb + 1) * 8) + 2 * al((nb + 1) * 4) + 3 * al((nc + 1) * 8) + 8 * 256;
+    total += 2 * al(scanTiles(nv) * 4) + al(scanTiles(ne) * 4) + al(nv);            /* boundary export / verdict */
     return total + (1 << 20);
 }
 } // namespace
@@ -392,6 +486,10 @@ struct mlsgpu_mesher
     std::vector<uint64_t> chunkVStart, chunkTStart;     /* [chunks + 1] */
     std::vector<uint32_t> outChunks;                    /* dense chunk indices that have triangles */
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    /* boundary export (mlsgpu_hip_mesher_boundary): valid until the next add */
+    bool analyzed = false;
+    std::vector<uint64_t> bKeys, bRootVertices, bRootTriangles;
+    std::vector<uint32_t> bKeyRoot;
 
     /* kept between finalize calls; grown on demand (or up front by reserve) */
     void *slab = nullptr;
@@ -440,6 +538,7 @@ struct mlsgpu_mesher
     }
     int regroupByChunk();
     void dropResults() { finalized = false; }
+    int finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uint8_t *keepRoots, uint64_t numRoots);
     ~mlsgpu_mesher()
     {
         hipFree(outVertices);
@@ -554,6 +653,7 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
     m->extGid.used += ne;
     m->extChunk.used += ne;
     m->blocks.push_back(r);
+    m->analyzed = false;
     return MLSGPU_OK;
 }
 
@@ -575,6 +675,7 @@ MLSGPU_API int mlsgpu_hip_mesher_reset(mlsgpu_mesher *m)
     m->chunkIds.clear();
     m->outChunks.clear();
     m->finalized = false;
+    m->analyzed = false;
     return MLSGPU_OK;
 }
 
@@ -651,6 +752,15 @@ MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
 {
     REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
     std::lock_guard<std::mutex> lock(m->mutex);
+    return m->finalizeImpl(numChunks, false, nullptr, 0);
+}
+
+/* analyzeOnly: weld + components, then the boundary export instead of any output.  keepRoots: the caller's verdict per
+ * dense root (the numbering of the last export; the union-find hooks larger roots under smaller ones, so a component's
+ * root is its smallest welded vertex whatever the schedule and the numbering is reproducible) replaces the prune rule. */
+int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uint8_t *keepRoots, uint64_t numRoots)
+{
+    mlsgpu_mesher *const m = this;
     mlsgpu_ctx *ctx = m->ctx;
     HIP_CHECK(hipSetDevice(ctx->device));
     m->dropResults();
@@ -661,9 +771,17 @@ MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
     m->chunkTStart.assign(nc + 1, 0);
     m->outChunks.clear();
     std::fill(m->stats, m->stats + 8, 0);
+    if (analyzeOnly)
+    {
+        m->bKeys.clear();
+        m->bKeyRoot.clear();
+        m->bRootVertices.clear();
+        m->bRootTriangles.clear();
+        m->analyzed = true;
+    }
     if (nv == 0 || nt == 0)
     {
-        m->finalized = true;
+        m->finalized = !analyzeOnly;
         if (numChunks)
             *numChunks = 0;
         return MLSGPU_OK;
@@ -685,10 +803,12 @@ MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
     HIP_CHECK(hipMemsetAsync(size, 0, nv * 4, ctx->stream));
 
     /* 1. weld */
+    SortResult<uint64_t> sorted = {nullptr, nullptr};
+    uint64_t *keysA = nullptr, *keysB = nullptr;
+    uint32_t *slotsA = nullptr, *slotsB = nullptr;
     if (ne > 0)
     {
-        uint64_t *keysA, *keysB;
-        uint32_t *slotsA, *slotsB, *hist, *tileSums;
+        uint32_t *hist, *tileSums;
         PROPAGATE(S.get(&keysA, ne));
         PROPAGATE(S.get(&keysB, ne));
         PROPAGATE(S.get(&slotsA, ne));
@@ -696,7 +816,6 @@ MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
         PROPAGATE(S.get(&hist, sortHistElems(ne)));
         PROPAGATE(S.get(&tileSums, scanTiles(std::max<uint64_t>(sortHistElems(ne), ne))));
         HIP_CHECK(hipMemcpyAsync(keysA, m->extKeys.ptr, ne * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        SortResult<uint64_t> sorted;
         PROPAGATE(radixSort<uint64_t>(ctx, "mesher.weld.time", keysA, slotsA, keysB, slotsB, ne, 64, true, hist, tileSums, &sorted));
         LAUNCH(ctx, "mesher.weld.time", externalRepsKernel, dim3(divUp(ne, 256)), B, (const uint64_t *) sorted.keys,
                (const uint32_t *) sorted.vals, (const uint32_t *) m->extGid.ptr, (const uint32_t *) m->extChunk.ptr, ne, compRep, outRep);
@@ -711,6 +830,75 @@ MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
     LAUNCH(ctx, "mesher.components.time", compressKernel, dim3(divUp(nv, 256)), B, parent, (const uint32_t *) compRep, nv, root);
     LAUNCH(ctx, "mesher.components.time", componentSizeKernel, dim3(divUp(divUp(nv, 64 * SIZE_SPAN), 4)), B,
            (const uint32_t *) compRep, (const uint32_t *) root, nv, size);
+
+    /* 2b. several meshers, one job: the dense roots (needed by both the export and the verdict) */
+    uint32_t rootCount = 0;
+    uint32_t *const rootId = parent;            /* the union-find forest is not needed any more */
+    uint32_t *const denseOf = vIndex;           /* the output pass rewrites it later */
+    if (analyzeOnly || keepRoots != nullptr)
+    {
+        uint32_t *dRootTotal, *rootTiles;
+        PROPAGATE(S.get(&dRootTotal, 1));
+        PROPAGATE(S.get(&rootTiles, scanTiles(nv)));
+        PROPAGATE((exclusiveScan<uint32_t>(ctx, "mesher.components.time", IsRootIn{compRep, root}, RootOut{rootId, denseOf}, nv, 0u,
+                                           rootTiles, dRootTotal)));
+        HIP_CHECK(hipMemcpyAsync(&rootCount, dRootTotal, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    if (analyzeOnly)
+    {
+        uint32_t hFailed = 0;
+        HIP_CHECK(hipMemcpyAsync(&hFailed, dFailed, 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (hFailed != 0)
+            return setError(MLSGPU_ERR_HIP, "mesher: component union did not converge");
+        /* vertices and triangles per root (outRep is only needed by an output pass: it holds the triangle counts here) */
+        uint32_t *const tcount = outRep, *const vcount = compRep;    /* compRep's last reader was the root scan */
+        HIP_CHECK(hipMemsetAsync(tcount, 0, (size_t) rootCount * 4, ctx->stream));
+        LAUNCH(ctx, "mesher.components.time", componentTrianglesKernel, dim3(divUp(divUp(nt, 64 * SIZE_SPAN), 4)), B,
+               (const uint32_t *) m->triangles.ptr, (const uint32_t *) root, (const uint32_t *) denseOf, nt, tcount);
+        LAUNCH(ctx, "mesher.components.time", gatherSizesKernel, dim3(divUp(rootCount, 256)), B, (const uint32_t *) rootId,
+               (const uint32_t *) size, rootCount, vcount);
+        std::vector<uint32_t> hv(rootCount), ht(rootCount);
+        HIP_CHECK(hipMemcpyAsync(hv.data(), vcount, (size_t) rootCount * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_CHECK(hipMemcpyAsync(ht.data(), tcount, (size_t) rootCount * 4, hipMemcpyDeviceToHost, ctx->stream));
+        uint32_t keyCount = 0;
+        if (ne > 0)
+        {
+            /* the distinct keys with their roots, into the sort's spare buffers */
+            uint64_t *keyOut = sorted.keys == keysA ? keysB : keysA;
+            uint32_t *rootOut = sorted.vals == slotsA ? slotsB : slotsA;
+            uint32_t *dKeyTotal, *keyTiles;
+            PROPAGATE(S.get(&dKeyTotal, 1));
+            PROPAGATE(S.get(&keyTiles, scanTiles(ne)));
+            PROPAGATE((exclusiveScan<uint32_t>(ctx, "mesher.weld.time", FirstOfRunIn{sorted.keys},
+                                               KeyRootOut{sorted.keys, sorted.vals, m->extGid.ptr, root, denseOf, keyOut, rootOut},
+                                               ne, 0u, keyTiles, dKeyTotal)));
+            HIP_CHECK(hipMemcpyAsync(&keyCount, dKeyTotal, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            m->bKeys.resize(keyCount);
+            m->bKeyRoot.resize(keyCount);
+            HIP_CHECK(hipMemcpyAsync(m->bKeys.data(), keyOut, (size_t) keyCount * 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipMemcpyAsync(m->bKeyRoot.data(), rootOut, (size_t) keyCount * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        m->bRootVertices.assign(hv.begin(), hv.end());
+        m->bRootTriangles.assign(ht.begin(), ht.end());
+        if (numChunks)
+            *numChunks = 0;
+        return MLSGPU_OK;
+    }
+    if (keepRoots != nullptr)
+    {
+        if (numRoots != rootCount || !m->analyzed || m->bRootVertices.size() != rootCount)
+            return setError(MLSGPU_ERR_LENGTH, "mesher: %llu verdicts for %u components (call boundary first, no add in between)",
+                            (unsigned long long) numRoots, rootCount);
+        uint8_t *dKeep;
+        PROPAGATE(S.get(&dKeep, rootCount));
+        HIP_CHECK(hipMemcpyAsync(dKeep, keepRoots, rootCount, hipMemcpyHostToDevice, ctx->stream));
+        LAUNCH(ctx, "mesher.components.time", applyVerdictKernel, dim3(divUp(rootCount, 256)), B, (const uint32_t *) rootId,
+               (const uint8_t *) dKeep, rootCount, size);
+    }
 
     /* 3. prune threshold, src/mesher.cpp:498-527 */
     unsigned long long *dStats;
@@ -727,7 +915,8 @@ MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
     if (hFailed != 0)
         return setError(MLSGPU_ERR_HIP, "mesher: component union did not converge");
     const uint64_t totalVertices = hStats[0];
-    const uint64_t threshold = (uint64_t) ((double) totalVertices * m->pruneThreshold);
+    /* with a verdict the "sizes" are all-or-nothing and the threshold is 1 */
+    const uint64_t threshold = keepRoots != nullptr ? 1 : (uint64_t) ((double) totalVertices * m->pruneThreshold);
     LAUNCH(ctx, "mesher.components.time", componentStatsKernel, statsGrid, B, (const uint32_t *) compRep,
            (const uint32_t *) root, (const uint32_t *) size, nv, threshold, dStats, 1);
 
@@ -811,6 +1000,14 @@ MLSGPU_API int mlsgpu_hip_mesher_finalize(mlsgpu_mesher *m, uint32_t *numChunks)
     m->stats[2] = hStats[1];
     m->stats[3] = hStats[2];
     m->stats[4] = hStats[3];
+    if (keepRoots != nullptr)
+    {
+        /* this mesher's own part of the job: kept components and their welded vertices from the export */
+        m->stats[4] = 0;
+        for (uint64_t r = 0; r < numRoots; r++)
+            if (keepRoots[r])
+                m->stats[4] += m->bRootVertices[r];
+    }
     m->stats[5] = totals[1];
     m->stats[6] = nv;
     m->stats[7] = nt;
@@ -839,6 +1036,41 @@ MLSGPU_API int mlsgpu_hip_mesher_stats(mlsgpu_mesher *m, uint64_t out[8])
     REQUIRE(m != nullptr && out != nullptr && m->finalized, MLSGPU_ERR_INVALID);
     std::copy(m->stats, m->stats + 8, out);
     return MLSGPU_OK;
+}
+
+/* ---- several meshers, one job: the device sink's side of mlsgpu_amd/dist_sink.py (see include/mlsgpu_hip.h) ---- */
+MLSGPU_API int mlsgpu_hip_mesher_boundary(mlsgpu_mesher *m, uint64_t *numKeys, uint64_t *numRoots)
+{
+    REQUIRE(m != nullptr && numKeys != nullptr && numRoots != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    PROPAGATE(m->finalizeImpl(nullptr, true, nullptr, 0));
+    *numKeys = m->bKeys.size();
+    *numRoots = m->bRootVertices.size();
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_mesher_boundary_read(mlsgpu_mesher *m, uint64_t *keys, uint32_t *keyRoot, uint64_t *rootVertices,
+                                               uint64_t *rootTriangles)
+{
+    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    REQUIRE(m->analyzed, MLSGPU_ERR_INVALID);
+    REQUIRE((m->bKeys.empty() || (keys != nullptr && keyRoot != nullptr))
+            && (m->bRootVertices.empty() || (rootVertices != nullptr && rootTriangles != nullptr)), MLSGPU_ERR_INVALID);
+    std::copy(m->bKeys.begin(), m->bKeys.end(), keys);
+    std::copy(m->bKeyRoot.begin(), m->bKeyRoot.end(), keyRoot);
+    std::copy(m->bRootVertices.begin(), m->bRootVertices.end(), rootVertices);
+    std::copy(m->bRootTriangles.begin(), m->bRootTriangles.end(), rootTriangles);
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_mesher_finalize_with(mlsgpu_mesher *m, const uint8_t *keepRoot, uint64_t numRoots, uint32_t *numChunks)
+{
+    REQUIRE(m != nullptr && (numRoots == 0 || keepRoot != nullptr), MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    REQUIRE(m->analyzed, MLSGPU_ERR_INVALID);
+    static const uint8_t none = 0;
+    return m->finalizeImpl(numChunks, false, numRoots ? keepRoot : &none, numRoots);
 }
 
 /* FastPly::Writer's file (src/fast_ply.cpp:443-521): header padded to a multiple of 4, float32 x y z per vertex,

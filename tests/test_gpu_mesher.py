@@ -124,3 +124,38 @@ def test_worker_meshes_weld_into_a_closed_surface(tmp_path):
     mesher.close()
     del worker
     ctx.close()
+
+
+@pytest.mark.parametrize("seed,prune,ranks", [(1, 0.0, 2), (2, 0.01, 3), (3, 0.05, 4), (4, 0.3, 2)])
+def test_several_device_sinks_one_job(seed, prune, ranks):
+    """Several meshers, one job (one process per GPU): every sink welds and labels its own blocks in HBM and exports its
+    boundary; dist_sink.merge_boundaries unites components across sinks and applies the prune rule to the whole job; every
+    sink finalizes with that verdict.  Blocks are dealt to the sinks round-robin (a seam between every two blocks); each
+    sink's output equals the oracle's chunk for it and the whole-job statistics equal the single-sink oracle's."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import dist_sink
+    meshes = random_meshes(seed, blocks=12, chunks=1)
+    owner = [b % ranks for b in range(12)]
+    exp, exp_stats = mo.mesh_sink([dict(mm, chunk=owner[i]) for i, mm in enumerate(meshes)], prune)
+    ctx = m.Context(0)
+    sinks = [m.Mesher(ctx, prune) for _ in range(ranks)]
+    for i, mm in enumerate(meshes):
+        sinks[owner[i]].add(0, mm["vertices"], mm["num_internal"], mm["keys"], mm["triangles"])
+    parts = [s.boundary() for s in sinks]
+    keep, stats = dist_sink.merge_boundaries(parts, prune)
+    for k in exp_stats:
+        assert stats[k] == exp_stats[k], k
+    exp_by = {c: (v, t) for c, v, t in exp}
+    kept_local = 0
+    for r, s in enumerate(sinks):
+        n = s.finalize_with(keep[r])
+        if r in exp_by:
+            assert n == 1
+            c = s.chunk(0)
+            assert mo.isomorphic(c["vertices"], c["triangles"], *exp_by[r])
+        else:
+            assert n == 0
+        kept_local += s.stats()["kept_triangles"]
+        s.close()
+    assert kept_local == exp_stats["kept_triangles"]
+    ctx.close()
