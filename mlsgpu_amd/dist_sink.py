@@ -1,7 +1,9 @@
 """Cross-rank finish of the mesh sink for one-process-per-GPU runs.
 
-Every rank welds the ship-outs of ITS buckets with a HostMesher (OOCMesher's weld, src/mesher.cpp:220-469).  What is
-left is global: a connected component may cross rank boundaries, and the prune threshold is a fraction of the TOTAL
+Every rank welds the ship-outs of ITS buckets with a welder of its own -- a HostMesher (OOCMesher's weld on the host,
+src/mesher.cpp:220-469) or a device Mesher (the same weld in HBM; the meshes never leave the GPU) -- both export the same
+boundary (keys with the component holding the vertex, component sizes) and accept the same verdict.  What is left is
+global: a connected component may cross rank boundaries, and the prune threshold is a fraction of the TOTAL
 number of welded vertices (getStatistics, src/mesher.cpp:491-536).  The reference's MPI build sends every ship-out to
 one rank's mesher instead (src/mlsgpu_mpi.cpp); here only the boundary travels -- each rank's external keys with the
 clump that holds the vertex, and the clump sizes -- in ONE all-gather (the path's only exchange step; a few tens of MB
@@ -47,7 +49,7 @@ def merge_boundaries(parts, prune_threshold):
 
 
 def global_prune(mesher, prune_threshold, dist=None):
-    """Finalizes `mesher` (this rank's HostMesher) with the whole job's components and threshold.  `dist`:
+    """Finalizes `mesher` (this rank's HostMesher or device Mesher) with the whole job's components and threshold.  `dist`:
     torch.distributed, initialised, or None for a single process.  Returns (number of output chunks, whole-job stats)."""
     mine = mesher.boundary()
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

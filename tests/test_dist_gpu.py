@@ -1,6 +1,7 @@
 """The one-process-per-GPU path on real devices: two ranks (sharing GPU 0 on a one-GPU box, gloo for the exchange), each
-running ITS share of one cloud's buckets through its own bucket farm, host read-back and HostMesher, then the one
-all-gather of dist_sink.global_prune; and bench.py's N > 1 mode launched the way the driver launches it."""
+running ITS share of one cloud's buckets through its own bucket farm into its own welder -- a HostMesher behind the
+read-back ring, then a device sink whose meshes never leave HBM -- followed by the one all-gather of
+dist_sink.global_prune; and bench.py's N > 1 mode launched the way the driver launches it."""
 import json
 import os
 import socket
@@ -39,16 +40,27 @@ cloud = synth.shells_cloud(120_000, 95.0, 16.0, 1.5, 2.5, seed=321)
 cloud = np.concatenate([cloud, synth.sphere_cloud(600, (10.0, 10.0, 10.0), 4.0, 1.0, 1.5, seed=3)])
 allb, buckets = synth.bucketize(cloud, 96, 32)
 mine = farm.rank_share(list(range(len(buckets))), rank, world)
-welder = m.HostMesher(0.02)
-f = m.BucketFarm([rank %% ndev], max(b.count for b in buckets), workers_per_device=2, max_cells=63)
-f.set_host_output(8 << 20, welder)
-for i in mine:
-    b = buckets[i]
-    f.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, rank)
-f.finish()
-f.close()
-n, stats = dist_sink.global_prune(welder, 0.02, dist)
 ok = True
+results = []
+for route in ("host", "device"):
+    # host: ship-outs read back through the pinned ring into this rank's HostMesher; device: appended to this rank's
+    # device sink, the meshes stay in HBM and only the boundary travels
+    ctx = m.Context(rank %% ndev)
+    welder = m.HostMesher(0.02) if route == "host" else m.Mesher(ctx, 0.02)
+    f = m.BucketFarm([rank %% ndev], max(b.count for b in buckets), workers_per_device=2, max_cells=63,
+                     sink=None if route == "host" else welder)
+    if route == "host":
+        f.set_host_output(8 << 20, welder)
+    for i in mine:
+        b = buckets[i]
+        f.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, rank)
+    f.finish()
+    f.close()
+    n, stats = dist_sink.global_prune(welder, 0.02, dist)
+    got = welder.chunk(0) if n else None
+    if got is not None and route == "device":
+        got = (got["chunk"], got["vertices"], got["triangles"])
+    results.append((n, stats, got))
 if rank == 0:
     ref = allb.copy()
     everything = []
@@ -60,10 +72,10 @@ if rank == 0:
             ni = g["num_internal"]
             everything.append(dict(chunk=owner, vertices=g["vertices"], num_internal=ni, keys=g["keys"][ni:], triangles=g["triangles"]))
     exp, exp_stats = mo.mesh_sink(everything, 0.02)
-    ok = all(stats[k] == exp_stats[k] for k in exp_stats) and stats["kept_components"] < stats["components"]
-    _, v, t = welder.chunk(0)
     ev, et = [(v_, t_) for c, v_, t_ in exp if c == 0][0]
-    ok = ok and n == 1 and mo.isomorphic(v, t, ev, et)
+    for n, stats, got in results:
+        ok = ok and all(stats[k] == exp_stats[k] for k in exp_stats) and stats["kept_components"] < stats["components"]
+        ok = ok and n == 1 and mo.isomorphic(got[1], got[2], ev, et)
 flag = torch.tensor([1 if ok else 0])
 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
 dist.destroy_process_group()
