@@ -651,6 +651,23 @@ def main():
             "device_workers": nworkers,
             "note": "meshes never leave HBM; finalize = key sort + union-find + sizes + two compaction scans",
         }
+        # what one rank of a one-process-per-GPU job pays instead of finalize: the boundary export, the merge of all ranks'
+        # exports (here: its own) and the output pass with the merged verdict (mlsgpu_amd/dist_sink.py)
+        from mlsgpu_amd import dist_sink
+        t0 = time.perf_counter()
+        part = sink.boundary()
+        b_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        keep, dstats = dist_sink.merge_boundaries([part], 0.02)
+        m_s = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        sink.finalize_with(keep[0])
+        ctx.synchronize()
+        f_s = time.perf_counter() - t0
+        result["mesh_sink"]["distributed"] = {
+            "boundary_ms": round(b_s * 1e3, 3), "merge_ms": round(m_s * 1e3, 3), "finalize_with_ms": round(f_s * 1e3, 3),
+            "keys": int(len(part[0])), "components": int(len(part[2])), "export_bytes": int(sum(a.nbytes for a in part)),
+            "same_verdict": dstats["kept_triangles"] == st["kept_triangles"] and dstats["total_vertices"] == st["total_vertices"]}
         sink.close()
 
     # ---- device-bucketer leg (never `value`): the RAW cloud resident in HBM, partitioned on the device exactly as
