@@ -117,6 +117,8 @@ MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkI
     const uint64_t nv = mesh->numVertices, nt = mesh->numTriangles, ni = mesh->numInternalVertices, ne = nv - ni;
     REQUIRE((nv == 0 || mesh->vertices != nullptr) && (nt == 0 || mesh->triangles != nullptr)
             && (ne == 0 || mesh->vertexKeys != nullptr), MLSGPU_ERR_INVALID);
+    for (uint64_t t = 0; t < 3 * nt; t++)       /* before anything is appended: a bad mesh leaves the sink unchanged */
+        REQUIRE(mesh->triangles[t] < nv, MLSGPU_ERR_INVALID);
     std::lock_guard<std::mutex> lock(m->mutex);
     m->finalized = false;
     Block b;
@@ -145,7 +147,6 @@ MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkI
     for (uint64_t t = 0; t < nt; t++)
     {
         const uint32_t *tri = mesh->triangles + 3 * t;
-        REQUIRE(tri[0] < nv && tri[1] < nv && tri[2] < nv, MLSGPU_ERR_INVALID);
         for (int e = 0; e < 2; e++)
         {
             int32_t a = ufRoot(uf, (int32_t) tri[e]), c = ufRoot(uf, (int32_t) tri[e + 1]);

@@ -82,3 +82,21 @@ def test_argument_checks():
         mesher.stats()                       # not finalized
     with pytest.raises(m.InvalidArgument):
         m.HostMesher(1.5)
+
+
+def test_bad_mesh_leaves_the_sink_unchanged_and_empty_sinks_finalize():
+    import mlsgpu_amd as m
+    mesher = m.HostMesher()
+    assert mesher.finalize() == 0 and mesher.stats()["total_vertices"] == 0         # nothing added
+    a = CASES["simple"]["meshes"][0]
+    mesher.add(0, a["vertices"], a["num_internal"], a["keys"], a["triangles"])
+    with pytest.raises(m.InvalidArgument):
+        mesher.add(0, a["vertices"], a["num_internal"], a["keys"], np.array([[0, 1, 99]], np.uint32))
+    assert mesher.finalize() == 1
+    st = mesher.stats()
+    assert st["vertices_added"] == len(a["vertices"]) and st["triangles_added"] == len(a["triangles"])
+    keys, kc, cv, ct = mesher.boundary()
+    assert cv.sum() == st["total_vertices"] and ct.sum() == st["triangles_added"]
+    with pytest.raises(m.LengthError):
+        mesher.finalize_with(np.ones(len(cv) + 1, np.uint8))
+    assert mesher.finalize_with(np.zeros(len(cv), np.uint8)) == 0                   # everything pruned by verdict
