@@ -159,3 +159,32 @@ def test_several_device_sinks_one_job(seed, prune, ranks):
         s.close()
     assert kept_local == exp_stats["kept_triangles"]
     ctx.close()
+
+
+def test_boundary_api_edge_cases():
+    import mlsgpu_amd as m
+    ctx = m.Context(0)
+    sink = m.Mesher(ctx)
+    with pytest.raises(m.InvalidArgument):
+        sink.finalize_with(np.zeros(0, np.uint8))                  # no boundary() yet
+    keys, kr, rv, rt = sink.boundary()                             # an empty sink has an empty boundary
+    assert len(keys) == len(rv) == 0
+    assert sink.finalize_with(np.zeros(0, np.uint8)) == 0
+    a = CASES["weld"]["meshes"]
+    for mesh in a:
+        sink.add(0, mesh["vertices"], mesh["num_internal"], mesh["keys"], mesh["triangles"])
+    with pytest.raises(m.InvalidArgument):
+        sink.finalize_with(np.zeros(0, np.uint8))                  # the boundary is stale after add
+    keys, kr, rv, rt = sink.boundary()
+    assert len(np.unique(keys)) == len(keys) and np.all(keys[1:] > keys[:-1]) and kr.max() < len(rv)
+    assert rt.sum() == sum(len(mesh["triangles"]) for mesh in a)
+    with pytest.raises(m.LengthError):
+        sink.finalize_with(np.ones(len(rv) + 1, np.uint8))
+    assert sink.finalize_with(np.ones(len(rv), np.uint8)) == 1     # keep everything == finalize with threshold 0
+    kept = sink.chunk(0)
+    assert sink.finalize() == 1
+    same = sink.chunk(0)
+    np.testing.assert_array_equal(kept["vertices"].view(np.uint32), same["vertices"].view(np.uint32))
+    np.testing.assert_array_equal(kept["triangles"], same["triangles"])
+    sink.close()
+    ctx.close()
