@@ -170,6 +170,7 @@ def test_boundary_api_edge_cases():
     keys, kr, rv, rt = sink.boundary()                             # an empty sink has an empty boundary
     assert len(keys) == len(rv) == 0
     assert sink.finalize_with(np.zeros(0, np.uint8)) == 0
+    sink.reset()                                                   # a finalized sink takes no more meshes until it is reset
     a = CASES["weld"]["meshes"]
     for mesh in a:
         sink.add(0, mesh["vertices"], mesh["num_internal"], mesh["keys"], mesh["triangles"])
