@@ -384,6 +384,46 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    # The instrumented passes (per-kernel HIP-event timing on one worker, work counters, output digest) run BEFORE the
+    # warm-up and the timed region: they are needed anyway, and they leave the clocks, the caches and every arena in the
+    # state of a running job, so that a short timed region (the driver's K = 20) measures the same steady state as a
+    # long one.
+    # ---- per-kernel durations: passes on ONE worker with HIP events around every launch.  Kept out of the headline
+    # region because with several workers the streams overlap and an event pair then measures a kernel sharing the GPU,
+    # not the kernel; single-worker durations are what the roofline divides by (and what `rocprofv3 --kernel-trace
+    # --stats ... --workers 1` reports). ----
+    kernel_stats = {}
+    ksteps = max(1, min(args.steps, 10))
+    if not args.no_timing:
+        ctx.reset_stats()
+        ctx.set_timing(True)
+        for _ in range(ksteps):
+            work.copy_from(pristine)
+            for b in buckets:
+                workers[0].process(work, b.first, b.count, b.low, b.num_vertices, collector=m.binding.SizeCollector())
+        ctx.set_timing(False)
+        kernel_stats = dict(ctx.stats())
+
+    # ---- algorithmic work + output digest (one instrumented, untimed pass on worker 0) ----
+    counters = m.DeviceBuffer(ctx, array=np.zeros(3, np.uint64))
+    w0 = workers[0]
+    before = w0.marching_counters()
+    w0.set_mls_stats(counters)
+    work.copy_from(pristine)
+    corners = entries = 0
+    check = m.binding.ChecksumCollector(ctx)
+    for b in buckets:
+        w0.process(work, b.first, b.count, b.low, b.num_vertices, collector=check)
+        entries += w0.tree_num_entries()
+        corners += int(np.prod([-(-n // 8) * 8 for n in b.num_vertices]))
+    ctx.synchronize()
+    listed, tests, hits = (int(x) for x in counters.download(np.uint64))
+    w0.set_mls_stats(None)
+    after = w0.marching_counters()
+    mc = {k: after[k] - before[k] for k in after}
+    digest = check.digest()
+
+
     for _ in range(args.warmup):
         step()
     barrier()
@@ -408,44 +448,10 @@ def main():
         per_rank = t.cpu().numpy()
         total_splats = int(per_rank[:, 3].sum())
 
-    # ---- per-kernel durations: passes on ONE worker with HIP events around every launch.  Kept out of the headline
-    # region because with several workers the streams overlap and an event pair then measures a kernel sharing the GPU,
-    # not the kernel; single-worker durations are what the roofline divides by (and what `rocprofv3 --kernel-trace
-    # --stats ... --workers 1` reports). ----
-    kernel_stats = {}
-    ksteps = max(1, min(args.steps, 10))
-    if not args.no_timing:
-        ctx.reset_stats()
-        ctx.set_timing(True)
-        for _ in range(ksteps):
-            work.copy_from(pristine)
-            for b in buckets:
-                workers[0].process(work, b.first, b.count, b.low, b.num_vertices, collector=m.binding.SizeCollector())
-        ctx.set_timing(False)
-        kernel_stats = dict(ctx.stats())
     triangles = sum(c.triangles for c in collectors) // max(args.steps, 1)
     vertices = sum(c.vertices for c in collectors) // max(args.steps, 1)
     external = sum(c.external for c in collectors) // max(args.steps, 1)
     shipouts = sum(c.batches for c in collectors) // max(args.steps, 1)
-
-    # ---- algorithmic work + output digest (one instrumented, untimed pass on worker 0) ----
-    counters = m.DeviceBuffer(ctx, array=np.zeros(3, np.uint64))
-    w0 = workers[0]
-    before = w0.marching_counters()
-    w0.set_mls_stats(counters)
-    work.copy_from(pristine)
-    corners = entries = 0
-    check = m.binding.ChecksumCollector(ctx)
-    for b in buckets:
-        w0.process(work, b.first, b.count, b.low, b.num_vertices, collector=check)
-        entries += w0.tree_num_entries()
-        corners += int(np.prod([-(-n // 8) * 8 for n in b.num_vertices]))
-    ctx.synchronize()
-    listed, tests, hits = (int(x) for x in counters.download(np.uint64))
-    w0.set_mls_stats(None)
-    after = w0.marching_counters()
-    mc = {k: after[k] - before[k] for k in after}
-    digest = check.digest()
     if check.vertices != vertices or check.triangles != triangles:
         raise SystemExit("the timed passes produced %d vertices / %d triangles per step, the checked pass %d / %d"
                          % (vertices, triangles, check.vertices, check.triangles))
@@ -551,7 +557,7 @@ def main():
         stages.sort(key=lambda s: -s["ms_per_step"])
         single_ms = sum(v[0] for k, v in kernel_stats.items() if k == "device.compute") / K
         pc = "kernel.mls.processCorners.time"
-        measured = ("hipEvent pairs on the worker's stream, %d single-worker passes after the timed region (%.1f ms per pass)"
+        measured = ("hipEvent pairs on the worker's stream, %d single-worker passes before the timed region (%.1f ms per pass)"
                     % (K, single_ms))
         if stages and stages[0]["stat"] == pc:
             # Dominant kernel = processCorners: fp32 VALU + LDS work (>= 140 flop/B); no MFMA is issued (no dense
