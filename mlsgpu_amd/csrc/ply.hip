@@ -448,8 +448,8 @@ MLSGPU_API int mlsgpu_hip_fileset_read(mlsgpu_fileset *f, uint64_t first, uint64
 /*
  * Files -> device memory with bounded host memory: what the reference's ReaderThread + circular buffer + async I/O do
  * for its out-of-core splat sets (src/splat_set.h:560-700, src/async_io.h:95-140), for clouds that fit in HBM (one
- * billion splats are 32 GB of 288).  `readerThreads` host threads (0 = 4) decode consecutive chunks of bufferSize / 4
- * bytes, each into its own quarter of ONE pinned buffer of bufferSize bytes; the calling thread sends every finished
+ * billion splats are 32 GB of 288).  `readerThreads` host threads (0 = 4, at most 64) decode consecutive chunks of
+ * bufferSize / max(4, readerThreads) bytes, each into its own slot of ONE pinned buffer of bufferSize bytes; the calling thread sends every finished
  * chunk to dOut on ctx's stream, and a quarter is reused once its copy has completed -- file reads, decoding and PCIe
  * overlap, and the host never holds more than bufferSize bytes of the cloud however many files of whatever size.
  */
@@ -461,16 +461,19 @@ MLSGPU_API int mlsgpu_hip_fileset_load(mlsgpu_fileset *f, mlsgpu_ctx *ctx, uint6
     if (count == 0)
         return MLSGPU_OK;
     HIP_CHECK(hipSetDevice(ctx->device));
-    enum { SLOTS = 4 };
+    /* one slot per reader thread, at least four (the reference pipelines reads through a fixed fraction of its buffer,
+     * src/splat_set.h:455-462); a host with many cores decodes with as many threads as the caller asks for */
+    const uint32_t wanted = std::min<uint32_t>(readerThreads == 0 ? 4u : readerThreads, 64u);
+    const uint64_t SLOTS = std::max<uint32_t>(4u, wanted);
     const uint64_t chunk = std::max<uint64_t>(1, f->bufferSize / SLOTS / sizeof(mlsgpu_splat));
     const uint64_t jobs = (count + chunk - 1) / chunk;
-    const uint32_t threads = (uint32_t) std::min<uint64_t>(std::min<uint32_t>(readerThreads == 0 ? 4u : readerThreads, SLOTS), jobs);
+    const uint32_t threads = (uint32_t) std::min<uint64_t>(wanted, jobs);
     mlsgpu_splat *pinned = nullptr;
     if (hipHostMalloc((void **) &pinned, SLOTS * chunk * sizeof(mlsgpu_splat)) != hipSuccess)
         return setError(MLSGPU_ERR_NOMEM, "fileset load: cannot pin %llu bytes", (unsigned long long) (SLOTS * chunk * sizeof(mlsgpu_splat)));
-    hipEvent_t copied[SLOTS] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> copied(SLOTS, nullptr);
     int rc = MLSGPU_OK;
-    for (int s = 0; s < SLOTS && rc == MLSGPU_OK; s++)
+    for (uint64_t s = 0; s < SLOTS && rc == MLSGPU_OK; s++)
         if (hipEventCreateWithFlags(&copied[s], hipEventDisableTiming) != hipSuccess)
             rc = setError(MLSGPU_ERR_HIP, "fileset load: cannot create an event");
 
@@ -555,7 +558,7 @@ MLSGPU_API int mlsgpu_hip_fileset_load(mlsgpu_fileset *f, mlsgpu_ctx *ctx, uint6
         failed = MLSGPU_ERR_HIP;
         failText = "fileset load: synchronise failed";
     }
-    for (int s = 0; s < SLOTS; s++)
+    for (uint64_t s = 0; s < SLOTS; s++)
         if (copied[s]) hipEventDestroy(copied[s]);
     hipHostFree(pinned);
     if (failed != MLSGPU_OK)
