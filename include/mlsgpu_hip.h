@@ -285,6 +285,9 @@ int mlsgpu_hip_farm_finish(mlsgpu_farm *farm);
 /* out[0] buckets, [1] splats copied, [2] H2D bytes, [3] device items, [4] ship-outs, [5] vertices, [6] triangles,
  * [7] external vertices; per device d: out[8 + d] = buckets processed there (up to 16 devices). */
 int mlsgpu_hip_farm_stats(mlsgpu_farm *farm, uint64_t out[24]);
+/* The most device items (DeviceWorkerGroup::WorkItem, src/workers.h:165-181) that were in flight at once since the farm
+ * was created: taken from a group's pool by the copy side and not yet returned by a device worker. */
+int mlsgpu_hip_farm_in_flight_max(mlsgpu_farm *farm, uint64_t *out);
 
 /* HostKeyMesh, src/mesh.h:125-179: a ship-out in host memory -- keys of the EXTERNAL vertices only (they are the last
  * numVertices - numInternalVertices vertices), packed float xyz, uint32 index triplets. */

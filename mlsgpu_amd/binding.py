@@ -193,6 +193,7 @@ def lib():
     sig("mlsgpu_hip_farm_submit_device", C.c_int, vp, C.c_int, vp, vp, u64, P(GridStruct), vp, vp, u64)
     sig("mlsgpu_hip_farm_finish", C.c_int, vp)
     sig("mlsgpu_hip_farm_stats", C.c_int, vp, vp)
+    sig("mlsgpu_hip_farm_in_flight_max", C.c_int, vp, vp)
     sig("mlsgpu_hip_farm_set_host_output", C.c_int, vp, u64, vp, vp)
     sig("mlsgpu_hip_farm_host_stats", C.c_int, vp, vp)
     sig("mlsgpu_hip_host_mesher_create", C.c_int, P(vp))
@@ -1195,6 +1196,9 @@ class BucketFarm:
         names = ["buckets", "splats", "h2d_bytes", "items", "shipouts", "vertices", "triangles", "external"]
         d = dict(zip(names, [int(x) for x in out[:8]]))
         d["per_device"] = [int(x) for x in out[8:24]]
+        hi = C.c_uint64(0)
+        check(lib().mlsgpu_hip_farm_in_flight_max(self.h, C.byref(hi)))
+        d["in_flight_max"] = int(hi.value)
         return d
 
     def close(self):

@@ -47,6 +47,18 @@ int setError(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)
             return rc__;                \
     } while (0)
 
+/* Restores the calling thread's current device on every exit path.  Entry points that switch devices (peer appends, the
+ * farm's dispatch to another GPU's copy stream) are called from worker threads in the middle of their own device's work;
+ * anything device-implicit they do afterwards (event creation, hipMalloc) must still target their own GPU. */
+struct DeviceGuard
+{
+    int saved = -1;
+    DeviceGuard() { if (hipGetDevice(&saved) != hipSuccess) saved = -1; }
+    ~DeviceGuard() { if (saved >= 0) (void) hipSetDevice(saved); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
 /* ---------------------------------------------------------------- context */
 
 struct Stat

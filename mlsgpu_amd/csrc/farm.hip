@@ -55,7 +55,18 @@ struct DeviceGroup               /* DeviceWorkerGroup, src/workers.h:214-350 */
     uint64_t bucketsDone = 0;
     std::vector<std::thread> threads;
     std::vector<hipEvent_t> eventPool;   /* read-back events of this device (guarded by the farm's mutex) */
-    mlsgpu_splat *peerScratch = nullptr; /* a bucket gathered here before it is peer-copied to another GPU's item */
+    /* Buckets of a cloud resident HERE on their way to another GPU's item: gathered into one buffer of a small ring,
+     * then peer-copied on the target's copy stream.  `loaded` (this device) orders the copy behind the gather, `busy` (the
+     * target item's copy event) orders the ring slot's next gather behind the copy -- both waits happen on the GPUs, so
+     * several leaves are in flight at once; the host only waits for its own gather (the id list is the caller's). */
+    struct PeerSlot
+    {
+        mlsgpu_splat *ptr = nullptr;
+        hipEvent_t loaded = nullptr;
+        hipEvent_t busy = nullptr;
+    };
+    std::vector<PeerSlot> peerRing;
+    size_t peerCur = 0;
 };
 
 /* One ship-out on its way to the host: OutputGeneratorBuilder::Functor's MesherGroup::WorkItem, src/workers.h:488-509 */
@@ -84,6 +95,7 @@ struct Farm
     int error = MLSGPU_OK;
     std::string errorText;
     uint64_t inFlightItems = 0;
+    uint64_t inFlightMax = 0;            /* high-water mark of inFlightItems */
 
     /* staging (CopyGroupBase::Worker: pinned + bufferedItems + bufferedSplats).  A ring of numDevices + 1 (at least
      * two) portable pinned buffers: while one is being filled, one copy per GPU can be in flight, each on its own
@@ -207,7 +219,10 @@ int hostReadBack(OutputThunk *t, const mlsgpu_mesh *mesh)
     }
     int rc = MLSGPU_OK;
     hipStream_t stream = static_cast<hipStream_t>(mlsgpu_hip_ctx_stream(t->ctx));
-    if (s->done == nullptr && hipEventCreateWithFlags(&s->done, hipEventDisableTiming) != hipSuccess)
+    /* the event must belong to the worker's device whatever an output functor before this one left current */
+    if (hipSetDevice(t->group->device) != hipSuccess)
+        rc = setError(MLSGPU_ERR_HIP, "farm: cannot select device %d", t->group->device);
+    if (rc == MLSGPU_OK && s->done == nullptr && hipEventCreateWithFlags(&s->done, hipEventDisableTiming) != hipSuccess)
         rc = setError(MLSGPU_ERR_HIP, "farm: cannot create a read-back event");
     char *blob = f->ring + s->offset;
     const uint64_t ne = mesh->numVertices - mesh->numInternalVertices;
@@ -416,6 +431,7 @@ int flushBatch(Farm *f)
 {
     if (f->bufferedItems.empty())
         return MLSGPU_OK;
+    DeviceGuard restore;
     DeviceGroup *out = nullptr;
     WorkItem *item = nullptr;
     {
@@ -433,6 +449,7 @@ int flushBatch(Farm *f)
         out->pool.pop_front();
         out->unallocated -= f->bufferedSplats;
         f->inFlightItems++;
+        f->inFlightMax = std::max(f->inFlightMax, f->inFlightItems);
     }
     const uint64_t splats = f->bufferedSplats;
     item->subItems.swap(f->bufferedItems);
@@ -582,7 +599,11 @@ MLSGPU_API void mlsgpu_hip_farm_destroy(mlsgpu_farm *f)
         }
         for (hipEvent_t e : g->eventPool)
             hipEventDestroy(e);
-        hipFree(g->peerScratch);
+        for (auto &ps : g->peerRing)
+        {
+            hipFree(ps.ptr);
+            if (ps.loaded) hipEventDestroy(ps.loaded);
+        }
         if (g->copyCtx) mlsgpu_hip_ctx_destroy(g->copyCtx);
         if (g->copyStream) hipStreamDestroy(g->copyStream);
     }
@@ -698,6 +719,7 @@ MLSGPU_API int mlsgpu_hip_farm_submit_device(mlsgpu_farm *f, int device, const m
         out->pool.pop_front();
         out->unallocated -= numSplats;
         f->inFlightItems++;
+        f->inFlightMax = std::max(f->inFlightMax, f->inFlightItems);
     }
     SubItem sub;
     sub.chunkId = chunkId;
@@ -711,40 +733,72 @@ MLSGPU_API int mlsgpu_hip_farm_submit_device(mlsgpu_farm *f, int device, const m
     item->subItems.assign(1, sub);
     item->numSplats = numSplats;
     static const bool forcePeer = getenv("MLSGPU_HIP_FARM_FORCE_PEER") != nullptr;   /* tests: the peer route on one GPU */
+    DeviceGuard restore;
     int rc = MLSGPU_OK;
     if (out->device == device && !forcePeer)
     {
         rc = mlsgpu_hip_bucket_load(out->copyCtx, dSplats, dIds, numSplats, fullGrid, item->dSplats);
         if (rc == MLSGPU_OK && hipEventRecord(item->copyEvent, out->copyStream) != hipSuccess)
             rc = setError(MLSGPU_ERR_HIP, "farm: cannot record the load event");
-        /* the id list belongs to the caller (the bucketer reuses it after its callback returns) */
-        if (rc == MLSGPU_OK && hipStreamSynchronize(out->copyStream) != hipSuccess)
+        /* the id list belongs to the caller (the bucketer reuses it after its callback returns): wait for the gather,
+         * the only work on this copy stream */
+        if (rc == MLSGPU_OK && hipEventSynchronize(item->copyEvent) != hipSuccess)
             rc = setError(MLSGPU_ERR_HIP, "farm: the device-side load failed");
     }
     else
     {
         /* gather + transform where the cloud lives, then device-to-device over the fabric */
-        if (src->peerScratch == nullptr
-            && (hipSetDevice(device) != hipSuccess
-                || hipMalloc((void **) &src->peerScratch, f->cfg.worker.maxBucketSplats * sizeof(mlsgpu_splat)) != hipSuccess))
-            rc = setError(MLSGPU_ERR_NOMEM, "farm: cannot allocate the peer scratch on device %d", device);
-        if (rc == MLSGPU_OK)
-            rc = mlsgpu_hip_bucket_load(src->copyCtx, dSplats, dIds, numSplats, fullGrid, src->peerScratch);
-        if (rc == MLSGPU_OK && hipStreamSynchronize(src->copyStream) != hipSuccess)
-            rc = setError(MLSGPU_ERR_HIP, "farm: the device-side load failed");
-        hipError_t e = hipSuccess;
-        if (rc == MLSGPU_OK)
+        hipError_t e = hipSetDevice(device);
+        if (e == hipSuccess && src->peerRing.empty())
+        {
+            src->peerRing.resize(std::max<size_t>(2, f->groups.size()));
+            for (auto &ps : src->peerRing)
+                if (e == hipSuccess)
+                {
+                    e = hipMalloc((void **) &ps.ptr, f->cfg.worker.maxBucketSplats * sizeof(mlsgpu_splat));
+                    if (e == hipSuccess)
+                        e = hipEventCreateWithFlags(&ps.loaded, hipEventDisableTiming);
+                }
+            if (e != hipSuccess)
+                rc = setError(MLSGPU_ERR_NOMEM, "farm: cannot allocate the peer scratch ring on device %d", device);
+        }
+        DeviceGroup::PeerSlot *ps = nullptr;
+        if (rc == MLSGPU_OK && e == hipSuccess)
+        {
+            ps = &src->peerRing[src->peerCur];
+            src->peerCur = (src->peerCur + 1) % src->peerRing.size();
+            /* the slot's previous bucket must have left it: ordered on the GPU, not on the host */
+            if (ps->busy != nullptr)
+                e = hipStreamWaitEvent(src->copyStream, ps->busy, 0);
+            ps->busy = nullptr;
+        }
+        if (rc == MLSGPU_OK && e == hipSuccess)
+            rc = mlsgpu_hip_bucket_load(src->copyCtx, dSplats, dIds, numSplats, fullGrid, ps->ptr);
+        if (rc == MLSGPU_OK && e == hipSuccess)
+            e = hipEventRecord(ps->loaded, src->copyStream);
+        if (rc == MLSGPU_OK && e == hipSuccess)
             e = hipSetDevice(out->device);
+        if (rc == MLSGPU_OK && e == hipSuccess)
+            e = hipStreamWaitEvent(out->copyStream, ps->loaded, 0);
         if (rc == MLSGPU_OK && e == hipSuccess && numSplats > 0)
-            e = hipMemcpyPeerAsync(item->dSplats, out->device, src->peerScratch, device, numSplats * sizeof(mlsgpu_splat),
+            e = hipMemcpyPeerAsync(item->dSplats, out->device, ps->ptr, device, numSplats * sizeof(mlsgpu_splat),
                                    out->copyStream);
         if (rc == MLSGPU_OK && e == hipSuccess)
             e = hipEventRecord(item->copyEvent, out->copyStream);
-        /* the scratch is reused by the next bucket */
         if (rc == MLSGPU_OK && e == hipSuccess)
-            e = hipStreamSynchronize(out->copyStream);
+        {
+            ps->busy = item->copyEvent;
+            /* the caller's id list is free again once the gather has run; the peer copy goes on without the host */
+            e = hipEventSynchronize(ps->loaded);
+        }
         if (rc == MLSGPU_OK && e != hipSuccess)
-            rc = setError(MLSGPU_ERR_HIP, "farm: peer copy %d -> %d failed: %s", device, out->device, hipGetErrorString(e));
+        {
+            rc = setError(MLSGPU_ERR_HIP, "farm: peer route %d -> %d failed: %s", device, out->device, hipGetErrorString(e));
+            hipStreamSynchronize(src->copyStream);
+            hipStreamSynchronize(out->copyStream);
+            if (ps != nullptr)
+                ps->busy = nullptr;
+        }
     }
     if (rc != MLSGPU_OK)
         return abandonItem(f, out, item, numSplats, rc);
@@ -788,6 +842,15 @@ MLSGPU_API int mlsgpu_hip_farm_host_stats(mlsgpu_farm *f, uint64_t out[4])
     std::lock_guard<std::mutex> l(f->mutex);
     for (int i = 0; i < 4; i++)
         out[i] = f->hostStats[i];
+    return MLSGPU_OK;
+}
+
+/* most device items that were in flight (taken from a pool, not yet handed back by a worker) at the same time */
+MLSGPU_API int mlsgpu_hip_farm_in_flight_max(mlsgpu_farm *f, uint64_t *out)
+{
+    REQUIRE(f != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> l(f->mutex);
+    *out = f->inFlightMax;
     return MLSGPU_OK;
 }
 

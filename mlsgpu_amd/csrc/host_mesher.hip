@@ -120,6 +120,29 @@ MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkI
     for (uint64_t t = 0; t < 3 * nt; t++)       /* before anything is appended: a bad mesh leaves the sink unchanged */
         REQUIRE(mesh->triangles[t] < nv, MLSGPU_ERR_INVALID);
     std::lock_guard<std::mutex> lock(m->mutex);
+    /* computeLocalComponents, src/mesher.cpp:220-236: union by size, negative value = -(size) at a root.  It only reads
+     * the incoming mesh, so it runs -- with the "too many connected components" check (:252) -- before anything is appended:
+     * a mesh that cannot be taken leaves the sink unchanged. */
+    std::vector<int32_t> &uf = m->uf;
+    uf.assign(nv, -1);
+    for (uint64_t t = 0; t < nt; t++)
+    {
+        const uint32_t *tri = mesh->triangles + 3 * t;
+        for (int e = 0; e < 2; e++)
+        {
+            int32_t a = ufRoot(uf, (int32_t) tri[e]), c = ufRoot(uf, (int32_t) tri[e + 1]);
+            if (a == c)
+                continue;
+            if (uf[a] > uf[c])          /* a is the smaller tree */
+                std::swap(a, c);
+            uf[a] += uf[c];
+            uf[c] = a;
+        }
+    }
+    uint64_t roots = 0;
+    for (uint64_t i = 0; i < nv; i++)
+        roots += uf[i] < 0;
+    REQUIRE(m->clumps.size() + roots < 0x7FFFFFFFu, MLSGPU_ERR_LENGTH);
     m->finalized = false;
     Block b;
     auto it = m->chunkIndex.find(chunkId);
@@ -141,30 +164,12 @@ MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkI
     m->triangles.insert(m->triangles.end(), mesh->triangles, mesh->triangles + 3 * nt);
     m->extKeys.insert(m->extKeys.end(), mesh->vertexKeys, mesh->vertexKeys + ne);
 
-    /* computeLocalComponents, src/mesher.cpp:220-236: union by size, negative value = -(size) at a root */
-    std::vector<int32_t> &uf = m->uf;
-    uf.assign(nv, -1);
-    for (uint64_t t = 0; t < nt; t++)
-    {
-        const uint32_t *tri = mesh->triangles + 3 * t;
-        for (int e = 0; e < 2; e++)
-        {
-            int32_t a = ufRoot(uf, (int32_t) tri[e]), c = ufRoot(uf, (int32_t) tri[e + 1]);
-            if (a == c)
-                continue;
-            if (uf[a] > uf[c])          /* a is the smaller tree */
-                std::swap(a, c);
-            uf[a] += uf[c];
-            uf[c] = a;
-        }
-    }
     /* updateGlobalClumps, :238-281 */
     const uint64_t cBase = m->clumpOf.size();
     m->clumpOf.resize(cBase + nv);
     for (uint64_t i = 0; i < nv; i++)
         if (uf[i] < 0)
         {
-            REQUIRE(m->clumps.size() < 0x7FFFFFFFu, MLSGPU_ERR_LENGTH);     /* "too many connected components" */
             m->clumpOf[cBase + i] = (uint32_t) m->clumps.size();
             Clump c;
             c.vertices = (uint64_t) -(int64_t) uf[i];

@@ -594,14 +594,14 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
     const int home = m->ctx->device;
     static const bool forcePeer = getenv("MLSGPU_HIP_MESHER_FORCE_PEER") != nullptr;    /* tests: the peer route on one GPU */
     const bool peer = from->device != home || forcePeer;
+    DeviceGuard restore;        /* the caller is a worker in the middle of ITS device's work (Marching's output functor) */
     HIP_CHECK(hipSetDevice(home));
     PROPAGATE(m->ensureAddStream());
     /* OOCMesher::add indexes chunks[chunkId.gen] (src/mesher.cpp:380-384): any arrival order; dense index = first arrival */
     uint32_t chunk = 0;
     while (chunk < m->chunkIds.size() && m->chunkIds[chunk] != chunkId)
         chunk++;
-    if (chunk == m->chunkIds.size())
-        m->chunkIds.push_back(chunkId);
+    const bool newChunk = chunk == m->chunkIds.size();     /* recorded with the block, once everything has succeeded */
     const uint64_t nv = mesh->numVertices, nt = mesh->numTriangles, ne = nv - mesh->numInternalVertices;
     REQUIRE(m->vertices.used / 3 + nv < (uint64_t(1) << 32), MLSGPU_ERR_LENGTH);
     /* the arenas may move: every earlier append has completed (each add synchronises before it returns) */
@@ -652,6 +652,8 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
     m->extKeys.used += ne;
     m->extGid.used += ne;
     m->extChunk.used += ne;
+    if (newChunk)
+        m->chunkIds.push_back(chunkId);
     m->blocks.push_back(r);
     m->analyzed = false;
     return MLSGPU_OK;

@@ -247,6 +247,61 @@ print("ok")
 
 
 @pytest.mark.gpu
+def test_submit_device_keeps_many_leaves_in_flight_and_sink_plus_host_output():
+    """Round 3 (ADVICE): (1) eight device groups fed from ONE resident cloud through the peer route --
+    every leaf gathered into a slot of the scratch ring and peer-copied on its target's copy stream, ordered by events on
+    the GPUs, so the copy side runs ahead of the workers: at least as many device items in flight as there are groups;
+    (2) a device sink AND host output on the same farm with the peer routes forced: after the peer append the worker's
+    read-back event must still be created on the worker's device (mlsgpu_hip_mesher_add restores it).  Both welds equal
+    the oracle's."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import os, sys
+sys.path[:0] = [%r, %r, %r]
+import numpy as np
+import mesher_oracle as mo
+import mlsgpu_amd as m
+from mlsgpu_amd import synth
+from test_farm_gpu import _oracle_meshes
+cloud = synth.shells_cloud(120_000, 95.0, 16.0, 1.5, 2.5, seed=321)
+allb, buckets = synth.bucketize(cloud, 96, 32)
+cap = max(b.count for b in buckets)
+exp, exp_stats = mo.mesh_sink(_oracle_meshes(allb, buckets), 0.02)
+ctx = m.Context(0)
+raw = m.DeviceBuffer(ctx, array=allb)
+ids = [m.DeviceBuffer(ctx, array=np.arange(b.first, b.first + b.count, dtype=np.uint32)) for b in buckets]
+ext = (0, 95, 0, 95, 0, 95)
+sink = m.Mesher(ctx, 0.02)
+welder = m.HostMesher(0.02)
+farm = m.BucketFarm([0] * 8, cap, workers_per_device=1, max_cells=63, sink=sink)
+farm.set_host_output(16 << 20, welder)
+for i, b in enumerate(buckets):
+    farm.submit_device(0, raw, ids[i].ptr, b.count, (0.0, 0.0, 0.0), 1.0, ext, b.low, b.num_vertices, 0)
+farm.finish()
+st = farm.stats()
+assert st["in_flight_max"] >= 8, st
+assert sum(1 for x in st["per_device"][:8] if x > 0) >= 4, st
+for w in (sink, welder):
+    assert w.finalize() == 1
+    stats = w.stats()
+    for k in ("total_vertices", "threshold", "components", "kept_components", "kept_vertices", "kept_triangles"):
+        assert stats[k] == exp_stats[k], (k, stats[k], exp_stats[k])
+got = sink.chunk(0)
+assert mo.isomorphic(got["vertices"], got["triangles"], exp[0][1], exp[0][2])
+hv = welder.chunk(0)
+assert mo.isomorphic(hv[1], hv[2], exp[0][1], exp[0][2])
+farm.close()
+print("ok")
+""" % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+       os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    env = dict(os.environ, MLSGPU_HIP_FARM_FORCE_PEER="1", MLSGPU_HIP_MESHER_FORCE_PEER="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stdout + out.stderr
+
+
+@pytest.mark.gpu
 def test_farm_on_two_real_devices():
     """the farm with its device groups on DIFFERENT GPUs (staging events belong to the item's device; a
     bucket resident on GPU 0 reaches GPU 1's group by a peer copy; ship-outs of both GPUs are welded by the host welder and,
@@ -268,11 +323,14 @@ def test_farm_on_two_real_devices():
     exp, exp_stats = mo.mesh_sink(_oracle_meshes(allb, buckets), 0.02)
     ctx = m.Context(0)
     raw = m.DeviceBuffer(ctx, array=allb)
-    for route in ("host", "device"):
+    for route in ("host", "device", "both"):
         welder = m.HostMesher(0.02) if route == "host" else m.Mesher(ctx, 0.02)
         farm = m.BucketFarm([0, 1], cap, workers_per_device=2, max_cells=63, sink=None if route == "host" else welder)
         if route == "host":
             farm.set_host_output(16 << 20, welder)
+        if route == "both":
+            # after a peer append into GPU 0's sink, GPU 1's worker creates its read-back event on GPU 1
+            farm.set_host_output(16 << 20, None)
         for i, b in enumerate(buckets):
             if i % 2 == 0:
                 farm.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, 0)
