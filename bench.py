@@ -51,6 +51,10 @@ try:
     CFG3_UNIFORM_DIGEST = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg3_uniform.json")))["digest"]
 except Exception:   # noqa: BLE001 - the fixture is optional for the benchmark
     CFG3_UNIFORM_DIGEST = None
+try:    # rank 0's slab of the N > 1 workload (tests/test_gpu_configs.py::test_cfg4_slab_full_density)
+    CFG4SLAB_DIGEST = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg4slab_uniform.json")))["digest"]
+except Exception:   # noqa: BLE001
+    CFG4SLAB_DIGEST = None
 
 
 def parse_args():
@@ -58,8 +62,11 @@ def parse_args():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=200, help="timed passes (default: about 5 s of timed region at N = 1)")
     p.add_argument("--warmup", type=int, default=5)
-    p.add_argument("--workload", default="auto", choices=["auto", "cfg2", "cfg3", "cfg4slab"],
-                   help="auto: cfg3 at N = 1, the cfg4 slab family at N > 1; cfg4slab runs one slab of cfg4 at N = 1")
+    p.add_argument("--workload", default="auto", choices=["auto", "cfg2", "cfg3", "cfg4slab", "cfg5"],
+                   help="auto: cfg3 at N = 1, the cfg4 slab family at N > 1; cfg4slab runs one slab of cfg4 at N = 1; cfg5: "
+                        "BASELINE configs[4], 2048^3 grid, 10^9 splats read from PLY files (written to --cfg5-dir first)")
+    p.add_argument("--cfg5-dir", default="/dev/shm", help="where cfg5's PLY files are written (28 GB at scale 1)")
+    p.add_argument("--cfg5-files", type=int, default=8)
     p.add_argument("--dist", default="uniform", choices=["uniform", "shells"])
     p.add_argument("--scale", type=float, default=1.0, help="splat-count scale (debug only; 1.0 = BASELINE size)")
     p.add_argument("--mesh-memory-mb", type=int, default=4096, help="Marching mesh arena per worker")
@@ -142,6 +149,162 @@ def build_workload(args, rank, world, device):
     del zc
     return dict(bucketed=bucketed, buckets=buckets, n_splats=mine, text=text, cloud=None, grid=dims, name="cfg4slab",
                 all_buckets=len(boxes))
+
+
+# ---------------------------------------------------------------------------------------------------- cfg5
+
+CFG5_PARTITION = dict(max_splats=2097152, max_cells=255, chunk_cells=0, micro_cells=63, max_split=1 << 30)   # reference defaults
+
+
+def cfg5_paths(directory, nfiles, n, dist):
+    return [os.path.join(directory, "mlsgpu_cfg5_%s_%d_%dof%d.ply" % (dist, n, k, nfiles)) for k in range(nfiles)]
+
+
+def run_cfg5(args, rank, world, local_rank, device, dist, reduce_device):
+    """BASELINE configs[4]: 2048^3 grid, 10^9 splats in PLY files -> FileSet reader threads -> HBM -> Bucket::bucket on the
+    device -> the farm's device workers (leaves by device-side gathers).  The cloud (32 GB) and its partition live in HBM;
+    the meshes are counted and checksummed on the device (the noise cloud's mesh is tens of G triangles).
+    N > 1: every rank loads the files (page cache) and takes the leaves l with l % N == rank -- the bucket fan-out."""
+    import shutil
+
+    import torch
+
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as mb, farm, synth
+    g = synth.CONFIGS["cfg5"]["grid"]
+    n = max(int(synth.CONFIGS["cfg5"]["splats"] * args.scale), 1)
+    paths = cfg5_paths(args.cfg5_dir, args.cfg5_files, n, args.dist)
+    need = n * 28 + 4096 * len(paths)
+    wrote_s = 0.0
+    if rank == 0 and not all(os.path.exists(p) and os.path.getsize(p) > 0 for p in paths):
+        free = shutil.disk_usage(args.cfg5_dir).free
+        if free < need * 1.05:
+            raise SystemExit("cfg5: %s has %.1f GB free, the files need %.1f GB (use --cfg5-dir or --scale)"
+                             % (args.cfg5_dir, free / 1e9, need / 1e9))
+        t0 = time.time()
+        synth.write_cloud_ply(paths, "cfg5", device, scale=args.scale, dist=args.dist)
+        wrote_s = time.time() - t0
+    if dist is not None:
+        dist.barrier()
+    ctx = m.Context(local_rank)
+    nworkers = max(1, args.workers)
+    fs = mb.FileSet(paths, buffer_size=512 << 20)
+    assert len(fs) == n
+    raw = m.DeviceBuffer(ctx, nbytes=n * 32)
+    ext = (0, g - 1, 0, g - 1, 0, g - 1)
+    ref0 = (0.0, 0.0, 0.0)
+
+    def load():
+        fs.load(ctx, raw, reader_threads=32)
+        ctx.synchronize()
+    t0 = time.perf_counter()
+    load()                                            # also the warm-up of the page cache
+    first_load_s = time.perf_counter() - t0
+    # sizes of the partition (untimed): worker capacity, voxels
+    leaves = mb.bucket_cloud(ctx, raw, n, ref0, 1.0, ext, on_bucket=lambda leaf, ids: None, **CFG5_PARTITION)
+    mine = [i for i in range(len(leaves)) if i % world == rank]
+    voxels = sum(farm.leaf_cells(leaves[i]) for i in mine)
+    pmax = max(l["num_splats"] for l in leaves)
+    pcells = max(max(l["extents"][2 * a + 1] - l["extents"][2 * a] for a in range(3)) for l in leaves)
+    bfarm = m.BucketFarm([local_rank], pmax, workers_per_device=nworkers, spare=1, max_cells=pcells,
+                         mesh_memory=args.mesh_memory_mb << 20, collect="checksum")
+
+    def resident_pass():
+        farm.partition_to_farm(ctx, bfarm, local_rank, raw, n, ref0, 1.0, ext, CFG5_PARTITION,
+                               keep=(lambda i: i % world == rank) if world > 1 else None)
+        bfarm.finish()
+    resident_pass()                                   # warm-up + the checked pass
+    if bfarm.error is not None:
+        raise bfarm.error
+    digest = bfarm.digest()
+    st0 = bfarm.stats()
+    bfarm.checksums = False                           # the timed passes only count (the farm's own counters)
+    for _ in range(max(0, args.warmup - 1)):
+        resident_pass()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        resident_pass()
+    ctx.synchronize()
+    torch.cuda.synchronize()
+    own_elapsed = time.perf_counter() - t0
+    if dist is not None:
+        dist.barrier()
+    elapsed, total_voxels, _ = farm.combine(own_elapsed, voxels * args.steps, dist, reduce_device)
+    st1 = bfarm.stats()
+    per_pass = {k: (st1[k] - st0[k]) // max(args.steps + max(0, args.warmup - 1), 1) for k in ("shipouts", "vertices", "triangles", "external", "buckets")}
+    if per_pass["vertices"] != st0["vertices"] or per_pass["triangles"] != st0["triangles"]:
+        raise SystemExit("cfg5: the timed passes produced %d vertices / %d triangles per pass, the checked pass %d / %d"
+                         % (per_pass["vertices"], per_pass["triangles"], st0["vertices"], st0["triangles"]))
+    # from the files: load + partition + pipeline, L passes (never `value`)
+    L = max(1, args.leg_steps)
+    bucket_s = 0.0
+    t0 = time.perf_counter()
+    for _ in range(L):
+        mb.bucket_cloud(ctx, raw, n, ref0, 1.0, ext, on_bucket=lambda leaf, ids: None, **CFG5_PARTITION)
+    ctx.synchronize()
+    bucket_s = (time.perf_counter() - t0) / L
+    load_s = 0.0
+    t0 = time.perf_counter()
+    for _ in range(L):
+        t1 = time.perf_counter()
+        load()
+        load_s += time.perf_counter() - t1
+        resident_pass()
+    files_s = (time.perf_counter() - t0) / L
+    load_s /= L
+    t0 = time.perf_counter()
+    bg = mb.bounding_grid(ctx, raw, n, 1.0, 63)
+    ctx.synchronize()
+    bound_s = time.perf_counter() - t0
+    ms_per_step = elapsed / args.steps * 1e3
+    golden = None
+    try:
+        golden = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg5_%s.json" % args.dist))).get(str(n))
+    except Exception:   # noqa: BLE001 - the fixture is optional for the benchmark
+        golden = None
+    result = {
+        "metric": "Mvoxels/s evaluated+triangulated", "value": round(total_voxels / elapsed / 1e6, 3), "unit": "Mvoxels/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "msplats_per_s": round(n * args.steps / elapsed / 1e6, 3), "timed_region_s": round(elapsed, 3),
+        "config": {
+            "workload": "cfg5: %d^3 grid, %d splats (%s) in %d PLY files, loaded into HBM (32 B per splat), partitioned on the "
+                        "device with the reference's defaults (255 cells, 2 097 152 splats per bucket, 63-cell microblocks): %d "
+                        "buckets of <= %d cells per side, <= %d splats; octree+MLS+MC on every bucket, meshes counted and "
+                        "checksummed in HBM" % (g, n, args.dist, len(paths), len(leaves), pcells, pmax),
+            "voxels_per_step": int(total_voxels // args.steps), "buckets": len(leaves), "buckets_this_rank": len(mine),
+            "bucket_splats_total": int(sum(l["num_splats"] for l in leaves)), "device_workers": nworkers,
+            "mesh_memory_mb": args.mesh_memory_mb, "timed_region": "cloud resident in HBM -> Bucket::bucket -> device gathers -> "
+            "device workers (the partition is recomputed in every step)",
+            "triangles_per_step": st0["triangles"], "vertices_per_step": st0["vertices"], "shipouts_per_step": st0["shipouts"],
+            "sharding": "leaf l of the partition goes to rank l mod N; every rank holds the cloud" if world > 1 else "single GPU",
+            "files_written_s": round(wrote_s, 1), "file_bytes": int(sum(os.path.getsize(p) for p in paths)),
+        },
+        "output_digest": {"rank0_digest": digest, "what": "sha256/16 over (bucket number, sizes and vertex / triangle / external-key "
+                          "checksums of its ship-outs) in bucket order, computed on the device"},
+        "from_files": {
+            "ms_per_pass": round(files_s * 1e3, 1), "msplats_per_s": round(n / files_s / 1e6, 1),
+            "mvoxels_per_s": round(voxels / files_s / 1e6, 1),
+            "loader_ms": round(load_s * 1e3, 1), "loader_GBps_of_splats": round(n * 32 / load_s / 1e9, 2),
+            "loader_GBps_of_file": round(n * 28 / load_s / 1e9, 2), "first_load_ms": round(first_load_s * 1e3, 1),
+            "bucketing_ms": round(bucket_s * 1e3, 2), "bucketing_msplats_per_s": round(n / bucket_s / 1e6, 1),
+            "bounding_grid_ms": round(bound_s * 1e3, 2), "bounding_grid_extents": [int(x) for x in bg[2]],
+            "passes": L,
+            "note": "PLY files in %s (page cache) -> 32 reader threads decoding into a 512 MiB pinned buffer -> H2D -> the timed "
+                    "region's pipeline; never `value`" % args.cfg5_dir},
+    }
+    if golden is not None and world == 1:
+        result["output_digest"]["expected"] = golden["digest"]
+        result["output_digest"]["ok"] = digest == golden["digest"]
+        if digest != golden["digest"]:
+            raise SystemExit("cfg5 digest %s differs from the pinned %s" % (digest, golden["digest"]))
+    if rank == 0:
+        print(json.dumps(result))
+    bfarm.close()
+    fs.close()
 
 
 # ---------------------------------------------------------------------------------------------------- legs
@@ -296,6 +459,139 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     return out
 
 
+def multi_gpu_legs(m, args, result, dist, reduce_device, rank, world, local_rank, ndev, ctx, bucketed_t, buckets, max_count,
+                   max_cells, voxels, L, nworkers):
+    """N > 1 only, never `value`.
+    transfer_inclusive: SURVEY 8(d)'s region on every rank at once, with the weld in it -- host splats -> the rank's farm
+        (pinned staging, H2D) -> device workers -> ship-outs appended to the rank's device sink -> dist_sink.global_prune
+        (boundary export, ONE all-gather, merged verdict, output pass) -> the rank's welded, pruned mesh read back.
+    single_process: the reference's own shape (src/mlsgpu_core.cpp:704-741): ONE process, one copy side, a device group
+        per GPU, fed from one place -- rank 0 drives all N GPUs while the other ranks wait; N x rank 0's slab, from host
+        memory (one copy thread + staging, what the manual names as the limiter) and from a cloud resident on GPU 0 (peer
+        copies over xGMI)."""
+    import torch
+
+    from mlsgpu_amd import dist_sink
+    host = bucketed_t.cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
+    views = [host[b.first:b.first + b.count] for b in buckets]
+
+    def wall(fn, steps):
+        """max over ranks of the time of `steps` calls, bracketed by barriers"""
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        out = None
+        for _ in range(steps):
+            out = fn()
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0
+        dist.barrier()
+        t = torch.tensor([own], dtype=torch.float64, device=reduce_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / steps, out
+
+    # ---- transfer-inclusive, every rank, with the cross-rank weld ----
+    sink = m.Mesher(ctx, 0.02)
+    bfarm = m.BucketFarm([local_rank], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
+                         mesh_memory=args.mesh_memory_mb << 20, sink=sink)
+    pinned = m.binding.PinnedBuffer(1)
+    parts = {}
+
+    def sink_pass():
+        t0 = time.perf_counter()
+        for b, v in zip(buckets, views):
+            bfarm.submit(v, b.low, b.num_vertices, rank)
+        bfarm.finish()
+        t1 = time.perf_counter()
+        nchunks, stats = dist_sink.global_prune(sink, 0.02, dist)
+        t2 = time.perf_counter()
+        nbytes = 0
+        for i in range(nchunks):
+            nbytes += m.binding.download_into_pinned(ctx, sink.chunk(i, download=False), pinned)
+        ctx.synchronize()
+        t3 = time.perf_counter()
+        sink.reset()
+        parts.update(pass_ms=(t1 - t0) * 1e3, weld_ms=(t2 - t1) * 1e3, readback_ms=(t3 - t2) * 1e3, nbytes=nbytes, stats=stats)
+        return nbytes
+    sink_pass()                                       # warm-up: arenas, pinned landing buffer
+    dt, nbytes = wall(sink_pass, L)
+    tot = torch.tensor([float(nbytes), float(host.nbytes)], dtype=torch.float64, device=reduce_device)
+    dist.all_reduce(tot)
+    st = parts["stats"]
+    result["transfer_inclusive"] = {
+        "device_sink_global_weld": {
+            "value": round(voxels * world / dt / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(dt * 1e3, 3),
+            "h2d_GB_per_step": round(float(tot[1].item()) / 1e9, 3), "d2h_GB_per_step": round(float(tot[0].item()) / 1e9, 3),
+            "rank0_ms": {k: round(parts[k], 2) for k in ("pass_ms", "weld_ms", "readback_ms")},
+            "whole_job": {k: int(st[k]) for k in ("total_vertices", "components", "kept_components", "kept_vertices", "kept_triangles")},
+            "note": "every rank at once: host splats -> pinned staging -> H2D -> %d device workers -> ship-outs appended in HBM -> "
+                    "per-rank weld + boundary export -> ONE all-gather -> merged components and prune threshold (0.02 of the "
+                    "whole job) -> output pass -> the rank's mesh read back into pinned memory; time = slowest rank" % nworkers},
+        "distribution": "uniform"}
+    bfarm.close()
+    sink.close()
+    pinned.free()
+
+    # ---- the reference's shape: one process, N device groups; rank 0 drives, the others wait ----
+    devices = [d % ndev for d in range(world)]
+    single = None
+    dist.barrier()
+    if rank == 0:
+        sfarm = m.BucketFarm(devices, max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
+                             mesh_memory=args.mesh_memory_mb << 20)
+
+        def host_fed():
+            for rep in range(world):
+                for i, (b, v) in enumerate(zip(buckets, views)):
+                    sfarm.submit(v, b.low, b.num_vertices, rep)
+            sfarm.finish()
+        host_fed()
+        s0 = sfarm.stats()
+        t0 = time.perf_counter()
+        for _ in range(L):
+            host_fed()
+        host_s = (time.perf_counter() - t0) / L
+        s1 = sfarm.stats()
+        # the same buckets resident on GPU 0, handed out by device gathers (another GPU's group: scratch ring + peer copy)
+        raw = m.DeviceBuffer(ctx, nbytes=bucketed_t.numel() * 4, borrow=bucketed_t.data_ptr())
+        iota = m.DeviceBuffer(ctx, array=np.arange(max_count, dtype=np.uint32))
+        gx, gy, gz = result["_grid"]
+        ext = (0, gx - 1, 0, gy - 1, 0, gz - 1)
+
+        class _Sub:
+            def __init__(self, ptr):
+                self.ptr = ptr
+
+        def device_fed():
+            for rep in range(world):
+                for b in buckets:
+                    sfarm.submit_device(local_rank, _Sub(raw.ptr + 32 * b.first), iota.ptr, b.count, (0.0, 0.0, 0.0), 1.0, ext,
+                                        b.low, b.num_vertices, rep)
+            sfarm.finish()
+        device_fed()
+        t0 = time.perf_counter()
+        for _ in range(L):
+            device_fed()
+        dev_s = (time.perf_counter() - t0) / L
+        s2 = sfarm.stats()
+        single = {
+            "devices": devices, "buckets_per_pass": world * len(buckets),
+            "host_fed": {"value": round(voxels * world / host_s / 1e6, 3), "unit": "Mvoxels/s", "ms_per_pass": round(host_s * 1e3, 2),
+                         "h2d_GBps": round((s1["h2d_bytes"] - s0["h2d_bytes"]) / L / host_s / 1e9, 2)},
+            "device_fed": {"value": round(voxels * world / dev_s / 1e6, 3), "unit": "Mvoxels/s", "ms_per_pass": round(dev_s * 1e3, 2)},
+            "buckets_per_device_last_pass": [int(x) for x in (np.array(s2["per_device"][:world]) - np.array(s1["per_device"][:world]))] ,
+            "in_flight_max": s2["in_flight_max"],
+            "note": "ONE process (rank 0) with one device group per GPU, %d workers each, the other ranks idle: N x rank 0's slab "
+                    "from pageable host memory through ONE copy side (4 copy threads -> pinned staging -> H2D to the chosen "
+                    "group), and from a cloud resident on GPU 0 (device gather, peer copy to other GPUs' items); meshes counted "
+                    "only" % nworkers}
+        sfarm.close()
+        del raw, iota
+    dist.barrier()
+    if single is not None:
+        result["single_process"] = single
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -330,6 +626,12 @@ def main():
 
     import mlsgpu_amd as m
     from mlsgpu_amd import farm
+
+    if args.workload == "cfg5":
+        run_cfg5(args, rank, world, local_rank, device, dist, reduce_device)
+        if dist is not None:
+            dist.destroy_process_group()
+        return
 
     # ---- workload (generated in HBM, untimed) ----
     t0 = time.time()
@@ -427,6 +729,19 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # N > 1: ONE rank's slab alone on its GPU while the other ranks are parked at the barrier -- the per-GPU rate the
+    # N-rank value is held against (same cloud, same density, same process, measured in this run)
+    ref_steps = max(3, min(args.steps, 10))
+    ref_elapsed = None
+    if dist is not None:
+        if rank == 0:
+            t0 = time.perf_counter()
+            for _ in range(ref_steps):
+                step()
+            for c in ctxs:
+                c.synchronize()
+            ref_elapsed = time.perf_counter() - t0
+        barrier()
     collectors[:] = [m.binding.SizeCollector() for _ in range(nworkers)]
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -493,12 +808,19 @@ def main():
             "what": "sha256/16 over (sizes, vertex / triangle / external-key checksums) of every ship-out of one pass of rank "
                     "0's buckets, computed on the device (mlsgpu_hip_mesh_checksum)"},
     }
+    result["_grid"] = W["grid"]
     if W["name"] == "cfg3" and args.dist == "uniform" and args.scale == 1.0 and CFG3_UNIFORM_DIGEST is not None:
         result["output_digest"]["expected"] = CFG3_UNIFORM_DIGEST
         result["output_digest"]["ok"] = digest == CFG3_UNIFORM_DIGEST
         if digest != CFG3_UNIFORM_DIGEST:
             raise SystemExit("output digest %s differs from the pinned %s: the timed pipeline did not produce the meshes "
                              "the parity tests check" % (digest, CFG3_UNIFORM_DIGEST))
+    if W["name"] == "cfg4slab" and args.scale == 1.0 and CFG4SLAB_DIGEST is not None:
+        result["output_digest"]["expected"] = CFG4SLAB_DIGEST
+        result["output_digest"]["ok"] = digest == CFG4SLAB_DIGEST
+        if digest != CFG4SLAB_DIGEST:
+            raise SystemExit("output digest %s of rank 0's slab differs from the pinned %s (tests/golden/cfg4slab_uniform.json)"
+                             % (digest, CFG4SLAB_DIGEST))
     if world > ndev:
         result["debug_shared_gpu"] = "%d ranks on %d GPU(s) (MLSGPU_BENCH_BACKEND=gloo): a check of the N > 1 code path, NOT an N-GPU measurement" % (world, ndev)
     if per_rank is not None:
@@ -509,9 +831,16 @@ def main():
             "note": "every rank is one GPU working on its own slab; value = sum of voxels / slowest rank's time",
             "reading_the_scaling_curve": "the N = 1 point of the driver's curve is cfg3 (0.37 splats per voxel); the N > 1 "
                                          "points are slabs of cfg4 (0.19 splats per voxel, the density BASELINE names), a lighter "
-                                         "cloud per voxel: ONE slab on ONE GPU runs at 8299 Mvoxels/s "
-                                         "(profiles/r02_bench_cfg4slab_n1.json, `python bench.py --workload cfg4slab`), which is the "
-                                         "per-GPU rate to hold the N > 1 values against"}
+                                         "cloud per voxel: hold the N > 1 values against per_gpu_reference (rank 0's slab alone on "
+                                         "its GPU, measured in this run), not against the N = 1 point"}
+        ref = torch.zeros(1, dtype=torch.float64, device=reduce_device)
+        if rank == 0:
+            ref[0] = voxels * ref_steps / ref_elapsed / 1e6
+        dist.all_reduce(ref)
+        result["per_gpu_reference"] = {
+            "value": round(float(ref.item()), 3), "unit": "Mvoxels/s", "steps": ref_steps,
+            "what": "rank 0's slab (25 buckets) alone on GPU 0, the other ranks parked at a barrier; same process, same cloud"}
+        result["scaling_efficiency"] = round(value / (world * float(ref.item())), 4)
 
     # ---- roofline: algorithmic bytes over HIP-event kernel time, per stage ----
     if kernel_stats and not args.no_timing:
@@ -626,6 +955,10 @@ def main():
 
     secondary = world == 1 and not args.headline_only
     L = max(1, args.leg_steps)
+
+    if world > 1 and not args.headline_only:
+        multi_gpu_legs(m, args, result, dist, reduce_device, rank, world, local_rank, ndev, ctxs[0], bucketed_t, buckets,
+                       max_count, max_cells, voxels, L, nworkers)
 
     # ---- mesh-sink leg (never `value`): every ship-out of one pass appended to the device mesher (d2d), then
     # finalize = weld by key across buckets + connected components + prune (--fit-prune default 0.02) + compaction ----
@@ -792,6 +1125,7 @@ def main():
             result["cpu_baseline"] = cb
             result["gpu_over_cpu"] = round(value / cb["value"], 1)
 
+    result.pop("_grid", None)
     if rank == 0:
         print(json.dumps(result))
     pool.shutdown()

@@ -1121,7 +1121,30 @@ class BucketFarm:
             except Exception as e:   # never let an exception cross the C boundary
                 self.error = e
                 return 1
-        self._cb = FARM_OUTPUT_FN(cb) if collect else C.cast(None, FARM_OUTPUT_FN)
+        self.checksums = True     # collect="checksum": set False to stop recording (the callback then only returns)
+        self.sums = {}            # chunkId -> [(vertices, triangles, internal, 3 checksums)] (collect="checksum")
+        self.shipouts = {}        # chunkId -> ship-outs seen
+
+        def cb_sum(user, device, chunk, ctxh, meshp):
+            # sizes + device-side checksums of every ship-out, per chunk (nothing is copied to the host): with one chunk id
+            # per bucket the digest below does not depend on which worker ran which bucket
+            try:
+                if not self.checksums:      # timed passes: the farm's own counters suffice
+                    return 0
+                mm = meshp.contents
+                out = np.zeros(3, np.uint64)
+                check(lib().mlsgpu_hip_mesh_checksum(ctxh, meshp, _p(out)))
+                rec = (int(mm.numVertices), int(mm.numTriangles), int(mm.numInternalVertices)) + tuple(int(x) for x in out)
+                with self._lock:
+                    self.sums.setdefault(int(chunk), []).append(rec)
+                return 0
+            except Exception as e:   # never let an exception cross the C boundary
+                self.error = e
+                return 1
+        if collect == "checksum":
+            self._cb = FARM_OUTPUT_FN(cb_sum)
+        else:
+            self._cb = FARM_OUTPUT_FN(cb) if collect else C.cast(None, FARM_OUTPUT_FN)
         user = None
         if sink is not None:
             # a device Mesher: the workers append their ship-outs to it, in C (mlsgpu_hip_mesher_farm_output)
@@ -1189,6 +1212,16 @@ class BucketFarm:
         if self.error is not None:
             raise self.error
         check(rc)
+
+    def digest(self):
+        """sha256/16 over (chunk id, ship-out records) in chunk order (collect="checksum")."""
+        import hashlib
+        h = hashlib.sha256()
+        for chunk in sorted(self.sums):
+            h.update(np.array([chunk, len(self.sums[chunk])], np.uint64).tobytes())
+            for rec in self.sums[chunk]:
+                h.update(np.array(rec, np.uint64).tobytes())
+        return h.hexdigest()[:16]
 
     def stats(self):
         out = np.zeros(24, np.uint64)

@@ -59,6 +59,23 @@ struct DeviceGuard
     DeviceGuard &operator=(const DeviceGuard &) = delete;
 };
 
+/* Direct copies between two GPUs (xGMI) need peer access enabled in both directions; harmless when it already is, and
+ * when the devices cannot reach each other the runtime stages the copy through the host. */
+static inline void enablePeerAccess(int a, int b)
+{
+    if (a == b)
+        return;
+    DeviceGuard restore;
+    for (int k = 0; k < 2; k++)
+    {
+        const int from = k ? b : a, to = k ? a : b;
+        int can = 0;
+        if (hipSetDevice(from) == hipSuccess && hipDeviceCanAccessPeer(&can, from, to) == hipSuccess && can)
+            (void) hipDeviceEnablePeerAccess(to, 0);
+        (void) hipGetLastError();       /* "already enabled" is not an error */
+    }
+}
+
 /* ---------------------------------------------------------------- context */
 
 struct Stat

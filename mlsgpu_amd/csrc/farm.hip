@@ -549,6 +549,10 @@ MLSGPU_API int mlsgpu_hip_farm_create(const mlsgpu_farm_config *cfg, mlsgpu_farm
         mlsgpu_hip_farm_destroy(f);
         return rc;
     }
+    for (auto &a : f->groups)
+        for (auto &b : f->groups)
+            if (a->device < b->device)
+                enablePeerAccess(a->device, b->device);
     f->liveWorkers = (uint32_t) f->groups.size() * f->cfg.workersPerDevice;
     for (auto &g : f->groups)
         for (uint32_t w = 0; w < f->cfg.workersPerDevice; w++)

@@ -480,6 +480,7 @@ struct mlsgpu_mesher
     std::vector<MeshRecord> blocks;
     std::vector<uint64_t> chunkIds;             /* dense index -> caller's id, arrival order */
     bool finalized = false;
+    bool peerEnabled[16] = {};                  /* peer access towards the GPUs whose workers have appended */
     /* results */
     float *outVertices = nullptr;
     uint32_t *outTriangles = nullptr;
@@ -595,6 +596,11 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
     static const bool forcePeer = getenv("MLSGPU_HIP_MESHER_FORCE_PEER") != nullptr;    /* tests: the peer route on one GPU */
     const bool peer = from->device != home || forcePeer;
     DeviceGuard restore;        /* the caller is a worker in the middle of ITS device's work (Marching's output functor) */
+    if (from->device != home && !m->peerEnabled[from->device & 15])
+    {
+        enablePeerAccess(home, from->device);
+        m->peerEnabled[from->device & 15] = true;
+    }
     HIP_CHECK(hipSetDevice(home));
     PROPAGATE(m->ensureAddStream());
     /* OOCMesher::add indexes chunks[chunkId.gen] (src/mesher.cpp:380-384): any arrival order; dense index = first arrival */

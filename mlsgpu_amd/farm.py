@@ -34,3 +34,35 @@ def combine(elapsed_s, units, dist=None, device=None):
 def throughput(units, elapsed_s):
     """Mega-units per second."""
     return units / elapsed_s / 1e6
+
+
+def leaf_geometry(leaf, ext):
+    """(low extent relative to the grid, corners per axis) of a Bucket::bucket leaf."""
+    low = [leaf["extents"][2 * a] - ext[2 * a] for a in range(3)]
+    nv = [leaf["extents"][2 * a + 1] - leaf["extents"][2 * a] + 1 for a in range(3)]
+    return low, nv
+
+
+def partition_to_farm(ctx, bucket_farm, device, raw, num_splats, reference, spacing, ext, params, chunk_of=None,
+                      keep=None):
+    """A cloud resident on `device` -> Bucket::bucket on the device (mlsgpu_hip_bucket) -> every leaf handed to the
+    farm's device path while its id list is valid (gather + transform kernel into a device item, peer copy for another
+    GPU's group), as CopyGroup + BucketLoader do with host buckets (src/workers.cpp:377-418).  chunk_of(leaf number) ->
+    chunk id (default: the leaf number, one chunk per bucket); keep(leaf number) -> False skips a leaf (another rank's).
+    Returns the list of leaves (all of them, skipped ones included).  The caller calls bucket_farm.finish()."""
+    from . import binding as mb
+    count = [0]
+    def leaf_work(leaf, d_ids):
+        i = count[0]
+        count[0] += 1
+        if keep is not None and not keep(i):
+            return
+        low, nv = leaf_geometry(leaf, ext)
+        bucket_farm.submit_device(device, raw, d_ids, leaf["num_splats"], reference, spacing, ext, low, nv,
+                                  i if chunk_of is None else chunk_of(i))
+    return mb.bucket_cloud(ctx, raw, num_splats, reference, spacing, ext, on_bucket=leaf_work, **params)
+
+
+def leaf_cells(leaf):
+    e = leaf["extents"]
+    return (e[1] - e[0]) * (e[3] - e[2]) * (e[5] - e[4])

@@ -94,6 +94,7 @@ CONFIGS = {
     "cfg2": dict(grid=256, splats=5_000_000),
     "cfg3": dict(grid=512, splats=50_000_000),
     "cfg4": dict(grid=1024, splats=200_000_000),
+    "cfg5": dict(grid=2048, splats=1_000_000_000),   # configs[4]: read from PLY files (write_cloud_ply)
 }
 
 
@@ -194,6 +195,60 @@ def make_cloud_device(cfg, device, scale=1.0, seed_offset=0, dist="uniform"):
     if dist == "shells":
         return shells_cloud_device(n, float(g - 1), 16.0, 1.0, 2.0, cloud_seed(cfg, seed_offset), device), g
     return uniform_cloud_device(n, float(g - 1), 2.0, 3.0, cloud_seed(cfg, seed_offset), device), g
+
+
+PLY_ROW = np.dtype([("p", "<f4", 3), ("n", "<f4", 3), ("r", "<f4")])     # x y z nx ny nz radius, doc/mlsgpu-user-manual.xml:178-197
+
+
+def ply_header(count):
+    return ("ply\nformat binary_little_endian 1.0\nelement vertex %d\n" % count
+            + "".join("property float32 %s\n" % n for n in ("x", "y", "z", "nx", "ny", "nz", "radius")) + "end_header\n").encode("ascii")
+
+
+def write_cloud_ply(paths, cfg, device, scale=1.0, dist="uniform", chunk=16_000_000):
+    """Writes the cloud of a BASELINE config as len(paths) binary PLY files (equal, consecutive id ranges), generating it on
+    `device` chunk by chunk -- the 10^9 splats of cfg5 never exist in one piece outside the files (28 GB).  One writer
+    thread per file (file writes and device-to-host copies release the GIL).  Returns the number of splats written."""
+    import threading
+
+    import torch
+    c = CONFIGS[cfg]
+    g = c["grid"]
+    n = max(int(c["splats"] * scale), 1)
+    seed = cloud_seed(cfg)
+    base, extra = divmod(n, len(paths))
+    ranges, lo = [], 0
+    for k in range(len(paths)):
+        cnt = base + (1 if k < extra else 0)
+        ranges.append((lo, cnt))
+        lo += cnt
+    gen_lock = threading.Lock()        # one chunk on the device at a time: generation is not the slow part
+    errors = []
+
+    def write_one(path, first, count):
+        try:
+            with open(path, "wb") as f:
+                f.write(ply_header(count))
+                for lo in range(0, count, chunk):
+                    m = min(chunk, count - lo)
+                    with gen_lock:
+                        if dist == "shells":
+                            t = shells_cloud_device(m, float(g - 1), 16.0, 1.0, 2.0, seed, device, first=first + lo)
+                        else:
+                            t = uniform_cloud_device(m, float(g - 1), 2.0, 3.0, seed, device, first=first + lo)
+                        rows = t[:, [0, 1, 2, 4, 5, 6, 3]].contiguous().cpu()
+                        del t
+                    f.write(rows.numpy().tobytes())
+        except Exception as e:      # noqa: BLE001 - reported by the caller's thread
+            errors.append(e)
+    threads = [threading.Thread(target=write_one, args=(p, r[0], r[1])) for p, r in zip(paths, ranges)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        raise errors[0]
+    return n
 
 
 def grid_buckets(dims, max_cells=255, runs=None):

@@ -108,6 +108,15 @@ def test_bench_two_ranks_one_sharded_cloud():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["per_rank"]["buckets"] == [25, 25]
     assert d["config"]["voxels_per_step"] == 1023 * 1023 * 255
     assert "cfg4" in d["config"]["workload"] and d["value"] > 0
+    # round 3: what limits N GPUs is in the line -- the per-GPU reference measured in the same run, the transfer-inclusive
+    # region with the cross-rank weld, and the reference's one-process shape (host-fed and device-fed)
+    assert d["per_gpu_reference"]["value"] > 0 and 0 < d["scaling_efficiency"] < 2
+    ti = d["transfer_inclusive"]["device_sink_global_weld"]
+    assert ti["value"] > 0 and ti["d2h_GB_per_step"] > 0 and ti["whole_job"]["kept_components"] >= 1
+    sp = d["single_process"]
+    assert sp["devices"] == [0, 0] and sp["buckets_per_pass"] == 50
+    assert sp["host_fed"]["value"] > 0 and sp["device_fed"]["value"] > 0 and sp["in_flight_max"] >= 2
+    assert sum(sp["buckets_per_device_last_pass"]) == 50 and min(sp["buckets_per_device_last_pass"]) > 0
     # without a launcher bench.py starts the ranks itself; with a launcher of the wrong size it refuses
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "1",
                           "--warmup", "0", "--no-timing"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)

@@ -4,6 +4,12 @@ cfg3  512^3 grid, 50 M uniform splats, 27 buckets: the cloud bench.py times.  Or
       face, centre), size-independent properties on all 27 (bucket tiling, cross-bucket agreement of shared vertices bit
       for bit, key multiplicity), and the totals + digest that bench.py prints for its timed passes, pinned in
       tests/golden/cfg3_uniform.json.
+cfg4s rank 0's slab of the sharded cfg4 cloud at FULL density (what bench.py --gpus N runs on every GPU): totals + digest
+      pinned in tests/golden/cfg4slab_uniform.json, which bench.py compares at N > 1 as it does cfg3 at N = 1.
+cfg5  2048^3 grid, 10^9 splats (a smaller count only if the box lacks the RAM) written as 8 PLY files by the device
+      generator -> FileSet reader threads -> HBM -> Bucket::bucket on the device -> eight device groups by device-side
+      gathers: partition properties on all ~730 buckets, oracle bit-parity on three leaves, cross-bucket agreement on a
+      neighbourhood, totals + digest pinned in tests/golden/cfg5_uniform.json.
 cfg4  1024^3 grid cut 8 ways: the multi-device bucket farm with eight device groups (all on GPU 0 here: a one-GPU box
       stands in for eight GPUs; on an 8-GPU node pass MLSGPU_TEST_DEVICES=0,1,...,7), ship-outs read back through the
       pinned circular buffer into the host welder; splat count reduced, oracle parity on sampled buckets, and the Euler
@@ -208,3 +214,197 @@ def test_cfg4_shape_eight_device_groups():
     del w, buf
     ctx.close()
     welder.close()
+
+
+def test_cfg4_slab_full_density(ctx):
+    """The per-GPU unit of bench.py --gpus N: slab 0 (128 corner slices, 25 buckets) of BASELINE configs[3]'s 200 M-splat
+    uniform cloud, generated in HBM exactly as bench.py does.  Totals and digest are pinned; oracle bit-parity on the
+    corner bucket."""
+    import torch
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as mb, synth
+    dev = torch.device("cuda", 0)
+    cloud, g = synth.make_cloud_device("cfg4", dev)
+    assert len(cloud) == 200_000_000 and g == 1024
+    slab = 128
+    boxes = synth.grid_buckets((g, g, slab * 8), 255, runs=(0, 0, 8))
+    per = len(boxes) // 8
+    bucketed, buckets = synth.bucketize_device(cloud, boxes[:per])
+    del cloud
+    torch.cuda.synchronize()
+    assert len(buckets) == 25 and sum(b.cells for b in buckets) == 1023 * 1023 * (buckets[0].num_vertices[2] - 1)
+    max_cells = max(max(b.num_vertices) for b in buckets) - 1
+    max_count = max(b.count for b in buckets)
+    nbytes = bucketed.numel() * 4
+    pristine = m.DeviceBuffer(ctx, nbytes=nbytes, borrow=bucketed.data_ptr())
+    work = m.DeviceBuffer(ctx, nbytes=nbytes)
+    w = m.Worker(ctx, max_count, max_cells=max_cells, mesh_memory=4096 << 20)
+    work.copy_from(pristine)
+    col = mb.ChecksumCollector(ctx)
+    for b in buckets:
+        w.process(work, b.first, b.count, b.low, b.num_vertices, collector=col)
+    got = dict(splats=int(bucketed.shape[0]), triangles=int(col.triangles), vertices=int(col.vertices),
+               external=int(col.external), shipouts=col.batches, digest=col.digest())
+    path = os.path.join(os.path.dirname(GOLDEN), "cfg4slab_uniform.json")
+    if os.environ.get("MLSGPU_WRITE_GOLDEN"):
+        out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "cfg4slab_uniform.json")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        json.dump(got, open(out, "w"), indent=1)
+    else:
+        exp = json.load(open(path))
+        assert got == {k: exp[k] for k in got}, (got, exp)
+    b = buckets[0]
+    host = bucketed[b.first:b.first + b.count].cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
+    del w
+    mm = 1 << 30
+    w = m.Worker(ctx, max_count, max_cells=max_cells, mesh_memory=mm)
+    work.copy_from(pristine)
+    batches = w.process(work, b.first, b.count, b.low, b.num_vertices)
+    exp_b, st = ob.bucket(host, 0, b.count, b.num_vertices, b.low, max_cells=max_cells, max_swathe=max_cells + 1, mesh_memory=mm)
+    assert st["shipouts"] == len(batches) >= 1
+    assert_batches_equal(batches, exp_b)
+
+
+def cfg5_count():
+    """10^9 splats need 28 GB of files in /dev/shm and a few GB of host memory on top; an eighth of the cloud otherwise (same
+    grid, same route).  MLSGPU_CFG5_SPLATS overrides."""
+    import shutil
+    if os.environ.get("MLSGPU_CFG5_SPLATS"):
+        return int(os.environ["MLSGPU_CFG5_SPLATS"])
+    try:
+        avail = int(next(l for l in open("/proc/meminfo") if l.startswith("MemAvailable")).split()[1]) * 1024
+        free = shutil.disk_usage("/dev/shm").free
+    except Exception:   # noqa: BLE001
+        avail = free = 0
+    return 1_000_000_000 if (avail > (96 << 30) and free > (40 << 30)) else 125_000_000
+
+
+def test_cfg5_full_shape_from_files():
+    import shutil
+    import tempfile
+    import torch
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as mb, farm as fm, synth
+    n = cfg5_count()
+    g = synth.CONFIGS["cfg5"]["grid"]
+    assert g == 2048
+    dev = torch.device("cuda", 0)
+    tmp = tempfile.mkdtemp(prefix="mlsgpu_cfg5_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        paths = [os.path.join(tmp, "part%d.ply" % k) for k in range(8)]
+        assert synth.write_cloud_ply(paths, "cfg5", dev, scale=n / synth.CONFIGS["cfg5"]["splats"]) == n
+        assert sum(os.path.getsize(p) for p in paths) > 28 * n
+        ctx = m.Context(0)
+        fs = mb.FileSet(paths, buffer_size=512 << 20)
+        assert len(fs) == n
+        raw = m.DeviceBuffer(ctx, nbytes=n * 32)
+        fs.load(ctx, raw, reader_threads=32)
+        ctx.synchronize()
+        # what arrived in HBM is the generator's cloud: positions, radii and normals bit for bit, quality = 1 / r^2 as the
+        # reader computes it (src/fast_ply.cpp:334-350)
+        for first in (0, n // 2 - 500, n - 1000):
+            got = raw.download(m.SPLAT_DTYPE, 1000, offset=first * 32)
+            exp = synth.uniform_cloud(1000, float(g - 1), 2.0, 3.0, synth.cloud_seed("cfg5"), first=first)
+            for f in ("position", "radius", "normal"):
+                np.testing.assert_array_equal(got[f].view(np.uint32), exp[f].view(np.uint32))
+            np.testing.assert_allclose(got["quality"], 1.0 / (exp["radius"].astype(np.float64) ** 2), rtol=3e-7)
+        ext = (0, g - 1, 0, g - 1, 0, g - 1)
+        ref0 = (0.0, 0.0, 0.0)
+        bp = dict(max_splats=2097152, max_cells=255, chunk_cells=0, micro_cells=63, max_split=1 << 30)
+        devices = farm_devices(8)
+        # ---- the partition: every leaf within the caps, the leaves tile the grid ----
+        picked = {}
+
+        def note(leaf, d_ids):
+            picked[len(picked)] = None
+        leaves = mb.bucket_cloud(ctx, raw, n, ref0, 1.0, ext, on_bucket=note, **bp)
+        assert len(leaves) >= 512
+        cover = np.zeros((33, 33, 33), np.int32)          # 63-cell microblocks: 2047 = 32 * 63 + 31
+        for l in leaves:
+            e = l["extents"]
+            assert l["num_splats"] <= bp["max_splats"] and max(e[1] - e[0], e[3] - e[2], e[5] - e[4]) <= 255
+            assert all(e[2 * a] % 63 == 0 and (e[2 * a + 1] % 63 == 0 or e[2 * a + 1] == g - 1) for a in range(3))
+            cover[e[0] // 63:-(-e[1] // 63), e[2] // 63:-(-e[3] // 63), e[4] // 63:-(-e[5] // 63)] += 1
+        assert cover.min() == 1 and cover.max() == 1
+        assert sum(fm.leaf_cells(l) for l in leaves) == (g - 1) ** 3
+        pmax = max(l["num_splats"] for l in leaves)
+        pcells = max(max(l["extents"][2 * a + 1] - l["extents"][2 * a] for a in range(3)) for l in leaves)
+        # ---- files -> ... -> eight device groups: every bucket's ship-outs counted and checksummed on the device ----
+        bfarm = m.BucketFarm(devices, pmax, workers_per_device=1, spare=1, max_cells=pcells, mesh_memory=1 << 30,
+                             collect="checksum")
+        leaves2 = fm.partition_to_farm(ctx, bfarm, devices[0], raw, n, ref0, 1.0, ext, bp)
+        bfarm.finish()
+        assert bfarm.error is None
+        assert [l["extents"] for l in leaves2] == [l["extents"] for l in leaves]
+        st = bfarm.stats()
+        assert st["buckets"] == len(leaves) and sum(st["per_device"][:8]) == len(leaves)
+        assert min(st["per_device"][:8]) > 0 and st["in_flight_max"] >= 2
+        assert sum(len(v) for v in bfarm.sums.values()) == st["shipouts"]
+        assert sum(r[0] for v in bfarm.sums.values() for r in v) == st["vertices"]
+        assert sum(r[1] for v in bfarm.sums.values() for r in v) == st["triangles"]
+        got = dict(splats=n, buckets=len(leaves), bucket_splats=int(sum(l["num_splats"] for l in leaves)),
+                   triangles=st["triangles"], vertices=st["vertices"], external=st["external"], shipouts=st["shipouts"],
+                   digest=bfarm.digest())
+        per_leaf = {k: list(v) for k, v in bfarm.sums.items()}
+        bfarm.close()
+        path = os.path.join(os.path.dirname(GOLDEN), "cfg5_uniform.json")
+        if os.environ.get("MLSGPU_WRITE_GOLDEN"):
+            out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "cfg5_uniform_%d.json" % n)
+            os.makedirs(os.path.dirname(out), exist_ok=True)
+            json.dump(got, open(out, "w"), indent=1)
+        else:
+            exp = json.load(open(path))[str(n)]
+            assert got == {k: exp[k] for k in got}, (got, exp)
+        # ---- three leaves against the oracle, bit for bit (a corner leaf, an edge leaf, a face leaf: the thin ones, so that
+        # the CPU finishes in seconds), and their per-leaf records against what the farm saw ----
+        order = sorted(range(len(leaves)), key=lambda i: (fm.leaf_cells(leaves[i]), i))
+        sample = [order[0], order[len(order) // 16], order[len(order) // 4]]
+        # ... plus the neighbours of the middle leaf for the cross-bucket check
+        mid = min(range(len(leaves)), key=lambda i: sum(abs(leaves[i]["extents"][2 * a] - 1008) for a in range(3)))
+        em = leaves[mid]["extents"]
+        hood = [i for i, l in enumerate(leaves)
+                if all(l["extents"][2 * a] <= em[2 * a + 1] and l["extents"][2 * a + 1] >= em[2 * a] for a in range(3))][:8]
+        wanted = set(sample) | set(hood)
+        ids = {}
+        counter = [0]
+
+        def grab(leaf, d_ids):
+            i = counter[0]
+            counter[0] += 1
+            if i in wanted:
+                staged = m.DeviceBuffer(ctx, nbytes=max(leaf["num_splats"], 1) * 32)
+                mb.bucket_load(ctx, raw, d_ids, leaf["num_splats"], ref0, 1.0, ext, staged)
+                ctx.synchronize()
+                ids[i] = staged
+        mb.bucket_cloud(ctx, raw, n, ref0, 1.0, ext, on_bucket=grab, **bp)
+        mm = 1 << 30
+        w = m.Worker(ctx, pmax, max_cells=pcells, mesh_memory=mm)
+        for i in sample:
+            low, nv = fm.leaf_geometry(leaves[i], ext)
+            cnt = leaves[i]["num_splats"]
+            host = ids[i].download(m.SPLAT_DTYPE, cnt)
+            col = mb.ChecksumCollector(ctx)
+            w.process(ids[i], 0, cnt, low, nv, collector=col)
+            assert col.sums == per_leaf.get(i, []), i
+            ids[i].upload(host)
+            batches = w.process(ids[i], 0, cnt, low, nv)
+            exp_b, _ = ob.bucket(host.copy(), 0, cnt, nv, low, max_cells=pcells, max_swathe=pcells + 1, mesh_memory=mm)
+            assert_batches_equal(batches, exp_b)
+            del batches, exp_b
+        # ---- cross-bucket agreement: vertices that neighbouring buckets share (same key) are bit-identical ----
+        col = mb.ExternalCollector(ctx)
+        for i in hood:
+            low, nv = fm.leaf_geometry(leaves[i], ext)
+            w.process(ids[i], 0, leaves[i]["num_splats"], low, nv, collector=col)
+        keys = np.concatenate(col.ext_keys)
+        verts = np.concatenate(col.ext_vertices).view(np.uint32)
+        o = np.argsort(keys, kind="stable")
+        keys, verts = keys[o], verts[o]
+        same = keys[1:] == keys[:-1]
+        assert same.sum() > 1000 * (len(hood) - 1)
+        assert np.all(verts[1:][same] == verts[:-1][same])
+        del w, ids
+        fs.close()
+        ctx.close()
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
