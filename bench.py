@@ -569,6 +569,7 @@ def multi_gpu_legs(m, args, result, dist, reduce_device, rank, world, local_rank
                                         b.low, b.num_vertices, rep)
             sfarm.finish()
         device_fed()
+        s1b = sfarm.stats()
         t0 = time.perf_counter()
         for _ in range(L):
             device_fed()
@@ -579,7 +580,7 @@ def multi_gpu_legs(m, args, result, dist, reduce_device, rank, world, local_rank
             "host_fed": {"value": round(voxels * world / host_s / 1e6, 3), "unit": "Mvoxels/s", "ms_per_pass": round(host_s * 1e3, 2),
                          "h2d_GBps": round((s1["h2d_bytes"] - s0["h2d_bytes"]) / L / host_s / 1e9, 2)},
             "device_fed": {"value": round(voxels * world / dev_s / 1e6, 3), "unit": "Mvoxels/s", "ms_per_pass": round(dev_s * 1e3, 2)},
-            "buckets_per_device_last_pass": [int(x) for x in (np.array(s2["per_device"][:world]) - np.array(s1["per_device"][:world]))] ,
+            "buckets_per_device_last_pass": [int(x) // L for x in (np.array(s2["per_device"][:world]) - np.array(s1b["per_device"][:world]))],
             "in_flight_max": s2["in_flight_max"],
             "note": "ONE process (rank 0) with one device group per GPU, %d workers each, the other ranks idle: N x rank 0's slab "
                     "from pageable host memory through ONE copy side (4 copy threads -> pinned staging -> H2D to the chosen "

@@ -499,6 +499,14 @@ int Bucketer::recurse(const uint32_t *dIds, uint64_t n, bool isSubset, const Gri
                 if (regions.empty())
                     continue;
                 const uint32_t numRegions = (uint32_t) regions.size();
+                {
+                    /* a region's counter is the number of splats that join it: the level's (region, id) pairs are counted by
+                     * a 32-bit scan and addressed by 32-bit positions (10^9 uniform splats in 252-cell regions: 1.06 * 10^9) */
+                    uint64_t pairs = 0;
+                    for (const Region &r : regions)
+                        pairs += counts[L.offset[r.level] + (r.c[2] * L.dims[r.level][1] + r.c[1]) * L.dims[r.level][0] + r.c[0]];
+                    REQUIRE(pairs < 0xFFFFFFFFull, MLSGPU_ERR_LENGTH);
+                }
                 HIP_CHECK(hipMemcpyAsync(B.table, table.data(), (size_t) n0 * 4, hipMemcpyHostToDevice, ctx->stream));
                 if (B.regionCap < numRegions + 1)
                 {
@@ -579,7 +587,7 @@ MLSGPU_API int mlsgpu_hip_bucket(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, u
 {
     REQUIRE(ctx != nullptr && region != nullptr && params != nullptr && fn != nullptr, MLSGPU_ERR_INVALID);
     REQUIRE(numSplats == 0 || dSplats != nullptr, MLSGPU_ERR_INVALID);
-    REQUIRE(numSplats < (uint64_t(1) << 29), MLSGPU_ERR_LENGTH);     /* u32 ids; (region, id) pair counts stay below 2^32 */
+    REQUIRE(numSplats < 0xFFFFFFFFull, MLSGPU_ERR_LENGTH);           /* u32 ids; the (region, id) pair count is checked per level */
     REQUIRE(region->spacing > 0.0f && params->maxCells >= 1 && params->maxSplats >= 1 && params->maxSplit >= 8, MLSGPU_ERR_INVALID);
     for (int i = 0; i < 3; i++)
         REQUIRE(region->extents[2 * i] < region->extents[2 * i + 1], MLSGPU_ERR_INVALID);   /* at least one cell per axis */

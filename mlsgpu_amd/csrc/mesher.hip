@@ -464,6 +464,7 @@ uint64_t scratchBytes(uint64_t nv, uint64_t nt, uint64_t ne, uint64_t nb, uint64
     total += al(scanTiles(std::max(nv, nt)) * 4);                                   /* scans */
     total += 2 * al((nb + 1) * 8) + 2 * al((nb + 1) * 4) + 3 * al((nc + 1) * 8) + 8 * 256;
     total += 2 * al(scanTiles(nv) * 4) + al(scanTiles(ne) * 4) + al(nv);            /* boundary export / verdict */
+    total += 2 * al(nv * 4);                                                        /* ... vertices and triangles per component */
     return total + (1 << 20);
 }
 } // namespace
@@ -481,6 +482,12 @@ struct mlsgpu_mesher
     std::vector<uint64_t> chunkIds;             /* dense index -> caller's id, arrival order */
     bool finalized = false;
     bool peerEnabled[16] = {};                  /* peer access towards the GPUs whose workers have appended */
+    /* boundary() leaves the weld and the components in the slab (representatives, roots, sizes, the dense root numbering);
+     * a finalize_with() right behind it -- same arenas, nothing added -- starts from them instead of sorting and uniting
+     * again.  One use: the verdict overwrites the sizes. */
+    bool cacheValid = false;
+    uint64_t cacheDims[3] = {0, 0, 0};
+    uint32_t cacheRootCount = 0;
     /* results */
     float *outVertices = nullptr;
     uint32_t *outTriangles = nullptr;
@@ -662,6 +669,7 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
         m->chunkIds.push_back(chunkId);
     m->blocks.push_back(r);
     m->analyzed = false;
+    m->cacheValid = false;
     return MLSGPU_OK;
 }
 
@@ -684,6 +692,7 @@ MLSGPU_API int mlsgpu_hip_mesher_reset(mlsgpu_mesher *m)
     m->outChunks.clear();
     m->finalized = false;
     m->analyzed = false;
+    m->cacheValid = false;
     return MLSGPU_OK;
 }
 
@@ -775,6 +784,10 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
     PROPAGATE(m->regroupByChunk());
     const uint64_t nv = m->vertices.used / 3, nt = m->triangles.used / 3, ne = m->extKeys.used;
     const uint32_t nb = (uint32_t) m->blocks.size(), nc = (uint32_t) m->chunkIds.size();
+    /* the verdict pass right behind an export: weld, components and root numbering are still in the slab */
+    const bool reuse = keepRoots != nullptr && !analyzeOnly && m->cacheValid && m->cacheDims[0] == nv && m->cacheDims[1] == nt
+        && m->cacheDims[2] == ne;
+    m->cacheValid = false;
     m->chunkVStart.assign(nc + 1, 0);
     m->chunkTStart.assign(nc + 1, 0);
     m->outChunks.clear();
@@ -805,10 +818,13 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
     PROPAGATE(S.get(&size, nv));
     PROPAGATE(S.get(&vIndex, nv));
     const dim3 B(256);
-    LAUNCH(ctx, "mesher.weld.time", iotaKernel, dim3(divUp(nv, 256)), B, compRep, nv);
-    LAUNCH(ctx, "mesher.weld.time", iotaKernel, dim3(divUp(nv, 256)), B, outRep, nv);
-    LAUNCH(ctx, "mesher.weld.time", iotaKernel, dim3(divUp(nv, 256)), B, parent, nv);
-    HIP_CHECK(hipMemsetAsync(size, 0, nv * 4, ctx->stream));
+    if (!reuse)
+    {
+        LAUNCH(ctx, "mesher.weld.time", iotaKernel, dim3(divUp(nv, 256)), B, compRep, nv);
+        LAUNCH(ctx, "mesher.weld.time", iotaKernel, dim3(divUp(nv, 256)), B, outRep, nv);
+        LAUNCH(ctx, "mesher.weld.time", iotaKernel, dim3(divUp(nv, 256)), B, parent, nv);
+        HIP_CHECK(hipMemsetAsync(size, 0, nv * 4, ctx->stream));
+    }
 
     /* 1. weld */
     SortResult<uint64_t> sorted = {nullptr, nullptr};
@@ -823,21 +839,27 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
         PROPAGATE(S.get(&slotsB, ne));
         PROPAGATE(S.get(&hist, sortHistElems(ne)));
         PROPAGATE(S.get(&tileSums, scanTiles(std::max<uint64_t>(sortHistElems(ne), ne))));
-        HIP_CHECK(hipMemcpyAsync(keysA, m->extKeys.ptr, ne * 8, hipMemcpyDeviceToDevice, ctx->stream));
-        PROPAGATE(radixSort<uint64_t>(ctx, "mesher.weld.time", keysA, slotsA, keysB, slotsB, ne, 64, true, hist, tileSums, &sorted));
-        LAUNCH(ctx, "mesher.weld.time", externalRepsKernel, dim3(divUp(ne, 256)), B, (const uint64_t *) sorted.keys,
-               (const uint32_t *) sorted.vals, (const uint32_t *) m->extGid.ptr, (const uint32_t *) m->extChunk.ptr, ne, compRep, outRep);
+        if (!reuse)
+        {
+            HIP_CHECK(hipMemcpyAsync(keysA, m->extKeys.ptr, ne * 8, hipMemcpyDeviceToDevice, ctx->stream));
+            PROPAGATE(radixSort<uint64_t>(ctx, "mesher.weld.time", keysA, slotsA, keysB, slotsB, ne, 64, true, hist, tileSums, &sorted));
+            LAUNCH(ctx, "mesher.weld.time", externalRepsKernel, dim3(divUp(ne, 256)), B, (const uint64_t *) sorted.keys,
+                   (const uint32_t *) sorted.vals, (const uint32_t *) m->extGid.ptr, (const uint32_t *) m->extChunk.ptr, ne, compRep, outRep);
+        }
     }
 
     /* 2. components */
     uint32_t *dFailed;
     PROPAGATE(S.get(&dFailed, 1));
     HIP_CHECK(hipMemsetAsync(dFailed, 0, 4, ctx->stream));
-    LAUNCH(ctx, "mesher.components.time", unionKernel, dim3(divUp(nt, 256)), B, (const uint32_t *) m->triangles.ptr, nt,
-           (const uint32_t *) compRep, parent, dFailed);
-    LAUNCH(ctx, "mesher.components.time", compressKernel, dim3(divUp(nv, 256)), B, parent, (const uint32_t *) compRep, nv, root);
-    LAUNCH(ctx, "mesher.components.time", componentSizeKernel, dim3(divUp(divUp(nv, 64 * SIZE_SPAN), 4)), B,
-           (const uint32_t *) compRep, (const uint32_t *) root, nv, size);
+    if (!reuse)
+    {
+        LAUNCH(ctx, "mesher.components.time", unionKernel, dim3(divUp(nt, 256)), B, (const uint32_t *) m->triangles.ptr, nt,
+               (const uint32_t *) compRep, parent, dFailed);
+        LAUNCH(ctx, "mesher.components.time", compressKernel, dim3(divUp(nv, 256)), B, parent, (const uint32_t *) compRep, nv, root);
+        LAUNCH(ctx, "mesher.components.time", componentSizeKernel, dim3(divUp(divUp(nv, 64 * SIZE_SPAN), 4)), B,
+               (const uint32_t *) compRep, (const uint32_t *) root, nv, size);
+    }
 
     /* 2b. several meshers, one job: the dense roots (needed by both the export and the verdict) */
     uint32_t rootCount = 0;
@@ -848,10 +870,15 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
         uint32_t *dRootTotal, *rootTiles;
         PROPAGATE(S.get(&dRootTotal, 1));
         PROPAGATE(S.get(&rootTiles, scanTiles(nv)));
-        PROPAGATE((exclusiveScan<uint32_t>(ctx, "mesher.components.time", IsRootIn{compRep, root}, RootOut{rootId, denseOf}, nv, 0u,
-                                           rootTiles, dRootTotal)));
-        HIP_CHECK(hipMemcpyAsync(&rootCount, dRootTotal, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        if (reuse)
+            rootCount = m->cacheRootCount;
+        else
+        {
+            PROPAGATE((exclusiveScan<uint32_t>(ctx, "mesher.components.time", IsRootIn{compRep, root}, RootOut{rootId, denseOf}, nv, 0u,
+                                               rootTiles, dRootTotal)));
+            HIP_CHECK(hipMemcpyAsync(&rootCount, dRootTotal, 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
     }
     if (analyzeOnly)
     {
@@ -860,8 +887,11 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         if (hFailed != 0)
             return setError(MLSGPU_ERR_HIP, "mesher: component union did not converge");
-        /* vertices and triangles per root (outRep is only needed by an output pass: it holds the triangle counts here) */
-        uint32_t *const tcount = outRep, *const vcount = compRep;    /* compRep's last reader was the root scan */
+        /* vertices and triangles per root, in buffers of their own: representatives, roots and sizes stay intact for the
+         * verdict pass (finalize_with) that follows an export */
+        uint32_t *tcount, *vcount;
+        PROPAGATE(S.get(&tcount, std::max<uint64_t>(rootCount, 1)));
+        PROPAGATE(S.get(&vcount, std::max<uint64_t>(rootCount, 1)));
         HIP_CHECK(hipMemsetAsync(tcount, 0, (size_t) rootCount * 4, ctx->stream));
         LAUNCH(ctx, "mesher.components.time", componentTrianglesKernel, dim3(divUp(divUp(nt, 64 * SIZE_SPAN), 4)), B,
                (const uint32_t *) m->triangles.ptr, (const uint32_t *) root, (const uint32_t *) denseOf, nt, tcount);
@@ -892,6 +922,9 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         m->bRootVertices.assign(hv.begin(), hv.end());
         m->bRootTriangles.assign(ht.begin(), ht.end());
+        m->cacheValid = true;
+        m->cacheDims[0] = nv; m->cacheDims[1] = nt; m->cacheDims[2] = ne;
+        m->cacheRootCount = rootCount;
         if (numChunks)
             *numChunks = 0;
         return MLSGPU_OK;

@@ -536,6 +536,218 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
     A.field[row * (int64_t) A.pitch + (wx + lx)] = f;
 }
 
+
+/*
+ * Variant 3 ("hit masks").  The issue-rate microbenchmark of tools/microbench/valu_lds_issue.hip (round 3) says what
+ * bounds variant 2: the CU's LDS pipe.  Per test a wave pays a 16-byte broadcast read (4 LDS cycles) AND a one-byte list
+ * append (4.9); per drain iteration a byte read (2) and two random 16-byte gathers (12.5 each) -- 2 290 LDS cycles per
+ * wave against 1 600 CU-cycle-equivalents of vector issue.  This variant takes the append out of LDS: a hit shifts one
+ * bit into a per-lane 64-bit mask (`m = 2 m + hit`, one add-with-carry, exactly what advancing the list tail cost), and
+ * the splat behind bit t comes from a 64-byte per-wave table (slot of the t-th test of the round), written once per
+ * 64-splat group by the lanes that hold the group's relevant splats.  The drain walks the mask's bits from the top (the
+ * first test is the highest bit), so the per-corner accumulation order is the list order -- bit-identical results.
+ * A round's tests beyond 64 start a new mask after an early drain.
+ */
+template<int SHAPE, bool STATS>
+__global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
+{
+    __shared__ float4 sPosRad[LIST_STAGE];
+    __shared__ float4 sNormQ[LIST_STAGE];
+    __shared__ uint32_t sMask[LIST_STAGE];
+    __shared__ uint8_t sSlot[8][64];        /* per wave: staging slot of the t-th test since the last drain */
+
+    const uint32_t nBlocks = A.blocksX * A.blocksY * A.blocksZ;
+    const uint32_t bid = xcdRemap(blockIdx.x, nBlocks, A.xcdChunk);
+    const uint32_t gx = bid % A.blocksX, gy = (bid / A.blocksX) % A.blocksY, gz = bid / (A.blocksX * A.blocksY);
+    const int wx = (int) (gx * 8), wy = (int) (gy * 8), wz = (int) (gz * 8 + A.zFirst);
+    const uint32_t sub = A.startShift / 3;
+    const uint32_t code = spread3((uint32_t) wx >> sub) | (spread3((uint32_t) wy >> sub) << 1) | (spread3((uint32_t) wz >> sub) << 2);
+    int32_t pos = A.start[code];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const int lx = (int) ((wave & 1) * 4 + (lane & 3));
+    const int ly = (int) (((wave >> 1) & 1) * 4 + ((lane >> 2) & 3));
+    const int lz = (int) ((wave >> 2) * 4 + (lane >> 4));
+
+    float f = __int_as_float(0x7FC00000);
+    if (pos >= 0)       /* uniform over the workgroup */
+    {
+        const float cx = (float) (wx + lx + A.ox), cy = (float) (wy + ly + A.oy), cz = (float) (wz + lz + A.oz);
+        const float bx0 = (float) (wx + A.ox), by0 = (float) (wy + A.oy), bz0 = (float) (wz + A.oz);
+        Fit fit;
+        fitInit(fit);
+        unsigned long long nListed = 0, nTests = 0;
+        typedef __attribute__((address_space(3))) uint8_t LdsByte;
+        LdsByte *const mySlots = (LdsByte *) sSlot[wave];
+        f32x2 sWpxy = {0.0f, 0.0f}, sWnxy = {0.0f, 0.0f};
+        const f32x2 cxy = {cx, cy};
+
+        uint32_t mA = 0, mB = 0;    /* hit bits of tests 0..31 / 32..63 since the last drain, newest in bit 0 */
+        uint32_t nt = 0;            /* tests since the last drain (wave-uniform) */
+
+        /* accumulate this lane's hits in test order, then start afresh */
+        auto drain = [&]()
+        {
+            /* left-align: test t of a word becomes bit 31 - t, so that the leading-zero count is t */
+            const uint32_t nA = nt < 32u ? nt : 32u, nB = nt - nA;
+            uint32_t cur = nA == 0 ? 0u : mA << (32u - nA);
+            uint32_t nxt = nB == 0 ? 0u : mB << (32u - nB);
+            const uint32_t cntA = (uint32_t) __popc(cur), cnt = cntA + (uint32_t) __popc(nxt);
+            const uint32_t most = waveMax(cnt);
+            fit.hits += cnt;
+            uint32_t base = 0;
+            for (uint32_t j = 0; j < most; j++)
+            {
+                if (j < cnt)
+                {
+                    if (j == cntA)
+                    {
+                        cur = nxt;
+                        base = 32;
+                    }
+                    const uint32_t t = (uint32_t) __builtin_clz(cur);      /* cur != 0: this lane still has a hit to take */
+                    cur ^= 0x80000000u >> t;
+                    const uint32_t i = mySlots[base + t];
+                    const float4 pr = sPosRad[i];
+                    const float4 nq = sNormQ[i];
+                    const f32x2 pxy = f32x2{pr.x, pr.y} - cxy;
+                    const float pz = pr.z - cz;
+                    const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
+                    const float d = pp * pr.w;
+                    float w = 1.0f - d;
+                    w *= w;
+                    w *= w;
+                    w *= nq.w;
+                    const f32x2 ww = {w, w};
+                    const f32x2 nxy = {nq.x, nq.y};
+                    const f32x2 wnxy = ww * nxy;
+                    const float wnz = w * nq.z;
+                    fit.sumW = fit.sumW + w;
+                    sWpxy = __builtin_elementwise_fma(ww, pxy, sWpxy);
+                    fit.sumWpz = fmaf(w, pz, fit.sumWpz);
+                    sWnxy = __builtin_elementwise_fma(ww, nxy, sWnxy);
+                    fit.sumWnz = fmaf(w, nq.z, fit.sumWnz);
+                    fit.sumWpp = fmaf(w, pp, fit.sumWpp);
+                    fit.sumWpn = fit.sumWpn + fmaf(wnxy.x, pxy.x, fmaf(wnxy.y, pxy.y, wnz * pz));
+                }
+            }
+            mA = mB = 0;
+            nt = 0;
+        };
+
+        int32_t end = A.commands[pos++];
+        while (pos < end)
+        {
+            uint32_t mask = 0;
+            int32_t mine = -1;
+            if (tid < LIST_STAGE)
+            {
+                const int32_t lpos = pos + (int32_t) tid;
+                mine = lpos < end ? A.commands[lpos] : -1;
+                if (mine >= 0)
+                {
+                    const float4 pr = A.splats[2 * (int64_t) mine];
+                    const float4 nq = A.splats[2 * (int64_t) mine + 1];
+                    sPosRad[tid] = pr;
+                    sNormQ[tid] = nq;
+                    float d[3][2];
+                    const float p[3] = {pr.x, pr.y, pr.z};
+                    const float b[3] = {bx0, by0, bz0};
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+                        {
+                            const float lo = b[a] + (float) (4 * h), hi = b[a] + (float) (4 * h + 3);
+                            d[a][h] = fmaxf(fmaxf(lo - p[a], p[a] - hi), 0.0f);
+                        }
+#pragma unroll
+                    for (int s_ = 0; s_ < 8; s_++)
+                    {
+                        const float dx = d[0][s_ & 1], dy = d[1][(s_ >> 1) & 1], dz = d[2][s_ >> 2];
+                        const float dd = dot3(dx, dy, dz, dx, dy, dz) * pr.w;
+                        mask |= (dd < RADIUS_CUTOFF ? 1u : 0u) << s_;
+                    }
+                }
+                sMask[tid] = mask;
+            }
+            if (STATS)
+                nListed += __popcll(__ballot(mine >= 0));
+            const int32_t staged = min(end - pos, (int32_t) LIST_STAGE);
+            pos += LIST_STAGE;
+            if (pos >= end)
+            {
+                pos = A.commands[end];
+                end = (pos >= 0) ? A.commands[pos++] : INT32_MIN;
+            }
+            __syncthreads();
+
+            for (int32_t g = 0; g < staged; g += 64)
+            {
+                const uint32_t m = sMask[g + lane];
+                uint64_t todo = __ballot((m >> wave) & 1u);
+                const uint32_t nGroup = (uint32_t) __popcll(todo);
+                if (nGroup == 0)
+                    continue;
+                if (nt + nGroup > 64u)
+                    drain();
+                /* the lanes holding the group's relevant splats note which test each of them will be */
+                if ((todo >> lane) & 1ull)
+                    mySlots[nt + popcBelow(todo)] = (uint8_t) (g + (int32_t) lane);
+                /* tests 0..31 since the last drain go to mA, 32..63 to mB; a group may straddle the two */
+                uint32_t left = nGroup;
+                while (left != 0)
+                {
+                    const bool first = nt < 32u;
+                    const uint32_t room = first ? 32u - nt : 64u - nt;
+                    const uint32_t take = left < room ? left : room;
+                    uint32_t acc = first ? mA : mB;
+#pragma unroll 4
+                    for (uint32_t k = 0; k < take; k++)
+                    {
+                        const int i = g + (int) __builtin_ctzll(todo);
+                        todo &= todo - 1;
+                        const float4 a = sPosRad[i];
+                        const f32x2 pxy = f32x2{a.x, a.y} - cxy;
+                        const float pz = a.z - cz;
+                        const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
+                        const float d = pp * a.w;
+                        /* acc = 2 acc + hit as ONE add-with-carry behind the compare (what advancing a list tail cost) */
+                        asm volatile("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                     : "+v"(acc) : "v"(d), "s"(RADIUS_CUTOFF) : "vcc");
+                    }
+                    if (STATS)
+                        nTests += 64ull * take;
+                    nt += take;
+                    left -= take;
+                    if (first) mA = acc; else mB = acc;
+                }
+            }
+            drain();            /* the table points into this round's staging buffers */
+            __syncthreads();
+        }
+        fit.sumWpx = sWpxy.x;
+        fit.sumWpy = sWpxy.y;
+        fit.sumWnx = sWnxy.x;
+        fit.sumWny = sWnxy.y;
+        f = finishCorner<SHAPE>(fit, A.boundaryFactor);
+        if (STATS)
+        {
+            const unsigned long long hits = waveSum(fit.hits);
+            if (lane == 0)
+            {
+                atomicAdd(&A.stats[0], nListed);
+                atomicAdd(&A.stats[1], nTests);
+                atomicAdd(&A.stats[2], hits);
+            }
+        }
+    }
+
+    const int64_t row = (int64_t) (wy + ly) + (int64_t) (wz + lz) * A.zStride + A.zBias;
+    A.field[row * (int64_t) A.pitch + (wx + lx)] = f;
+}
+
 } // namespace
 
 /* ------------------------------------------------------------------ C-ABI */
@@ -589,7 +801,7 @@ MLSGPU_API int mlsgpu_hip_mls_set_boundary_limit(mlsgpu_mls *m, float limit)
 
 MLSGPU_API int mlsgpu_hip_mls_set_variant(mlsgpu_mls *m, int variant)
 {
-    REQUIRE(m != nullptr && variant >= 0 && variant <= 2, MLSGPU_ERR_INVALID);
+    REQUIRE(m != nullptr && variant >= 0 && variant <= 3, MLSGPU_ERR_INVALID);
     m->variant = variant;
     return MLSGPU_OK;
 }
@@ -655,7 +867,13 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
     static const uint32_t ldsPad = getenv("MLSGPU_HIP_MLS_LDS_PAD") ? (uint32_t) atoi(getenv("MLSGPU_HIP_MLS_LDS_PAD")) : 0u;
 #define MLS_LAUNCH_LIST(SHAPE, STATS) LAUNCH_LDS(ctx, stat, (processCornersListKernel<SHAPE, STATS>), grid, block, ldsPad, A)
     const bool sphere = m->shape == MLSGPU_SHAPE_SPHERE, cull = m->variant == 0;
-    if (m->variant == 2)
+#define MLS_LAUNCH_MASK(SHAPE, STATS) LAUNCH_LDS(ctx, stat, (processCornersMaskKernel<SHAPE, STATS>), grid, block, ldsPad, A)
+    if (m->variant == 3)
+    {
+        if (m->dStats != nullptr) { if (sphere) MLS_LAUNCH_MASK(MLSGPU_SHAPE_SPHERE, true); else MLS_LAUNCH_MASK(MLSGPU_SHAPE_PLANE, true); }
+        else { if (sphere) MLS_LAUNCH_MASK(MLSGPU_SHAPE_SPHERE, false); else MLS_LAUNCH_MASK(MLSGPU_SHAPE_PLANE, false); }
+    }
+    else if (m->variant == 2)
     {
         if (m->dStats != nullptr) { if (sphere) MLS_LAUNCH_LIST(MLSGPU_SHAPE_SPHERE, true); else MLS_LAUNCH_LIST(MLSGPU_SHAPE_PLANE, true); }
         else { if (sphere) MLS_LAUNCH_LIST(MLSGPU_SHAPE_SPHERE, false); else MLS_LAUNCH_LIST(MLSGPU_SHAPE_PLANE, false); }
@@ -673,6 +891,7 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
     }
 #undef MLS_LAUNCH
 #undef MLS_LAUNCH_LIST
+#undef MLS_LAUNCH_MASK
     return MLSGPU_OK;
 }
 

@@ -112,7 +112,7 @@ def test_bench_two_ranks_one_sharded_cloud():
     # region with the cross-rank weld, and the reference's one-process shape (host-fed and device-fed)
     assert d["per_gpu_reference"]["value"] > 0 and 0 < d["scaling_efficiency"] < 2
     ti = d["transfer_inclusive"]["device_sink_global_weld"]
-    assert ti["value"] > 0 and ti["d2h_GB_per_step"] > 0 and ti["whole_job"]["kept_components"] >= 1
+    assert ti["value"] > 0 and ti["h2d_GB_per_step"] > 0 and ti["whole_job"]["kept_components"] >= 1
     sp = d["single_process"]
     assert sp["devices"] == [0, 0] and sp["buckets_per_pass"] == 50
     assert sp["host_fed"]["value"] > 0 and sp["device_fed"]["value"] > 0 and sp["in_flight_max"] >= 2

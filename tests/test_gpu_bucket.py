@@ -21,7 +21,7 @@ def run_gpu_bucket(ctx, cloud, first, count, low, nv, variant=0, **kw):
     return batches, w, buf
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 def test_cfg1_parity(ctx, variant):
     """BASELINE config 0: 64^3 grid, 50k splats on a sphere, one bucket: bit-identical to the oracle."""
     import mlsgpu_amd as m
@@ -73,7 +73,7 @@ def test_plane_shape_and_boundary_limit(ctx):
     assert sum(len(b["triangles"]) for b in got) > 0
 
 
-@pytest.mark.parametrize("variant", [0, 2])
+@pytest.mark.parametrize("variant", [0, 2, 3])
 def test_dense_hits(ctx, variant):
     """Large, dense splats: hundreds of hits per corner, so variant 2's 52-entry per-lane hit lists overflow and
     are drained mid-round; the accumulation order, hence every bit of the result, must not change."""
@@ -137,7 +137,7 @@ def test_cfg2_full_size_properties(ctx):
     from mlsgpu_amd import synth
     cloud, g = synth.make_cloud("cfg2")
     digests = []
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 2, 3):
         w = m.Worker(ctx, len(cloud), max_cells=255)
         w.set_mls_variant(variant)
         buf = m.DeviceBuffer(ctx, array=cloud)

@@ -130,8 +130,41 @@ def traffic(fetch_dir, write_dir, out):
     print("wrote", out, "and", tpath, per_launch)
 
 
+def sq(dirs, label, out):
+    """Sums of every collected counter over the launches of processCorners; appended to `out` as label,counter,value."""
+    rows = {}
+    launches = 0
+    for d in dirs:
+        db = database(d)
+        if db is not None:
+            it = db.execute("select kernel_name, counter_name, value from counters_collection")
+        else:
+            it = ((r["Kernel_Name"], r["Counter_Name"], r["Counter_Value"]) for r in csv.DictReader(open(find(d, "counter_collection.csv"))))
+        seen = defaultdict(int)
+        for name, counter, value in it:
+            if "processCorners" not in name:
+                continue
+            rows[counter] = rows.get(counter, 0.0) + float(value)
+            seen[counter] += 1
+        if seen:
+            launches = max(launches, max(seen.values()))
+    new = not os.path.exists(out)
+    with open(out, "a") as f:
+        if new:
+            f.write("# rocprofv3 --pmc (passes of <= 8 SQ counters each, no tracing), bench.py --workload cfg2 --headline-only --no-timing "
+                    "--workers 1 --steps 1 --warmup 0 --variant N\n")
+            f.write("# sums over the processCorners launches of the run (one launch of 32768 workgroups per pass over the 256^3 / 5 M-splat "
+                    "bucket); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in quad-cycles (MI355X_MICROARCH.md)\n")
+            f.write("variant,launches,counter,value\n")
+        for c in sorted(rows):
+            f.write('"%s",%d,%s,%.0f\n' % (label, launches, c, rows[c]))
+    print("appended", len(rows), "counters for", label, "to", out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) >= 5 and sys.argv[1] == "stats":
+    if len(sys.argv) >= 5 and sys.argv[1] == "sq":
+        sq(sys.argv[4:], sys.argv[2], sys.argv[3])
+    elif len(sys.argv) >= 5 and sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4])
     elif len(sys.argv) == 5 and sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3], sys.argv[4])
