@@ -1094,6 +1094,7 @@ class BucketFarm:
         cfg.devices = C.cast(self._devs, C.POINTER(C.c_int32))
         cfg.workersPerDevice = workers_per_device
         cfg.spare = spare
+        cfg.copyThreads = worker_kw.get("copy_threads", 0)      # host threads of one bucket's copy into pinned staging; 0 = 4
         w = cfg.worker
         w.maxBucketSplats = max_bucket_splats
         w.maxCells = worker_kw.get("max_cells", 255)

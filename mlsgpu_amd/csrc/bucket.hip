@@ -80,18 +80,18 @@ struct LevelLayout
     uint32_t offset[MAX_LEVELS + 1];
 };
 
-/* countSplats + upsweepCounts (src/bucket.cpp:161-174, 207-246) without the delta encoding */
-template<bool LDS>
-__global__ __launch_bounds__(256) void bucketCountKernel(RegionView V, LevelLayout L, uint32_t *counts, uint64_t n)
+/* countSplats + upsweepCounts (src/bucket.cpp:161-174, 207-246) without the delta encoding.
+ * Levels >= ldsFrom (the coarse ones: few nodes, every splat of the cloud lands on them -- 10^9 atomic adds on ONE word for
+ * the root of BASELINE configs[4]) are counted in LDS and flushed once per workgroup; the finer levels below, whose nodes
+ * do not fit, take one global atomic per (splat, node), spread over tens of thousands of words. */
+__global__ __launch_bounds__(256) void bucketCountKernel(RegionView V, LevelLayout L, uint32_t *counts, uint64_t n, uint32_t ldsFrom)
 {
-    __shared__ uint32_t local[LDS ? LDS_NODES : 1];
+    __shared__ uint32_t local[LDS_NODES];
     const uint32_t total = L.offset[L.levels];
-    if (LDS)
-    {
-        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x)
-            local[i] = 0;
-        __syncthreads();
-    }
+    const uint32_t ldsBase = ldsFrom < L.levels ? L.offset[ldsFrom] : total;
+    for (uint32_t i = threadIdx.x; i < total - ldsBase; i += blockDim.x)
+        local[i] = 0;
+    __syncthreads();
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
     {
         uint32_t lo[3], hi[3];
@@ -105,20 +105,17 @@ __global__ __launch_bounds__(256) void bucketCountKernel(RegionView V, LevelLayo
                     for (uint32_t x = lo[0] >> l; x <= (hi[0] >> l); x++)
                     {
                         const uint32_t node = L.offset[l] + (z * dy + y) * dx + x;
-                        if (LDS)
-                            atomicAdd(&local[node], 1u);
+                        if (l >= ldsFrom)
+                            atomicAdd(&local[node - ldsBase], 1u);
                         else
                             atomicAdd(&counts[node], 1u);
                     }
         }
     }
-    if (LDS)
-    {
-        __syncthreads();
-        for (uint32_t i = threadIdx.x; i < total; i += blockDim.x)
-            if (local[i] != 0)
-                atomicAdd(&counts[i], local[i]);
-    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < total - ldsBase; i += blockDim.x)
+        if (local[i] != 0)
+            atomicAdd(&counts[ldsBase + i], local[i]);
 }
 
 /* bucketSplats, src/bucket.cpp:271-302: table[microblock] = region id << 5 | node level */
@@ -451,10 +448,11 @@ int Bucketer::recurse(const uint32_t *dIds, uint64_t n, bool isSubset, const Gri
                 if (n > 0)
                 {
                     const uint32_t blocks = (uint32_t) std::min<uint64_t>(divUp(n, 256), 4096);
-                    if (totalNodes <= LDS_NODES)
-                        LAUNCH(ctx, "bucket.count.time", (bucketCountKernel<true>), dim3(blocks), dim3(256), V, L, B.counts, n);
-                    else
-                        LAUNCH(ctx, "bucket.count.time", (bucketCountKernel<false>), dim3(blocks), dim3(256), V, L, B.counts, n);
+                    /* the coarsest levels that fit the LDS table together (levels are stored finest first) */
+                    uint32_t ldsFrom = L.levels;
+                    while (ldsFrom > 0 && totalNodes - L.offset[ldsFrom - 1] <= LDS_NODES)
+                        ldsFrom--;
+                    LAUNCH(ctx, "bucket.count.time", bucketCountKernel, dim3(blocks), dim3(256), V, L, B.counts, n, ldsFrom);
                 }
                 std::vector<uint32_t> counts(totalNodes);
                 HIP_CHECK(hipMemcpyAsync(counts.data(), B.counts, totalNodes * 4, hipMemcpyDeviceToHost, ctx->stream));

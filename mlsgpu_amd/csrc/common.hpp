@@ -155,35 +155,55 @@ __device__ __forceinline__ uint32_t popcBelow(uint64_t mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
 }
 
+/* Cross-lane steps as DPP modifiers of the vector instruction itself (gfx9: row_shr, row_bcast15 / 31, wave_shr) instead
+ * of ds_bpermute round trips through the LDS crossbar: a scan is six dependent VALU instructions, not six LDS latencies.
+ * update_dpp(old, src, ctrl, row_mask, bank_mask, bound_ctrl = false): lanes without a source lane, or outside the masks,
+ * get `old`. */
+#define DPP_ROW_SHR(n) (0x110 + (n))
+#define DPP_WAVE_SHR1 0x138
+#define DPP_ROW_BCAST15 0x142
+#define DPP_ROW_BCAST31 0x143
+
 /* inclusive prefix sum across the 64 lanes of a wave */
 __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v)
 {
-    const uint32_t lane = laneId();
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1)
-    {
-        uint32_t t = __shfl_up(v, d, WAVE);
-        if (lane >= (uint32_t) d)
-            v += t;
-    }
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, DPP_ROW_SHR(1), 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, DPP_ROW_SHR(2), 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, DPP_ROW_SHR(4), 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, DPP_ROW_SHR(8), 0xf, 0xf, false);
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, DPP_ROW_BCAST15, 0xa, 0xf, false);   /* rows 1, 3 += row 0 / 2 */
+    v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, DPP_ROW_BCAST31, 0xc, 0xf, false);   /* rows 2, 3 += rows 0 + 1 */
     return v;
 }
 
+/* the sum over the wave, in every lane */
 __device__ __forceinline__ uint32_t waveSum(uint32_t v)
 {
-#pragma unroll
-    for (int d = WAVE / 2; d >= 1; d >>= 1)
-        v += __shfl_xor(v, d, WAVE);
-    return v;
+    return (uint32_t) __builtin_amdgcn_readlane((int) waveInclusiveScan(v), 63);
 }
 
-/* maximum over the wave, in every lane */
+/* maximum over the wave, in every lane (wave-uniform) */
 __device__ __forceinline__ uint32_t waveMax(uint32_t v)
 {
-#pragma unroll
-    for (int d = WAVE / 2; d >= 1; d >>= 1)
-        v = max(v, (uint32_t) __shfl_xor(v, d, WAVE));
-    return __builtin_amdgcn_readfirstlane(v);
+    v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, DPP_ROW_SHR(1), 0xf, 0xf, false));
+    v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, DPP_ROW_SHR(2), 0xf, 0xf, false));
+    v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, DPP_ROW_SHR(4), 0xf, 0xf, false));
+    v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, DPP_ROW_SHR(8), 0xf, 0xf, false));
+    v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, DPP_ROW_BCAST15, 0xa, 0xf, false));
+    v = max(v, (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, DPP_ROW_BCAST31, 0xc, 0xf, false));
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+}
+
+/* value of lane - 1; lane 0 gets zero */
+__device__ __forceinline__ uint32_t waveShiftUp1(uint32_t v)
+{
+    return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, DPP_WAVE_SHR1, 0xf, 0xf, false);
+}
+
+/* value of lane + 1; lane 63 gets zero */
+__device__ __forceinline__ uint32_t waveShiftDown1(uint32_t v)
+{
+    return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
 }
 
 __device__ __forceinline__ uint32_t readLane(uint32_t v, int lane)

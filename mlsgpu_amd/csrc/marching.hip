@@ -258,7 +258,8 @@ __global__ __launch_bounds__(256) void cellCodeKernel(uint8_t *codes, U3 *rowCou
         const uint32_t r0 = y + F.zStride * z + (uint32_t) F.zBias, r1 = r0 + F.zStride;
         const uint32_t xc = min(x, cw);
         const float a0 = F.at(xc, r0), a1 = F.at(xc, r0 + 1), a2 = F.at(xc, r1), a3 = F.at(xc, r1 + 1);
-        float b0 = __shfl_down(a0, 1, 64), b1 = __shfl_down(a1, 1, 64), b2 = __shfl_down(a2, 1, 64), b3 = __shfl_down(a3, 1, 64);
+        float b0 = __uint_as_float(waveShiftDown1(__float_as_uint(a0))), b1 = __uint_as_float(waveShiftDown1(__float_as_uint(a1)));
+        float b2 = __uint_as_float(waveShiftDown1(__float_as_uint(a2))), b3 = __uint_as_float(waveShiftDown1(__float_as_uint(a3)));
         if (lane == 63 && x < cw)
         {
             b0 = F.at(x + 1, r0); b1 = F.at(x + 1, r0 + 1); b2 = F.at(x + 1, r1); b3 = F.at(x + 1, r1 + 1);
@@ -759,7 +760,7 @@ __global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, 
                 c[dy][dz] = next[dy][dz];
                 const uint32_t xn = x0 + 64 + lane;
                 next[dy][dz] = (rowOk[dy][dz] && xn < L.cw) ? rowPtr[dy][dz][xn] : 0u;
-                const uint32_t up = __shfl_up(c[dy][dz], 1, 64);
+                const uint32_t up = waveShiftUp1(c[dy][dz]);
                 m[dy][dz] = lane == 0 ? prev[dy][dz] : up;
                 prev[dy][dz] = readLane(c[dy][dz], 63);
             }

@@ -57,11 +57,7 @@ __device__ __forceinline__ U3 waveInclusiveScanT(U3 v)
     return U3{waveInclusiveScan(v.a), waveInclusiveScan(v.b), waveInclusiveScan(v.c)};
 }
 /* value of lane-1; lane 0 gets zero */
-__device__ __forceinline__ uint32_t waveShiftUpT(uint32_t v)
-{
-    uint32_t t = __shfl_up(v, 1, 64);
-    return laneId() == 0 ? 0u : t;
-}
+__device__ __forceinline__ uint32_t waveShiftUpT(uint32_t v) { return waveShiftUp1(v); }
 __device__ __forceinline__ U3 waveShiftUpT(U3 v) { return U3{waveShiftUpT(v.a), waveShiftUpT(v.b), waveShiftUpT(v.c)}; }
 __device__ __forceinline__ uint32_t readLaneT(uint32_t v, int lane) { return readLane(v, lane); }
 __device__ __forceinline__ U3 readLaneT(U3 v, int lane)

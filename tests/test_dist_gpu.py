@@ -116,7 +116,7 @@ def test_bench_two_ranks_one_sharded_cloud():
     sp = d["single_process"]
     assert sp["devices"] == [0, 0] and sp["buckets_per_pass"] == 50
     assert sp["host_fed"]["value"] > 0 and sp["device_fed"]["value"] > 0 and sp["in_flight_max"] >= 2
-    assert sum(sp["buckets_per_device_last_pass"]) == 50 and min(sp["buckets_per_device_last_pass"]) > 0
+    assert sum(sp["buckets_per_device_device_fed"]) == 50 * sp["device_fed_passes"] and min(sp["buckets_per_device_device_fed"]) > 0
     # without a launcher bench.py starts the ranks itself; with a launcher of the wrong size it refuses
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "1",
                           "--warmup", "0", "--no-timing"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
