@@ -73,6 +73,7 @@ def parse_args():
     p.add_argument("--workers", type=int, default=4, help="device worker threads per GPU (measured 2..4: +0..6 %)")
     p.add_argument("--variant", type=int, default=2, help="MLS kernel variant: 0 culled, 1 basic, 2 culled + hit lists, 3 culled + hit masks")
     p.add_argument("--leg-steps", type=int, default=3, help="passes of every secondary leg")
+    p.add_argument("--copy-threads", type=int, default=8, help="host threads copying one bucket into pinned staging (transfer legs)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-transfer", action="store_true", help="skip the transfer-inclusive legs (SURVEY 8d timed region)")
     p.add_argument("--no-shells", action="store_true", help="skip the D1 (shells) secondary measurement")
@@ -406,7 +407,7 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     views = [bucketed_host[b.first:b.first + b.count] for b in buckets]
     nworkers = max(1, min(args.workers, len(buckets)))
     farm = m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
-                        mesh_memory=args.mesh_memory_mb << 20)
+                        mesh_memory=args.mesh_memory_mb << 20, copy_threads=args.copy_threads)
     farm.set_host_output(6 << 30, None)
 
     def stream_pass():
@@ -425,8 +426,9 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
         "value": round(voxels / dt / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(dt * 1e3, 3),
         "h2d_GB_per_step": round(bucketed_host.nbytes / 1e9, 3), "d2h_GB_per_step": round(d2h / 1e9, 3),
         "link_GBps": round((bucketed_host.nbytes + d2h) / dt / 1e9, 2), "ring_waits": hs["ring_waits"] - before["ring_waits"],
-        "note": "pageable host splats -> pinned staging (4 copy threads) -> H2D -> %d device workers -> every ship-out "
-                "read back through a 6 GiB pinned circular buffer, consumed (dropped) by the farm's mesher thread" % nworkers}
+        "note": "pageable host splats -> pinned staging (%d copy threads) -> H2D -> %d device workers -> every ship-out "
+                "read back through a 6 GiB pinned circular buffer, consumed (dropped) by the farm's mesher thread"
+                % (args.copy_threads, nworkers)}
     farm.close()
     if not with_sink:
         return out
@@ -434,10 +436,14 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     # k's weld, prune and read-back run, job k + 1's splats are already on their way in -- the steady state of a stream of
     # jobs, which is what the ship-out route's ring gives the reference (its read-backs overlap the next buckets too).
     import threading
-    fctx = [m.Context(device_index) for _ in range(2)]          # every sink welds and reads back on a stream of its own
+    # every sink welds and reads back on a stream of its own, of HIGH priority: the weld of job k competes with the
+    # kernels of job k + 1 for the GPU, and it is the weld that is on the critical path of the steady state
+    import torch
+    hi = [torch.cuda.Stream(device=device_index, priority=-1) for _ in range(2)]
+    fctx = [m.Context(device_index, stream=s_.cuda_stream) for s_ in hi]
     sinks = [m.Mesher(c, 0.02) for c in fctx]
     farms = [m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
-                          mesh_memory=args.mesh_memory_mb << 20, sink=s_) for s_ in sinks]
+                          mesh_memory=args.mesh_memory_mb << 20, sink=s_, copy_threads=args.copy_threads) for s_ in sinks]
     pins = [m.binding.PinnedBuffer(1) for _ in range(2)]
     got_bytes = [0, 0]
     errors = []
@@ -476,7 +482,7 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     submit_job(0)
     finish_job(0)
     single_s = time.perf_counter() - t0        # one job alone, nothing overlapped: its latency
-    jobs = max(steps, 2)
+    jobs = max(3 * steps, 9)                  # the pipeline's fill and drain (one job's weld) amortised over the jobs
     t0 = time.perf_counter()
     run_jobs(jobs)
     dt = (time.perf_counter() - t0) / jobs

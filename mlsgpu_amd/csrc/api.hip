@@ -96,6 +96,70 @@ MLSGPU_API int mlsgpu_hip_device_count(int *count)
     return MLSGPU_OK;
 }
 
+namespace
+{
+__global__ void mailboxPublishKernel(const uint32_t *src, uint32_t words, uint32_t *box, uint32_t seq)
+{
+    for (uint32_t i = 0; i < words; i++)
+        __hip_atomic_store(box + 1 + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+} // namespace
+
+int mlsgpu::HostMailbox::create()
+{
+    if (host != nullptr)
+        return MLSGPU_OK;
+    if (hipHostMalloc((void **) &host, (WORDS + 1) * 4, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess)
+        return setError(MLSGPU_ERR_NOMEM, "cannot allocate the pinned read-back words");
+    std::memset(host, 0, (WORDS + 1) * 4);
+    if (hipHostGetDevicePointer((void **) &dev, host, 0) != hipSuccess)
+    {
+        hipHostFree(host);
+        host = nullptr;
+        return setError(MLSGPU_ERR_HIP, "cannot map the pinned read-back words");
+    }
+    seq = 0;
+    return MLSGPU_OK;
+}
+
+void mlsgpu::HostMailbox::destroy()
+{
+    if (host != nullptr)
+        hipHostFree(host);
+    host = dev = nullptr;
+}
+
+int mlsgpu::HostMailbox::publish(hipStream_t stream, const void *src, uint32_t words)
+{
+    REQUIRE(host != nullptr && words <= WORDS, MLSGPU_ERR_INVALID);
+    seq++;
+    if (seq == 0)
+        seq = 1;
+    hipLaunchKernelGGL(mailboxPublishKernel, dim3(1), dim3(1), 0, stream, static_cast<const uint32_t *>(src), words, dev, seq);
+    HIP_CHECK(hipGetLastError());
+    return MLSGPU_OK;
+}
+
+int mlsgpu::HostMailbox::wait(hipStream_t stream)
+{
+    /* poll; after a while make sure the stream is still healthy (a failed kernel would never publish) */
+    uint64_t spins = 0;
+    while (__atomic_load_n(host, __ATOMIC_ACQUIRE) != seq)
+    {
+        __builtin_ia32_pause();
+        if (++spins == (1ull << 22))
+        {
+            spins = 0;
+            HIP_CHECK(hipStreamSynchronize(stream));
+            if (__atomic_load_n(host, __ATOMIC_ACQUIRE) != seq)
+                return setError(MLSGPU_ERR_HIP, "a device read-back never arrived");
+        }
+    }
+    return MLSGPU_OK;
+}
+
 MLSGPU_API int mlsgpu_hip_ctx_create(int device, void *stream, mlsgpu_ctx **out)
 {
     REQUIRE(out != nullptr, MLSGPU_ERR_INVALID);

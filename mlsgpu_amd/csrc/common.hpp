@@ -117,6 +117,29 @@ struct mlsgpu_ctx
 namespace mlsgpu
 {
 
+/*
+ * Small device -> host read-backs on the critical path (the octree's entry count, Marching's swathe totals and welded
+ * counts: 4 to 24 bytes each, three per bucket, each followed by a host decision).  A hipMemcpyAsync of a few bytes plus
+ * hipStreamSynchronize costs a copy-engine submission and a signal wait; here a one-thread kernel stores the words straight
+ * into mapped, coherent pinned memory, a sequence number behind a system-scope fence, and the host polls that word.  The
+ * stream is not drained: what the host enqueues next lands behind the kernel that published.
+ */
+struct HostMailbox
+{
+    enum { WORDS = 8 };
+    uint32_t *host = nullptr;       /* [0] = sequence number of the last publication, [1 .. WORDS] = payload */
+    uint32_t *dev = nullptr;        /* the same memory as the device sees it */
+    uint32_t seq = 0;
+
+    int create();
+    void destroy();
+    /* enqueue: copy `words` 32-bit words from device memory `src` to the mailbox (on `stream`) */
+    int publish(hipStream_t stream, const void *src, uint32_t words);
+    /* block until the last publication has landed; the payload is host[1 ..] */
+    int wait(hipStream_t stream);
+    const uint32_t *payload() const { return host + 1; }
+};
+
 /* Launch a kernel on the context's stream, timing it under a reference stat name when enabled. */
 #define LAUNCH(ctx, statName, kernel, grid, block, ...) LAUNCH_LDS(ctx, statName, kernel, grid, block, 0, __VA_ARGS__)
 

@@ -1067,6 +1067,7 @@ struct mlsgpu_marching
     uint32_t *dHist = nullptr, *dTileSums = nullptr;
     Readback *dReadback = nullptr;          /* device words */
     Readback *hReadback = nullptr;          /* pinned */
+    HostMailbox box;                        /* the totals a host decision waits for (swathe totals, welded counts) */
     uint2 *hHistogram = nullptr;            /* pinned, maxDepth entries (viReadback in the reference) */
 
     /* lattice weld (single-swathe buckets) */
@@ -1233,6 +1234,8 @@ MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, ui
         rc = setError(MLSGPU_ERR_NOMEM, "Marching: cannot allocate pinned readback");
     if (rc == MLSGPU_OK && hipHostMalloc((void **) &m->hHistogram, (uint64_t) maxDepth * 8) != hipSuccess)
         rc = setError(MLSGPU_ERR_NOMEM, "Marching: cannot allocate pinned histogram");
+    if (rc == MLSGPU_OK)
+        rc = m->box.create();
     if (rc != MLSGPU_OK)
     {
         mlsgpu_hip_marching_destroy(m);
@@ -1288,6 +1291,7 @@ MLSGPU_API void mlsgpu_hip_marching_destroy(mlsgpu_marching *m)
     hipFree(m->dLatWords); hipFree(m->dLatRows);
     if (m->hReadback) hipHostFree(m->hReadback);
     if (m->hHistogram) hipHostFree(m->hHistogram);
+    m->box.destroy();
     delete m;
 }
 
@@ -1313,9 +1317,10 @@ int mlsgpu_marching::generateCells(const mlsgpu_swathe &sw, U3 *totals)
     }
     int pend = -1;
     if (ctx->timing) pend = ctx->beginTiming(ctx->statId("kernel.marching.readback.time"));
-    HIP_CHECK(hipMemcpyAsync(&hReadback->totals, &dReadback->totals, sizeof(U3), hipMemcpyDeviceToHost, ctx->stream));
+    PROPAGATE(box.publish(ctx->stream, &dReadback->totals, 3));
     if (pend >= 0) ctx->endTiming(pend);
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));        /* the reference's queue.finish(), :548 */
+    PROPAGATE(box.wait(ctx->stream));                    /* the reference's queue.finish(), :548 */
+    std::memcpy(&hReadback->totals, box.payload(), sizeof(U3));
     *totals = hReadback->totals;
     return MLSGPU_OK;
 }
@@ -1425,8 +1430,9 @@ int mlsgpu_marching::shipOutLattice(const mlsgpu_swathe &sw, const uint32_t size
                L, C, devTables(), (const uint2 *) dCells, (const uint2 *) dViStart, dIndices,
                (const U3 *) &dReadback->batchTotals);
     }
-    HIP_CHECK(hipMemcpyAsync(&hReadback->classTotals, &dReadback->classTotals, 2 * sizeof(U3), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    PROPAGATE(box.publish(ctx->stream, &dReadback->classTotals, 6));     /* classTotals and batchTotals are adjacent */
+    PROPAGATE(box.wait(ctx->stream));
+    std::memcpy(&hReadback->classTotals, box.payload(), 2 * sizeof(U3));
     const U3 ct = hReadback->classTotals, bt = hReadback->batchTotals;
     if (bt.a != cellsInBatch || bt.b != sizes[0] || bt.c != sizes[1])
         return setError(MLSGPU_ERR_INVALID, "lattice weld: batch accounting mismatch (%u/%u cells, %u/%u vertices, %u/%u indices)",

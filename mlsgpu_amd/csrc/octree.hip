@@ -32,7 +32,7 @@ struct mlsgpu_tree
     int32_t *dStart = nullptr, *dJumpPos = nullptr, *dCommands = nullptr;
     uint32_t *dKeysA = nullptr, *dKeysB = nullptr, *dValsA = nullptr, *dValsB = nullptr;
     uint32_t *dHist = nullptr, *dTileSums = nullptr, *dNumEntries = nullptr;
-    uint32_t *hNumEntries = nullptr;    /* pinned: the entry count comes back to the host once per build */
+    HostMailbox entryBox;               /* the entry count comes back to the host once per build */
     uint8_t *dSlotMasks = nullptr;      /* per splat: which of its 8 candidate slots are real entries */
     mlsgpu_splat *dSplats = nullptr;   /* borrowed between build and clear_splats */
 };
@@ -365,8 +365,8 @@ MLSGPU_API int mlsgpu_hip_tree_create(mlsgpu_ctx *ctx, uint64_t maxLevels, uint6
     alloc((void **) &t->dTileSums, tileSums * 4);
     alloc((void **) &t->dNumEntries, 4);
     alloc((void **) &t->dSlotMasks, maxSplats);
-    if (rc == MLSGPU_OK && hipHostMalloc((void **) &t->hNumEntries, 4) != hipSuccess)
-        rc = setError(MLSGPU_ERR_NOMEM, "octree: cannot allocate the pinned read-back word");
+    if (rc == MLSGPU_OK)
+        rc = t->entryBox.create();
     if (rc != MLSGPU_OK)
     {
         mlsgpu_hip_tree_destroy(t);
@@ -384,7 +384,7 @@ MLSGPU_API void mlsgpu_hip_tree_destroy(mlsgpu_tree *t)
     hipFree(t->dStart); hipFree(t->dJumpPos); hipFree(t->dCommands);
     hipFree(t->dKeysA); hipFree(t->dKeysB); hipFree(t->dValsA); hipFree(t->dValsB);
     hipFree(t->dHist); hipFree(t->dTileSums); hipFree(t->dNumEntries); hipFree(t->dSlotMasks);
-    if (t->hNumEntries) hipHostFree(t->hNumEntries);
+    t->entryBox.destroy();
     delete t;
 }
 
@@ -433,9 +433,9 @@ MLSGPU_API int mlsgpu_hip_tree_build(mlsgpu_tree *t, mlsgpu_splat *dSplats, uint
         /* The entry count (2.4 .. 3.8 per splat on the BASELINE clouds, 8 at most) comes back to the host here: the sort
          * and the command scan launch on n instead of 8N elements, which more than pays for the one synchronisation
          * (cfg3: -2.6 % per step on the noise cloud, -2 % on the shells cloud; the other worker fills the gap). */
-        HIP_CHECK(hipMemcpyAsync(t->hNumEntries, t->dNumEntries, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        const uint64_t sortN = *t->hNumEntries;
+        PROPAGATE(t->entryBox.publish(ctx->stream, t->dNumEntries, 1));
+        PROPAGATE(t->entryBox.wait(ctx->stream));
+        const uint64_t sortN = t->entryBox.payload()[0];
         SortResult<uint32_t> sorted;
         PROPAGATE(radixSort<uint32_t>(ctx, "kernel.octree.sort.time", t->dKeysA, t->dValsA, t->dKeysB, t->dValsB,
                                       sortN, (uint32_t) (3 * (maxShift - minShift) + 1), false,

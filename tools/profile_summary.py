@@ -130,6 +130,65 @@ def traffic(fetch_dir, write_dir, out):
     print("wrote", out, "and", tpath, per_launch)
 
 
+def traffic_resolved(rd_dir, wr_dir, out):
+    """HBM traffic per launch from the request-size-resolved TCC counters (round 3).  rocprofv3's FETCH_SIZE
+    is (BUBBLE*128 + (RDREQ - BUBBLE - RDREQ_32B)*64 + RDREQ_32B*32) / 1024: on gfx950 the 128-byte read requests are in
+    TCC_EA0_RDREQ_128B, not in TCC_BUBBLE, so FETCH_SIZE tallies them at 64 bytes -- exactly half for a kernel whose reads
+    are all 128-byte requests, exact for one whose reads are 32- or 64-byte requests.  Here every size is counted at its own
+    width, per kernel; the csv also gives what FETCH_SIZE would have said and the ratio (the kernel's own correction)."""
+    cols = {}
+    calls = {}
+    for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum", "TCC_EA0_RDREQ_128B_sum"):
+        cols[c], calls = counters(rd_dir, c)
+    wcalls = {}
+    for c in ("TCC_EA0_WRREQ_sum", "TCC_EA0_WRREQ_64B_sum"):
+        cols[c], wcalls = counters(wr_dir, c)
+    names = sorted(set(cols["TCC_EA0_RDREQ_sum"]) | set(cols["TCC_EA0_WRREQ_sum"]),
+                   key=lambda k: -(cols["TCC_EA0_RDREQ_sum"].get(k, 0) + cols["TCC_EA0_WRREQ_sum"].get(k, 0)))
+
+    def row(k):
+        r, r32, r64, r128 = (cols[c].get(k, 0.0) for c in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_64B_sum",
+                                                           "TCC_EA0_RDREQ_128B_sum"))
+        w, w64 = cols["TCC_EA0_WRREQ_sum"].get(k, 0.0), cols["TCC_EA0_WRREQ_64B_sum"].get(k, 0.0)
+        fetch = 32 * r32 + 64 * r64 + 128 * r128
+        formula = 32 * r32 + 64 * (r - r32)
+        write = 64 * w64 + 32 * (w - w64)
+        return r, r32, r64, r128, w, w64, fetch, formula, write
+    with open(out, "w") as f:
+        f.write("# rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum / --pmc "
+                "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum (two separate passes, no tracing), bench.py --headline-only --no-timing "
+                "--workers 1 --steps 1 --warmup 0\n")
+        f.write("# fetch bytes = 32*R32 + 64*R64 + 128*R128; FETCH_SIZE's formula counts the 128-byte requests at 64 (its TCC_BUBBLE "
+                "term is empty on gfx950): factor = fetch / formula is the kernel's own correction, between 1 and 2\n")
+        f.write("kernel,calls,RDREQ,RDREQ_32B,RDREQ_64B,RDREQ_128B,sizes_add_up,fetch_bytes_per_launch,FETCH_SIZE_formula_bytes_per_launch,"
+                "factor,WRREQ,WRREQ_64B,write_bytes_per_launch\n")
+        for k in names:
+            r, r32, r64, r128, w, w64, fetch, formula, write = row(k)
+            n = max(calls.get(k, 0), wcalls.get(k, 0), 1)
+            f.write('"%s",%d,%.0f,%.0f,%.0f,%.0f,%s,%.0f,%.0f,%.3f,%.0f,%.0f,%.0f\n'
+                    % (k, n, r, r32, r64, r128, "yes" if abs(r - r32 - r64 - r128) <= 1e-6 * max(r, 1) else "no", fetch / n,
+                       formula / n, fetch / formula if formula else 0.0, w, w64, write / n))
+    per_launch, factors = {}, {}
+    for label, needle in TRACKED.items():
+        fk = [k for k in names if needle in k]
+        if not fk:
+            continue
+        n = sum(max(calls.get(k, 0), wcalls.get(k, 0)) for k in fk)
+        rows = [row(k) for k in fk]
+        per_launch[label] = int((sum(x[6] for x in rows) + sum(x[8] for x in rows)) / max(n, 1))
+        factors[label] = round(sum(x[6] for x in rows) / max(sum(x[7] for x in rows), 1), 3)
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    doc = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    doc["cfg3/uniform"] = per_launch
+    doc["_fetch_correction_per_kernel"] = factors
+    doc["_note"] = ("HBM bytes per launch = 32*RDREQ_32B + 64*RDREQ_64B + 128*RDREQ_128B + 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B), every "
+                    "request at its own width, from " + os.path.relpath(out, ROOT) + ".  _fetch_correction_per_kernel is what a "
+                    "FETCH_SIZE reading of that kernel would have to be multiplied by (2.0 = all reads are 128-byte requests, the "
+                    "guide's streaming case; 1.0 = none are): rounds 1-2 doubled every kernel.")
+    json.dump(doc, open(tpath, "w"), indent=1)
+    print("wrote", out, "and", tpath, per_launch, factors)
+
+
 def sq(dirs, label, out):
     """Sums of every collected counter over the launches of processCorners; appended to `out` as label,counter,value."""
     rows = {}
@@ -166,6 +225,8 @@ if __name__ == "__main__":
         sq(sys.argv[4:], sys.argv[2], sys.argv[3])
     elif len(sys.argv) >= 5 and sys.argv[1] == "stats":
         stats(sys.argv[2], sys.argv[3], sys.argv[4])
+    elif len(sys.argv) == 5 and sys.argv[1] == "traffic_resolved":
+        traffic_resolved(sys.argv[2], sys.argv[3], sys.argv[4])
     elif len(sys.argv) == 5 and sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
