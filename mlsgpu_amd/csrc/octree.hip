@@ -16,6 +16,8 @@
 #include "common.hpp"
 #include "primitives.hpp"
 
+#include <cstdlib>
+
 using namespace mlsgpu;
 
 struct LevelOffsets
@@ -204,6 +206,249 @@ struct EntryWriteOut
             }
     }
 };
+
+/*
+ * writeEntries fused with the FIRST pass of the entry sort (round 3).  The entries of a tile of ENT_TILE splats are never
+ * written in (splat, slot) order: the counting kernel histograms the low digit of their keys per tile while it evaluates the
+ * box tests, one digit scan turns the histograms into positions (the same kernel the sort uses), and the scattering kernel
+ * regenerates the tile's entries from the remembered slot masks, lines them up in LDS in (splat, slot) order -- the order a
+ * stable sort has to start from -- and sends them straight to where the first LSD pass would have put them.  That is one
+ * write and one read of all entries (16 bytes each) and two launches less than writeEntries + histogram + scatter; the
+ * remaining passes of the sort are unchanged.  Results are identical: same keys, same stable order.
+ */
+enum
+{
+    ENT_TILE = 512,                 /* splats per workgroup, one per thread (measured 256: 94 us per bucket in the scatter) */
+    ENT_CAP = 8 * ENT_TILE,         /* at most eight entries per splat */
+    ENT_BIN_BITS = 8                /* the fused pass handles digits of up to 8 bits */
+};
+
+__global__ __launch_bounds__(ENT_TILE) void entryHistKernel(EntryParams P, uint8_t *slotMasks, uint32_t *hist, uint32_t numTiles,
+                                                            uint64_t n, uint32_t digitBits)
+{
+    __shared__ uint32_t bins[1 << ENT_BIN_BITS];
+    const uint32_t numBins = 1u << digitBits, dmask = numBins - 1;
+    for (uint32_t d = threadIdx.x; d < numBins; d += ENT_TILE)
+        bins[d] = 0;
+    __syncthreads();
+    const uint64_t i = (uint64_t) blockIdx.x * ENT_TILE + threadIdx.x;
+    if (i < n)
+    {
+        const float4 pr = reinterpret_cast<const float4 *>(P.splats + (i + P.firstSplat))[0];
+        uint32_t k[8];
+        const uint32_t mask = splatEntries(P, pr, k);
+        slotMasks[i] = (uint8_t) mask;
+#pragma unroll
+        for (int o = 0; o < 8; o++)
+            if (mask & (1u << o))
+                atomicAdd(&bins[k[o] & dmask], 1u);
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < numBins; d += ENT_TILE)
+        hist[(uint64_t) d * numTiles + blockIdx.x] = bins[d];
+}
+
+/* the number of entries = the sum of the digit totals */
+__global__ __launch_bounds__(256) void entryTotalKernel(const uint32_t *digitTotals, uint32_t numBins, uint32_t *total)
+{
+    __shared__ uint32_t waveTotals[4];
+    uint32_t v = 0;
+    for (uint32_t d = threadIdx.x; d < numBins; d += 256)
+        v += digitTotals[d];
+    v = waveSum(v);
+    if ((threadIdx.x & 63) == 0)
+        waveTotals[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        *total = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
+}
+
+__global__ __launch_bounds__(ENT_TILE) void entryScatterKernel(EntryParams P, const uint8_t *slotMasks, const uint32_t *hist,
+                                                               const uint32_t *digitTotals, uint32_t numTiles, uint64_t n,
+                                                               uint32_t digitBits, uint32_t *keysOut, uint32_t *valsOut)
+{
+    enum { BINS = 1 << ENT_BIN_BITS, WAVES = ENT_TILE / 64, MAX_ROUNDS = ENT_CAP / ENT_TILE };
+    __shared__ uint32_t waveBins[WAVES][BINS];
+    __shared__ uint32_t tileBase[BINS];
+    __shared__ uint32_t waveTotals[WAVES], waveTotalsAll[WAVES], waveCnt[WAVES];
+    __shared__ uint32_t sKeys[ENT_CAP];         /* the tile's keys in (splat, slot) order; afterwards the reorder buffer */
+    __shared__ uint32_t sVals[ENT_CAP];         /* ... and their splat ids */
+    const uint32_t numBins = 1u << digitBits, dmask = numBins - 1;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint32_t d = threadIdx.x; d < numBins; d += ENT_TILE)
+    {
+#pragma unroll
+        for (int w = 0; w < WAVES; w++)
+            waveBins[w][d] = 0;
+    }
+    /* 1. the tile's entries, lined up in (splat, slot) order */
+    const uint64_t i = (uint64_t) blockIdx.x * ENT_TILE + threadIdx.x;
+    const uint32_t mask = i < n ? (uint32_t) slotMasks[i] : 0u;
+    const uint32_t cnt = (uint32_t) __popc(mask);
+    const uint32_t incl = waveInclusiveScan(cnt);
+    if (lane == 63)
+        waveCnt[wave] = incl;
+    __syncthreads();
+    uint32_t pos = incl - cnt, tileCount = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < WAVES; w++)
+    {
+        if (w < wave)
+            pos += waveCnt[w];
+        tileCount += waveCnt[w];
+    }
+    if (i < n)
+    {
+        const uint32_t gid = (uint32_t) i + P.firstSplat;
+        float4 *sp = reinterpret_cast<float4 *>(P.splats + gid);
+        const float4 pr = sp[0];
+        reinterpret_cast<float *>(sp)[3] = 1.0f / (pr.w * pr.w);        /* kernels/octree.cl:193 */
+        if (mask != 0)
+        {
+            /* prepare (octree.cl:79-90) again for the node coordinates; the box tests are not repeated */
+            const int lox = floorToInt(pr.x - pr.w), loy = floorToInt(pr.y - pr.w), loz = floorToInt(pr.z - pr.w);
+            const int hix = floorToInt(pr.x + pr.w), hiy = floorToInt(pr.y + pr.w), hiz = floorToInt(pr.z + pr.w);
+            int shift = levelShift(lox, loy, loz, hix, hiy, hiz);
+            shift = min(max(shift, P.minShift), P.maxShift);
+            const int ilx = max(lox - P.bx, 0) >> shift;
+            const int ily = max(loy - P.by, 0) >> shift;
+            const int ilz = max(loz - P.bz, 0) >> shift;
+            const uint32_t levelOffset = P.levelOffsets.v[shift];
+#pragma unroll
+            for (int o = 0; o < 8; o++)
+                if (mask & (1u << o))
+                {
+                    sKeys[pos] = makeCode(ilx + (o & 1), ily + ((o >> 1) & 1), ilz + (o >> 2)) + levelOffset;
+                    sVals[pos] = gid;
+                    pos++;
+                }
+        }
+    }
+    __syncthreads();
+    if (tileCount == 0)
+        return;
+    /* 2. one stable LSD pass over the tile, as sortScatterKernel: wave w owns `rounds` x 64 consecutive elements */
+    const uint32_t rounds = (tileCount + ENT_TILE - 1) / ENT_TILE;
+    const uint32_t first = wave * rounds * 64 + lane;
+    uint32_t keys[MAX_ROUNDS];
+#pragma unroll
+    for (int j = 0; j < MAX_ROUNDS; j++)
+    {
+        const uint32_t e = first + j * 64;
+        const bool valid = (uint32_t) j < rounds && e < tileCount;
+        keys[j] = valid ? sKeys[e] : 0u;
+        if (valid)
+            atomicAdd(&waveBins[wave][keys[j] & dmask], 1u);
+    }
+    __syncthreads();
+    {
+        const uint32_t per = numBins > ENT_TILE ? numBins / ENT_TILE : 1;
+        const uint32_t d0 = threadIdx.x * per;
+        uint32_t mine = 0, mineAll = 0;
+        if (d0 < numBins)
+            for (uint32_t k = 0; k < per; k++)
+            {
+                mineAll += digitTotals[d0 + k];
+#pragma unroll
+                for (int w = 0; w < WAVES; w++)
+                    mine += waveBins[w][d0 + k];
+            }
+        const uint32_t inclMine = waveInclusiveScan(mine), inclAll = waveInclusiveScan(mineAll);
+        if (lane == 63)
+        {
+            waveTotals[wave] = inclMine;
+            waveTotalsAll[wave] = inclAll;
+        }
+        __syncthreads();
+        uint32_t run = inclMine - mine, base = inclAll - mineAll;
+        for (uint32_t w = 0; w < wave; w++)
+        {
+            run += waveTotals[w];
+            base += waveTotalsAll[w];
+        }
+        if (d0 < numBins)
+            for (uint32_t k = 0; k < per; k++)
+            {
+                const uint32_t d = d0 + k;
+                tileBase[d] = base + hist[(uint64_t) d * numTiles + blockIdx.x] - run;
+                base += digitTotals[d];
+#pragma unroll
+                for (int w = 0; w < WAVES; w++)
+                {
+                    const uint32_t c = waveBins[w][d];
+                    waveBins[w][d] = run;
+                    run += c;
+                }
+            }
+    }
+    __syncthreads();
+    uint32_t dst[MAX_ROUNDS];
+#pragma unroll
+    for (int j = 0; j < MAX_ROUNDS; j++)
+    {
+        dst[j] = 0;
+        if ((uint32_t) j >= rounds)     /* uniform: a tile holds 3.8 entries per splat on average, 8 at most */
+            continue;
+        const uint32_t e = first + j * 64;
+        const bool valid = e < tileCount;
+        const uint32_t digit = keys[j] & dmask;
+        uint64_t peers = __ballot(valid);
+        for (uint32_t b = 0; b < digitBits; b++)
+        {
+            const bool bit = (digit >> b) & 1u;
+            const uint64_t m = __ballot(bit);
+            peers &= bit ? m : ~m;
+        }
+        dst[j] = 0;
+        if (valid)
+        {
+            const uint32_t rank = popcBelow(peers);
+            dst[j] = waveBins[wave][digit] + rank;
+            sKeys[dst[j]] = keys[j];
+            if (rank == 0)
+                waveBins[wave][digit] = dst[j] + (uint32_t) __popcll(peers);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    uint32_t out[MAX_ROUNDS];
+#pragma unroll
+    for (int k = 0; k < MAX_ROUNDS; k++)
+    {
+        const uint32_t p = threadIdx.x + k * ENT_TILE;
+        out[k] = 0;
+        if (p < tileCount)
+        {
+            const uint32_t key = sKeys[p];
+            out[k] = tileBase[key & dmask] + p;
+            keysOut[out[k]] = key;
+        }
+    }
+    /* the ids take the same route: every thread fetches the ids of ITS elements before anything is overwritten */
+    uint32_t vals[MAX_ROUNDS];
+#pragma unroll
+    for (int j = 0; j < MAX_ROUNDS; j++)
+    {
+        const uint32_t e = first + j * 64;
+        vals[j] = ((uint32_t) j < rounds && e < tileCount) ? sVals[e] : 0u;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < MAX_ROUNDS; j++)
+    {
+        const uint32_t e = first + j * 64;
+        if ((uint32_t) j < rounds && e < tileCount)
+            sVals[dst[j]] = vals[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < MAX_ROUNDS; k++)
+    {
+        const uint32_t p = threadIdx.x + k * ENT_TILE;
+        if (p < tileCount)
+            valsOut[out[k]] = sVals[p];
+    }
+}
 
 /* countCommands (kernels/octree.cl:230-239) as the scan's producer.  The reference leaves the
  * last indicator unwritten; an exclusive scan never reads it, so any value serves. */
@@ -426,20 +671,44 @@ MLSGPU_API int mlsgpu_hip_tree_build(mlsgpu_tree *t, mlsgpu_splat *dSplats, uint
     if (numSplats > 0)
     {
         EntryParams P{dSplats, offset[0], offset[1], offset[2], lo, minShift, maxShift, (uint32_t) firstSplat};
-        /* writeEntries: count, scan, write compacted; the entry count stays on the device (t->dNumEntries) */
-        PROPAGATE((exclusiveScan2<uint32_t, EntryCountIn, EntryMaskIn, EntryWriteOut>(
-            ctx, "kernel.octree.writeEntries.time", EntryCountIn{P, t->dSlotMasks}, EntryMaskIn{t->dSlotMasks},
-            EntryWriteOut{P, t->dSlotMasks, t->dKeysA, t->dValsA}, numSplats, 0u, t->dTileSums, t->dNumEntries)));
-        /* The entry count (2.4 .. 3.8 per splat on the BASELINE clouds, 8 at most) comes back to the host here: the sort
-         * and the command scan launch on n instead of 8N elements, which more than pays for the one synchronisation
-         * (cfg3: -2.6 % per step on the noise cloud, -2 % on the shells cloud; the other worker fills the gap). */
-        PROPAGATE(t->entryBox.publish(ctx->stream, t->dNumEntries, 1));
-        PROPAGATE(t->entryBox.wait(ctx->stream));
-        const uint64_t sortN = t->entryBox.payload()[0];
+        const uint32_t keyBits = (uint32_t) (3 * (maxShift - minShift) + 1);
+        const uint32_t passes = sortPasses(keyBits, SortCaps<uint32_t>::MAX_DIGIT_BITS);
+        const uint32_t perPass = (keyBits + passes - 1) / passes;
+        static const bool fusedOff = getenv("MLSGPU_HIP_OCTREE_FUSED") != nullptr && atoi(getenv("MLSGPU_HIP_OCTREE_FUSED")) == 0;
+        const bool fused = perPass <= ENT_BIN_BITS && !fusedOff;      /* wider digits (deep trees) take the separate passes */
+        uint64_t sortN = 0;
         SortResult<uint32_t> sorted;
-        PROPAGATE(radixSort<uint32_t>(ctx, "kernel.octree.sort.time", t->dKeysA, t->dValsA, t->dKeysB, t->dValsB,
-                                      sortN, (uint32_t) (3 * (maxShift - minShift) + 1), false,
-                                      t->dHist, t->dTileSums, &sorted, t->dNumEntries));
+        if (fused)
+        {
+            /* writeEntries + the sort's first pass as one count / digit scan / scatter, see entryScatterKernel */
+            const char *stat = "kernel.octree.writeEntries.time";
+            const uint32_t tilesE = divUp(numSplats, ENT_TILE);
+            uint32_t *const dDigitTotals = t->dHist + (uint64_t) (1u << perPass) * tilesE;
+            LAUNCH(ctx, stat, entryHistKernel, dim3(tilesE), dim3(ENT_TILE), P, t->dSlotMasks, t->dHist, tilesE, numSplats, perPass);
+            LAUNCH(ctx, stat, (sortDigitScanKernel<uint32_t>), dim3(1u << perPass), dim3(PRIM_BLOCK), t->dHist, dDigitTotals, tilesE);
+            LAUNCH(ctx, stat, entryTotalKernel, dim3(1), dim3(256), (const uint32_t *) dDigitTotals, 1u << perPass, t->dNumEntries);
+            /* The entry count (2.4 .. 3.8 per splat on the BASELINE clouds, 8 at most) comes back to the host: the remaining
+             * sort pass and the command scan launch on n instead of 8N elements. */
+            PROPAGATE(t->entryBox.publish(ctx->stream, t->dNumEntries, 1));
+            LAUNCH(ctx, stat, entryScatterKernel, dim3(tilesE), dim3(ENT_TILE), P, (const uint8_t *) t->dSlotMasks,
+                   (const uint32_t *) t->dHist, (const uint32_t *) dDigitTotals, tilesE, numSplats, perPass, t->dKeysB, t->dValsB);
+            PROPAGATE(t->entryBox.wait(ctx->stream));
+            sortN = t->entryBox.payload()[0];
+            PROPAGATE(radixSort<uint32_t>(ctx, "kernel.octree.sort.time", t->dKeysB, t->dValsB, t->dKeysA, t->dValsA,
+                                          sortN, keyBits, false, t->dHist, t->dTileSums, &sorted, t->dNumEntries, perPass));
+        }
+        else
+        {
+            /* writeEntries: count, scan, write compacted; the entry count stays on the device (t->dNumEntries) */
+            PROPAGATE((exclusiveScan2<uint32_t, EntryCountIn, EntryMaskIn, EntryWriteOut>(
+                ctx, "kernel.octree.writeEntries.time", EntryCountIn{P, t->dSlotMasks}, EntryMaskIn{t->dSlotMasks},
+                EntryWriteOut{P, t->dSlotMasks, t->dKeysA, t->dValsA}, numSplats, 0u, t->dTileSums, t->dNumEntries)));
+            PROPAGATE(t->entryBox.publish(ctx->stream, t->dNumEntries, 1));
+            PROPAGATE(t->entryBox.wait(ctx->stream));
+            sortN = t->entryBox.payload()[0];
+            PROPAGATE(radixSort<uint32_t>(ctx, "kernel.octree.sort.time", t->dKeysA, t->dValsA, t->dKeysB, t->dValsB,
+                                          sortN, keyBits, false, t->dHist, t->dTileSums, &sorted, t->dNumEntries));
+        }
         /* countCommands + scan(seed 1) + writeSplatIds, src/splat_tree_cl.cpp:310-317 */
         IndicatorIn in{sorted.keys, t->dNumEntries};
         SplatIdsOut outF{t->dCommands, t->dStart, t->dJumpPos, sorted.keys, sorted.vals, t->dNumEntries};

@@ -525,8 +525,10 @@ static inline uint64_t sortHistElems(uint64_t n) { return (uint64_t) SORT_MAX_BI
 template<typename K>
 static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *valsA, K *keysB, uint32_t *valsB,
                      uint64_t n, uint32_t bits, bool iota, uint32_t *dHist, uint32_t *dTileSums,
-                     SortResult<K> *result, const uint32_t *nDev = nullptr)
+                     SortResult<K> *result, const uint32_t *nDev = nullptr, uint32_t doneBits = 0)
 {
+    /* doneBits: the lowest doneBits key bits have been sorted already (by a pass of that width fused into the producer of
+     * the keys); the remaining passes keep the split of the whole sort */
     result->keys = keysA;
     result->vals = valsA;
     if (n == 0)
@@ -545,10 +547,10 @@ static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *
     }
     const uint32_t passes = sortPasses(bits, maxDigit);
     const uint32_t perPass = (bits + passes - 1) / passes;
-    uint32_t shift = 0;
+    uint32_t shift = doneBits;
     K *kin = keysA, *kout = keysB;
     uint32_t *vin = valsA, *vout = valsB;
-    for (uint32_t p = 0; p < passes; p++)
+    for (uint32_t p = 0; shift < bits; p++)
     {
         const uint32_t digitBits = (bits - shift) < perPass ? (bits - shift) : perPass;
         LAUNCH(ctx, statName, (sortHistKernel<K>), dim3(tiles), dim3(PRIM_BLOCK),

@@ -1,12 +1,17 @@
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out/r03
-bash tools/profile_run.sh r03 > gpurun_out/r03/profile_run.log 2>&1
-tail -3 gpurun_out/r03/profile_run.log
-for ct in 4 8 16; do
-python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-partition --no-sink --copy-threads $ct > gpurun_out/r03/bench_legs_ct$ct.json 2> gpurun_out/r03/bench_legs.err
+(timeout 600 python -m pytest tests/test_gpu_tree.py tests/test_gpu_bucket.py -x -q -m gpu) 2>&1 | tail -2
+rm -rf /tmp/prof_f
+rocprofv3 --kernel-trace --stats -d /tmp/prof_f -o run -- python3 bench.py --headline-only --no-timing --workers 1 --steps 5 --warmup 1 > gpurun_out/r03/prof_f.log 2>&1
+python3 tools/profile_summary.py stats /tmp/prof_f gpurun_out/r03/fused_kernel_stats.csv "fused"
+grep -E "entry|sortDigit|sortHist|sortScatter" gpurun_out/r03/fused_kernel_stats.csv | cut -c1-150
+for f in 0 1; do
+MLSGPU_HIP_OCTREE_FUSED=$f python bench.py --headline-only --steps 60 > gpurun_out/r03/head_fused$f.json 2> gpurun_out/r03/head_fused$f.err
 python - <<P
 import json
-d=json.loads(open('gpurun_out/r03/bench_legs_ct$ct.json').read().strip().splitlines()[-1])
-t=d['transfer_inclusive']; s=d['shells']['transfer_inclusive']
-print('ct $ct uniform ship', t['shipouts']['ms_per_step'], 'sink', t['device_sink']['ms_per_step'], t['device_sink']['one_job_alone_ms'], '| shells ship', s['shipouts']['ms_per_step'], 'sink', s['device_sink']['ms_per_step'], s['device_sink']['one_job_alone_ms'])
+d=json.loads(open('gpurun_out/r03/head_fused$f.json').read().strip().splitlines()[-1])
+k=d['kernel_ms_per_step']
+print('fused $f', d['value'], d['ms_per_step'], 'compute', k['device.compute'], 'entries', k['kernel.octree.writeEntries.time'], 'sort', k['kernel.octree.sort.time'], d['output_digest'].get('ok'))
 P
 done
