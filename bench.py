@@ -891,14 +891,18 @@ def main():
     if kernel_stats and not args.no_timing:
         K = ksteps
         T, O, Vw, C = 3 * triangles, mc["occupied"], vertices, voxels
-        sort_passes = 2       # 17 key bits at <= 10 bits per pass
+        # 16 key bits in two 8-bit passes; the first is fused into writeEntries (octree.hip entryScatterKernel) unless
+        # MLSGPU_HIP_OCTREE_FUSED=0, so the sort stage proper is one pass
+        sort_passes = 2 if os.environ.get("MLSGPU_HIP_OCTREE_FUSED") == "0" else 1
+        we_name = "writeEntries (count+scan+write%s)" % (", first sort pass fused" if sort_passes == 1 else "")
+        sort_name = "sortHist+sortScatter (octree entries, %d pass)" % sort_passes
         nb_splats = int(bucketed_t.shape[0])
         models = {
             # stat name: (kernel, algorithmic bytes per step)
             "kernel.mls.processCorners.time": ("processCorners", 36 * listed + 4 * corners),
-            "kernel.octree.sort.time": ("sortHist+sortScatter (octree entries)", sort_passes * 20 * entries),
+            "kernel.octree.sort.time": (sort_name, sort_passes * 20 * entries),
             # 16 N read + 16 N written back (1 / r^2) + 8 E' of entries
-            "kernel.octree.writeEntries.time": ("writeEntries (count+scan+write)", 32 * nb_splats + 8 * entries),
+            "kernel.octree.writeEntries.time": (we_name, 32 * nb_splats + 8 * entries),
             "kernel.octree.scan.time": ("countCommands+scan+writeSplatIds", 2 * 4 * entries + 8 * entries + 4 * entries),
             "kernel.marching.generateElements.time": ("latticeTriangles", 4 * T + 16 * O + O),
             "kernel.marching.compactVertices.time": ("latticeVertices", 12 * Vw + 8 * external + 8 * Vw),
@@ -914,9 +918,9 @@ def main():
                 tj = {}
         traffic_of = {"processCorners": ["processCorners"], "latticeTriangles": ["latticeTriangles"],
                       "latticeVertices": ["latticeVertices"], "latticeMask": ["latticeMask"],
-                      "cellCode+classify": ["cellCode"], "writeEntries (count+scan+write)": ["writeEntries"],
+                      "cellCode+classify": ["cellCode"], we_name: ["writeEntries"],
                       "countCommands+scan+writeSplatIds": ["writeSplatIds"],
-                      "sortHist+sortScatter (octree entries)": ["sortHist", "sortScatter"]}
+                      sort_name: ["sortHist", "sortScatter"]}
         stages = []
         for stat, (kname, nb) in models.items():
             if stat in kernel_stats and kernel_stats[stat][1] > 0:

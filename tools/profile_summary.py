@@ -35,7 +35,7 @@ TRACKED = {
     "sortScatter": "sortScatterKernel",
     "sortHist": "sortHistKernel",
     "cellCode": "cellCodeKernel",
-    "writeEntries": "EntryWriteOut",
+    "writeEntries": "entryScatterKernel",
     "writeSplatIds": "SplatIdsOut",
 }
 
