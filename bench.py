@@ -751,6 +751,21 @@ def main():
         ctx.set_timing(False)
         kernel_stats = dict(ctx.stats())
 
+    # ---- one worker alone, nothing instrumented: what the host decisions and launch gaps of a bucket cost when no other
+    # worker fills them (the instrumented device.compute above carries two event records per launch) ----
+    single_worker_ms = None
+    if not args.no_timing:
+        sw_steps = max(3, min(args.steps, 10))
+        col1 = m.binding.SizeCollector()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(sw_steps):
+            for b in buckets:
+                m.binding.check(m.lib().mlsgpu_hip_memcpy_d2d(ctx.h, work.ptr + 32 * b.first, pristine.ptr + 32 * b.first, 32 * b.count))
+                workers[0].process(work, b.first, b.count, b.low, b.num_vertices, collector=col1)
+        ctx.synchronize()
+        single_worker_ms = (time.perf_counter() - t0) / sw_steps * 1e3
+
     # ---- algorithmic work + output digest (one instrumented, untimed pass on worker 0) ----
     counters = m.DeviceBuffer(ctx, array=np.zeros(3, np.uint64))
     w0 = workers[0]
@@ -1000,6 +1015,10 @@ def main():
                 "peak_GBps": HBM_PEAK_GBS, "frac": round(moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "note": "PMC traffic of the tracked kernels / step time with %d device workers" % nworkers}
         result["kernel_ms_per_step"] = {k: round(v[0] / K, 3) for k, v in sorted(kernel_stats.items())}
+        result["single_worker_ms_per_step"] = {
+            "value": round(single_worker_ms, 3),
+            "what": "the same buckets on ONE device worker, un-instrumented (three host decisions and ~40 launches per bucket "
+                    "with nothing to overlap them); kernel_ms_per_step['device.compute'] is the instrumented pass"}
         result["work_per_step"] = {"octree_entries": entries, "occupied_cells": O, "unwelded_vertices": mc["unwelded"],
                                    "welded_vertices": Vw, "external_vertices": external, "indices": T}
 

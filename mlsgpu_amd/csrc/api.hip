@@ -100,10 +100,13 @@ namespace
 {
 __global__ void mailboxPublishKernel(const uint32_t *src, uint32_t words, uint32_t *box, uint32_t seq)
 {
-    for (uint32_t i = 0; i < words; i++)
-        __hip_atomic_store(box + 1 + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    /* one wave: a word per lane, then lane 0 publishes behind a system-scope fence (the stores of one wave instruction are
+     * ordered before it) */
+    if (threadIdx.x < words)
+        __hip_atomic_store(box + 1 + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __threadfence_system();
-    __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0)
+        __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 } // namespace
 
@@ -134,10 +137,8 @@ void mlsgpu::HostMailbox::destroy()
 int mlsgpu::HostMailbox::publish(hipStream_t stream, const void *src, uint32_t words)
 {
     REQUIRE(host != nullptr && words <= WORDS, MLSGPU_ERR_INVALID);
-    seq++;
-    if (seq == 0)
-        seq = 1;
-    hipLaunchKernelGGL(mailboxPublishKernel, dim3(1), dim3(1), 0, stream, static_cast<const uint32_t *>(src), words, dev, seq);
+    reserve();
+    hipLaunchKernelGGL(mailboxPublishKernel, dim3(1), dim3(64), 0, stream, static_cast<const uint32_t *>(src), words, dev, seq);
     HIP_CHECK(hipGetLastError());
     return MLSGPU_OK;
 }

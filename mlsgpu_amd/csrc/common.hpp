@@ -126,13 +126,22 @@ namespace mlsgpu
  */
 struct HostMailbox
 {
-    enum { WORDS = 8 };
+    enum { WORDS = 12 };
     uint32_t *host = nullptr;       /* [0] = sequence number of the last publication, [1 .. WORDS] = payload */
     uint32_t *dev = nullptr;        /* the same memory as the device sees it */
     uint32_t seq = 0;
 
     int create();
     void destroy();
+    /* for a kernel that publishes by itself (payload words first, then a system-scope fence, then the sequence number into
+     * dev[0]): the sequence number it has to write; wait() then waits for that one */
+    uint32_t reserve()
+    {
+        seq++;
+        if (seq == 0)
+            seq = 1;
+        return seq;
+    }
     /* enqueue: copy `words` 32-bit words from device memory `src` to the mailbox (on `stream`) */
     int publish(hipStream_t stream, const void *src, uint32_t words);
     /* block until the last publication has landed; the payload is host[1 ..] */

@@ -249,7 +249,8 @@ __global__ __launch_bounds__(ENT_TILE) void entryHistKernel(EntryParams P, uint8
 }
 
 /* the number of entries = the sum of the digit totals */
-__global__ __launch_bounds__(256) void entryTotalKernel(const uint32_t *digitTotals, uint32_t numBins, uint32_t *total)
+__global__ __launch_bounds__(256) void entryTotalKernel(const uint32_t *digitTotals, uint32_t numBins, uint32_t *total,
+                                                        uint32_t *box, uint32_t seq)
 {
     __shared__ uint32_t waveTotals[4];
     uint32_t v = 0;
@@ -260,7 +261,14 @@ __global__ __launch_bounds__(256) void entryTotalKernel(const uint32_t *digitTot
         waveTotals[threadIdx.x >> 6] = v;
     __syncthreads();
     if (threadIdx.x == 0)
-        *total = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
+    {
+        const uint32_t sum = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
+        *total = sum;
+        /* ... and straight to the host (HostMailbox): the count sizes the launches that follow */
+        __hip_atomic_store(box + 1, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();
+        __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 __global__ __launch_bounds__(ENT_TILE) void entryScatterKernel(EntryParams P, const uint8_t *slotMasks, const uint32_t *hist,
@@ -686,10 +694,11 @@ MLSGPU_API int mlsgpu_hip_tree_build(mlsgpu_tree *t, mlsgpu_splat *dSplats, uint
             uint32_t *const dDigitTotals = t->dHist + (uint64_t) (1u << perPass) * tilesE;
             LAUNCH(ctx, stat, entryHistKernel, dim3(tilesE), dim3(ENT_TILE), P, t->dSlotMasks, t->dHist, tilesE, numSplats, perPass);
             LAUNCH(ctx, stat, (sortDigitScanKernel<uint32_t>), dim3(1u << perPass), dim3(PRIM_BLOCK), t->dHist, dDigitTotals, tilesE);
-            LAUNCH(ctx, stat, entryTotalKernel, dim3(1), dim3(256), (const uint32_t *) dDigitTotals, 1u << perPass, t->dNumEntries);
             /* The entry count (2.4 .. 3.8 per splat on the BASELINE clouds, 8 at most) comes back to the host: the remaining
              * sort pass and the command scan launch on n instead of 8N elements. */
-            PROPAGATE(t->entryBox.publish(ctx->stream, t->dNumEntries, 1));
+            const uint32_t seq = t->entryBox.reserve();
+            LAUNCH(ctx, stat, entryTotalKernel, dim3(1), dim3(256), (const uint32_t *) dDigitTotals, 1u << perPass, t->dNumEntries,
+                   t->entryBox.dev, seq);
             LAUNCH(ctx, stat, entryScatterKernel, dim3(tilesE), dim3(ENT_TILE), P, (const uint8_t *) t->dSlotMasks,
                    (const uint32_t *) t->dHist, (const uint32_t *) dDigitTotals, tilesE, numSplats, perPass, t->dKeysB, t->dValsB);
             PROPAGATE(t->entryBox.wait(ctx->stream));
