@@ -366,8 +366,10 @@ int mlsgpu_hip_bucket_load(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, const u
  * device item is filled by mlsgpu_hip_bucket_load (gather of dIds + transform into fullGrid's vertex coordinates) --
  * no host copy.  Like a host bucket it goes to the device group with the most unallocated capacity
  * (src/workers.cpp:320-351), `device`'s own on a tie: for another GPU the gather runs on `device` and the item is
- * filled by a peer copy, so a cloud resident on one GPU feeds all of them.  dIds may be reused when the call returns.
- * lowExtent / numVertices as for mlsgpu_hip_worker_process.  */
+ * filled by a peer copy on the target's copy stream out of a ring of scratch buffers on `device` (gather -> copy -> reuse of
+ * the slot are ordered by events on the GPUs), so a cloud resident on one GPU feeds all of them with several leaves in
+ * flight.  The call returns when the gather has run: dIds may be reused, the peer copy and the bucket go on without the
+ * caller.  lowExtent / numVertices as for mlsgpu_hip_worker_process.  */
 int mlsgpu_hip_farm_submit_device(mlsgpu_farm *farm, int device, const mlsgpu_splat *dSplats, const uint32_t *dIds,
                                   uint64_t numSplats, const mlsgpu_grid *fullGrid, const int32_t lowExtent[3],
                                   const uint32_t numVertices[3], uint64_t chunkId);
