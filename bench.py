@@ -515,8 +515,17 @@ def multi_gpu_legs(m, args, result, dist, reduce_device, rank, world, local_rank
     import torch
 
     from mlsgpu_amd import dist_sink
-    host = bucketed_t.cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
-    views = [host[b.first:b.first + b.count] for b in buckets]
+
+    class LegFailed(Exception):
+        pass
+
+    def all_ok(ok, what):
+        """collective: True on every rank iff every rank is fine -- a rank that failed locally must not leave the others in
+        a collective it never reaches"""
+        t = torch.tensor([1 if ok else 0], dtype=torch.int64, device=reduce_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if int(t.item()) != 1:
+            raise LegFailed(what)
 
     def wall(fn, steps):
         """max over ranks of the time of `steps` calls, bracketed by barriers"""
@@ -534,107 +543,148 @@ def multi_gpu_legs(m, args, result, dist, reduce_device, rank, world, local_rank
         return float(t.item()) / steps, out
 
     # ---- transfer-inclusive, every rank, with the cross-rank weld ----
-    sink = m.Mesher(ctx, 0.02)
-    bfarm = m.BucketFarm([local_rank], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
-                         mesh_memory=args.mesh_memory_mb << 20, sink=sink)
-    pinned = m.binding.PinnedBuffer(1)
+    local_error = None
+    host = views = sink = bfarm = pinned = None
+    try:
+        host = bucketed_t.cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
+        views = [host[b.first:b.first + b.count] for b in buckets]
+        sink = m.Mesher(ctx, 0.02)
+        bfarm = m.BucketFarm([local_rank], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
+                             mesh_memory=args.mesh_memory_mb << 20, sink=sink)
+        pinned = m.binding.PinnedBuffer(1)
+    except Exception as e:      # noqa: BLE001
+        local_error = "%s: %s" % (type(e).__name__, e)
     parts = {}
 
     def sink_pass():
+        nonlocal local_error
         t0 = time.perf_counter()
-        for b, v in zip(buckets, views):
-            bfarm.submit(v, b.low, b.num_vertices, rank)
-        bfarm.finish()
-        t1 = time.perf_counter()
-        nchunks, stats = dist_sink.global_prune(sink, 0.02, dist)
-        t2 = time.perf_counter()
+        mine = None
+        try:
+            for b, v in zip(buckets, views):
+                bfarm.submit(v, b.low, b.num_vertices, rank)
+            bfarm.finish()
+            t1 = time.perf_counter()
+            mine = sink.boundary()
+        except Exception as e:      # noqa: BLE001
+            local_error = "%s: %s" % (type(e).__name__, e)
+        all_ok(local_error is None, "pass / boundary export")
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        keep, stats = dist_sink.merge_boundaries(gathered, 0.02)       # the same computation on every rank
         nbytes = 0
-        for i in range(nchunks):
-            nbytes += m.binding.download_into_pinned(ctx, sink.chunk(i, download=False), pinned)
-        ctx.synchronize()
-        t3 = time.perf_counter()
-        sink.reset()
-        parts.update(pass_ms=(t1 - t0) * 1e3, weld_ms=(t2 - t1) * 1e3, readback_ms=(t3 - t2) * 1e3, nbytes=nbytes, stats=stats)
+        try:
+            nchunks = sink.finalize_with(keep[rank])
+            t2 = time.perf_counter()
+            for i in range(nchunks):
+                nbytes += m.binding.download_into_pinned(ctx, sink.chunk(i, download=False), pinned)
+            ctx.synchronize()
+            t3 = time.perf_counter()
+            sink.reset()
+            parts.update(pass_ms=(t1 - t0) * 1e3, weld_ms=(t2 - t1) * 1e3, readback_ms=(t3 - t2) * 1e3, nbytes=nbytes, stats=stats)
+        except Exception as e:      # noqa: BLE001
+            local_error = "%s: %s" % (type(e).__name__, e)
+        all_ok(local_error is None, "verdict pass / read-back")
         return nbytes
-    sink_pass()                                       # warm-up: arenas, pinned landing buffer
-    dt, nbytes = wall(sink_pass, L)
-    tot = torch.tensor([float(nbytes), float(host.nbytes)], dtype=torch.float64, device=reduce_device)
-    dist.all_reduce(tot)
-    st = parts["stats"]
-    result["transfer_inclusive"] = {
-        "device_sink_global_weld": {
-            "value": round(voxels * world / dt / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(dt * 1e3, 3),
-            "h2d_GB_per_step": round(float(tot[1].item()) / 1e9, 3), "d2h_GB_per_step": round(float(tot[0].item()) / 1e9, 3),
-            "rank0_ms": {k: round(parts[k], 2) for k in ("pass_ms", "weld_ms", "readback_ms")},
-            "whole_job": {k: int(st[k]) for k in ("total_vertices", "components", "kept_components", "kept_vertices", "kept_triangles")},
-            "note": "every rank at once: host splats -> pinned staging -> H2D -> %d device workers -> ship-outs appended in HBM -> "
-                    "per-rank weld + boundary export -> ONE all-gather -> merged components and prune threshold (0.02 of the "
-                    "whole job) -> output pass -> the rank's mesh read back into pinned memory; time = slowest rank" % nworkers},
-        "distribution": "uniform"}
-    bfarm.close()
-    sink.close()
-    pinned.free()
+    try:
+        all_ok(local_error is None, "set-up")
+        sink_pass()                                       # warm-up: arenas, pinned landing buffer
+        dt, nbytes = wall(sink_pass, L)
+        tot = torch.tensor([float(nbytes), float(host.nbytes)], dtype=torch.float64, device=reduce_device)
+        dist.all_reduce(tot)
+        st = parts["stats"]
+        result["transfer_inclusive"] = {
+            "device_sink_global_weld": {
+                "value": round(voxels * world / dt / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(dt * 1e3, 3),
+                "h2d_GB_per_step": round(float(tot[1].item()) / 1e9, 3), "d2h_GB_per_step": round(float(tot[0].item()) / 1e9, 3),
+                "rank0_ms": {k: round(parts[k], 2) for k in ("pass_ms", "weld_ms", "readback_ms")},
+                "whole_job": {k: int(st[k]) for k in ("total_vertices", "components", "kept_components", "kept_vertices", "kept_triangles")},
+                "note": "every rank at once: host splats -> pinned staging -> H2D -> %d device workers -> ship-outs appended in HBM -> "
+                        "per-rank weld + boundary export -> ONE all-gather -> merged components and prune threshold (0.02 of the "
+                        "whole job) -> output pass -> the rank's mesh read back into pinned memory; time = slowest rank" % nworkers},
+            "distribution": "uniform"}
+    except LegFailed as e:
+        result["transfer_inclusive"] = {"error": "a rank failed in %s%s" % (e, ": " + local_error if local_error else "")}
+    for obj in (bfarm, sink):
+        try:
+            if obj is not None:
+                obj.close()
+        except Exception:       # noqa: BLE001
+            pass
+    if pinned is not None:
+        pinned.free()
 
     # ---- the reference's shape: one process, N device groups; rank 0 drives, the others wait ----
     devices = [d % ndev for d in range(world)]
     single = None
     dist.barrier()
-    if rank == 0:
-        sfarm = m.BucketFarm(devices, max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
-                             mesh_memory=args.mesh_memory_mb << 20)
-
-        def host_fed():
-            for rep in range(world):
-                for i, (b, v) in enumerate(zip(buckets, views)):
-                    sfarm.submit(v, b.low, b.num_vertices, rep)
-            sfarm.finish()
-        host_fed()
-        s0 = sfarm.stats()
-        t0 = time.perf_counter()
-        for _ in range(L):
-            host_fed()
-        host_s = (time.perf_counter() - t0) / L
-        s1 = sfarm.stats()
-        # the same buckets resident on GPU 0, handed out by device gathers (another GPU's group: scratch ring + peer copy)
-        raw = m.DeviceBuffer(ctx, nbytes=bucketed_t.numel() * 4, borrow=bucketed_t.data_ptr())
-        iota = m.DeviceBuffer(ctx, array=np.arange(max_count, dtype=np.uint32))
-        gx, gy, gz = result["_grid"]
-        ext = (0, gx - 1, 0, gy - 1, 0, gz - 1)
-
-        class _Sub:
-            def __init__(self, ptr):
-                self.ptr = ptr
-
-        def device_fed():
-            for rep in range(world):
-                for b in buckets:
-                    sfarm.submit_device(local_rank, _Sub(raw.ptr + 32 * b.first), iota.ptr, b.count, (0.0, 0.0, 0.0), 1.0, ext,
-                                        b.low, b.num_vertices, rep)
-            sfarm.finish()
-        device_fed()
-        s1b = sfarm.stats()
-        t0 = time.perf_counter()
-        for _ in range(L):
-            device_fed()
-        dev_s = (time.perf_counter() - t0) / L
-        s2 = sfarm.stats()
-        single = {
-            "devices": devices, "buckets_per_pass": world * len(buckets),
-            "host_fed": {"value": round(voxels * world / host_s / 1e6, 3), "unit": "Mvoxels/s", "ms_per_pass": round(host_s * 1e3, 2),
-                         "h2d_GBps": round((s1["h2d_bytes"] - s0["h2d_bytes"]) / L / host_s / 1e9, 2)},
-            "device_fed": {"value": round(voxels * world / dev_s / 1e6, 3), "unit": "Mvoxels/s", "ms_per_pass": round(dev_s * 1e3, 2)},
-            "buckets_per_device_device_fed": [int(x) for x in (np.array(s2["per_device"][:world]) - np.array(s1b["per_device"][:world]))],
-            "device_fed_passes": L,
-            "in_flight_max": s2["in_flight_max"],
-            "note": "ONE process (rank 0) with one device group per GPU, %d workers each, the other ranks idle: N x rank 0's slab "
-                    "from pageable host memory through ONE copy side (4 copy threads -> pinned staging -> H2D to the chosen "
-                    "group), and from a cloud resident on GPU 0 (device gather, peer copy to other GPUs' items); meshes counted "
-                    "only" % nworkers}
-        sfarm.close()
-        del raw, iota
+    try:
+        if rank == 0:
+            single = single_process_leg(m, args, result, ctx, local_rank, devices, bucketed_t, buckets, views, max_count, max_cells,
+                                        voxels, L, nworkers, world)
+    except Exception as e:      # noqa: BLE001 - rank 0 still has to reach the barrier the others wait at
+        single = {"error": "%s: %s" % (type(e).__name__, e)}
     dist.barrier()
     if single is not None:
         result["single_process"] = single
+
+
+def single_process_leg(m, args, result, ctx, local_rank, devices, bucketed_t, buckets, views, max_count, max_cells, voxels, L,
+                       nworkers, world):
+    """The reference's own shape (src/mlsgpu_core.cpp:704-741) on rank 0: one farm over every GPU, N x rank 0's slab."""
+    sfarm = m.BucketFarm(devices, max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
+                         mesh_memory=args.mesh_memory_mb << 20)
+
+    def host_fed():
+        for rep in range(world):
+            for i, (b, v) in enumerate(zip(buckets, views)):
+                sfarm.submit(v, b.low, b.num_vertices, rep)
+        sfarm.finish()
+    host_fed()
+    s0 = sfarm.stats()
+    t0 = time.perf_counter()
+    for _ in range(L):
+        host_fed()
+    host_s = (time.perf_counter() - t0) / L
+    s1 = sfarm.stats()
+    # the same buckets resident on GPU 0, handed out by device gathers (another GPU's group: scratch ring + peer copy)
+    raw = m.DeviceBuffer(ctx, nbytes=bucketed_t.numel() * 4, borrow=bucketed_t.data_ptr())
+    iota = m.DeviceBuffer(ctx, array=np.arange(max_count, dtype=np.uint32))
+    gx, gy, gz = result["_grid"]
+    ext = (0, gx - 1, 0, gy - 1, 0, gz - 1)
+
+    class _Sub:
+        def __init__(self, ptr):
+            self.ptr = ptr
+
+    def device_fed():
+        for rep in range(world):
+            for b in buckets:
+                sfarm.submit_device(local_rank, _Sub(raw.ptr + 32 * b.first), iota.ptr, b.count, (0.0, 0.0, 0.0), 1.0, ext,
+                                    b.low, b.num_vertices, rep)
+        sfarm.finish()
+    device_fed()
+    s1b = sfarm.stats()
+    t0 = time.perf_counter()
+    for _ in range(L):
+        device_fed()
+    dev_s = (time.perf_counter() - t0) / L
+    s2 = sfarm.stats()
+    single = {
+        "devices": devices, "buckets_per_pass": world * len(buckets),
+        "host_fed": {"value": round(voxels * world / host_s / 1e6, 3), "unit": "Mvoxels/s", "ms_per_pass": round(host_s * 1e3, 2),
+                     "h2d_GBps": round((s1["h2d_bytes"] - s0["h2d_bytes"]) / L / host_s / 1e9, 2)},
+        "device_fed": {"value": round(voxels * world / dev_s / 1e6, 3), "unit": "Mvoxels/s", "ms_per_pass": round(dev_s * 1e3, 2)},
+        "buckets_per_device_device_fed": [int(x) for x in (np.array(s2["per_device"][:world]) - np.array(s1b["per_device"][:world]))],
+        "device_fed_passes": L,
+        "in_flight_max": s2["in_flight_max"],
+        "note": "ONE process (rank 0) with one device group per GPU, %d workers each, the other ranks idle: N x rank 0's slab "
+                "from pageable host memory through ONE copy side (4 copy threads -> pinned staging -> H2D to the chosen "
+                "group), and from a cloud resident on GPU 0 (device gather, peer copy to other GPUs' items); meshes counted "
+                "only" % nworkers}
+    sfarm.close()
+    del raw, iota
+    return single
 
 
 def main():
@@ -875,7 +925,8 @@ def main():
         if digest != CFG3_UNIFORM_DIGEST:
             raise SystemExit("output digest %s differs from the pinned %s: the timed pipeline did not produce the meshes "
                              "the parity tests check" % (digest, CFG3_UNIFORM_DIGEST))
-    if W["name"] == "cfg4slab" and args.scale == 1.0 and CFG4SLAB_DIGEST is not None:
+    # rank 0's slab of a SHARDED run (N >= 2: 128 cell slices; the one-slab grid of N = 1 has 127) is the pinned one
+    if W["name"] == "cfg4slab" and world > 1 and rank == 0 and args.scale == 1.0 and CFG4SLAB_DIGEST is not None:
         result["output_digest"]["expected"] = CFG4SLAB_DIGEST
         result["output_digest"]["ok"] = digest == CFG4SLAB_DIGEST
         if digest != CFG4SLAB_DIGEST:
@@ -1032,104 +1083,110 @@ def main():
     # ---- mesh-sink leg (never `value`): every ship-out of one pass appended to the device mesher (d2d), then
     # finalize = weld by key across buckets + connected components + prune (--fit-prune default 0.02) + compaction ----
     if secondary and not args.no_sink:
-        sink = m.Mesher(ctx, 0.02)
-        sink.reserve(mc["welded"] + 1024, mc["indices"] // 3 + 1024, mc["external"] + 1024)   # counts of the stats pass
-        work.copy_from(pristine)
-        ctx.synchronize()
+        try:     # a secondary leg never costs the line its headline
+            sink = m.Mesher(ctx, 0.02)
+            sink.reserve(mc["welded"] + 1024, mc["indices"] // 3 + 1024, mc["external"] + 1024)   # counts of the stats pass
+            work.copy_from(pristine)
+            ctx.synchronize()
 
-        def sink_share(k):
-            col = sink.collector(ctxs[k], 0)
-            for b in farm.worker_share(buckets, k, nworkers):
-                workers[k].process(work, b.first, b.count, b.low, b.num_vertices, collector=col)
-            ctxs[k].synchronize()
-        t0 = time.perf_counter()
-        list(pool.map(sink_share, range(nworkers)))
-        add_s = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        nchunks = sink.finalize()
-        ctx.synchronize()
-        fin_s = time.perf_counter() - t0
-        st = sink.stats()
-        result["mesh_sink"] = {
-            "pass_with_appends_ms": round(add_s * 1e3, 3), "finalize_ms": round(fin_s * 1e3, 3),
-            "finalize_mvertices_per_s": round(st["vertices_added"] / fin_s / 1e6, 1), "chunks": nchunks,
-            "vertices_added": st["vertices_added"], "triangles_added": st["triangles_added"],
-            "welded_vertices": st["total_vertices"], "components": st["components"], "kept_components": st["kept_components"],
-            "kept_vertices": st["kept_vertices"], "kept_triangles": st["kept_triangles"],
-            "device_workers": nworkers,
-            "note": "meshes never leave HBM; finalize = key sort + union-find + sizes + two compaction scans",
-        }
-        # what one rank of a one-process-per-GPU job pays instead of finalize: the boundary export, the merge of all ranks'
-        # exports (here: its own) and the output pass with the merged verdict (mlsgpu_amd/dist_sink.py)
-        from mlsgpu_amd import dist_sink
-        t0 = time.perf_counter()
-        part = sink.boundary()
-        b_s = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        keep, dstats = dist_sink.merge_boundaries([part], 0.02)
-        m_s = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        sink.finalize_with(keep[0])
-        ctx.synchronize()
-        f_s = time.perf_counter() - t0
-        result["mesh_sink"]["distributed"] = {
-            "boundary_ms": round(b_s * 1e3, 3), "merge_ms": round(m_s * 1e3, 3), "finalize_with_ms": round(f_s * 1e3, 3),
-            "keys": int(len(part[0])), "components": int(len(part[2])), "export_bytes": int(sum(a.nbytes for a in part)),
-            "same_verdict": dstats["kept_triangles"] == st["kept_triangles"] and dstats["total_vertices"] == st["total_vertices"]}
-        sink.close()
+            def sink_share(k):
+                col = sink.collector(ctxs[k], 0)
+                for b in farm.worker_share(buckets, k, nworkers):
+                    workers[k].process(work, b.first, b.count, b.low, b.num_vertices, collector=col)
+                ctxs[k].synchronize()
+            t0 = time.perf_counter()
+            list(pool.map(sink_share, range(nworkers)))
+            add_s = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            nchunks = sink.finalize()
+            ctx.synchronize()
+            fin_s = time.perf_counter() - t0
+            st = sink.stats()
+            result["mesh_sink"] = {
+                "pass_with_appends_ms": round(add_s * 1e3, 3), "finalize_ms": round(fin_s * 1e3, 3),
+                "finalize_mvertices_per_s": round(st["vertices_added"] / fin_s / 1e6, 1), "chunks": nchunks,
+                "vertices_added": st["vertices_added"], "triangles_added": st["triangles_added"],
+                "welded_vertices": st["total_vertices"], "components": st["components"], "kept_components": st["kept_components"],
+                "kept_vertices": st["kept_vertices"], "kept_triangles": st["kept_triangles"],
+                "device_workers": nworkers,
+                "note": "meshes never leave HBM; finalize = key sort + union-find + sizes + two compaction scans",
+            }
+            # what one rank of a one-process-per-GPU job pays instead of finalize: the boundary export, the merge of all ranks'
+            # exports (here: its own) and the output pass with the merged verdict (mlsgpu_amd/dist_sink.py)
+            from mlsgpu_amd import dist_sink
+            t0 = time.perf_counter()
+            part = sink.boundary()
+            b_s = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            keep, dstats = dist_sink.merge_boundaries([part], 0.02)
+            m_s = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            sink.finalize_with(keep[0])
+            ctx.synchronize()
+            f_s = time.perf_counter() - t0
+            result["mesh_sink"]["distributed"] = {
+                "boundary_ms": round(b_s * 1e3, 3), "merge_ms": round(m_s * 1e3, 3), "finalize_with_ms": round(f_s * 1e3, 3),
+                "keys": int(len(part[0])), "components": int(len(part[2])), "export_bytes": int(sum(a.nbytes for a in part)),
+                "same_verdict": dstats["kept_triangles"] == st["kept_triangles"] and dstats["total_vertices"] == st["total_vertices"]}
+            sink.close()
+        except Exception as e:      # noqa: BLE001 - reported in the line
+            result.setdefault("leg_errors", {})['mesh_sink'] = "%s: %s" % (type(e).__name__, e)
 
     # ---- device-bucketer leg (never `value`): the RAW cloud resident in HBM, partitioned on the device exactly as
     # the reference's Bucket::bucket would with its defaults (255-cell buckets, 63-cell microblocks, 2 097 152 splats,
     # src/mlsgpu_core.cpp:112-132,655-678), each leaf gathered + transformed on the device and run through a worker ----
     if secondary and not args.no_partition and W["cloud"] is not None:
-        from mlsgpu_amd import binding as mb
-        grid = W["grid"][0]
-        n_splats = W["n_splats"]
-        raw = m.DeviceBuffer(ctx, nbytes=W["cloud"].numel() * 4, borrow=W["cloud"].data_ptr())
-        ext = (0, grid - 1, 0, grid - 1, 0, grid - 1)
-        bp = dict(max_splats=args.partition_max_splats, max_cells=255, chunk_cells=0, micro_cells=63, max_split=1 << 30)
-        leaves = mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=lambda leaf, ids: None, **bp)
-        ctx.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(L):
-            mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=lambda leaf, ids: None, **bp)
-        ctx.synchronize()
-        part_s = (time.perf_counter() - t0) / L
-        pmax = max(l["num_splats"] for l in leaves)
-        pcells = max(max(l["extents"][2 * i + 1] - l["extents"][2 * i] for i in range(3)) for l in leaves)
-        # the bucketer's callback hands every leaf to the bucket farm's device path (gather + transform kernel into a
-        # device item, then the farm's worker threads), as CopyGroup does with host buckets
-        pfarm = m.BucketFarm([local_rank], pmax, workers_per_device=nworkers, spare=1, max_cells=pcells,
-                             mesh_memory=args.mesh_memory_mb << 20)
-        leaf_no = [0]
+        try:     # a secondary leg never costs the line its headline
+            from mlsgpu_amd import binding as mb
+            grid = W["grid"][0]
+            n_splats = W["n_splats"]
+            raw = m.DeviceBuffer(ctx, nbytes=W["cloud"].numel() * 4, borrow=W["cloud"].data_ptr())
+            ext = (0, grid - 1, 0, grid - 1, 0, grid - 1)
+            bp = dict(max_splats=args.partition_max_splats, max_cells=255, chunk_cells=0, micro_cells=63, max_split=1 << 30)
+            leaves = mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=lambda leaf, ids: None, **bp)
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(L):
+                mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=lambda leaf, ids: None, **bp)
+            ctx.synchronize()
+            part_s = (time.perf_counter() - t0) / L
+            pmax = max(l["num_splats"] for l in leaves)
+            pcells = max(max(l["extents"][2 * i + 1] - l["extents"][2 * i] for i in range(3)) for l in leaves)
+            # the bucketer's callback hands every leaf to the bucket farm's device path (gather + transform kernel into a
+            # device item, then the farm's worker threads), as CopyGroup does with host buckets
+            pfarm = m.BucketFarm([local_rank], pmax, workers_per_device=nworkers, spare=1, max_cells=pcells,
+                                 mesh_memory=args.mesh_memory_mb << 20)
+            leaf_no = [0]
 
-        def leaf_work(leaf, d_ids):
-            low = leaf["extents"][0::2]
-            nv = [leaf["extents"][2 * i + 1] - leaf["extents"][2 * i] + 1 for i in range(3)]
-            pfarm.submit_device(local_rank, raw, d_ids, leaf["num_splats"], (0.0, 0.0, 0.0), 1.0, ext, low, nv, leaf_no[0])
-            leaf_no[0] += 1
+            def leaf_work(leaf, d_ids):
+                low = leaf["extents"][0::2]
+                nv = [leaf["extents"][2 * i + 1] - leaf["extents"][2 * i] + 1 for i in range(3)]
+                pfarm.submit_device(local_rank, raw, d_ids, leaf["num_splats"], (0.0, 0.0, 0.0), 1.0, ext, low, nv, leaf_no[0])
+                leaf_no[0] += 1
 
-        def partition_pass():
-            mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=leaf_work, **bp)
-            pfarm.finish()
-        partition_pass()                            # warm-up
-        t0 = time.perf_counter()
-        for _ in range(L):
-            partition_pass()
-        pipe_s = (time.perf_counter() - t0) / L
-        pvox = sum((l["extents"][1] - l["extents"][0]) * (l["extents"][3] - l["extents"][2]) * (l["extents"][5] - l["extents"][4])
-                   for l in leaves)
-        result["device_partition"] = {
-            "buckets": len(leaves), "bucket_splats_total": int(sum(l["num_splats"] for l in leaves)),
-            "max_bucket_cells": int(pcells), "bucketing_ms": round(part_s * 1e3, 3),
-            "bucketing_msplats_per_s": round(n_splats / part_s / 1e6, 1),
-            "pipeline_ms_per_step": round(pipe_s * 1e3, 3), "pipeline_mvoxels_per_s": round(pvox / pipe_s / 1e6, 3),
-            "device_workers": nworkers,
-            "note": "raw cloud resident in HBM -> mlsgpu_hip_bucket (reference partition) -> mlsgpu_hip_farm_submit_device "
-                    "(device gather + transform) -> the farm's device workers; bucketing is inside the pipeline time",
-        }
-        pfarm.close()
-        del raw
+            def partition_pass():
+                mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=leaf_work, **bp)
+                pfarm.finish()
+            partition_pass()                            # warm-up
+            t0 = time.perf_counter()
+            for _ in range(L):
+                partition_pass()
+            pipe_s = (time.perf_counter() - t0) / L
+            pvox = sum((l["extents"][1] - l["extents"][0]) * (l["extents"][3] - l["extents"][2]) * (l["extents"][5] - l["extents"][4])
+                       for l in leaves)
+            result["device_partition"] = {
+                "buckets": len(leaves), "bucket_splats_total": int(sum(l["num_splats"] for l in leaves)),
+                "max_bucket_cells": int(pcells), "bucketing_ms": round(part_s * 1e3, 3),
+                "bucketing_msplats_per_s": round(n_splats / part_s / 1e6, 1),
+                "pipeline_ms_per_step": round(pipe_s * 1e3, 3), "pipeline_mvoxels_per_s": round(pvox / pipe_s / 1e6, 3),
+                "device_workers": nworkers,
+                "note": "raw cloud resident in HBM -> mlsgpu_hip_bucket (reference partition) -> mlsgpu_hip_farm_submit_device "
+                        "(device gather + transform) -> the farm's device workers; bucketing is inside the pipeline time",
+            }
+            pfarm.close()
+            del raw
+        except Exception as e:      # noqa: BLE001 - reported in the line
+            result.setdefault("leg_errors", {})['device_partition'] = "%s: %s" % (type(e).__name__, e)
     W["cloud"] = None
 
     # the remaining legs start from HOST memory: one copy of the bucketed splats
@@ -1141,51 +1198,57 @@ def main():
 
     # ---- transfer-inclusive legs (never `value`): SURVEY 8(d)'s region, host splats in -> last mesh byte out ----
     if secondary and not args.no_transfer:
-        result["transfer_inclusive"] = transfer_legs(m, args, local_rank, bucketed_host, buckets, max_count, max_cells, voxels, L)
-        result["transfer_inclusive"]["distribution"] = args.dist
+        try:     # a secondary leg never costs the line its headline
+            result["transfer_inclusive"] = transfer_legs(m, args, local_rank, bucketed_host, buckets, max_count, max_cells, voxels, L)
+            result["transfer_inclusive"]["distribution"] = args.dist
+        except Exception as e:      # noqa: BLE001 - reported in the line
+            result.setdefault("leg_errors", {})['transfer_inclusive'] = "%s: %s" % (type(e).__name__, e)
 
     # ---- D1 ("shells", SURVEY 8d: report both): resident rate and the same transfer-inclusive legs ----
     if secondary and not args.no_shells and args.dist == "uniform" and args.workload in ("auto", "cfg3"):
-        from mlsgpu_amd import synth
-        cloud, g = synth.make_cloud_device("cfg3", device, scale=args.scale, dist="shells")
-        sb_t, sbuckets = synth.bucketize_device(cloud, synth.grid_buckets((g, g, g), 255))
-        del cloud
-        torch.cuda.synchronize()
-        smax = max(b.count for b in sbuckets)
-        scells = max(max(b.num_vertices) for b in sbuckets) - 1
-        svox = sum(b.cells for b in sbuckets)
-        sprist = m.DeviceBuffer(ctx, nbytes=sb_t.numel() * 4, borrow=sb_t.data_ptr())
-        swork = m.DeviceBuffer(ctx, nbytes=sb_t.numel() * 4)
-        sworkers = [m.Worker(c, smax, max_cells=scells, mesh_memory=args.mesh_memory_mb << 20) for c in ctxs]
-        scol = [m.binding.SizeCollector() for _ in range(nworkers)]
+        try:     # a secondary leg never costs the line its headline
+            from mlsgpu_amd import synth
+            cloud, g = synth.make_cloud_device("cfg3", device, scale=args.scale, dist="shells")
+            sb_t, sbuckets = synth.bucketize_device(cloud, synth.grid_buckets((g, g, g), 255))
+            del cloud
+            torch.cuda.synchronize()
+            smax = max(b.count for b in sbuckets)
+            scells = max(max(b.num_vertices) for b in sbuckets) - 1
+            svox = sum(b.cells for b in sbuckets)
+            sprist = m.DeviceBuffer(ctx, nbytes=sb_t.numel() * 4, borrow=sb_t.data_ptr())
+            swork = m.DeviceBuffer(ctx, nbytes=sb_t.numel() * 4)
+            sworkers = [m.Worker(c, smax, max_cells=scells, mesh_memory=args.mesh_memory_mb << 20) for c in ctxs]
+            scol = [m.binding.SizeCollector() for _ in range(nworkers)]
 
-        def s_share(k):
-            for b in farm.worker_share(sbuckets, k, nworkers):
-                sworkers[k].process(swork, b.first, b.count, b.low, b.num_vertices, collector=scol[k])
-            ctxs[k].synchronize()
+            def s_share(k):
+                for b in farm.worker_share(sbuckets, k, nworkers):
+                    sworkers[k].process(swork, b.first, b.count, b.low, b.num_vertices, collector=scol[k])
+                ctxs[k].synchronize()
 
-        def s_step():
-            swork.copy_from(sprist)
-            ctx.synchronize()
-            list(pool.map(s_share, range(nworkers)))
-        for _ in range(2):
-            s_step()
-        ssteps = max(10, min(args.steps, 50))
-        scol[:] = [m.binding.SizeCollector() for _ in range(nworkers)]
-        t0 = time.perf_counter()
-        for _ in range(ssteps):
-            s_step()
-        s_dt = (time.perf_counter() - t0) / ssteps
-        shells = {"value": round(svox / s_dt / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(s_dt * 1e3, 3), "steps": ssteps,
-                  "workload": "cfg3 grid, %d splats on concentric shells (D1 of SURVEY 8d), %d buckets" % (int(50_000_000 * args.scale), len(sbuckets)),
-                  "triangles_per_step": sum(c.triangles for c in scol) // ssteps,
-                  "vertices_per_step": sum(c.vertices for c in scol) // ssteps}
-        sb_host = sb_t.cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1) if not args.no_transfer else None
-        del sworkers, swork, sprist, sb_t
-        torch.cuda.empty_cache()
-        if not args.no_transfer:
-            shells["transfer_inclusive"] = transfer_legs(m, args, local_rank, sb_host, sbuckets, smax, scells, svox, L)
-        result["shells"] = shells
+            def s_step():
+                swork.copy_from(sprist)
+                ctx.synchronize()
+                list(pool.map(s_share, range(nworkers)))
+            for _ in range(2):
+                s_step()
+            ssteps = max(10, min(args.steps, 50))
+            scol[:] = [m.binding.SizeCollector() for _ in range(nworkers)]
+            t0 = time.perf_counter()
+            for _ in range(ssteps):
+                s_step()
+            s_dt = (time.perf_counter() - t0) / ssteps
+            shells = {"value": round(svox / s_dt / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(s_dt * 1e3, 3), "steps": ssteps,
+                      "workload": "cfg3 grid, %d splats on concentric shells (D1 of SURVEY 8d), %d buckets" % (int(50_000_000 * args.scale), len(sbuckets)),
+                      "triangles_per_step": sum(c.triangles for c in scol) // ssteps,
+                      "vertices_per_step": sum(c.vertices for c in scol) // ssteps}
+            sb_host = sb_t.cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1) if not args.no_transfer else None
+            del sworkers, swork, sprist, sb_t
+            torch.cuda.empty_cache()
+            if not args.no_transfer:
+                shells["transfer_inclusive"] = transfer_legs(m, args, local_rank, sb_host, sbuckets, smax, scells, svox, L)
+            result["shells"] = shells
+        except Exception as e:      # noqa: BLE001 - reported in the line
+            result.setdefault("leg_errors", {})['shells'] = "%s: %s" % (type(e).__name__, e)
 
     # ---- CPU baseline: the oracle ("port") parallel over buckets on the host cores, rank 0 at N = 1 only ----
     # ---- SURVEY 8(d)'s own timed region at the top level of the line (never `value`: the contract wants inputs resident) ----
@@ -1198,10 +1261,13 @@ def main():
                       "pinned ring (SURVEY 8d's region; the noise cloud's 13.6 GB of mesh per step is bounded by the PCIe link)")
         result["value_8d_region"] = v8
     if rank == 0 and secondary and cpu_sample is not None:
-        cb = cpu_baseline(cpu_sample[0], cpu_sample[1], 63)
-        if cb is not None:
-            result["cpu_baseline"] = cb
-            result["gpu_over_cpu"] = round(value / cb["value"], 1)
+        try:     # a secondary leg never costs the line its headline
+            cb = cpu_baseline(cpu_sample[0], cpu_sample[1], 63)
+            if cb is not None:
+                result["cpu_baseline"] = cb
+                result["gpu_over_cpu"] = round(value / cb["value"], 1)
+        except Exception as e:      # noqa: BLE001 - reported in the line
+            result.setdefault("leg_errors", {})['cpu_baseline'] = "%s: %s" % (type(e).__name__, e)
 
     result.pop("_grid", None)
     if rank == 0:
