@@ -502,7 +502,7 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     return out
 
 
-def multi_gpu_legs(m, args, result, dist, reduce_device, rank, world, local_rank, ndev, ctx, bucketed_t, buckets, max_count,
+def multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, local_rank, ndev, ctx, bucketed_t, buckets, max_count,
                    max_cells, voxels, L, nworkers):
     """N > 1 only, never `value`.
     transfer_inclusive: SURVEY 8(d)'s region on every rank at once, with the weld in it -- host splats -> the rank's farm
@@ -617,14 +617,15 @@ def multi_gpu_legs(m, args, result, dist, reduce_device, rank, world, local_rank
     # ---- the reference's shape: one process, N device groups; rank 0 drives, the others wait ----
     devices = [d % ndev for d in range(world)]
     single = None
-    dist.barrier()
+    torch.cuda.synchronize()
+    dist.barrier(group=park)
     try:
         if rank == 0:
             single = single_process_leg(m, args, result, ctx, local_rank, devices, bucketed_t, buckets, views, max_count, max_cells,
                                         voxels, L, nworkers, world)
     except Exception as e:      # noqa: BLE001 - rank 0 still has to reach the barrier the others wait at
         single = {"error": "%s: %s" % (type(e).__name__, e)}
-    dist.barrier()
+    dist.barrier(group=park)
     if single is not None:
         result["single_process"] = single
 
@@ -717,6 +718,11 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+    # Ranks that only WAIT while one rank works alone (the per-GPU reference, the one-process farm) wait on the CPU (gloo):
+    # a rank parked in an RCCL barrier keeps a spinning kernel on its GPU, and the one-process leg uses those GPUs.
+    park = None
+    if world > 1:
+        park = dist.new_group(backend="gloo") if backend == "nccl" else dist.group.WORLD
     reduce_device = "cuda" if (dist is not None and backend == "nccl") else None
 
     import mlsgpu_amd as m
@@ -851,6 +857,7 @@ def main():
             for c in ctxs:
                 c.synchronize()
             ref_elapsed = time.perf_counter() - t0
+        dist.barrier(group=park)
         barrier()
     collectors[:] = [m.binding.SizeCollector() for _ in range(nworkers)]
     t0 = time.perf_counter()
@@ -1077,7 +1084,7 @@ def main():
     L = max(1, args.leg_steps)
 
     if world > 1 and not args.headline_only:
-        multi_gpu_legs(m, args, result, dist, reduce_device, rank, world, local_rank, ndev, ctxs[0], bucketed_t, buckets,
+        multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, local_rank, ndev, ctxs[0], bucketed_t, buckets,
                        max_count, max_cells, voxels, L, nworkers)
 
     # ---- mesh-sink leg (never `value`): every ship-out of one pass appended to the device mesher (d2d), then
