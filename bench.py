@@ -712,7 +712,11 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # MLSGPU_BENCH_FORCE_DIST=1 (with `torch.distributed.run --nproc-per-node 1 bench.py --gpus 1 --workload cfg4slab`): the
+    # N > 1 code path -- RCCL process group, collectives, the N > 1 legs -- with ONE rank, for a box with one GPU.  A check
+    # of that code, never a measurement; the line says so.
+    force_dist = world == 1 and os.environ.get("MLSGPU_BENCH_FORCE_DIST") == "1" and "RANK" in os.environ
+    if world > 1 or force_dist:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -721,7 +725,7 @@ def main():
     # Ranks that only WAIT while one rank works alone (the per-GPU reference, the one-process farm) wait on the CPU (gloo):
     # a rank parked in an RCCL barrier keeps a spinning kernel on its GPU, and the one-process leg uses those GPUs.
     park = None
-    if world > 1:
+    if dist is not None:
         park = dist.new_group(backend="gloo") if backend == "nccl" else dist.group.WORLD
     reduce_device = "cuda" if (dist is not None and backend == "nccl") else None
 
@@ -939,6 +943,8 @@ def main():
         if digest != CFG4SLAB_DIGEST:
             raise SystemExit("output digest %s of rank 0's slab differs from the pinned %s (tests/golden/cfg4slab_uniform.json)"
                              % (digest, CFG4SLAB_DIGEST))
+    if force_dist:
+        result["debug_forced_dist"] = "ONE rank with the N > 1 code path (MLSGPU_BENCH_FORCE_DIST=1): a check of that code, not a measurement"
     if world > ndev:
         result["debug_shared_gpu"] = "%d ranks on %d GPU(s) (MLSGPU_BENCH_BACKEND=gloo): a check of the N > 1 code path, NOT an N-GPU measurement" % (world, ndev)
     if per_rank is not None:
@@ -1080,10 +1086,10 @@ def main():
         result["work_per_step"] = {"octree_entries": entries, "occupied_cells": O, "unwelded_vertices": mc["unwelded"],
                                    "welded_vertices": Vw, "external_vertices": external, "indices": T}
 
-    secondary = world == 1 and not args.headline_only
+    secondary = dist is None and not args.headline_only
     L = max(1, args.leg_steps)
 
-    if world > 1 and not args.headline_only:
+    if dist is not None and not args.headline_only:
         multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, local_rank, ndev, ctxs[0], bucketed_t, buckets,
                        max_count, max_cells, voxels, L, nworkers)
 

@@ -124,3 +124,18 @@ def test_bench_two_ranks_one_sharded_cloud():
     assert json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])["n_gpus"] == 2
     out = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--scale", "0.02", "--steps", "1", "--warmup", "0"], env)
     assert out.returncode != 0 and "does not match WORLD_SIZE" in (out.stdout + out.stderr)
+
+
+def test_bench_rccl_code_path_with_one_rank():
+    """The N > 1 code path of bench.py over RCCL (`nccl` backend: process group with a device id, float64 / int64 all-reduces
+    on the GPU, all_gather_object, the gloo side group the waiting ranks park on, every N > 1 leg) with ONE rank on the box's
+    GPU -- the shared-GPU runs above use gloo, and a one-GPU box cannot hold two RCCL ranks."""
+    env = {"MLSGPU_BENCH_FORCE_DIST": "1", "MLSGPU_BENCH_BACKEND": "nccl"}
+    out = _launch(1, [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "cfg4slab", "--scale", "0.02", "--steps", "2",
+                      "--warmup", "1", "--no-timing"], env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and "debug_forced_dist" in d and d["per_rank"]["buckets"] == [25]
+    assert d["per_gpu_reference"]["value"] > 0 and "leg_errors" not in d
+    assert d["transfer_inclusive"]["device_sink_global_weld"]["value"] > 0
+    assert d["single_process"]["host_fed"]["value"] > 0 and d["single_process"]["device_fed"]["value"] > 0
