@@ -280,7 +280,8 @@ int mlsgpu_hip_farm_submit(mlsgpu_farm *farm, const mlsgpu_splat *hSplats, uint6
 int mlsgpu_hip_farm_acquire(mlsgpu_farm *farm, uint64_t numSplats, mlsgpu_splat **out);
 int mlsgpu_hip_farm_push(mlsgpu_farm *farm, uint64_t numSplats, const int32_t lowExtent[3], const uint32_t numVertices[3],
                          uint64_t chunkId);
-/* Flushes the last batch and waits until every queued bucket has been processed; reports the first error. */
+/* Flushes the last batch and waits until every queued bucket has been processed; reports the first error.  After an error
+ * the farm refuses further buckets (queued ones are handed back unprocessed, their capacity restored): finish and destroy it. */
 int mlsgpu_hip_farm_finish(mlsgpu_farm *farm);
 /* out[0] buckets, [1] splats copied, [2] H2D bytes, [3] device items, [4] ship-outs, [5] vertices, [6] triangles,
  * [7] external vertices; per device d: out[8 + d] = buckets processed there (up to 16 devices). */

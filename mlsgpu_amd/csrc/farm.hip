@@ -356,6 +356,7 @@ void workerMain(Farm *farm, DeviceGroup *g)
             if (e != hipSuccess)
                 farm->fail(MLSGPU_ERR_HIP, hipGetErrorString(e));
         }
+        size_t processed = 0;
         for (size_t i = 0; run && i < item->subItems.size() && e == hipSuccess; i++)
         {
             const SubItem &sub = item->subItems[i];
@@ -367,9 +368,20 @@ void workerMain(Farm *farm, DeviceGroup *g)
                 farm->fail(rc, mlsgpu_hip_last_error());
                 break;
             }
+            processed = i + 1;
             std::lock_guard<std::mutex> l(farm->mutex);
             g->unallocated += sub.numSplats;         /* src/workers.cpp:281-284 */
             g->bucketsDone++;
+        }
+        if (processed < item->subItems.size())
+        {
+            /* a failed or skipped item (the farm has failed: it refuses further work and can only be finished and destroyed):
+             * the copy that filled it may still be running -- it must not be when the item is handed out again -- and the
+             * splats of the buckets that were not processed go back to the group's capacity */
+            hipStreamSynchronize(g->copyStream);
+            std::lock_guard<std::mutex> l(farm->mutex);
+            for (size_t i = processed; i < item->subItems.size(); i++)
+                g->unallocated += item->subItems[i].numSplats;
         }
         {
             /* freeItem, src/workers.cpp:148-161 */
@@ -736,7 +748,14 @@ MLSGPU_API int mlsgpu_hip_farm_submit_device(mlsgpu_farm *f, int device, const m
     sub.numSplats = numSplats;
     item->subItems.assign(1, sub);
     item->numSplats = numSplats;
-    static const bool forcePeer = getenv("MLSGPU_HIP_FARM_FORCE_PEER") != nullptr;   /* tests: the peer route on one GPU */
+    /* tests: the peer route on one GPU.  Said once on stderr, because left set by accident it sends every device-side
+     * bucket through the scratch ring */
+    static const bool forcePeer = [] {
+        const bool on = getenv("MLSGPU_HIP_FARM_FORCE_PEER") != nullptr;
+        if (on)
+            fprintf(stderr, "mlsgpu_hip: MLSGPU_HIP_FARM_FORCE_PEER is set: device-side buckets take the peer route (test hook)\n");
+        return on;
+    }();
     DeviceGuard restore;
     int rc = MLSGPU_OK;
     if (out->device == device && !forcePeer)

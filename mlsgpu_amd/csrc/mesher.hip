@@ -600,7 +600,12 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
     std::lock_guard<std::mutex> lock(m->mutex);
     REQUIRE(!m->finalized, MLSGPU_ERR_INVALID);
     const int home = m->ctx->device;
-    static const bool forcePeer = getenv("MLSGPU_HIP_MESHER_FORCE_PEER") != nullptr;    /* tests: the peer route on one GPU */
+    static const bool forcePeer = [] {          /* tests: the peer route on one GPU; said once, it synchronises every append */
+        const bool on = getenv("MLSGPU_HIP_MESHER_FORCE_PEER") != nullptr;
+        if (on)
+            fprintf(stderr, "mlsgpu_hip: MLSGPU_HIP_MESHER_FORCE_PEER is set: ship-outs take the peer route (test hook)\n");
+        return on;
+    }();
     const bool peer = from->device != home || forcePeer;
     DeviceGuard restore;        /* the caller is a worker in the middle of ITS device's work (Marching's output functor) */
     if (from->device != home && !m->peerEnabled[from->device & 15])

@@ -864,7 +864,12 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
 #define MLS_LAUNCH(SHAPE, CULL, STATS) LAUNCH(ctx, stat, (processCornersKernel<SHAPE, CULL, STATS>), grid, block, A)
     /* tuning aid: dynamic LDS that the kernel never touches lowers its occupancy (3 workgroups per CU from 8 KB, 2 from
      * 20 KB), leaving wave slots to the memory-bound kernels of the other device workers */
-    static const uint32_t ldsPad = getenv("MLSGPU_HIP_MLS_LDS_PAD") ? (uint32_t) atoi(getenv("MLSGPU_HIP_MLS_LDS_PAD")) : 0u;
+    static const uint32_t ldsPad = [] {
+        /* clamped to what still launches beside the kernels' static LDS (36 KB at most) in the CU's 160 KB */
+        const char *e = getenv("MLSGPU_HIP_MLS_LDS_PAD");
+        const long v = e ? atol(e) : 0;
+        return (uint32_t) (v < 0 ? 0 : (v > 120 * 1024 ? 120 * 1024 : v));
+    }();
 #define MLS_LAUNCH_LIST(SHAPE, STATS) LAUNCH_LDS(ctx, stat, (processCornersListKernel<SHAPE, STATS>), grid, block, ldsPad, A)
     const bool sphere = m->shape == MLSGPU_SHAPE_SPHERE, cull = m->variant == 0;
 #define MLS_LAUNCH_MASK(SHAPE, STATS) LAUNCH_LDS(ctx, stat, (processCornersMaskKernel<SHAPE, STATS>), grid, block, ldsPad, A)
