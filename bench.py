@@ -260,6 +260,42 @@ def run_cfg5(args, rank, world, local_rank, device, dist, reduce_device):
     bg = mb.bounding_grid(ctx, raw, n, 1.0, 63)
     ctx.synchronize()
     bound_s = time.perf_counter() - t0
+    # out of core: the same set as if it did NOT fit the device -- the files streamed through a chunk buffer, once to count
+    # and once per batch of top-level regions that fit the budget (mlsgpu_hip_bucket_stream); a third of the cloud at a time
+    streamed = None
+    if world == 1 and not args.headline_only:
+        try:
+            budget = max(int(n * 0.3), 1)
+            chunk = max(min(64_000_000, n // 4), 1)
+            bfarm.checksums = True
+            bfarm.sums.clear()
+
+            def stream_leaf(leaf, d_splats, d_ids, count=[0]):
+                low, nv = farm.leaf_geometry(leaf, ext)
+                bfarm.submit_device(local_rank, d_splats, d_ids, leaf["num_splats"], ref0, 1.0, ext, low, nv, count[0])
+                count[0] += 1
+            t0 = time.perf_counter()
+            sg = mb.bounding_grid_files(ctx, fs, 1.0, 63, chunk, reader_threads=32)
+            sbound_s = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            sleaves, sstats = mb.bucket_cloud_stream(ctx, fs, ref0, 1.0, ext, budget_splats=budget, chunk_splats=chunk,
+                                                     reader_threads=32, on_bucket=stream_leaf, **CFG5_PARTITION)
+            bfarm.finish()
+            stream_s = time.perf_counter() - t0
+            streamed = {
+                "ms_per_pass": round(stream_s * 1e3, 1), "msplats_per_s": round(n / stream_s / 1e6, 1),
+                "mvoxels_per_s": round(voxels / stream_s / 1e6, 1), "budget_splats": budget, "chunk_splats": chunk,
+                "file_passes": sstats["file_passes"], "batches": sstats["batches"], "largest_batch": sstats["largest_batch"],
+                "splats_loaded_into_batches": sstats["batch_splats"], "buckets": len(sleaves),
+                "same_buckets_as_resident": [l["extents"] for l in sleaves] == [l["extents"] for l in leaves]
+                and [l["num_splats"] for l in sleaves] == [l["num_splats"] for l in leaves],
+                "same_meshes_as_resident": bfarm.digest() == digest,
+                "bounding_grid_from_files_ms": round(sbound_s * 1e3, 1), "bounding_grid_matches": list(sg[2]) == list(bg[2]),
+                "note": "the set treated as larger than the device: never more than budget_splats of it resident; files -> chunk "
+                        "buffer -> microblock-octree counters (pass 1) -> per batch of top-level regions: files -> filter into the "
+                        "batch buffer in file order -> member lists, recursion, device gathers into the farm (mlsgpu_hip_bucket_stream)"}
+        except Exception as e:      # noqa: BLE001
+            streamed = {"error": "%s: %s" % (type(e).__name__, e)}
     ms_per_step = elapsed / args.steps * 1e3
     golden = None
     try:
@@ -297,6 +333,8 @@ def run_cfg5(args, rank, world, local_rank, device, dist, reduce_device):
             "note": "PLY files in %s (page cache) -> 32 reader threads decoding into a 512 MiB pinned buffer -> H2D -> the timed "
                     "region's pipeline; never `value`" % args.cfg5_dir},
     }
+    if streamed is not None:
+        result["out_of_core"] = streamed
     if golden is not None and world == 1:
         # the triangle total does not depend on how the mesh memory cuts a bucket into ship-outs; the digest is pinned for
         # this bench's own mesh memory

@@ -33,7 +33,7 @@ int main(int argc, char **argv)
 {
     std::vector<std::int32_t> devices(1, 0);
     bool hostWeld = false;
-    std::uint64_t bufferBytes = 0;
+    std::uint64_t bufferBytes = 0, hbmSplats = 0;
     std::vector<std::string> plys, rest;
     for (int i = 1; i < argc; i++)
     {
@@ -50,6 +50,8 @@ int main(int argc, char **argv)
             hostWeld = std::string(argv[++i]) == "host";
         else if (a == "--buffer" && i + 1 < argc)
             bufferBytes = strtoull(argv[++i], NULL, 10);
+        else if (a == "--hbm-splats" && i + 1 < argc)       // the cloud does not fit the device: stream it, this many at a time
+            hbmSplats = strtoull(argv[++i], NULL, 10);
         else if (rest.empty() && isPly(a))
             plys.push_back(a);
         else
@@ -57,7 +59,7 @@ int main(int argc, char **argv)
     }
     if (plys.size() < 2 || rest.empty() || devices.empty())
     {
-        std::cerr << "usage: reconstruct [--devices 0,1] [--weld device|host] [--buffer BYTES] in.ply [more.ply ...] out.ply "
+        std::cerr << "usage: reconstruct [--devices 0,1] [--weld device|host] [--buffer BYTES] [--hbm-splats N] in.ply [more.ply ...] out.ply "
                      "spacing [smooth] [levels] [subsampling] [prune] [maxSplats]\n";
         return 2;
     }
@@ -86,11 +88,18 @@ int main(int argc, char **argv)
         }
         const int home = devices[0];                            // the cloud (and the device sink) live on the first GPU
         Context ctx(home);
-        Buffer<Splat> cloud(ctx, numSplats);
-        // files -> HBM: reader threads decode into pinned quarters while earlier chunks travel; no host copy of the cloud
-        files.load(ctx, cloud, 0, numSplats);
+        const bool streamed = hbmSplats != 0;                   // the set is larger than what may be resident at once
+        const std::uint64_t chunkSplats = streamed ? std::max<std::uint64_t>(hbmSplats / 4, 1) : 0;
+        Buffer<Splat> cloud(ctx, streamed ? 1 : numSplats);
         Bucket::Grid grid;
-        check(mlsgpu_hip_bounding_grid(ctx.get(), cloud.get(), numSplats, spacing, microCells, &grid));
+        if (streamed)
+            grid = files.boundingGrid(ctx, spacing, microCells, chunkSplats);      // one pass over the files
+        else
+        {
+            // files -> HBM: reader threads decode into pinned quarters while earlier chunks travel; no host copy of the cloud
+            files.load(ctx, cloud, 0, numSplats);
+            check(mlsgpu_hip_bounding_grid(ctx.get(), cloud.get(), numSplats, spacing, microCells, &grid));
+        }
 
         mlsgpu_worker_config cfg;
         std::memset(&cfg, 0, sizeof(cfg));
@@ -114,12 +123,21 @@ int main(int argc, char **argv)
             BucketFarm farm(devices, cfg, 4 /* --device-threads */, 1, hostWeld ? NULL : &deviceMesher);
             if (hostWeld)
                 farm.setHostOutput(std::uint64_t(512) << 20 /* --mem-mesh */, hostMesher);
-            Bucket::bucket(ctx, cloud, numSplats, grid, maxSplats, maxCells, 0, microCells, std::uint64_t(1) << 30,
-                           [&](const Bucket::Bin &bin)
-            {
-                farm.submitDevice(home, cloud, bin, grid, 0);
-                bins++;
-            });
+            if (streamed)
+                // out of core: the files streamed through a chunk buffer, a batch of top-level regions resident at a time
+                Bucket::bucketStream(ctx, files, grid, maxSplats, maxCells, 0, microCells, std::uint64_t(1) << 30, hbmSplats,
+                                     chunkSplats, 0, [&](const Bucket::Bin &bin)
+                {
+                    farm.submitDevice(home, bin, grid, 0);
+                    bins++;
+                });
+            else
+                Bucket::bucket(ctx, cloud, numSplats, grid, maxSplats, maxCells, 0, microCells, std::uint64_t(1) << 30,
+                               [&](const Bucket::Bin &bin)
+                {
+                    farm.submitDevice(home, cloud, bin, grid, 0);
+                    bins++;
+                });
             farm.finish();
         }
         const std::vector<std::string> comments(1, "mlsgpu-hip example: reconstruct");

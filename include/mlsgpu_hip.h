@@ -342,6 +342,8 @@ typedef struct mlsgpu_bucket        /* what ProcessorType's callback receives, s
     uint32_t depth;                 /* Recursion::depth */
     uint64_t numSplats;
     const uint32_t *dIds;           /* device: ids of the bucket's splats, ascending; valid during the callback */
+    const mlsgpu_splat *dSplats;    /* device: the array the ids index -- the caller's cloud (mlsgpu_hip_bucket) or the batch
+                                     * of the streamed set that is resident during the callback (mlsgpu_hip_bucket_stream) */
 } mlsgpu_bucket;
 typedef int (*mlsgpu_bucket_fn)(void *user, mlsgpu_ctx *ctx, const mlsgpu_bucket *bucket);
 /* Splits `region` into buckets of at most maxCells cells per side and maxSplats splats and calls fn for each non-empty
@@ -494,6 +496,21 @@ int mlsgpu_hip_fileset_read(mlsgpu_fileset *files, uint64_t first, uint64_t coun
  * clouds that fit in HBM: 10^9 splats are 32 GB of 288).  Returns when dOut[0 .. count) is complete. */
 int mlsgpu_hip_fileset_load(mlsgpu_fileset *files, mlsgpu_ctx *ctx, uint64_t first, uint64_t count, mlsgpu_splat *dOut,
                             uint32_t readerThreads);
+/* Bucket::bucket over a FileSet that need NOT fit the device -- the role of the reference's blob index and host bucketing
+ * (FastBlobSet, src/splat_set.h:713-905; bucketRecurse, src/bucket_impl.h:439-560) for data beyond HBM.  The files are
+ * streamed through a chunk buffer of `chunkSplats` splats: once to count the level's microblock octree (the reference's first
+ * pass over the blobs), then once per BATCH of top-level regions that fit `budgetSplats` splats together (its second); a
+ * batch is resident while its regions are split further and its buckets handed to `fn`, whose mlsgpu_bucket::dSplats is the
+ * batch and dIds positions in it (valid during the callback: mlsgpu_hip_farm_submit_device copies the bucket out).  The
+ * buckets -- extents, order, member splats in file order -- are those mlsgpu_hip_bucket makes of the same set resident.
+ * stats (may be NULL): [0] passes over the files, [1] batches, [2] splats loaded into batches, [3] largest batch.
+ * MLSGPU_ERR_LENGTH if one top-level region alone exceeds the budget. */
+/* FastBlobSet::makeBoundingGrid (src/splat_set_impl.h:770-811) for such a set: one pass over the files through a chunk buffer */
+int mlsgpu_hip_fileset_bounding_grid(mlsgpu_fileset *files, mlsgpu_ctx *ctx, float spacing, uint32_t bucketSize,
+                                     uint64_t chunkSplats, uint32_t readerThreads, mlsgpu_grid *out);
+int mlsgpu_hip_bucket_stream(mlsgpu_ctx *ctx, mlsgpu_fileset *files, const mlsgpu_grid *region,
+                             const mlsgpu_bucket_params *params, uint64_t budgetSplats, uint64_t chunkSplats,
+                             uint32_t readerThreads, mlsgpu_bucket_fn fn, void *user, uint64_t *cellSplats, uint64_t stats[4]);
 
 /* DeviceWorkerGroupBase::computeMaxSwathe, src/workers.cpp:169-182 */
 uint32_t mlsgpu_hip_compute_max_swathe(uint32_t yMax, uint32_t y, uint32_t yAlign, uint32_t zAlign);

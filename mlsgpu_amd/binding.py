@@ -85,7 +85,7 @@ class BucketParams(C.Structure):
 
 class BucketStruct(C.Structure):
     _fields_ = [("extents", C.c_int32 * 6), ("chunk", C.c_uint64 * 3), ("depth", C.c_uint32), ("numSplats", C.c_uint64),
-                ("dIds", C.c_void_p)]
+                ("dIds", C.c_void_p), ("dSplats", C.c_void_p)]
 
 
 BUCKET_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(BucketStruct))
@@ -238,6 +238,8 @@ def lib():
     sig("mlsgpu_hip_write_ply", C.c_int, C.c_char_p, vp, u64, vp, u64, vp, u32)
     sig("mlsgpu_hip_bucket", C.c_int, vp, vp, u64, P(GridStruct), P(BucketParams), BUCKET_FN, vp, P(u64))
     sig("mlsgpu_hip_bucket_load", C.c_int, vp, vp, vp, u64, P(GridStruct), vp)
+    sig("mlsgpu_hip_fileset_bounding_grid", C.c_int, vp, vp, C.c_float, C.c_uint32, u64, C.c_uint32, P(GridStruct))
+    sig("mlsgpu_hip_bucket_stream", C.c_int, vp, vp, P(GridStruct), P(BucketParams), u64, u64, C.c_uint32, BUCKET_FN, vp, vp, vp)
     sig("mlsgpu_hip_bounding_grid", C.c_int, vp, vp, u64, f32, u32, P(GridStruct))
     sig("mlsgpu_hip_test_make_code", C.c_int, vp, C.c_int, C.c_int, C.c_int, P(u32))
     sig("mlsgpu_hip_test_level_shift", C.c_int, vp, vp, vp, P(i32))
@@ -1298,6 +1300,56 @@ def bucket_cloud(ctx, d_splats, num_splats, reference, spacing, extents, max_spl
         raise e
     check(rc)
     return leaves
+
+
+class _DevicePtr:
+    """what BucketFarm.submit_device and bucket_load take for the cloud: anything with .ptr"""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+
+def bucket_cloud_stream(ctx, fileset, reference, spacing, extents, max_splats, max_cells, budget_splats, chunk_splats,
+                        chunk_cells=0, micro_cells=0, max_split=1 << 30, reader_threads=0, on_bucket=None):
+    """Bucket::bucket over a FileSet that need not fit the device (mlsgpu_hip_bucket_stream).  on_bucket(leaf, d_splats,
+    d_ids_ptr): d_splats (.ptr) is the resident batch the ids index, valid during the call.  Returns (leaves, stats)."""
+    leaves = []
+    failure = []
+
+    def cb(_user, _ctx, b):
+        try:
+            b = b.contents
+            leaf = dict(extents=tuple(int(b.extents[i]) for i in range(6)), chunk=tuple(int(b.chunk[i]) for i in range(3)),
+                        depth=int(b.depth), num_splats=int(b.numSplats))
+            if on_bucket is not None:
+                on_bucket(leaf, _DevicePtr(b.dSplats), b.dIds)
+            leaves.append(leaf)
+            return 0
+        except Exception as e:      # noqa: BLE001 - reported after the C call returns
+            failure.append(e)
+            return 1
+    fn = BUCKET_FN(cb)
+    g = _grid_struct(reference, spacing, extents)
+    p = BucketParams(max_splats, max_cells, chunk_cells, micro_cells, max_split)
+    cell = C.c_uint64(0)
+    stats = np.zeros(4, np.uint64)
+    rc = lib().mlsgpu_hip_bucket_stream(ctx.h, fileset.h, C.byref(g), C.byref(p), budget_splats, chunk_splats, reader_threads,
+                                        fn, None, C.byref(cell), _p(stats))
+    if failure:
+        raise failure[0]
+    if rc == 6:
+        e = DensityError("[6] " + lib().mlsgpu_hip_last_error().decode("utf-8", "replace"))
+        e.cell_splats = int(cell.value)
+        raise e
+    check(rc)
+    return leaves, dict(zip(["file_passes", "batches", "batch_splats", "largest_batch"], [int(x) for x in stats]))
+
+
+def bounding_grid_files(ctx, fileset, spacing, bucket_size, chunk_splats, reader_threads=0):
+    """FastBlobSet::makeBoundingGrid for a FileSet that need not fit the device: (reference, spacing, extents)."""
+    g = GridStruct()
+    check(lib().mlsgpu_hip_fileset_bounding_grid(fileset.h, ctx.h, spacing, bucket_size, chunk_splats, reader_threads, C.byref(g)))
+    return tuple(g.reference), float(g.spacing), tuple(int(x) for x in g.extents)
 
 
 def bounding_grid(ctx, d_splats, num_splats, spacing, bucket_size):

@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <functional>
 #include <memory>
 
 using namespace mlsgpu;
@@ -123,6 +124,7 @@ struct RegionCountIn
 {
     RegionView V;
     const uint32_t *table;
+    uint32_t rFirst = 0, rEnd = 0xFFFFFFFFu;    /* only regions [rFirst, rEnd) count (a batch of the streamed top level) */
     __device__ __forceinline__ uint32_t operator()(uint64_t i) const
     {
         uint32_t lo[3], hi[3];
@@ -135,7 +137,8 @@ struct RegionCountIn
                 {
                     const uint32_t t = table[(z * V.dims[1] + y) * V.dims[0] + x];
                     const uint32_t mask = (1u << (t & 31u)) - 1;
-                    if ((x == lo[0] || (x & mask) == 0) && (y == lo[1] || (y & mask) == 0) && (z == lo[2] || (z & mask) == 0))
+                    if ((t >> 5) - rFirst < rEnd - rFirst
+                        && (x == lo[0] || (x & mask) == 0) && (y == lo[1] || (y & mask) == 0) && (z == lo[2] || (z & mask) == 0))
                         k++;
                 }
         return k;
@@ -147,6 +150,7 @@ struct RegionEmitOut
     RegionView V;
     const uint32_t *table;
     uint32_t *keys, *vals;
+    uint32_t rFirst = 0, rEnd = 0xFFFFFFFFu;    /* as RegionCountIn; keys are relative to rFirst */
     __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t count) const
     {
         if (count == 0)
@@ -160,15 +164,37 @@ struct RegionEmitOut
                 {
                     const uint32_t t = table[(z * V.dims[1] + y) * V.dims[0] + x];
                     const uint32_t mask = (1u << (t & 31u)) - 1;
-                    if ((x == lo[0] || (x & mask) == 0) && (y == lo[1] || (y & mask) == 0) && (z == lo[2] || (z & mask) == 0))
+                    if ((t >> 5) - rFirst < rEnd - rFirst
+                        && (x == lo[0] || (x & mask) == 0) && (y == lo[1] || (y & mask) == 0) && (z == lo[2] || (z & mask) == 0))
                     {
-                        keys[excl] = t >> 5;
+                        keys[excl] = (t >> 5) - rFirst;
                         vals[excl] = id;
                         excl++;
                     }
                 }
     }
 };
+
+/* The streamed top level (mlsgpu_hip_bucket_stream): does splat i of the chunk in flight join a region of the batch being
+ * assembled? ... */
+struct BatchJoinIn
+{
+    RegionCountIn C;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return C(i) != 0 ? 1u : 0u; }
+};
+/* ... and if so it is appended to the batch, in file order */
+struct BatchCopyOut
+{
+    const mlsgpu_splat *chunk;
+    mlsgpu_splat *batch;
+    const uint32_t *base;       /* device: splats of the batch so far */
+    __device__ __forceinline__ void operator()(uint64_t i, uint32_t excl, uint32_t joins) const
+    {
+        if (joins)
+            batch[(uint64_t) *base + excl] = chunk[i];
+    }
+};
+__global__ void addCountKernel(uint32_t *base, const uint32_t *add) { *base += *add; }
 
 /* first pair of every region in the region-sorted list (every region has at least one member) */
 __global__ void regionStartsKernel(const uint32_t *keys, uint64_t n, uint32_t *starts)
@@ -323,6 +349,9 @@ struct Bucketer
 
     int recurse(const uint32_t *dIds, uint64_t n, bool isSubset, const GridBox &grid, uint32_t chunkCells, uint32_t microCells,
                 uint32_t depth, const uint64_t chunkIn[3]);
+    /* the top level over a splat set that is NOT resident: see mlsgpu_hip_bucket_stream */
+    int recurseStream(mlsgpu_fileset *files, uint64_t n, const GridBox &grid, uint64_t budget, uint64_t chunkSplats,
+                      uint32_t readerThreads, uint64_t stats[4]);
 };
 
 /* bucketRecurse, src/bucket_impl.h:439-560 */
@@ -345,6 +374,7 @@ int Bucketer::recurse(const uint32_t *dIds, uint64_t n, bool isSubset, const Gri
         b.depth = depth;
         b.numSplats = n;
         b.dIds = dIds;
+        b.dSplats = dSplats;
         const int rc = fn(user, ctx, &b);
         if (rc != 0)
             return setError(MLSGPU_ERR_CALLBACK, "bucket callback failed with %d", rc);
@@ -578,6 +608,309 @@ int Bucketer::recurse(const uint32_t *dIds, uint64_t n, bool isSubset, const Gri
     return MLSGPU_OK;
 }
 
+/*
+ * The top level of bucketRecurse (src/bucket_impl.h:439-560) over a splat set that does not fit the device: where the
+ * reference streams its blobs twice per level through one host thread (count, then append ranges), the files are streamed
+ * through a chunk buffer in HBM --
+ *   pass 1   every chunk adds to the SAME microblock-octree counters (bucketCountKernel, unchanged); the host picks the
+ *            level's regions from them exactly as for a resident cloud (same counters, same traversal);
+ *   pass 2.. the regions are taken in order, as many at a time as fit `budget` splats by their counters; the files are
+ *            streamed again, a scan keeps the splats that join a region of the batch and appends them to the batch buffer
+ *            IN FILE ORDER, and from there on the batch is a resident cloud: member lists, recursion, callbacks.
+ * Region numbering, member order and therefore every bucket are those of the resident path (ids are positions in the
+ * batch; mlsgpu_bucket::dSplats says in which array).  Passes over the files: 1 + number of batches.
+ */
+int Bucketer::recurseStream(mlsgpu_fileset *files, uint64_t n, const GridBox &grid, uint64_t budget, uint64_t chunkSplats,
+                            uint32_t readerThreads, uint64_t stats[4])
+{
+    uint32_t cellDims[3];
+    for (int i = 0; i < 3; i++)
+        cellDims[i] = grid.cells(i);
+    const uint32_t maxCellDim = std::max(std::max(cellDims[0], cellDims[1]), cellDims[2]);
+    if (maxCellDim == 1)
+    {
+        cellSplats = n;
+        return setError(MLSGPU_ERR_DENSITY, "Too many splats covering one cell (%llu)", (unsigned long long) n);
+    }
+    /* the level's geometry: as recurse() for the whole set (not a subset: the top level always splits) */
+    uint32_t chunkCells = P.chunkCells;
+    uint32_t microSize = P.microCells;
+    if (microSize == 0 || microSize > maxCellDim)
+        microSize = chooseMicroSize(cellDims, P.maxSplit, n, P.maxSplats, P.maxCells);
+    while (true)
+    {
+        uint64_t microBlocks = 1;
+        for (int i = 0; i < 3; i++)
+            microBlocks = mulSat(microBlocks, divUp(cellDims[i], microSize));
+        if (microBlocks <= P.maxSplit)
+            break;
+        microSize *= 2;
+    }
+    if (chunkCells == 0)
+        chunkCells = maxCellDim;
+    else
+        chunkCells = std::min(maxCellDim, chunkCells);
+    if (chunkCells > P.maxCells)
+    {
+        uint64_t grain = (uint64_t) P.maxCells / microSize * microSize;
+        if (grain == 0)
+            grain = microSize;
+        chunkCells = (uint32_t) ((chunkCells + grain - 1) / grain * grain);
+    }
+    else
+        chunkCells = roundUp(chunkCells, microSize);
+    uint32_t chunks[3];
+    for (int i = 0; i < 3; i++)
+        chunks[i] = divUp(cellDims[i], chunkCells);
+    uint32_t macroLevels = 1;
+    while (((uint64_t) microSize << (macroLevels - 1)) < chunkCells)
+        macroLevels++;
+    REQUIRE(macroLevels <= MAX_LEVELS, MLSGPU_ERR_LENGTH);
+    const uint32_t chunkRatio = chunkCells / microSize;
+
+    while (depthList->size() <= 0)
+        depthList->emplace_back(new DepthBuffers);
+    DepthBuffers &B = *(*depthList)[0];
+    if (B.total == nullptr)
+        PROPAGATE(ensure(&B.total, 2));
+
+    /* the chunk in flight, the batch, and two words: splats of the batch so far, splats the last chunk added */
+    mlsgpu_splat *dChunk = nullptr, *dBatch = nullptr;
+    uint32_t *dWords = nullptr, *dScanSums = nullptr;
+    struct Free
+    {
+        mlsgpu_splat *&a, *&b;
+        uint32_t *&c, *&d;
+        ~Free() { hipFree(a); hipFree(b); hipFree(c); hipFree(d); }
+    } release{dChunk, dBatch, dWords, dScanSums};
+    HIP_CHECK(hipMalloc((void **) &dChunk, chunkSplats * sizeof(mlsgpu_splat)));
+    HIP_CHECK(hipMalloc((void **) &dBatch, budget * sizeof(mlsgpu_splat)));
+    HIP_CHECK(hipMalloc((void **) &dWords, 2 * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc((void **) &dScanSums, ((size_t) scanTiles(chunkSplats) + 1) * sizeof(uint32_t)));
+
+    auto forEachFileChunk = [&](const std::function<int(uint64_t)> &body) -> int
+    {
+        for (uint64_t first = 0; first < n; first += chunkSplats)
+        {
+            const uint64_t cnt = std::min<uint64_t>(chunkSplats, n - first);
+            PROPAGATE(mlsgpu_hip_fileset_load(files, ctx, first, cnt, dChunk, readerThreads));
+            PROPAGATE(body(cnt));
+        }
+        stats[0]++;
+        return MLSGPU_OK;
+    };
+
+    for (uint32_t cx = 0; cx < chunks[0]; cx++)
+        for (uint32_t cy = 0; cy < chunks[1]; cy++)
+            for (uint32_t cz = 0; cz < chunks[2]; cz++)
+            {
+                const uint32_t cc[3] = {cx, cy, cz};
+                GridBox sub;
+                for (int i = 0; i < 3; i++)
+                {
+                    const int64_t off = (int64_t) cc[i] * chunkCells;
+                    sub.lo[i] = (int32_t) (grid.lo[i] + off);
+                    sub.hi[i] = (int32_t) std::min<int64_t>(grid.lo[i] + off + chunkCells, grid.hi[i]);
+                }
+                RegionView V;
+                V.splats = dChunk;
+                V.ids = nullptr;
+                V.invSpacing = 1.0f / full.spacing;
+                V.microSize = microSize;
+                LevelLayout L;
+                L.levels = macroLevels;
+                for (int i = 0; i < 3; i++)
+                {
+                    V.ref[i] = full.reference[i];
+                    V.first[i] = grid.lo[i];
+                    V.bias[i] = (int32_t) (cc[i] * chunkRatio);
+                    V.dims[i] = divUp(sub.cells(i), microSize);
+                }
+                uint64_t totalNodes = 0;
+                for (uint32_t l = 0; l < macroLevels; l++)
+                {
+                    L.offset[l] = (uint32_t) totalNodes;
+                    uint64_t t = 1;
+                    for (int i = 0; i < 3; i++)
+                    {
+                        L.dims[l][i] = divUp(V.dims[i], (uint64_t) 1 << l);
+                        t *= L.dims[l][i];
+                    }
+                    totalNodes += t;
+                    REQUIRE(totalNodes <= (1u << 24), MLSGPU_ERR_LENGTH);
+                }
+                L.offset[macroLevels] = (uint32_t) totalNodes;
+                const uint32_t n0 = V.dims[0] * V.dims[1] * V.dims[2];
+                if (B.nodeCap < totalNodes)
+                {
+                    PROPAGATE(ensure(&B.counts, totalNodes));
+                    PROPAGATE(ensure(&B.table, totalNodes));
+                    B.nodeCap = (uint32_t) totalNodes;
+                }
+                /* pass 1: the counters of the whole set, chunk after chunk */
+                HIP_CHECK(hipMemsetAsync(B.counts, 0, totalNodes * 4, ctx->stream));
+                uint32_t ldsFrom = L.levels;
+                while (ldsFrom > 0 && totalNodes - L.offset[ldsFrom - 1] <= LDS_NODES)
+                    ldsFrom--;
+                PROPAGATE(forEachFileChunk([&](uint64_t cnt) -> int
+                {
+                    const uint32_t blocks = (uint32_t) std::min<uint64_t>(divUp(cnt, 256), 4096);
+                    LAUNCH(ctx, "bucket.count.time", bucketCountKernel, dim3(blocks), dim3(256), V, L, B.counts, cnt, ldsFrom);
+                    /* the next load overwrites the chunk buffer on another stream-ordered path: finish first */
+                    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                    return MLSGPU_OK;
+                }));
+                std::vector<uint32_t> counts(totalNodes);
+                HIP_CHECK(hipMemcpyAsync(counts.data(), B.counts, totalNodes * 4, hipMemcpyDeviceToHost, ctx->stream));
+                HIP_CHECK(hipStreamSynchronize(ctx->stream));
+
+                /* pickNodes (src/bucket.cpp:248-269, PickNodes :333-352): depth-first, children x fastest -- as recurse() */
+                struct Region { uint32_t c[3]; uint32_t level; uint32_t count; };
+                std::vector<Region> regions;
+                std::vector<uint32_t> table(n0, 0);
+                struct Frame { uint32_t c[3]; uint32_t level; };
+                std::vector<Frame> stack;
+                stack.push_back(Frame{{0, 0, 0}, macroLevels - 1});
+                while (!stack.empty())
+                {
+                    const Frame f = stack.back();
+                    stack.pop_back();
+                    const uint32_t count = counts[L.offset[f.level] + (f.c[2] * L.dims[f.level][1] + f.c[1]) * L.dims[f.level][0] + f.c[0]];
+                    if (count == 0)
+                        continue;
+                    if (f.level == 0 || (((uint64_t) microSize << f.level) <= P.maxCells && count <= P.maxSplats))
+                    {
+                        const uint32_t id = (uint32_t) regions.size();
+                        REQUIRE(id < (1u << 27), MLSGPU_ERR_LENGTH);
+                        regions.push_back(Region{{f.c[0], f.c[1], f.c[2]}, f.level, count});
+                        for (uint32_t z = f.c[2] << f.level; z < std::min(V.dims[2], (f.c[2] + 1) << f.level); z++)
+                            for (uint32_t y = f.c[1] << f.level; y < std::min(V.dims[1], (f.c[1] + 1) << f.level); y++)
+                                for (uint32_t x = f.c[0] << f.level; x < std::min(V.dims[0], (f.c[0] + 1) << f.level); x++)
+                                    table[(z * V.dims[1] + y) * V.dims[0] + x] = (id << 5) | f.level;
+                        continue;
+                    }
+                    for (int idx = 7; idx >= 0; idx--)
+                    {
+                        const Frame ch{{f.c[0] * 2 + (idx & 1), f.c[1] * 2 + ((idx >> 1) & 1), f.c[2] * 2 + (uint32_t) (idx >> 2)}, f.level - 1};
+                        bool inside = true;
+                        for (int j = 0; j < 3; j++)
+                            if (((uint64_t) ch.c[j] << ch.level) >= V.dims[j])
+                                inside = false;
+                        if (inside)
+                            stack.push_back(ch);
+                    }
+                }
+                if (regions.empty())
+                    continue;
+                const uint32_t numRegions = (uint32_t) regions.size();
+                HIP_CHECK(hipMemcpyAsync(B.table, table.data(), (size_t) n0 * 4, hipMemcpyHostToDevice, ctx->stream));
+                HIP_CHECK(hipStreamSynchronize(ctx->stream));          /* `table` is a local */
+
+                const uint64_t chunk[3] = {cx, cy, cz};
+                for (uint32_t r0 = 0; r0 < numRegions;)
+                {
+                    /* as many consecutive regions as fit the batch buffer by their counters (a splat that joins two of them
+                     * is counted twice and stored once) */
+                    uint32_t r1 = r0;
+                    uint64_t sum = 0;
+                    while (r1 < numRegions && sum + regions[r1].count <= budget)
+                        sum += regions[r1++].count;
+                    if (r1 == r0)
+                        return setError(MLSGPU_ERR_LENGTH, "bucket stream: a region of %u splats does not fit the device budget of "
+                                        "%llu splats", regions[r0].count, (unsigned long long) budget);
+                    REQUIRE(sum < 0xFFFFFFFFull, MLSGPU_ERR_LENGTH);
+                    stats[1]++;
+                    /* pass 2: the batch's splats, in file order */
+                    HIP_CHECK(hipMemsetAsync(dWords, 0, 8, ctx->stream));
+                    RegionCountIn joins{V, B.table, r0, r1};
+                    PROPAGATE(forEachFileChunk([&](uint64_t cnt) -> int
+                    {
+                        PROPAGATE((exclusiveScan2<uint32_t, BatchJoinIn, BatchJoinIn, BatchCopyOut>(
+                            ctx, "bucket.members.time", BatchJoinIn{joins}, BatchJoinIn{joins},
+                            BatchCopyOut{dChunk, dBatch, dWords}, cnt, 0u, dScanSums, dWords + 1)));
+                        hipLaunchKernelGGL(addCountKernel, dim3(1), dim3(1), 0, ctx->stream, dWords, (const uint32_t *) (dWords + 1));
+                        HIP_CHECK(hipGetLastError());
+                        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                        return MLSGPU_OK;
+                    }));
+                    uint32_t nb = 0;
+                    HIP_CHECK(hipMemcpyAsync(&nb, dWords, 4, hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                    REQUIRE(nb <= budget, MLSGPU_ERR_LENGTH);
+                    stats[2] += nb;
+                    stats[3] = std::max<uint64_t>(stats[3], nb);
+
+                    /* from here the batch is a resident cloud: member lists of regions [r0, r1) and the recursion, as recurse() */
+                    RegionView VB = V;
+                    VB.splats = dBatch;
+                    const uint32_t nr = r1 - r0;
+                    if (B.regionCap < nr + 1)
+                    {
+                        PROPAGATE(ensure(&B.starts, nr + 1));
+                        B.regionCap = nr + 1;
+                    }
+                    const RegionCountIn in{VB, B.table, r0, r1};
+                    if (B.scanCap < scanTiles(nb))
+                    {
+                        PROPAGATE(ensure(&B.scanSums, scanTiles(nb)));
+                        B.scanCap = scanTiles(nb);
+                    }
+                    PROPAGATE((scanPhase1<uint32_t, RegionCountIn>(ctx, "bucket.members.time", in, nb, 0u, B.scanSums, B.total)));
+                    uint32_t totalPairs = 0;
+                    HIP_CHECK(hipMemcpyAsync(&totalPairs, B.total, 4, hipMemcpyDeviceToHost, ctx->stream));
+                    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                    if (B.pairCap < totalPairs)
+                    {
+                        const uint64_t cap = (uint64_t) totalPairs + totalPairs / 8 + 1024;
+                        PROPAGATE(ensure(&B.keysA, cap));
+                        PROPAGATE(ensure(&B.valsA, cap));
+                        PROPAGATE(ensure(&B.keysB, cap));
+                        PROPAGATE(ensure(&B.valsB, cap));
+                        PROPAGATE(ensure(&B.hist, sortHistElems(cap)));
+                        PROPAGATE(ensure(&B.tileSums, scanTiles(std::max<uint64_t>(sortHistElems(cap), cap))));
+                        B.pairCap = cap;
+                    }
+                    PROPAGATE((scanPhase2<uint32_t, RegionCountIn, RegionEmitOut>(ctx, "bucket.members.time", in,
+                                                                                   RegionEmitOut{VB, B.table, B.keysA, B.valsA, r0, r1}, nb,
+                                                                                   (const uint32_t *) B.scanSums)));
+                    SortResult<uint32_t> sorted{B.keysA, B.valsA};
+                    PROPAGATE(radixSort<uint32_t>(ctx, "bucket.members.time", B.keysA, B.valsA, B.keysB, B.valsB, totalPairs,
+                                                  bitsForCount(nr), false, B.hist, B.tileSums, &sorted));
+                    std::vector<uint32_t> starts(nr + 1, 0);
+                    if (totalPairs > 0)
+                    {
+                        hipLaunchKernelGGL(regionStartsKernel, dim3(divUp(totalPairs, 256)), dim3(256), 0, ctx->stream,
+                                           (const uint32_t *) sorted.keys, (uint64_t) totalPairs, B.starts);
+                        HIP_CHECK(hipMemcpyAsync(starts.data(), B.starts, (size_t) nr * 4, hipMemcpyDeviceToHost, ctx->stream));
+                        HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                    }
+                    starts[nr] = totalPairs;
+                    const mlsgpu_splat *const saved = dSplats;
+                    dSplats = dBatch;
+                    int rc = MLSGPU_OK;
+                    const uint32_t *members = sorted.vals;
+                    for (uint32_t r = r0; r < r1 && rc == MLSGPU_OK; r++)
+                    {
+                        GridBox child;
+                        for (int i = 0; i < 3; i++)     /* Node::toCells clipped to the grid, src/bucket.cpp:113-122 */
+                        {
+                            const uint64_t lower = std::min<uint64_t>(((uint64_t) microSize * regions[r].c[i]) << regions[r].level, sub.cells(i));
+                            const uint64_t upper = std::min<uint64_t>((((uint64_t) microSize * regions[r].c[i]) << regions[r].level)
+                                                                      + ((uint64_t) microSize << regions[r].level), sub.cells(i));
+                            child.lo[i] = (int32_t) (sub.lo[i] + (int64_t) lower);
+                            child.hi[i] = (int32_t) (sub.lo[i] + (int64_t) upper);
+                        }
+                        rc = recurse(members + starts[r - r0], starts[r - r0 + 1] - starts[r - r0], true, child, 0, 0, 1, chunk);
+                    }
+                    dSplats = saved;
+                    PROPAGATE(rc);
+                    HIP_CHECK(hipStreamSynchronize(ctx->stream));       /* the batch buffer is refilled next */
+                    r0 = r1;
+                }
+            }
+    return MLSGPU_OK;
+}
+
 } // namespace
 
 MLSGPU_API int mlsgpu_hip_bucket(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, uint64_t numSplats, const mlsgpu_grid *region,
@@ -617,13 +950,9 @@ MLSGPU_API int mlsgpu_hip_bucket(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, u
     return rc;
 }
 
-/* FastBlobSet::makeBoundingGrid, src/splat_set_impl.h:770-811 */
-MLSGPU_API int mlsgpu_hip_bounding_grid(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, uint64_t numSplats, float spacing,
-                                        uint32_t bucketSize, mlsgpu_grid *out)
+/* detail::Bbox of device-resident splats folded into lo / hi (min and max are exact in any order) */
+static int foldBbox(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, uint64_t numSplats, float lo[3], float hi[3])
 {
-    REQUIRE(ctx != nullptr && out != nullptr && (numSplats == 0 || dSplats != nullptr), MLSGPU_ERR_INVALID);
-    REQUIRE(spacing > 0.0f && bucketSize >= 1, MLSGPU_ERR_INVALID);
-    HIP_CHECK(hipSetDevice(ctx->device));
     const uint32_t blocks = (uint32_t) std::max<uint64_t>(1, std::min<uint64_t>(divUp(numSplats, 256), 2048));
     float *dPartial = nullptr;
     HIP_CHECK(hipMalloc((void **) &dPartial, (size_t) blocks * 6 * sizeof(float)));
@@ -635,13 +964,56 @@ MLSGPU_API int mlsgpu_hip_bounding_grid(mlsgpu_ctx *ctx, const mlsgpu_splat *dSp
     hipFree(dPartial);
     if (e != hipSuccess)
         return setError(MLSGPU_ERR_HIP, "bounding grid: %s", hipGetErrorString(e));
-    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (uint32_t b = 0; b < blocks; b++)
         for (int a = 0; a < 3; a++)
         {
             lo[a] = std::min(lo[a], partial[(size_t) b * 6 + a]);
             hi[a] = std::max(hi[a], partial[(size_t) b * 6 + 3 + a]);
         }
+    return MLSGPU_OK;
+}
+
+static int gridFromBbox(const float lo[3], const float hi[3], float spacing, uint32_t bucketSize, mlsgpu_grid *out);
+
+/* FastBlobSet::makeBoundingGrid, src/splat_set_impl.h:770-811 */
+MLSGPU_API int mlsgpu_hip_bounding_grid(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, uint64_t numSplats, float spacing,
+                                        uint32_t bucketSize, mlsgpu_grid *out)
+{
+    REQUIRE(ctx != nullptr && out != nullptr && (numSplats == 0 || dSplats != nullptr), MLSGPU_ERR_INVALID);
+    REQUIRE(spacing > 0.0f && bucketSize >= 1, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    PROPAGATE(foldBbox(ctx, dSplats, numSplats, lo, hi));
+    return gridFromBbox(lo, hi, spacing, bucketSize, out);
+}
+
+/* ... for a FileSet that need not fit the device: one pass over the files through a chunk buffer (the bounding box is what
+ * FastBlobSet::computeBlobs accumulates while it makes its blobs, src/splat_set_impl.h:814-880) */
+MLSGPU_API int mlsgpu_hip_fileset_bounding_grid(mlsgpu_fileset *files, mlsgpu_ctx *ctx, float spacing, uint32_t bucketSize,
+                                                uint64_t chunkSplats, uint32_t readerThreads, mlsgpu_grid *out)
+{
+    REQUIRE(files != nullptr && ctx != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(spacing > 0.0f && bucketSize >= 1 && chunkSplats >= 1, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const uint64_t n = mlsgpu_hip_fileset_num_splats(files);
+    mlsgpu_splat *dChunk = nullptr;
+    HIP_CHECK(hipMalloc((void **) &dChunk, std::min<uint64_t>(chunkSplats, std::max<uint64_t>(n, 1)) * sizeof(mlsgpu_splat)));
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    int rc = MLSGPU_OK;
+    for (uint64_t first = 0; first < n && rc == MLSGPU_OK; first += chunkSplats)
+    {
+        const uint64_t cnt = std::min<uint64_t>(chunkSplats, n - first);
+        rc = mlsgpu_hip_fileset_load(files, ctx, first, cnt, dChunk, readerThreads);
+        if (rc == MLSGPU_OK)
+            rc = foldBbox(ctx, dChunk, cnt, lo, hi);
+    }
+    hipFree(dChunk);
+    PROPAGATE(rc);
+    return gridFromBbox(lo, hi, spacing, bucketSize, out);
+}
+
+static int gridFromBbox(const float lo[3], const float hi[3], float spacing, uint32_t bucketSize, mlsgpu_grid *out)
+{
     if (lo[0] > hi[0])
         return setError(MLSGPU_ERR_INVALID, "Must be at least one splat");        /* std::runtime_error, :773-774 */
     for (int a = 0; a < 3; a++)
@@ -671,4 +1043,44 @@ MLSGPU_API int mlsgpu_hip_bucket_load(mlsgpu_ctx *ctx, const mlsgpu_splat *dSpla
            fullGrid->reference[0], fullGrid->reference[1], fullGrid->reference[2], 1.0f / fullGrid->spacing,
            (float) fullGrid->extents[0], (float) fullGrid->extents[2], (float) fullGrid->extents[4], dOut);
     return MLSGPU_OK;
+}
+
+/* Bucket::bucket over a FileSet that need not fit the device (the role of FastBlobSet + the host bucketing of
+ * src/bucket_impl.h:439-560 for data beyond HBM; see Bucketer::recurseStream). */
+MLSGPU_API int mlsgpu_hip_bucket_stream(mlsgpu_ctx *ctx, mlsgpu_fileset *files, const mlsgpu_grid *region,
+                                        const mlsgpu_bucket_params *params, uint64_t budgetSplats, uint64_t chunkSplats,
+                                        uint32_t readerThreads, mlsgpu_bucket_fn fn, void *user, uint64_t *cellSplats,
+                                        uint64_t stats[4])
+{
+    REQUIRE(ctx != nullptr && files != nullptr && region != nullptr && params != nullptr && fn != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(region->spacing > 0.0f && params->maxCells >= 1 && params->maxSplats >= 1 && params->maxSplit >= 8, MLSGPU_ERR_INVALID);
+    REQUIRE(budgetSplats >= 1 && budgetSplats < 0xFFFFFFFFull && chunkSplats >= 1 && chunkSplats < 0xFFFFFFFFull, MLSGPU_ERR_INVALID);
+    for (int i = 0; i < 3; i++)
+        REQUIRE(region->extents[2 * i] < region->extents[2 * i + 1], MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    std::shared_ptr<void> &cached = ctx->scratchCache["bucket"];
+    if (!cached)
+        cached = std::shared_ptr<void>(new Bucketer::DepthList, [](void *p) { delete static_cast<Bucketer::DepthList *>(p); });
+    Bucketer b;
+    b.depthList = static_cast<Bucketer::DepthList *>(cached.get());
+    b.ctx = ctx;
+    b.dSplats = nullptr;
+    b.numSplats = mlsgpu_hip_fileset_num_splats(files);
+    b.full = *region;
+    b.P = *params;
+    b.fn = fn;
+    b.user = user;
+    GridBox g;
+    for (int i = 0; i < 3; i++)
+    {
+        g.lo[i] = region->extents[2 * i];
+        g.hi[i] = region->extents[2 * i + 1];
+    }
+    uint64_t local[4] = {0, 0, 0, 0};
+    const int rc = b.numSplats == 0 ? MLSGPU_OK
+        : b.recurseStream(files, b.numSplats, g, budgetSplats, chunkSplats, readerThreads, stats != nullptr ? stats : local);
+    if (cellSplats != nullptr)
+        *cellSplats = b.cellSplats;
+    hipStreamSynchronize(ctx->stream);
+    return rc;
 }

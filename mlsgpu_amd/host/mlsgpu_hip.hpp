@@ -598,6 +598,15 @@ public:
     void addFile(const std::string &path) { check(mlsgpu_hip_fileset_add_file(h, path.c_str())); }
     void setBufferSize(std::uint64_t bytes) { check(mlsgpu_hip_fileset_set_buffer_size(h, bytes)); }
     std::uint64_t maxSplats() const { return mlsgpu_hip_fileset_num_splats(h); }
+    mlsgpu_fileset *get() const { return h; }
+    /// FastBlobSet::getBoundingGrid for a set that need not fit the device: one pass over the files
+    mlsgpu_grid boundingGrid(const Context &ctx, float spacing, std::uint32_t bucketSize, std::uint64_t chunkSplats,
+                             unsigned readerThreads = 0)
+    {
+        mlsgpu_grid g;
+        check(mlsgpu_hip_fileset_bounding_grid(h, ctx.get(), spacing, bucketSize, chunkSplats, readerThreads, &g));
+        return g;
+    }
     void read(std::uint64_t first, std::uint64_t count, Splat *out) { check(mlsgpu_hip_fileset_read(h, first, count, out)); }
     void load(const Context &ctx, const Buffer<Splat> &out, std::uint64_t first, std::uint64_t count, unsigned readerThreads = 0)
     {
@@ -656,6 +665,18 @@ public:
             g.numVertices[i] = (std::uint32_t) (bin.extents[2 * i + 1] - bin.extents[2 * i] + 1);
         }
         check(mlsgpu_hip_farm_submit_device(h, device, cloud.get(), bin.dIds, bin.numSplats, &fullGrid, g.low, g.numVertices,
+                                            chunkId));
+    }
+    /// the same for a bin of Bucket::bucketStream: its splats are in the batch that is resident during the callback
+    void submitDevice(int device, const mlsgpu_bucket &bin, const mlsgpu_grid &fullGrid, std::uint64_t chunkId)
+    {
+        BucketGrid g;
+        for (int i = 0; i < 3; i++)
+        {
+            g.low[i] = bin.extents[2 * i] - fullGrid.extents[2 * i];
+            g.numVertices[i] = (std::uint32_t) (bin.extents[2 * i + 1] - bin.extents[2 * i] + 1);
+        }
+        check(mlsgpu_hip_farm_submit_device(h, device, bin.dSplats, bin.dIds, bin.numSplats, &fullGrid, g.low, g.numVertices,
                                             chunkId));
     }
     void finish() { check(mlsgpu_hip_farm_finish(h)); }
@@ -720,6 +741,30 @@ inline void bucket(const Context &ctx, const Buffer<Splat> &splats, std::uint64_
     detail::Thunk thunk{&process, std::exception_ptr()};
     std::uint64_t cellSplats = 0;
     const int rc = mlsgpu_hip_bucket(ctx.get(), splats.get(), numSplats, &region, &p, &detail::Thunk::call, &thunk, &cellSplats);
+    if (thunk.error)
+        std::rethrow_exception(thunk.error);
+    if (rc == MLSGPU_ERR_DENSITY)
+        throw DensityError(cellSplats);
+    check(rc);
+}
+
+/// Bucket::bucket over a FileSet that need NOT fit the device (mlsgpu_hip_bucket_stream): the files are streamed through a
+/// chunk buffer, once to count and once per batch of top-level regions that fit `budgetSplats`; bin.dSplats is the batch
+/// the ids index, valid during the call.  Same bins as bucket() makes of the set resident.
+inline void bucketStream(const Context &ctx, FileSet &files, const Grid &region, std::uint64_t maxSplats, std::uint32_t maxCells,
+                         std::uint32_t chunkCells, std::uint32_t microCells, std::uint64_t maxSplit, std::uint64_t budgetSplats,
+                         std::uint64_t chunkSplats, unsigned readerThreads, const Processor &process, std::uint64_t stats[4] = NULL)
+{
+    mlsgpu_bucket_params p;
+    p.maxSplats = maxSplats;
+    p.maxCells = maxCells;
+    p.chunkCells = chunkCells;
+    p.microCells = microCells;
+    p.maxSplit = maxSplit;
+    detail::Thunk thunk{&process, std::exception_ptr()};
+    std::uint64_t cellSplats = 0;
+    const int rc = mlsgpu_hip_bucket_stream(ctx.get(), files.get(), &region, &p, budgetSplats, chunkSplats, readerThreads,
+                                            &detail::Thunk::call, &thunk, &cellSplats, stats);
     if (thunk.error)
         std::rethrow_exception(thunk.error);
     if (rc == MLSGPU_ERR_DENSITY)

@@ -160,3 +160,99 @@ def test_cfg5_shape_files_to_welded_mesh(tmp_path):
     assert mo.isomorphic(got["vertices"], got["triangles"], exp[0][1], exp[0][2])
     sink.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("budget,chunk", [(60_000, 25_000), (400_000, 64), (5_000, 300_000)])
+def test_streamed_bucketing_equals_resident(tmp_path, budget, chunk):
+    """mlsgpu_hip_bucket_stream (a splat set that does not fit the device: the files streamed through a chunk buffer, once
+    to count and once per batch of top-level regions) makes the buckets mlsgpu_hip_bucket makes of the same set resident --
+    extents, order and member splats in file order -- whatever the budget and the chunk size; a budget below the largest
+    top-level region is a length error, not a wrong partition."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as mb, synth
+    cloud = synth.shells_cloud(150_000, 127.0, 24.0, 1.5, 2.5, seed=77)
+    cloud["position"] *= np.float32(0.5)
+    cloud["radius"] *= np.float32(0.5)
+    paths = make_files(tmp_path, cloud, [50_000, 30_000, 70_000])
+    spacing, bucket_size = 0.5, 63
+    fs = mb.FileSet(paths, buffer_size=256 << 10)
+    ctx = m.Context(0)
+    raw = m.DeviceBuffer(ctx, nbytes=len(fs) * 32)
+    fs.load(ctx, raw)
+    reference, _, ext = mb.bounding_grid(ctx, raw, len(fs), spacing, bucket_size)
+    bp = dict(max_splats=12_000, max_cells=bucket_size, chunk_cells=0, micro_cells=0, max_split=1 << 20)
+
+    def gather(store):
+        def take(leaf, d_splats, d_ids):
+            staged = m.DeviceBuffer(ctx, nbytes=max(leaf["num_splats"], 1) * 32)
+            mb.bucket_load(ctx, d_splats, d_ids, leaf["num_splats"], reference, spacing, ext, staged)
+            ctx.synchronize()
+            store.append(staged.download(m.SPLAT_DTYPE, leaf["num_splats"]))
+        return take
+    want = []
+    resident = mb.bucket_cloud(ctx, raw, len(fs), reference, spacing, ext,
+                               on_bucket=lambda leaf, d_ids: gather(want)(leaf, raw, d_ids), **bp)
+    assert len(resident) > 20 and max(l["depth"] for l in resident) >= 1
+    got = []
+    if budget < 6_000:          # below the largest top-level region (150 k splats in at most 27 microblocks)
+        with pytest.raises(mb.LengthError):
+            mb.bucket_cloud_stream(ctx, fs, reference, spacing, ext, budget_splats=budget, chunk_splats=chunk,
+                                   on_bucket=gather(got), **bp)
+        return
+    leaves, stats = mb.bucket_cloud_stream(ctx, fs, reference, spacing, ext, budget_splats=budget, chunk_splats=chunk,
+                                           on_bucket=gather(got), **bp)
+    assert [(l["extents"], l["chunk"], l["depth"], l["num_splats"]) for l in leaves] == \
+        [(l["extents"], l["chunk"], l["depth"], l["num_splats"]) for l in resident]
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert stats["file_passes"] == 1 + stats["batches"] and stats["largest_batch"] <= budget
+    if budget < len(fs):
+        assert stats["batches"] >= 2
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_streamed_set_to_welded_mesh(tmp_path):
+    """The out-of-core route end to end: files -> streamed bucketing (three batches) -> the farm's device path (every bucket
+    gathered out of the resident batch during the callback) -> device sink; the same welded, pruned mesh as the set resident."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import mesher_oracle as mo
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as mb, farm as fm, synth
+    cloud = synth.shells_cloud(150_000, 127.0, 24.0, 1.5, 2.5, seed=55)
+    cloud["position"] *= np.float32(0.5)
+    cloud["radius"] *= np.float32(0.5)
+    paths = make_files(tmp_path, cloud, [50_000, 30_000, 70_000])
+    spacing, bucket_size = 0.5, 63
+    fs = mb.FileSet(paths, buffer_size=256 << 10)
+    ctx = m.Context(0)
+    raw = m.DeviceBuffer(ctx, nbytes=len(fs) * 32)
+    fs.load(ctx, raw)
+    reference, _, ext = mb.bounding_grid(ctx, raw, len(fs), spacing, bucket_size)
+    bp = dict(max_splats=40_000, max_cells=bucket_size, chunk_cells=0, micro_cells=0, max_split=1 << 20)
+    origin = [reference[a] + spacing * ext[2 * a] for a in range(3)]
+    results = []
+    for streamed in (False, True):
+        sink = m.Mesher(ctx, 0.02)
+        farm = m.BucketFarm([0, 0], bp["max_splats"], workers_per_device=2, max_cells=bucket_size, sink=sink,
+                            grid_spacing=spacing, grid_origin=origin)
+        if streamed:
+            def work(leaf, d_splats, d_ids):
+                low, nv = fm.leaf_geometry(leaf, ext)
+                farm.submit_device(0, d_splats, d_ids, leaf["num_splats"], reference, spacing, ext, low, nv, 0)
+            leaves, stats = mb.bucket_cloud_stream(ctx, fs, reference, spacing, ext, budget_splats=70_000, chunk_splats=40_000,
+                                                   on_bucket=work, **bp)
+            assert stats["batches"] >= 3
+        else:
+            fm.partition_to_farm(ctx, farm, 0, raw, len(fs), reference, spacing, ext, bp, chunk_of=lambda i: 0)
+        farm.finish()
+        farm.close()
+        assert sink.finalize() == 1
+        results.append((sink.stats(), sink.chunk(0)))
+        sink.close()
+    (s0, c0), (s1, c1) = results
+    for k in ("total_vertices", "threshold", "components", "kept_components", "kept_vertices", "kept_triangles"):
+        assert s0[k] == s1[k], k
+    assert mo.isomorphic(c0["vertices"], c0["triangles"], c1["vertices"], c1["triangles"])
+    ctx.close()
