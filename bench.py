@@ -540,6 +540,35 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     return out
 
 
+def host_weld_leg(m, args, device_index, bucketed_host, buckets, max_count, max_cells, voxels):
+    """The reference's complete route, welder included: host splats -> farm -> every ship-out read back through the pinned ring
+    -> ONE mesher thread running OOCMesher's weld on the host (clumps, key map, union-find; src/mesher.cpp:220-311) ->
+    finalize (components, prune, one mesh).  One pass: the host welder takes ~18 M vertices/s, the device sink 3 800 M."""
+    nworkers = max(1, min(args.workers, len(buckets)))
+    welder = m.HostMesher(0.02)
+    farm = m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
+                        mesh_memory=args.mesh_memory_mb << 20, copy_threads=args.copy_threads)
+    farm.set_host_output(2 << 30, welder)
+    views = [bucketed_host[b.first:b.first + b.count] for b in buckets]
+    t0 = time.perf_counter()
+    for b, v in zip(buckets, views):
+        farm.submit(v, b.low, b.num_vertices, 0)
+    farm.finish()
+    t1 = time.perf_counter()
+    n = welder.finalize()
+    t2 = time.perf_counter()
+    st = welder.stats()
+    hs = farm.host_stats()
+    farm.close()
+    welder.close()
+    return {"value": round(voxels / (t2 - t0) / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round((t2 - t0) * 1e3, 1),
+            "pass_until_last_mesh_welded_ms": round((t1 - t0) * 1e3, 1), "finalize_ms": round((t2 - t1) * 1e3, 1),
+            "vertices_welded_per_s": round(st["vertices_added"] / (t2 - t0)), "chunks": n, "ring_waits": hs["ring_waits"],
+            "welded_vertices": st["total_vertices"], "kept_triangles": st["kept_triangles"],
+            "note": "one pass; the single mesher thread (hash map of external keys, union-find per block) bounds it, as the manual "
+                    "says of the reference (doc/mlsgpu-user-manual.xml:508-511)"}
+
+
 def multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, local_rank, ndev, ctx, bucketed_t, buckets, max_count,
                    max_cells, voxels, L, nworkers):
     """N > 1 only, never `value`.
@@ -1297,6 +1326,7 @@ def main():
             torch.cuda.empty_cache()
             if not args.no_transfer:
                 shells["transfer_inclusive"] = transfer_legs(m, args, local_rank, sb_host, sbuckets, smax, scells, svox, L)
+                shells["transfer_inclusive"]["host_weld"] = host_weld_leg(m, args, local_rank, sb_host, sbuckets, smax, scells, svox)
             result["shells"] = shells
         except Exception as e:      # noqa: BLE001 - reported in the line
             result.setdefault("leg_errors", {})['shells'] = "%s: %s" % (type(e).__name__, e)
