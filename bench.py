@@ -285,7 +285,7 @@ def run_cfg5(args, rank, world, local_rank, device, dist, reduce_device):
             streamed = {
                 "ms_per_pass": round(stream_s * 1e3, 1), "msplats_per_s": round(n / stream_s / 1e6, 1),
                 "mvoxels_per_s": round(voxels / stream_s / 1e6, 1), "budget_splats": budget, "chunk_splats": chunk,
-                "file_passes": sstats["file_passes"], "batches": sstats["batches"], "largest_batch": sstats["largest_batch"],
+                "file_passes": sstats["file_passes"], "batches": sstats["batches"], "chunks_skipped": sstats["chunks_skipped"],
                 "splats_loaded_into_batches": sstats["batch_splats"], "buckets": len(sleaves),
                 "same_buckets_as_resident": [l["extents"] for l in sleaves] == [l["extents"] for l in leaves]
                 and [l["num_splats"] for l in sleaves] == [l["num_splats"] for l in leaves],

@@ -503,7 +503,8 @@ int mlsgpu_hip_fileset_load(mlsgpu_fileset *files, mlsgpu_ctx *ctx, uint64_t fir
  * batch is resident while its regions are split further and its buckets handed to `fn`, whose mlsgpu_bucket::dSplats is the
  * batch and dIds positions in it (valid during the callback: mlsgpu_hip_farm_submit_device copies the bucket out).  The
  * buckets -- extents, order, member splats in file order -- are those mlsgpu_hip_bucket makes of the same set resident.
- * stats (may be NULL): [0] passes over the files, [1] batches, [2] splats loaded into batches, [3] largest batch.
+ * stats (may be NULL): [0] passes over the files, [1] batches, [2] splats loaded into batches, [3] file chunks a pass did
+ * not have to read (the first pass notes every chunk's bounding box; a batch skips the chunks that stay clear of its regions).
  * MLSGPU_ERR_LENGTH if one top-level region alone exceeds the budget. */
 /* FastBlobSet::makeBoundingGrid (src/splat_set_impl.h:770-811) for such a set: one pass over the files through a chunk buffer */
 int mlsgpu_hip_fileset_bounding_grid(mlsgpu_fileset *files, mlsgpu_ctx *ctx, float spacing, uint32_t bucketSize,

@@ -1342,7 +1342,7 @@ def bucket_cloud_stream(ctx, fileset, reference, spacing, extents, max_splats, m
         e.cell_splats = int(cell.value)
         raise e
     check(rc)
-    return leaves, dict(zip(["file_passes", "batches", "batch_splats", "largest_batch"], [int(x) for x in stats]))
+    return leaves, dict(zip(["file_passes", "batches", "batch_splats", "chunks_skipped"], [int(x) for x in stats]))
 
 
 def bounding_grid_files(ctx, fileset, spacing, bucket_size, chunk_splats, reader_threads=0):

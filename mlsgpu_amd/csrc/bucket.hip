@@ -27,6 +27,9 @@
 
 using namespace mlsgpu;
 
+/* detail::Bbox of device-resident splats folded into lo / hi (defined with the bounding-grid entry points below) */
+static int foldBbox(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, uint64_t numSplats, float lo[3], float hi[3]);
+
 namespace
 {
 
@@ -180,7 +183,18 @@ struct RegionEmitOut
 struct BatchJoinIn
 {
     RegionCountIn C;
-    __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return C(i) != 0 ? 1u : 0u; }
+    uint8_t *flags;             /* remembered for the scan's second phase (BatchFlagIn) */
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const
+    {
+        const uint32_t j = C(i) != 0 ? 1u : 0u;
+        flags[i] = (uint8_t) j;
+        return j;
+    }
+};
+struct BatchFlagIn
+{
+    const uint8_t *flags;
+    __device__ __forceinline__ uint32_t operator()(uint64_t i) const { return flags[i]; }
 };
 /* ... and if so it is appended to the batch, in file order */
 struct BatchCopyOut
@@ -677,23 +691,57 @@ int Bucketer::recurseStream(mlsgpu_fileset *files, uint64_t n, const GridBox &gr
     /* the chunk in flight, the batch, and two words: splats of the batch so far, splats the last chunk added */
     mlsgpu_splat *dChunk = nullptr, *dBatch = nullptr;
     uint32_t *dWords = nullptr, *dScanSums = nullptr;
+    uint8_t *dFlags = nullptr;
     struct Free
     {
         mlsgpu_splat *&a, *&b;
         uint32_t *&c, *&d;
-        ~Free() { hipFree(a); hipFree(b); hipFree(c); hipFree(d); }
-    } release{dChunk, dBatch, dWords, dScanSums};
+        uint8_t *&e;
+        ~Free() { hipFree(a); hipFree(b); hipFree(c); hipFree(d); hipFree(e); }
+    } release{dChunk, dBatch, dWords, dScanSums, dFlags};
     HIP_CHECK(hipMalloc((void **) &dChunk, chunkSplats * sizeof(mlsgpu_splat)));
     HIP_CHECK(hipMalloc((void **) &dBatch, budget * sizeof(mlsgpu_splat)));
     HIP_CHECK(hipMalloc((void **) &dWords, 2 * sizeof(uint32_t)));
     HIP_CHECK(hipMalloc((void **) &dScanSums, ((size_t) scanTiles(chunkSplats) + 1) * sizeof(uint32_t)));
+    HIP_CHECK(hipMalloc((void **) &dFlags, chunkSplats));
 
-    auto forEachFileChunk = [&](const std::function<int(uint64_t)> &body) -> int
+    /* The bounding box of every file chunk's splats (with their radii), noted in the first pass: a later pass skips the chunks
+     * that cannot reach the regions it is collecting -- what the reference's blob index buys on inputs whose files are
+     * spatially coherent (scans); a shuffled cloud skips nothing. */
+    const uint64_t numChunks = (n + chunkSplats - 1) / chunkSplats;
+    std::vector<float> chunkBox;        /* 6 per chunk: lo xyz, hi xyz; empty until the first pass has run */
+    auto forEachFileChunk = [&](const float *want, const std::function<int(uint64_t)> &body) -> int
     {
-        for (uint64_t first = 0; first < n; first += chunkSplats)
+        const bool note = chunkBox.empty();
+        if (note)
+            chunkBox.assign(numChunks * 6, 0.0f);
+        for (uint64_t c = 0; c < numChunks; c++)
         {
+            const uint64_t first = c * chunkSplats;
             const uint64_t cnt = std::min<uint64_t>(chunkSplats, n - first);
+            float *box = &chunkBox[c * 6];
+            if (!note && want != nullptr)
+            {
+                bool reach = true;
+                for (int a = 0; a < 3; a++)
+                    reach = reach && box[a] <= want[3 + a] && box[3 + a] >= want[a];
+                if (!reach)
+                {
+                    stats[3]++;
+                    continue;
+                }
+            }
             PROPAGATE(mlsgpu_hip_fileset_load(files, ctx, first, cnt, dChunk, readerThreads));
+            if (note)
+            {
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                PROPAGATE(foldBbox(ctx, dChunk, cnt, lo, hi));
+                for (int a = 0; a < 3; a++)
+                {
+                    box[a] = lo[a];
+                    box[3 + a] = hi[a];
+                }
+            }
             PROPAGATE(body(cnt));
         }
         stats[0]++;
@@ -752,7 +800,7 @@ int Bucketer::recurseStream(mlsgpu_fileset *files, uint64_t n, const GridBox &gr
                 uint32_t ldsFrom = L.levels;
                 while (ldsFrom > 0 && totalNodes - L.offset[ldsFrom - 1] <= LDS_NODES)
                     ldsFrom--;
-                PROPAGATE(forEachFileChunk([&](uint64_t cnt) -> int
+                PROPAGATE(forEachFileChunk(nullptr, [&](uint64_t cnt) -> int
                 {
                     const uint32_t blocks = (uint32_t) std::min<uint64_t>(divUp(cnt, 256), 4096);
                     LAUNCH(ctx, "bucket.count.time", bucketCountKernel, dim3(blocks), dim3(256), V, L, B.counts, cnt, ldsFrom);
@@ -823,10 +871,21 @@ int Bucketer::recurseStream(mlsgpu_fileset *files, uint64_t n, const GridBox &gr
                     /* pass 2: the batch's splats, in file order */
                     HIP_CHECK(hipMemsetAsync(dWords, 0, 8, ctx->stream));
                     RegionCountIn joins{V, B.table, r0, r1};
-                    PROPAGATE(forEachFileChunk([&](uint64_t cnt) -> int
+                    /* the batch's regions in world coordinates, a cell wider on every side: a splat joins a region by the cells
+                     * its box [p - r, p + r] floors into, and a chunk whose box stays clear of all of them has no member */
+                    float want[6] = {INFINITY, INFINITY, INFINITY, -INFINITY, -INFINITY, -INFINITY};
+                    for (uint32_t r = r0; r < r1; r++)
+                        for (int i = 0; i < 3; i++)
+                        {
+                            const int64_t lowerCell = (int64_t) sub.lo[i] + (((int64_t) microSize * regions[r].c[i]) << regions[r].level);
+                            const int64_t upperCell = lowerCell + ((int64_t) microSize << regions[r].level);
+                            want[i] = std::min(want[i], full.reference[i] + full.spacing * (float) (lowerCell - 1));
+                            want[3 + i] = std::max(want[3 + i], full.reference[i] + full.spacing * (float) (upperCell + 1));
+                        }
+                    PROPAGATE(forEachFileChunk(want, [&](uint64_t cnt) -> int
                     {
-                        PROPAGATE((exclusiveScan2<uint32_t, BatchJoinIn, BatchJoinIn, BatchCopyOut>(
-                            ctx, "bucket.members.time", BatchJoinIn{joins}, BatchJoinIn{joins},
+                        PROPAGATE((exclusiveScan2<uint32_t, BatchJoinIn, BatchFlagIn, BatchCopyOut>(
+                            ctx, "bucket.members.time", BatchJoinIn{joins, dFlags}, BatchFlagIn{dFlags},
                             BatchCopyOut{dChunk, dBatch, dWords}, cnt, 0u, dScanSums, dWords + 1)));
                         hipLaunchKernelGGL(addCountKernel, dim3(1), dim3(1), 0, ctx->stream, dWords, (const uint32_t *) (dWords + 1));
                         HIP_CHECK(hipGetLastError());
@@ -838,7 +897,6 @@ int Bucketer::recurseStream(mlsgpu_fileset *files, uint64_t n, const GridBox &gr
                     HIP_CHECK(hipStreamSynchronize(ctx->stream));
                     REQUIRE(nb <= budget, MLSGPU_ERR_LENGTH);
                     stats[2] += nb;
-                    stats[3] = std::max<uint64_t>(stats[3], nb);
 
                     /* from here the batch is a resident cloud: member lists of regions [r0, r1) and the recursion, as recurse() */
                     RegionView VB = V;

@@ -163,8 +163,9 @@ def test_cfg5_shape_files_to_welded_mesh(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("budget,chunk", [(60_000, 25_000), (400_000, 64), (5_000, 300_000)])
-def test_streamed_bucketing_equals_resident(tmp_path, budget, chunk):
+@pytest.mark.parametrize("budget,chunk,coherent", [(60_000, 25_000, False), (400_000, 64, False), (5_000, 300_000, False),
+                                                  (60_000, 10_000, True)])
+def test_streamed_bucketing_equals_resident(tmp_path, budget, chunk, coherent):
     """mlsgpu_hip_bucket_stream (a splat set that does not fit the device: the files streamed through a chunk buffer, once
     to count and once per batch of top-level regions) makes the buckets mlsgpu_hip_bucket makes of the same set resident --
     extents, order and member splats in file order -- whatever the budget and the chunk size; a budget below the largest
@@ -174,6 +175,8 @@ def test_streamed_bucketing_equals_resident(tmp_path, budget, chunk):
     cloud = synth.shells_cloud(150_000, 127.0, 24.0, 1.5, 2.5, seed=77)
     cloud["position"] *= np.float32(0.5)
     cloud["radius"] *= np.float32(0.5)
+    if coherent:        # files in scan order (here: sorted along z): a batch's pass skips the chunks that stay clear of it
+        cloud = cloud[np.argsort(cloud["position"][:, 2], kind="stable")]
     paths = make_files(tmp_path, cloud, [50_000, 30_000, 70_000])
     spacing, bucket_size = 0.5, 63
     fs = mb.FileSet(paths, buffer_size=256 << 10)
@@ -181,6 +184,7 @@ def test_streamed_bucketing_equals_resident(tmp_path, budget, chunk):
     raw = m.DeviceBuffer(ctx, nbytes=len(fs) * 32)
     fs.load(ctx, raw)
     reference, _, ext = mb.bounding_grid(ctx, raw, len(fs), spacing, bucket_size)
+    assert mb.bounding_grid_files(ctx, fs, spacing, bucket_size, chunk)[2] == ext
     bp = dict(max_splats=12_000, max_cells=bucket_size, chunk_cells=0, micro_cells=0, max_split=1 << 20)
 
     def gather(store):
@@ -206,9 +210,10 @@ def test_streamed_bucketing_equals_resident(tmp_path, budget, chunk):
         [(l["extents"], l["chunk"], l["depth"], l["num_splats"]) for l in resident]
     for a, b in zip(got, want):
         np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
-    assert stats["file_passes"] == 1 + stats["batches"] and stats["largest_batch"] <= budget
+    assert stats["file_passes"] == 1 + stats["batches"] and stats["batch_splats"] >= len(fs)
     if budget < len(fs):
         assert stats["batches"] >= 2
+    assert (stats["chunks_skipped"] > 0) == coherent
     ctx.close()
 
 
