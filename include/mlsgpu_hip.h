@@ -453,6 +453,14 @@ int mlsgpu_hip_host_mesher_boundary_read(mlsgpu_host_mesher *mesher, uint64_t *k
 int mlsgpu_hip_host_mesher_finalize_with(mlsgpu_host_mesher *mesher, const uint8_t *keepClump, uint64_t numClumps,
                                          uint32_t *numChunks);
 
+/* Output chunk i of a finalized mesher (mlsgpu_hip_mesher_chunk) written as FastPly::Writer's file STRAIGHT FROM HBM through
+ * two pinned buffers of bufferBytes / 2 (0 = 64 MiB): while one piece is written the next travels, faces are packed into the
+ * file's 13-byte records on the device, and the host never holds more of the mesh than the buffer -- the role of the
+ * reference's asynchronous writer (src/async_io.h:95-140) for outputs larger than host memory.  Same bytes as
+ * mlsgpu_hip_write_ply of the downloaded arrays. */
+int mlsgpu_hip_mesher_write_ply(mlsgpu_mesher *mesher, uint32_t i, const char *path, const char *const *comments,
+                                uint32_t numComments, uint64_t bufferBytes);
+
 /* FastPly::Writer's file from host memory (src/fast_ply.cpp:443-521): binary little endian, header padded to 4 bytes,
  * float32 x y z, faces as uint8 3 + 3 x uint32 */
 int mlsgpu_hip_write_ply(const char *path, const float *vertices, uint64_t numVertices, const uint32_t *triangles,

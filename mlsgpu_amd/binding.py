@@ -194,6 +194,7 @@ def lib():
     sig("mlsgpu_hip_farm_finish", C.c_int, vp)
     sig("mlsgpu_hip_farm_stats", C.c_int, vp, vp)
     sig("mlsgpu_hip_farm_in_flight_max", C.c_int, vp, vp)
+    sig("mlsgpu_hip_mesher_write_ply", C.c_int, vp, C.c_uint32, C.c_char_p, vp, C.c_uint32, u64)
     sig("mlsgpu_hip_farm_set_host_output", C.c_int, vp, u64, vp, vp)
     sig("mlsgpu_hip_farm_host_stats", C.c_int, vp, vp)
     sig("mlsgpu_hip_host_mesher_create", C.c_int, P(vp))
@@ -710,6 +711,12 @@ class Mesher:
                 check(lib().mlsgpu_hip_memcpy_d2h(self.ctx.h, _p(t), pt.value, t.nbytes, 0))
             out["vertices"], out["triangles"] = v, t
         return out
+
+    def write_ply(self, i, path, comments=(), buffer_bytes=0):
+        """Output chunk i straight from HBM into FastPly::Writer's file through a bounded pinned buffer."""
+        arr = (C.c_char_p * max(len(comments), 1))(*[c.encode("ascii") for c in comments])
+        check(lib().mlsgpu_hip_mesher_write_ply(self.h, i, str(path).encode(), C.cast(arr, C.c_void_p) if comments else None,
+                                                len(comments), buffer_bytes))
 
     def stats(self):
         out = np.zeros(8, np.uint64)

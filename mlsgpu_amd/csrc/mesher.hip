@@ -1119,13 +1119,10 @@ MLSGPU_API int mlsgpu_hip_mesher_finalize_with(mlsgpu_mesher *m, const uint8_t *
     return m->finalizeImpl(numChunks, false, numRoots ? keepRoot : &none, numRoots);
 }
 
-/* FastPly::Writer's file (src/fast_ply.cpp:443-521): header padded to a multiple of 4, float32 x y z per vertex,
- * uint8 3 + 3 x uint32 per face; host memory in, one file out */
-MLSGPU_API int mlsgpu_hip_write_ply(const char *path, const float *vertices, uint64_t numVertices, const uint32_t *triangles,
-                                    uint64_t numTriangles, const char *const *comments, uint32_t numComments)
+namespace
 {
-    REQUIRE(path != nullptr && (numVertices == 0 || vertices != nullptr) && (numTriangles == 0 || triangles != nullptr),
-            MLSGPU_ERR_INVALID);
+std::string plyHeader(uint64_t numVertices, uint64_t numTriangles, const char *const *comments, uint32_t numComments)
+{
     std::string head = "ply\nformat binary_little_endian 1.0\n";
     for (uint32_t i = 0; i < numComments; i++)
         head += std::string("comment ") + comments[i] + "\n";
@@ -1138,6 +1135,134 @@ MLSGPU_API int mlsgpu_hip_write_ply(const char *path, const float *vertices, uin
         size++;
     }
     head += "\nend_header\n";
+    return head;
+}
+
+/* a face of the file: the count byte and three indices, 13 bytes, packed on the device */
+__global__ __launch_bounds__(256) void packFacesKernel(const uint32_t *triangles, uint64_t n, uint8_t *out)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    uint8_t *o = out + 13 * i;
+    o[0] = 3;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+    {
+        const uint32_t v = triangles[3 * i + k];
+        o[1 + 4 * k] = (uint8_t) v;
+        o[2 + 4 * k] = (uint8_t) (v >> 8);
+        o[3 + 4 * k] = (uint8_t) (v >> 16);
+        o[4 + 4 * k] = (uint8_t) (v >> 24);
+    }
+}
+} // namespace
+
+/*
+ * One output chunk of a finalized mesher straight from HBM into FastPly::Writer's file, through two pinned buffers of
+ * bufferBytes / 2: while one piece is written, the next travels (the role of src/async_io.h:95-140 behind the reference's
+ * writer: the host never holds more of the mesh than the buffer).  Faces are packed into the file's 13-byte records on the
+ * device.  The file is byte for byte what mlsgpu_hip_write_ply makes of the downloaded arrays.
+ */
+MLSGPU_API int mlsgpu_hip_mesher_write_ply(mlsgpu_mesher *m, uint32_t i, const char *path, const char *const *comments,
+                                           uint32_t numComments, uint64_t bufferBytes)
+{
+    REQUIRE(m != nullptr && path != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    REQUIRE(m->finalized && i < m->outChunks.size(), MLSGPU_ERR_INVALID);
+    mlsgpu_ctx *ctx = m->ctx;
+    HIP_CHECK(hipSetDevice(ctx->device));
+    const uint32_t c = m->outChunks[i];
+    const uint64_t nv = m->chunkVStart[c + 1] - m->chunkVStart[c], nt = m->chunkTStart[c + 1] - m->chunkTStart[c];
+    const uint8_t *dV = reinterpret_cast<const uint8_t *>(m->outVertices + 3 * (uint64_t) m->chunkVStart[c]);
+    const uint32_t *dT = m->outTriangles + 3 * (uint64_t) m->chunkTStart[c];
+    if (bufferBytes == 0)
+        bufferBytes = uint64_t(64) << 20;
+    /* a piece holds whole 12-byte vertices and whole 13-byte faces */
+    const uint64_t piece = std::max<uint64_t>(bufferBytes / 2 / 156, 1) * 156;
+    uint8_t *pinned[2] = {nullptr, nullptr}, *dPack = nullptr;
+    hipEvent_t done[2] = {nullptr, nullptr};
+    FILE *f = nullptr;
+    int rc = MLSGPU_OK;
+    auto cleanup = [&]()
+    {
+        for (int k = 0; k < 2; k++)
+        {
+            if (pinned[k]) hipHostFree(pinned[k]);
+            if (done[k]) hipEventDestroy(done[k]);
+        }
+        hipFree(dPack);
+        if (f != nullptr)
+            std::fclose(f);
+    };
+    for (int k = 0; k < 2 && rc == MLSGPU_OK; k++)
+        if (hipHostMalloc((void **) &pinned[k], piece) != hipSuccess || hipEventCreateWithFlags(&done[k], hipEventDisableTiming) != hipSuccess)
+            rc = setError(MLSGPU_ERR_NOMEM, "mesher: cannot allocate %llu bytes of pinned write buffer", (unsigned long long) piece);
+    if (rc == MLSGPU_OK && hipMalloc((void **) &dPack, 2 * piece) != hipSuccess)
+        rc = setError(MLSGPU_ERR_NOMEM, "mesher: cannot allocate the face packing buffer");
+    if (rc == MLSGPU_OK && (f = std::fopen(path, "wb")) == nullptr)
+        rc = setError(MLSGPU_ERR_INVALID, "cannot open %s for writing", path);
+    if (rc != MLSGPU_OK)
+    {
+        cleanup();
+        return rc;
+    }
+    const std::string head = plyHeader(nv, nt, comments, numComments);
+    bool ok = std::fwrite(head.data(), 1, head.size(), f) == head.size();
+    /* the pieces of the file body in order: vertex bytes, then face records; piece k + 1 is on its way while k is written */
+    const uint64_t vBytes = 12 * nv, fBytes = 13 * nt, total = vBytes + fBytes;
+    const uint64_t vPieces = (vBytes + piece - 1) / piece, fPieces = (fBytes + piece - 1) / piece, pieces = vPieces + fPieces;
+    auto issue = [&](uint64_t k) -> hipError_t
+    {
+        const int slot = (int) (k & 1);
+        if (k < vPieces)
+        {
+            const uint64_t off = k * piece, n = std::min(piece, vBytes - off);
+            hipError_t e = hipMemcpyAsync(pinned[slot], dV + off, n, hipMemcpyDeviceToHost, ctx->stream);
+            return e != hipSuccess ? e : hipEventRecord(done[slot], ctx->stream);
+        }
+        const uint64_t off = (k - vPieces) * piece, n = std::min(piece, fBytes - off);
+        const uint64_t firstFace = off / 13, faces = n / 13;
+        uint8_t *pack = dPack + (uint64_t) slot * piece;
+        hipLaunchKernelGGL(packFacesKernel, dim3(divUp(faces, 256)), dim3(256), 0, ctx->stream, dT + 3 * firstFace, faces, pack);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess)
+            e = hipMemcpyAsync(pinned[slot], pack, n, hipMemcpyDeviceToHost, ctx->stream);
+        return e != hipSuccess ? e : hipEventRecord(done[slot], ctx->stream);
+    };
+    hipError_t e = pieces > 0 ? issue(0) : hipSuccess;
+    uint64_t written = 0;
+    for (uint64_t k = 0; k < pieces && ok && e == hipSuccess; k++)
+    {
+        if (k + 1 < pieces)
+            e = issue(k + 1);
+        if (e == hipSuccess)
+            e = hipEventSynchronize(done[k & 1]);
+        if (e != hipSuccess)
+            break;
+        const uint64_t n = k < vPieces ? std::min(piece, vBytes - k * piece) : std::min(piece, fBytes - (k - vPieces) * piece);
+        ok = std::fwrite(pinned[k & 1], 1, n, f) == n;
+        written += n;
+    }
+    hipStreamSynchronize(ctx->stream);
+    ok = (std::fclose(f) == 0) && ok && written == total;
+    f = nullptr;
+    cleanup();
+    if (e != hipSuccess)
+        return setError(MLSGPU_ERR_HIP, "mesher: reading the mesh back failed: %s", hipGetErrorString(e));
+    if (!ok)
+        return setError(MLSGPU_ERR_INVALID, "writing %s failed", path);
+    return MLSGPU_OK;
+}
+
+/* FastPly::Writer's file (src/fast_ply.cpp:443-521): header padded to a multiple of 4, float32 x y z per vertex,
+ * uint8 3 + 3 x uint32 per face; host memory in, one file out */
+MLSGPU_API int mlsgpu_hip_write_ply(const char *path, const float *vertices, uint64_t numVertices, const uint32_t *triangles,
+                                    uint64_t numTriangles, const char *const *comments, uint32_t numComments)
+{
+    REQUIRE(path != nullptr && (numVertices == 0 || vertices != nullptr) && (numTriangles == 0 || triangles != nullptr),
+            MLSGPU_ERR_INVALID);
+    const std::string head = plyHeader(numVertices, numTriangles, comments, numComments);
     FILE *f = std::fopen(path, "wb");
     if (f == nullptr)
         return setError(MLSGPU_ERR_INVALID, "cannot open %s for writing", path);

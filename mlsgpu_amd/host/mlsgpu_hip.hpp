@@ -516,6 +516,8 @@ public:
         mlsgpu_ctx *fromCtx = from.get();
         return [mesher, fromCtx, chunkId](void *, const DeviceKeyMesh &mesh) { check(mlsgpu_hip_mesher_add(mesher, fromCtx, chunkId, &mesh)); };
     }
+    /// pinned host memory a write may hold (two buffers of half this; 0 = 64 MiB), whatever the size of the mesh
+    std::uint64_t writeBufferBytes = 0;
     /// MesherBase::write: returns the number of files written.
     std::size_t write(const Namer &namer, const std::vector<std::string> &comments = std::vector<std::string>())
     {
@@ -524,20 +526,15 @@ public:
         std::vector<const char *> cstr;
         for (const std::string &c : comments)
             cstr.push_back(c.c_str());
-        std::vector<float> vertices;
-        std::vector<std::uint32_t> triangles;
         for (std::uint32_t i = 0; i < chunks; i++)
         {
             std::uint64_t id, nv, nt;
             const float *dV;
             const std::uint32_t *dT;
             check(mlsgpu_hip_mesher_chunk(h, i, &id, &nv, &nt, &dV, &dT));
-            vertices.resize(3 * nv);
-            triangles.resize(3 * nt);
-            check(mlsgpu_hip_memcpy_d2h(ctx->get(), vertices.data(), dV, vertices.size() * sizeof(float), 0));
-            check(mlsgpu_hip_memcpy_d2h(ctx->get(), triangles.data(), dT, triangles.size() * sizeof(std::uint32_t), 0));
-            check(mlsgpu_hip_write_ply(namer(id).c_str(), vertices.data(), nv, triangles.data(), nt,
-                                       cstr.empty() ? NULL : cstr.data(), (std::uint32_t) cstr.size()));
+            // straight from HBM through a bounded pinned buffer (the reference's asynchronous writer, src/async_io.h)
+            check(mlsgpu_hip_mesher_write_ply(h, i, namer(id).c_str(), cstr.empty() ? NULL : cstr.data(),
+                                              (std::uint32_t) cstr.size(), writeBufferBytes));
         }
         return chunks;
     }

@@ -120,7 +120,16 @@ def test_worker_meshes_weld_into_a_closed_surface(tmp_path):
     assert mo.isomorphic(got["vertices"], got["triangles"], exp[0][1], exp[0][2])
     path = tmp_path / "out.ply"
     b.write_ply(path, got["vertices"], got["triangles"], ["mlsgpu version: test"])
-    assert open(path, "rb").read() == mo.ply_bytes(got["vertices"], got["triangles"], ["mlsgpu version: test"])
+    want = mo.ply_bytes(got["vertices"], got["triangles"], ["mlsgpu version: test"])
+    assert open(path, "rb").read() == want
+    # the same file straight from HBM through a bounded pinned buffer (mlsgpu_hip_mesher_write_ply), whatever its size:
+    # pieces of 156 bytes (one vertex-and-face quantum), of a few KB, and one piece for everything
+    for buffer_bytes in (1, 4096, 1 << 16, 0):
+        streamed = tmp_path / ("streamed_%d.ply" % buffer_bytes)
+        mesher.write_ply(0, streamed, ["mlsgpu version: test"], buffer_bytes)
+        assert open(streamed, "rb").read() == want, buffer_bytes
+    with pytest.raises(b.InvalidArgument):
+        mesher.write_ply(1, tmp_path / "none.ply")
     mesher.close()
     del worker
     ctx.close()
