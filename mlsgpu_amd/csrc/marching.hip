@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void compactRowCellsKernel(const uint8_t *code
         if (code != 0)
         {
             const uint32_t pos = cellBase + popcBelow(occ);
-            cells[pos] = make_uint2(x | (y << 16), z);
+            cells[pos] = make_uint2(x | (y << 16), z | (code << 16));     /* the code rides along: one dependent load less */
             viStart[pos] = make_uint2(0u, indexBase + incl - ni);
         }
         cellBase += (uint32_t) __popcll(occ);
@@ -959,11 +959,14 @@ __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeVie
     if (gid < numCells)
     {
         const uint2 cell = cells[gid];
-        const uint32_t x = cell.x & 0xFFFFu, y = cell.x >> 16, z = cell.y;
-        const uint32_t code = C.at(x, y, z);
+        const uint32_t x = cell.x & 0xFFFFu, y = cell.x >> 16, z = cell.y & 0xFFFFu;
+        const uint32_t code = cell.y >> 16;                  /* packed by compactRowCellsKernel */
         const uint32_t local = viStart[gid].y - blockBase;
-        const uint32_t *rec = T.rec + code * 16;
-        const uint32_t ni = rec[3] >> 8;
+        /* the whole record at once (index count in word 3, index bytes in words 4..12), together with the nine words */
+        const uint4 *rec4 = (const uint4 *) T.rec + code * 4;
+        const uint4 r0 = rec4[0], r1 = rec4[1], r2 = rec4[2];
+        const uint32_t r12 = T.rec[code * 16 + 12];
+        const uint32_t ni = r0.w >> 8;
         /* the nine rows' words */
         const uint32_t wIdx = (2 * x) >> 6, sh = (2 * x) & 63;
         LatWord wd[9];
@@ -1001,9 +1004,13 @@ __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeVie
         }
         /* a reference is the word index of the vertex's welded index inside sIdx: one LDS read resolves it */
         const uint32_t first = threadIdx.x * MAX_CELL_VERTICES;
-        for (uint32_t q = 0; 4 * q < ni; q++)
+        const uint32_t iws[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r12};
+#pragma unroll
+        for (uint32_t q = 0; q < 9; q++)
         {
-            const uint32_t iw = rec[4 + q];
+            if (4 * q >= ni)
+                break;
+            const uint32_t iw = iws[q];
             const uint32_t left = ni - 4 * q;
             sRef[local + 4 * q] = (uint16_t) (first + (iw & 0xFF));
             if (left > 1) sRef[local + 4 * q + 1] = (uint16_t) (first + ((iw >> 8) & 0xFF));
@@ -1015,9 +1022,154 @@ __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeVie
     }
     __syncthreads();
     const uint32_t span = sSpan;
-    for (uint32_t k = threadIdx.x; k < span; k += blockDim.x)
+    /* four positions per thread and trip, so that the two dependent LDS reads of a position overlap the others' */
+    const uint32_t *flat = &sIdx[0][0];
+    for (uint32_t k0 = 0; k0 < span; k0 += 4 * 256)
     {
-        indices[blockBase + k] = (&sIdx[0][0])[sRef[k]];
+        uint32_t ref[4], val[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const uint32_t k = k0 + 256 * u + threadIdx.x;
+            ref[u] = k < span ? sRef[k] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            val[u] = flat[ref[u]];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            const uint32_t k = k0 + 256 * u + threadIdx.x;
+            if (k < span)
+                indices[blockBase + k] = val[u];
+        }
+    }
+}
+
+/* The same emission without the compacted cell list: one wave per ROW of cells, lane = cell x, 64 cells at a time.  The
+ * code bytes are one coalesced read, the row's first index slot comes from the scan of the row totals and a cell's slot
+ * from a wave scan of the per-code index counts -- so the (cell, first slot) records that compactRowCellsKernel wrote and
+ * latticeTrianglesKernel read back (16 bytes per occupied cell each way, and a dependent load in front of everything
+ * else) do not exist.  The nine lattice rows are the same for the whole wave.  Index order is unchanged: rows in (z, y)
+ * order, cells by x, a cell's indices in table order.  Each wave stages its own span in LDS; no workgroup barrier. */
+__global__ __launch_bounds__(256) void latticeTrianglesRowKernel(Lattice L, CodeView C, DevTables T, const U3 *rowCounts,
+                                                                 const U3 *rowStarts, uint32_t zFirst, uint32_t *indices,
+                                                                 uint32_t numRows)
+{
+    __shared__ uint32_t sIdx[4][64][MAX_CELL_VERTICES];
+    __shared__ uint16_t sRef[4][64 * MAX_CELL_INDICES];     /* lane * 13 + vertex slot */
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+    if (r >= numRows)
+        return;
+    if (rowCounts[r].a == 0)
+        return;
+    const uint32_t y = r % L.ch, z = r / L.ch + zFirst;
+    uint32_t indexBase = rowStarts[r].c;
+    const uint8_t *codeRow = C.codes + ((uint64_t) (z - C.z0) * C.ch + y) * C.cw;
+    const LatWord *rowWords[9];
+    bool rowFlagged[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++)
+    {
+        const uint32_t y2 = 2 * y + (q % 3), z2 = 2 * z + (q / 3);
+        rowWords[q] = L.words + (uint64_t) ((z2 - L.z2First) * L.rowsPerLayer + y2) * L.nw;
+        rowFlagged[q] = y2 == 0 || y2 == L.topy || z2 == L.z2First;
+    }
+    uint32_t (*myIdx)[MAX_CELL_VERTICES] = sIdx[wv];
+    uint16_t *myRef = sRef[wv];
+    const uint4 *rec4 = (const uint4 *) T.rec;                 /* a code's record is four aligned 16-byte words */
+    uint32_t nextCode = lane < L.cw ? codeRow[lane] : 0u;
+    for (uint32_t x0 = 0; x0 < L.cw; x0 += 64)
+    {
+        const uint32_t x = x0 + lane;
+        const uint32_t code = nextCode;
+        nextCode = x + 64 < L.cw ? codeRow[x + 64] : 0u;
+        /* everything this chunk reads from memory is requested here, before the first use: the record (index count in
+         * word 3, index bytes in words 4..12) and the nine lattice words do not depend on one another.  (Requesting them one
+         * chunk ahead, between the previous chunk's LDS writes and its write-out, was measured: no change.) */
+        const uint4 r0 = rec4[code * 4], r1 = rec4[code * 4 + 1], r2 = rec4[code * 4 + 2];
+        const uint32_t r12 = T.rec[code * 16 + 12];
+        const uint32_t xc = min(x, L.cw - 1);
+        const uint32_t wIdx = (2 * xc) >> 6, sh = (2 * xc) & 63;
+        LatWord wd[9];
+#pragma unroll
+        for (int q = 0; q < 9; q++)
+            wd[q] = rowWords[q][wIdx];
+        const uint32_t ni = code != 0 ? r0.w >> 8 : 0u;
+        const uint32_t incl = waveInclusiveScan(ni);
+        const uint32_t span = readLane(incl, 63);
+        if (span == 0)
+            continue;
+        const uint32_t local = incl - ni;
+        if (code != 0)
+        {
+            uint64_t below[3];
+            below[0] = (1ull << sh) - 1;
+            below[1] = (2ull << sh) - 1;
+            below[2] = sh == 62 ? ~0ull : (4ull << sh) - 1;
+            const bool atX0 = x == 0, atTop = 2 * x + 2 == L.topx;
+            uint32_t slot = 0;
+#pragma unroll
+            for (int e = 0; e < NUM_EDGES; e++)
+            {
+                const int a = edgeIndices[e][0], b = edgeIndices[e][1];
+                const int px = (a & 1) + (b & 1), py = ((a >> 1) & 1) + ((b >> 1) & 1), pz = ((a >> 2) & 1) + ((b >> 2) & 1);
+                const int q = py + 3 * pz;
+                if (((code >> a) ^ (code >> b)) & 1u)
+                {
+                    uint32_t idx = wd[q].prefix + (uint32_t) __popcll(wd[q].mask & below[px]);
+                    if (px == 0 && atX0 && !rowFlagged[q])
+                        idx = wd[q].flag & LAT_FLAG_INDEX;
+                    if (px == 2 && atTop && !rowFlagged[q])
+                        idx = (wd[q].flag & LAT_FLAG_INDEX) + (wd[q].flag >> 31);
+                    myIdx[lane][slot++] = idx;
+                }
+            }
+            const uint32_t first = lane * MAX_CELL_VERTICES;
+            const uint32_t iws[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r12};
+#pragma unroll
+            for (uint32_t q = 0; q < 9; q++)
+            {
+                if (4 * q >= ni)
+                    break;
+                const uint32_t iw = iws[q];
+                const uint32_t left = ni - 4 * q;
+                myRef[local + 4 * q] = (uint16_t) (first + (iw & 0xFF));
+                if (left > 1) myRef[local + 4 * q + 1] = (uint16_t) (first + ((iw >> 8) & 0xFF));
+                if (left > 2) myRef[local + 4 * q + 2] = (uint16_t) (first + ((iw >> 16) & 0xFF));
+                if (left > 3) myRef[local + 4 * q + 3] = (uint16_t) (first + (iw >> 24));
+            }
+        }
+        /* the wave's LDS operations execute in order: the reads below see the writes above without a barrier */
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        /* four positions per lane and trip, so that the two dependent LDS reads of a position overlap the others' */
+        const uint32_t *flat = &myIdx[0][0];
+        for (uint32_t k0 = 0; k0 < span; k0 += 256)
+        {
+            uint32_t ref[4], val[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const uint32_t k = k0 + 64 * u + lane;
+                ref[u] = k < span ? myRef[k] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                val[u] = flat[ref[u]];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                const uint32_t k = k0 + 64 * u + lane;
+                if (k < span)
+                    indices[indexBase + k] = val[u];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        indexBase += span;
     }
 }
 
@@ -1423,12 +1575,26 @@ int mlsgpu_marching::shipOutLattice(const mlsgpu_swathe &sw, const uint32_t size
     const uint32_t cellsInBatch = bufferedCells;
     if (cellRows > 0 && cellsInBatch > 0)
     {
-        LAUNCH(ctx, "kernel.marching.scanElements.time", compactRowCellsKernel, dim3(divUp(cellRows, 4)), dim3(256),
-               (const uint8_t *) dCellCode, L.cw, L.ch, codeZ0, zTop, (const U3 *) dRowStarts, (const uchar2 *) dCount,
-               dCells, dViStart, cellRows);
-        LAUNCH(ctx, "kernel.marching.generateElements.time", latticeTrianglesKernel, dim3(divUp(cellsInBatch, 256)), dim3(256),
-               L, C, devTables(), (const uint2 *) dCells, (const uint2 *) dViStart, dIndices,
-               (const U3 *) &dReadback->batchTotals);
+        /* Two routes to the same index list.  By ROWS (one wave per row of cells, no compacted cell list): no
+         * compactRowCells launch and 32 bytes per occupied cell less traffic, but a wave per row whatever it holds -- the
+         * faster one when most cells are occupied (cfg3 noise cloud, 85 %: 4.2 -> 3.6 ms per step).  By CELLS (compact, then
+         * one thread per occupied cell): time follows the surface, 0.70 against 1.31 ms per step on the shells cloud
+         * (~6 % occupied).  MLSGPU_HIP_TRIANGLES_BY_CELLS=0/1 forces one. */
+        static const char *const routeEnv = getenv("MLSGPU_HIP_TRIANGLES_BY_CELLS");
+        const bool byCells = routeEnv != nullptr ? routeEnv[0] != '0'
+                                                 : (uint64_t) cellsInBatch * 2 < (uint64_t) cellRows * L.cw;
+        if (byCells)
+        {
+            LAUNCH(ctx, "kernel.marching.scanElements.time", compactRowCellsKernel, dim3(divUp(cellRows, 4)), dim3(256),
+                   (const uint8_t *) dCellCode, L.cw, L.ch, codeZ0, zTop, (const U3 *) dRowStarts, (const uchar2 *) dCount,
+                   dCells, dViStart, cellRows);
+            LAUNCH(ctx, "kernel.marching.generateElements.time", latticeTrianglesKernel, dim3(divUp(cellsInBatch, 256)), dim3(256),
+                   L, C, devTables(), (const uint2 *) dCells, (const uint2 *) dViStart, dIndices,
+                   (const U3 *) &dReadback->batchTotals);
+        }
+        else
+            LAUNCH(ctx, "kernel.marching.generateElements.time", latticeTrianglesRowKernel, dim3(divUp(cellRows, 4)), dim3(256),
+                   L, C, devTables(), firstRow, (const U3 *) dRowStarts, zTop, dIndices, cellRows);
     }
     PROPAGATE(box.publish(ctx->stream, &dReadback->classTotals, 6));     /* classTotals and batchTotals are adjacent */
     PROPAGATE(box.wait(ctx->stream));

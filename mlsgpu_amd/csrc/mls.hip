@@ -35,7 +35,7 @@ struct mlsgpu_mls
 {
     mlsgpu_ctx *ctx = nullptr;
     int shape = MLSGPU_SHAPE_SPHERE;
-    int variant = 2;             /* culled + hit lists: the fastest on both BASELINE clouds; 0 and 1 stay selectable */
+    int variant = 3;             /* culled + hit masks: the fastest on both BASELINE clouds (round 3); 0-2 stay selectable */
     const mlsgpu_splat *dSplats = nullptr;
     const int32_t *dCommands = nullptr;
     const int32_t *dStart = nullptr;
@@ -75,6 +75,16 @@ __device__ __forceinline__ void fitInit(Fit &f)
     f.sumWnx = f.sumWny = f.sumWnz = 0.0f;
     f.sumW = 0.0f;
     f.hits = 0;
+}
+
+/* 1 iff d < RADIUS_CUTOFF, as the sign bit of the difference instead of a compare: a compare writes VCC and the
+ * add-with-carry behind it waits for that (6.8 issue cycles per instruction of the pair at 8 waves per SIMD against 2.6 for
+ * plain vector instructions, profiles/r03_valu_lds_issue_microbench.txt).  The subtraction is exact for d within a factor
+ * of two of the cutoff and has the sign of the exact difference otherwise; d == cutoff gives +0; d is a product of finite
+ * non-negative values, and the NaN the hardware makes from 0 * inf is the positive one, which a compare rejects as well. */
+__device__ __forceinline__ uint32_t hitBit(float d)
+{
+    return __float_as_uint(d - RADIUS_CUTOFF) >> 31;
 }
 
 /* sphereFitAdd, kernels/mls.cl:129-139 (planeFitAdd :141-148 keeps a subset of the same sums). */
@@ -507,7 +517,7 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
                         const float d = pp * a.w;
                         /* branch-free append: write the slot, keep it only if hit (the next append overwrites it) */
                         *tail = (uint8_t) i;
-                        tail += d < RADIUS_CUTOFF ? 1 : 0;
+                        tail += hitBit(d);
                         asm volatile("" : "+v"(tail));      /* keep the tail itself in a register, not base + count */
                     }
                 }
@@ -538,23 +548,26 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
 
 
 /*
- * Variant 3 ("hit masks").  The issue-rate microbenchmark of tools/microbench/valu_lds_issue.hip (round 3) says what
- * bounds variant 2: the CU's LDS pipe.  Per test a wave pays a 16-byte broadcast read (4 LDS cycles) AND a one-byte list
- * append (4.9); per drain iteration a byte read (2) and two random 16-byte gathers (12.5 each) -- 2 290 LDS cycles per
- * wave against 1 600 CU-cycle-equivalents of vector issue.  This variant takes the append out of LDS: a hit shifts one
- * bit into a per-lane 64-bit mask (`m = 2 m + hit`, one add-with-carry, exactly what advancing the list tail cost), and
- * the splat behind bit t comes from a 64-byte per-wave table (slot of the t-th test of the round), written once per
- * 64-splat group by the lanes that hold the group's relevant splats.  The drain walks the mask's bits from the top (the
- * first test is the highest bit), so the per-corner accumulation order is the list order -- bit-identical results.
- * A round's tests beyond 64 start a new mask after an early drain.
+ * Variant 3 ("hit masks", the default).  The issue-rate microbenchmark of tools/microbench/valu_lds_issue.hip (round 3)
+ * prices variant 2: per test a wave pays a 16-byte broadcast read (4 LDS cycles) AND a one-byte list append (4.9); per drain
+ * iteration a byte read (2) and two random 16-byte gathers (12.5 each).  This variant takes the append out of LDS: a hit
+ * shifts one bit into a per-lane 64-bit mask -- `m = 2 m + hit` as ONE v_alignbit_b32 that shifts in the sign bit of
+ * (d - cutoff), see hitBit(); the first version used a compare and an add-with-carry, whose VCC round trip cost 6 % of the
+ * kernel -- and the splat behind bit t comes from a 128-byte per-wave table (byte offset of the slot of the t-th test since
+ * the last drain), written once per 64-splat group by the lanes that hold the group's relevant splats.  The drain walks the
+ * mask's bits from the top (the first test is the highest bit), so the per-corner accumulation order is the list order --
+ * bit-identical results.  A round's tests beyond 64 start a new mask after an early drain.  Without the 26 KB of lists a
+ * round stages 512 splats (one per thread) instead of 256: fewer rounds, barriers and partial drains.
  */
+#define MASK_STAGE 512      /* one record per thread; no per-lane lists, so 18.5 KB of LDS per workgroup */
+
 template<int SHAPE, bool STATS>
 __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
 {
-    __shared__ float4 sPosRad[LIST_STAGE];
-    __shared__ float4 sNormQ[LIST_STAGE];
-    __shared__ uint32_t sMask[LIST_STAGE];
-    __shared__ uint8_t sSlot[8][64];        /* per wave: staging slot of the t-th test since the last drain */
+    __shared__ float4 sPosRad[MASK_STAGE];
+    __shared__ float4 sNormQ[MASK_STAGE];
+    __shared__ uint32_t sMask[MASK_STAGE];
+    __shared__ uint16_t sSlot[8][64];       /* per wave: staging slot (as a byte offset) of the t-th test since the last drain */
 
     const uint32_t nBlocks = A.blocksX * A.blocksY * A.blocksZ;
     const uint32_t bid = xcdRemap(blockIdx.x, nBlocks, A.xcdChunk);
@@ -578,8 +591,8 @@ __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
         Fit fit;
         fitInit(fit);
         unsigned long long nListed = 0, nTests = 0;
-        typedef __attribute__((address_space(3))) uint8_t LdsByte;
-        LdsByte *const mySlots = (LdsByte *) sSlot[wave];
+        typedef __attribute__((address_space(3))) uint16_t LdsSlot;
+        LdsSlot *const mySlots = (LdsSlot *) sSlot[wave];
         f32x2 sWpxy = {0.0f, 0.0f}, sWnxy = {0.0f, 0.0f};
         const f32x2 cxy = {cx, cy};
 
@@ -596,7 +609,7 @@ __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
             const uint32_t cntA = (uint32_t) __popc(cur), cnt = cntA + (uint32_t) __popc(nxt);
             const uint32_t most = waveMax(cnt);
             fit.hits += cnt;
-            uint32_t base = 0;
+            LdsSlot *tbl = mySlots;
             for (uint32_t j = 0; j < most; j++)
             {
                 if (j < cnt)
@@ -604,13 +617,13 @@ __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
                     if (j == cntA)
                     {
                         cur = nxt;
-                        base = 32;
+                        tbl = mySlots + 32;
                     }
                     const uint32_t t = (uint32_t) __builtin_clz(cur);      /* cur != 0: this lane still has a hit to take */
                     cur ^= 0x80000000u >> t;
-                    const uint32_t i = mySlots[base + t];
-                    const float4 pr = sPosRad[i];
-                    const float4 nq = sNormQ[i];
+                    const uint32_t off = tbl[t];                   /* the slot's byte offset in both staging arrays */
+                    const float4 pr = *(const float4 *) ((const char *) sPosRad + off);
+                    const float4 nq = *(const float4 *) ((const char *) sNormQ + off);
                     const f32x2 pxy = f32x2{pr.x, pr.y} - cxy;
                     const float pz = pr.z - cz;
                     const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
@@ -641,7 +654,6 @@ __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
         {
             uint32_t mask = 0;
             int32_t mine = -1;
-            if (tid < LIST_STAGE)
             {
                 const int32_t lpos = pos + (int32_t) tid;
                 mine = lpos < end ? A.commands[lpos] : -1;
@@ -663,19 +675,19 @@ __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
                             d[a][h] = fmaxf(fmaxf(lo - p[a], p[a] - hi), 0.0f);
                         }
 #pragma unroll
-                    for (int s_ = 0; s_ < 8; s_++)
+                    for (int s_ = 7; s_ >= 0; s_--)
                     {
                         const float dx = d[0][s_ & 1], dy = d[1][(s_ >> 1) & 1], dz = d[2][s_ >> 2];
                         const float dd = dot3(dx, dy, dz, dx, dy, dz) * pr.w;
-                        mask |= (dd < RADIUS_CUTOFF ? 1u : 0u) << s_;
+                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(dd - RADIUS_CUTOFF), 31);   /* hitBit(dd) */
                     }
                 }
                 sMask[tid] = mask;
             }
             if (STATS)
                 nListed += __popcll(__ballot(mine >= 0));
-            const int32_t staged = min(end - pos, (int32_t) LIST_STAGE);
-            pos += LIST_STAGE;
+            const int32_t staged = min(end - pos, (int32_t) MASK_STAGE);
+            pos += MASK_STAGE;
             if (pos >= end)
             {
                 pos = A.commands[end];
@@ -694,7 +706,7 @@ __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
                     drain();
                 /* the lanes holding the group's relevant splats note which test each of them will be */
                 if ((todo >> lane) & 1ull)
-                    mySlots[nt + popcBelow(todo)] = (uint8_t) (g + (int32_t) lane);
+                    mySlots[nt + popcBelow(todo)] = (uint16_t) ((g + (int32_t) lane) * (int32_t) sizeof(float4));
                 /* tests 0..31 since the last drain go to mA, 32..63 to mB; a group may straddle the two */
                 uint32_t left = nGroup;
                 while (left != 0)
@@ -713,9 +725,8 @@ __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
                         const float pz = a.z - cz;
                         const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
                         const float d = pp * a.w;
-                        /* acc = 2 acc + hit as ONE add-with-carry behind the compare (what advancing a list tail cost) */
-                        asm volatile("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                                     : "+v"(acc) : "v"(d), "s"(RADIUS_CUTOFF) : "vcc");
+                        /* acc = 2 acc + hit: the difference's sign bit shifted in by one v_alignbit_b32 (see hitBit) */
+                        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(d - RADIUS_CUTOFF), 31);
                     }
                     if (STATS)
                         nTests += 64ull * take;

@@ -28,8 +28,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernels of the bench's per-stage table -> substring of the demangled kernel name
 TRACKED = {
-    "processCorners": "processCornersListKernel<0, false>",
-    "latticeTriangles": "latticeTrianglesKernel",
+    "processCorners": "processCornersMaskKernel<0, false>",
+    "latticeTriangles": "latticeTriangles",      # by rows (noise cloud) or by cells (surface-like data)
     "latticeVertices": "latticeVerticesKernel",
     "latticeMask": "latticeMaskKernel",
     "sortScatter": "sortScatterKernel",
@@ -193,6 +193,8 @@ def sq(dirs, label, out):
     """Sums of every collected counter over the launches of processCorners; appended to `out` as label,counter,value."""
     rows = {}
     launches = 0
+    # MLSGPU_SQ_KERNELS=a,b,c: other kernels (substrings of the name), one block of rows per kernel
+    kernels = [k for k in os.environ.get("MLSGPU_SQ_KERNELS", "processCorners").split(",") if k]
     for d in dirs:
         db = database(d)
         if db is not None:
@@ -201,10 +203,12 @@ def sq(dirs, label, out):
             it = ((r["Kernel_Name"], r["Counter_Name"], r["Counter_Value"]) for r in csv.DictReader(open(find(d, "counter_collection.csv"))))
         seen = defaultdict(int)
         for name, counter, value in it:
-            if "processCorners" not in name:
+            hit = [k for k in kernels if k in name]
+            if not hit:
                 continue
-            rows[counter] = rows.get(counter, 0.0) + float(value)
-            seen[counter] += 1
+            key = (hit[0], counter) if len(kernels) > 1 else counter
+            rows[key] = rows.get(key, 0.0) + float(value)
+            seen[key] += 1
         if seen:
             launches = max(launches, max(seen.values()))
     new = not os.path.exists(out)
@@ -216,7 +220,10 @@ def sq(dirs, label, out):
                     "bucket); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in quad-cycles (MI355X_MICROARCH.md)\n")
             f.write("variant,launches,counter,value\n")
         for c in sorted(rows):
-            f.write('"%s",%d,%s,%.0f\n' % (label, launches, c, rows[c]))
+            if isinstance(c, tuple):
+                f.write('"%s: %s",%d,%s,%.0f\n' % (label, c[0], launches, c[1], rows[c]))
+            else:
+                f.write('"%s",%d,%s,%.0f\n' % (label, launches, c, rows[c]))
     print("appended", len(rows), "counters for", label, "to", out)
 
 
