@@ -557,9 +557,14 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
  * the last drain), written once per 64-splat group by the lanes that hold the group's relevant splats.  The drain walks the
  * mask's bits from the top (the first test is the highest bit), so the per-corner accumulation order is the list order --
  * bit-identical results.  A round's tests beyond 64 start a new mask after an early drain.  Without the 26 KB of lists a
- * round stages 512 splats (one per thread) instead of 256: fewer rounds, barriers and partial drains.
+ * round stages 1024 splats instead of 256 (see MASK_STAGE).
  */
-#define MASK_STAGE 512      /* one record per thread; no per-lane lists, so 18.5 KB of LDS per workgroup */
+#ifndef MASK_STAGE
+#define MASK_STAGE 1024
+#endif
+/* Two records per thread and round: 37.9 KB of LDS per workgroup, four workgroups per CU as before.  A block of the
+ * BASELINE clouds lists ~700 splats, so most blocks are ONE round -- no second pair of barriers and no forced drain of a
+ * half-filled mask in between (measured per step on cfg3: 256-splat rounds 10.25 ms, 512: 9.84, 1024: 9.61). */
 
 template<int SHAPE, bool STATS>
 __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
@@ -652,17 +657,19 @@ __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
         int32_t end = A.commands[pos++];
         while (pos < end)
         {
-            uint32_t mask = 0;
-            int32_t mine = -1;
+#pragma unroll
+            for (int part = 0; part < MASK_STAGE / 512; part++)
             {
-                const int32_t lpos = pos + (int32_t) tid;
-                mine = lpos < end ? A.commands[lpos] : -1;
+                const uint32_t slot = tid + 512u * (uint32_t) part;
+                uint32_t mask = 0;
+                const int32_t lpos = pos + (int32_t) slot;
+                const int32_t mine = lpos < end ? A.commands[lpos] : -1;
                 if (mine >= 0)
                 {
                     const float4 pr = A.splats[2 * (int64_t) mine];
                     const float4 nq = A.splats[2 * (int64_t) mine + 1];
-                    sPosRad[tid] = pr;
-                    sNormQ[tid] = nq;
+                    sPosRad[slot] = pr;
+                    sNormQ[slot] = nq;
                     float d[3][2];
                     const float p[3] = {pr.x, pr.y, pr.z};
                     const float b[3] = {bx0, by0, bz0};
@@ -682,10 +689,10 @@ __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
                         mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(dd - RADIUS_CUTOFF), 31);   /* hitBit(dd) */
                     }
                 }
-                sMask[tid] = mask;
+                sMask[slot] = mask;
+                if (STATS)
+                    nListed += __popcll(__ballot(mine >= 0));
             }
-            if (STATS)
-                nListed += __popcll(__ballot(mine >= 0));
             const int32_t staged = min(end - pos, (int32_t) MASK_STAGE);
             pos += MASK_STAGE;
             if (pos >= end)
