@@ -71,7 +71,7 @@ def parse_args():
     p.add_argument("--scale", type=float, default=1.0, help="splat-count scale (debug only; 1.0 = BASELINE size)")
     p.add_argument("--mesh-memory-mb", type=int, default=4096, help="Marching mesh arena per worker")
     p.add_argument("--workers", type=int, default=4, help="device worker threads per GPU (measured 2..4: +0..6 %)")
-    p.add_argument("--variant", type=int, default=3, help="MLS kernel variant: 0 culled, 1 basic, 2 culled + hit lists, 3 culled + hit masks")
+    p.add_argument("--variant", type=int, default=4, help="MLS kernel variant: 0 culled, 1 basic, 2 culled + hit lists, 3 culled + hit masks, 4 culled + cube streams")
     p.add_argument("--leg-steps", type=int, default=3, help="passes of every secondary leg")
     p.add_argument("--copy-threads", type=int, default=8, help="host threads copying one bucket into pinned staging (transfer legs)")
     p.add_argument("--no-cpu-baseline", action="store_true")
@@ -982,7 +982,7 @@ def main():
             "bucket_splats_total": int(bucketed_t.shape[0]),
             "mesh_memory_mb": args.mesh_memory_mb,
             "device_workers": nworkers,
-            "mls_variant": {0: "culled", 1: "basic", 2: "culled+hit-lists", 3: "culled+hit-masks"}[args.variant],
+            "mls_variant": {0: "culled", 1: "basic", 2: "culled+hit-lists", 3: "culled+hit-masks", 4: "culled+cube-streams"}[args.variant],
             "sharding": "one process per GPU, rank r owns z-slab r (25 buckets); no data-path collective" if world > 1
                         else "single GPU",
             "triangles_per_step": triangles,

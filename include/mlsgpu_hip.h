@@ -166,8 +166,8 @@ int mlsgpu_hip_mls_enqueue(mlsgpu_mls *mls, float *dField, uint64_t pitch, uint6
 /* Fills *gen so the functor can be passed to mlsgpu_hip_marching_generate (alignment = wgs = {8,8,8}). */
 int mlsgpu_hip_mls_generator(mlsgpu_mls *mls, mlsgpu_generator *gen);
 /* Selects the kernel variant: 0 = sub-block culled, 1 = basic list walk (the reference's structure),
- * 2 = sub-block culled with per-lane hit lists, 3 = sub-block culled with per-lane hit masks (the default: fastest on
- * both BASELINE clouds).  All give bit-identical results. */
+ * 2 = sub-block culled with per-lane hit lists, 3 = sub-block culled with per-lane hit masks, 4 = as 3 with one splat
+ * stream per 2x2x2 cube of corners (the default: fastest on both BASELINE clouds).  All give bit-identical results. */
 int mlsgpu_hip_mls_set_variant(mlsgpu_mls *mls, int variant);
 /* Measurement aid: with a non-NULL device array of 3 uint64 the next enqueues run an instrumented kernel that
  * adds [0] listed splats (Sigma L of SURVEY 8d), [1] (corner, splat) distance tests executed, [2] hits (H).

@@ -35,7 +35,7 @@ struct mlsgpu_mls
 {
     mlsgpu_ctx *ctx = nullptr;
     int shape = MLSGPU_SHAPE_SPHERE;
-    int variant = 3;             /* culled + hit masks: the fastest on both BASELINE clouds (round 3); 0-2 stay selectable */
+    int variant = 4;             /* culled + cube streams: the fastest on both BASELINE clouds (round 3); 0-3 stay selectable */
     const mlsgpu_splat *dSplats = nullptr;
     const int32_t *dCommands = nullptr;
     const int32_t *dStart = nullptr;
@@ -766,6 +766,268 @@ __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
     A.field[row * (int64_t) A.pitch + (wx + lx)] = f;
 }
 
+/*
+ * Variant 4 ("cube streams").  What is left of variant 3's time is vector work, and more than half of its vector
+ * instructions are distance tests of which one lane in six is a hit: a wave tests all 64 corners of its 4x4x4 sub-block
+ * against every splat whose support reaches the sub-block.  Here the wave's eight 2x2x2 CUBES of corners (8 lanes each) get
+ * their own streams: the relevant splats of a window (up to 64, compacted as in variant 3) are culled once more, one lane
+ * per splat, against the eight cubes (the same conservative box test as the sub-block masks), and each cube's survivors are
+ * appended, in window order, to the cube's list in LDS.  A test iteration then serves EIGHT different splats -- lane l
+ * tests the k-th splat of its own cube's list -- and the number of iterations is the longest of the eight lists instead of
+ * the size of the window: by the Minkowski volumes of box + support sphere (radius 2.5: 140 against 404 cells) a cube sees
+ * about a third of what the sub-block sees.  Hits are bits of one 32-bit mask per lane (iteration k of the current chunk of
+ * 32), the drain walks them from the top and finds the splat in the lane's own list, so every corner still accumulates its
+ * hits in list order: bit-identical results.
+ */
+#define CUBE_STAGE 768
+
+template<int SHAPE, bool STATS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void processCornersCubeKernel(MlsArgs A)
+{
+    __shared__ float4 sPosRad[CUBE_STAGE];
+    __shared__ float4 sNormQ[CUBE_STAGE];
+    __shared__ uint8_t sMask[CUBE_STAGE];
+    __shared__ uint16_t sSlot[8][64];          /* per wave: byte offsets of the window's relevant splats */
+    __shared__ uint16_t sList[8][8][64];       /* per wave and cube: byte offsets of the splats that can reach the cube */
+
+    const uint32_t nBlocks = A.blocksX * A.blocksY * A.blocksZ;
+    const uint32_t bid = xcdRemap(blockIdx.x, nBlocks, A.xcdChunk);
+    const uint32_t gx = bid % A.blocksX, gy = (bid / A.blocksX) % A.blocksY, gz = bid / (A.blocksX * A.blocksY);
+    const int wx = (int) (gx * 8), wy = (int) (gy * 8), wz = (int) (gz * 8 + A.zFirst);
+    const uint32_t sub = A.startShift / 3;
+    const uint32_t code = spread3((uint32_t) wx >> sub) | (spread3((uint32_t) wy >> sub) << 1) | (spread3((uint32_t) wz >> sub) << 2);
+    int32_t pos = A.start[code];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const int lx = (int) ((wave & 1) * 4 + (lane & 3));
+    const int ly = (int) (((wave >> 1) & 1) * 4 + ((lane >> 2) & 3));
+    const int lz = (int) ((wave >> 2) * 4 + (lane >> 4));
+
+    float f = __int_as_float(0x7FC00000);
+    if (pos >= 0)       /* uniform over the workgroup */
+    {
+        const float cx = (float) (wx + lx + A.ox), cy = (float) (wy + ly + A.oy), cz = (float) (wz + lz + A.oz);
+        const float bx0 = (float) (wx + A.ox), by0 = (float) (wy + A.oy), bz0 = (float) (wz + A.oz);
+        /* corner coordinates of the wave's sub-block origin, for the cube tests */
+        const float sbx = bx0 + (float) ((wave & 1) * 4), sby = by0 + (float) (((wave >> 1) & 1) * 4), sbz = bz0 + (float) ((wave >> 2) * 4);
+        Fit fit;
+        fitInit(fit);
+        unsigned long long nListed = 0, nTests = 0;
+        typedef __attribute__((address_space(3))) uint16_t LdsSlot;
+        LdsSlot *const mySlots = (LdsSlot *) sSlot[wave];
+        const uint32_t myCube = ((lane >> 1) & 1u) | (((lane >> 3) & 1u) << 1) | (((lane >> 5) & 1u) << 2);
+        LdsSlot *const myList = (LdsSlot *) sList[wave][myCube];
+        f32x2 sWpxy = {0.0f, 0.0f}, sWnxy = {0.0f, 0.0f};
+        const f32x2 cxy = {cx, cy};
+        uint32_t nt = 0;            /* relevant splats in the window (wave-uniform) */
+
+        /* every list entry that is ever read is a valid offset: zero until written */
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            sList[wave][c][lane] = 0;
+
+        /* accumulate this lane's hits of one chunk of iterations, in list order */
+        auto drain = [&](uint32_t cur, LdsSlot *chunk)
+        {
+            const uint32_t cnt = (uint32_t) __popc(cur);
+            const uint32_t most = waveMax(cnt);
+            fit.hits += cnt;
+            for (uint32_t j = 0; j < most; j++)
+            {
+                if (j < cnt)
+                {
+                    const uint32_t t = (uint32_t) __builtin_clz(cur);      /* cur != 0: this lane still has a hit to take */
+                    cur ^= 0x80000000u >> t;
+                    const uint32_t off = chunk[t];
+                    const float4 pr = *(const float4 *) ((const char *) sPosRad + off);
+                    const float4 nq = *(const float4 *) ((const char *) sNormQ + off);
+                    const f32x2 pxy = f32x2{pr.x, pr.y} - cxy;
+                    const float pz = pr.z - cz;
+                    const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
+                    const float d = pp * pr.w;
+                    float w = 1.0f - d;
+                    w *= w;
+                    w *= w;
+                    w *= nq.w;
+                    const f32x2 ww = {w, w};
+                    const f32x2 nxy = {nq.x, nq.y};
+                    const f32x2 wnxy = ww * nxy;
+                    const float wnz = w * nq.z;
+                    fit.sumW = fit.sumW + w;
+                    sWpxy = __builtin_elementwise_fma(ww, pxy, sWpxy);
+                    fit.sumWpz = fmaf(w, pz, fit.sumWpz);
+                    sWnxy = __builtin_elementwise_fma(ww, nxy, sWnxy);
+                    fit.sumWnz = fmaf(w, nq.z, fit.sumWnz);
+                    fit.sumWpp = fmaf(w, pp, fit.sumWpp);
+                    fit.sumWpn = fit.sumWpn + fmaf(wnxy.x, pxy.x, fmaf(wnxy.y, pxy.y, wnz * pz));
+                }
+            }
+        };
+
+        /* the window's relevant splats: cube lists, tests, accumulation */
+        auto processWindow = [&]()
+        {
+            /* (the table was written by other lanes of this wave: LDS operations of a wave execute in order) */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            /* 1. one lane per relevant splat: which of the eight cubes can its support reach? */
+            uint32_t fine = 0, off = 0;
+            if (lane < nt)
+            {
+                off = mySlots[lane];
+                const float4 pr = *(const float4 *) ((const char *) sPosRad + off);
+                float d[3][2];
+                const float p[3] = {pr.x, pr.y, pr.z};
+                const float b[3] = {sbx, sby, sbz};
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int h = 0; h < 2; h++)
+                    {
+                        const float lo = b[a] + (float) (2 * h), hi = b[a] + (float) (2 * h + 1);
+                        d[a][h] = fmaxf(fmaxf(lo - p[a], p[a] - hi), 0.0f);
+                    }
+#pragma unroll
+                for (int c = 7; c >= 0; c--)
+                {
+                    const float dx = d[0][c & 1], dy = d[1][(c >> 1) & 1], dz = d[2][c >> 2];
+                    const float dd = dot3(dx, dy, dz, dx, dy, dz) * pr.w;
+                    fine = __builtin_amdgcn_alignbit(fine, __float_as_uint(dd - RADIUS_CUTOFF), 31);   /* hitBit(dd) */
+                }
+            }
+            /* 2. the cubes' lists, in window order */
+            uint32_t myCnt = 0, maxCnt = 0;
+#pragma unroll
+            for (uint32_t c = 0; c < 8; c++)
+            {
+                const uint64_t bal = __ballot((fine >> c) & 1u);
+                const uint32_t n = (uint32_t) __popcll(bal);
+                if ((fine >> c) & 1u)
+                    sList[wave][c][popcBelow(bal)] = (uint16_t) off;
+                myCnt = myCube == c ? n : myCnt;
+                maxCnt = n > maxCnt ? n : maxCnt;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            /* 3. chunks of up to 32 iterations: lane l tests the k-th splat of its own cube's list */
+            for (uint32_t k0 = 0; k0 < maxCnt; k0 += 32)
+            {
+                const uint32_t K = maxCnt - k0 < 32u ? maxCnt - k0 : 32u;
+                LdsSlot *const chunk = myList + k0;
+                uint32_t acc = 0;
+#pragma unroll 4
+                for (uint32_t k = 0; k < K; k++)
+                {
+                    const uint32_t o = chunk[k];
+                    const float4 a = *(const float4 *) ((const char *) sPosRad + o);
+                    const f32x2 pxy = f32x2{a.x, a.y} - cxy;
+                    const float pz = a.z - cz;
+                    const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
+                    const float d = pp * a.w;
+                    acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(d - RADIUS_CUTOFF), 31);     /* acc = 2 acc + hitBit(d) */
+                }
+                if (STATS)
+                    nTests += 64ull * K;
+                /* iteration k sits in bit K - 1 - k; the lane's list ends after v of the K iterations (what it read beyond
+                 * is somebody's older entry): drop those bits and left-align, so that the leading-zero count is k */
+                const uint32_t v = myCnt > k0 ? (myCnt - k0 < K ? myCnt - k0 : K) : 0u;
+                const uint32_t cur = v == 0 ? 0u : (acc >> (K - v)) << (32u - v);
+                drain(cur, chunk);
+            }
+            nt = 0;
+        };
+
+        int32_t end = A.commands[pos++];
+        while (pos < end)
+        {
+#pragma unroll
+            for (int part = 0; part < 2; part++)
+            {
+                const uint32_t slot = tid + 512u * (uint32_t) part;
+                if (slot >= CUBE_STAGE)
+                    continue;
+                uint32_t mask = 0;
+                const int32_t lpos = pos + (int32_t) slot;
+                const int32_t mine = lpos < end ? A.commands[lpos] : -1;
+                if (mine >= 0)
+                {
+                    const float4 pr = A.splats[2 * (int64_t) mine];
+                    const float4 nq = A.splats[2 * (int64_t) mine + 1];
+                    sPosRad[slot] = pr;
+                    sNormQ[slot] = nq;
+                    float d[3][2];
+                    const float p[3] = {pr.x, pr.y, pr.z};
+                    const float b[3] = {bx0, by0, bz0};
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+                        {
+                            const float lo = b[a] + (float) (4 * h), hi = b[a] + (float) (4 * h + 3);
+                            d[a][h] = fmaxf(fmaxf(lo - p[a], p[a] - hi), 0.0f);
+                        }
+#pragma unroll
+                    for (int s_ = 7; s_ >= 0; s_--)
+                    {
+                        const float dx = d[0][s_ & 1], dy = d[1][(s_ >> 1) & 1], dz = d[2][s_ >> 2];
+                        const float dd = dot3(dx, dy, dz, dx, dy, dz) * pr.w;
+                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(dd - RADIUS_CUTOFF), 31);   /* hitBit(dd) */
+                    }
+                }
+                sMask[slot] = (uint8_t) mask;
+                if (STATS)
+                    nListed += __popcll(__ballot(mine >= 0));
+            }
+            const int32_t staged = min(end - pos, (int32_t) CUBE_STAGE);
+            pos += CUBE_STAGE;
+            if (pos >= end)
+            {
+                pos = A.commands[end];
+                end = (pos >= 0) ? A.commands[pos++] : INT32_MIN;
+            }
+            __syncthreads();
+
+            for (int32_t g = 0; g < staged; g += 64)
+            {
+                const uint32_t m = sMask[g + lane];
+                const uint64_t todo = __ballot((m >> wave) & 1u);
+                const uint32_t nGroup = (uint32_t) __popcll(todo);
+                if (nGroup == 0)
+                    continue;
+                if (nt + nGroup > 64u)
+                    processWindow();
+                if ((todo >> lane) & 1ull)
+                    mySlots[nt + popcBelow(todo)] = (uint16_t) ((g + (int32_t) lane) * (int32_t) sizeof(float4));
+                nt += nGroup;
+            }
+            if (nt != 0)
+                processWindow();            /* the offsets point into this round's staging buffers */
+            __syncthreads();
+        }
+        fit.sumWpx = sWpxy.x;
+        fit.sumWpy = sWpxy.y;
+        fit.sumWnx = sWnxy.x;
+        fit.sumWny = sWnxy.y;
+        f = finishCorner<SHAPE>(fit, A.boundaryFactor);
+        if (STATS)
+        {
+            const unsigned long long hits = waveSum(fit.hits);
+            if (lane == 0)
+            {
+                atomicAdd(&A.stats[0], nListed);
+                atomicAdd(&A.stats[1], nTests);
+                atomicAdd(&A.stats[2], hits);
+            }
+        }
+    }
+
+    const int64_t row = (int64_t) (wy + ly) + (int64_t) (wz + lz) * A.zStride + A.zBias;
+    A.field[row * (int64_t) A.pitch + (wx + lx)] = f;
+}
+
 } // namespace
 
 /* ------------------------------------------------------------------ C-ABI */
@@ -819,7 +1081,7 @@ MLSGPU_API int mlsgpu_hip_mls_set_boundary_limit(mlsgpu_mls *m, float limit)
 
 MLSGPU_API int mlsgpu_hip_mls_set_variant(mlsgpu_mls *m, int variant)
 {
-    REQUIRE(m != nullptr && variant >= 0 && variant <= 3, MLSGPU_ERR_INVALID);
+    REQUIRE(m != nullptr && variant >= 0 && variant <= 4, MLSGPU_ERR_INVALID);
     m->variant = variant;
     return MLSGPU_OK;
 }
@@ -891,6 +1153,13 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
 #define MLS_LAUNCH_LIST(SHAPE, STATS) LAUNCH_LDS(ctx, stat, (processCornersListKernel<SHAPE, STATS>), grid, block, ldsPad, A)
     const bool sphere = m->shape == MLSGPU_SHAPE_SPHERE, cull = m->variant == 0;
 #define MLS_LAUNCH_MASK(SHAPE, STATS) LAUNCH_LDS(ctx, stat, (processCornersMaskKernel<SHAPE, STATS>), grid, block, ldsPad, A)
+#define MLS_LAUNCH_CUBE(SHAPE, STATS) LAUNCH_LDS(ctx, stat, (processCornersCubeKernel<SHAPE, STATS>), grid, block, ldsPad, A)
+    if (m->variant == 4)
+    {
+        if (m->dStats != nullptr) { if (sphere) MLS_LAUNCH_CUBE(MLSGPU_SHAPE_SPHERE, true); else MLS_LAUNCH_CUBE(MLSGPU_SHAPE_PLANE, true); }
+        else { if (sphere) MLS_LAUNCH_CUBE(MLSGPU_SHAPE_SPHERE, false); else MLS_LAUNCH_CUBE(MLSGPU_SHAPE_PLANE, false); }
+    }
+    else
     if (m->variant == 3)
     {
         if (m->dStats != nullptr) { if (sphere) MLS_LAUNCH_MASK(MLSGPU_SHAPE_SPHERE, true); else MLS_LAUNCH_MASK(MLSGPU_SHAPE_PLANE, true); }
@@ -915,6 +1184,7 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
 #undef MLS_LAUNCH
 #undef MLS_LAUNCH_LIST
 #undef MLS_LAUNCH_MASK
+#undef MLS_LAUNCH_CUBE
     return MLSGPU_OK;
 }
 

@@ -21,7 +21,7 @@ def run_gpu_bucket(ctx, cloud, first, count, low, nv, variant=0, **kw):
     return batches, w, buf
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 def test_cfg1_parity(ctx, variant):
     """BASELINE config 0: 64^3 grid, 50k splats on a sphere, one bucket: bit-identical to the oracle."""
     import mlsgpu_amd as m

@@ -44,7 +44,7 @@ def test_fit_sphere(ctx):
     np.testing.assert_array_equal(params.view(np.uint32), exp.view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("shape", [0, 1])
 def test_process_corners(ctx, variant, shape):
     """TestMls::testProcessCorners (hand-built command list: >= 4 hits / < 4 hits / no hits)."""

@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernels of the bench's per-stage table -> substring of the demangled kernel name
 TRACKED = {
-    "processCorners": "processCornersMaskKernel<0, false>",
+    "processCorners": "processCornersCubeKernel<0, false>",
     "latticeTriangles": "latticeTriangles",      # by rows (noise cloud) or by cells (surface-like data)
     "latticeVertices": "latticeVerticesKernel",
     "latticeMask": "latticeMaskKernel",
