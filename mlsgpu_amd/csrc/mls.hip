@@ -779,7 +779,7 @@ __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
  * 32), the drain walks them from the top and finds the splat in the lane's own list, so every corner still accumulates its
  * hits in list order: bit-identical results.
  */
-#define CUBE_STAGE 768
+#define CUBE_STAGE 512      /* measured per step on cfg3: 512-splat rounds 8.25 ms, 768: 8.36; 25.5 KB of LDS per workgroup */
 
 template<int SHAPE, bool STATS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void processCornersCubeKernel(MlsArgs A)
