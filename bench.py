@@ -1107,6 +1107,11 @@ def main():
                 "executed_flops_per_launch": int(done_flops // max(launches // K, 1)),
                 "executed": "10 flops per (corner, splat) lane-test executed + 25 per hit; the tests of lanes outside the support "
                             "are executed work, the culled ones are not counted",
+                "reading_frac": "frac counts EXECUTED flops, so it falls when finer culling removes tests: rounds 1-2 executed "
+                                "20.9 G lane-tests per step for these 3.47 G hits at 390 us per launch (frac 0.18), the cube "
+                                "streams of round 3 execute 9.3 G at ~300 us (frac 0.14); avg_launch_ms and "
+                                "algorithmic_equiv_frac (the reference algorithm's flop count over the same time) are the "
+                                "figures that compare across rounds",
                 "algorithmic_equiv_TFLOPs": round(alg_flops / (ms * 1e-3) / 1e12, 3),
                 "algorithmic_equiv_frac": round(alg_flops / (ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS, 4),
                 "algorithmic_equiv": "SURVEY 8d: 10*512*SigmaL + 25*H flops of the reference's every-corner-tests-every-listed-"
