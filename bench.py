@@ -70,7 +70,13 @@ def parse_args():
     p.add_argument("--dist", default="uniform", choices=["uniform", "shells"])
     p.add_argument("--scale", type=float, default=1.0, help="splat-count scale (debug only; 1.0 = BASELINE size)")
     p.add_argument("--mesh-memory-mb", type=int, default=4096, help="Marching mesh arena per worker")
-    p.add_argument("--workers", type=int, default=4, help="device worker threads per GPU (measured 2..4: +0..6 %)")
+    p.add_argument("--workers", type=int, default=2,
+                   help="device worker threads per GPU for the resident-input passes (round 3, cfg3 uniform: 1 / 2 / 3 / 4 / 6 workers "
+                        "23.1 / 21.2-21.6 / 21.6-22.2 / 22.2-22.5 / 22.1 ms per step -- every kernel fills the GPU, a second worker "
+                        "hides the host's gaps and more only interleave)")
+    p.add_argument("--farm-workers", type=int, default=4,
+                   help="device workers per GPU of the farm legs (host splats in, meshes out): transfers want more in flight "
+                        "(shells cloud, 8d region: 2 971 Mvoxels/s with 2, 3 719 with 4)")
     p.add_argument("--variant", type=int, default=4, help="MLS kernel variant: 0 culled, 1 basic, 2 culled + hit lists, 3 culled + hit masks, 4 culled + cube streams")
     p.add_argument("--leg-steps", type=int, default=3, help="passes of every secondary leg")
     p.add_argument("--copy-threads", type=int, default=8, help="host threads copying one bucket into pinned staging (transfer legs)")
@@ -188,7 +194,7 @@ def run_cfg5(args, rank, world, local_rank, device, dist, reduce_device):
     if dist is not None:
         dist.barrier()
     ctx = m.Context(local_rank)
-    nworkers = max(1, args.workers)
+    nworkers = max(1, args.farm_workers)
     fs = mb.FileSet(paths, buffer_size=512 << 20)
     assert len(fs) == n
     raw = m.DeviceBuffer(ctx, nbytes=n * 32)
@@ -443,7 +449,7 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     route "device_sink": ship-outs appended to the device mesher, weld / components / prune in HBM, ONE read-back."""
     out = {}
     views = [bucketed_host[b.first:b.first + b.count] for b in buckets]
-    nworkers = max(1, min(args.workers, len(buckets)))
+    nworkers = max(1, min(args.farm_workers, len(buckets)))
     farm = m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
                         mesh_memory=args.mesh_memory_mb << 20, copy_threads=args.copy_threads)
     farm.set_host_output(6 << 30, None)
@@ -544,7 +550,7 @@ def host_weld_leg(m, args, device_index, bucketed_host, buckets, max_count, max_
     """The reference's complete route, welder included: host splats -> farm -> every ship-out read back through the pinned ring
     -> ONE mesher thread running OOCMesher's weld on the host (clumps, key map, union-find; src/mesher.cpp:220-311) ->
     finalize (components, prune, one mesh).  One pass: the host welder takes ~18 M vertices/s, the device sink 3 800 M."""
-    nworkers = max(1, min(args.workers, len(buckets)))
+    nworkers = max(1, min(args.farm_workers, len(buckets)))
     welder = m.HostMesher(0.02)
     farm = m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
                         mesh_memory=args.mesh_memory_mb << 20, copy_threads=args.copy_threads)
@@ -1163,7 +1169,7 @@ def main():
 
     if dist is not None and not args.headline_only:
         multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, local_rank, ndev, ctxs[0], bucketed_t, buckets,
-                       max_count, max_cells, voxels, L, nworkers)
+                       max_count, max_cells, voxels, L, max(1, args.farm_workers))
 
     # ---- mesh-sink leg (never `value`): every ship-out of one pass appended to the device mesher (d2d), then
     # finalize = weld by key across buckets + connected components + prune (--fit-prune default 0.02) + compaction ----
@@ -1239,7 +1245,8 @@ def main():
             pcells = max(max(l["extents"][2 * i + 1] - l["extents"][2 * i] for i in range(3)) for l in leaves)
             # the bucketer's callback hands every leaf to the bucket farm's device path (gather + transform kernel into a
             # device item, then the farm's worker threads), as CopyGroup does with host buckets
-            pfarm = m.BucketFarm([local_rank], pmax, workers_per_device=nworkers, spare=1, max_cells=pcells,
+            pworkers = max(1, args.farm_workers)
+            pfarm = m.BucketFarm([local_rank], pmax, workers_per_device=pworkers, spare=1, max_cells=pcells,
                                  mesh_memory=args.mesh_memory_mb << 20)
             leaf_no = [0]
 
@@ -1264,7 +1271,7 @@ def main():
                 "max_bucket_cells": int(pcells), "bucketing_ms": round(part_s * 1e3, 3),
                 "bucketing_msplats_per_s": round(n_splats / part_s / 1e6, 1),
                 "pipeline_ms_per_step": round(pipe_s * 1e3, 3), "pipeline_mvoxels_per_s": round(pvox / pipe_s / 1e6, 3),
-                "device_workers": nworkers,
+                "device_workers": pworkers,
                 "note": "raw cloud resident in HBM -> mlsgpu_hip_bucket (reference partition) -> mlsgpu_hip_farm_submit_device "
                         "(device gather + transform) -> the farm's device workers; bucketing is inside the pipeline time",
             }
