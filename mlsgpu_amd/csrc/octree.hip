@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void entryTotalKernel(const uint32_t *digitTot
     }
 }
 
-__global__ __launch_bounds__(ENT_TILE) void entryScatterKernel(EntryParams P, const uint8_t *slotMasks, const uint32_t *hist,
+__global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void entryScatterKernel(EntryParams P, const uint8_t *slotMasks, const uint32_t *hist,
                                                                const uint32_t *digitTotals, uint32_t numTiles, uint64_t n,
                                                                uint32_t digitBits, uint32_t *keysOut, uint32_t *valsOut)
 {
@@ -280,7 +280,8 @@ __global__ __launch_bounds__(ENT_TILE) void entryScatterKernel(EntryParams P, co
     __shared__ uint32_t tileBase[BINS];
     __shared__ uint32_t waveTotals[WAVES], waveTotalsAll[WAVES], waveCnt[WAVES];
     __shared__ uint32_t sKeys[ENT_CAP];         /* the tile's keys in (splat, slot) order; afterwards the reorder buffer */
-    __shared__ uint32_t sVals[ENT_CAP];         /* ... and their splat ids */
+    __shared__ uint16_t sVals[ENT_CAP];         /* ... and their splats, as the thread that holds the splat (the id is the
+                                                 * tile's first id + that): 33 instead of 41 KB, four workgroups per CU */
     const uint32_t numBins = 1u << digitBits, dmask = numBins - 1;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t d = threadIdx.x; d < numBins; d += ENT_TILE)
@@ -327,7 +328,7 @@ __global__ __launch_bounds__(ENT_TILE) void entryScatterKernel(EntryParams P, co
                 if (mask & (1u << o))
                 {
                     sKeys[pos] = makeCode(ilx + (o & 1), ily + ((o >> 1) & 1), ilz + (o >> 2)) + levelOffset;
-                    sVals[pos] = gid;
+                    sVals[pos] = (uint16_t) threadIdx.x;
                     pos++;
                 }
         }
@@ -433,12 +434,13 @@ __global__ __launch_bounds__(ENT_TILE) void entryScatterKernel(EntryParams P, co
         }
     }
     /* the ids take the same route: every thread fetches the ids of ITS elements before anything is overwritten */
-    uint32_t vals[MAX_ROUNDS];
+    const uint32_t tileFirstId = blockIdx.x * ENT_TILE + P.firstSplat;
+    uint16_t vals[MAX_ROUNDS];
 #pragma unroll
     for (int j = 0; j < MAX_ROUNDS; j++)
     {
         const uint32_t e = first + j * 64;
-        vals[j] = ((uint32_t) j < rounds && e < tileCount) ? sVals[e] : 0u;
+        vals[j] = ((uint32_t) j < rounds && e < tileCount) ? sVals[e] : (uint16_t) 0;
     }
     __syncthreads();
 #pragma unroll
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(ENT_TILE) void entryScatterKernel(EntryParams P, co
     {
         const uint32_t p = threadIdx.x + k * ENT_TILE;
         if (p < tileCount)
-            valsOut[out[k]] = sVals[p];
+            valsOut[out[k]] = tileFirstId + sVals[p];
     }
 }
 
