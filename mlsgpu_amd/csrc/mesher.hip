@@ -388,6 +388,42 @@ __global__ __launch_bounds__(256) void componentTrianglesKernel(const uint32_t *
         atomicAdd(&count[pendingRoot], pendingCount);
 }
 
+/* The same count for FEW components (surface-like data: a handful of sheets whose triangles alternate along every row of
+ * cells, so the run-length trick above flushes at almost every step and a million global atomics land on a dozen
+ * addresses): per-workgroup bins in LDS, one global atomic per bin and workgroup. */
+#define FEW_COMPONENTS 2048
+__global__ __launch_bounds__(256) void componentTrianglesFewKernel(const uint32_t *tri, const uint32_t *root, const uint32_t *denseOf,
+                                                                   uint64_t nt, uint32_t numRoots, uint32_t *count)
+{
+    __shared__ uint32_t bins[FEW_COMPONENTS];
+    for (uint32_t d = threadIdx.x; d < numRoots; d += 256)
+        bins[d] = 0;
+    __syncthreads();
+    const uint64_t wave = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t first = wave * (64 * SIZE_SPAN);
+    for (uint32_t s = 0; s < SIZE_SPAN; s++)
+    {
+        const uint64_t t = first + (uint64_t) s * 64 + laneId();
+        if (first + (uint64_t) s * 64 >= nt)
+            break;
+        const bool counts = t < nt;
+        const uint32_t mine = counts ? denseOf[root[tri[3 * t]]] : 0u;
+        uint64_t todo = __ballot(counts);
+        while (todo != 0)
+        {
+            const uint32_t r = readLane(mine, (int) __builtin_ctzll(todo));
+            const uint64_t same = __ballot(counts && mine == r) & todo;
+            if (laneId() == 0)
+                atomicAdd(&bins[r], (uint32_t) __popcll(same));
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < numRoots; d += 256)
+        if (bins[d] != 0)
+            atomicAdd(&count[d], bins[d]);
+}
+
 __global__ void gatherSizesKernel(const uint32_t *rootId, const uint32_t *size, uint32_t n, uint32_t *out)
 {
     const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -924,8 +960,12 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
         PROPAGATE(S.get(&tcount, std::max<uint64_t>(rootCount, 1)));
         PROPAGATE(S.get(&vcount, std::max<uint64_t>(rootCount, 1)));
         HIP_CHECK(hipMemsetAsync(tcount, 0, (size_t) rootCount * 4, ctx->stream));
-        LAUNCH(ctx, "mesher.components.time", componentTrianglesKernel, dim3(divUp(divUp(nt, 64 * SIZE_SPAN), 4)), B,
-               (const uint32_t *) m->triangles.ptr, (const uint32_t *) root, (const uint32_t *) denseOf, nt, tcount);
+        if (rootCount <= FEW_COMPONENTS)
+            LAUNCH(ctx, "mesher.components.time", componentTrianglesFewKernel, dim3(divUp(divUp(nt, 64 * SIZE_SPAN), 4)), B,
+                   (const uint32_t *) m->triangles.ptr, (const uint32_t *) root, (const uint32_t *) denseOf, nt, rootCount, tcount);
+        else
+            LAUNCH(ctx, "mesher.components.time", componentTrianglesKernel, dim3(divUp(divUp(nt, 64 * SIZE_SPAN), 4)), B,
+                   (const uint32_t *) m->triangles.ptr, (const uint32_t *) root, (const uint32_t *) denseOf, nt, tcount);
         LAUNCH(ctx, "mesher.components.time", gatherSizesKernel, dim3(divUp(rootCount, 256)), B, (const uint32_t *) rootId,
                (const uint32_t *) size, rootCount, vcount);
         std::vector<uint32_t> hv(rootCount), ht(rootCount);
