@@ -12,13 +12,13 @@ is its own chunk(s): a vertex shared with another rank appears in both, exactly 
 the reference (externalRemap is per chunk, src/mesher.cpp:538-567).
 """
 import numpy as np
+from scipy.sparse import coo_matrix
+from scipy.sparse.csgraph import connected_components
 
 
 def merge_boundaries(parts, prune_threshold):
     """parts[r] = (keys, key_clump, clump_vertices, clump_triangles) of rank r's mesher (HostMesher.boundary()).
     Returns (keep, stats): keep[r] = uint8 verdict per clump of rank r; stats as the mesher's (whole job)."""
-    from scipy.sparse import coo_matrix
-    from scipy.sparse.csgraph import connected_components
     offsets = np.concatenate([[0], np.cumsum([len(p[2]) for p in parts])]).astype(np.int64)
     n = int(offsets[-1])
     keys = np.concatenate([np.asarray(p[0], np.uint64) for p in parts]) if parts else np.zeros(0, np.uint64)
