@@ -1584,7 +1584,7 @@ int mlsgpu_marching::shipOutLattice(const mlsgpu_swathe &sw, const uint32_t size
          * faster one when most cells are occupied (cfg3 noise cloud, 85 %: 4.2 -> 3.6 ms per step).  By CELLS (compact, then
          * one thread per occupied cell): time follows the surface, 0.70 against 1.31 ms per step on the shells cloud
          * (~6 % occupied).  MLSGPU_HIP_TRIANGLES_BY_CELLS=0/1 forces one. */
-        static const char *const routeEnv = getenv("MLSGPU_HIP_TRIANGLES_BY_CELLS");
+        const char *const routeEnv = getenv("MLSGPU_HIP_TRIANGLES_BY_CELLS");     /* read per ship-out: tests flip it */
         const bool byCells = routeEnv != nullptr ? routeEnv[0] != '0'
                                                  : (uint64_t) cellsInBatch * 2 < (uint64_t) cellRows * L.cw;
         if (byCells)

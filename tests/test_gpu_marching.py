@@ -141,6 +141,28 @@ def test_lattice_and_sort_welds_agree(ctx, name, monkeypatch):
     assert_batches_equal(lattice, exp)
 
 
+@pytest.mark.parametrize("route", ["0", "1"])
+@pytest.mark.parametrize("case", ["tsphere", "noise"])
+def test_triangle_routes_agree(ctx, case, route, monkeypatch):
+    """The lattice weld emits its index list by rows of cells (dense data) or from a compacted cell list (surface-like
+    data), chosen per ship-out by the share of occupied cells: forced either way, on a surface and on a noise field
+    (every code, NaN holes), every batch equals the oracle's."""
+    import mlsgpu_amd as m
+    monkeypatch.setenv("MLSGPU_HIP_TRIANGLES_BY_CELLS", route)
+    alignment = (8, 8, 8)
+    if case == "noise":
+        size, fn = (97, 67, 41), noise_fn(205, 0.03)
+    else:
+        (_, _, _), size, fn = GENERATE_CASES["tsphere"]
+    mw, mh, md = size[0] + 3, size[1] + 2, size[2] + 5
+    for mesh_memory in ((mw - 1) * (mh - 1) * 872 * 400, (mw - 1) * (mh - 1) * 872 * 2):
+        mc = m.Marching(ctx, mw, mh, md, 64, mesh_memory, alignment)
+        got = mc.generate(m.binding.HostGenerator(ctx, fn, alignment), size, (7, 0, 3))
+        exp = ob.MarchingOracle(mw, mh, md, 64, mesh_memory, alignment).generate(host_generator(fn), size, (7, 0, 3))
+        assert len(got) >= 1
+        assert_batches_equal(got, exp)
+
+
 def test_empty_and_degenerate(ctx):
     import mlsgpu_amd as m
     mc = m.Marching(ctx, 16, 16, 16, 8, 15 * 15 * 872, (8, 8, 8))
