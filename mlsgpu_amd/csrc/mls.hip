@@ -787,7 +787,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ float4 sPosRad[CUBE_STAGE];
     __shared__ float4 sNormQ[CUBE_STAGE];
     __shared__ uint8_t sMask[CUBE_STAGE];
-    __shared__ uint16_t sSlot[8][64];          /* per wave: byte offsets of the window's relevant splats */
+    __shared__ uint16_t sSlot[8][128];         /* per wave: byte offsets of the window's relevant splats (64) + what a group
+                                                * of 64 staged splats adds beyond a full window */
     __shared__ uint16_t sList[8][8][64];       /* per wave and cube: byte offsets of the splats that can reach the cube */
 
     const uint32_t nBlocks = A.blocksX * A.blocksY * A.blocksZ;
@@ -866,7 +867,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         };
 
         /* the window's relevant splats: cube lists, tests, accumulation */
-        auto processWindow = [&]()
+        auto processWindow = [&](const uint32_t nt)
         {
             /* (the table was written by other lanes of this wave: LDS operations of a wave execute in order) */
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -937,7 +938,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 const uint32_t cur = v == 0 ? 0u : (acc >> (K - v)) << (32u - v);
                 drain(cur, chunk);
             }
-            nt = 0;
         };
 
         int32_t end = A.commands[pos++];
@@ -997,14 +997,25 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 const uint32_t nGroup = (uint32_t) __popcll(todo);
                 if (nGroup == 0)
                     continue;
-                if (nt + nGroup > 64u)
-                    processWindow();
                 if ((todo >> lane) & 1ull)
                     mySlots[nt + popcBelow(todo)] = (uint16_t) ((g + (int32_t) lane) * (int32_t) sizeof(float4));
                 nt += nGroup;
+                if (nt >= 64u)
+                {
+                    /* always a FULL window: the first 64 entries now, the rest of this group moves to the front */
+                    processWindow(64u);
+                    nt -= 64u;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const uint16_t carried = lane < nt ? mySlots[64u + lane] : (uint16_t) 0;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < nt)
+                        mySlots[lane] = carried;
+                }
             }
             if (nt != 0)
-                processWindow();            /* the offsets point into this round's staging buffers */
+                processWindow(nt);          /* the offsets point into this round's staging buffers */
+            nt = 0;
             __syncthreads();
         }
         fit.sumWpx = sWpxy.x;
