@@ -483,62 +483,76 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     # every sink welds and reads back on a stream of its own, of HIGH priority: the weld of job k competes with the
     # kernels of job k + 1 for the GPU, and it is the weld that is on the critical path of the steady state
     import torch
-    hi = [torch.cuda.Stream(device=device_index, priority=-1) for _ in range(2)]
+    NS = 3      # sinks in rotation: two welds may be in flight while the next job streams in (two sinks: 47-54 ms per job)
+    hi = [torch.cuda.Stream(device=device_index, priority=int(os.environ.get("MLSGPU_BENCH_SINK_PRIORITY", "-1"))) for _ in range(NS)]
     fctx = [m.Context(device_index, stream=s_.cuda_stream) for s_ in hi]
     sinks = [m.Mesher(c, 0.02) for c in fctx]
     farms = [m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
                           mesh_memory=args.mesh_memory_mb << 20, sink=s_, copy_threads=args.copy_threads) for s_ in sinks]
-    pins = [m.binding.PinnedBuffer(1) for _ in range(2)]
-    got_bytes = [0, 0]
+    pins = [m.binding.PinnedBuffer(1) for _ in range(NS)]
+    got_bytes = [0] * NS
     errors = []
 
+    phase = {"submit": 0.0, "weld": 0.0, "read_back": 0.0, "jobs": 0}      # seconds, summed over the timed jobs
+
     def submit_job(k):
+        t = time.perf_counter()
         for b, v in zip(buckets, views):
             farms[k].submit(v, b.low, b.num_vertices, 0)
         farms[k].finish()
+        phase["submit"] += time.perf_counter() - t
 
     def finish_job(k):
         try:
+            t = time.perf_counter()
             n = sinks[k].finalize()
+            t1 = time.perf_counter()
             nb = 0
             for i in range(n):
                 nb += m.binding.download_into_pinned(fctx[k], sinks[k].chunk(i, download=False), pins[k])
             fctx[k].synchronize()
             sinks[k].reset()
             got_bytes[k] = nb
+            phase["weld"] += t1 - t
+            phase["read_back"] += time.perf_counter() - t1
+            phase["jobs"] += 1
         except Exception as e:      # noqa: BLE001 - raised by the main thread
             errors.append(e)
 
     def run_jobs(count):
-        prev = None
+        pending = []                           # finish threads in flight, oldest first: at most NS - 1
         for j in range(count):
-            k = j & 1
+            k = j % NS
             submit_job(k)
-            if prev is not None:
-                prev.join()
-            prev = threading.Thread(target=finish_job, args=(k,))
-            prev.start()
-        prev.join()
+            while len(pending) >= NS - 1:      # sink (j + 1) % NS must be free before the next job is submitted into it
+                pending.pop(0).join()
+            t = threading.Thread(target=finish_job, args=(k,))
+            t.start()
+            pending.append(t)
+        for t in pending:
+            t.join()
         if errors:
             raise errors[0]
-    run_jobs(2)                                # warm-up; sizes the arenas and the pinned landing buffers
+    run_jobs(NS)                               # warm-up; sizes the arenas and the pinned landing buffers
     t0 = time.perf_counter()
     submit_job(0)
     finish_job(0)
     single_s = time.perf_counter() - t0        # one job alone, nothing overlapped: its latency
     jobs = max(3 * steps, 9)                  # the pipeline's fill and drain (one job's weld) amortised over the jobs
+    phase.update(submit=0.0, weld=0.0, read_back=0.0, jobs=0)
     t0 = time.perf_counter()
     run_jobs(jobs)
     dt = (time.perf_counter() - t0) / jobs
     out["device_sink"] = {
+        "phases_ms_per_job": {k_: round(phase[k_] / max(phase["jobs"], 1) * 1e3, 2) for k_ in ("submit", "weld", "read_back")},
         "value": round(voxels / dt / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(dt * 1e3, 3),
         "one_job_alone_ms": round(single_s * 1e3, 3),
         "h2d_GB_per_step": round(bucketed_host.nbytes / 1e9, 3), "d2h_GB_per_step": round(got_bytes[0] / 1e9, 3),
         "note": "host splats -> farm -> ship-outs appended in HBM -> weld + components + prune (0.02) on the device -> ONE "
-                "read-back of the final mesh into pinned memory; consecutive jobs alternate between two sinks, so a job's "
-                "weld and read-back overlap the next job's transfer and compute (ms_per_step is the steady state over %d "
-                "jobs; one_job_alone_ms is a single job's latency)" % jobs}
-    for k in range(2):
+                "read-back of the final mesh into pinned memory; consecutive jobs rotate through %d sinks, so a job's "
+                "weld and read-back overlap the following jobs' transfer and compute (ms_per_step is the steady state over %d "
+                "jobs; one_job_alone_ms is a single job's latency)" % (NS, jobs)}
+    for k in range(NS):
         pins[k].free()
         farms[k].close()
         sinks[k].close()

@@ -68,6 +68,21 @@ __global__ void rebaseTrianglesKernel(uint32_t *tri, uint64_t n3, uint32_t base)
         tri[i] += base;
 }
 
+/* copy + rebase in one pass (same-device appends): four indices per thread */
+__global__ __launch_bounds__(256) void copyRebaseTrianglesKernel(uint32_t *dst, const uint32_t *src, uint64_t n3, uint32_t base)
+{
+    const uint64_t i = ((uint64_t) blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i + 4 <= n3 && ((((uintptr_t) dst) | ((uintptr_t) src)) & 15) == 0)
+    {
+        uint4 v = *reinterpret_cast<const uint4 *>(src + i);
+        v.x += base; v.y += base; v.z += base; v.w += base;
+        *reinterpret_cast<uint4 *>(dst + i) = v;
+    }
+    else
+        for (uint64_t k = i; k < n3 && k < i + 4; k++)
+            dst[k] = src[k] + base;
+}
+
 __global__ void fillExternalsKernel(uint32_t *gid, uint32_t *chunk, uint64_t n, uint32_t firstGid, uint32_t chunkIndex)
 {
     const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
@@ -606,6 +621,39 @@ struct mlsgpu_mesher
             HIP_CHECK(hipStreamCreateWithFlags(&addStream, hipStreamNonBlocking));
         return MLSGPU_OK;
     }
+    /* appends that are still running on their producers' streams (same-device appends do not wait on the host: the
+     * producer's next kernels are behind the copies in stream order).  Waited for before an arena moves, before any
+     * analysis and before a reset. */
+    struct PendingAppend
+    {
+        int device;
+        hipEvent_t done;
+    };
+    std::vector<PendingAppend> pending, eventPool;
+    int takeEvent(int device, hipEvent_t *ev)      /* `device` is current */
+    {
+        for (size_t i = 0; i < eventPool.size(); i++)
+            if (eventPool[i].device == device)
+            {
+                *ev = eventPool[i].done;
+                eventPool.erase(eventPool.begin() + (long) i);
+                return MLSGPU_OK;
+            }
+        HIP_CHECK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+        return MLSGPU_OK;
+    }
+    int drainPending(size_t keep = 0)
+    {
+        while (pending.size() > keep)
+        {
+            const hipError_t e = hipEventSynchronize(pending.front().done);
+            eventPool.push_back(pending.front());
+            pending.erase(pending.begin());
+            if (e != hipSuccess)
+                return setError(MLSGPU_ERR_HIP, "mesher: an append failed: %s", hipGetErrorString(e));
+        }
+        return MLSGPU_OK;
+    }
     int regroupByChunk();
     void dropResults() { finalized = false; }
     int finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uint8_t *keepRoots, uint64_t numRoots);
@@ -615,6 +663,9 @@ struct mlsgpu_mesher
         hipFree(outTriangles);
         hipFree(slab);
         if (addStream) hipStreamDestroy(addStream);
+        drainPending();
+        for (auto &e : eventPool)
+            hipEventDestroy(e.done);
     }
 };
 
@@ -684,7 +735,10 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
     const bool newChunk = chunk == m->chunkIds.size();     /* recorded with the block, once everything has succeeded */
     const uint64_t nv = mesh->numVertices, nt = mesh->numTriangles, ne = nv - mesh->numInternalVertices;
     REQUIRE(m->vertices.used / 3 + nv < (uint64_t(1) << 32), MLSGPU_ERR_LENGTH);
-    /* the arenas may move: every earlier append has completed (each add synchronises before it returns) */
+    /* an arena that has to grow moves: every earlier append must have landed first (reserve() up front avoids both) */
+    if (m->vertices.used + 3 * nv > m->vertices.cap || m->triangles.used + 3 * nt > m->triangles.cap
+        || m->extKeys.used + ne > m->extKeys.cap || m->extGid.used + ne > m->extGid.cap || m->extChunk.used + ne > m->extChunk.cap)
+        PROPAGATE(m->drainPending());
     PROPAGATE(m->vertices.reserve(m->addStream, m->vertices.used + 3 * nv));
     PROPAGATE(m->triangles.reserve(m->addStream, m->triangles.used + 3 * nt));
     PROPAGATE(m->extKeys.reserve(m->addStream, m->extKeys.used + ne));
@@ -709,7 +763,11 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
                     : hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, from->stream);
     };
     HIP_CHECK(append(m->vertices.ptr + m->vertices.used, mesh->dVertices, 3 * nv * sizeof(float)));
-    HIP_CHECK(append(m->triangles.ptr + m->triangles.used, mesh->dTriangles, 3 * nt * sizeof(uint32_t)));
+    if (peer)
+        HIP_CHECK(append(m->triangles.ptr + m->triangles.used, mesh->dTriangles, 3 * nt * sizeof(uint32_t)));
+    else if (nt > 0)
+        hipLaunchKernelGGL(copyRebaseTrianglesKernel, dim3(divUp(divUp(3 * nt, 4), 256)), dim3(256), 0, from->stream,
+                           m->triangles.ptr + m->triangles.used, mesh->dTriangles, 3 * nt, (uint32_t) (m->vertices.used / 3));
     HIP_CHECK(append(m->extKeys.ptr + m->extKeys.used, mesh->dVertexKeys + mesh->numInternalVertices, ne * sizeof(uint64_t)));
     hipStream_t fix = from->stream;
     if (peer)
@@ -718,15 +776,36 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
         HIP_CHECK(hipSetDevice(home));
         fix = m->addStream;
     }
-    if (nt > 0)
+    if (nt > 0 && peer)
         hipLaunchKernelGGL(rebaseTrianglesKernel, dim3(divUp(3 * nt, 256)), dim3(256), 0, fix,
                            m->triangles.ptr + m->triangles.used, 3 * nt, r.vBase);
     if (ne > 0)
         hipLaunchKernelGGL(fillExternalsKernel, dim3(divUp(ne, 256)), dim3(256), 0, fix,
                            m->extGid.ptr + m->extGid.used, m->extChunk.ptr + m->extChunk.used, ne, r.vBase + r.nInternal, chunk);
     HIP_CHECK(hipGetLastError());
-    /* the mesh is Marching's and is reused for the next ship-out: the copies must have left it */
-    HIP_CHECK(hipStreamSynchronize(fix));
+    if (peer)
+    {
+        /* the fix-ups ran on the mesher's stream, not the producer's: the mesh is Marching's and is reused for the next
+         * ship-out, so they must have finished */
+        HIP_CHECK(hipStreamSynchronize(fix));
+    }
+    else
+    {
+        /* same device: copies and fix-ups are on the PRODUCER's stream, ahead of whatever it does to the mesh next -- the
+         * worker goes on without waiting; the mesher remembers that this append is still in flight */
+        mlsgpu_mesher::PendingAppend p{from->device, nullptr};
+        PROPAGATE(m->takeEvent(from->device, &p.done));
+        if (hipEventRecord(p.done, fix) != hipSuccess)
+        {
+            m->eventPool.push_back(p);
+            HIP_CHECK(hipStreamSynchronize(fix));
+        }
+        else
+        {
+            m->pending.push_back(p);
+            PROPAGATE(m->drainPending(512));       /* bounds the list on jobs of thousands of ship-outs */
+        }
+    }
     m->vertices.used += 3 * nv;
     m->triangles.used += 3 * nt;
     m->extKeys.used += ne;
@@ -752,6 +831,7 @@ MLSGPU_API int mlsgpu_hip_mesher_reset(mlsgpu_mesher *m)
 {
     REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
     std::lock_guard<std::mutex> lock(m->mutex);
+    PROPAGATE(m->drainPending());
     m->vertices.used = m->triangles.used = 0;
     m->extKeys.used = m->extGid.used = m->extChunk.used = 0;
     m->blocks.clear();
@@ -846,6 +926,7 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
 {
     mlsgpu_mesher *const m = this;
     mlsgpu_ctx *ctx = m->ctx;
+    PROPAGATE(m->drainPending());
     HIP_CHECK(hipSetDevice(ctx->device));
     m->dropResults();
     PROPAGATE(m->regroupByChunk());
