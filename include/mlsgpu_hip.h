@@ -387,8 +387,10 @@ int mlsgpu_hip_mesher_set_prune_threshold(mlsgpu_mesher *mesher, double threshol
 /* Optional: room for this many vertices / triangles / external vertices in total (the arenas grow by reallocation
  * otherwise). */
 int mlsgpu_hip_mesher_reserve(mlsgpu_mesher *mesher, uint64_t numVertices, uint64_t numTriangles, uint64_t numExternal);
-/* MesherBase::InputFunctor for a DeviceKeyMesh: appends a copy of the mesh (device to device, on `from`'s stream, which
- * is synchronised before returning: Marching reuses the mesh).  Thread safe; `from` is the calling worker's context, on
+/* MesherBase::InputFunctor for a DeviceKeyMesh: appends a copy of the mesh (device to device, on `from`'s stream).  On the
+ * mesher's own device the call does not wait for the copy: it is ahead of whatever `from`'s stream does to the mesh next
+ * (Marching reuses it), and the mesher waits for its pending appends before anything reads the arenas (finalize, boundary,
+ * reset, a growing arena); a peer append synchronises.  Thread safe; `from` is the calling worker's context, on
  * the mesher's device or on ANOTHER GPU (then the append is a peer copy over the fabric: several GPUs' buckets welded
  * in one GPU's HBM).  Blocks may arrive in any order, chunk ids interleaved (OOCMesher::add indexes chunks[chunkId.gen]
  * and accepts any arrival order too); output chunks are in order of first arrival. */
