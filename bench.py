@@ -505,10 +505,11 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     def finish_job(k):
         try:
             t = time.perf_counter()
-            n = sinks[k].finalize()
+            skip = os.environ.get("MLSGPU_BENCH_SINK_SKIP", "")      # diagnosis: "weld", "readback"
+            n = 0 if skip == "weld" else sinks[k].finalize()
             t1 = time.perf_counter()
             nb = 0
-            for i in range(n):
+            for i in range(0 if skip == "readback" else n):
                 nb += m.binding.download_into_pinned(fctx[k], sinks[k].chunk(i, download=False), pins[k])
             fctx[k].synchronize()
             sinks[k].reset()
