@@ -79,6 +79,11 @@ def parse_args():
                         "(shells cloud, 8d region: 2 971 Mvoxels/s with 2, 3 719 with 4)")
     p.add_argument("--variant", type=int, default=4, help="MLS kernel variant: 0 culled, 1 basic, 2 culled + hit lists, 3 culled + hit masks, 4 culled + cube streams")
     p.add_argument("--leg-steps", type=int, default=3, help="passes of every secondary leg")
+    p.add_argument("--restore-splats", action="store_true",
+                   help="rounds 1-2's protocol: the tree build mutates the resident splats (radius -> 1/radius^2 in place, as the "
+                        "reference's does) and every bucket starts with a device-to-device restore of its splats inside the timed "
+                        "region.  Default since round 3: the workers keep the splats intact (mlsgpu_hip_worker_set_keep_splats), so "
+                        "the resident input needs no restoring; the line reports this mode's step beside the headline")
     p.add_argument("--copy-threads", type=int, default=8, help="host threads copying one bucket into pinned staging (transfer legs)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-transfer", action="store_true", help="skip the transfer-inclusive legs (SURVEY 8d timed region)")
@@ -852,20 +857,29 @@ def main():
     pristine = m.DeviceBuffer(ctx, nbytes=nbytes, borrow=bucketed_t.data_ptr())
     work = m.DeviceBuffer(ctx, nbytes=nbytes)
     workers = [m.Worker(c, max_count, max_cells=max_cells, mesh_memory=args.mesh_memory_mb << 20) for c in ctxs]
+    # The reference's octree build overwrites splat.w with 1/r^2 (kernels/octree.cl:193).  Its splats arrive by H2D copy for
+    # every work item, so nothing is lost; RESIDENT splats would have to be restored before every bucket (rounds 1-2 did
+    # that with a device-to-device copy inside the timed region).  Since round 3 the workers leave the splats intact
+    # (non-mutating build, processCorners takes the reciprocal while staging: bit-identical field) and the resident
+    # input is simply processed again.  --restore-splats brings the old protocol back; its step is reported either way.
+    mutating = [bool(args.restore_splats)]
     for w in workers:
         w.set_mls_variant(args.variant)
+        w.set_keep_splats(not mutating[0])
     pool = ThreadPoolExecutor(nworkers)
     collectors = [m.binding.SizeCollector() for _ in range(nworkers)]
 
+    def fresh(c, b):
+        if mutating[0]:
+            m.binding.check(m.lib().mlsgpu_hip_memcpy_d2d(c.h, work.ptr + 32 * b.first, pristine.ptr + 32 * b.first, 32 * b.count))
+
     def run_share(k):
-        # worker k takes buckets k, k + nworkers, ... (ctypes releases the GIL inside the library).
-        # The octree build overwrites splat.w with 1/r^2 (kernels/octree.cl:193), so every bucket starts from a fresh
-        # copy of its resident splats: a device-to-device copy ON THE WORKER'S STREAM, standing where the reference has the
-        # host-to-device copy of the work item (src/workers.cpp:356-361), overlapping the other workers' kernels exactly as
-        # that copy overlaps them.  It is inside the timed region.
+        # worker k takes buckets k, k + nworkers, ... (ctypes releases the GIL inside the library).  With a mutating build
+        # every bucket starts from a fresh copy of its resident splats, ON THE WORKER'S STREAM, where the reference has the
+        # host-to-device copy of the work item (src/workers.cpp:356-361), inside the timed region.
         w, col, c = workers[k], collectors[k], ctxs[k]
         for b in farm.worker_share(buckets, k, nworkers):
-            m.binding.check(m.lib().mlsgpu_hip_memcpy_d2d(c.h, work.ptr + 32 * b.first, pristine.ptr + 32 * b.first, 32 * b.count))
+            fresh(c, b)
             w.process(work, b.first, b.count, b.low, b.num_vertices, collector=col)
         c.synchronize()
 
@@ -909,7 +923,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(sw_steps):
             for b in buckets:
-                m.binding.check(m.lib().mlsgpu_hip_memcpy_d2d(ctx.h, work.ptr + 32 * b.first, pristine.ptr + 32 * b.first, 32 * b.count))
+                fresh(ctx, b)
                 workers[0].process(work, b.first, b.count, b.low, b.num_vertices, collector=col1)
         ctx.synchronize()
         single_worker_ms = (time.perf_counter() - t0) / sw_steps * 1e3
@@ -959,6 +973,29 @@ def main():
         c.synchronize()
     torch.cuda.synchronize()
     own_elapsed = time.perf_counter() - t0
+    # the other splat protocol, a few passes, never `value`: what the restore copies (or their absence) are worth
+    other_mode_ms = None
+    if dist is None and not args.headline_only:
+        timed_collectors = list(collectors)      # the counts of the timed passes stay what they are
+        collectors[:] = [m.binding.SizeCollector() for _ in range(nworkers)]
+        mutating[0] = not mutating[0]
+        for w in workers:
+            w.set_keep_splats(not mutating[0])
+        work.copy_from(pristine)
+        ctx.synchronize()
+        step()                                   # warm-up of the mode
+        t1 = time.perf_counter()
+        for _ in range(ref_steps):
+            step()
+        for c in ctxs:
+            c.synchronize()
+        other_mode_ms = (time.perf_counter() - t1) / ref_steps * 1e3
+        mutating[0] = not mutating[0]
+        for w in workers:
+            w.set_keep_splats(not mutating[0])
+        work.copy_from(pristine)
+        ctx.synchronize()
+        collectors[:] = timed_collectors
     if dist is not None:
         dist.barrier()
     # whole job: MAX of the elapsed time over ranks, SUM of the voxels (each rank ran `steps` passes over its buckets)
@@ -1003,6 +1040,10 @@ def main():
             "bucket_splats_total": int(bucketed_t.shape[0]),
             "mesh_memory_mb": args.mesh_memory_mb,
             "device_workers": nworkers,
+            "resident_splats": ("restored by a device-to-device copy before every bucket, inside the timed region (the tree build "
+                                "mutates them, as the reference's does)" if args.restore_splats else
+                                "processed in place: the workers keep them intact (non-mutating tree build, processCorners takes "
+                                "1/r^2 while staging; bit-identical output), so nothing is restored"),
             "mls_variant": {0: "culled", 1: "basic", 2: "culled+hit-lists", 3: "culled+hit-masks", 4: "culled+cube-streams"}[args.variant],
             "sharding": "one process per GPU, rank r owns z-slab r (25 buckets); no data-path collective" if world > 1
                         else "single GPU",
@@ -1017,6 +1058,12 @@ def main():
             "what": "sha256/16 over (sizes, vertex / triangle / external-key checksums) of every ship-out of one pass of rank "
                     "0's buckets, computed on the device (mlsgpu_hip_mesh_checksum)"},
     }
+    if other_mode_ms is not None:
+        result["other_splat_protocol"] = {
+            "ms_per_step": round(other_mode_ms, 3), "steps": ref_steps,
+            "what": ("keep-splats workers, no restore copies" if args.restore_splats else
+                     "rounds 1-2's protocol (--restore-splats): mutating tree build + a device-to-device restore of every bucket's "
+                     "splats inside the step")}
     result["_grid"] = W["grid"]
     if W["name"] == "cfg3" and args.dist == "uniform" and args.scale == 1.0 and CFG3_UNIFORM_DIGEST is not None:
         result["output_digest"]["expected"] = CFG3_UNIFORM_DIGEST

@@ -141,6 +141,12 @@ uint64_t mlsgpu_hip_tree_resource_usage(uint64_t maxLevels, uint64_t maxSplats);
  * dSplats until mlsgpu_hip_tree_clear_splats and MUTATES it (radius -> 1/radius^2). */
 int mlsgpu_hip_tree_build(mlsgpu_tree *tree, mlsgpu_splat *dSplats, uint64_t firstSplat, uint64_t numSplats,
                           const uint32_t size[3], const int32_t offset[3], uint32_t subsamplingShift);
+/* mutate = 0: builds leave dSplats as they are (no radius -> 1/radius^2, kernels/octree.cl:193); mlsgpu_hip_mls_set then
+ * makes processCorners take the reciprocal itself while it stages a splat -- the same expression on the same value, so the
+ * field is bit-identical.  For callers whose splats stay resident over several builds.  Default 1: the reference's
+ * behaviour. */
+int mlsgpu_hip_tree_set_mutate(mlsgpu_tree *tree, int mutate);
+int mlsgpu_hip_tree_mutates(const mlsgpu_tree *tree);
 void mlsgpu_hip_tree_clear_splats(mlsgpu_tree *tree);
 /* Measurement aid: (splat, node) entries of the last build (synchronises the stream). */
 int mlsgpu_hip_tree_num_entries(mlsgpu_tree *tree, uint64_t *out);
@@ -160,6 +166,9 @@ int mlsgpu_hip_mls_set(mlsgpu_mls *mls, const int32_t offset[3], const mlsgpu_tr
 int mlsgpu_hip_mls_set_buffers(mlsgpu_mls *mls, const int32_t offset[3], const mlsgpu_splat *dSplats,
                                const int32_t *dCommands, const int32_t *dStart, uint32_t subsamplingShift);
 int mlsgpu_hip_mls_set_boundary_limit(mlsgpu_mls *mls, float limit);   /* src/mls.cpp:137-144 */
+/* With explicit buffers (mlsgpu_hip_mls_set_buffers): 1 if the splats' radius slot still holds the radius, 0 (default) if
+ * it holds 1/radius^2 as after a mutating build.  mlsgpu_hip_mls_set takes it from the tree. */
+int mlsgpu_hip_mls_set_raw_radius(mlsgpu_mls *mls, int rawRadius);
 /* MlsFunctor::enqueue, src/mls.cpp:101-135.  fieldRows = rows allocated in dField (bounds check). */
 int mlsgpu_hip_mls_enqueue(mlsgpu_mls *mls, float *dField, uint64_t pitch, uint64_t fieldRows,
                            const mlsgpu_swathe *swathe);
@@ -241,6 +250,9 @@ uint64_t mlsgpu_hip_worker_resource_usage(const mlsgpu_worker_config *cfg);
 int mlsgpu_hip_worker_process(mlsgpu_worker *w, mlsgpu_splat *dSplats, uint64_t firstSplat, uint64_t numSplats,
                               const int32_t lowExtent[3], const uint32_t numVertices[3],
                               mlsgpu_output_fn output, void *outputUser);
+/* keep = 1: the worker does not modify dSplats (non-mutating tree build + raw-radius processCorners, see
+ * mlsgpu_hip_tree_set_mutate): resident splats can be processed again without being restored.  Default 0. */
+int mlsgpu_hip_worker_set_keep_splats(mlsgpu_worker *w, int keep);
 mlsgpu_tree *mlsgpu_hip_worker_tree(mlsgpu_worker *w);
 mlsgpu_mls *mlsgpu_hip_worker_mls(mlsgpu_worker *w);
 mlsgpu_marching *mlsgpu_hip_worker_marching(mlsgpu_worker *w);

@@ -147,6 +147,10 @@ def lib():
     sig("mlsgpu_hip_tree_destroy", None, vp)
     sig("mlsgpu_hip_tree_resource_usage", u64, u64, u64)
     sig("mlsgpu_hip_tree_build", C.c_int, vp, vp, u64, u64, vp, vp, u32)
+    sig("mlsgpu_hip_tree_set_mutate", C.c_int, vp, C.c_int)
+    sig("mlsgpu_hip_tree_mutates", C.c_int, vp)
+    sig("mlsgpu_hip_mls_set_raw_radius", C.c_int, vp, C.c_int)
+    sig("mlsgpu_hip_worker_set_keep_splats", C.c_int, vp, C.c_int)
     sig("mlsgpu_hip_tree_clear_splats", None, vp)
     sig("mlsgpu_hip_tree_num_entries", C.c_int, vp, P(u64))
     sig("mlsgpu_hip_tree_splats", vp, vp)
@@ -439,6 +443,10 @@ class SplatTree:
         check(lib().mlsgpu_hip_tree_build(self.h, splats.ptr, first_splat, num_splats, _p(_u3(size)),
                                           _p(_i3(offset)), subsampling_shift))
 
+    def set_mutate(self, mutate):
+        """False: builds leave the splats untouched (the radius stays the radius); MlsFunctor.set() follows."""
+        check(lib().mlsgpu_hip_tree_set_mutate(self.h, 1 if mutate else 0))
+
     def clear_splats(self):
         lib().mlsgpu_hip_tree_clear_splats(self.h)
 
@@ -480,6 +488,10 @@ class MlsFunctor:
 
     def set_boundary_limit(self, limit):
         check(lib().mlsgpu_hip_mls_set_boundary_limit(self.h, limit))
+
+    def set_raw_radius(self, raw):
+        """With set_buffers: True if the splats' radius slot still holds the radius (not 1/r^2)."""
+        check(lib().mlsgpu_hip_mls_set_raw_radius(self.h, 1 if raw else 0))
 
     def set_variant(self, variant):
         check(lib().mlsgpu_hip_mls_set_variant(self.h, variant))
@@ -1054,6 +1066,10 @@ class Worker:
 
     def set_mls_variant(self, variant):
         check(lib().mlsgpu_hip_mls_set_variant(lib().mlsgpu_hip_worker_mls(self.h), variant))
+
+    def set_keep_splats(self, keep):
+        """True: process() leaves the splats as they came (resident splats can be processed again)."""
+        check(lib().mlsgpu_hip_worker_set_keep_splats(self.h, 1 if keep else 0))
 
     def set_mls_stats(self, counters):
         """counters: DeviceBuffer of 3 uint64 (or None): see mlsgpu_hip_mls_set_stats."""

@@ -487,6 +487,16 @@ MLSGPU_API int mlsgpu_hip_worker_process(mlsgpu_worker *w, mlsgpu_splat *dSplats
     return MLSGPU_OK;
 }
 
+/* DeviceWorkerGroup's item buffer is rewritten by every H2D copy, so nothing downstream reads the splats the build has
+ * mutated; a caller whose splats are RESIDENT (several passes over the same buffer) keeps them intact with this: the tree
+ * is built without the in-place radius -> 1/radius^2 and processCorners takes the reciprocal while staging.  Same field,
+ * bit for bit. */
+MLSGPU_API int mlsgpu_hip_worker_set_keep_splats(mlsgpu_worker *w, int keep)
+{
+    REQUIRE(w != nullptr, MLSGPU_ERR_INVALID);
+    return mlsgpu_hip_tree_set_mutate(w->tree, keep ? 0 : 1);
+}
+
 MLSGPU_API mlsgpu_tree *mlsgpu_hip_worker_tree(mlsgpu_worker *w) { return w ? w->tree : nullptr; }
 MLSGPU_API mlsgpu_mls *mlsgpu_hip_worker_mls(mlsgpu_worker *w) { return w ? w->mls : nullptr; }
 MLSGPU_API mlsgpu_marching *mlsgpu_hip_worker_marching(mlsgpu_worker *w) { return w ? w->marching : nullptr; }

@@ -30,6 +30,7 @@ struct mlsgpu_tree;
 extern "C" const mlsgpu_splat *mlsgpu_hip_tree_splats(const mlsgpu_tree *);
 extern "C" const int32_t *mlsgpu_hip_tree_commands(const mlsgpu_tree *);
 extern "C" const int32_t *mlsgpu_hip_tree_start(const mlsgpu_tree *);
+extern "C" int mlsgpu_hip_tree_mutates(const mlsgpu_tree *);
 
 struct mlsgpu_mls
 {
@@ -43,6 +44,7 @@ struct mlsgpu_mls
     int32_t offset[3] = {0, 0, 0};
     float boundaryFactor = 0.0f;
     bool isSet = false;
+    bool rawRadius = false;      /* the splats still hold the radius (a tree built without mutation): 1/r^2 is taken at staging */
     unsigned long long *dStats = nullptr;   /* optional work counters, see mlsgpu_hip_mls_set_stats */
 };
 
@@ -193,8 +195,19 @@ struct MlsArgs
     uint32_t blocksX, blocksY, blocksZ;
     float boundaryFactor;
     uint32_t xcdChunk;           /* see xcdRemap */
+    uint32_t rawRadius;          /* splat.w is the radius, not 1/radius^2 */
     unsigned long long *stats;   /* [0] listed splats, [1] (corner, splat) distance tests, [2] hits */
 };
+
+/* position and 1/radius^2 of a listed splat.  A tree built without mutation leaves the radius in the splat; the same
+ * expression the build would have stored (kernels/octree.cl:193) is evaluated here, once per staged record. */
+__device__ __forceinline__ float4 stagedPosRad(const MlsArgs &A, int32_t id)
+{
+    float4 pr = A.splats[2 * (int64_t) id];
+    if (A.rawRadius)
+        pr.w = 1.0f / (pr.w * pr.w);
+    return pr;
+}
 
 /*
  * Workgroup -> block mapping.  Workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so consecutive
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(512) void processCornersKernel(MlsArgs A)
             uint32_t mask = 0;
             if (mine >= 0)
             {
-                const float4 pr = A.splats[2 * (int64_t) mine];
+                const float4 pr = stagedPosRad(A, mine);
                 const float4 nq = A.splats[2 * (int64_t) mine + 1];
                 sPosRad[tid] = pr;
                 sNormQ[tid] = nq;
@@ -454,7 +467,7 @@ __global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
                 mine = lpos < end ? A.commands[lpos] : -1;
                 if (mine >= 0)
                 {
-                    const float4 pr = A.splats[2 * (int64_t) mine];
+                    const float4 pr = stagedPosRad(A, mine);
                     const float4 nq = A.splats[2 * (int64_t) mine + 1];
                     sPosRad[tid] = pr;
                     sNormQ[tid] = nq;
@@ -666,7 +679,7 @@ __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
                 const int32_t mine = lpos < end ? A.commands[lpos] : -1;
                 if (mine >= 0)
                 {
-                    const float4 pr = A.splats[2 * (int64_t) mine];
+                    const float4 pr = stagedPosRad(A, mine);
                     const float4 nq = A.splats[2 * (int64_t) mine + 1];
                     sPosRad[slot] = pr;
                     sNormQ[slot] = nq;
@@ -954,7 +967,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 const int32_t mine = lpos < end ? A.commands[lpos] : -1;
                 if (mine >= 0)
                 {
-                    const float4 pr = A.splats[2 * (int64_t) mine];
+                    const float4 pr = stagedPosRad(A, mine);
                     const float4 nq = A.splats[2 * (int64_t) mine + 1];
                     sPosRad[slot] = pr;
                     sNormQ[slot] = nq;
@@ -1069,14 +1082,24 @@ MLSGPU_API int mlsgpu_hip_mls_set_buffers(mlsgpu_mls *m, const int32_t offset[3]
     for (int i = 0; i < 3; i++)
         m->offset[i] = offset[i];
     m->isSet = true;
+    m->rawRadius = false;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_mls_set_raw_radius(mlsgpu_mls *m, int rawRadius)
+{
+    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
+    m->rawRadius = rawRadius != 0;
     return MLSGPU_OK;
 }
 
 MLSGPU_API int mlsgpu_hip_mls_set(mlsgpu_mls *m, const int32_t offset[3], const mlsgpu_tree *tree, uint32_t subsamplingShift)
 {
     REQUIRE(m != nullptr && tree != nullptr, MLSGPU_ERR_INVALID);
-    return mlsgpu_hip_mls_set_buffers(m, offset, mlsgpu_hip_tree_splats(tree), mlsgpu_hip_tree_commands(tree),
-                                      mlsgpu_hip_tree_start(tree), subsamplingShift);
+    PROPAGATE(mlsgpu_hip_mls_set_buffers(m, offset, mlsgpu_hip_tree_splats(tree), mlsgpu_hip_tree_commands(tree),
+                                         mlsgpu_hip_tree_start(tree), subsamplingShift));
+    m->rawRadius = mlsgpu_hip_tree_mutates(tree) == 0;
+    return MLSGPU_OK;
 }
 
 MLSGPU_API int mlsgpu_hip_mls_set_boundary_limit(mlsgpu_mls *m, float limit)
@@ -1149,6 +1172,7 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
      *   The kernel is not HBM-bound, so the faster setting wins. */
     static const uint32_t xcdChunk = getenv("MLSGPU_HIP_MLS_XCD_CHUNK") ? (uint32_t) atoi(getenv("MLSGPU_HIP_MLS_XCD_CHUNK")) : 16u;
     A.xcdChunk = xcdChunk;
+    A.rawRadius = m->rawRadius ? 1u : 0u;
     const dim3 grid(A.blocksX * A.blocksY * A.blocksZ), block(512);
     const char *stat = "kernel.mls.processCorners.time";      /* src/mls.cpp:57 */
     A.stats = m->dStats;

@@ -37,6 +37,7 @@ struct mlsgpu_tree
     HostMailbox entryBox;               /* the entry count comes back to the host once per build */
     uint8_t *dSlotMasks = nullptr;      /* per splat: which of its 8 candidate slots are real entries */
     mlsgpu_splat *dSplats = nullptr;   /* borrowed between build and clear_splats */
+    bool mutate = true;                 /* radius -> 1/radius^2 in place (the reference); false: the splats stay as they came */
 };
 
 namespace
@@ -109,6 +110,7 @@ struct EntryParams
     LevelOffsets levelOffsets;
     int minShift, maxShift;
     uint32_t firstSplat;
+    uint32_t mutate;            /* write 1/r^2 into the radius slot (kernels/octree.cl:193), or leave the splats untouched */
 };
 
 __device__ __forceinline__ uint32_t splatEntries(const EntryParams &P, const float4 pr, uint32_t k[8])
@@ -183,7 +185,8 @@ struct EntryWriteOut
         const uint32_t gid = (uint32_t) i + P.firstSplat;
         float4 *sp = reinterpret_cast<float4 *>(P.splats + gid);
         const float4 pr = sp[0];
-        reinterpret_cast<float *>(sp)[3] = 1.0f / (pr.w * pr.w);
+        if (P.mutate)
+            reinterpret_cast<float *>(sp)[3] = 1.0f / (pr.w * pr.w);
         const uint32_t mask = slotMasks[i];
         if (mask == 0)
             return;
@@ -311,7 +314,8 @@ __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))
         const uint32_t gid = (uint32_t) i + P.firstSplat;
         float4 *sp = reinterpret_cast<float4 *>(P.splats + gid);
         const float4 pr = sp[0];
-        reinterpret_cast<float *>(sp)[3] = 1.0f / (pr.w * pr.w);        /* kernels/octree.cl:193 */
+        if (P.mutate)
+            reinterpret_cast<float *>(sp)[3] = 1.0f / (pr.w * pr.w);    /* kernels/octree.cl:193 */
         if (mask != 0)
         {
             /* prepare (octree.cl:79-90) again for the node coordinates; the box tests are not repeated */
@@ -680,7 +684,7 @@ MLSGPU_API int mlsgpu_hip_tree_build(mlsgpu_tree *t, mlsgpu_splat *dSplats, uint
     }
     if (numSplats > 0)
     {
-        EntryParams P{dSplats, offset[0], offset[1], offset[2], lo, minShift, maxShift, (uint32_t) firstSplat};
+        EntryParams P{dSplats, offset[0], offset[1], offset[2], lo, minShift, maxShift, (uint32_t) firstSplat, t->mutate ? 1u : 0u};
         const uint32_t keyBits = (uint32_t) (3 * (maxShift - minShift) + 1);
         const uint32_t passes = sortPasses(keyBits, SortCaps<uint32_t>::MAX_DIGIT_BITS);
         const uint32_t perPass = (keyBits + passes - 1) / passes;
@@ -744,6 +748,13 @@ MLSGPU_API int mlsgpu_hip_tree_num_entries(mlsgpu_tree *t, uint64_t *out)
 
 MLSGPU_API void mlsgpu_hip_tree_clear_splats(mlsgpu_tree *t) { if (t) t->dSplats = nullptr; }
 MLSGPU_API const mlsgpu_splat *mlsgpu_hip_tree_splats(const mlsgpu_tree *t) { return t->dSplats; }
+MLSGPU_API int mlsgpu_hip_tree_set_mutate(mlsgpu_tree *t, int mutate)
+{
+    REQUIRE(t != nullptr, MLSGPU_ERR_INVALID);
+    t->mutate = mutate != 0;
+    return MLSGPU_OK;
+}
+MLSGPU_API int mlsgpu_hip_tree_mutates(const mlsgpu_tree *t) { return t != nullptr && t->mutate ? 1 : 0; }
 MLSGPU_API const int32_t *mlsgpu_hip_tree_commands(const mlsgpu_tree *t) { return t->dCommands; }
 MLSGPU_API const int32_t *mlsgpu_hip_tree_start(const mlsgpu_tree *t) { return t->dStart; }
 MLSGPU_API uint64_t mlsgpu_hip_tree_commands_size(const mlsgpu_tree *t) { return t->commandsSize; }

@@ -46,6 +46,32 @@ def test_cfg1_parity(ctx, variant):
     assert is_manifold(len(v), tr) == ""
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4])
+def test_keep_splats(ctx, variant):
+    """mlsgpu_hip_worker_set_keep_splats (non-mutating tree build + processCorners taking 1/r^2 while it stages a splat,
+    in every kernel variant): the bucket's mesh is bit-identical to the oracle's (whose tree mutates its splats), the
+    device splats are untouched, and a second pass over the SAME buffer gives the same batches."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import synth
+    cloud, g = synth.make_cloud("cfg1")
+    w = m.Worker(ctx, len(cloud), max_cells=63)
+    w.set_mls_variant(variant)
+    w.set_keep_splats(True)
+    buf = m.DeviceBuffer(ctx, array=cloud)
+    got = w.process(buf, 0, len(cloud), (0, 0, 0), (g, g, g))
+    exp, _ = ob.bucket(cloud.copy(), 0, len(cloud), (g, g, g), (0, 0, 0), max_cells=63, max_swathe=64,
+                       mesh_memory=63 * 63 * 2 * 872)
+    assert_batches_equal(got, exp)
+    np.testing.assert_array_equal(buf.download(m.SPLAT_DTYPE, len(cloud)).view(np.uint32), cloud.view(np.uint32))
+    again = w.process(buf, 0, len(cloud), (0, 0, 0), (g, g, g))
+    assert_batches_equal(again, exp)
+    # and back: the reference's behaviour
+    w.set_keep_splats(False)
+    third = w.process(buf, 0, len(cloud), (0, 0, 0), (g, g, g))
+    assert_batches_equal(third, exp)
+    assert not np.array_equal(buf.download(m.SPLAT_DTYPE, len(cloud))["radius"], cloud["radius"])
+
+
 def test_offset_bucket_scale_bias_and_small_mesh_memory(ctx):
     """A bucket away from the origin, ragged size, tiny mesh memory (several ship-outs), scale/bias applied."""
     from mlsgpu_amd import synth

@@ -62,6 +62,22 @@ def compare_with_oracle(commands, start, mutated, splats, first, num, size, offs
     np.testing.assert_array_equal(mutated.view(np.uint32), s2.view(np.uint32))
 
 
+def test_build_without_mutation(ctx):
+    """mlsgpu_hip_tree_set_mutate(0): the same commands / start, and the splats are left as they came."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import synth
+    cloud, g = synth.make_cloud("cfg1", scale=0.5)
+    tree = m.SplatTree(ctx, 6, len(cloud))
+    tree.set_mutate(False)
+    buf = m.DeviceBuffer(ctx, array=cloud)
+    tree.enqueue_build(buf, 0, len(cloud), (64, 64, 64), (0, 0, 0), 3)
+    ctx.synchronize()
+    t = ob.Tree(cloud.copy(), 0, len(cloud), (64, 64, 64), (0, 0, 0), 3, 6)
+    np.testing.assert_array_equal(tree.start()[:t.num_start], t.start[:t.num_start])
+    np.testing.assert_array_equal(tree.commands()[:t.num_commands], t.commands[:t.num_commands])
+    np.testing.assert_array_equal(buf.download(m.SPLAT_DTYPE, len(cloud)).view(np.uint32), cloud.view(np.uint32))
+
+
 def test_build(ctx):
     """TestSplatTree::testBuild on the device result."""
     splats = make_splats(BUILD_SPLATS)
