@@ -125,6 +125,8 @@ public:
         check(mlsgpu_hip_tree_build(h, splats, firstSplat, numSplats, size, offset, subsamplingShift));
     }
     void clearSplats() { mlsgpu_hip_tree_clear_splats(h); }
+    /* false: enqueueBuild leaves the splats untouched (no radius -> 1/radius^2); MlsFunctor::set follows the tree */
+    void setMutate(bool mutate) { check(mlsgpu_hip_tree_set_mutate(h, mutate ? 1 : 0)); }
     const Splat *getSplats() const { return mlsgpu_hip_tree_splats(h); }
     const command_type *getCommands() const { return mlsgpu_hip_tree_commands(h); }
     const command_type *getStart() const { return mlsgpu_hip_tree_start(h); }
@@ -257,6 +259,8 @@ public:
         check(mlsgpu_hip_mls_set(h, offset, tree.get(), subsamplingShift));
     }
     void setBoundaryLimit(float limit) { check(mlsgpu_hip_mls_set_boundary_limit(h, limit)); }
+    /* with explicit buffers: the splats still hold the radius, not 1/radius^2 */
+    void setRawRadius(bool raw) { check(mlsgpu_hip_mls_set_raw_radius(h, raw ? 1 : 0)); }
     virtual const std::uint32_t *alignment() const { return wgs_; }
     virtual void enqueue(void *, float *distance, std::size_t pitch, const Marching::Swathe &swathe)
     {
