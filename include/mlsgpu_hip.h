@@ -141,6 +141,22 @@ uint64_t mlsgpu_hip_tree_resource_usage(uint64_t maxLevels, uint64_t maxSplats);
  * dSplats until mlsgpu_hip_tree_clear_splats and MUTATES it (radius -> 1/radius^2). */
 int mlsgpu_hip_tree_build(mlsgpu_tree *tree, mlsgpu_splat *dSplats, uint64_t firstSplat, uint64_t numSplats,
                           const uint32_t size[3], const int32_t offset[3], uint32_t subsamplingShift);
+/* Batches: a device worker may take several buckets -- the SubItems of one WorkItem (src/workers.h:148-181), which the
+ * reference's worker walks one by one (src/workers.cpp:232-286) -- through the path in lock-step.  Every kernel of the path
+ * has a bucket dimension (blockIdx.y = bucket, per-bucket arguments in the kernel-argument segment), so a batch is ONE set
+ * of launches and three host decisions; per bucket the results are those of the one-bucket entry points, bit for bit. */
+#define MLSGPU_MAX_BATCH 8
+typedef struct mlsgpu_tree_build
+{
+    mlsgpu_splat *dSplats;
+    uint64_t firstSplat, numSplats;
+    uint32_t size[3];
+    int32_t offset[3];
+} mlsgpu_tree_build;
+/* SplatTreeCL::enqueueBuild for `count` buckets at once: trees[k] (distinct trees of one context and one depth) is built
+ * from builds[k], arguments as mlsgpu_hip_tree_build.  One read-back of all the entry counts. */
+int mlsgpu_hip_tree_build_batch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *builds, uint32_t count,
+                                uint32_t subsamplingShift);
 /* mutate = 0: builds leave dSplats as they are (no radius -> 1/radius^2, kernels/octree.cl:193); mlsgpu_hip_mls_set then
  * makes processCorners take the reciprocal itself while it stages a splat -- the same expression on the same value, so the
  * field is bit-identical.  For callers whose splats stay resident over several builds.  Default 1: the reference's
@@ -174,9 +190,9 @@ int mlsgpu_hip_mls_enqueue(mlsgpu_mls *mls, float *dField, uint64_t pitch, uint6
                            const mlsgpu_swathe *swathe);
 /* Fills *gen so the functor can be passed to mlsgpu_hip_marching_generate (alignment = wgs = {8,8,8}). */
 int mlsgpu_hip_mls_generator(mlsgpu_mls *mls, mlsgpu_generator *gen);
-/* Selects the kernel variant: 0 = sub-block culled, 1 = basic list walk (the reference's structure),
- * 2 = sub-block culled with per-lane hit lists, 3 = sub-block culled with per-lane hit masks, 4 = as 3 with one splat
- * stream per 2x2x2 cube of corners (the default: fastest on both BASELINE clouds).  All give bit-identical results. */
+/* Selects the kernel: 4 = the default (sub-block culling + one splat stream per 2x2x2 cube of corners), 1 = the
+ * reference's structure (every corner walks every listed splat), kept for A/B.  Bit-identical results.  Other values are
+ * MLSGPU_ERR_INVALID (0, 2 and 3 were intermediate designs of earlier rounds). */
 int mlsgpu_hip_mls_set_variant(mlsgpu_mls *mls, int variant);
 /* Measurement aid: with a non-NULL device array of 3 uint64 the next enqueues run an instrumented kernel that
  * adds [0] listed splats (Sigma L of SURVEY 8d), [1] (corner, splat) distance tests executed, [2] hits (H).
@@ -227,6 +243,27 @@ int mlsgpu_hip_mesh_checksum(mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh, uint64_t 
 /* ScaleBiasFilter, src/mesh_filter.cpp:69-113 + kernels/scale_bias.cl:33-41: in place. */
 int mlsgpu_hip_scale_bias(mlsgpu_ctx *ctx, const mlsgpu_mesh *mesh, float scale, float bx, float by, float bz);
 
+/* The MlsFunctor behind a generator made by mlsgpu_hip_mls_generator, or NULL for any other generator. */
+mlsgpu_mls *mlsgpu_hip_mls_of_generator(const mlsgpu_generator *gen);
+/* kernel variant, work counters and boundary limit of `src` for `dst` (same shape) */
+int mlsgpu_hip_mls_copy_settings(mlsgpu_mls *dst, const mlsgpu_mls *src);
+/* MlsFunctor::enqueue (mlsgpu_hip_mls_enqueue) for `count` buckets in ONE launch: functor k fills dFields[k] (pitches[k]
+ * floats per row, fieldRows[k] rows -- NULL: unchecked) for swathes[k].  The functors share a context, the shape and the
+ * kernel variant. */
+int mlsgpu_hip_mls_enqueue_batch(mlsgpu_mls *const *mls, float *const *dFields, const uint64_t *pitches,
+                                 const uint64_t *fieldRows, const mlsgpu_swathe *swathes, uint32_t count);
+
+/* Output functor of a batch: as mlsgpu_output_fn, with the index of the bucket the mesh belongs to. */
+typedef int (*mlsgpu_batch_output_fn)(void *user, uint32_t index, void *stream, const mlsgpu_mesh *mesh);
+/* Marching::generate (src/marching.cpp:745-824) for `count` buckets in lock-step: marchings[k] (distinct objects of one
+ * context) takes generators[k], sizes[3k..] and keyOffsets[3k..]; one set of launches with a bucket dimension, the swathe
+ * totals and the welded counts of all buckets read back together.  Per bucket the meshes are those of
+ * mlsgpu_hip_marching_generate, bit for bit, delivered bucket by bucket in order.  Buckets that need several swathes, or
+ * whose swathe overflows the mesh memory, take the one-bucket path behind the shared launches.  Blocks. */
+int mlsgpu_hip_marching_generate_batch(mlsgpu_marching *const *marchings, const mlsgpu_generator *generators, uint32_t count,
+                                       mlsgpu_batch_output_fn output, void *outputUser,
+                                       const uint32_t *sizes, const uint32_t *keyOffsets);
+
 /* ---- DeviceWorkerGroupBase::Worker (src/workers.cpp:207-286): tree + MlsFunctor + Marching + ScaleBias ---- */
 typedef struct mlsgpu_worker_config
 {
@@ -250,6 +287,25 @@ uint64_t mlsgpu_hip_worker_resource_usage(const mlsgpu_worker_config *cfg);
 int mlsgpu_hip_worker_process(mlsgpu_worker *w, mlsgpu_splat *dSplats, uint64_t firstSplat, uint64_t numSplats,
                               const int32_t lowExtent[3], const uint32_t numVertices[3],
                               mlsgpu_output_fn output, void *outputUser);
+/* DeviceWorkerGroup::SubItem (src/workers.h:161-168): one bucket of a WorkItem whose splats share a device buffer */
+typedef struct mlsgpu_subitem
+{
+    uint64_t firstSplat, numSplats;
+    int32_t lowExtent[3];
+    uint32_t numVertices[3];
+} mlsgpu_subitem;
+/* Lanes: how many buckets the worker takes through the path in lock-step (1 .. MLSGPU_MAX_BATCH; default 1).  Each lane
+ * owns a tree, a distance field, a lattice and a mesh arena (mlsgpu_hip_worker_resource_usage bytes per lane). */
+int mlsgpu_hip_worker_set_batch(mlsgpu_worker *w, uint32_t lanes);
+uint32_t mlsgpu_hip_worker_batch(const mlsgpu_worker *w);
+/* The loop over the SubItems of a WorkItem (src/workers.cpp:232-286) with the buckets taken `lanes` at a time: per group
+ * one set of launches (octree build, processCorners, marching, each with a bucket dimension) and three host decisions.
+ * Every bucket's meshes equal mlsgpu_hip_worker_process's bit for bit; `output` receives them bucket by bucket, in order,
+ * with the bucket's index in `items`. */
+int mlsgpu_hip_worker_process_batch(mlsgpu_worker *w, mlsgpu_splat *dSplats, const mlsgpu_subitem *items, uint32_t numItems,
+                                    mlsgpu_batch_output_fn output, void *outputUser);
+mlsgpu_tree *mlsgpu_hip_worker_lane_tree(mlsgpu_worker *w, uint32_t lane);
+mlsgpu_marching *mlsgpu_hip_worker_lane_marching(mlsgpu_worker *w, uint32_t lane);
 /* keep = 1: the worker does not modify dSplats (non-mutating tree build + raw-radius processCorners, see
  * mlsgpu_hip_tree_set_mutate): resident splats can be processed again without being restored.  Default 0. */
 int mlsgpu_hip_worker_set_keep_splats(mlsgpu_worker *w, int keep);

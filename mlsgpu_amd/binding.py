@@ -74,6 +74,23 @@ class WorkerConfig(C.Structure):
                 ("gridOrigin", C.c_float * 3)]
 
 
+class SubItem(C.Structure):
+    """mlsgpu_subitem: DeviceWorkerGroup::SubItem, src/workers.h:161-168."""
+    _fields_ = [("firstSplat", C.c_uint64), ("numSplats", C.c_uint64), ("lowExtent", C.c_int32 * 3),
+                ("numVertices", C.c_uint32 * 3)]
+
+
+class TreeBuild(C.Structure):
+    """mlsgpu_tree_build: the arguments of SplatTreeCL::enqueueBuild for one bucket of a batch."""
+    _fields_ = [("dSplats", C.c_void_p), ("firstSplat", C.c_uint64), ("numSplats", C.c_uint64), ("size", C.c_uint32 * 3),
+                ("offset", C.c_int32 * 3)]
+
+
+MAX_BATCH = 8
+
+BATCH_OUTPUT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.POINTER(Mesh))
+
+
 class GridStruct(C.Structure):
     _fields_ = [("reference", C.c_float * 3), ("spacing", C.c_float), ("extents", C.c_int32 * 6)]
 
@@ -185,6 +202,16 @@ def lib():
     sig("mlsgpu_hip_worker_destroy", None, vp)
     sig("mlsgpu_hip_worker_resource_usage", u64, P(WorkerConfig))
     sig("mlsgpu_hip_worker_process", C.c_int, vp, vp, u64, u64, vp, vp, OUTPUT_FN, vp)
+    sig("mlsgpu_hip_worker_set_batch", C.c_int, vp, u32)
+    sig("mlsgpu_hip_worker_batch", u32, vp)
+    sig("mlsgpu_hip_worker_process_batch", C.c_int, vp, vp, P(SubItem), u32, BATCH_OUTPUT_FN, vp)
+    sig("mlsgpu_hip_worker_lane_tree", vp, vp, u32)
+    sig("mlsgpu_hip_worker_lane_marching", vp, vp, u32)
+    sig("mlsgpu_hip_tree_build_batch", C.c_int, P(vp), P(TreeBuild), u32, u32)
+    sig("mlsgpu_hip_mls_of_generator", vp, P(Generator))
+    sig("mlsgpu_hip_mls_copy_settings", C.c_int, vp, vp)
+    sig("mlsgpu_hip_mls_enqueue_batch", C.c_int, P(vp), P(vp), P(u64), P(u64), P(Swathe), u32)
+    sig("mlsgpu_hip_marching_generate_batch", C.c_int, P(vp), P(Generator), u32, BATCH_OUTPUT_FN, vp, vp, vp)
     sig("mlsgpu_hip_worker_tree", vp, vp)
     sig("mlsgpu_hip_worker_mls", vp, vp)
     sig("mlsgpu_hip_worker_marching", vp, vp)
@@ -1064,6 +1091,34 @@ class Worker:
         check(rc)
         return col.batches if isinstance(col, MeshCollector) else col
 
+    def set_batch(self, lanes):
+        """Room for `lanes` buckets in lock-step (process_batch); every lane owns a tree, a field and a mesh arena."""
+        check(lib().mlsgpu_hip_worker_set_batch(self.h, lanes))
+
+    def process_batch(self, splats, items, collector=None):
+        """The SubItems of a WorkItem (src/workers.cpp:232-286) through mlsgpu_hip_worker_process_batch: `items` is a list
+        of (first_splat, num_splats, low_extent, num_vertices) -- or objects with .first / .count / .low / .num_vertices -- in
+        the device buffer `splats`.  Without a collector every bucket's ship-outs are read back: a list (per bucket) of
+        lists of batches; with one, every mesh goes to it in bucket order and it is returned."""
+        arr = (SubItem * max(len(items), 1))()
+        for i, it in enumerate(items):
+            first, count, low, nv = (it if isinstance(it, (tuple, list)) else (it.first, it.count, it.low, it.num_vertices))
+            arr[i].firstSplat, arr[i].numSplats = first, count
+            for a in range(3):
+                arr[i].lowExtent[a] = int(low[a])
+                arr[i].numVertices[a] = int(nv[a])
+        cols = [collector] * len(items) if collector is not None else [MeshCollector(self.ctx) for _ in items]
+
+        def cb(user, index, stream, meshp):
+            return cols[index].cb(user, stream, meshp)
+        fn = BATCH_OUTPUT_FN(cb)
+        rc = lib().mlsgpu_hip_worker_process_batch(self.h, splats.ptr, arr, len(items), fn, None)
+        for c in cols:
+            if getattr(c, "error", None) is not None:
+                raise c.error
+        check(rc)
+        return collector if collector is not None else [c.batches for c in cols]
+
     def set_mls_variant(self, variant):
         check(lib().mlsgpu_hip_mls_set_variant(lib().mlsgpu_hip_worker_mls(self.h), variant))
 
@@ -1075,9 +1130,14 @@ class Worker:
         """counters: DeviceBuffer of 3 uint64 (or None): see mlsgpu_hip_mls_set_stats."""
         check(lib().mlsgpu_hip_mls_set_stats(lib().mlsgpu_hip_worker_mls(self.h), counters.ptr if counters else None))
 
-    def marching_counters(self):
+    def marching_counters(self, lane=None):
+        """Marching's counters: of one lane, or (default) summed over the worker's lanes."""
+        n = lib().mlsgpu_hip_worker_batch(self.h)
         out = np.zeros(8, np.uint64)
-        check(lib().mlsgpu_hip_marching_counters(lib().mlsgpu_hip_worker_marching(self.h), _p(out)))
+        for k in (range(n) if lane is None else [lane]):
+            one = np.zeros(8, np.uint64)
+            check(lib().mlsgpu_hip_marching_counters(lib().mlsgpu_hip_worker_lane_marching(self.h, k), _p(one)))
+            out += one
         names = ["overflows", "shipouts", "nonempty", "occupied", "unwelded", "indices", "welded", "external"]
         return dict(zip(names, [int(x) for x in out]))
 
@@ -1086,8 +1146,8 @@ class Worker:
         check(lib().mlsgpu_hip_tree_num_entries(lib().mlsgpu_hip_worker_tree(self.h), C.byref(n)))
         return n.value
 
-    def tree_arrays(self):
-        t = lib().mlsgpu_hip_worker_tree(self.h)
+    def tree_arrays(self, lane=0):
+        t = lib().mlsgpu_hip_worker_lane_tree(self.h, lane)
         commands = download_ptr(self.ctx, lib().mlsgpu_hip_tree_commands(t), np.int32,
                                 lib().mlsgpu_hip_tree_commands_size(t))
         start = download_ptr(self.ctx, lib().mlsgpu_hip_tree_start(t), np.int32, lib().mlsgpu_hip_tree_start_size(t))

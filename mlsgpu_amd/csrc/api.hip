@@ -108,6 +108,16 @@ __global__ void mailboxPublishKernel(const uint32_t *src, uint32_t words, uint32
     if (threadIdx.x == 0)
         __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+__global__ void mailboxGatherKernel(Lanes<const uint32_t *> srcs, uint32_t count, uint32_t wordsEach, uint32_t *box, uint32_t seq)
+{
+    /* one wave: word t comes from source t / wordsEach */
+    const uint32_t t = threadIdx.x;
+    if (t < count * wordsEach)
+        __hip_atomic_store(box + 1 + t, srcs.a[t / wordsEach][t % wordsEach], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    if (t == 0)
+        __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 } // namespace
 
 int mlsgpu::HostMailbox::create()
@@ -139,6 +149,18 @@ int mlsgpu::HostMailbox::publish(hipStream_t stream, const void *src, uint32_t w
     REQUIRE(host != nullptr && words <= WORDS, MLSGPU_ERR_INVALID);
     reserve();
     hipLaunchKernelGGL(mailboxPublishKernel, dim3(1), dim3(64), 0, stream, static_cast<const uint32_t *>(src), words, dev, seq);
+    HIP_CHECK(hipGetLastError());
+    return MLSGPU_OK;
+}
+
+int mlsgpu::HostMailbox::publishGather(hipStream_t stream, const void *const *srcs, uint32_t count, uint32_t wordsEach)
+{
+    REQUIRE(host != nullptr && count >= 1 && count <= MAX_LANES && count * wordsEach <= WORDS, MLSGPU_ERR_INVALID);
+    Lanes<const uint32_t *> s;
+    for (uint32_t k = 0; k < MAX_LANES; k++)
+        s.a[k] = static_cast<const uint32_t *>(srcs[k < count ? k : 0]);
+    reserve();
+    hipLaunchKernelGGL(mailboxGatherKernel, dim3(1), dim3(64), 0, stream, s, count, wordsEach, dev, seq);
     HIP_CHECK(hipGetLastError());
     return MLSGPU_OK;
 }
@@ -370,15 +392,25 @@ MLSGPU_API uint32_t mlsgpu_hip_compute_max_swathe(uint32_t yMax, uint32_t y, uin
     return chunks * zAlign;
 }
 
+/* one bucket's worth of objects; a worker has one LANE per bucket it can take through the path in lock-step */
+struct WorkerLane
+{
+    mlsgpu_tree *tree = nullptr;
+    mlsgpu_mls *mls = nullptr;
+    mlsgpu_marching *marching = nullptr;
+};
+
 struct mlsgpu_worker
 {
     mlsgpu_ctx *ctx = nullptr;
     mlsgpu_worker_config cfg;
-    mlsgpu_tree *tree = nullptr;
-    mlsgpu_mls *mls = nullptr;
-    mlsgpu_marching *marching = nullptr;
+    std::vector<WorkerLane> lanes;          /* lanes[0] is the worker of the reference */
+    bool keepSplats = false;
     mlsgpu_output_fn userOutput = nullptr;
     void *userOutputData = nullptr;
+    mlsgpu_batch_output_fn batchOutput = nullptr;
+    void *batchOutputData = nullptr;
+    uint32_t batchBase = 0;                 /* index of the first bucket of the group that is being processed */
 };
 
 static void resolveConfig(mlsgpu_worker_config &c)
@@ -395,13 +427,48 @@ static void resolveConfig(mlsgpu_worker_config &c)
 
 MLSGPU_API uint64_t mlsgpu_hip_worker_resource_usage(const mlsgpu_worker_config *cfgIn)
 {
-    /* DeviceWorkerGroup::resourceUsage, src/workers.cpp:184-205 (per worker, without the item pool) */
+    /* DeviceWorkerGroup::resourceUsage, src/workers.cpp:184-205 (per worker lane, without the item pool) */
     mlsgpu_worker_config c = *cfgIn;
     resolveConfig(c);
     const uint32_t wgs[3] = {8, 8, 8};
     const uint32_t block = c.maxCells + 1;
     return mlsgpu_hip_marching_resource_usage(block, block, roundUp(block, 8), c.maxSwathe, c.meshMemory, wgs)
         + mlsgpu_hip_tree_resource_usage(c.levels, c.maxBucketSplats);
+}
+
+static void destroyLane(WorkerLane &l)
+{
+    mlsgpu_hip_marching_destroy(l.marching);
+    mlsgpu_hip_mls_destroy(l.mls);
+    mlsgpu_hip_tree_destroy(l.tree);
+    l = WorkerLane();
+}
+
+/* the objects DeviceWorkerGroupBase::Worker's constructor makes (src/workers.cpp:207-225) */
+static int createLane(mlsgpu_worker *w, WorkerLane *out)
+{
+    const mlsgpu_worker_config &c = w->cfg;
+    mlsgpu_ctx *ctx = w->ctx;
+    WorkerLane l;
+    const uint32_t wgs[3] = {8, 8, 8};
+    const uint32_t block = c.maxCells + 1;
+    int rc = mlsgpu_hip_tree_create(ctx, c.levels, c.maxBucketSplats, &l.tree);
+    if (rc == MLSGPU_OK) rc = mlsgpu_hip_mls_create(ctx, c.shape, &l.mls);
+    if (rc == MLSGPU_OK) rc = mlsgpu_hip_mls_set_boundary_limit(l.mls, c.boundaryLimit);
+    /* depth padded to the MLS block size so that the default maxSwathe (whole bucket) is not rounded DOWN
+     * to a multiple of 8 below the bucket depth (src/marching.cpp:373), which would cost a second swathe */
+    if (rc == MLSGPU_OK) rc = mlsgpu_hip_marching_create(ctx, block, block, roundUp(block, 8), c.maxSwathe, c.meshMemory, wgs, &l.marching);
+    if (rc == MLSGPU_OK)
+        rc = mlsgpu_hip_marching_set_vertex_transform(l.marching, 1, c.gridSpacing, c.gridOrigin[0], c.gridOrigin[1], c.gridOrigin[2]);
+    if (rc == MLSGPU_OK) rc = mlsgpu_hip_tree_set_mutate(l.tree, w->keepSplats ? 0 : 1);
+    if (rc != MLSGPU_OK)
+    {
+        const std::string text = mlsgpu::lastError;     /* the destructors below do not touch it, but be explicit */
+        destroyLane(l);
+        return setError(rc, "%s", text.c_str());
+    }
+    *out = l;
+    return MLSGPU_OK;
 }
 
 MLSGPU_API int mlsgpu_hip_worker_create(mlsgpu_ctx *ctx, const mlsgpu_worker_config *cfgIn, mlsgpu_worker **out)
@@ -418,21 +485,14 @@ MLSGPU_API int mlsgpu_hip_worker_create(mlsgpu_ctx *ctx, const mlsgpu_worker_con
         rc = setError(MLSGPU_ERR_INVALID, "worker: need subsampling >= 3, 1 <= levels <= 10, subsampling + levels <= 14");
     if (rc == MLSGPU_OK && c.maxCells + 1 > (1u << (c.levels + c.subsampling - 1)))
         rc = setError(MLSGPU_ERR_LENGTH, "worker: maxCells + 1 exceeds the octree side 2^(levels+subsampling-1)");
-    const uint32_t wgs[3] = {8, 8, 8};
-    const uint32_t block = c.maxCells + 1;
-    if (rc == MLSGPU_OK) rc = mlsgpu_hip_tree_create(ctx, c.levels, c.maxBucketSplats, &w->tree);
-    if (rc == MLSGPU_OK) rc = mlsgpu_hip_mls_create(ctx, c.shape, &w->mls);
-    if (rc == MLSGPU_OK) rc = mlsgpu_hip_mls_set_boundary_limit(w->mls, c.boundaryLimit);
-    /* depth padded to the MLS block size so that the default maxSwathe (whole bucket) is not rounded DOWN
-     * to a multiple of 8 below the bucket depth (src/marching.cpp:373), which would cost a second swathe */
-    if (rc == MLSGPU_OK) rc = mlsgpu_hip_marching_create(ctx, block, block, roundUp(block, 8), c.maxSwathe, c.meshMemory, wgs, &w->marching);
-    if (rc == MLSGPU_OK)
-        rc = mlsgpu_hip_marching_set_vertex_transform(w->marching, 1, c.gridSpacing, c.gridOrigin[0], c.gridOrigin[1], c.gridOrigin[2]);
+    WorkerLane lane;
+    if (rc == MLSGPU_OK) rc = createLane(w, &lane);
     if (rc != MLSGPU_OK)
     {
         mlsgpu_hip_worker_destroy(w);
         return rc;
     }
+    w->lanes.push_back(lane);
     *out = w;
     return MLSGPU_OK;
 }
@@ -441,21 +501,45 @@ MLSGPU_API void mlsgpu_hip_worker_destroy(mlsgpu_worker *w)
 {
     if (!w)
         return;
-    mlsgpu_hip_marching_destroy(w->marching);
-    mlsgpu_hip_mls_destroy(w->mls);
-    mlsgpu_hip_tree_destroy(w->tree);
+    for (WorkerLane &l : w->lanes)
+        destroyLane(l);
     delete w;
 }
 
+/* Room for `lanes` buckets in lock-step (mlsgpu_hip_worker_process_batch): every lane has its own tree, field, lattice and
+ * mesh arena -- mlsgpu_hip_worker_resource_usage bytes each; 288 GB of HBM hold many.  Lanes are only added. */
+MLSGPU_API int mlsgpu_hip_worker_set_batch(mlsgpu_worker *w, uint32_t lanes)
+{
+    REQUIRE(w != nullptr && !w->lanes.empty(), MLSGPU_ERR_INVALID);
+    REQUIRE(lanes >= 1 && lanes <= MLSGPU_MAX_BATCH, MLSGPU_ERR_LENGTH);
+    HIP_CHECK(hipSetDevice(w->ctx->device));
+    while (w->lanes.size() < lanes)
+    {
+        WorkerLane l;
+        PROPAGATE(createLane(w, &l));
+        w->lanes.push_back(l);
+    }
+    return MLSGPU_OK;
+}
+
+MLSGPU_API uint32_t mlsgpu_hip_worker_batch(const mlsgpu_worker *w) { return w ? (uint32_t) w->lanes.size() : 0; }
+
 /* MeshFilterChain::operator() with the one ScaleBiasFilter the worker installs
- * (src/workers.cpp:226-230, src/mesh_filter.cpp:45-66): filter, then the user's output functor. */
+ * (src/workers.cpp:226-230, src/mesh_filter.cpp:45-66): filter, then the user's output functor.
+ * (Scale / bias is folded into Marching's vertex emission, mlsgpu_hip_marching_set_vertex_transform.) */
 static int workerOutput(void *user, void *stream, const mlsgpu_mesh *mesh)
 {
     mlsgpu_worker *w = static_cast<mlsgpu_worker *>(user);
-    const mlsgpu_worker_config &c = w->cfg;
-    (void) c;   /* scale/bias is folded into Marching's vertex emission (mlsgpu_hip_marching_set_vertex_transform) */
     if (w->userOutput)
         return w->userOutput(w->userOutputData, stream, mesh);
+    return 0;
+}
+
+static int workerBatchOutput(void *user, uint32_t index, void *stream, const mlsgpu_mesh *mesh)
+{
+    mlsgpu_worker *w = static_cast<mlsgpu_worker *>(user);
+    if (w->batchOutput)
+        return w->batchOutput(w->batchOutputData, w->batchBase + index, stream, mesh);
     return 0;
 }
 
@@ -473,17 +557,80 @@ MLSGPU_API int mlsgpu_hip_worker_process(mlsgpu_worker *w, mlsgpu_splat *dSplats
         size[i] = numVertices[i];
         expanded[i] = roundUp(size[i], 8);
     }
+    WorkerLane &l = w->lanes[0];
     w->userOutput = output;
     w->userOutputData = outputUser;
     int pend = -1;
     if (w->ctx->timing) pend = w->ctx->beginTiming(w->ctx->statId("device.compute"));
-    PROPAGATE(mlsgpu_hip_tree_build(w->tree, dSplats, firstSplat, numSplats, expanded, lowExtent, w->cfg.subsampling));
-    PROPAGATE(mlsgpu_hip_mls_set(w->mls, lowExtent, w->tree, w->cfg.subsampling));
+    PROPAGATE(mlsgpu_hip_tree_build(l.tree, dSplats, firstSplat, numSplats, expanded, lowExtent, w->cfg.subsampling));
+    PROPAGATE(mlsgpu_hip_mls_set(l.mls, lowExtent, l.tree, w->cfg.subsampling));
     mlsgpu_generator gen;
-    PROPAGATE(mlsgpu_hip_mls_generator(w->mls, &gen));
-    PROPAGATE(mlsgpu_hip_marching_generate(w->marching, &gen, workerOutput, w, size, keyOffset));
+    PROPAGATE(mlsgpu_hip_mls_generator(l.mls, &gen));
+    PROPAGATE(mlsgpu_hip_marching_generate(l.marching, &gen, workerOutput, w, size, keyOffset));
     if (pend >= 0) w->ctx->endTiming(pend);
-    mlsgpu_hip_tree_clear_splats(w->tree);
+    mlsgpu_hip_tree_clear_splats(l.tree);
+    return MLSGPU_OK;
+}
+
+/*
+ * The SubItems of a WorkItem (src/workers.h:148-181; the reference's worker walks them one by one, src/workers.cpp:232-286)
+ * through the path in groups of as many buckets as the worker has lanes (mlsgpu_hip_worker_set_batch): per group ONE set of
+ * launches -- octree build, processCorners, marching -- with a bucket dimension, and three host decisions instead of three
+ * per bucket.  Every bucket's meshes are those of mlsgpu_hip_worker_process, bit for bit; `output` gets them bucket by
+ * bucket, in order, with the bucket's index.
+ */
+MLSGPU_API int mlsgpu_hip_worker_process_batch(mlsgpu_worker *w, mlsgpu_splat *dSplats, const mlsgpu_subitem *items,
+                                               uint32_t numItems, mlsgpu_batch_output_fn output, void *outputUser)
+{
+    REQUIRE(w != nullptr && dSplats != nullptr && (items != nullptr || numItems == 0), MLSGPU_ERR_INVALID);
+    for (uint32_t i = 0; i < numItems; i++)
+        for (int a = 0; a < 3; a++)
+            REQUIRE(items[i].lowExtent[a] >= 0, MLSGPU_ERR_INVALID);     /* keyOffset is cl_uint in the reference */
+    w->batchOutput = output;
+    w->batchOutputData = outputUser;
+    const uint32_t width = (uint32_t) w->lanes.size();
+    for (uint32_t base = 0; base < numItems; base += width)
+    {
+        const uint32_t count = std::min(width, numItems - base);
+        w->batchBase = base;
+        mlsgpu_tree *trees[MLSGPU_MAX_BATCH];
+        mlsgpu_marching *marchings[MLSGPU_MAX_BATCH];
+        mlsgpu_tree_build builds[MLSGPU_MAX_BATCH];
+        mlsgpu_generator gens[MLSGPU_MAX_BATCH];
+        uint32_t sizes[3 * MLSGPU_MAX_BATCH], keyOffsets[3 * MLSGPU_MAX_BATCH];
+        for (uint32_t k = 0; k < count; k++)
+        {
+            const mlsgpu_subitem &it = items[base + k];
+            WorkerLane &l = w->lanes[k];
+            trees[k] = l.tree;
+            marchings[k] = l.marching;
+            builds[k].dSplats = dSplats;
+            builds[k].firstSplat = it.firstSplat;
+            builds[k].numSplats = it.numSplats;
+            for (int a = 0; a < 3; a++)
+            {
+                /* src/workers.cpp:237-261 */
+                keyOffsets[3 * k + a] = (uint32_t) it.lowExtent[a];
+                sizes[3 * k + a] = it.numVertices[a];
+                builds[k].size[a] = roundUp(it.numVertices[a], 8);
+                builds[k].offset[a] = it.lowExtent[a];
+            }
+            if (k > 0)
+                PROPAGATE(mlsgpu_hip_mls_copy_settings(l.mls, w->lanes[0].mls));
+        }
+        int pend = -1;
+        if (w->ctx->timing) pend = w->ctx->beginTiming(w->ctx->statId("device.compute"));
+        PROPAGATE(mlsgpu_hip_tree_build_batch(trees, builds, count, w->cfg.subsampling));
+        for (uint32_t k = 0; k < count; k++)
+        {
+            PROPAGATE(mlsgpu_hip_mls_set(w->lanes[k].mls, items[base + k].lowExtent, w->lanes[k].tree, w->cfg.subsampling));
+            PROPAGATE(mlsgpu_hip_mls_generator(w->lanes[k].mls, &gens[k]));
+        }
+        PROPAGATE(mlsgpu_hip_marching_generate_batch(marchings, gens, count, workerBatchOutput, w, sizes, keyOffsets));
+        if (pend >= 0) w->ctx->endTiming(pend);
+        for (uint32_t k = 0; k < count; k++)
+            mlsgpu_hip_tree_clear_splats(w->lanes[k].tree);
+    }
     return MLSGPU_OK;
 }
 
@@ -494,9 +641,21 @@ MLSGPU_API int mlsgpu_hip_worker_process(mlsgpu_worker *w, mlsgpu_splat *dSplats
 MLSGPU_API int mlsgpu_hip_worker_set_keep_splats(mlsgpu_worker *w, int keep)
 {
     REQUIRE(w != nullptr, MLSGPU_ERR_INVALID);
-    return mlsgpu_hip_tree_set_mutate(w->tree, keep ? 0 : 1);
+    w->keepSplats = keep != 0;
+    for (WorkerLane &l : w->lanes)
+        PROPAGATE(mlsgpu_hip_tree_set_mutate(l.tree, keep ? 0 : 1));
+    return MLSGPU_OK;
 }
 
-MLSGPU_API mlsgpu_tree *mlsgpu_hip_worker_tree(mlsgpu_worker *w) { return w ? w->tree : nullptr; }
-MLSGPU_API mlsgpu_mls *mlsgpu_hip_worker_mls(mlsgpu_worker *w) { return w ? w->mls : nullptr; }
-MLSGPU_API mlsgpu_marching *mlsgpu_hip_worker_marching(mlsgpu_worker *w) { return w ? w->marching : nullptr; }
+/* the objects of lane 0: the reference's worker */
+MLSGPU_API mlsgpu_tree *mlsgpu_hip_worker_tree(mlsgpu_worker *w) { return w ? w->lanes[0].tree : nullptr; }
+MLSGPU_API mlsgpu_mls *mlsgpu_hip_worker_mls(mlsgpu_worker *w) { return w ? w->lanes[0].mls : nullptr; }
+MLSGPU_API mlsgpu_marching *mlsgpu_hip_worker_marching(mlsgpu_worker *w) { return w ? w->lanes[0].marching : nullptr; }
+MLSGPU_API mlsgpu_tree *mlsgpu_hip_worker_lane_tree(mlsgpu_worker *w, uint32_t lane)
+{
+    return w && lane < w->lanes.size() ? w->lanes[lane].tree : nullptr;
+}
+MLSGPU_API mlsgpu_marching *mlsgpu_hip_worker_lane_marching(mlsgpu_worker *w, uint32_t lane)
+{
+    return w && lane < w->lanes.size() ? w->lanes[lane].marching : nullptr;
+}

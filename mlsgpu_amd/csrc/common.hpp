@@ -126,7 +126,7 @@ namespace mlsgpu
  */
 struct HostMailbox
 {
-    enum { WORDS = 12 };
+    enum { WORDS = 64 };            /* six words per bucket of a batch (MAX_LANES buckets) and room to spare */
     uint32_t *host = nullptr;       /* [0] = sequence number of the last publication, [1 .. WORDS] = payload */
     uint32_t *dev = nullptr;        /* the same memory as the device sees it */
     uint32_t seq = 0;
@@ -144,6 +144,8 @@ struct HostMailbox
     }
     /* enqueue: copy `words` 32-bit words from device memory `src` to the mailbox (on `stream`) */
     int publish(hipStream_t stream, const void *src, uint32_t words);
+    /* the same for a batch: `wordsEach` words from each of `count` device addresses, laid out one source after the other */
+    int publishGather(hipStream_t stream, const void *const *srcs, uint32_t count, uint32_t wordsEach);
     /* block until the last publication has landed; the payload is host[1 ..] */
     int wait(hipStream_t stream);
     const uint32_t *payload() const { return host + 1; }
@@ -166,6 +168,20 @@ struct HostMailbox
         if (pend__ >= 0) (ctx)->endTiming(pend__);                                            \
         HIP_CHECK(hipGetLastError());                                                         \
     } while (0)
+
+/*
+ * Batches.  A device worker may take several buckets (the SubItems of a WorkItem, src/workers.h:148-181) through the path
+ * in lock-step: every kernel has a bucket dimension -- blockIdx.y selects the LANE, whose arguments are one element of an
+ * array passed by value in the kernel-argument segment (read through the scalar cache, no upload of a parameter block),
+ * grid.x covers the largest lane and the workgroups beyond a smaller lane's own extent leave at once.  A single bucket is a
+ * batch of one: same kernels, same results.
+ */
+enum { MAX_LANES = MLSGPU_MAX_BATCH };
+template<typename A>
+struct Lanes
+{
+    A a[MAX_LANES];
+};
 
 static inline uint32_t divUp(uint64_t a, uint64_t b) { return (uint32_t) ((a + b - 1) / b); }
 static inline uint32_t roundUp(uint32_t a, uint32_t b) { return (a + b - 1) / b * b; }
@@ -207,6 +223,13 @@ __device__ __forceinline__ uint32_t waveInclusiveScan(uint32_t v)
     v += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, DPP_ROW_BCAST31, 0xc, 0xf, false);   /* rows 2, 3 += rows 0 + 1 */
     return v;
 }
+
+/* The reductions below read lane 63 of the scan, and the shifts use the gfx9 wave_shr / wave_shl DPP controls: they need a
+ * FULL, CONVERGENT wave64 (every caller in this library is one; an inactive lane 63 would hand back stale register
+ * contents, where a ds_bpermute version reads zero from inactive lanes). */
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "the wave helpers are written for gfx950 (wave64, gfx9 DPP controls)"
+#endif
 
 /* the sum over the wave, in every lane */
 __device__ __forceinline__ uint32_t waveSum(uint32_t v)

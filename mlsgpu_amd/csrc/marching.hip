@@ -242,13 +242,27 @@ struct CodeView
 /* One wave per row of cells (fixed y, z): code bytes plus the row's (occupied, vertices, indices) totals.
  * The row totals feed the swathe totals, the per-slice histogram and, in the lattice weld, each row's first
  * cell / index slot -- a 256x smaller scan than one over cells. */
-__global__ __launch_bounds__(256) void cellCodeKernel(uint8_t *codes, U3 *rowCounts, FieldView F, uint32_t cw, uint32_t ch,
-                                                       uint32_t zFirst, uint32_t numRows, const uchar2 *countTable)
+struct CellCodeArgs
 {
+    uint8_t *codes;
+    U3 *rowCounts;
+    FieldView F;
+    uint32_t cw, ch, zFirst, numRows;
+    const uchar2 *countTable;
+};
+
+__global__ __launch_bounds__(256) void cellCodeKernel(Lanes<CellCodeArgs> lanes)
+{
+    const CellCodeArgs &A = lanes.a[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= numRows)
+    if (row >= A.numRows)
         return;
+    uint8_t *const codes = A.codes;
+    U3 *const rowCounts = A.rowCounts;
+    const FieldView &F = A.F;
+    const uint32_t cw = A.cw, ch = A.ch, zFirst = A.zFirst;
+    const uchar2 *const countTable = A.countTable;
     const uint32_t y = row % ch, z = row / ch + zFirst;
     U3 sum{0u, 0u, 0u};
     for (uint32_t x0 = 0; x0 < cw; x0 += 64)
@@ -350,14 +364,28 @@ __global__ __launch_bounds__(64) void sliceHistogramKernel(const U3 *rowCounts, 
 /* Lattice weld: the occupied cells of the batch in cell-linear order with each cell's first index slot.
  * One wave per row of cells; a row's first cell / index slot come from the exclusive scan of the row totals,
  * positions inside the row from a ballot rank and a wave scan. */
-__global__ __launch_bounds__(256) void compactRowCellsKernel(const uint8_t *codes, uint32_t cw, uint32_t ch, uint32_t z0,
-                                                              uint32_t zFirst, const U3 *rowStarts, const uchar2 *countTable,
-                                                              uint2 *cells, uint2 *viStart, uint32_t numRows)
+struct CompactRowCellsArgs
 {
+    const uint8_t *codes;
+    uint32_t cw, ch, z0, zFirst;
+    const U3 *rowStarts;
+    const uchar2 *countTable;
+    uint2 *cells, *viStart;
+    uint32_t numRows;
+};
+
+__global__ __launch_bounds__(256) void compactRowCellsKernel(Lanes<CompactRowCellsArgs> lanes)
+{
+    const CompactRowCellsArgs &A = lanes.a[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r >= numRows)
+    if (r >= A.numRows)
         return;
+    const uint8_t *const codes = A.codes;
+    const uint32_t cw = A.cw, ch = A.ch, z0 = A.z0, zFirst = A.zFirst;
+    const U3 *const rowStarts = A.rowStarts;
+    const uchar2 *const countTable = A.countTable;
+    uint2 *const cells = A.cells, *const viStart = A.viStart;
     const uint32_t y = r % ch, z = r / ch + zFirst;
     const uint8_t *row = codes + ((uint64_t) (z - z0) * ch + y) * cw;
     const U3 start = rowStarts[r];
@@ -684,13 +712,25 @@ __device__ __forceinline__ uint32_t edgeBit(uint32_t code, uint32_t a, uint32_t 
  * adjacent cell rows) plus a lane shift for cell x-1.  The seven bits of 64 corners become the rows' words
  * (even/odd x2 interleaved) through two lane permutations and one ballot per word.
  */
-__global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, const U3 *cellRowCounts, uint32_t zCellFirst,
-                                                         uint32_t zCellLast, uint32_t H, uint32_t numCornerRows)
+struct LatticeMaskArgs
 {
+    Lattice L;
+    CodeView C;
+    const U3 *cellRowCounts;
+    uint32_t zCellFirst, zCellLast, H, numCornerRows;
+};
+
+__global__ __launch_bounds__(256) void latticeMaskKernel(Lanes<LatticeMaskArgs> lanes)
+{
+    const LatticeMaskArgs &A = lanes.a[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t cr = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (cr >= numCornerRows)
+    if (cr >= A.numCornerRows)
         return;
+    const Lattice &L = A.L;
+    const CodeView &C = A.C;
+    const U3 *const cellRowCounts = A.cellRowCounts;
+    const uint32_t zCellFirst = A.zCellFirst, zCellLast = A.zCellLast, H = A.H;
     const uint32_t y = cr % H, z = cr / H + zCellFirst;
     const uint32_t W = L.cw + 1;
     /* adjacent cell rows (y - dy, z - dz); a row outside the batch contributes no occupied cell */
@@ -831,11 +871,19 @@ __global__ __launch_bounds__(256) void latticeMaskKernel(Lattice L, CodeView C, 
 
 /* After the scan of the row counts, one thread per word: make the word's prefix an absolute output index and
  * give every word of a class-0/1 row the row's class-2 start and its two column bits. */
-__global__ __launch_bounds__(256) void latticePatchKernel(Lattice L, uint32_t numWords)
+struct LatticePatchArgs
 {
+    Lattice L;
+    uint32_t numWords;
+};
+
+__global__ __launch_bounds__(256) void latticePatchKernel(Lanes<LatticePatchArgs> lanes)
+{
+    const LatticePatchArgs &A = lanes.a[blockIdx.y];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= numWords)
+    if (i >= A.numWords)
         return;
+    const Lattice &L = A.L;
     const uint32_t row = i / L.nw;
     const uint32_t z2 = row / L.rowsPerLayer + L.z2First, y2 = row % L.rowsPerLayer;
     const uint32_t rc = L.rowClass(y2, z2);
@@ -853,14 +901,32 @@ __global__ __launch_bounds__(256) void latticePatchKernel(Lattice L, uint32_t nu
 /* One wave per row: positions (interp, kernels/marching.cl:130-138) and external keys of the existing points.
  * The row's words come through the scalar unit; the field values of up to four words are requested before the
  * first is used (the kernel is bound by memory latency, not bytes). */
-__global__ __launch_bounds__(256) void latticeVerticesKernel(Lattice L, FieldView F, float *outVertices, uint64_t *outKeys,
-                                                             uint32_t gox, uint32_t goy, uint32_t goz,
-                                                             uint64_t keyOffset, VertexTransform X, uint32_t numRows)
+struct LatticeVerticesArgs
 {
+    Lattice L;
+    FieldView F;
+    float *outVertices;
+    uint64_t *outKeys;
+    uint32_t gox, goy, goz;
+    uint64_t keyOffset;
+    VertexTransform X;
+    uint32_t numRows;
+};
+
+__global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVerticesArgs> lanes)
+{
+    const LatticeVerticesArgs &A = lanes.a[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (row >= numRows)
+    if (row >= A.numRows)
         return;
+    const Lattice &L = A.L;
+    const FieldView &F = A.F;
+    float *const outVertices = A.outVertices;
+    uint64_t *const outKeys = A.outKeys;
+    const uint32_t gox = A.gox, goy = A.goy, goz = A.goz;
+    const uint64_t keyOffset = A.keyOffset;
+    const VertexTransform &X = A.X;
     const uint32_t z2 = row / L.rowsPerLayer + L.z2First, y2 = row % L.rowsPerLayer;
     const uint32_t cz = z2 >> 1, pz = z2 & 1, cy = y2 >> 1, py = y2 & 1;
     const bool rowExternal = L.rowClass(y2, z2) != 0;
@@ -944,14 +1010,26 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lattice L, FieldVie
  *
  * A block's cells are consecutive in the compacted list, so their index ranges are one contiguous span of the
  * output: it is assembled in LDS and written with fully coalesced stores. */
-__global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeView C, DevTables T, const uint2 *cells,
-                                                              const uint2 *viStart, uint32_t *indices,
-                                                              const U3 *batchTotals)
+struct LatticeTrianglesArgs
+{
+    Lattice L;
+    DevTables T;
+    const uint2 *cells, *viStart;
+    uint32_t *indices;
+    const U3 *batchTotals;
+};
+
+__global__ __launch_bounds__(256) void latticeTrianglesKernel(Lanes<LatticeTrianglesArgs> lanes)
 {
     __shared__ uint32_t sIdx[256][MAX_CELL_VERTICES];
     __shared__ uint16_t sRef[256 * MAX_CELL_INDICES];   /* thread * 13 + vertex slot: 18 KB instead of 36 KB of indices */
     __shared__ uint32_t sSpan;
-    const uint32_t numCells = batchTotals->a;           /* grid covers the host's count; the device value rules */
+    const LatticeTrianglesArgs &A = lanes.a[blockIdx.y];
+    const Lattice &L = A.L;
+    const DevTables &T = A.T;
+    const uint2 *const cells = A.cells, *const viStart = A.viStart;
+    uint32_t *const indices = A.indices;
+    const uint32_t numCells = A.batchTotals->a;         /* grid covers the host's count; the device value rules */
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x * blockDim.x >= numCells)
         return;
@@ -1052,10 +1130,26 @@ __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lattice L, CodeVie
  * latticeTrianglesKernel read back (16 bytes per occupied cell each way, and a dependent load in front of everything
  * else) do not exist.  The nine lattice rows are the same for the whole wave.  Index order is unchanged: rows in (z, y)
  * order, cells by x, a cell's indices in table order.  Each wave stages its own span in LDS; no workgroup barrier. */
-__global__ __launch_bounds__(256) void latticeTrianglesRowKernel(Lattice L, CodeView C, DevTables T, const U3 *rowCounts,
-                                                                 const U3 *rowStarts, uint32_t zFirst, uint32_t *indices,
-                                                                 uint32_t numRows)
+struct LatticeTrianglesRowArgs
 {
+    Lattice L;
+    CodeView C;
+    DevTables T;
+    const U3 *rowCounts, *rowStarts;
+    uint32_t zFirst;
+    uint32_t *indices;
+    uint32_t numRows;
+};
+
+__global__ __launch_bounds__(256) void latticeTrianglesRowKernel(Lanes<LatticeTrianglesRowArgs> lanes)
+{
+    const LatticeTrianglesRowArgs &A = lanes.a[blockIdx.y];
+    const Lattice &L = A.L;
+    const CodeView &C = A.C;
+    const DevTables &T = A.T;
+    const U3 *const rowCounts = A.rowCounts, *const rowStarts = A.rowStarts;
+    const uint32_t zFirst = A.zFirst, numRows = A.numRows;
+    uint32_t *const indices = A.indices;
     __shared__ uint32_t sIdx[4][64][MAX_CELL_VERTICES];
     /* (lane % 16) * 13 + vertex slot: a byte, because the write-out knows which QUARTER of the wave (16 cells) a position
      * belongs to from three wave-uniform bounds.  5.6 instead of 7.9 KB of LDS per wave: seven workgroups per CU, not five. */
@@ -1257,7 +1351,8 @@ struct mlsgpu_marching
     int computeCodes(const mlsgpu_swathe &sw);
     int shipOut(const mlsgpu_swathe &sw, const uint32_t sizes[2], uint32_t zTop, uint32_t zMax);
     int shipOutSorted(const uint32_t sizes[2], uint32_t zMax, mlsgpu_mesh *mesh);
-    int shipOutLattice(const mlsgpu_swathe &sw, const uint32_t sizes[2], uint32_t zTop, uint32_t zMax, mlsgpu_mesh *mesh);
+    int shipOutDone(const uint32_t sizes[2], const mlsgpu_mesh &mesh);
+    CellCodeArgs cellCodeArgs(const mlsgpu_swathe &sw);
     int addSlices(const mlsgpu_swathe &sw, uint32_t offsets[2], uint32_t &zTop, uint32_t *shipOuts);
     template<typename K> int weld(uint32_t nv, uint32_t zMax);
 };
@@ -1510,15 +1605,39 @@ int mlsgpu_marching::weld(uint32_t nv, uint32_t zMax)
 }
 
 /* cellCodeKernel over the cells of one top-level swathe */
-int mlsgpu_marching::computeCodes(const mlsgpu_swathe &sw)
+CellCodeArgs mlsgpu_marching::cellCodeArgs(const mlsgpu_swathe &sw)
 {
     const uint32_t cw = sw.width - 1, ch = sw.height - 1;
-    const uint32_t rows = ch * (sw.zLast - sw.zFirst);
+    const uint32_t rows = cw > 0 ? ch * (sw.zLast - sw.zFirst) : 0u;
     codeZ0 = sw.zFirst;
-    if (rows > 0 && cw > 0)
-        LAUNCH(ctx, "kernel.marching.genOccupied.time", cellCodeKernel, dim3(divUp(rows, 4)), dim3(256),
-               dCellCode, dRowCounts, view(sw), cw, ch, sw.zFirst, rows, (const uchar2 *) dCount);
+    return CellCodeArgs{dCellCode, dRowCounts, view(sw), cw, ch, sw.zFirst, rows, (const uchar2 *) dCount};
+}
+
+/* ... for the buckets of a batch (one launch); a single bucket is a batch of one */
+static int computeCodesLanes(mlsgpu_marching *const *ms, const mlsgpu_swathe *sws, uint32_t count)
+{
+    mlsgpu_ctx *ctx = ms[0]->ctx;
+    Lanes<CellCodeArgs> L;
+    uint32_t maxRows = 0;
+    for (uint32_t k = 0; k < MAX_LANES; k++)
+    {
+        if (k < count)
+        {
+            L.a[k] = ms[k]->cellCodeArgs(sws[k]);
+            maxRows = std::max(maxRows, L.a[k].numRows);
+        }
+        else
+            L.a[k] = L.a[0];
+    }
+    if (maxRows > 0)
+        LAUNCH(ctx, "kernel.marching.genOccupied.time", cellCodeKernel, dim3(divUp(maxRows, 4), count), dim3(256), L);
     return MLSGPU_OK;
+}
+
+int mlsgpu_marching::computeCodes(const mlsgpu_swathe &sw)
+{
+    mlsgpu_marching *self = this;
+    return computeCodesLanes(&self, &sw, 1);
 }
 
 /* shipOut, src/marching.cpp:553-625, sort-based: works on the unwelded buffers filled by generateElements */
@@ -1539,96 +1658,201 @@ int mlsgpu_marching::shipOutSorted(const uint32_t sizes[2], uint32_t zMax, mlsgp
     return MLSGPU_OK;
 }
 
-/* shipOut without a sort: the lattice weld over cells z in [zTop, zMax) of the resident swathe */
-int mlsgpu_marching::shipOutLattice(const mlsgpu_swathe &sw, const uint32_t sizes[2], uint32_t zTop, uint32_t zMax,
-                                    mlsgpu_mesh *mesh)
+/* one bucket of a batched ship-out */
+struct ShipLane
 {
-    (void) sizes;
-    const uint32_t W = sw.width, H = sw.height;
-    Lattice L;
-    L.words = dLatWords;
-    L.rowCounts = dLatRows;
-    L.totals = &dReadback->classTotals;
-    L.nw = (2 * W - 1 + 63) / 64;
-    L.rowsPerLayer = 2 * H - 1;
-    L.topx = 2 * (W - 1);
-    L.topy = 2 * (H - 1);
-    L.z2First = 2 * zTop;
-    L.z2Last = 2 * zMax;
-    L.cw = W - 1;
-    L.ch = H - 1;
-    const uint32_t numRows = (2 * (zMax - zTop) + 1) * L.rowsPerLayer;
-    REQUIRE(numRows <= latRowsMax && L.nw <= latWords, MLSGPU_ERR_LENGTH);
-    const CodeView C = codeView(sw);
-    const uint32_t cornerRows = (zMax - zTop + 1) * H;
-    LAUNCH(ctx, "kernel.marching.countUniqueVertices.time", latticeMaskKernel, dim3(divUp(cornerRows, 4)), dim3(256),
-           L, C, (const U3 *) dRowCounts, zTop, zMax, H, cornerRows);
-    PROPAGATE((exclusiveScan<U3>(ctx, "kernel.marching.scanUint.time", ArrayIn<U3>{dLatRows}, ArrayOut<U3>{dLatRows},
-                                 numRows, U3{0, 0, 0}, dTileSums3, &dReadback->classTotals)));
-    LAUNCH(ctx, "kernel.marching.scanUint.time", latticePatchKernel, dim3(divUp(numRows * L.nw, 256)), dim3(256), L, numRows * L.nw);
-    const uint64_t keyOffsetL = ((uint64_t) keyOffset[2] << (2 * KEY_AXIS_BITS + 1))
-        | ((uint64_t) keyOffset[1] << (KEY_AXIS_BITS + 1))
-        | ((uint64_t) keyOffset[0] << 1);                                   /* src/marching.cpp:594-597 */
-    LAUNCH(ctx, "kernel.marching.compactVertices.time", latticeVerticesKernel, dim3(divUp(numRows, 4)), dim3(256),
-           L, view(sw), dWelded, dWeldedKeys, keyOffset[0], keyOffset[1], keyOffset[2], keyOffsetL, transform, numRows);
-    /* first cell / index slot of every row of cells of the batch, the compacted cells, then the triangles */
-    const uint32_t cellRows = (zMax - zTop) * L.ch;
-    const U3 *firstRow = dRowCounts + (uint64_t) (zTop - codeZ0) * L.ch;
-    PROPAGATE((exclusiveScan<U3>(ctx, "kernel.marching.scanElements.time", ArrayIn<U3>{firstRow}, ArrayOut<U3>{dRowStarts},
-                                 cellRows, U3{0, 0, 0}, dTileSums3, &dReadback->batchTotals)));
-    const uint32_t cellsInBatch = bufferedCells;
-    if (cellRows > 0 && cellsInBatch > 0)
+    mlsgpu_marching *m;
+    mlsgpu_swathe sw;
+    uint32_t sizes[2];
+    uint32_t zTop, zMax;
+    mlsgpu_mesh mesh;           /* out: sizes filled in */
+};
+
+/* shipOut without a sort: the lattice weld over cells z in [zTop, zMax) of the resident swathe -- for every bucket of a
+ * batch with ONE set of launches (blockIdx.y = bucket) and one read-back of all the welded counts */
+static int shipOutLatticeLanes(ShipLane *lanes, uint32_t count)
+{
+    REQUIRE(count >= 1 && count <= MAX_LANES, MLSGPU_ERR_INVALID);
+    mlsgpu_ctx *ctx = lanes[0].m->ctx;
+    Lattice Ls[MAX_LANES];
+    CodeView Cs[MAX_LANES];
+    uint32_t numRows[MAX_LANES], cornerRows[MAX_LANES], cellRows[MAX_LANES];
+    const U3 *firstRow[MAX_LANES];
+    uint64_t keyOffsetL[MAX_LANES];
+    for (uint32_t k = 0; k < count; k++)
     {
-        /* Two routes to the same index list.  By ROWS (one wave per row of cells, no compacted cell list): no
-         * compactRowCells launch and 32 bytes per occupied cell less traffic, but a wave per row whatever it holds -- the
-         * faster one when most cells are occupied (cfg3 noise cloud, 85 %: 4.2 -> 3.6 ms per step).  By CELLS (compact, then
-         * one thread per occupied cell): time follows the surface, 0.70 against 1.31 ms per step on the shells cloud
-         * (~6 % occupied).  MLSGPU_HIP_TRIANGLES_BY_CELLS=0/1 forces one. */
-        const char *const routeEnv = getenv("MLSGPU_HIP_TRIANGLES_BY_CELLS");     /* read per ship-out: tests flip it */
-        const bool byCells = routeEnv != nullptr ? routeEnv[0] != '0'
-                                                 : (uint64_t) cellsInBatch * 2 < (uint64_t) cellRows * L.cw;
-        if (byCells)
-        {
-            LAUNCH(ctx, "kernel.marching.scanElements.time", compactRowCellsKernel, dim3(divUp(cellRows, 4)), dim3(256),
-                   (const uint8_t *) dCellCode, L.cw, L.ch, codeZ0, zTop, (const U3 *) dRowStarts, (const uchar2 *) dCount,
-                   dCells, dViStart, cellRows);
-            LAUNCH(ctx, "kernel.marching.generateElements.time", latticeTrianglesKernel, dim3(divUp(cellsInBatch, 256)), dim3(256),
-                   L, C, devTables(), (const uint2 *) dCells, (const uint2 *) dViStart, dIndices,
-                   (const U3 *) &dReadback->batchTotals);
-        }
-        else
-            LAUNCH(ctx, "kernel.marching.generateElements.time", latticeTrianglesRowKernel, dim3(divUp(cellRows, 4)), dim3(256),
-                   L, C, devTables(), firstRow, (const U3 *) dRowStarts, zTop, dIndices, cellRows);
+        mlsgpu_marching *m = lanes[k].m;
+        const mlsgpu_swathe &sw = lanes[k].sw;
+        const uint32_t zTop = lanes[k].zTop, zMax = lanes[k].zMax;
+        const uint32_t W = sw.width, H = sw.height;
+        Lattice &L = Ls[k];
+        L.words = m->dLatWords;
+        L.rowCounts = m->dLatRows;
+        L.totals = &m->dReadback->classTotals;
+        L.nw = (2 * W - 1 + 63) / 64;
+        L.rowsPerLayer = 2 * H - 1;
+        L.topx = 2 * (W - 1);
+        L.topy = 2 * (H - 1);
+        L.z2First = 2 * zTop;
+        L.z2Last = 2 * zMax;
+        L.cw = W - 1;
+        L.ch = H - 1;
+        numRows[k] = (2 * (zMax - zTop) + 1) * L.rowsPerLayer;
+        REQUIRE(numRows[k] <= m->latRowsMax && L.nw <= m->latWords, MLSGPU_ERR_LENGTH);
+        Cs[k] = m->codeView(sw);
+        cornerRows[k] = (zMax - zTop + 1) * H;
+        cellRows[k] = (zMax - zTop) * L.ch;
+        firstRow[k] = m->dRowCounts + (uint64_t) (zTop - m->codeZ0) * L.ch;
+        keyOffsetL[k] = ((uint64_t) m->keyOffset[2] << (2 * KEY_AXIS_BITS + 1))
+            | ((uint64_t) m->keyOffset[1] << (KEY_AXIS_BITS + 1))
+            | ((uint64_t) m->keyOffset[0] << 1);                                /* src/marching.cpp:594-597 */
     }
-    PROPAGATE(box.publish(ctx->stream, &dReadback->classTotals, 6));     /* classTotals and batchTotals are adjacent */
+    auto lane = [&](uint32_t k) { return k < count ? k : 0u; };
+    /* existence masks */
+    {
+        Lanes<LatticeMaskArgs> A;
+        uint32_t most = 0;
+        for (uint32_t j = 0; j < MAX_LANES; j++)
+        {
+            const uint32_t k = lane(j);
+            A.a[j] = LatticeMaskArgs{Ls[k], Cs[k], (const U3 *) lanes[k].m->dRowCounts, lanes[k].zTop, lanes[k].zMax,
+                                     lanes[k].sw.height, j < count ? cornerRows[k] : 0u};
+            most = std::max(most, A.a[j].numCornerRows);
+        }
+        LAUNCH(ctx, "kernel.marching.countUniqueVertices.time", latticeMaskKernel, dim3(divUp(most, 4), count), dim3(256), A);
+    }
+    typedef ScanJob<U3, ArrayIn<U3>, ArrayIn<U3>, ArrayOut<U3> > RowJob;
+    {
+        RowJob jobs[MAX_LANES];
+        for (uint32_t k = 0; k < count; k++)
+        {
+            mlsgpu_marching *m = lanes[k].m;
+            jobs[k] = RowJob{ArrayIn<U3>{m->dLatRows}, ArrayIn<U3>{m->dLatRows}, ArrayOut<U3>{m->dLatRows}, numRows[k],
+                             U3{0, 0, 0}, m->dTileSums3, &m->dReadback->classTotals, nullptr};
+        }
+        PROPAGATE((exclusiveScanBatch<U3, ArrayIn<U3>, ArrayIn<U3>, ArrayOut<U3> >(ctx, "kernel.marching.scanUint.time", jobs, count)));
+    }
+    {
+        Lanes<LatticePatchArgs> A;
+        uint32_t most = 0;
+        for (uint32_t j = 0; j < MAX_LANES; j++)
+        {
+            const uint32_t k = lane(j);
+            A.a[j] = LatticePatchArgs{Ls[k], j < count ? numRows[k] * Ls[k].nw : 0u};
+            most = std::max(most, A.a[j].numWords);
+        }
+        LAUNCH(ctx, "kernel.marching.scanUint.time", latticePatchKernel, dim3(divUp(most, 256), count), dim3(256), A);
+    }
+    {
+        Lanes<LatticeVerticesArgs> A;
+        uint32_t most = 0;
+        for (uint32_t j = 0; j < MAX_LANES; j++)
+        {
+            const uint32_t k = lane(j);
+            mlsgpu_marching *m = lanes[k].m;
+            A.a[j] = LatticeVerticesArgs{Ls[k], m->view(lanes[k].sw), m->dWelded, m->dWeldedKeys, m->keyOffset[0], m->keyOffset[1],
+                                         m->keyOffset[2], keyOffsetL[k], m->transform, j < count ? numRows[k] : 0u};
+            most = std::max(most, A.a[j].numRows);
+        }
+        LAUNCH(ctx, "kernel.marching.compactVertices.time", latticeVerticesKernel, dim3(divUp(most, 4), count), dim3(256), A);
+    }
+    /* first cell / index slot of every row of cells of the batch, the compacted cells, then the triangles */
+    {
+        RowJob jobs[MAX_LANES];
+        for (uint32_t k = 0; k < count; k++)
+        {
+            mlsgpu_marching *m = lanes[k].m;
+            jobs[k] = RowJob{ArrayIn<U3>{firstRow[k]}, ArrayIn<U3>{firstRow[k]}, ArrayOut<U3>{m->dRowStarts}, cellRows[k],
+                             U3{0, 0, 0}, m->dTileSums3, &m->dReadback->batchTotals, nullptr};
+        }
+        PROPAGATE((exclusiveScanBatch<U3, ArrayIn<U3>, ArrayIn<U3>, ArrayOut<U3> >(ctx, "kernel.marching.scanElements.time", jobs, count)));
+    }
+    /* Two routes to the same index list, chosen per bucket.  By ROWS (one wave per row of cells, no compacted cell list): no
+     * compactRowCells launch and 32 bytes per occupied cell less traffic, but a wave per row whatever it holds -- the
+     * faster one when most cells are occupied (cfg3 noise cloud, 85 %: 4.2 -> 3.6 ms per step).  By CELLS (compact, then
+     * one thread per occupied cell): time follows the surface, 0.70 against 1.31 ms per step on the shells cloud
+     * (~6 % occupied).  MLSGPU_HIP_TRIANGLES_BY_CELLS=0/1 forces one. */
+    {
+        const char *const routeEnv = getenv("MLSGPU_HIP_TRIANGLES_BY_CELLS");     /* read per ship-out: tests flip it */
+        uint32_t byCells[MAX_LANES], byRows[MAX_LANES], nc = 0, nr = 0;
+        for (uint32_t k = 0; k < count; k++)
+        {
+            const uint32_t cellsInBatch = lanes[k].m->bufferedCells;
+            if (cellRows[k] == 0 || cellsInBatch == 0)
+                continue;
+            const bool cellsRoute = routeEnv != nullptr ? routeEnv[0] != '0'
+                                                        : (uint64_t) cellsInBatch * 2 < (uint64_t) cellRows[k] * Ls[k].cw;
+            if (cellsRoute) byCells[nc++] = k; else byRows[nr++] = k;
+        }
+        if (nc > 0)
+        {
+            Lanes<CompactRowCellsArgs> A;
+            Lanes<LatticeTrianglesArgs> B;
+            uint32_t mostRows = 0, mostCells = 0;
+            for (uint32_t j = 0; j < MAX_LANES; j++)
+            {
+                const uint32_t k = byCells[j < nc ? j : 0];
+                mlsgpu_marching *m = lanes[k].m;
+                A.a[j] = CompactRowCellsArgs{(const uint8_t *) m->dCellCode, Ls[k].cw, Ls[k].ch, m->codeZ0, lanes[k].zTop,
+                                             (const U3 *) m->dRowStarts, (const uchar2 *) m->dCount, m->dCells, m->dViStart,
+                                             j < nc ? cellRows[k] : 0u};
+                B.a[j] = LatticeTrianglesArgs{Ls[k], m->devTables(), (const uint2 *) m->dCells, (const uint2 *) m->dViStart,
+                                              m->dIndices, (const U3 *) &m->dReadback->batchTotals};
+                mostRows = std::max(mostRows, A.a[j].numRows);
+                if (j < nc)
+                    mostCells = std::max(mostCells, m->bufferedCells);
+            }
+            LAUNCH(ctx, "kernel.marching.scanElements.time", compactRowCellsKernel, dim3(divUp(mostRows, 4), nc), dim3(256), A);
+            LAUNCH(ctx, "kernel.marching.generateElements.time", latticeTrianglesKernel, dim3(divUp(mostCells, 256), nc), dim3(256), B);
+        }
+        if (nr > 0)
+        {
+            Lanes<LatticeTrianglesRowArgs> A;
+            uint32_t most = 0;
+            for (uint32_t j = 0; j < MAX_LANES; j++)
+            {
+                const uint32_t k = byRows[j < nr ? j : 0];
+                mlsgpu_marching *m = lanes[k].m;
+                A.a[j] = LatticeTrianglesRowArgs{Ls[k], Cs[k], m->devTables(), firstRow[k], (const U3 *) m->dRowStarts,
+                                                 lanes[k].zTop, m->dIndices, j < nr ? cellRows[k] : 0u};
+                most = std::max(most, A.a[j].numRows);
+            }
+            LAUNCH(ctx, "kernel.marching.generateElements.time", latticeTrianglesRowKernel, dim3(divUp(most, 4), nr), dim3(256), A);
+        }
+    }
+    /* the welded counts of every bucket, one publication (classTotals and batchTotals are adjacent) */
+    HostMailbox &box = lanes[0].m->box;
+    const void *srcs[MAX_LANES];
+    for (uint32_t k = 0; k < count; k++)
+        srcs[k] = &lanes[k].m->dReadback->classTotals;
+    PROPAGATE(box.publishGather(ctx->stream, srcs, count, 6));
     PROPAGATE(box.wait(ctx->stream));
-    std::memcpy(&hReadback->classTotals, box.payload(), 2 * sizeof(U3));
-    const U3 ct = hReadback->classTotals, bt = hReadback->batchTotals;
-    if (bt.a != cellsInBatch || bt.b != sizes[0] || bt.c != sizes[1])
-        return setError(MLSGPU_ERR_INVALID, "lattice weld: batch accounting mismatch (%u/%u cells, %u/%u vertices, %u/%u indices)",
-                        bt.a, cellsInBatch, bt.b, sizes[0], bt.c, sizes[1]);
-    mesh->numVertices = (uint64_t) ct.a + ct.b + ct.c;
-    mesh->numInternalVertices = ct.a;
+    for (uint32_t k = 0; k < count; k++)
+    {
+        mlsgpu_marching *m = lanes[k].m;
+        std::memcpy(&m->hReadback->classTotals, box.payload() + 6 * k, 2 * sizeof(U3));
+        const U3 ct = m->hReadback->classTotals, bt = m->hReadback->batchTotals;
+        if (bt.a != m->bufferedCells || bt.b != lanes[k].sizes[0] || bt.c != lanes[k].sizes[1])
+            return setError(MLSGPU_ERR_INVALID, "lattice weld: batch accounting mismatch (%u/%u cells, %u/%u vertices, %u/%u indices)",
+                            bt.a, m->bufferedCells, bt.b, lanes[k].sizes[0], bt.c, lanes[k].sizes[1]);
+        mlsgpu_mesh &mesh = lanes[k].mesh;
+        mesh.dVertices = m->dWelded;
+        mesh.dTriangles = m->dIndices;
+        mesh.dVertexKeys = m->dWeldedKeys;
+        mesh.numTriangles = lanes[k].sizes[1] / 3;
+        mesh.numVertices = (uint64_t) ct.a + ct.b + ct.c;
+        mesh.numInternalVertices = ct.a;
+    }
     return MLSGPU_OK;
 }
 
-/* shipOut, src/marching.cpp:553-625 */
-int mlsgpu_marching::shipOut(const mlsgpu_swathe &sw, const uint32_t sizes[2], uint32_t zTop, uint32_t zMax)
+/* the tail of shipOut (src/marching.cpp:619-624): counters, then the output functor */
+int mlsgpu_marching::shipOutDone(const uint32_t sizes[2], const mlsgpu_mesh &mesh)
 {
-    const uint32_t nv = sizes[0], ni = sizes[1];
-    mlsgpu_mesh mesh;
-    mesh.dVertices = dWelded;
-    mesh.dTriangles = dIndices;
-    mesh.dVertexKeys = dWeldedKeys;
-    mesh.numTriangles = ni / 3;
-    if (direct)
-        PROPAGATE(shipOutLattice(sw, sizes, zTop, zMax, &mesh));
-    else
-        PROPAGATE(shipOutSorted(sizes, zMax, &mesh));
     bufferedCells = 0;
     counters[1]++;
-    counters[4] += nv;
-    counters[5] += ni;
+    counters[4] += sizes[0];
+    counters[5] += sizes[1];
     counters[6] += mesh.numVertices;
     counters[7] += mesh.numVertices - mesh.numInternalVertices;
     if (output != nullptr)
@@ -1638,6 +1862,24 @@ int mlsgpu_marching::shipOut(const mlsgpu_swathe &sw, const uint32_t sizes[2], u
             return setError(MLSGPU_ERR_CALLBACK, "output functor failed with %d", rc);
     }
     return MLSGPU_OK;
+}
+
+/* shipOut, src/marching.cpp:553-625 */
+int mlsgpu_marching::shipOut(const mlsgpu_swathe &sw, const uint32_t sizes[2], uint32_t zTop, uint32_t zMax)
+{
+    if (direct)
+    {
+        ShipLane lane{this, sw, {sizes[0], sizes[1]}, zTop, zMax, mlsgpu_mesh()};
+        PROPAGATE(shipOutLatticeLanes(&lane, 1));
+        return shipOutDone(sizes, lane.mesh);
+    }
+    mlsgpu_mesh mesh;
+    mesh.dVertices = dWelded;
+    mesh.dTriangles = dIndices;
+    mesh.dVertexKeys = dWeldedKeys;
+    mesh.numTriangles = sizes[1] / 3;
+    PROPAGATE(shipOutSorted(sizes, zMax, &mesh));
+    return shipOutDone(sizes, mesh);
 }
 
 /* addSlices, src/marching.cpp:627-743 */
@@ -1737,35 +1979,30 @@ int mlsgpu_marching::addSlices(const mlsgpu_swathe &swathe, uint32_t offsets[2],
     return MLSGPU_OK;
 }
 
-/* Marching::generate, src/marching.cpp:745-824 */
-MLSGPU_API int mlsgpu_hip_marching_generate(mlsgpu_marching *m, const mlsgpu_generator *generator,
-                                            mlsgpu_output_fn output, void *outputUser,
-                                            const uint32_t size[3], const uint32_t keyOffset[3])
+/* the argument checks and per-call state of Marching::generate (src/marching.cpp:745-786) */
+static int beginGenerate(mlsgpu_marching *m, const mlsgpu_generator *generator, mlsgpu_output_fn output, void *outputUser,
+                         const uint32_t size[3], const uint32_t keyOffset[3], mlsgpu_swathe *swathe)
 {
     REQUIRE(m != nullptr && generator != nullptr && generator->enqueue != nullptr, MLSGPU_ERR_INVALID);
     REQUIRE(size != nullptr && keyOffset != nullptr, MLSGPU_ERR_INVALID);
-    mlsgpu_swathe swathe;
-    swathe.width = size[0];
-    swathe.height = size[1];
-    swathe.zStride = m->zStride;
+    swathe->width = size[0];
+    swathe->height = size[1];
+    swathe->zStride = m->zStride;
     const uint32_t depth = size[2];
-    REQUIRE(1u <= swathe.width && swathe.width <= m->maxWidth, MLSGPU_ERR_LENGTH);
-    REQUIRE(1u <= swathe.height && swathe.height <= m->maxHeight, MLSGPU_ERR_LENGTH);
+    REQUIRE(1u <= swathe->width && swathe->width <= m->maxWidth, MLSGPU_ERR_LENGTH);
+    REQUIRE(1u <= swathe->height && swathe->height <= m->maxHeight, MLSGPU_ERR_LENGTH);
     REQUIRE(1u <= depth && depth <= m->maxDepth, MLSGPU_ERR_LENGTH);
     /* global coordinates must fit the 20.1 key fields (MAX_GLOBAL_DIMENSION, src/marching.h:145-150) */
     for (int i = 0; i < 3; i++)
         REQUIRE((uint64_t) keyOffset[i] + size[i] <= (1u << 20) - 1, MLSGPU_ERR_LENGTH);
-    mlsgpu_ctx *ctx = m->ctx;
-    HIP_CHECK(hipSetDevice(ctx->device));
-
     m->generator = generator;
     m->output = output;
     m->outputUser = outputUser;
     for (int i = 0; i < 3; i++)
         m->keyOffset[i] = keyOffset[i];
     /* the generate-time key layout: only as many bits as this bucket's doubled local coordinates need */
-    m->layout.bx = bitsFor(2 * (swathe.width - 1));
-    m->layout.by = bitsFor(2 * (swathe.height - 1));
+    m->layout.bx = bitsFor(2 * (swathe->width - 1));
+    m->layout.by = bitsFor(2 * (swathe->height - 1));
     m->layout.bz = bitsFor(2 * (depth - 1));
     m->wideKeys = m->layout.bits() > 32;
     /* One swathe covers the bucket: weld from the resident field without sorting.  Otherwise (or when forced
@@ -1779,6 +2016,27 @@ MLSGPU_API int mlsgpu_hip_marching_generate(mlsgpu_marching *m, const mlsgpu_gen
     if (!m->direct && !m->legacyBuffers)
         return setError(MLSGPU_ERR_LENGTH, "Marching: depth %u needs several swathes but was created for one", depth);
     m->bufferedCells = 0;
+    return MLSGPU_OK;
+}
+
+static int callGenerator(const mlsgpu_generator *generator, mlsgpu_marching *m, const mlsgpu_swathe *swathe)
+{
+    const int rc = generator->enqueue(generator->user, m->ctx->stream, m->dField, m->imageWidth, swathe);
+    if (rc != 0)
+        return rc > 0 && rc <= MLSGPU_ERR_CALLBACK ? rc : setError(MLSGPU_ERR_CALLBACK, "generator failed with %d", rc);
+    return MLSGPU_OK;
+}
+
+/* Marching::generate, src/marching.cpp:745-824 */
+MLSGPU_API int mlsgpu_hip_marching_generate(mlsgpu_marching *m, const mlsgpu_generator *generator,
+                                            mlsgpu_output_fn output, void *outputUser,
+                                            const uint32_t size[3], const uint32_t keyOffset[3])
+{
+    mlsgpu_swathe swathe;
+    PROPAGATE(beginGenerate(m, generator, output, outputUser, size, keyOffset, &swathe));
+    const uint32_t depth = size[2];
+    mlsgpu_ctx *ctx = m->ctx;
+    HIP_CHECK(hipSetDevice(ctx->device));
 
     uint32_t offsets[2] = {0, 0};
     uint32_t zTop = 0;
@@ -1791,11 +2049,7 @@ MLSGPU_API int mlsgpu_hip_marching_generate(mlsgpu_marching *m, const mlsgpu_gen
         if (z != 0)
             PROPAGATE(mlsgpu_hip_marching_copy_slice(m, m->dField, m->imageWidth, m->maxSwathe, 0,
                                                      swathe.width, swathe.height, swathe.zStride));
-        {
-            const int rc = generator->enqueue(generator->user, ctx->stream, m->dField, m->imageWidth, &swathe);
-            if (rc != 0)
-                return rc > 0 && rc <= MLSGPU_ERR_CALLBACK ? rc : setError(MLSGPU_ERR_CALLBACK, "generator failed with %d", rc);
-        }
+        PROPAGATE(callGenerator(generator, m, &swathe));
         if (z > 0)
             swathe.zFirst--;
         PROPAGATE(m->computeCodes(swathe));
@@ -1805,6 +2059,155 @@ MLSGPU_API int mlsgpu_hip_marching_generate(mlsgpu_marching *m, const mlsgpu_gen
     {
         PROPAGATE(m->shipOut(swathe, offsets, zTop, depth - 1));
         shipOuts++;
+    }
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return MLSGPU_OK;
+}
+
+/*
+ * Marching::generate for the buckets of a batch (the SubItems of one WorkItem, which the reference's worker walks one by
+ * one, src/workers.cpp:232-286), in lock-step: one Marching object per bucket (own field, lattice and mesh arena), every
+ * kernel launched once for the whole batch, the swathe totals and the welded counts of all buckets read back together --
+ * three host decisions per BATCH.  Per bucket the results are those of mlsgpu_hip_marching_generate, bit for bit: the same
+ * kernels run on the same data, only the launch is shared.  Meshes are handed to `output` bucket by bucket, in order.
+ *
+ * The shared launches cover buckets that take the lattice weld (one swathe spans the bucket) and whose swathe fits the mesh
+ * memory; a bucket that overflows is finished by the sequential path behind the batch (the reference's slice splitting),
+ * and when any bucket needs several swathes the whole batch is processed one bucket at a time.
+ */
+namespace
+{
+struct BatchThunk
+{
+    mlsgpu_batch_output_fn fn;
+    void *user;
+    uint32_t index;
+};
+int batchThunkOutput(void *user, void *stream, const mlsgpu_mesh *mesh)
+{
+    const BatchThunk *t = static_cast<const BatchThunk *>(user);
+    return t->fn != nullptr ? t->fn(t->user, t->index, stream, mesh) : 0;
+}
+} // namespace
+
+extern "C" mlsgpu_mls *mlsgpu_hip_mls_of_generator(const mlsgpu_generator *gen);
+
+MLSGPU_API int mlsgpu_hip_marching_generate_batch(mlsgpu_marching *const *ms, const mlsgpu_generator *generators, uint32_t count,
+                                                  mlsgpu_batch_output_fn output, void *outputUser,
+                                                  const uint32_t *sizes, const uint32_t *keyOffsets)
+{
+    REQUIRE(ms != nullptr && generators != nullptr && sizes != nullptr && keyOffsets != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(count >= 1 && count <= MLSGPU_MAX_BATCH, MLSGPU_ERR_LENGTH);
+    BatchThunk thunks[MAX_LANES];
+    mlsgpu_swathe sws[MAX_LANES];
+    for (uint32_t k = 0; k < count; k++)
+    {
+        REQUIRE(ms[k] != nullptr && ms[k]->ctx == ms[0]->ctx, MLSGPU_ERR_INVALID);
+        for (uint32_t j = 0; j < k; j++)
+            REQUIRE(ms[j] != ms[k], MLSGPU_ERR_INVALID);
+        thunks[k] = BatchThunk{output, outputUser, k};
+    }
+    mlsgpu_ctx *ctx = ms[0]->ctx;
+    bool lockStep = count > 1;
+    for (uint32_t k = 0; k < count; k++)
+    {
+        PROPAGATE(beginGenerate(ms[k], &generators[k], batchThunkOutput, &thunks[k], sizes + 3 * k, keyOffsets + 3 * k, &sws[k]));
+        lockStep = lockStep && ms[k]->direct;
+    }
+    if (!lockStep)
+    {
+        for (uint32_t k = 0; k < count; k++)
+            PROPAGATE(mlsgpu_hip_marching_generate(ms[k], &generators[k], batchThunkOutput, &thunks[k], sizes + 3 * k, keyOffsets + 3 * k));
+        return MLSGPU_OK;
+    }
+    HIP_CHECK(hipSetDevice(ctx->device));
+    /* every bucket is one swathe: slices [0, depth - 1], stored from row block 1 (src/marching.cpp:787-802) */
+    mlsgpu_mls *functors[MAX_LANES];
+    float *fields[MAX_LANES];
+    uint64_t pitches[MAX_LANES];
+    bool allMls = true;
+    for (uint32_t k = 0; k < count; k++)
+    {
+        sws[k].zFirst = 0;
+        sws[k].zLast = sizes[3 * k + 2] - 1;
+        sws[k].zBias = (int32_t) sws[k].zStride;
+        functors[k] = mlsgpu_hip_mls_of_generator(&generators[k]);
+        allMls = allMls && functors[k] != nullptr;
+        fields[k] = ms[k]->dField;
+        pitches[k] = ms[k]->imageWidth;
+    }
+    if (allMls)
+    {
+        /* MlsFunctors: processCorners of the whole batch is one launch */
+        const int rc = mlsgpu_hip_mls_enqueue_batch(functors, fields, pitches, nullptr, sws, count);
+        if (rc != MLSGPU_OK)
+            return rc;
+    }
+    else
+        for (uint32_t k = 0; k < count; k++)
+            PROPAGATE(callGenerator(&generators[k], ms[k], &sws[k]));
+    PROPAGATE(computeCodesLanes(ms, sws, count));
+    /* generateCells (src/marching.cpp:500-551): the swathe totals of every bucket, one read-back */
+    {
+        typedef ScanJob<U3, ArrayIn<U3>, NoIn, NoOut> TotalsJob;
+        TotalsJob jobs[MAX_LANES];
+        const void *srcs[MAX_LANES];
+        for (uint32_t k = 0; k < count; k++)
+        {
+            mlsgpu_marching *m = ms[k];
+            const uint32_t cw = sws[k].width - 1, ch = sws[k].height - 1;
+            const uint64_t rows = cw > 0 ? (uint64_t) ch * (sws[k].zLast - sws[k].zFirst) : 0;
+            jobs[k] = TotalsJob{ArrayIn<U3>{m->dRowCounts}, NoIn(), NoOut(), rows, U3{0, 0, 0}, m->dTileSums3,
+                                &m->dReadback->totals, nullptr};
+            srcs[k] = &m->dReadback->totals;
+        }
+        PROPAGATE((scanPhase1Batch<U3, ArrayIn<U3>, NoIn, NoOut>(ctx, "kernel.marching.genOccupied.time", jobs, count)));
+        int pend = -1;
+        if (ctx->timing) pend = ctx->beginTiming(ctx->statId("kernel.marching.readback.time"));
+        PROPAGATE(ms[0]->box.publishGather(ctx->stream, srcs, count, 3));
+        if (pend >= 0) ctx->endTiming(pend);
+        PROPAGATE(ms[0]->box.wait(ctx->stream));                 /* the reference's queue.finish(), :548 */
+    }
+    /* addSlices (src/marching.cpp:627-743) for a bucket that is one swathe with nothing buffered: it either fits the mesh
+     * memory and waits for the ship-out at the end of the bucket, or it has to be split */
+    ShipLane ship[MAX_LANES];
+    uint32_t shipOf[MAX_LANES], numShip = 0;
+    bool split[MAX_LANES];
+    for (uint32_t k = 0; k < count; k++)
+    {
+        mlsgpu_marching *m = ms[k];
+        std::memcpy(&m->hReadback->totals, ms[0]->box.payload() + 3 * k, sizeof(U3));
+        const U3 totals = m->hReadback->totals;
+        split[k] = false;
+        shipOf[k] = MAX_LANES;
+        if (totals.a == 0)
+            continue;
+        if (totals.b > m->vertexSpace || totals.c > m->indexSpace)
+        {
+            split[k] = true;
+            continue;
+        }
+        m->bufferedCells += totals.a;
+        m->counters[3] += totals.a;
+        m->counters[2] += 1;
+        shipOf[k] = numShip;
+        ship[numShip++] = ShipLane{m, sws[k], {totals.b, totals.c}, 0u, sizes[3 * k + 2] - 1, mlsgpu_mesh()};
+    }
+    if (numShip > 0)
+        PROPAGATE(shipOutLatticeLanes(ship, numShip));
+    /* results bucket by bucket, in order; a bucket that has to be split goes through the sequential path here */
+    for (uint32_t k = 0; k < count; k++)
+    {
+        mlsgpu_marching *m = ms[k];
+        if (shipOf[k] != MAX_LANES)
+            PROPAGATE(m->shipOutDone(ship[shipOf[k]].sizes, ship[shipOf[k]].mesh));
+        else if (split[k])
+        {
+            uint32_t offsets[2] = {0, 0}, zTop = 0, shipOuts = 0;
+            PROPAGATE(m->addSlices(sws[k], offsets, zTop, &shipOuts));
+            if (offsets[0] > 0)
+                PROPAGATE(m->shipOut(sws[k], offsets, zTop, sizes[3 * k + 2] - 1));
+        }
     }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return MLSGPU_OK;

@@ -694,6 +694,11 @@ MLSGPU_API int mlsgpu_hip_mesher_reserve(mlsgpu_mesher *m, uint64_t numVertices,
     std::lock_guard<std::mutex> lock(m->mutex);
     HIP_CHECK(hipSetDevice(m->ctx->device));
     PROPAGATE(m->ensureAddStream());
+    /* an arena that grows moves (copy on addStream, old buffer freed): same-device appends may still be running on their
+     * producers' streams, so they must have landed first -- the rule mlsgpu_hip_mesher_add follows before it grows one */
+    if (3 * numVertices > m->vertices.cap || 3 * numTriangles > m->triangles.cap || numExternal > m->extKeys.cap
+        || numExternal > m->extGid.cap || numExternal > m->extChunk.cap)
+        PROPAGATE(m->drainPending());
     PROPAGATE(m->vertices.reserve(m->addStream, 3 * numVertices));
     PROPAGATE(m->triangles.reserve(m->addStream, 3 * numTriangles));
     PROPAGATE(m->extKeys.reserve(m->addStream, numExternal));
@@ -762,27 +767,45 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
         return peer ? hipMemcpyPeerAsync(dst, home, src, from->device, bytes, from->stream)
                     : hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, from->stream);
     };
-    HIP_CHECK(append(m->vertices.ptr + m->vertices.used, mesh->dVertices, 3 * nv * sizeof(float)));
-    if (peer)
-        HIP_CHECK(append(m->triangles.ptr + m->triangles.used, mesh->dTriangles, 3 * nt * sizeof(uint32_t)));
-    else if (nt > 0)
-        hipLaunchKernelGGL(copyRebaseTrianglesKernel, dim3(divUp(divUp(3 * nt, 4), 256)), dim3(256), 0, from->stream,
-                           m->triangles.ptr + m->triangles.used, mesh->dTriangles, 3 * nt, (uint32_t) (m->vertices.used / 3));
-    HIP_CHECK(append(m->extKeys.ptr + m->extKeys.used, mesh->dVertexKeys + mesh->numInternalVertices, ne * sizeof(uint64_t)));
+    /* A failure after the first enqueue leaves work on the producer's stream that writes [used, used + n) of the arenas
+     * while `used` does not advance: the next append (possibly from another worker's stream) would write the same range
+     * under it, and finalize / reset would not wait for it.  Every failing path therefore drains the producer's stream
+     * (and the mesher's, for a peer append) before it reports. */
     hipStream_t fix = from->stream;
-    if (peer)
+    auto enqueue = [&]() -> int
     {
-        HIP_CHECK(hipStreamSynchronize(from->stream));
-        HIP_CHECK(hipSetDevice(home));
-        fix = m->addStream;
+        HIP_CHECK(append(m->vertices.ptr + m->vertices.used, mesh->dVertices, 3 * nv * sizeof(float)));
+        if (peer)
+            HIP_CHECK(append(m->triangles.ptr + m->triangles.used, mesh->dTriangles, 3 * nt * sizeof(uint32_t)));
+        else if (nt > 0)
+            hipLaunchKernelGGL(copyRebaseTrianglesKernel, dim3(divUp(divUp(3 * nt, 4), 256)), dim3(256), 0, from->stream,
+                               m->triangles.ptr + m->triangles.used, mesh->dTriangles, 3 * nt, (uint32_t) (m->vertices.used / 3));
+        HIP_CHECK(append(m->extKeys.ptr + m->extKeys.used, mesh->dVertexKeys + mesh->numInternalVertices, ne * sizeof(uint64_t)));
+        if (peer)
+        {
+            HIP_CHECK(hipStreamSynchronize(from->stream));
+            HIP_CHECK(hipSetDevice(home));
+            fix = m->addStream;
+        }
+        if (nt > 0 && peer)
+            hipLaunchKernelGGL(rebaseTrianglesKernel, dim3(divUp(3 * nt, 256)), dim3(256), 0, fix,
+                               m->triangles.ptr + m->triangles.used, 3 * nt, r.vBase);
+        if (ne > 0)
+            hipLaunchKernelGGL(fillExternalsKernel, dim3(divUp(ne, 256)), dim3(256), 0, fix,
+                               m->extGid.ptr + m->extGid.used, m->extChunk.ptr + m->extChunk.used, ne, r.vBase + r.nInternal, chunk);
+        HIP_CHECK(hipGetLastError());
+        return MLSGPU_OK;
+    };
+    {
+        const int rcEnqueue = enqueue();
+        if (rcEnqueue != MLSGPU_OK)
+        {
+            (void) hipStreamSynchronize(from->stream);
+            if (fix != from->stream)
+                (void) hipStreamSynchronize(fix);
+            return rcEnqueue;
+        }
     }
-    if (nt > 0 && peer)
-        hipLaunchKernelGGL(rebaseTrianglesKernel, dim3(divUp(3 * nt, 256)), dim3(256), 0, fix,
-                           m->triangles.ptr + m->triangles.used, 3 * nt, r.vBase);
-    if (ne > 0)
-        hipLaunchKernelGGL(fillExternalsKernel, dim3(divUp(ne, 256)), dim3(256), 0, fix,
-                           m->extGid.ptr + m->extGid.used, m->extChunk.ptr + m->extChunk.used, ne, r.vBase + r.nInternal, chunk);
-    HIP_CHECK(hipGetLastError());
     if (peer)
     {
         /* the fix-ups ran on the mesher's stream, not the producer's: the mesh is Marching's and is reused for the next

@@ -5,23 +5,24 @@
  * One 512-thread workgroup (8 waves) evaluates one 8x8x8 block of grid corners, all of which share
  * one octree leaf and therefore one splat list (src/mls.cpp:53-54: wgs = {8,8,8}, subsamplingMin 3).
  * Per corner the splats are accumulated in LIST ORDER (leaf range first, then each ancestor's),
- * which fixes the floating-point summation order; both variants below keep that order, so their
+ * which fixes the floating-point summation order; both kernels below keep that order, so their
  * results are bit-identical to each other and to the oracle.
  *
- * Variant 0 (default, "culled"): the workgroup stages up to 512 listed splats per round into LDS
- * (position/radius and normal/quality, one coalescable 32-byte record per thread) and tags each
- * with an 8-bit mask of the 4x4x4 sub-blocks its support sphere can reach.  Each wave owns one
- * sub-block (lane = x + 4y + 16z), ballots the mask 64 splats at a time and only visits the
- * splats that can touch its 64 corners -- typically 4-6x fewer distance tests than the
- * reference's every-corner-tests-every-listed-splat loop.  The cull test has the same fma
- * structure as the per-corner distance, so by monotonicity of rounding it never drops a splat a
- * corner would accept (DESIGN.md "processCorners").
- * Variant 1 ("basic"): the reference's structure (every thread walks every staged splat).
+ * Variant 4 (default, "cube streams", processCornersCubeKernel): 512 listed splats per round are staged in LDS and
+ * tagged with the 4x4x4 sub-blocks their support can reach; each wave owns a sub-block and gives each of its eight 2x2x2
+ * cubes of corners its own stream of candidate splats; hits are accumulated in list order.  See the kernel.
+ * Variant 1 ("basic", processCornersKernel): the reference's structure (every thread walks every staged splat), kept as
+ * the A/B partner of the parity tests.
+ * (Rounds 1-3 carried three intermediate designs -- sub-block culling alone, per-lane hit lists, hit masks -- as variants
+ * 0, 2 and 3; they are gone from the product, their measurements are in profiles/NOTES_r0*.md.)
+ *
+ * Both kernels have a bucket dimension (common.hpp, Lanes): blockIdx.y selects the bucket of a batch.
  *
  * Floating-point contract: compiled with -ffp-contract=off; fmaf only where written.
  */
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 using namespace mlsgpu;
@@ -82,11 +83,30 @@ __device__ __forceinline__ void fitInit(Fit &f)
 /* 1 iff d < RADIUS_CUTOFF, as the sign bit of the difference instead of a compare: a compare writes VCC and the
  * add-with-carry behind it waits for that (6.8 issue cycles per instruction of the pair at 8 waves per SIMD against 2.6 for
  * plain vector instructions, profiles/r03_valu_lds_issue_microbench.txt).  The subtraction is exact for d within a factor
- * of two of the cutoff and has the sign of the exact difference otherwise; d == cutoff gives +0; d is a product of finite
- * non-negative values, and the NaN the hardware makes from 0 * inf is the positive one, which a compare rejects as well. */
+ * of two of the cutoff and has the sign of the exact difference otherwise; d == cutoff gives +0, -inf gives -inf (a hit for
+ * the compare as well) and the NaN the hardware MAKES (0 * inf, inf - inf) is the positive one, which a compare rejects
+ * too.  A NaN that comes IN with a splat keeps its sign through the arithmetic, and a negative one would read as a hit:
+ * such a splat never reaches a test -- staging gives a record with a NaN position or 1/r^2 an empty sub-block mask
+ * (splatIsNan), which is what `d < cutoff` does with it at every corner. */
 __device__ __forceinline__ uint32_t hitBit(float d)
 {
     return __float_as_uint(d - RADIUS_CUTOFF) >> 31;
+}
+
+/* a staged record no corner can accept: d = |p - c|^2 * invr2 is a NaN for every corner */
+__device__ __forceinline__ bool splatIsNan(const float4 pr)
+{
+    return (pr.x != pr.x) | (pr.y != pr.y) | (pr.z != pr.z) | (pr.w != pr.w);
+}
+
+/* The box tests that cull a splat for a sub-block or a cube are conservative because d grows with the distance -- for
+ * 1/r^2 >= 0, which is all a tree can hold, and for finite negative values too (every d is <= 0: hits everywhere, boxes
+ * included).  The one value of a hand-built list (mlsgpu_hip_mls_set_buffers) that breaks it is -inf: a corner at any
+ * distance > 0 has d = -inf, a hit for `d < cutoff`, while a box that CONTAINS the splat has distance 0 and 0 * -inf is a
+ * NaN.  Such a record is not culled. */
+__device__ __forceinline__ bool splatNeverCulled(const float4 pr)
+{
+    return __float_as_uint(pr.w) == 0xFF800000u;
 }
 
 /* sphereFitAdd, kernels/mls.cl:129-139 (planeFitAdd :141-148 keeps a subset of the same sums). */
@@ -193,6 +213,7 @@ struct MlsArgs
     int32_t zBias;
     uint32_t zFirst;
     uint32_t blocksX, blocksY, blocksZ;
+    uint32_t numBlocks;          /* blocksX * blocksY * blocksZ: workgroups of this lane; the grid covers the largest lane */
     float boundaryFactor;
     uint32_t xcdChunk;           /* see xcdRemap */
     uint32_t rawRadius;          /* splat.w is the radius, not 1/radius^2 */
@@ -235,15 +256,17 @@ __device__ __forceinline__ uint32_t xcdRemap(uint32_t id, uint32_t n, uint32_t c
     return g * super + (j % 8) * chunk + j / 8;
 }
 
-template<int SHAPE, bool CULL, bool STATS>
-__global__ __launch_bounds__(512) void processCornersKernel(MlsArgs A)
+/* Variant 1: the reference's loop (kernels/mls.cl:342-390) -- every corner tests every listed splat, 512 staged per round */
+template<int SHAPE, bool STATS>
+__global__ __launch_bounds__(512) void processCornersKernel(Lanes<MlsArgs> lanes)
 {
     __shared__ float4 sPosRad[STAGE];
     __shared__ float4 sNormQ[STAGE];
-    __shared__ uint32_t sMask[STAGE];
 
-    const uint32_t nBlocks = A.blocksX * A.blocksY * A.blocksZ;
-    const uint32_t bid = xcdRemap(blockIdx.x, nBlocks, A.xcdChunk);
+    const MlsArgs &A = lanes.a[blockIdx.y];
+    if (blockIdx.x >= A.numBlocks)
+        return;
+    const uint32_t bid = xcdRemap(blockIdx.x, A.numBlocks, A.xcdChunk);
     const uint32_t gx = bid % A.blocksX, gy = (bid / A.blocksX) % A.blocksY, gz = bid / (A.blocksX * A.blocksY);
     const int wx = (int) (gx * 8), wy = (int) (gy * 8), wz = (int) (gz * 8 + A.zFirst);
     /* makeCode(wid) >> startShift (kernels/mls.cl:318) == makeCode(wid >> subsampling): Morton digits are independent */
@@ -262,8 +285,6 @@ __global__ __launch_bounds__(512) void processCornersKernel(MlsArgs A)
     if (pos >= 0)       /* uniform over the workgroup */
     {
         const float cx = (float) (wx + lx + A.ox), cy = (float) (wy + ly + A.oy), cz = (float) (wz + lz + A.oz);
-        /* corner-coordinate bounds of the two half-blocks per axis, for the cull masks */
-        const float bx0 = (float) (wx + A.ox), by0 = (float) (wy + A.oy), bz0 = (float) (wz + A.oz);
         Fit fit;
         fitInit(fit);
         unsigned long long nListed = 0, nTests = 0;
@@ -273,40 +294,11 @@ __global__ __launch_bounds__(512) void processCornersKernel(MlsArgs A)
             /* stage up to STAGE listed splats (kernels/mls.cl:342-352 stages 256) */
             const int32_t lpos = pos + (int32_t) tid;
             const int32_t mine = lpos < end ? A.commands[lpos] : -1;
-            uint32_t mask = 0;
             if (mine >= 0)
             {
-                const float4 pr = stagedPosRad(A, mine);
-                const float4 nq = A.splats[2 * (int64_t) mine + 1];
-                sPosRad[tid] = pr;
-                sNormQ[tid] = nq;
-                if (CULL)
-                {
-                    /* distance from the splat centre to the corner range [b, b+3] of each half-block,
-                     * per axis; squared and summed with dot3's fma structure (monotone => conservative) */
-                    float d[3][2];
-                    const float p[3] = {pr.x, pr.y, pr.z};
-                    const float b[3] = {bx0, by0, bz0};
-#pragma unroll
-                    for (int a = 0; a < 3; a++)
-#pragma unroll
-                        for (int h = 0; h < 2; h++)
-                        {
-                            const float lo = b[a] + (float) (4 * h), hi = b[a] + (float) (4 * h + 3);
-                            d[a][h] = fmaxf(fmaxf(lo - p[a], p[a] - hi), 0.0f);
-                        }
-#pragma unroll
-                    for (int s = 0; s < 8; s++)
-                    {
-                        const float dx = d[0][s & 1], dy = d[1][(s >> 1) & 1], dz = d[2][s >> 2];
-                        const float dd = dot3(dx, dy, dz, dx, dy, dz) * pr.w;
-                        mask |= (dd < RADIUS_CUTOFF ? 1u : 0u) << s;
-                    }
-                }
-                else
-                    mask = 0xFFu;
+                sPosRad[tid] = stagedPosRad(A, mine);
+                sNormQ[tid] = A.splats[2 * (int64_t) mine + 1];
             }
-            sMask[tid] = mask;
             if (STATS)
                 nListed += __popcll(__ballot(mine >= 0));
             const int32_t staged = min(end - pos, (int32_t) STAGE);
@@ -320,448 +312,26 @@ __global__ __launch_bounds__(512) void processCornersKernel(MlsArgs A)
             }
             __syncthreads();
 
-            for (int32_t g = 0; g < staged; g += 64)
+            for (int32_t i = 0; i < staged; i++)
             {
-                const uint32_t m = sMask[g + lane];      /* entries beyond `staged` hold mask 0 */
-                uint64_t todo = __ballot((m >> wave) & 1u);
-                while (todo != 0)
-                {
-                    const int i = g + (int) __builtin_ctzll(todo);
-                    todo &= todo - 1;
-                    if (STATS)
-                        nTests += 64;
-                    const float4 pr = sPosRad[i];
-                    const float px = pr.x - cx, py = pr.y - cy, pz = pr.z - cz;
-                    const float pp = dot3(px, py, pz, px, py, pz);
-                    const float d = pp * pr.w;
-                    if (d < RADIUS_CUTOFF)
-                    {
-                        const float4 nq = sNormQ[i];
-                        float w = 1.0f - d;
-                        w *= w;
-                        w *= w;
-                        w *= nq.w;
-                        fitAdd(fit, w, px, py, pz, pp, nq.x, nq.y, nq.z);
-                    }
-                }
-            }
-            __syncthreads();
-        }
-        f = finishCorner<SHAPE>(fit, A.boundaryFactor);
-        if (STATS)
-        {
-            const unsigned long long hits = waveSum(fit.hits);
-            if (lane == 0)
-            {
-                atomicAdd(&A.stats[0], nListed);
-                atomicAdd(&A.stats[1], nTests);
-                atomicAdd(&A.stats[2], hits);
-            }
-        }
-    }
-
-    const int64_t row = (int64_t) (wy + ly) + (int64_t) (wz + lz) * A.zStride + A.zBias;
-    A.field[row * (int64_t) A.pitch + (wx + lx)] = f;
-}
-
-/*
- * Variant 2 ("hit lists").  Same staging and sub-block masks as variant 0, but the per-wave visit of a
- * relevant splat only runs the distance test; a lane that is hit appends the splat's staging slot to its
- * own byte list in LDS.  After the round every lane walks ITS list (in order, so the per-corner
- * accumulation order is unchanged) and does the weighted accumulation.  In variant 0 the ~25-instruction
- * accumulation runs for the whole wave whenever any lane is hit, at ~1/6 lane utilisation on uniform data;
- * here it runs max-hits-per-lane times at ~2/3 utilisation.  Results are bit-identical (same operations on
- * the same values in the same order per corner).
- */
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-#define LIST_STAGE 256
-#define LIST_CAP 52        /* bytes per lane; 13 dwords (odd) keeps the per-lane rows on different LDS banks */
-
-template<int SHAPE, bool STATS>
-__global__ __launch_bounds__(512) void processCornersListKernel(MlsArgs A)
-{
-    __shared__ float4 sPosRad[LIST_STAGE];
-    __shared__ float4 sNormQ[LIST_STAGE];
-    __shared__ uint32_t sMask[LIST_STAGE];
-    __shared__ uint8_t sList[512][LIST_CAP];
-
-    const uint32_t nBlocks = A.blocksX * A.blocksY * A.blocksZ;
-    const uint32_t bid = xcdRemap(blockIdx.x, nBlocks, A.xcdChunk);
-    const uint32_t gx = bid % A.blocksX, gy = (bid / A.blocksX) % A.blocksY, gz = bid / (A.blocksX * A.blocksY);
-    const int wx = (int) (gx * 8), wy = (int) (gy * 8), wz = (int) (gz * 8 + A.zFirst);
-    const uint32_t sub = A.startShift / 3;
-    const uint32_t code = spread3((uint32_t) wx >> sub) | (spread3((uint32_t) wy >> sub) << 1) | (spread3((uint32_t) wz >> sub) << 2);
-    int32_t pos = A.start[code];
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t wave = tid >> 6, lane = tid & 63;
-    const int lx = (int) ((wave & 1) * 4 + (lane & 3));
-    const int ly = (int) (((wave >> 1) & 1) * 4 + ((lane >> 2) & 3));
-    const int lz = (int) ((wave >> 2) * 4 + (lane >> 4));
-
-    float f = __int_as_float(0x7FC00000);
-    if (pos >= 0)       /* uniform over the workgroup */
-    {
-        const float cx = (float) (wx + lx + A.ox), cy = (float) (wy + ly + A.oy), cz = (float) (wz + lz + A.oz);
-        const float bx0 = (float) (wx + A.ox), by0 = (float) (wy + A.oy), bz0 = (float) (wz + A.oz);
-        Fit fit;
-        fitInit(fit);
-        unsigned long long nListed = 0, nTests = 0;
-        /* the list is addressed by its 32-bit LDS offset so that the tail lives in one register */
-        typedef __attribute__((address_space(3))) uint8_t LdsByte;
-        LdsByte *const myList = (LdsByte *) sList[tid];
-        LdsByte *const listEnd = myList + LIST_CAP;
-        LdsByte *tail = myList;     /* one past this lane's last listed hit */
-
-        /* The eleven running sums, with the x/y components of sum(w p) and sum(w n) as register pairs: the
-         * pairs match how a staged splat arrives from LDS (float4 = two aligned pairs), so the accumulation is
-         * v_pk_fma_f32 without register shuffles.  Each component is the same IEEE operation as in fitAdd. */
-        f32x2 sWpxy = {0.0f, 0.0f}, sWnxy = {0.0f, 0.0f};
-        const f32x2 cxy = {cx, cy};
-
-        /* accumulate this lane's listed hits, in list order, then empty the list */
-        auto drain = [&]()
-        {
-            const uint32_t cnt = (uint32_t) (tail - myList);
-            const uint32_t most = waveMax(cnt);
-            fit.hits += cnt;
-            for (uint32_t j = 0; j < most; j++)
-            {
-                if (j < cnt)
-                {
-                    const uint32_t i = myList[j];
-                    const float4 pr = sPosRad[i];
-                    const float4 nq = sNormQ[i];
-                    const f32x2 pxy = f32x2{pr.x, pr.y} - cxy;
-                    const float pz = pr.z - cz;
-                    const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
-                    const float d = pp * pr.w;
-                    float w = 1.0f - d;
-                    w *= w;
-                    w *= w;
-                    w *= nq.w;
-                    const f32x2 ww = {w, w};
-                    const f32x2 nxy = {nq.x, nq.y};
-                    const f32x2 wnxy = ww * nxy;
-                    const float wnz = w * nq.z;
-                    fit.sumW = fit.sumW + w;
-                    sWpxy = __builtin_elementwise_fma(ww, pxy, sWpxy);
-                    fit.sumWpz = fmaf(w, pz, fit.sumWpz);
-                    sWnxy = __builtin_elementwise_fma(ww, nxy, sWnxy);
-                    fit.sumWnz = fmaf(w, nq.z, fit.sumWnz);
-                    fit.sumWpp = fmaf(w, pp, fit.sumWpp);
-                    fit.sumWpn = fit.sumWpn + fmaf(wnxy.x, pxy.x, fmaf(wnxy.y, pxy.y, wnz * pz));
-                }
-            }
-            tail = myList;
-        };
-
-        int32_t end = A.commands[pos++];
-        while (pos < end)
-        {
-            uint32_t mask = 0;
-            int32_t mine = -1;
-            if (tid < LIST_STAGE)
-            {
-                const int32_t lpos = pos + (int32_t) tid;
-                mine = lpos < end ? A.commands[lpos] : -1;
-                if (mine >= 0)
-                {
-                    const float4 pr = stagedPosRad(A, mine);
-                    const float4 nq = A.splats[2 * (int64_t) mine + 1];
-                    sPosRad[tid] = pr;
-                    sNormQ[tid] = nq;
-                    float d[3][2];
-                    const float p[3] = {pr.x, pr.y, pr.z};
-                    const float b[3] = {bx0, by0, bz0};
-#pragma unroll
-                    for (int a = 0; a < 3; a++)
-#pragma unroll
-                        for (int h = 0; h < 2; h++)
-                        {
-                            const float lo = b[a] + (float) (4 * h), hi = b[a] + (float) (4 * h + 3);
-                            d[a][h] = fmaxf(fmaxf(lo - p[a], p[a] - hi), 0.0f);
-                        }
-#pragma unroll
-                    for (int s = 0; s < 8; s++)
-                    {
-                        const float dx = d[0][s & 1], dy = d[1][(s >> 1) & 1], dz = d[2][s >> 2];
-                        const float dd = dot3(dx, dy, dz, dx, dy, dz) * pr.w;
-                        mask |= (dd < RADIUS_CUTOFF ? 1u : 0u) << s;
-                    }
-                }
-                sMask[tid] = mask;
-            }
-            if (STATS)
-                nListed += __popcll(__ballot(mine >= 0));
-            const int32_t staged = min(end - pos, (int32_t) LIST_STAGE);
-            pos += LIST_STAGE;
-            if (pos >= end)
-            {
-                pos = A.commands[end];
-                end = (pos >= 0) ? A.commands[pos++] : INT32_MIN;
-            }
-            __syncthreads();
-
-            for (int32_t g = 0; g < staged; g += 64)
-            {
-                const uint32_t m = sMask[g + lane];
-                uint64_t todo = __ballot((m >> wave) & 1u);
-                /* up to four relevant splats between capacity checks; per splat the x/y differences are one
-                 * packed subtract on the pair as it arrives from LDS, the rest scalar -- the same IEEE operations
-                 * as dot3() in the basic kernel */
-                while (todo != 0)
-                {
-                    if (__any(tail + 4 > listEnd))
-                        drain();
-#pragma unroll
-                    for (int k = 0; k < 4; k++)
-                    {
-                        if (todo == 0)
-                            break;
-                        const int i = g + (int) __builtin_ctzll(todo);
-                        todo &= todo - 1;
-                        if (STATS)
-                            nTests += 64;
-                        const float4 a = sPosRad[i];
-                        const f32x2 pxy = f32x2{a.x, a.y} - cxy;
-                        const float pz = a.z - cz;
-                        const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
-                        const float d = pp * a.w;
-                        /* branch-free append: write the slot, keep it only if hit (the next append overwrites it) */
-                        *tail = (uint8_t) i;
-                        tail += hitBit(d);
-                        asm volatile("" : "+v"(tail));      /* keep the tail itself in a register, not base + count */
-                    }
-                }
-            }
-            drain();            /* the lists point into this round's staging buffers */
-            __syncthreads();
-        }
-        fit.sumWpx = sWpxy.x;
-        fit.sumWpy = sWpxy.y;
-        fit.sumWnx = sWnxy.x;
-        fit.sumWny = sWnxy.y;
-        f = finishCorner<SHAPE>(fit, A.boundaryFactor);
-        if (STATS)
-        {
-            const unsigned long long hits = waveSum(fit.hits);
-            if (lane == 0)
-            {
-                atomicAdd(&A.stats[0], nListed);
-                atomicAdd(&A.stats[1], nTests);
-                atomicAdd(&A.stats[2], hits);
-            }
-        }
-    }
-
-    const int64_t row = (int64_t) (wy + ly) + (int64_t) (wz + lz) * A.zStride + A.zBias;
-    A.field[row * (int64_t) A.pitch + (wx + lx)] = f;
-}
-
-
-/*
- * Variant 3 ("hit masks", the default).  The issue-rate microbenchmark of tools/microbench/valu_lds_issue.hip (round 3)
- * prices variant 2: per test a wave pays a 16-byte broadcast read (4 LDS cycles) AND a one-byte list append (4.9); per drain
- * iteration a byte read (2) and two random 16-byte gathers (12.5 each).  This variant takes the append out of LDS: a hit
- * shifts one bit into a per-lane 64-bit mask -- `m = 2 m + hit` as ONE v_alignbit_b32 that shifts in the sign bit of
- * (d - cutoff), see hitBit(); the first version used a compare and an add-with-carry, whose VCC round trip cost 6 % of the
- * kernel -- and the splat behind bit t comes from a 128-byte per-wave table (byte offset of the slot of the t-th test since
- * the last drain), written once per 64-splat group by the lanes that hold the group's relevant splats.  The drain walks the
- * mask's bits from the top (the first test is the highest bit), so the per-corner accumulation order is the list order --
- * bit-identical results.  A round's tests beyond 64 start a new mask after an early drain.  Without the 26 KB of lists a
- * round stages 1024 splats instead of 256 (see MASK_STAGE).
- */
-#ifndef MASK_STAGE
-#define MASK_STAGE 1024
-#endif
-/* Two records per thread and round: 37.9 KB of LDS per workgroup, four workgroups per CU as before.  A block of the
- * BASELINE clouds lists ~700 splats, so most blocks are ONE round -- no second pair of barriers and no forced drain of a
- * half-filled mask in between (measured per step on cfg3: 256-splat rounds 10.25 ms, 512: 9.84, 1024: 9.61). */
-
-template<int SHAPE, bool STATS>
-__global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
-{
-    __shared__ float4 sPosRad[MASK_STAGE];
-    __shared__ float4 sNormQ[MASK_STAGE];
-    __shared__ uint32_t sMask[MASK_STAGE];
-    __shared__ uint16_t sSlot[8][64];       /* per wave: staging slot (as a byte offset) of the t-th test since the last drain */
-
-    const uint32_t nBlocks = A.blocksX * A.blocksY * A.blocksZ;
-    const uint32_t bid = xcdRemap(blockIdx.x, nBlocks, A.xcdChunk);
-    const uint32_t gx = bid % A.blocksX, gy = (bid / A.blocksX) % A.blocksY, gz = bid / (A.blocksX * A.blocksY);
-    const int wx = (int) (gx * 8), wy = (int) (gy * 8), wz = (int) (gz * 8 + A.zFirst);
-    const uint32_t sub = A.startShift / 3;
-    const uint32_t code = spread3((uint32_t) wx >> sub) | (spread3((uint32_t) wy >> sub) << 1) | (spread3((uint32_t) wz >> sub) << 2);
-    int32_t pos = A.start[code];
-
-    const uint32_t tid = threadIdx.x;
-    const uint32_t wave = tid >> 6, lane = tid & 63;
-    const int lx = (int) ((wave & 1) * 4 + (lane & 3));
-    const int ly = (int) (((wave >> 1) & 1) * 4 + ((lane >> 2) & 3));
-    const int lz = (int) ((wave >> 2) * 4 + (lane >> 4));
-
-    float f = __int_as_float(0x7FC00000);
-    if (pos >= 0)       /* uniform over the workgroup */
-    {
-        const float cx = (float) (wx + lx + A.ox), cy = (float) (wy + ly + A.oy), cz = (float) (wz + lz + A.oz);
-        const float bx0 = (float) (wx + A.ox), by0 = (float) (wy + A.oy), bz0 = (float) (wz + A.oz);
-        Fit fit;
-        fitInit(fit);
-        unsigned long long nListed = 0, nTests = 0;
-        typedef __attribute__((address_space(3))) uint16_t LdsSlot;
-        LdsSlot *const mySlots = (LdsSlot *) sSlot[wave];
-        f32x2 sWpxy = {0.0f, 0.0f}, sWnxy = {0.0f, 0.0f};
-        const f32x2 cxy = {cx, cy};
-
-        uint32_t mA = 0, mB = 0;    /* hit bits of tests 0..31 / 32..63 since the last drain, newest in bit 0 */
-        uint32_t nt = 0;            /* tests since the last drain (wave-uniform) */
-
-        /* accumulate this lane's hits in test order, then start afresh */
-        auto drain = [&]()
-        {
-            /* left-align: test t of a word becomes bit 31 - t, so that the leading-zero count is t */
-            const uint32_t nA = nt < 32u ? nt : 32u, nB = nt - nA;
-            uint32_t cur = nA == 0 ? 0u : mA << (32u - nA);
-            uint32_t nxt = nB == 0 ? 0u : mB << (32u - nB);
-            const uint32_t cntA = (uint32_t) __popc(cur), cnt = cntA + (uint32_t) __popc(nxt);
-            const uint32_t most = waveMax(cnt);
-            fit.hits += cnt;
-            LdsSlot *tbl = mySlots;
-            for (uint32_t j = 0; j < most; j++)
-            {
-                if (j < cnt)
-                {
-                    if (j == cntA)
-                    {
-                        cur = nxt;
-                        tbl = mySlots + 32;
-                    }
-                    const uint32_t t = (uint32_t) __builtin_clz(cur);      /* cur != 0: this lane still has a hit to take */
-                    cur ^= 0x80000000u >> t;
-                    const uint32_t off = tbl[t];                   /* the slot's byte offset in both staging arrays */
-                    const float4 pr = *(const float4 *) ((const char *) sPosRad + off);
-                    const float4 nq = *(const float4 *) ((const char *) sNormQ + off);
-                    const f32x2 pxy = f32x2{pr.x, pr.y} - cxy;
-                    const float pz = pr.z - cz;
-                    const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
-                    const float d = pp * pr.w;
-                    float w = 1.0f - d;
-                    w *= w;
-                    w *= w;
-                    w *= nq.w;
-                    const f32x2 ww = {w, w};
-                    const f32x2 nxy = {nq.x, nq.y};
-                    const f32x2 wnxy = ww * nxy;
-                    const float wnz = w * nq.z;
-                    fit.sumW = fit.sumW + w;
-                    sWpxy = __builtin_elementwise_fma(ww, pxy, sWpxy);
-                    fit.sumWpz = fmaf(w, pz, fit.sumWpz);
-                    sWnxy = __builtin_elementwise_fma(ww, nxy, sWnxy);
-                    fit.sumWnz = fmaf(w, nq.z, fit.sumWnz);
-                    fit.sumWpp = fmaf(w, pp, fit.sumWpp);
-                    fit.sumWpn = fit.sumWpn + fmaf(wnxy.x, pxy.x, fmaf(wnxy.y, pxy.y, wnz * pz));
-                }
-            }
-            mA = mB = 0;
-            nt = 0;
-        };
-
-        int32_t end = A.commands[pos++];
-        while (pos < end)
-        {
-#pragma unroll
-            for (int part = 0; part < MASK_STAGE / 512; part++)
-            {
-                const uint32_t slot = tid + 512u * (uint32_t) part;
-                uint32_t mask = 0;
-                const int32_t lpos = pos + (int32_t) slot;
-                const int32_t mine = lpos < end ? A.commands[lpos] : -1;
-                if (mine >= 0)
-                {
-                    const float4 pr = stagedPosRad(A, mine);
-                    const float4 nq = A.splats[2 * (int64_t) mine + 1];
-                    sPosRad[slot] = pr;
-                    sNormQ[slot] = nq;
-                    float d[3][2];
-                    const float p[3] = {pr.x, pr.y, pr.z};
-                    const float b[3] = {bx0, by0, bz0};
-#pragma unroll
-                    for (int a = 0; a < 3; a++)
-#pragma unroll
-                        for (int h = 0; h < 2; h++)
-                        {
-                            const float lo = b[a] + (float) (4 * h), hi = b[a] + (float) (4 * h + 3);
-                            d[a][h] = fmaxf(fmaxf(lo - p[a], p[a] - hi), 0.0f);
-                        }
-#pragma unroll
-                    for (int s_ = 7; s_ >= 0; s_--)
-                    {
-                        const float dx = d[0][s_ & 1], dy = d[1][(s_ >> 1) & 1], dz = d[2][s_ >> 2];
-                        const float dd = dot3(dx, dy, dz, dx, dy, dz) * pr.w;
-                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(dd - RADIUS_CUTOFF), 31);   /* hitBit(dd) */
-                    }
-                }
-                sMask[slot] = mask;
                 if (STATS)
-                    nListed += __popcll(__ballot(mine >= 0));
-            }
-            const int32_t staged = min(end - pos, (int32_t) MASK_STAGE);
-            pos += MASK_STAGE;
-            if (pos >= end)
-            {
-                pos = A.commands[end];
-                end = (pos >= 0) ? A.commands[pos++] : INT32_MIN;
-            }
-            __syncthreads();
-
-            for (int32_t g = 0; g < staged; g += 64)
-            {
-                const uint32_t m = sMask[g + lane];
-                uint64_t todo = __ballot((m >> wave) & 1u);
-                const uint32_t nGroup = (uint32_t) __popcll(todo);
-                if (nGroup == 0)
-                    continue;
-                if (nt + nGroup > 64u)
-                    drain();
-                /* the lanes holding the group's relevant splats note which test each of them will be */
-                if ((todo >> lane) & 1ull)
-                    mySlots[nt + popcBelow(todo)] = (uint16_t) ((g + (int32_t) lane) * (int32_t) sizeof(float4));
-                /* tests 0..31 since the last drain go to mA, 32..63 to mB; a group may straddle the two */
-                uint32_t left = nGroup;
-                while (left != 0)
+                    nTests += 64;
+                const float4 pr = sPosRad[i];
+                const float px = pr.x - cx, py = pr.y - cy, pz = pr.z - cz;
+                const float pp = dot3(px, py, pz, px, py, pz);
+                const float d = pp * pr.w;
+                if (d < RADIUS_CUTOFF)
                 {
-                    const bool first = nt < 32u;
-                    const uint32_t room = first ? 32u - nt : 64u - nt;
-                    const uint32_t take = left < room ? left : room;
-                    uint32_t acc = first ? mA : mB;
-#pragma unroll 4
-                    for (uint32_t k = 0; k < take; k++)
-                    {
-                        const int i = g + (int) __builtin_ctzll(todo);
-                        todo &= todo - 1;
-                        const float4 a = sPosRad[i];
-                        const f32x2 pxy = f32x2{a.x, a.y} - cxy;
-                        const float pz = a.z - cz;
-                        const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
-                        const float d = pp * a.w;
-                        /* acc = 2 acc + hit: the difference's sign bit shifted in by one v_alignbit_b32 (see hitBit) */
-                        acc = __builtin_amdgcn_alignbit(acc, __float_as_uint(d - RADIUS_CUTOFF), 31);
-                    }
-                    if (STATS)
-                        nTests += 64ull * take;
-                    nt += take;
-                    left -= take;
-                    if (first) mA = acc; else mB = acc;
+                    const float4 nq = sNormQ[i];
+                    float w = 1.0f - d;
+                    w *= w;
+                    w *= w;
+                    w *= nq.w;
+                    fitAdd(fit, w, px, py, pz, pp, nq.x, nq.y, nq.z);
                 }
             }
-            drain();            /* the table points into this round's staging buffers */
             __syncthreads();
         }
-        fit.sumWpx = sWpxy.x;
-        fit.sumWpy = sWpxy.y;
-        fit.sumWnx = sWnxy.x;
-        fit.sumWny = sWnxy.y;
         f = finishCorner<SHAPE>(fit, A.boundaryFactor);
         if (STATS)
         {
@@ -778,6 +348,8 @@ __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
     const int64_t row = (int64_t) (wy + ly) + (int64_t) (wz + lz) * A.zStride + A.zBias;
     A.field[row * (int64_t) A.pitch + (wx + lx)] = f;
 }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 /*
  * Variant 4 ("cube streams").  What is left of variant 3's time is vector work, and more than half of its vector
@@ -795,7 +367,7 @@ __global__ __launch_bounds__(512) void processCornersMaskKernel(MlsArgs A)
 #define CUBE_STAGE 512      /* measured per step on cfg3: 512-splat rounds 8.25 ms, 768: 8.36; 25.5 KB of LDS per workgroup */
 
 template<int SHAPE, bool STATS>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void processCornersCubeKernel(MlsArgs A)
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void processCornersCubeKernel(Lanes<MlsArgs> lanes)
 {
     __shared__ float4 sPosRad[CUBE_STAGE];
     __shared__ float4 sNormQ[CUBE_STAGE];
@@ -804,8 +376,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                 * of 64 staged splats adds beyond a full window */
     __shared__ uint16_t sList[8][8][64];       /* per wave and cube: byte offsets of the splats that can reach the cube */
 
-    const uint32_t nBlocks = A.blocksX * A.blocksY * A.blocksZ;
-    const uint32_t bid = xcdRemap(blockIdx.x, nBlocks, A.xcdChunk);
+    const MlsArgs &A = lanes.a[blockIdx.y];
+    if (blockIdx.x >= A.numBlocks)
+        return;
+    const uint32_t bid = xcdRemap(blockIdx.x, A.numBlocks, A.xcdChunk);
     const uint32_t gx = bid % A.blocksX, gy = (bid / A.blocksX) % A.blocksY, gz = bid / (A.blocksX * A.blocksY);
     const int wx = (int) (gx * 8), wy = (int) (gy * 8), wz = (int) (gz * 8 + A.zFirst);
     const uint32_t sub = A.startShift / 3;
@@ -910,6 +484,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     const float dd = dot3(dx, dy, dz, dx, dy, dz) * pr.w;
                     fine = __builtin_amdgcn_alignbit(fine, __float_as_uint(dd - RADIUS_CUTOFF), 31);   /* hitBit(dd) */
                 }
+                if (splatNeverCulled(pr))
+                    fine = 0xFFu;
             }
             /* 2. the cubes' lists, in window order */
             uint32_t myCnt = 0, maxCnt = 0;
@@ -989,6 +565,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                         const float dd = dot3(dx, dy, dz, dx, dy, dz) * pr.w;
                         mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(dd - RADIUS_CUTOFF), 31);   /* hitBit(dd) */
                     }
+                    if (splatNeverCulled(pr))
+                        mask = 0xFFu;
+                    if (splatIsNan(pr))
+                        mask = 0;       /* no corner accepts it (see hitBit): it never enters a window */
                 }
                 sMask[slot] = (uint8_t) mask;
                 if (STATS)
@@ -1115,7 +695,8 @@ MLSGPU_API int mlsgpu_hip_mls_set_boundary_limit(mlsgpu_mls *m, float limit)
 
 MLSGPU_API int mlsgpu_hip_mls_set_variant(mlsgpu_mls *m, int variant)
 {
-    REQUIRE(m != nullptr && variant >= 0 && variant <= 4, MLSGPU_ERR_INVALID);
+    /* 4 = cube streams (default), 1 = the reference's structure; 0, 2 and 3 were intermediate designs of rounds 1-3 */
+    REQUIRE(m != nullptr && (variant == 1 || variant == 4), MLSGPU_ERR_INVALID);
     m->variant = variant;
     return MLSGPU_OK;
 }
@@ -1127,8 +708,8 @@ MLSGPU_API int mlsgpu_hip_mls_set_stats(mlsgpu_mls *m, uint64_t *dCounters)
     return MLSGPU_OK;
 }
 
-MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pitch, uint64_t fieldRows,
-                                      const mlsgpu_swathe *sw)
+/* MlsFunctor::enqueue's checks (src/mls.cpp:108-116) and one lane's kernel arguments */
+static int mlsLaneArgs(mlsgpu_mls *m, float *dField, uint64_t pitch, uint64_t fieldRows, const mlsgpu_swathe *sw, MlsArgs *out)
 {
     REQUIRE(m != nullptr && dField != nullptr && sw != nullptr, MLSGPU_ERR_INVALID);
     REQUIRE(m->isSet, MLSGPU_ERR_INVALID);
@@ -1147,9 +728,6 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
     const uint32_t sub = m->startShift / 3;
     REQUIRE(((sw->zFirst + 8 * blocksZ - 1) >> sub) < 1024 && ((width - 1) >> sub) < 1024 && ((height - 1) >> sub) < 1024,
             MLSGPU_ERR_LENGTH);
-
-    mlsgpu_ctx *ctx = m->ctx;
-    HIP_CHECK(hipSetDevice(ctx->device));
     MlsArgs A;
     A.field = dField;
     A.pitch = pitch;
@@ -1164,6 +742,7 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
     A.blocksX = width / 8;
     A.blocksY = height / 8;
     A.blocksZ = blocksZ;
+    A.numBlocks = A.blocksX * A.blocksY * A.blocksZ;
     A.boundaryFactor = m->boundaryFactor;
     /* measured on cfg3 (ms per step shells / noise cloud, HBM fetch per launch on the noise cloud):
      *   one contiguous eighth per XCD 12.5 / 10.6, 424 MB;  runs of 4: 9.5 / 10.5, 700 MB;  16: 9.5 / 10.5, 624 MB;
@@ -1173,10 +752,31 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
     static const uint32_t xcdChunk = getenv("MLSGPU_HIP_MLS_XCD_CHUNK") ? (uint32_t) atoi(getenv("MLSGPU_HIP_MLS_XCD_CHUNK")) : 16u;
     A.xcdChunk = xcdChunk;
     A.rawRadius = m->rawRadius ? 1u : 0u;
-    const dim3 grid(A.blocksX * A.blocksY * A.blocksZ), block(512);
-    const char *stat = "kernel.mls.processCorners.time";      /* src/mls.cpp:57 */
     A.stats = m->dStats;
-#define MLS_LAUNCH(SHAPE, CULL, STATS) LAUNCH(ctx, stat, (processCornersKernel<SHAPE, CULL, STATS>), grid, block, A)
+    *out = A;
+    return MLSGPU_OK;
+}
+
+/* MlsFunctor::enqueue for the buckets of a batch: one launch, blockIdx.y = bucket.  The functors share a context, the
+ * shape, the kernel variant and whether work counters are collected (the first functor's settings select the kernel). */
+static int mlsEnqueueLanes(mlsgpu_mls *const *ms, const MlsArgs *args, uint32_t count)
+{
+    mlsgpu_mls *const m = ms[0];
+    mlsgpu_ctx *ctx = m->ctx;
+    for (uint32_t k = 1; k < count; k++)
+        REQUIRE(ms[k]->ctx == ctx && ms[k]->shape == m->shape && ms[k]->variant == m->variant
+                && (ms[k]->dStats != nullptr) == (m->dStats != nullptr), MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    Lanes<MlsArgs> L;
+    uint32_t maxBlocks = 0;
+    for (uint32_t k = 0; k < MAX_LANES; k++)
+    {
+        L.a[k] = args[k < count ? k : 0];
+        if (k < count)
+            maxBlocks = std::max(maxBlocks, L.a[k].numBlocks);
+    }
+    const dim3 grid(maxBlocks, count), block(512);
+    const char *stat = "kernel.mls.processCorners.time";      /* src/mls.cpp:57 */
     /* tuning aid: dynamic LDS that the kernel never touches lowers its occupancy (3 workgroups per CU from 8 KB, 2 from
      * 20 KB), leaving wave slots to the memory-bound kernels of the other device workers */
     static const uint32_t ldsPad = [] {
@@ -1185,42 +785,40 @@ MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pit
         const long v = e ? atol(e) : 0;
         return (uint32_t) (v < 0 ? 0 : (v > 120 * 1024 ? 120 * 1024 : v));
     }();
-#define MLS_LAUNCH_LIST(SHAPE, STATS) LAUNCH_LDS(ctx, stat, (processCornersListKernel<SHAPE, STATS>), grid, block, ldsPad, A)
-    const bool sphere = m->shape == MLSGPU_SHAPE_SPHERE, cull = m->variant == 0;
-#define MLS_LAUNCH_MASK(SHAPE, STATS) LAUNCH_LDS(ctx, stat, (processCornersMaskKernel<SHAPE, STATS>), grid, block, ldsPad, A)
-#define MLS_LAUNCH_CUBE(SHAPE, STATS) LAUNCH_LDS(ctx, stat, (processCornersCubeKernel<SHAPE, STATS>), grid, block, ldsPad, A)
+    const bool sphere = m->shape == MLSGPU_SHAPE_SPHERE, stats = m->dStats != nullptr;    /* stats: an instrumented build,
+                                                                                            * never in a timed run */
+#define MLS_LAUNCH(KERNEL, SHAPE, STATS) LAUNCH_LDS(ctx, stat, (KERNEL<SHAPE, STATS>), grid, block, ldsPad, L)
+#define MLS_LAUNCH_ANY(KERNEL)                                                                                   \
+    do {                                                                                                         \
+        if (stats) { if (sphere) MLS_LAUNCH(KERNEL, MLSGPU_SHAPE_SPHERE, true); else MLS_LAUNCH(KERNEL, MLSGPU_SHAPE_PLANE, true); } \
+        else { if (sphere) MLS_LAUNCH(KERNEL, MLSGPU_SHAPE_SPHERE, false); else MLS_LAUNCH(KERNEL, MLSGPU_SHAPE_PLANE, false); }     \
+    } while (0)
     if (m->variant == 4)
-    {
-        if (m->dStats != nullptr) { if (sphere) MLS_LAUNCH_CUBE(MLSGPU_SHAPE_SPHERE, true); else MLS_LAUNCH_CUBE(MLSGPU_SHAPE_PLANE, true); }
-        else { if (sphere) MLS_LAUNCH_CUBE(MLSGPU_SHAPE_SPHERE, false); else MLS_LAUNCH_CUBE(MLSGPU_SHAPE_PLANE, false); }
-    }
+        MLS_LAUNCH_ANY(processCornersCubeKernel);
     else
-    if (m->variant == 3)
-    {
-        if (m->dStats != nullptr) { if (sphere) MLS_LAUNCH_MASK(MLSGPU_SHAPE_SPHERE, true); else MLS_LAUNCH_MASK(MLSGPU_SHAPE_PLANE, true); }
-        else { if (sphere) MLS_LAUNCH_MASK(MLSGPU_SHAPE_SPHERE, false); else MLS_LAUNCH_MASK(MLSGPU_SHAPE_PLANE, false); }
-    }
-    else if (m->variant == 2)
-    {
-        if (m->dStats != nullptr) { if (sphere) MLS_LAUNCH_LIST(MLSGPU_SHAPE_SPHERE, true); else MLS_LAUNCH_LIST(MLSGPU_SHAPE_PLANE, true); }
-        else { if (sphere) MLS_LAUNCH_LIST(MLSGPU_SHAPE_SPHERE, false); else MLS_LAUNCH_LIST(MLSGPU_SHAPE_PLANE, false); }
-    }
-    else if (m->dStats != nullptr)
-    {
-        /* instrumented build: only reachable through mlsgpu_hip_mls_set_stats, never in a timed run */
-        if (sphere) { if (cull) MLS_LAUNCH(MLSGPU_SHAPE_SPHERE, true, true); else MLS_LAUNCH(MLSGPU_SHAPE_SPHERE, false, true); }
-        else { if (cull) MLS_LAUNCH(MLSGPU_SHAPE_PLANE, true, true); else MLS_LAUNCH(MLSGPU_SHAPE_PLANE, false, true); }
-    }
-    else
-    {
-        if (sphere) { if (cull) MLS_LAUNCH(MLSGPU_SHAPE_SPHERE, true, false); else MLS_LAUNCH(MLSGPU_SHAPE_SPHERE, false, false); }
-        else { if (cull) MLS_LAUNCH(MLSGPU_SHAPE_PLANE, true, false); else MLS_LAUNCH(MLSGPU_SHAPE_PLANE, false, false); }
-    }
+        MLS_LAUNCH_ANY(processCornersKernel);
+#undef MLS_LAUNCH_ANY
 #undef MLS_LAUNCH
-#undef MLS_LAUNCH_LIST
-#undef MLS_LAUNCH_MASK
-#undef MLS_LAUNCH_CUBE
     return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_mls_enqueue(mlsgpu_mls *m, float *dField, uint64_t pitch, uint64_t fieldRows,
+                                      const mlsgpu_swathe *sw)
+{
+    MlsArgs A;
+    PROPAGATE(mlsLaneArgs(m, dField, pitch, fieldRows, sw, &A));
+    return mlsEnqueueLanes(&m, &A, 1);
+}
+
+MLSGPU_API int mlsgpu_hip_mls_enqueue_batch(mlsgpu_mls *const *ms, float *const *dFields, const uint64_t *pitches,
+                                            const uint64_t *fieldRows, const mlsgpu_swathe *swathes, uint32_t count)
+{
+    REQUIRE(ms != nullptr && dFields != nullptr && pitches != nullptr && swathes != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(count >= 1 && count <= MLSGPU_MAX_BATCH, MLSGPU_ERR_LENGTH);
+    MlsArgs args[MAX_LANES];
+    for (uint32_t k = 0; k < count; k++)
+        PROPAGATE(mlsLaneArgs(ms[k], dFields[k], pitches[k], fieldRows != nullptr ? fieldRows[k] : UINT64_MAX, &swathes[k], &args[k]));
+    return mlsEnqueueLanes(ms, args, count);
 }
 
 static int mlsGeneratorEnqueue(void *user, void *stream, float *dField, uint64_t pitch, const mlsgpu_swathe *swathe)
@@ -1237,6 +835,23 @@ MLSGPU_API int mlsgpu_hip_mls_generator(mlsgpu_mls *m, mlsgpu_generator *gen)
     gen->alignment[0] = gen->alignment[1] = gen->alignment[2] = 8;   /* MlsFunctor::wgs, src/mls.cpp:53 */
     gen->enqueue = mlsGeneratorEnqueue;
     gen->user = m;
+    return MLSGPU_OK;
+}
+
+/* the MlsFunctor behind a generator made by mlsgpu_hip_mls_generator, or NULL: Marching's batched generate launches
+ * processCorners for all its buckets at once when every generator is one */
+MLSGPU_API mlsgpu_mls *mlsgpu_hip_mls_of_generator(const mlsgpu_generator *gen)
+{
+    return gen != nullptr && gen->enqueue == mlsGeneratorEnqueue ? static_cast<mlsgpu_mls *>(gen->user) : nullptr;
+}
+
+/* kernel variant, work counters and boundary limit of `src` for `dst` (the lanes of a batched worker follow lane 0) */
+MLSGPU_API int mlsgpu_hip_mls_copy_settings(mlsgpu_mls *dst, const mlsgpu_mls *src)
+{
+    REQUIRE(dst != nullptr && src != nullptr && dst->shape == src->shape, MLSGPU_ERR_INVALID);
+    dst->variant = src->variant;
+    dst->dStats = src->dStats;
+    dst->boundaryFactor = src->boundaryFactor;
     return MLSGPU_OK;
 }
 

@@ -226,59 +226,105 @@ enum
     ENT_BIN_BITS = 8                /* the fused pass handles digits of up to 8 bits */
 };
 
-__global__ __launch_bounds__(ENT_TILE) void entryHistKernel(EntryParams P, uint8_t *slotMasks, uint32_t *hist, uint32_t numTiles,
-                                                            uint64_t n, uint32_t digitBits)
+struct EntryHistArgs
 {
+    EntryParams P;
+    uint8_t *slotMasks;
+    uint32_t *hist;
+    uint32_t numTiles;
+    uint64_t n;
+};
+
+__global__ __launch_bounds__(ENT_TILE) void entryHistKernel(Lanes<EntryHistArgs> lanes, uint32_t digitBits)
+{
+    const EntryHistArgs &A = lanes.a[blockIdx.y];
+    if (blockIdx.x >= A.numTiles)
+        return;
     __shared__ uint32_t bins[1 << ENT_BIN_BITS];
     const uint32_t numBins = 1u << digitBits, dmask = numBins - 1;
     for (uint32_t d = threadIdx.x; d < numBins; d += ENT_TILE)
         bins[d] = 0;
     __syncthreads();
     const uint64_t i = (uint64_t) blockIdx.x * ENT_TILE + threadIdx.x;
-    if (i < n)
+    if (i < A.n)
     {
-        const float4 pr = reinterpret_cast<const float4 *>(P.splats + (i + P.firstSplat))[0];
+        const float4 pr = reinterpret_cast<const float4 *>(A.P.splats + (i + A.P.firstSplat))[0];
         uint32_t k[8];
-        const uint32_t mask = splatEntries(P, pr, k);
-        slotMasks[i] = (uint8_t) mask;
+        const uint32_t mask = splatEntries(A.P, pr, k);
+        A.slotMasks[i] = (uint8_t) mask;
 #pragma unroll
         for (int o = 0; o < 8; o++)
             if (mask & (1u << o))
                 atomicAdd(&bins[k[o] & dmask], 1u);
     }
     __syncthreads();
+    uint32_t *const hist = A.hist;
+    const uint32_t numTiles = A.numTiles;
     for (uint32_t d = threadIdx.x; d < numBins; d += ENT_TILE)
         hist[(uint64_t) d * numTiles + blockIdx.x] = bins[d];
 }
 
-/* the number of entries = the sum of the digit totals */
-__global__ __launch_bounds__(256) void entryTotalKernel(const uint32_t *digitTotals, uint32_t numBins, uint32_t *total,
+struct EntryTotalArgs
+{
+    const uint32_t *digitTotals;
+    uint32_t *total;
+};
+
+/* the number of entries = the sum of the digit totals; one workgroup adds up every lane's in turn */
+__global__ __launch_bounds__(256) void entryTotalKernel(Lanes<EntryTotalArgs> lanes, uint32_t count, uint32_t numBins,
                                                         uint32_t *box, uint32_t seq)
 {
     __shared__ uint32_t waveTotals[4];
-    uint32_t v = 0;
-    for (uint32_t d = threadIdx.x; d < numBins; d += 256)
-        v += digitTotals[d];
-    v = waveSum(v);
-    if ((threadIdx.x & 63) == 0)
-        waveTotals[threadIdx.x >> 6] = v;
-    __syncthreads();
+    for (uint32_t k = 0; k < count; k++)
+    {
+        const uint32_t *const digitTotals = lanes.a[k].digitTotals;
+        uint32_t v = 0;
+        for (uint32_t d = threadIdx.x; d < numBins; d += 256)
+            v += digitTotals[d];
+        v = waveSum(v);
+        if ((threadIdx.x & 63) == 0)
+            waveTotals[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            const uint32_t sum = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
+            *lanes.a[k].total = sum;
+            /* ... and straight to the host (HostMailbox): the count sizes the launches that follow */
+            __hip_atomic_store(box + 1 + k, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == 0)
     {
-        const uint32_t sum = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
-        *total = sum;
-        /* ... and straight to the host (HostMailbox): the count sizes the launches that follow */
-        __hip_atomic_store(box + 1, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __threadfence_system();
         __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
-__global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void entryScatterKernel(EntryParams P, const uint8_t *slotMasks, const uint32_t *hist,
-                                                               const uint32_t *digitTotals, uint32_t numTiles, uint64_t n,
-                                                               uint32_t digitBits, uint32_t *keysOut, uint32_t *valsOut)
+struct EntryScatterArgs
+{
+    EntryParams P;
+    const uint8_t *slotMasks;
+    const uint32_t *hist;
+    const uint32_t *digitTotals;
+    uint32_t numTiles;
+    uint64_t n;
+    uint32_t *keysOut, *valsOut;
+};
+
+__global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void entryScatterKernel(Lanes<EntryScatterArgs> lanes, uint32_t digitBits)
 {
     enum { BINS = 1 << ENT_BIN_BITS, WAVES = ENT_TILE / 64, MAX_ROUNDS = ENT_CAP / ENT_TILE };
+    const EntryScatterArgs &A = lanes.a[blockIdx.y];
+    if (blockIdx.x >= A.numTiles)
+        return;
+    const EntryParams &P = A.P;
+    const uint8_t *const slotMasks = A.slotMasks;
+    const uint32_t *const hist = A.hist;
+    const uint32_t *const digitTotals = A.digitTotals;
+    const uint32_t numTiles = A.numTiles;
+    const uint64_t n = A.n;
+    uint32_t *const keysOut = A.keysOut, *const valsOut = A.valsOut;
     __shared__ uint32_t waveBins[WAVES][BINS];
     __shared__ uint32_t tileBase[BINS];
     __shared__ uint32_t waveTotals[WAVES], waveTotalsAll[WAVES], waveCnt[WAVES];
@@ -507,10 +553,18 @@ struct SplatIdsOut
  * or -1.  start[] of a non-empty node is written by writeSplatIds and never changes, so every node
  * can fetch it independently.
  */
-__global__ __launch_bounds__(256) void writeStartKernel(int32_t *start, int32_t *commands, const int32_t *jumpPos,
-                                                        LevelOffsets levelOffsets, int minShift, int maxShift,
-                                                        uint32_t numStart)
+struct WriteStartArgs
 {
+    int32_t *start, *commands;
+    const int32_t *jumpPos;
+};
+
+__global__ __launch_bounds__(256) void writeStartKernel(Lanes<WriteStartArgs> lanes, LevelOffsets levelOffsets, int minShift,
+                                                        int maxShift, uint32_t numStart)
+{
+    const WriteStartArgs &A = lanes.a[blockIdx.y];
+    int32_t *const start = A.start, *const commands = A.commands;
+    const int32_t *const jumpPos = A.jumpPos;
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= numStart)
         return;
@@ -537,6 +591,14 @@ __global__ __launch_bounds__(256) void writeStartKernel(int32_t *start, int32_t 
     }
     else
         start[p] = prev;
+}
+
+/* fill(jumpPos, -1), kernels/octree.cl:346, for every lane */
+__global__ __launch_bounds__(256) void fillKernel(Lanes<int32_t *> lanes, uint32_t n, int32_t value)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n)
+        lanes.a[blockIdx.y][i] = value;
 }
 
 __global__ void testHelpersKernel(int op, const int32_t *iargs, const float *fargs, uint32_t *out)
@@ -647,19 +709,32 @@ MLSGPU_API void mlsgpu_hip_tree_destroy(mlsgpu_tree *t)
     delete t;
 }
 
-MLSGPU_API int mlsgpu_hip_tree_build(mlsgpu_tree *t, mlsgpu_splat *dSplats, uint64_t firstSplat, uint64_t numSplats,
-                                     const uint32_t size[3], const int32_t offset[3], uint32_t subsamplingShift)
+/* SplatTreeCL::enqueueBuild (src/splat_tree_cl.cpp:269-335) for the buckets of a batch in lock-step: the trees (one per
+ * lane, same levels, one context) are built by ONE set of launches whose workgroups pick their lane by blockIdx.y; the
+ * entry counts of all lanes come back through one mailbox publication.  A single build is a batch of one. */
+static int treeBuildBatch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *reqs, uint32_t count, uint32_t subsamplingShift)
 {
-    REQUIRE(t != nullptr && dSplats != nullptr && size != nullptr && offset != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(trees != nullptr && reqs != nullptr && count >= 1 && count <= MAX_LANES, MLSGPU_ERR_INVALID);
+    mlsgpu_tree *const t0 = trees[0];
+    REQUIRE(t0 != nullptr, MLSGPU_ERR_INVALID);
+    mlsgpu_ctx *ctx = t0->ctx;
     /* src/splat_tree_cl.cpp:277-281 */
-    REQUIRE(numSplats <= t->maxSplats, MLSGPU_ERR_LENGTH);
-    REQUIRE(firstSplat < 0xFFFFFFFFull - numSplats, MLSGPU_ERR_LENGTH);
-    REQUIRE(t->maxLevels + subsamplingShift - 1 < 31, MLSGPU_ERR_LENGTH);
-    const uint32_t maxSize = 1u << (t->maxLevels + subsamplingShift - 1);
-    REQUIRE(size[0] <= maxSize && size[1] <= maxSize && size[2] <= maxSize, MLSGPU_ERR_LENGTH);
-    const int maxShift = (int) (t->maxLevels + subsamplingShift - 1);
+    REQUIRE(t0->maxLevels + subsamplingShift - 1 < 31, MLSGPU_ERR_LENGTH);
+    const uint32_t maxSize = 1u << (t0->maxLevels + subsamplingShift - 1);
+    for (uint32_t k = 0; k < count; k++)
+    {
+        const mlsgpu_tree *t = trees[k];
+        const mlsgpu_tree_build &r = reqs[k];
+        REQUIRE(t != nullptr && r.dSplats != nullptr, MLSGPU_ERR_INVALID);
+        REQUIRE(t->ctx == ctx && t->maxLevels == t0->maxLevels, MLSGPU_ERR_INVALID);
+        for (uint32_t j = 0; j < k; j++)
+            REQUIRE(trees[j] != t, MLSGPU_ERR_INVALID);
+        REQUIRE(r.numSplats <= t->maxSplats, MLSGPU_ERR_LENGTH);
+        REQUIRE(r.firstSplat < 0xFFFFFFFFull - r.numSplats, MLSGPU_ERR_LENGTH);
+        REQUIRE(r.size[0] <= maxSize && r.size[1] <= maxSize && r.size[2] <= maxSize, MLSGPU_ERR_LENGTH);
+    }
+    const int maxShift = (int) (t0->maxLevels + subsamplingShift - 1);
     const int minShift = (int) subsamplingShift < maxShift ? (int) subsamplingShift : maxShift;
-    mlsgpu_ctx *ctx = t->ctx;
     HIP_CHECK(hipSetDevice(ctx->device));
 
     LevelOffsets lo;
@@ -671,68 +746,151 @@ MLSGPU_API int mlsgpu_hip_tree_build(mlsgpu_tree *t, mlsgpu_splat *dSplats, uint
         pos += uint64_t(1) << (3 * (maxShift - i));
     }
     const uint32_t numStart = (uint32_t) pos;
-    REQUIRE(numStart <= t->maxStart, MLSGPU_ERR_LENGTH);
-    t->numLevels = (uint32_t) (maxShift - minShift + 1);
-    t->dSplats = dSplats;
+    const uint32_t keyBits = (uint32_t) (3 * (maxShift - minShift) + 1);
+    const uint32_t passes = sortPasses(keyBits, SortCaps<uint32_t>::MAX_DIGIT_BITS);
+    const uint32_t perPass = (keyBits + passes - 1) / passes;
+    static const bool fusedOff = getenv("MLSGPU_HIP_OCTREE_FUSED") != nullptr && atoi(getenv("MLSGPU_HIP_OCTREE_FUSED")) == 0;
+    const bool fused = perPass <= ENT_BIN_BITS && !fusedOff;      /* wider digits (deep trees) take the separate passes */
 
-    /* fill(jumpPos, -1), kernels/octree.cl:346 */
+    Lanes<int32_t *> jump;
+    Lanes<WriteStartArgs> ws;
+    for (uint32_t k = 0; k < MAX_LANES; k++)
     {
-        int pend = -1;
-        if (ctx->timing) pend = ctx->beginTiming(ctx->statId("kernel.octree.fill.time"));
-        HIP_CHECK(hipMemsetAsync(t->dJumpPos, 0xFF, (size_t) numStart * 4, ctx->stream));
-        if (pend >= 0) ctx->endTiming(pend);
+        mlsgpu_tree *t = trees[k < count ? k : 0];
+        if (k < count)
+        {
+            REQUIRE(numStart <= t->maxStart, MLSGPU_ERR_LENGTH);
+            t->numLevels = (uint32_t) (maxShift - minShift + 1);
+            t->dSplats = reqs[k].dSplats;
+        }
+        jump.a[k] = t->dJumpPos;
+        ws.a[k] = WriteStartArgs{t->dStart, t->dCommands, t->dJumpPos};
     }
-    if (numSplats > 0)
+    /* fill(jumpPos, -1), kernels/octree.cl:346 */
+    LAUNCH(ctx, "kernel.octree.fill.time", fillKernel, dim3(divUp(numStart, 256), count), dim3(256), jump, numStart, (int32_t) -1);
+
+    /* the lanes that hold splats */
+    uint32_t act[MAX_LANES], na = 0;
+    for (uint32_t k = 0; k < count; k++)
+        if (reqs[k].numSplats > 0)
+            act[na++] = k;
+    if (na > 0)
     {
-        EntryParams P{dSplats, offset[0], offset[1], offset[2], lo, minShift, maxShift, (uint32_t) firstSplat, t->mutate ? 1u : 0u};
-        const uint32_t keyBits = (uint32_t) (3 * (maxShift - minShift) + 1);
-        const uint32_t passes = sortPasses(keyBits, SortCaps<uint32_t>::MAX_DIGIT_BITS);
-        const uint32_t perPass = (keyBits + passes - 1) / passes;
-        static const bool fusedOff = getenv("MLSGPU_HIP_OCTREE_FUSED") != nullptr && atoi(getenv("MLSGPU_HIP_OCTREE_FUSED")) == 0;
-        const bool fused = perPass <= ENT_BIN_BITS && !fusedOff;      /* wider digits (deep trees) take the separate passes */
-        uint64_t sortN = 0;
-        SortResult<uint32_t> sorted;
+        auto params = [&](uint32_t k) {
+            const mlsgpu_tree_build &r = reqs[k];
+            return EntryParams{r.dSplats, r.offset[0], r.offset[1], r.offset[2], lo, minShift, maxShift, (uint32_t) r.firstSplat,
+                               trees[k]->mutate ? 1u : 0u};
+        };
+        SortJob<uint32_t> sortJobs[MAX_LANES];
+        uint64_t sortN[MAX_LANES];
         if (fused)
         {
             /* writeEntries + the sort's first pass as one count / digit scan / scatter, see entryScatterKernel */
             const char *stat = "kernel.octree.writeEntries.time";
-            const uint32_t tilesE = divUp(numSplats, ENT_TILE);
-            uint32_t *const dDigitTotals = t->dHist + (uint64_t) (1u << perPass) * tilesE;
-            LAUNCH(ctx, stat, entryHistKernel, dim3(tilesE), dim3(ENT_TILE), P, t->dSlotMasks, t->dHist, tilesE, numSplats, perPass);
-            LAUNCH(ctx, stat, (sortDigitScanKernel<uint32_t>), dim3(1u << perPass), dim3(PRIM_BLOCK), t->dHist, dDigitTotals, tilesE);
-            /* The entry count (2.4 .. 3.8 per splat on the BASELINE clouds, 8 at most) comes back to the host: the remaining
+            Lanes<EntryHistArgs> eh;
+            Lanes<SortDigitScanArgs> ds;
+            Lanes<EntryTotalArgs> et;
+            Lanes<EntryScatterArgs> es;
+            uint32_t maxTiles = 0;
+            for (uint32_t a = 0; a < MAX_LANES; a++)
+            {
+                const uint32_t k = act[a < na ? a : 0];
+                mlsgpu_tree *t = trees[k];
+                const uint32_t tilesE = a < na ? divUp(reqs[k].numSplats, ENT_TILE) : 0u;
+                uint32_t *const dDigitTotals = t->dHist + (uint64_t) (1u << perPass) * divUp(reqs[k].numSplats, ENT_TILE);
+                const EntryParams P = params(k);
+                eh.a[a] = EntryHistArgs{P, t->dSlotMasks, t->dHist, tilesE, reqs[k].numSplats};
+                ds.a[a] = SortDigitScanArgs{t->dHist, dDigitTotals, tilesE};
+                et.a[a] = EntryTotalArgs{dDigitTotals, t->dNumEntries};
+                es.a[a] = EntryScatterArgs{P, t->dSlotMasks, t->dHist, dDigitTotals, tilesE, reqs[k].numSplats, t->dKeysB, t->dValsB};
+                maxTiles = std::max(maxTiles, tilesE);
+            }
+            LAUNCH(ctx, stat, entryHistKernel, dim3(maxTiles, na), dim3(ENT_TILE), eh, perPass);
+            LAUNCH(ctx, stat, (sortDigitScanKernel<uint32_t>), dim3(1u << perPass, na), dim3(PRIM_BLOCK), ds);
+            /* The entry counts (2.4 .. 3.8 per splat on the BASELINE clouds, 8 at most) come back to the host: the remaining
              * sort pass and the command scan launch on n instead of 8N elements. */
-            const uint32_t seq = t->entryBox.reserve();
-            LAUNCH(ctx, stat, entryTotalKernel, dim3(1), dim3(256), (const uint32_t *) dDigitTotals, 1u << perPass, t->dNumEntries,
-                   t->entryBox.dev, seq);
-            LAUNCH(ctx, stat, entryScatterKernel, dim3(tilesE), dim3(ENT_TILE), P, (const uint8_t *) t->dSlotMasks,
-                   (const uint32_t *) t->dHist, (const uint32_t *) dDigitTotals, tilesE, numSplats, perPass, t->dKeysB, t->dValsB);
-            PROPAGATE(t->entryBox.wait(ctx->stream));
-            sortN = t->entryBox.payload()[0];
-            PROPAGATE(radixSort<uint32_t>(ctx, "kernel.octree.sort.time", t->dKeysB, t->dValsB, t->dKeysA, t->dValsA,
-                                          sortN, keyBits, false, t->dHist, t->dTileSums, &sorted, t->dNumEntries, perPass));
+            const uint32_t seq = t0->entryBox.reserve();
+            LAUNCH(ctx, stat, entryTotalKernel, dim3(1), dim3(256), et, na, 1u << perPass, t0->entryBox.dev, seq);
+            LAUNCH(ctx, stat, entryScatterKernel, dim3(maxTiles, na), dim3(ENT_TILE), es, perPass);
+            PROPAGATE(t0->entryBox.wait(ctx->stream));
+            for (uint32_t a = 0; a < na; a++)
+            {
+                mlsgpu_tree *t = trees[act[a]];
+                sortN[a] = t0->entryBox.payload()[a];
+                sortJobs[a] = SortJob<uint32_t>{t->dKeysB, t->dValsB, t->dKeysA, t->dValsA, sortN[a], t->dHist, t->dNumEntries,
+                                                SortResult<uint32_t>{nullptr, nullptr}};
+            }
+            PROPAGATE(radixSortBatch<uint32_t>(ctx, "kernel.octree.sort.time", sortJobs, na, keyBits, false, perPass));
         }
         else
         {
             /* writeEntries: count, scan, write compacted; the entry count stays on the device (t->dNumEntries) */
-            PROPAGATE((exclusiveScan2<uint32_t, EntryCountIn, EntryMaskIn, EntryWriteOut>(
-                ctx, "kernel.octree.writeEntries.time", EntryCountIn{P, t->dSlotMasks}, EntryMaskIn{t->dSlotMasks},
-                EntryWriteOut{P, t->dSlotMasks, t->dKeysA, t->dValsA}, numSplats, 0u, t->dTileSums, t->dNumEntries)));
-            PROPAGATE(t->entryBox.publish(ctx->stream, t->dNumEntries, 1));
-            PROPAGATE(t->entryBox.wait(ctx->stream));
-            sortN = t->entryBox.payload()[0];
-            PROPAGATE(radixSort<uint32_t>(ctx, "kernel.octree.sort.time", t->dKeysA, t->dValsA, t->dKeysB, t->dValsB,
-                                          sortN, keyBits, false, t->dHist, t->dTileSums, &sorted, t->dNumEntries));
+            typedef ScanJob<uint32_t, EntryCountIn, EntryMaskIn, EntryWriteOut> EntryJob;
+            EntryJob jobs[MAX_LANES];
+            const void *counts[MAX_LANES];
+            for (uint32_t a = 0; a < na; a++)
+            {
+                const uint32_t k = act[a];
+                mlsgpu_tree *t = trees[k];
+                const EntryParams P = params(k);
+                jobs[a] = EntryJob{EntryCountIn{P, t->dSlotMasks}, EntryMaskIn{t->dSlotMasks},
+                                   EntryWriteOut{P, t->dSlotMasks, t->dKeysA, t->dValsA}, reqs[k].numSplats, 0u, t->dTileSums,
+                                   t->dNumEntries, nullptr};
+                counts[a] = t->dNumEntries;
+            }
+            PROPAGATE((exclusiveScanBatch<uint32_t, EntryCountIn, EntryMaskIn, EntryWriteOut>(
+                ctx, "kernel.octree.writeEntries.time", jobs, na)));
+            PROPAGATE(t0->entryBox.publishGather(ctx->stream, counts, na, 1));
+            PROPAGATE(t0->entryBox.wait(ctx->stream));
+            for (uint32_t a = 0; a < na; a++)
+            {
+                mlsgpu_tree *t = trees[act[a]];
+                sortN[a] = t0->entryBox.payload()[a];
+                sortJobs[a] = SortJob<uint32_t>{t->dKeysA, t->dValsA, t->dKeysB, t->dValsB, sortN[a], t->dHist, t->dNumEntries,
+                                                SortResult<uint32_t>{nullptr, nullptr}};
+            }
+            PROPAGATE(radixSortBatch<uint32_t>(ctx, "kernel.octree.sort.time", sortJobs, na, keyBits, false));
         }
         /* countCommands + scan(seed 1) + writeSplatIds, src/splat_tree_cl.cpp:310-317 */
-        IndicatorIn in{sorted.keys, t->dNumEntries};
-        SplatIdsOut outF{t->dCommands, t->dStart, t->dJumpPos, sorted.keys, sorted.vals, t->dNumEntries};
-        PROPAGATE((exclusiveScan<uint32_t>(ctx, "kernel.octree.scan.time", in, outF, sortN, 1u,
-                                           t->dTileSums, (uint32_t *) nullptr, t->dNumEntries)));
+        typedef ScanJob<uint32_t, IndicatorIn, IndicatorIn, SplatIdsOut> CommandJob;
+        CommandJob cj[MAX_LANES];
+        for (uint32_t a = 0; a < na; a++)
+        {
+            mlsgpu_tree *t = trees[act[a]];
+            const SortResult<uint32_t> &sorted = sortJobs[a].result;
+            const IndicatorIn in{sorted.keys, t->dNumEntries};
+            cj[a] = CommandJob{in, in, SplatIdsOut{t->dCommands, t->dStart, t->dJumpPos, sorted.keys, sorted.vals, t->dNumEntries},
+                               sortN[a], 1u, t->dTileSums, (uint32_t *) nullptr, t->dNumEntries};
+        }
+        PROPAGATE((exclusiveScanBatch<uint32_t, IndicatorIn, IndicatorIn, SplatIdsOut>(ctx, "kernel.octree.scan.time", cj, na)));
     }
-    LAUNCH(ctx, "kernel.octree.writeStart.time", writeStartKernel, dim3(divUp(numStart, 256)), dim3(256),
-           t->dStart, t->dCommands, (const int32_t *) t->dJumpPos, lo, minShift, maxShift, numStart);
+    LAUNCH(ctx, "kernel.octree.writeStart.time", writeStartKernel, dim3(divUp(numStart, 256), count), dim3(256),
+           ws, lo, minShift, maxShift, numStart);
     return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_tree_build(mlsgpu_tree *t, mlsgpu_splat *dSplats, uint64_t firstSplat, uint64_t numSplats,
+                                     const uint32_t size[3], const int32_t offset[3], uint32_t subsamplingShift)
+{
+    REQUIRE(t != nullptr && dSplats != nullptr && size != nullptr && offset != nullptr, MLSGPU_ERR_INVALID);
+    mlsgpu_tree_build r;
+    r.dSplats = dSplats;
+    r.firstSplat = firstSplat;
+    r.numSplats = numSplats;
+    for (int i = 0; i < 3; i++)
+    {
+        r.size[i] = size[i];
+        r.offset[i] = offset[i];
+    }
+    return treeBuildBatch(&t, &r, 1, subsamplingShift);
+}
+
+MLSGPU_API int mlsgpu_hip_tree_build_batch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *builds, uint32_t count,
+                                           uint32_t subsamplingShift)
+{
+    REQUIRE(trees != nullptr && builds != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(count >= 1 && count <= MLSGPU_MAX_BATCH, MLSGPU_ERR_LENGTH);
+    return treeBuildBatch(trees, builds, count, subsamplingShift);
 }
 
 MLSGPU_API int mlsgpu_hip_tree_num_entries(mlsgpu_tree *t, uint64_t *out)

@@ -17,6 +17,7 @@
 
 #include "common.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace mlsgpu
@@ -67,12 +68,29 @@ __device__ __forceinline__ U3 readLaneT(U3 v, int lane)
 
 /* ------------------------------------------------------------------ scan */
 
+/* Every kernel here has a bucket dimension (common.hpp, Lanes): blockIdx.y is the lane, the lane's arguments are one
+ * element of the by-value array, and workgroups beyond the lane's own number of tiles leave at once. */
+
+template<typename T, typename In>
+struct ScanReduceArgs
+{
+    In in;
+    T *tileSums;
+    uint64_t n;
+    const uint32_t *nDev;       /* element count produced on the device; the grid covers the upper bound n */
+    uint32_t numTiles;
+};
+
 /* tileSums[b] = sum of in(i) over tile b */
 template<typename T, typename In>
-__global__ __launch_bounds__(PRIM_BLOCK) void scanReduceKernel(In in, T *tileSums, uint64_t n, const uint32_t *nDev)
+__global__ __launch_bounds__(PRIM_BLOCK) void scanReduceKernel(Lanes<ScanReduceArgs<T, In> > lanes)
 {
-    if (nDev != nullptr && *nDev < n)
-        n = *nDev;      /* element count produced on the device; the grid covers the upper bound */
+    const ScanReduceArgs<T, In> &A = lanes.a[blockIdx.y];
+    if (blockIdx.x >= A.numTiles)
+        return;
+    uint64_t n = A.n;
+    if (A.nDev != nullptr && *A.nDev < n)
+        n = *A.nDev;
     __shared__ T waveTotals[PRIM_WAVES];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t base = (uint64_t) blockIdx.x * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
@@ -82,7 +100,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanReduceKernel(In in, T *tileSum
     {
         uint64_t i = base + (uint64_t) j * 64;
         if (i < n)
-            sum = sum + in(i);
+            sum = sum + A.in(i);
     }
     T incl = waveInclusiveScanT(sum);
     if (lane == 63)
@@ -93,17 +111,29 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanReduceKernel(In in, T *tileSum
         T t = waveTotals[0];
         for (int w = 1; w < PRIM_WAVES; w++)
             t = t + waveTotals[w];
-        tileSums[blockIdx.x] = t;
+        A.tileSums[blockIdx.x] = t;
     }
 }
 
-/* Single block: exclusive scan of the tile sums in place, starting at `seed`; grand total (incl. seed) to *total. */
 template<typename T>
-__global__ __launch_bounds__(PRIM_BLOCK) void scanTileSumsKernel(T *tileSums, uint32_t numTiles, T seed, T *total)
+struct ScanTileSumsArgs
 {
+    T *tileSums;
+    uint32_t numTiles;
+    T seed;
+    T *total;
+};
+
+/* One workgroup per lane: exclusive scan of the tile sums in place, starting at `seed`; grand total (incl. seed) to *total. */
+template<typename T>
+__global__ __launch_bounds__(PRIM_BLOCK) void scanTileSumsKernel(Lanes<ScanTileSumsArgs<T> > lanes)
+{
+    const ScanTileSumsArgs<T> &A = lanes.a[blockIdx.y];
     __shared__ T waveTotals[PRIM_WAVES];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    T carry = seed;
+    const uint32_t numTiles = A.numTiles;
+    T *const tileSums = A.tileSums;
+    T carry = A.seed;
     for (uint32_t base = 0; base < numTiles; base += PRIM_BLOCK)
     {
         const uint32_t i = base + threadIdx.x;
@@ -126,9 +156,22 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanTileSumsKernel(T *tileSums, ui
         carry = all;
         __syncthreads();
     }
-    if (threadIdx.x == 0 && total != nullptr)
-        *total = carry;
+    if (threadIdx.x == 0 && A.total != nullptr)
+        *A.total = carry;
 }
+
+template<typename T, typename In, typename Out>
+struct ScanApplyArgs
+{
+    In in;
+    Out out;
+    const T *tileSums;
+    uint64_t n;
+    const uint32_t *nDev;
+    T seed;
+    T *total;
+    uint32_t numTiles;
+};
 
 /* out(i, exclusivePrefix(i), in(i)) for every i < n.
  * FUSED = false: tileSums already hold each tile's exclusive prefix (scanTileSumsKernel ran).
@@ -136,11 +179,14 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanTileSumsKernel(T *tileSums, ui
  *                SCAN_FUSED_MAX_TILES L2-resident values), which saves the single-workgroup launch in between;
  *                the last workgroup writes the grand total. */
 template<typename T, typename In, typename Out, bool FUSED>
-__global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(In in, Out out, const T *tileSums, uint64_t n, const uint32_t *nDev,
-                                                              T seed, T *total)
+__global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(Lanes<ScanApplyArgs<T, In, Out> > lanes)
 {
-    if (nDev != nullptr && *nDev < n)
-        n = *nDev;
+    const ScanApplyArgs<T, In, Out> &A = lanes.a[blockIdx.y];
+    if (blockIdx.x >= A.numTiles)
+        return;
+    uint64_t n = A.n;
+    if (A.nDev != nullptr && *A.nDev < n)
+        n = *A.nDev;
     __shared__ T waveTotals[PRIM_WAVES];
     __shared__ T wavePrefix[PRIM_WAVES];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -153,6 +199,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(In in, Out out, co
     if (FUSED)
     {
         /* the predecessors' sums are requested first: their latency hides behind the tile's own loads */
+        const T *const tileSums = A.tileSums;
         for (uint32_t t = threadIdx.x; t < blockIdx.x; t += PRIM_BLOCK)
             before = before + tileSums[t];
     }
@@ -163,7 +210,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(In in, Out out, co
     for (int j = 0; j < PRIM_ITEMS; j++)
     {
         uint64_t i = base + (uint64_t) j * 64;
-        vals[j] = i < n ? in(i) : zeroOf(T());
+        vals[j] = i < n ? A.in(i) : zeroOf(T());
         T incl = waveInclusiveScanT(vals[j]);
         excl[j] = running + waveShiftUpT(incl);
         running = running + readLaneT(incl, 63);
@@ -179,21 +226,21 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(In in, Out out, co
     __syncthreads();
     if (FUSED)
     {
-        before = seed;
+        before = A.seed;
 #pragma unroll
         for (int w = 0; w < PRIM_WAVES; w++)
             before = before + wavePrefix[w];
-        if (total != nullptr && blockIdx.x == lastTile && threadIdx.x == 0)
+        if (A.total != nullptr && blockIdx.x == lastTile && threadIdx.x == 0)
         {
             T all = before;
 #pragma unroll
             for (int w = 0; w < PRIM_WAVES; w++)
                 all = all + waveTotals[w];
-            *total = all;
+            *A.total = all;
         }
     }
     else
-        before = tileSums[blockIdx.x];
+        before = A.tileSums[blockIdx.x];
     for (uint32_t w = 0; w < wave; w++)
         before = before + waveTotals[w];
 #pragma unroll
@@ -201,59 +248,130 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(In in, Out out, co
     {
         uint64_t i = base + (uint64_t) j * 64;
         if (i < n)
-            out(i, before + excl[j], vals[j]);
+            A.out(i, before + excl[j], vals[j]);
     }
 }
 
 #endif /* __HIPCC__ */
 
-/* Host driver.  Workspace: tileSums must hold scanTiles(n) elements of T. */
+/* Host drivers.  Workspace: dTileSums must hold scanTiles(n) + 1 elements of T. */
 static inline uint32_t scanTiles(uint64_t n) { return divUp(n, PRIM_TILE); }
-
-#ifdef __HIPCC__
-/* Phase 1: tile sums of in() scanned from `seed`; grand total (incl. seed) to *dTotal (may be null). */
-template<typename T, typename In>
-static int scanPhase1(mlsgpu_ctx *ctx, const char *statName, In in, uint64_t n, T seed, T *dTileSums, T *dTotal,
-                      const uint32_t *nDev = nullptr)
-{
-    const uint32_t tiles = scanTiles(n);
-    if (tiles > 0)
-        LAUNCH(ctx, statName, (scanReduceKernel<T, In>), dim3(tiles), dim3(PRIM_BLOCK), in, dTileSums, n, nDev);
-    LAUNCH(ctx, statName, (scanTileSumsKernel<T>), dim3(1), dim3(PRIM_BLOCK), dTileSums, tiles, seed, dTotal);
-    return MLSGPU_OK;
-}
-
-/* Phase 2: out(i, exclusivePrefix(i), in(i)) for all i, using the tile sums of phase 1. */
-template<typename T, typename In, typename Out>
-static int scanPhase2(mlsgpu_ctx *ctx, const char *statName, In in, Out out, uint64_t n, const T *dTileSums,
-                      const uint32_t *nDev = nullptr)
-{
-    const uint32_t tiles = scanTiles(n);
-    if (tiles > 0)
-        LAUNCH(ctx, statName, (scanApplyKernel<T, In, Out, false>), dim3(tiles), dim3(PRIM_BLOCK), in, out, dTileSums, n, nDev,
-               zeroOf(T()), (T *) nullptr);
-    return MLSGPU_OK;
-}
 
 /* largest scan (in tiles) whose workgroups add up their predecessors' tile sums themselves */
 #define SCAN_FUSED_MAX_TILES 4096u
 
-/* in1 feeds the tile sums, in2 the scan proper (they must agree; a first pass may cache what the second reads) */
+#ifdef __HIPCC__
+/* One scan of a batch: in1 feeds the tile sums, in2 the scan proper (they must agree; a first pass may cache what the
+ * second reads); out(i, prefix, value) consumes; grand total (incl. seed) to *dTotal (may be null). */
+template<typename T, typename In1, typename In2, typename Out>
+struct ScanJob
+{
+    In1 in1;
+    In2 in2;
+    Out out;
+    uint64_t n;
+    T seed;
+    T *dTileSums;
+    T *dTotal;
+    const uint32_t *nDev;
+};
+
+/* Phase 1 for every lane: tile sums of in1() scanned from the seed; grand totals written. */
+template<typename T, typename In1, typename In2, typename Out>
+static int scanPhase1Batch(mlsgpu_ctx *ctx, const char *statName, const ScanJob<T, In1, In2, Out> *jobs, uint32_t count)
+{
+    REQUIRE(count >= 1 && count <= MAX_LANES, MLSGPU_ERR_INVALID);
+    Lanes<ScanReduceArgs<T, In1> > r;
+    Lanes<ScanTileSumsArgs<T> > t;
+    uint32_t maxTiles = 0;
+    for (uint32_t k = 0; k < MAX_LANES; k++)
+    {
+        const ScanJob<T, In1, In2, Out> &j = jobs[k < count ? k : 0];
+        const uint32_t tiles = k < count ? scanTiles(j.n) : 0u;
+        r.a[k] = ScanReduceArgs<T, In1>{j.in1, j.dTileSums, j.n, j.nDev, tiles};
+        t.a[k] = ScanTileSumsArgs<T>{j.dTileSums, tiles, j.seed, j.dTotal};
+        maxTiles = tiles > maxTiles ? tiles : maxTiles;
+    }
+    if (maxTiles > 0)
+        LAUNCH(ctx, statName, (scanReduceKernel<T, In1>), dim3(maxTiles, count), dim3(PRIM_BLOCK), r);
+    LAUNCH(ctx, statName, (scanTileSumsKernel<T>), dim3(1, count), dim3(PRIM_BLOCK), t);
+    return MLSGPU_OK;
+}
+
+/* Phase 2 for every lane: out(i, exclusivePrefix(i), in2(i)) for all i, using the tile sums of phase 1. */
+template<typename T, typename In1, typename In2, typename Out>
+static int scanPhase2Batch(mlsgpu_ctx *ctx, const char *statName, const ScanJob<T, In1, In2, Out> *jobs, uint32_t count)
+{
+    REQUIRE(count >= 1 && count <= MAX_LANES, MLSGPU_ERR_INVALID);
+    Lanes<ScanApplyArgs<T, In2, Out> > a;
+    uint32_t maxTiles = 0;
+    for (uint32_t k = 0; k < MAX_LANES; k++)
+    {
+        const ScanJob<T, In1, In2, Out> &j = jobs[k < count ? k : 0];
+        const uint32_t tiles = k < count ? scanTiles(j.n) : 0u;
+        a.a[k] = ScanApplyArgs<T, In2, Out>{j.in2, j.out, (const T *) j.dTileSums, j.n, j.nDev, zeroOf(T()), (T *) nullptr, tiles};
+        maxTiles = tiles > maxTiles ? tiles : maxTiles;
+    }
+    if (maxTiles > 0)
+        LAUNCH(ctx, statName, (scanApplyKernel<T, In2, Out, false>), dim3(maxTiles, count), dim3(PRIM_BLOCK), a);
+    return MLSGPU_OK;
+}
+
+/* The whole scan for every lane of a batch. */
+template<typename T, typename In1, typename In2, typename Out>
+static int exclusiveScanBatch(mlsgpu_ctx *ctx, const char *statName, const ScanJob<T, In1, In2, Out> *jobs, uint32_t count)
+{
+    REQUIRE(count >= 1 && count <= MAX_LANES, MLSGPU_ERR_INVALID);
+    uint32_t maxTiles = 0;
+    for (uint32_t k = 0; k < count; k++)
+        maxTiles = std::max(maxTiles, scanTiles(jobs[k].n));
+    if (maxTiles <= SCAN_FUSED_MAX_TILES)
+    {
+        /* two launches: raw tile sums, then the scan proper.  An empty lane still runs its tile 0, which reports the total. */
+        Lanes<ScanReduceArgs<T, In1> > r;
+        Lanes<ScanApplyArgs<T, In2, Out> > a;
+        for (uint32_t k = 0; k < MAX_LANES; k++)
+        {
+            const ScanJob<T, In1, In2, Out> &j = jobs[k < count ? k : 0];
+            const uint32_t tiles = k < count ? std::max(scanTiles(j.n), 1u) : 0u;
+            r.a[k] = ScanReduceArgs<T, In1>{j.in1, j.dTileSums, j.n, j.nDev, tiles};
+            a.a[k] = ScanApplyArgs<T, In2, Out>{j.in2, j.out, (const T *) j.dTileSums, j.n, j.nDev, j.seed, j.dTotal, tiles};
+        }
+        maxTiles = std::max(maxTiles, 1u);
+        LAUNCH(ctx, statName, (scanReduceKernel<T, In1>), dim3(maxTiles, count), dim3(PRIM_BLOCK), r);
+        LAUNCH(ctx, statName, (scanApplyKernel<T, In2, Out, true>), dim3(maxTiles, count), dim3(PRIM_BLOCK), a);
+        return MLSGPU_OK;
+    }
+    PROPAGATE((scanPhase1Batch<T, In1, In2, Out>(ctx, statName, jobs, count)));
+    return scanPhase2Batch<T, In1, In2, Out>(ctx, statName, jobs, count);
+}
+
+/* single-bucket forms */
+struct NoIn { };
+struct NoOut { };
+
+template<typename T, typename In>
+static int scanPhase1(mlsgpu_ctx *ctx, const char *statName, In in, uint64_t n, T seed, T *dTileSums, T *dTotal,
+                      const uint32_t *nDev = nullptr)
+{
+    const ScanJob<T, In, NoIn, NoOut> job{in, NoIn(), NoOut(), n, seed, dTileSums, dTotal, nDev};
+    return scanPhase1Batch<T, In, NoIn, NoOut>(ctx, statName, &job, 1);
+}
+
+template<typename T, typename In, typename Out>
+static int scanPhase2(mlsgpu_ctx *ctx, const char *statName, In in, Out out, uint64_t n, const T *dTileSums,
+                      const uint32_t *nDev = nullptr)
+{
+    const ScanJob<T, NoIn, In, Out> job{NoIn(), in, out, n, zeroOf(T()), const_cast<T *>(dTileSums), (T *) nullptr, nDev};
+    return scanPhase2Batch<T, NoIn, In, Out>(ctx, statName, &job, 1);
+}
+
 template<typename T, typename In1, typename In2, typename Out>
 static int exclusiveScan2(mlsgpu_ctx *ctx, const char *statName, In1 in1, In2 in2, Out out, uint64_t n, T seed,
                           T *dTileSums, T *dTotal, const uint32_t *nDev = nullptr)
 {
-    const uint32_t tiles = scanTiles(n);
-    if (tiles > 0 && tiles <= SCAN_FUSED_MAX_TILES)
-    {
-        /* two launches: raw tile sums, then the scan proper */
-        LAUNCH(ctx, statName, (scanReduceKernel<T, In1>), dim3(tiles), dim3(PRIM_BLOCK), in1, dTileSums, n, nDev);
-        LAUNCH(ctx, statName, (scanApplyKernel<T, In2, Out, true>), dim3(tiles), dim3(PRIM_BLOCK), in2, out, (const T *) dTileSums,
-               n, nDev, seed, dTotal);
-        return MLSGPU_OK;
-    }
-    PROPAGATE((scanPhase1<T, In1>(ctx, statName, in1, n, seed, dTileSums, dTotal, nDev)));
-    return scanPhase2<T, In2, Out>(ctx, statName, in2, out, n, (const T *) dTileSums, nDev);
+    const ScanJob<T, In1, In2, Out> job{in1, in2, out, n, seed, dTileSums, dTotal, nDev};
+    return exclusiveScanBatch<T, In1, In2, Out>(ctx, statName, &job, 1);
 }
 
 template<typename T, typename In, typename Out>
@@ -280,18 +398,31 @@ struct ArrayOut
 /* ------------------------------------------------------------------ radix sort */
 
 template<typename K>
-__global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(const K *keys, uint32_t *hist, uint64_t n,
-                                                             uint32_t shift, uint32_t digitBits, uint32_t numTiles,
-                                                             const uint32_t *nDev)
+struct SortHistArgs
 {
-    if (nDev != nullptr && *nDev < n)
-        n = *nDev;
+    const K *keys;
+    uint32_t *hist;
+    uint64_t n;
+    const uint32_t *nDev;
+    uint32_t numTiles;
+};
+
+template<typename K>
+__global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(Lanes<SortHistArgs<K> > lanes, uint32_t shift, uint32_t digitBits)
+{
+    const SortHistArgs<K> &A = lanes.a[blockIdx.y];
+    if (blockIdx.x >= A.numTiles)
+        return;
+    uint64_t n = A.n;
+    if (A.nDev != nullptr && *A.nDev < n)
+        n = *A.nDev;
     __shared__ uint32_t bins[SORT_MAX_BINS];
     const uint32_t numBins = 1u << digitBits;
     const K mask = (K) (numBins - 1);
     for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
         bins[d] = 0;
     __syncthreads();
+    const K *const keys = A.keys;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t base = (uint64_t) blockIdx.x * SORT_TILE + (uint64_t) wave * SORT_WAVE_SPAN + lane;
 #pragma unroll 4
@@ -302,18 +433,29 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(const K *keys, uint
             atomicAdd(&bins[(uint32_t) ((keys[i] >> shift) & mask)], 1u);
     }
     __syncthreads();
+    uint32_t *const hist = A.hist;
+    const uint32_t numTiles = A.numTiles;
     for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
         hist[(uint64_t) d * numTiles + blockIdx.x] = bins[d];
 }
 
-/* hist[d][0 .. numTiles) -> its exclusive prefix along the tiles, in place; digitTotals[d] = the digit's count.  One
- * workgroup per digit: the whole scan of a pass's histogram is this ONE small launch (the scatter kernel turns the 2^bits
- * digit totals into digit bases itself), where a generic scan of the 2^bits x numTiles array took two. */
-template<typename T>    /* T = uint32_t; a template only so that the header can be included by several translation units */
-__global__ __launch_bounds__(PRIM_BLOCK) void sortDigitScanKernel(T *hist, T *digitTotals, uint32_t numTiles)
+struct SortDigitScanArgs
 {
+    uint32_t *hist;
+    uint32_t *digitTotals;
+    uint32_t numTiles;
+};
+
+/* hist[d][0 .. numTiles) -> its exclusive prefix along the tiles, in place; digitTotals[d] = the digit's count.  One
+ * workgroup per digit (and lane): the whole scan of a pass's histogram is this ONE small launch (the scatter kernel turns
+ * the 2^bits digit totals into digit bases itself), where a generic scan of the 2^bits x numTiles array took two. */
+template<typename T>    /* T = uint32_t; a template only so that the header can be included by several translation units */
+__global__ __launch_bounds__(PRIM_BLOCK) void sortDigitScanKernel(Lanes<SortDigitScanArgs> lanes)
+{
+    const SortDigitScanArgs &A = lanes.a[blockIdx.y];
     __shared__ T waveTotals[PRIM_WAVES];
-    T *row = hist + (uint64_t) blockIdx.x * numTiles;
+    const uint32_t numTiles = A.numTiles;
+    T *row = A.hist + (uint64_t) blockIdx.x * numTiles;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t carry = 0;
     for (uint32_t base = 0; base < numTiles; base += PRIM_BLOCK)
@@ -338,12 +480,26 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortDigitScanKernel(T *hist, T *di
         __syncthreads();
     }
     if (threadIdx.x == 0)
-        digitTotals[blockIdx.x] = carry;
+        A.digitTotals[blockIdx.x] = carry;
 }
 
 /* Largest digit a key type can be sorted by per pass: bounded by the LDS the scatter kernel needs
  * (tile of keys + values, per-wave bins).  64 KB of static LDS per workgroup. */
 template<typename K> struct SortCaps { enum { MAX_DIGIT_BITS = sizeof(K) == 8 ? 9 : SORT_MAX_DIGIT_BITS }; };
+
+template<typename K>
+struct SortScatterArgs
+{
+    const K *keysIn;
+    const uint32_t *valsIn;
+    K *keysOut;
+    uint32_t *valsOut;
+    const uint32_t *hist;
+    const uint32_t *digitTotals;
+    uint64_t n;
+    const uint32_t *nDev;
+    uint32_t numTiles;
+};
 
 /*
  * Scatter pass.  hist[d][tile] = keys with digit d in the tiles before this one (sortDigitScanKernel), digitTotals[d] =
@@ -358,11 +514,7 @@ template<typename K> struct SortCaps { enum { MAX_DIGIT_BITS = sizeof(K) == 8 ? 
  *      digit's run leaves as one contiguous, coalesced burst instead of 64 scattered dwords per store.
  */
 template<typename K, bool IOTA, int BIN_BITS>
-__global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn, const uint32_t *valsIn,
-                                                                K *keysOut, uint32_t *valsOut,
-                                                                const uint32_t *hist, const uint32_t *digitTotals,
-                                                                uint64_t n, uint32_t shift, uint32_t digitBits,
-                                                                uint32_t numTiles, const uint32_t *nDev)
+__global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatterArgs<K> > lanes, uint32_t shift, uint32_t digitBits)
 {
     enum { BINS = 1 << BIN_BITS };
     __shared__ uint32_t waveBins[PRIM_WAVES][BINS];
@@ -371,11 +523,22 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(const K *keysIn,
     /* the tile is reordered in two phases through ONE buffer (keys, then values): half the LDS, twice the
      * resident workgroups, which is what this latency-bound kernel needs */
     __shared__ K sTile[SORT_TILE];
-    if (nDev != nullptr && *nDev < n)
-        n = *nDev;
+    const SortScatterArgs<K> &A = lanes.a[blockIdx.y];
+    if (blockIdx.x >= A.numTiles)
+        return;
+    uint64_t n = A.n;
+    if (A.nDev != nullptr && *A.nDev < n)
+        n = *A.nDev;
     const uint64_t tileFirst = (uint64_t) blockIdx.x * SORT_TILE;
     if (tileFirst >= n)
         return;
+    const K *const keysIn = A.keysIn;
+    const uint32_t *const valsIn = A.valsIn;
+    K *const keysOut = A.keysOut;
+    uint32_t *const valsOut = A.valsOut;
+    const uint32_t *const hist = A.hist;
+    const uint32_t *const digitTotals = A.digitTotals;
+    const uint32_t numTiles = A.numTiles;
     const uint32_t tileCount = (uint32_t) (n - tileFirst < SORT_TILE ? n - tileFirst : SORT_TILE);
     const uint32_t numBins = 1u << digitBits;
     const K mask = (K) (numBins - 1);
@@ -516,26 +679,43 @@ static inline uint32_t sortPasses(uint32_t bits, uint32_t maxDigitBits) { return
 static inline uint32_t sortTiles(uint64_t n) { return divUp(n, SORT_TILE); }
 static inline uint64_t sortHistElems(uint64_t n) { return (uint64_t) SORT_MAX_BINS * ((uint64_t) sortTiles(n) + 1); }
 
+/* one lane of a batched sort: (keysA, valsA)[0..n) sorted stably by key bits [0, bits); keysB/valsB are same-sized
+ * temporaries (the reference aliases its sort temporaries onto other buffers the same way, src/splat_tree_cl.cpp:129,
+ * src/marching.cpp:405); dHist: sortHistElems(n) uint32 */
+template<typename K>
+struct SortJob
+{
+    K *keysA;
+    uint32_t *valsA;
+    K *keysB;
+    uint32_t *valsB;
+    uint64_t n;
+    uint32_t *dHist;
+    const uint32_t *nDev;
+    SortResult<K> result;       /* out */
+};
+
 /*
- * Sorts (keysA, valsA)[0..n) stably by key bits [0, bits).  keysB/valsB are same-sized temporaries
- * (the reference aliases its sort temporaries onto other buffers the same way,
- * src/splat_tree_cl.cpp:129, src/marching.cpp:405).  iota: values are 0..n-1 and valsA is not read.
- * dHist: sortHistElems(n) uint32; dTileSums: not used any more (kept for the call sites' sake).
+ * Sorts every lane's pairs.  iota: values are 0..n-1 and valsA is not read.  doneBits: the lowest doneBits key bits have
+ * been sorted already (by a pass of that width fused into the producer of the keys); the remaining passes keep the split of
+ * the whole sort.  The passes -- digit widths, hence the kernels -- are the same for every lane.
  */
 template<typename K>
-static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *valsA, K *keysB, uint32_t *valsB,
-                     uint64_t n, uint32_t bits, bool iota, uint32_t *dHist, uint32_t *dTileSums,
-                     SortResult<K> *result, const uint32_t *nDev = nullptr, uint32_t doneBits = 0)
+static int radixSortBatch(mlsgpu_ctx *ctx, const char *statName, SortJob<K> *jobs, uint32_t count, uint32_t bits, bool iota,
+                          uint32_t doneBits = 0)
 {
-    /* doneBits: the lowest doneBits key bits have been sorted already (by a pass of that width fused into the producer of
-     * the keys); the remaining passes keep the split of the whole sort */
-    result->keys = keysA;
-    result->vals = valsA;
-    if (n == 0)
+    REQUIRE(count >= 1 && count <= MAX_LANES, MLSGPU_ERR_INVALID);
+    uint32_t maxTiles = 0;
+    uint32_t tiles[MAX_LANES];
+    for (uint32_t k = 0; k < count; k++)
+    {
+        jobs[k].result.keys = jobs[k].keysA;
+        jobs[k].result.vals = jobs[k].valsA;
+        tiles[k] = sortTiles(jobs[k].n);
+        maxTiles = std::max(maxTiles, tiles[k]);
+    }
+    if (maxTiles == 0)
         return MLSGPU_OK;
-    const uint32_t tiles = sortTiles(n);
-    (void) dTileSums;
-    uint32_t *const dDigitTotals = dHist + (uint64_t) SORT_MAX_BINS * tiles;
     if (bits == 0)
         bits = 1;    /* still run one pass so that iota values are materialised */
     uint32_t maxDigit = SortCaps<K>::MAX_DIGIT_BITS;
@@ -548,18 +728,28 @@ static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *
     const uint32_t passes = sortPasses(bits, maxDigit);
     const uint32_t perPass = (bits + passes - 1) / passes;
     uint32_t shift = doneBits;
-    K *kin = keysA, *kout = keysB;
-    uint32_t *vin = valsA, *vout = valsB;
+    bool flipped = false;
     for (uint32_t p = 0; shift < bits; p++)
     {
         const uint32_t digitBits = (bits - shift) < perPass ? (bits - shift) : perPass;
-        LAUNCH(ctx, statName, (sortHistKernel<K>), dim3(tiles), dim3(PRIM_BLOCK),
-               (const K *) kin, dHist, n, shift, digitBits, tiles, nDev);
-        LAUNCH(ctx, statName, (sortDigitScanKernel<uint32_t>), dim3(1u << digitBits), dim3(PRIM_BLOCK), dHist, dDigitTotals, tiles);
+        Lanes<SortHistArgs<K> > h;
+        Lanes<SortDigitScanArgs> d;
+        Lanes<SortScatterArgs<K> > s;
+        for (uint32_t k = 0; k < MAX_LANES; k++)
+        {
+            const SortJob<K> &j = jobs[k < count ? k : 0];
+            const uint32_t t = k < count ? tiles[k] : 0u;
+            K *const kin = flipped ? j.keysB : j.keysA, *const kout = flipped ? j.keysA : j.keysB;
+            uint32_t *const vin = flipped ? j.valsB : j.valsA, *const vout = flipped ? j.valsA : j.valsB;
+            uint32_t *const dDigitTotals = j.dHist + (uint64_t) SORT_MAX_BINS * sortTiles(j.n);
+            h.a[k] = SortHistArgs<K>{kin, j.dHist, j.n, j.nDev, t};
+            d.a[k] = SortDigitScanArgs{j.dHist, dDigitTotals, t};
+            s.a[k] = SortScatterArgs<K>{kin, vin, kout, vout, j.dHist, dDigitTotals, j.n, j.nDev, t};
+        }
+        LAUNCH(ctx, statName, (sortHistKernel<K>), dim3(maxTiles, count), dim3(PRIM_BLOCK), h, shift, digitBits);
+        LAUNCH(ctx, statName, (sortDigitScanKernel<uint32_t>), dim3(1u << digitBits, count), dim3(PRIM_BLOCK), d);
 #define SORT_SCATTER(IOTA, BITS)                                                                                       \
-        LAUNCH(ctx, statName, (sortScatterKernel<K, IOTA, BITS>), dim3(tiles), dim3(PRIM_BLOCK), (const K *) kin,      \
-               (const uint32_t *) vin, kout, vout, (const uint32_t *) dHist, (const uint32_t *) dDigitTotals, n, shift,\
-               digitBits, tiles, nDev)
+        LAUNCH(ctx, statName, (sortScatterKernel<K, IOTA, BITS>), dim3(maxTiles, count), dim3(PRIM_BLOCK), s, shift, digitBits)
         /* the kernel's bin tables are sized for the digit in use: fewer bins, more resident workgroups */
         const bool first = iota && p == 0;
         if (digitBits <= 8) { if (first) SORT_SCATTER(true, 8); else SORT_SCATTER(false, 8); }
@@ -567,11 +757,27 @@ static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *
         else { if (first) SORT_SCATTER(true, SortCaps<K>::MAX_DIGIT_BITS); else SORT_SCATTER(false, SortCaps<K>::MAX_DIGIT_BITS); }
 #undef SORT_SCATTER
         shift += digitBits;
-        K *tk = kin; kin = kout; kout = tk;
-        uint32_t *tv = vin; vin = vout; vout = tv;
+        flipped = !flipped;
     }
-    result->keys = kin;
-    result->vals = vin;
+    for (uint32_t k = 0; k < count; k++)
+        if (flipped && tiles[k] > 0)
+        {
+            jobs[k].result.keys = jobs[k].keysB;
+            jobs[k].result.vals = jobs[k].valsB;
+        }
+    return MLSGPU_OK;
+}
+
+/* single-bucket form; dTileSums: not used any more (kept for the call sites' sake) */
+template<typename K>
+static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *valsA, K *keysB, uint32_t *valsB,
+                     uint64_t n, uint32_t bits, bool iota, uint32_t *dHist, uint32_t *dTileSums,
+                     SortResult<K> *result, const uint32_t *nDev = nullptr, uint32_t doneBits = 0)
+{
+    (void) dTileSums;
+    SortJob<K> job{keysA, valsA, keysB, valsB, n, dHist, nDev, SortResult<K>{keysA, valsA}};
+    PROPAGATE(radixSortBatch<K>(ctx, statName, &job, 1, bits, iota, doneBits));
+    *result = job.result;
     return MLSGPU_OK;
 }
 #endif /* __HIPCC__ */

@@ -80,7 +80,8 @@ def test_struct_layouts_match_the_header(tmp_path):
     from mlsgpu_amd import binding as b
     pairs = [("mlsgpu_mesh", b.Mesh), ("mlsgpu_swathe", b.Swathe), ("mlsgpu_worker_config", b.WorkerConfig),
              ("mlsgpu_farm_config", b.FarmConfig), ("mlsgpu_grid", b.GridStruct), ("mlsgpu_bucket_params", b.BucketParams),
-             ("mlsgpu_bucket", b.BucketStruct), ("mlsgpu_generator", b.Generator)]
+             ("mlsgpu_bucket", b.BucketStruct), ("mlsgpu_generator", b.Generator), ("mlsgpu_subitem", b.SubItem),
+             ("mlsgpu_tree_build", b.TreeBuild)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mlsgpu_hip.h"', 'int main(void) {',
              'printf("mlsgpu_splat %zu %zu %zu %zu %zu\\n", sizeof(mlsgpu_splat), offsetof(mlsgpu_splat, position), '
              'offsetof(mlsgpu_splat, radius), offsetof(mlsgpu_splat, normal), offsetof(mlsgpu_splat, quality));']

@@ -66,6 +66,40 @@ def test_chunks_may_arrive_interleaved():
         assert mo.isomorphic(v, t, ev, et)
 
 
+def test_reserve_between_adds_keeps_pending_appends():
+    """mlsgpu_hip_mesher_reserve in the middle of a job: growing an arena moves it, so the same-device appends still
+    running on their producers' streams must land first.  Worker ship-outs are appended without a host
+    wait, then the arenas are grown several times with nothing finalized in between."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import synth
+    cloud = synth.shells_cloud(120_000, 95.0, 16.0, 1.5, 2.5, seed=321)
+    allb, buckets = synth.bucketize(cloud, 96, 32)
+
+    def run(grow):
+        ctx = m.Context(0)
+        dev = m.DeviceBuffer(ctx, array=allb)
+        worker = m.Worker(ctx, max(bk.count for bk in buckets), max_cells=63)
+        mesher = m.Mesher(ctx, 0.02)
+        room = 1 << 12
+        for bk in buckets:
+            worker.process(dev, bk.first, bk.count, bk.low, bk.num_vertices, collector=mesher.collector(ctx, 0))
+            if grow:
+                room *= 2
+                mesher.reserve(room, 2 * room, room // 4)      # no finalize, no synchronize in between
+        assert mesher.finalize() == 1
+        got, stats = mesher.chunk(0), mesher.stats()
+        mesher.close()
+        del worker, dev
+        ctx.close()
+        return got, stats
+
+    a, sa = run(False)
+    b, sb = run(True)
+    assert sa == sb
+    assert np.array_equal(a["vertices"].view(np.uint32), b["vertices"].view(np.uint32))
+    assert np.array_equal(a["triangles"], b["triangles"])
+
+
 def test_peer_route_appends(monkeypatch):
     """The cross-GPU append (peer copies on the producer's stream, index fix-ups on the mesher's device) forced on one
     GPU: same result as the local route."""
