@@ -77,7 +77,12 @@ def parse_args():
     p.add_argument("--farm-workers", type=int, default=4,
                    help="device workers per GPU of the farm legs (host splats in, meshes out): transfers want more in flight "
                         "(shells cloud, 8d region: 2 971 Mvoxels/s with 2, 3 719 with 4)")
-    p.add_argument("--variant", type=int, default=4, help="MLS kernel variant: 0 culled, 1 basic, 2 culled + hit lists, 3 culled + hit masks, 4 culled + cube streams")
+    p.add_argument("--batch", type=int, default=4,
+                   help="buckets a device worker takes through the path in lock-step (mlsgpu_hip_worker_process_batch: every "
+                        "kernel has a bucket dimension, one set of launches and three host decisions per batch); 1 = bucket by "
+                        "bucket (mlsgpu_hip_worker_process)")
+    p.add_argument("--variant", type=int, default=4, choices=[1, 4],
+                   help="MLS kernel: 4 sub-block culling + cube streams (default), 1 the reference's structure")
     p.add_argument("--leg-steps", type=int, default=3, help="passes of every secondary leg")
     p.add_argument("--restore-splats", action="store_true",
                    help="rounds 1-2's protocol: the tree build mutates the resident splats (radius -> 1/radius^2 in place, as the "
@@ -863,9 +868,11 @@ def main():
     # (non-mutating build, processCorners takes the reciprocal while staging: bit-identical field) and the resident
     # input is simply processed again.  --restore-splats brings the old protocol back; its step is reported either way.
     mutating = [bool(args.restore_splats)]
+    batch = max(1, min(args.batch, m.binding.MAX_BATCH, -(-len(buckets) // nworkers)))
     for w in workers:
         w.set_mls_variant(args.variant)
         w.set_keep_splats(not mutating[0])
+        w.set_batch(batch)
     pool = ThreadPoolExecutor(nworkers)
     collectors = [m.binding.SizeCollector() for _ in range(nworkers)]
 
@@ -873,15 +880,26 @@ def main():
         if mutating[0]:
             m.binding.check(m.lib().mlsgpu_hip_memcpy_d2d(c.h, work.ptr + 32 * b.first, pristine.ptr + 32 * b.first, 32 * b.count))
 
+    def run_buckets(w, c, some, col):
+        # a worker's buckets: `batch` at a time through ONE set of launches (the SubItems of a work item,
+        # src/workers.cpp:232-286), or bucket by bucket
+        if batch > 1:
+            for b in some:
+                fresh(c, b)
+            w.process_batch(work, some, collector=col)
+        else:
+            for b in some:
+                fresh(c, b)
+                w.process(work, b.first, b.count, b.low, b.num_vertices, collector=col)
+
+    shares = [list(farm.worker_share(buckets, k, nworkers)) for k in range(nworkers)]
+
     def run_share(k):
         # worker k takes buckets k, k + nworkers, ... (ctypes releases the GIL inside the library).  With a mutating build
         # every bucket starts from a fresh copy of its resident splats, ON THE WORKER'S STREAM, where the reference has the
         # host-to-device copy of the work item (src/workers.cpp:356-361), inside the timed region.
-        w, col, c = workers[k], collectors[k], ctxs[k]
-        for b in farm.worker_share(buckets, k, nworkers):
-            fresh(c, b)
-            w.process(work, b.first, b.count, b.low, b.num_vertices, collector=col)
-        c.synchronize()
+        run_buckets(workers[k], ctxs[k], shares[k], collectors[k])
+        ctxs[k].synchronize()
 
     def step():
         list(pool.map(run_share, range(nworkers)))
@@ -908,8 +926,7 @@ def main():
         ctx.set_timing(True)
         for _ in range(ksteps):
             work.copy_from(pristine)
-            for b in buckets:
-                workers[0].process(work, b.first, b.count, b.low, b.num_vertices, collector=m.binding.SizeCollector())
+            run_buckets(workers[0], ctx, buckets, m.binding.SizeCollector())
         ctx.set_timing(False)
         kernel_stats = dict(ctx.stats())
 
@@ -922,9 +939,7 @@ def main():
         ctx.synchronize()
         t0 = time.perf_counter()
         for _ in range(sw_steps):
-            for b in buckets:
-                fresh(ctx, b)
-                workers[0].process(work, b.first, b.count, b.low, b.num_vertices, collector=col1)
+            run_buckets(workers[0], ctx, buckets, col1)
         ctx.synchronize()
         single_worker_ms = (time.perf_counter() - t0) / sw_steps * 1e3
 
@@ -946,6 +961,14 @@ def main():
     after = w0.marching_counters()
     mc = {k: after[k] - before[k] for k in after}
     digest = check.digest()
+    if batch > 1:
+        # ... and the batched path the timed region runs: the same meshes, ship-out by ship-out
+        check_b = m.binding.ChecksumCollector(ctx)
+        run_buckets(w0, ctx, buckets, check_b)
+        ctx.synchronize()
+        if check_b.digest() != digest:
+            raise SystemExit("batched passes (batch %d) produce digest %s, bucket-by-bucket passes %s"
+                             % (batch, check_b.digest(), digest))
 
 
     for _ in range(args.warmup):
@@ -1040,11 +1063,12 @@ def main():
             "bucket_splats_total": int(bucketed_t.shape[0]),
             "mesh_memory_mb": args.mesh_memory_mb,
             "device_workers": nworkers,
+            "batch": batch,
             "resident_splats": ("restored by a device-to-device copy before every bucket, inside the timed region (the tree build "
                                 "mutates them, as the reference's does)" if args.restore_splats else
                                 "processed in place: the workers keep them intact (non-mutating tree build, processCorners takes "
                                 "1/r^2 while staging; bit-identical output), so nothing is restored"),
-            "mls_variant": {0: "culled", 1: "basic", 2: "culled+hit-lists", 3: "culled+hit-masks", 4: "culled+cube-streams"}[args.variant],
+            "mls_variant": {1: "basic", 4: "culled+cube-streams"}[args.variant],
             "sharding": "one process per GPU, rank r owns z-slab r (25 buckets); no data-path collective" if world > 1
                         else "single GPU",
             "triangles_per_step": triangles,

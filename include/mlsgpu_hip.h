@@ -445,6 +445,11 @@ int mlsgpu_hip_farm_submit_device(mlsgpu_farm *farm, int device, const mlsgpu_sp
                                   uint64_t numSplats, const mlsgpu_grid *fullGrid, const int32_t lowExtent[3],
                                   const uint32_t numVertices[3], uint64_t chunkId);
 
+/* The buckets of a device item (the SubItems of a WorkItem) are taken through the path `lanes` at a time by
+ * mlsgpu_hip_worker_process_batch instead of one by one (src/workers.cpp:232-286); 1 .. MLSGPU_MAX_BATCH, default 1.
+ * Outputs are unchanged and still arrive bucket by bucket. */
+int mlsgpu_hip_farm_set_batch(mlsgpu_farm *farm, uint32_t lanes);
+
 /* ---- mesh sink for meshes that stay in HBM: OOCMesher's weld / components / prune / per-chunk output,
  *      src/mesher.h:203-330, src/mesher.cpp:220-852 ---- */
 typedef struct mlsgpu_mesher mlsgpu_mesher;

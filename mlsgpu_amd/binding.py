@@ -222,6 +222,7 @@ def lib():
     sig("mlsgpu_hip_farm_acquire", C.c_int, vp, u64, P(vp))
     sig("mlsgpu_hip_farm_push", C.c_int, vp, u64, vp, vp, u64)
     sig("mlsgpu_hip_farm_submit_device", C.c_int, vp, C.c_int, vp, vp, u64, P(GridStruct), vp, vp, u64)
+    sig("mlsgpu_hip_farm_set_batch", C.c_int, vp, u32)
     sig("mlsgpu_hip_farm_finish", C.c_int, vp)
     sig("mlsgpu_hip_farm_stats", C.c_int, vp, vp)
     sig("mlsgpu_hip_farm_in_flight_max", C.c_int, vp, vp)
@@ -1241,6 +1242,10 @@ class BucketFarm:
         h = C.c_void_p()
         check(lib().mlsgpu_hip_farm_create(C.byref(cfg), self._cb, user, C.byref(h)))
         self.h = h
+
+    def set_batch(self, lanes):
+        """The workers take the buckets of a device item `lanes` at a time through one set of launches."""
+        check(lib().mlsgpu_hip_farm_set_batch(self.h, lanes))
 
     def submit(self, splats, low_extent, num_vertices, chunk_id):
         splats = np.ascontiguousarray(splats)

@@ -9,6 +9,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
@@ -96,6 +97,7 @@ struct Farm
     std::string errorText;
     uint64_t inFlightItems = 0;
     uint64_t inFlightMax = 0;            /* high-water mark of inFlightItems */
+    std::atomic<uint32_t> batch{1};      /* buckets of an item a worker takes through the path in lock-step */
 
     /* staging (CopyGroupBase::Worker: pinned + bufferedItems + bufferedSplats).  A ring of numDevices + 1 (at least
      * two) portable pinned buffers: while one is being filled, one copy per GPU can be in flight, each on its own
@@ -317,6 +319,22 @@ void mesherMain(Farm *f)
     }
 }
 
+struct BatchThunk
+{
+    Farm *farm;
+    DeviceGroup *group;
+    mlsgpu_ctx *ctx;
+    const WorkItem *item;
+};
+
+/* the output functor of a batch: the mesh belongs to the item's bucket `index` */
+int batchOutputThunk(void *user, uint32_t index, void *stream, const mlsgpu_mesh *mesh)
+{
+    BatchThunk *b = static_cast<BatchThunk *>(user);
+    OutputThunk t = {b->farm, b->group, b->ctx, b->item->subItems[index].chunkId};
+    return outputThunk(&t, stream, mesh);
+}
+
 /* DeviceWorkerGroupBase::Worker::operator(), src/workers.cpp:232-286 */
 void workerMain(Farm *farm, DeviceGroup *g)
 {
@@ -357,6 +375,41 @@ void workerMain(Farm *farm, DeviceGroup *g)
                 farm->fail(MLSGPU_ERR_HIP, hipGetErrorString(e));
         }
         size_t processed = 0;
+        const uint32_t lanes = farm->batch.load();
+        if (run && e == hipSuccess && lanes > 1 && item->subItems.size() > 1)
+        {
+            /* the SubItems of the item `lanes` at a time through ONE set of launches (mlsgpu_hip_worker_process_batch);
+             * meshes still arrive bucket by bucket, in order */
+            rc = mlsgpu_hip_worker_set_batch(worker, lanes);
+            std::vector<mlsgpu_subitem> subs(item->subItems.size());
+            for (size_t i = 0; i < subs.size(); i++)
+            {
+                const SubItem &sub = item->subItems[i];
+                subs[i].firstSplat = sub.firstSplat;
+                subs[i].numSplats = sub.numSplats;
+                for (int a = 0; a < 3; a++)
+                {
+                    subs[i].lowExtent[a] = sub.low[a];
+                    subs[i].numVertices[a] = sub.numVertices[a];
+                }
+            }
+            BatchThunk thunk = {farm, g, ctx, item};
+            if (rc == MLSGPU_OK)
+                rc = mlsgpu_hip_worker_process_batch(worker, item->dSplats, subs.data(), (uint32_t) subs.size(), batchOutputThunk, &thunk);
+            if (rc != MLSGPU_OK)
+                farm->fail(rc, mlsgpu_hip_last_error());
+            else
+            {
+                processed = subs.size();
+                std::lock_guard<std::mutex> l(farm->mutex);
+                for (const SubItem &sub : item->subItems)
+                {
+                    g->unallocated += sub.numSplats;         /* src/workers.cpp:281-284 */
+                    g->bucketsDone++;
+                }
+            }
+        }
+        else
         for (size_t i = 0; run && i < item->subItems.size() && e == hipSuccess; i++)
         {
             const SubItem &sub = item->subItems[i];
@@ -865,6 +918,17 @@ MLSGPU_API int mlsgpu_hip_farm_host_stats(mlsgpu_farm *f, uint64_t out[4])
     std::lock_guard<std::mutex> l(f->mutex);
     for (int i = 0; i < 4; i++)
         out[i] = f->hostStats[i];
+    return MLSGPU_OK;
+}
+
+/* Buckets of a device item the workers take through the path in lock-step (1 .. MLSGPU_MAX_BATCH; default 1: bucket by
+ * bucket, the reference's loop).  Takes effect with the next item a worker picks up; every worker then holds `lanes`
+ * sets of per-bucket buffers (mlsgpu_hip_worker_set_batch). */
+MLSGPU_API int mlsgpu_hip_farm_set_batch(mlsgpu_farm *f, uint32_t lanes)
+{
+    REQUIRE(f != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(lanes >= 1 && lanes <= MLSGPU_MAX_BATCH, MLSGPU_ERR_LENGTH);
+    f->batch.store(lanes);
     return MLSGPU_OK;
 }
 

@@ -23,16 +23,18 @@ def test_transform_splats_matches_grid_world_to_vertex():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("workers", [1, 2])
-def test_farm_matches_oracle(workers):
+@pytest.mark.parametrize("workers,lanes", [(1, 1), (2, 1), (1, 4), (2, 3)])
+def test_farm_matches_oracle(workers, lanes):
     """27 buckets submitted one by one; several share a device item (batching); every ship-out of every chunk
-    equals the oracle's, whatever worker thread processed it."""
+    equals the oracle's, whatever worker thread processed it -- bucket by bucket, or with the buckets of an item taken
+    through the path `lanes` at a time (mlsgpu_hip_farm_set_batch)."""
     import mlsgpu_amd as m
     from mlsgpu_amd import synth
     cloud = synth.shells_cloud(120_000, 95.0, 16.0, 1.5, 2.5, seed=321)
     allb, buckets = synth.bucketize(cloud, 96, 32)
-    cap = 3 * max(b.count for b in buckets) // 2          # room for more than one bucket per item
+    cap = (3 if lanes == 1 else 9) * max(b.count for b in buckets) // 2          # room for more than one bucket per item
     farm = m.BucketFarm([0], cap, workers_per_device=workers, collect=True, max_cells=63)
+    farm.set_batch(lanes)
     for i, b in enumerate(buckets):
         if i % 2 == 0:
             farm.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, i)
