@@ -84,6 +84,12 @@ def parse_args():
     p.add_argument("--variant", type=int, default=4, choices=[1, 4],
                    help="MLS kernel: 4 sub-block culling + cube streams (default), 1 the reference's structure")
     p.add_argument("--leg-steps", type=int, default=3, help="passes of every secondary leg")
+    p.add_argument("--legs", default="all", choices=["all", "none"],
+                   help="none: only the timed region, its roofline and (N > 1) the in-run per-GPU reference; all: the secondary legs "
+                        "too (never `value`)")
+    p.add_argument("--leg-budget-s", type=float, default=None,
+                   help="wall-clock budget of ALL secondary legs together (default: 150 s at N > 1, none at N = 1): a leg that would "
+                        "start after it is spent is skipped and named in leg_errors, so the line always arrives")
     p.add_argument("--restore-splats", action="store_true",
                    help="rounds 1-2's protocol: the tree build mutates the resident splats (radius -> 1/radius^2 in place, as the "
                         "reference's does) and every bucket starts with a device-to-device restore of its splats inside the timed "
@@ -96,10 +102,14 @@ def parse_args():
     p.add_argument("--no-partition", action="store_true", help="skip the device-bucketer leg (reference partition)")
     p.add_argument("--partition-max-splats", type=int, default=2097152,
                    help="bucket capacity of the device-bucketer leg (reference default 64 MiB / 32 B)")
+    p.add_argument("--partition-workers", type=int, default=2, help="device workers of the device-bucketer leg when --batch > 1")
     p.add_argument("--no-sink", action="store_true", help="skip the device mesh-sink leg (weld / components / prune)")
     p.add_argument("--no-timing", action="store_true", help="do not time individual kernels with HIP events")
     p.add_argument("--headline-only", action="store_true", help="only the timed region and the roofline")
-    return p.parse_args()
+    a = p.parse_args()
+    if a.legs == "none":
+        a.headline_only = True
+    return a
 
 
 def spawn_ranks(args):
@@ -193,7 +203,10 @@ def run_cfg5(args, rank, world, local_rank, device, dist, reduce_device):
     paths = cfg5_paths(args.cfg5_dir, args.cfg5_files, n, args.dist)
     need = n * 28 + 4096 * len(paths)
     wrote_s = 0.0
-    if rank == 0 and not all(os.path.exists(p) and os.path.getsize(p) > 0 for p in paths):
+    # files left by an earlier run are reused only when every one has EXACTLY the size the generator gives it (header + 28
+    # bytes per splat): a file truncated by a killed run is written again, not read
+    sizes = synth.cloud_ply_sizes(len(paths), "cfg5", args.scale)
+    if rank == 0 and not all(os.path.exists(p) and os.path.getsize(p) == sz for p, sz in zip(paths, sizes)):
         free = shutil.disk_usage(args.cfg5_dir).free
         if free < need * 1.05:
             raise SystemExit("cfg5: %s has %.1f GB free, the files need %.1f GB (use --cfg5-dir or --scale)"
@@ -601,7 +614,7 @@ def host_weld_leg(m, args, device_index, bucketed_host, buckets, max_count, max_
 
 
 def multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, local_rank, ndev, ctx, bucketed_t, buckets, max_count,
-                   max_cells, voxels, L, nworkers):
+                   max_cells, voxels, L, nworkers, deadline=None):
     """N > 1 only, never `value`.
     transfer_inclusive: SURVEY 8(d)'s region on every rank at once, with the weld in it -- host splats -> the rank's farm
         (pinned staging, H2D) -> device workers -> ship-outs appended to the rank's device sink -> dist_sink.global_prune
@@ -616,6 +629,19 @@ def multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, loca
 
     class LegFailed(Exception):
         pass
+
+    def in_budget(what):
+        """collective: False on every rank once ANY rank's clock is past the deadline of the secondary legs; the leg is then
+        skipped everywhere (nobody waits in a collective the others never reach) and named in leg_errors"""
+        if deadline is None:
+            return True
+        t = torch.tensor([1 if time.perf_counter() > deadline else 0], dtype=torch.int64, device=reduce_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if int(t.item()) != 0:
+            result.setdefault("leg_errors", {})[what] = ("skipped: the %.0f s budget of the secondary legs was spent (--leg-budget-s)"
+                                                         % args.leg_budget_s)
+            return False
+        return True
 
     def all_ok(ok, what):
         """collective: True on every rank iff every rank is fine -- a rank that failed locally must not leave the others in
@@ -643,6 +669,7 @@ def multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, loca
     # ---- transfer-inclusive, every rank, with the cross-rank weld ----
     local_error = None
     host = views = sink = bfarm = pinned = None
+    run_transfer = in_budget("transfer_inclusive")
     try:
         host = bucketed_t.cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
         views = [host[b.first:b.first + b.count] for b in buckets]
@@ -686,7 +713,11 @@ def multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, loca
         return nbytes
     try:
         all_ok(local_error is None, "set-up")
+        if not run_transfer:
+            raise LegFailed("budget")
         sink_pass()                                       # warm-up: arenas, pinned landing buffer
+        if not in_budget("transfer_inclusive (timed passes)"):
+            raise LegFailed("budget")
         dt, nbytes = wall(sink_pass, L)
         tot = torch.tensor([float(nbytes), float(host.nbytes)], dtype=torch.float64, device=reduce_device)
         dist.all_reduce(tot)
@@ -702,7 +733,8 @@ def multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, loca
                         "whole job) -> output pass -> the rank's mesh read back into pinned memory; time = slowest rank" % nworkers},
             "distribution": "uniform"}
     except LegFailed as e:
-        result["transfer_inclusive"] = {"error": "a rank failed in %s%s" % (e, ": " + local_error if local_error else "")}
+        if str(e) != "budget":
+            result["transfer_inclusive"] = {"error": "a rank failed in %s%s" % (e, ": " + local_error if local_error else "")}
     for obj in (bfarm, sink):
         try:
             if obj is not None:
@@ -716,11 +748,13 @@ def multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, loca
     devices = [d % ndev for d in range(world)]
     single = None
     torch.cuda.synchronize()
+    if not in_budget("single_process"):
+        return
     dist.barrier(group=park)
     try:
         if rank == 0:
             single = single_process_leg(m, args, result, ctx, local_rank, devices, bucketed_t, buckets, views, max_count, max_cells,
-                                        voxels, L, nworkers, world)
+                                        voxels, L, nworkers, world, deadline)
     except Exception as e:      # noqa: BLE001 - rank 0 still has to reach the barrier the others wait at
         single = {"error": "%s: %s" % (type(e).__name__, e)}
     dist.barrier(group=park)
@@ -729,7 +763,7 @@ def multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, loca
 
 
 def single_process_leg(m, args, result, ctx, local_rank, devices, bucketed_t, buckets, views, max_count, max_cells, voxels, L,
-                       nworkers, world):
+                       nworkers, world, deadline=None):
     """The reference's own shape (src/mlsgpu_core.cpp:704-741) on rank 0: one farm over every GPU, N x rank 0's slab."""
     sfarm = m.BucketFarm(devices, max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
                          mesh_memory=args.mesh_memory_mb << 20)
@@ -739,12 +773,21 @@ def single_process_leg(m, args, result, ctx, local_rank, devices, bucketed_t, bu
             for i, (b, v) in enumerate(zip(buckets, views)):
                 sfarm.submit(v, b.low, b.num_vertices, rep)
         sfarm.finish()
-    host_fed()
-    s0 = sfarm.stats()
+    def passes():
+        # as many timed passes as the budget of the secondary legs still allows (rank 0 works alone here: its clock rules)
+        return L if deadline is None else (L if time.perf_counter() + 2.0 < deadline else 1)
     t0 = time.perf_counter()
-    for _ in range(L):
+    host_fed()
+    warm_s = time.perf_counter() - t0
+    if deadline is not None and time.perf_counter() + warm_s > deadline:
+        sfarm.close()
+        return {"error": "skipped after the warm-up pass (%.1f s): the budget of the secondary legs was spent" % warm_s}
+    s0 = sfarm.stats()
+    Lh = passes()
+    t0 = time.perf_counter()
+    for _ in range(Lh):
         host_fed()
-    host_s = (time.perf_counter() - t0) / L
+    host_s = (time.perf_counter() - t0) / Lh
     s1 = sfarm.stats()
     # the same buckets resident on GPU 0, handed out by device gathers (another GPU's group: scratch ring + peer copy)
     raw = m.DeviceBuffer(ctx, nbytes=bucketed_t.numel() * 4, borrow=bucketed_t.data_ptr())
@@ -762,20 +805,27 @@ def single_process_leg(m, args, result, ctx, local_rank, devices, bucketed_t, bu
                 sfarm.submit_device(local_rank, _Sub(raw.ptr + 32 * b.first), iota.ptr, b.count, (0.0, 0.0, 0.0), 1.0, ext,
                                     b.low, b.num_vertices, rep)
         sfarm.finish()
+    if deadline is not None and time.perf_counter() > deadline:
+        sfarm.close()
+        return {"devices": devices, "buckets_per_pass": world * len(buckets),
+                "host_fed": {"value": round(voxels * world / host_s / 1e6, 3), "unit": "Mvoxels/s", "ms_per_pass": round(host_s * 1e3, 2),
+                             "h2d_GBps": round((s1["h2d_bytes"] - s0["h2d_bytes"]) / Lh / host_s / 1e9, 2)},
+                "device_fed": {"error": "skipped: the budget of the secondary legs was spent"}}
     device_fed()
     s1b = sfarm.stats()
+    Ld = passes()
     t0 = time.perf_counter()
-    for _ in range(L):
+    for _ in range(Ld):
         device_fed()
-    dev_s = (time.perf_counter() - t0) / L
+    dev_s = (time.perf_counter() - t0) / Ld
     s2 = sfarm.stats()
     single = {
         "devices": devices, "buckets_per_pass": world * len(buckets),
         "host_fed": {"value": round(voxels * world / host_s / 1e6, 3), "unit": "Mvoxels/s", "ms_per_pass": round(host_s * 1e3, 2),
-                     "h2d_GBps": round((s1["h2d_bytes"] - s0["h2d_bytes"]) / L / host_s / 1e9, 2)},
+                     "h2d_GBps": round((s1["h2d_bytes"] - s0["h2d_bytes"]) / Lh / host_s / 1e9, 2)},
         "device_fed": {"value": round(voxels * world / dev_s / 1e6, 3), "unit": "Mvoxels/s", "ms_per_pass": round(dev_s * 1e3, 2)},
         "buckets_per_device_device_fed": [int(x) for x in (np.array(s2["per_device"][:world]) - np.array(s1b["per_device"][:world]))],
-        "device_fed_passes": L,
+        "device_fed_passes": Ld,
         "in_flight_max": s2["in_flight_max"],
         "note": "ONE process (rank 0) with one device group per GPU, %d workers each, the other ranks idle: N x rank 0's slab "
                 "from pageable host memory through ONE copy side (4 copy threads -> pinned staging -> H2D to the chosen "
@@ -1056,6 +1106,9 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "msplats_per_s": round(total_splats * args.steps / elapsed / 1e6, 3),
+        # what the timed region does with the resident input (rounds 1-2 timed a per-bucket restore copy in place of the
+        # reference's per-item H2D transfer; the other protocol's step is under other_splat_protocol)
+        "input_protocol": "restored_by_d2d_copy_per_bucket" if args.restore_splats else "resident_in_place",
         "timed_region_s": round(elapsed, 3),
         "config": {
             "workload": W["text"],
@@ -1253,9 +1306,18 @@ def main():
     secondary = dist is None and not args.headline_only
     L = max(1, args.leg_steps)
 
+    # N > 1: the headline, the in-run per-GPU reference and the scaling efficiency leave on stderr BEFORE any secondary leg
+    # starts (the ONE line on stdout comes at the end): whatever happens to a leg, the curve is on record
+    if dist is not None and rank == 0:
+        early = {k: result[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "per_gpu_reference",
+                                        "scaling_efficiency") if k in result}
+        print("bench.py headline before the secondary legs: " + json.dumps(early), file=sys.stderr, flush=True)
+    if args.leg_budget_s is None and dist is not None:
+        args.leg_budget_s = 150.0
+    leg_deadline = None if args.leg_budget_s is None else time.perf_counter() + args.leg_budget_s
     if dist is not None and not args.headline_only:
         multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, local_rank, ndev, ctxs[0], bucketed_t, buckets,
-                       max_count, max_cells, voxels, L, max(1, args.farm_workers))
+                       max_count, max_cells, voxels, L, max(1, args.farm_workers), leg_deadline)
 
     # ---- mesh-sink leg (never `value`): every ship-out of one pass appended to the device mesher (d2d), then
     # finalize = weld by key across buckets + connected components + prune (--fit-prune default 0.02) + compaction ----
@@ -1331,9 +1393,13 @@ def main():
             pcells = max(max(l["extents"][2 * i + 1] - l["extents"][2 * i] for i in range(3)) for l in leaves)
             # the bucketer's callback hands every leaf to the bucket farm's device path (gather + transform kernel into a
             # device item, then the farm's worker threads), as CopyGroup does with host buckets
-            pworkers = max(1, args.farm_workers)
-            pfarm = m.BucketFarm([local_rank], pmax, workers_per_device=pworkers, spare=1, max_cells=pcells,
-                                 mesh_memory=args.mesh_memory_mb << 20)
+            # the leaves arrive one per device item; with lanes a worker takes as many queued items as fit a batch
+            # through one set of launches (mlsgpu_hip_farm_set_batch), so fewer workers and more spare items
+            pbatch = max(1, min(args.batch, m.binding.MAX_BATCH))
+            pworkers = max(1, args.farm_workers) if pbatch == 1 else max(1, args.partition_workers)
+            pfarm = m.BucketFarm([local_rank], pmax, workers_per_device=pworkers, spare=1 if pbatch == 1 else pbatch * pworkers,
+                                 max_cells=pcells, mesh_memory=args.mesh_memory_mb << 20)
+            pfarm.set_batch(pbatch)
             leaf_no = [0]
 
             def leaf_work(leaf, d_ids):
@@ -1357,7 +1423,7 @@ def main():
                 "max_bucket_cells": int(pcells), "bucketing_ms": round(part_s * 1e3, 3),
                 "bucketing_msplats_per_s": round(n_splats / part_s / 1e6, 1),
                 "pipeline_ms_per_step": round(pipe_s * 1e3, 3), "pipeline_mvoxels_per_s": round(pvox / pipe_s / 1e6, 3),
-                "device_workers": pworkers,
+                "device_workers": pworkers, "batch": pbatch,
                 "note": "raw cloud resident in HBM -> mlsgpu_hip_bucket (reference partition) -> mlsgpu_hip_farm_submit_device "
                         "(device gather + transform) -> the farm's device workers; bucketing is inside the pipeline time",
             }

@@ -293,6 +293,8 @@ typedef struct mlsgpu_subitem
     uint64_t firstSplat, numSplats;
     int32_t lowExtent[3];
     uint32_t numVertices[3];
+    mlsgpu_splat *dSplats;      /* NULL: the buffer given to the call (one WorkItem); else this bucket's own buffer, so that
+                                 * the buckets of several small WorkItems can share a batch */
 } mlsgpu_subitem;
 /* Lanes: how many buckets the worker takes through the path in lock-step (1 .. MLSGPU_MAX_BATCH; default 1).  Each lane
  * owns a tree, a distance field, a lattice and a mesh arena (mlsgpu_hip_worker_resource_usage bytes per lane). */

@@ -77,7 +77,7 @@ class WorkerConfig(C.Structure):
 class SubItem(C.Structure):
     """mlsgpu_subitem: DeviceWorkerGroup::SubItem, src/workers.h:161-168."""
     _fields_ = [("firstSplat", C.c_uint64), ("numSplats", C.c_uint64), ("lowExtent", C.c_int32 * 3),
-                ("numVertices", C.c_uint32 * 3)]
+                ("numVertices", C.c_uint32 * 3), ("dSplats", C.c_void_p)]
 
 
 class TreeBuild(C.Structure):

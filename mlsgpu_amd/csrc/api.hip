@@ -582,10 +582,13 @@ MLSGPU_API int mlsgpu_hip_worker_process(mlsgpu_worker *w, mlsgpu_splat *dSplats
 MLSGPU_API int mlsgpu_hip_worker_process_batch(mlsgpu_worker *w, mlsgpu_splat *dSplats, const mlsgpu_subitem *items,
                                                uint32_t numItems, mlsgpu_batch_output_fn output, void *outputUser)
 {
-    REQUIRE(w != nullptr && dSplats != nullptr && (items != nullptr || numItems == 0), MLSGPU_ERR_INVALID);
+    REQUIRE(w != nullptr && (items != nullptr || numItems == 0), MLSGPU_ERR_INVALID);
     for (uint32_t i = 0; i < numItems; i++)
+    {
+        REQUIRE(dSplats != nullptr || items[i].dSplats != nullptr, MLSGPU_ERR_INVALID);
         for (int a = 0; a < 3; a++)
             REQUIRE(items[i].lowExtent[a] >= 0, MLSGPU_ERR_INVALID);     /* keyOffset is cl_uint in the reference */
+    }
     w->batchOutput = output;
     w->batchOutputData = outputUser;
     const uint32_t width = (uint32_t) w->lanes.size();
@@ -604,7 +607,7 @@ MLSGPU_API int mlsgpu_hip_worker_process_batch(mlsgpu_worker *w, mlsgpu_splat *d
             WorkerLane &l = w->lanes[k];
             trees[k] = l.tree;
             marchings[k] = l.marching;
-            builds[k].dSplats = dSplats;
+            builds[k].dSplats = it.dSplats != nullptr ? it.dSplats : dSplats;
             builds[k].firstSplat = it.firstSplat;
             builds[k].numSplats = it.numSplats;
             for (int a = 0; a < 3; a++)

@@ -324,14 +324,14 @@ struct BatchThunk
     Farm *farm;
     DeviceGroup *group;
     mlsgpu_ctx *ctx;
-    const WorkItem *item;
+    std::vector<uint64_t> chunkIds;         /* of the batch's buckets, in order */
 };
 
-/* the output functor of a batch: the mesh belongs to the item's bucket `index` */
+/* the output functor of a batch: the mesh belongs to bucket `index` */
 int batchOutputThunk(void *user, uint32_t index, void *stream, const mlsgpu_mesh *mesh)
 {
     BatchThunk *b = static_cast<BatchThunk *>(user);
-    OutputThunk t = {b->farm, b->group, b->ctx, b->item->subItems[index].chunkId};
+    OutputThunk t = {b->farm, b->group, b->ctx, b->chunkIds[index]};
     return outputThunk(&t, stream, mesh);
 }
 
@@ -351,14 +351,22 @@ void workerMain(Farm *farm, DeviceGroup *g)
     }
     for (;;)
     {
-        WorkItem *item = nullptr;
+        /* One item, or -- with lanes -- as many queued items as fit a batch: device-side leaves arrive one bucket per item
+         * (mlsgpu_hip_farm_submit_device), and the buckets of several such items share one set of launches. */
+        std::vector<WorkItem *> taken;
+        const uint32_t lanes = farm->batch.load();
         {
             std::unique_lock<std::mutex> l(farm->mutex);
             farm->queueCond.wait(l, [&] { return farm->stopping || !g->queue.empty(); });
             if (g->queue.empty())
                 break;
-            item = g->queue.front();
-            g->queue.pop_front();
+            size_t subs = 0;
+            do
+            {
+                taken.push_back(g->queue.front());
+                subs += g->queue.front()->subItems.size();
+                g->queue.pop_front();
+            } while (lanes > 1 && !g->queue.empty() && subs + g->queue.front()->subItems.size() <= lanes);
         }
         /* after a failure the queued items are only handed back, so that finish() and destroy() never wait for them */
         bool run = ctx != nullptr;
@@ -368,82 +376,101 @@ void workerMain(Farm *farm, DeviceGroup *g)
         }
         /* wait[0] = work.copyEvent (src/workers.cpp:268) */
         hipError_t e = hipSuccess;
-        if (run)
-        {
-            e = hipStreamWaitEvent(static_cast<hipStream_t>(mlsgpu_hip_ctx_stream(ctx)), item->copyEvent, 0);
-            if (e != hipSuccess)
-                farm->fail(MLSGPU_ERR_HIP, hipGetErrorString(e));
-        }
-        size_t processed = 0;
-        const uint32_t lanes = farm->batch.load();
-        if (run && e == hipSuccess && lanes > 1 && item->subItems.size() > 1)
-        {
-            /* the SubItems of the item `lanes` at a time through ONE set of launches (mlsgpu_hip_worker_process_batch);
-             * meshes still arrive bucket by bucket, in order */
-            rc = mlsgpu_hip_worker_set_batch(worker, lanes);
-            std::vector<mlsgpu_subitem> subs(item->subItems.size());
-            for (size_t i = 0; i < subs.size(); i++)
+        for (WorkItem *item : taken)
+            if (run && e == hipSuccess)
             {
-                const SubItem &sub = item->subItems[i];
-                subs[i].firstSplat = sub.firstSplat;
-                subs[i].numSplats = sub.numSplats;
-                for (int a = 0; a < 3; a++)
-                {
-                    subs[i].lowExtent[a] = sub.low[a];
-                    subs[i].numVertices[a] = sub.numVertices[a];
-                }
+                e = hipStreamWaitEvent(static_cast<hipStream_t>(mlsgpu_hip_ctx_stream(ctx)), item->copyEvent, 0);
+                if (e != hipSuccess)
+                    farm->fail(MLSGPU_ERR_HIP, hipGetErrorString(e));
             }
-            BatchThunk thunk = {farm, g, ctx, item};
+        std::vector<size_t> processed(taken.size(), 0);
+        size_t numSubs = 0;
+        for (WorkItem *item : taken)
+            numSubs += item->subItems.size();
+        if (run && e == hipSuccess && lanes > 1 && numSubs > 1)
+        {
+            /* the SubItems `lanes` at a time through ONE set of launches (mlsgpu_hip_worker_process_batch); meshes still
+             * arrive bucket by bucket, in order */
+            rc = mlsgpu_hip_worker_set_batch(worker, lanes);
+            std::vector<mlsgpu_subitem> subs;
+            BatchThunk thunk = {farm, g, ctx, {}};
+            for (WorkItem *item : taken)
+                for (const SubItem &sub : item->subItems)
+                {
+                    mlsgpu_subitem s;
+                    s.firstSplat = sub.firstSplat;
+                    s.numSplats = sub.numSplats;
+                    for (int a = 0; a < 3; a++)
+                    {
+                        s.lowExtent[a] = sub.low[a];
+                        s.numVertices[a] = sub.numVertices[a];
+                    }
+                    s.dSplats = item->dSplats;
+                    subs.push_back(s);
+                    thunk.chunkIds.push_back(sub.chunkId);
+                }
             if (rc == MLSGPU_OK)
-                rc = mlsgpu_hip_worker_process_batch(worker, item->dSplats, subs.data(), (uint32_t) subs.size(), batchOutputThunk, &thunk);
+                rc = mlsgpu_hip_worker_process_batch(worker, nullptr, subs.data(), (uint32_t) subs.size(), batchOutputThunk, &thunk);
             if (rc != MLSGPU_OK)
                 farm->fail(rc, mlsgpu_hip_last_error());
             else
             {
-                processed = subs.size();
                 std::lock_guard<std::mutex> l(farm->mutex);
-                for (const SubItem &sub : item->subItems)
+                for (size_t t = 0; t < taken.size(); t++)
                 {
-                    g->unallocated += sub.numSplats;         /* src/workers.cpp:281-284 */
-                    g->bucketsDone++;
+                    processed[t] = taken[t]->subItems.size();
+                    for (const SubItem &sub : taken[t]->subItems)
+                    {
+                        g->unallocated += sub.numSplats;         /* src/workers.cpp:281-284 */
+                        g->bucketsDone++;
+                    }
                 }
             }
         }
         else
-        for (size_t i = 0; run && i < item->subItems.size() && e == hipSuccess; i++)
-        {
-            const SubItem &sub = item->subItems[i];
-            OutputThunk thunk = {farm, g, ctx, sub.chunkId};
-            rc = mlsgpu_hip_worker_process(worker, item->dSplats, sub.firstSplat, sub.numSplats, sub.low, sub.numVertices,
-                                           outputThunk, &thunk);
-            if (rc != MLSGPU_OK)
+            for (size_t t = 0; t < taken.size(); t++)
             {
-                farm->fail(rc, mlsgpu_hip_last_error());
-                break;
+                WorkItem *item = taken[t];
+                for (size_t i = 0; run && i < item->subItems.size() && e == hipSuccess; i++)
+                {
+                    const SubItem &sub = item->subItems[i];
+                    OutputThunk thunk = {farm, g, ctx, sub.chunkId};
+                    rc = mlsgpu_hip_worker_process(worker, item->dSplats, sub.firstSplat, sub.numSplats, sub.low, sub.numVertices,
+                                                   outputThunk, &thunk);
+                    if (rc != MLSGPU_OK)
+                    {
+                        farm->fail(rc, mlsgpu_hip_last_error());
+                        run = false;
+                        break;
+                    }
+                    processed[t] = i + 1;
+                    std::lock_guard<std::mutex> l(farm->mutex);
+                    g->unallocated += sub.numSplats;         /* src/workers.cpp:281-284 */
+                    g->bucketsDone++;
+                }
             }
-            processed = i + 1;
-            std::lock_guard<std::mutex> l(farm->mutex);
-            g->unallocated += sub.numSplats;         /* src/workers.cpp:281-284 */
-            g->bucketsDone++;
-        }
-        if (processed < item->subItems.size())
+        for (size_t t = 0; t < taken.size(); t++)
         {
-            /* a failed or skipped item (the farm has failed: it refuses further work and can only be finished and destroyed):
-             * the copy that filled it may still be running -- it must not be when the item is handed out again -- and the
-             * splats of the buckets that were not processed go back to the group's capacity */
-            hipStreamSynchronize(g->copyStream);
-            std::lock_guard<std::mutex> l(farm->mutex);
-            for (size_t i = processed; i < item->subItems.size(); i++)
-                g->unallocated += item->subItems[i].numSplats;
-        }
-        {
-            /* freeItem, src/workers.cpp:148-161 */
-            std::lock_guard<std::mutex> l(farm->mutex);
-            item->subItems.clear();
-            g->pool.push_back(item);
-            farm->inFlightItems--;
-            farm->popCond.notify_all();
-            farm->idleCond.notify_all();
+            WorkItem *item = taken[t];
+            if (processed[t] < item->subItems.size())
+            {
+                /* a failed or skipped item (the farm has failed: it refuses further work and can only be finished and
+                 * destroyed): the copy that filled it may still be running -- it must not be when the item is handed out
+                 * again -- and the splats of the buckets that were not processed go back to the group's capacity */
+                hipStreamSynchronize(g->copyStream);
+                std::lock_guard<std::mutex> l(farm->mutex);
+                for (size_t i = processed[t]; i < item->subItems.size(); i++)
+                    g->unallocated += item->subItems[i].numSplats;
+            }
+            {
+                /* freeItem, src/workers.cpp:148-161 */
+                std::lock_guard<std::mutex> l(farm->mutex);
+                item->subItems.clear();
+                g->pool.push_back(item);
+                farm->inFlightItems--;
+                farm->popCond.notify_all();
+                farm->idleCond.notify_all();
+            }
         }
     }
     if (ctx != nullptr)

@@ -205,6 +205,14 @@ def ply_header(count):
             + "".join("property float32 %s\n" % n for n in ("x", "y", "z", "nx", "ny", "nz", "radius")) + "end_header\n").encode("ascii")
 
 
+def cloud_ply_sizes(num_files, cfg, scale=1.0):
+    """The exact size in bytes of each file write_cloud_ply makes: header + 28 bytes per splat of the file's id range."""
+    n = max(int(CONFIGS[cfg]["splats"] * scale), 1)
+    base, extra = divmod(n, num_files)
+    return [len(ply_header(base + (1 if k < extra else 0))) + PLY_ROW.itemsize * (base + (1 if k < extra else 0))
+            for k in range(num_files)]
+
+
 def write_cloud_ply(paths, cfg, device, scale=1.0, dist="uniform", chunk=16_000_000):
     """Writes the cloud of a BASELINE config as len(paths) binary PLY files (equal, consecutive id ranges), generating it on
     `device` chunk by chunk -- the 10^9 splats of cfg5 never exist in one piece outside the files (28 GB).  One writer

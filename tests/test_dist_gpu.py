@@ -126,6 +126,36 @@ def test_bench_two_ranks_one_sharded_cloud():
     assert out.returncode != 0 and "does not match WORLD_SIZE" in (out.stdout + out.stderr)
 
 
+def test_driver_shaped_call_finishes_in_time():
+    """`bench.py --gpus 2 --steps 20 --warmup 5` exactly as the driver launches it, at FULL size (two slabs of cfg4: 200 M-splat
+    cloud per rank, 25 buckets each), both ranks on this box's one GPU: the line arrives within 300 s whatever the secondary
+    legs do -- they share a wall-clock budget (--leg-budget-s, 150 s by default at N > 1) and a leg that does not fit is
+    skipped and named in leg_errors -- and the headline with the in-run per-GPU reference is on stderr before any leg starts."""
+    import time
+    env = {"MLSGPU_BENCH_BACKEND": "gloo"}
+    t0 = time.time()
+    out = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"], env)
+    elapsed = time.time() - t0
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert elapsed < 300, elapsed
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["per_rank"]["buckets"] == [25, 25] and d["output_digest"]["ok"]
+    assert d["per_gpu_reference"]["value"] > 0 and 0 < d["scaling_efficiency"] < 2
+    early = [l for l in out.stderr.splitlines() if l.startswith("bench.py headline before the secondary legs: ")]
+    assert len(early) == 1
+    e = json.loads(early[0].split(": ", 1)[1])
+    assert e["value"] == d["value"] and e["scaling_efficiency"] == d["scaling_efficiency"]
+    # every secondary leg either reported or was skipped by name
+    for leg in ("transfer_inclusive", "single_process"):
+        assert leg in d or any(k.startswith(leg) for k in d.get("leg_errors", {})), leg
+    # and --legs none is the headline alone
+    out = _launch(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--scale", "0.02", "--steps", "2", "--warmup", "1",
+                      "--legs", "none"], env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert "transfer_inclusive" not in d and "single_process" not in d and d["per_gpu_reference"]["value"] > 0
+
+
 def test_bench_rccl_code_path_with_one_rank():
     """The N > 1 code path of bench.py over RCCL (`nccl` backend: process group with a device id, float64 / int64 all-reduces
     on the GPU, all_gather_object, the gloo side group the waiting ranks park on, every N > 1 leg) with ONE rank on the box's
