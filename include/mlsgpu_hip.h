@@ -381,7 +381,8 @@ typedef int (*mlsgpu_farm_host_output_fn)(void *user, int device, uint64_t chunk
  * next bucket -- and `fn` on the mesher thread once the reads have completed.  fn may be NULL (meshes are read back and
  * dropped).  Works for any number of GPUs: this is the path that brings buckets of different devices to ONE welder
  * (mlsgpu_hip_host_mesher_*).  Call before the first bucket is submitted; a device-side output functor given to
- * mlsgpu_hip_farm_create still runs first.  A ship-out larger than ringBytes is MLSGPU_ERR_LENGTH. */
+ * mlsgpu_hip_farm_create still runs first.  A ship-out larger than ringBytes is MLSGPU_ERR_LENGTH.  Calling it again
+ * BETWEEN jobs (after mlsgpu_hip_farm_finish) hands the next job's meshes to another consumer; the ring keeps its size. */
 int mlsgpu_hip_farm_set_host_output(mlsgpu_farm *farm, uint64_t ringBytes, mlsgpu_farm_host_output_fn fn, void *user);
 /* out[0] meshes read back, [1] bytes, [2] times a worker waited for ring space, [3] largest mesh in bytes */
 int mlsgpu_hip_farm_host_stats(mlsgpu_farm *farm, uint64_t out[4]);
@@ -507,6 +508,12 @@ typedef struct mlsgpu_host_mesher mlsgpu_host_mesher;
 int mlsgpu_hip_host_mesher_create(mlsgpu_host_mesher **out);
 void mlsgpu_hip_host_mesher_destroy(mlsgpu_host_mesher *mesher);
 int mlsgpu_hip_host_mesher_set_prune_threshold(mlsgpu_host_mesher *mesher, double threshold);
+/* Threads of the welder: add() copies the block and queues its work (local components, key map: OOCMesher::add,
+ * src/mesher.cpp:370-469) as a task, and finalize builds the output block by block on the same pool (the reference runs
+ * one mesher thread and parallelises its heavy rewrite with OpenMP, src/mesher.cpp:597-600).  0 = default:
+ * MLSGPU_HIP_HOST_MESHER_THREADS, else min(32, hardware threads).  Before the first add; results do not depend on it. */
+int mlsgpu_hip_host_mesher_set_threads(mlsgpu_host_mesher *mesher, uint32_t threads);
+uint32_t mlsgpu_hip_host_mesher_threads(mlsgpu_host_mesher *mesher);
 int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *mesher, uint64_t chunkId, const mlsgpu_host_mesh *mesh);
 /* a mlsgpu_farm_host_output_fn whose `user` is the mlsgpu_host_mesher */
 int mlsgpu_hip_host_mesher_farm_output(void *mesher, int device, uint64_t chunkId, const mlsgpu_host_mesh *mesh);

@@ -232,6 +232,8 @@ def lib():
     sig("mlsgpu_hip_host_mesher_create", C.c_int, P(vp))
     sig("mlsgpu_hip_host_mesher_destroy", None, vp)
     sig("mlsgpu_hip_host_mesher_set_prune_threshold", C.c_int, vp, C.c_double)
+    sig("mlsgpu_hip_host_mesher_set_threads", C.c_int, vp, u32)
+    sig("mlsgpu_hip_host_mesher_threads", u32, vp)
     sig("mlsgpu_hip_host_mesher_add", C.c_int, vp, u64, P(HostMesh))
     sig("mlsgpu_hip_host_mesher_farm_output", C.c_int, vp, C.c_int, u64, P(HostMesh))
     sig("mlsgpu_hip_host_mesher_finalize", C.c_int, vp, P(u32))
@@ -812,11 +814,16 @@ class HostMesher:
     """OOCMesher's weld on the host (src/mesher.cpp:220-469), in memory: the cross-GPU welder behind
     BucketFarm.set_host_output (include/mlsgpu_hip.h, "host mesh sink")."""
 
-    def __init__(self, prune_threshold=0.0):
+    def __init__(self, prune_threshold=0.0, threads=0):
         h = C.c_void_p()
         check(lib().mlsgpu_hip_host_mesher_create(C.byref(h)))
         self.h = h
         check(lib().mlsgpu_hip_host_mesher_set_prune_threshold(self.h, prune_threshold))
+        if threads:
+            check(lib().mlsgpu_hip_host_mesher_set_threads(self.h, threads))
+
+    def threads(self):
+        return lib().mlsgpu_hip_host_mesher_threads(self.h)
 
     def add(self, chunk_id, vertices, num_internal, keys, triangles):
         """keys: the external vertices' keys (len(vertices) - num_internal of them)."""

@@ -656,7 +656,16 @@ MLSGPU_API int mlsgpu_hip_farm_create(const mlsgpu_farm_config *cfg, mlsgpu_farm
 MLSGPU_API int mlsgpu_hip_farm_set_host_output(mlsgpu_farm *f, uint64_t ringBytes, mlsgpu_farm_host_output_fn fn, void *user)
 {
     REQUIRE(f != nullptr && ringBytes >= 4096, MLSGPU_ERR_INVALID);
-    REQUIRE(!f->hostOutput, MLSGPU_ERR_INVALID);
+    if (f->hostOutput)
+    {
+        /* between jobs (everything submitted has been finished): the next job's meshes go to another consumer; the ring
+         * keeps its size */
+        std::lock_guard<std::mutex> l(f->mutex);
+        REQUIRE(f->inFlightItems == 0 && f->hostQueue.empty() && f->bufferedItems.empty(), MLSGPU_ERR_INVALID);
+        f->hostFn = fn;
+        f->hostUser = user;
+        return MLSGPU_OK;
+    }
     REQUIRE(f->stats[0] == 0, MLSGPU_ERR_INVALID);          /* before the first bucket */
     ringBytes = (ringBytes + 63) & ~uint64_t(63);
     if (hipHostMalloc((void **) &f->ring, ringBytes, hipHostMallocPortable) != hipSuccess)

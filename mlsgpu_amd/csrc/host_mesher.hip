@@ -1,101 +1,415 @@
 /*
- * Host mesh sink: the weld OOCMesher performs on the reference's single mesher thread (src/mesher.cpp:220-469),
- * kept in memory.  This is the north_star's "welding stays on host" route and the cross-GPU welder: ship-outs of any
- * device reach it through the bucket farm's pinned circular buffer (mlsgpu_hip_farm_set_host_output).
+ * Host mesh sink: the weld OOCMesher performs on the host (src/mesher.cpp:220-469), kept in memory.  This is the
+ * north_star's "welding stays on host" route and the cross-GPU welder: ship-outs of any device reach it through the
+ * bucket farm's pinned circular buffer (mlsgpu_hip_farm_set_host_output).
  *
- * add() does what OOCMesher::add does per block (:370-469): union-find over two edges per triangle gives the block's
- * local components ("clumps", computeLocalComponents :220-236, updateGlobalClumps :238-281), and every external key
- * that has been seen before merges the two clumps and un-counts the shared vertex (updateClumpKeyMap :286-311).
- * finalize() is the part of MesherBase::write that precedes the file output (:763-852): component sizes, the prune
- * threshold uint64(total * threshold) with the `>=` keep test (getStatistics :491-536), and one mesh per chunk in
- * which a key occurs once (externalRemap :538-567).  Differences from the reference, all invisible up to the
- * isomorphism its own tests compare by (test/test_mesher.cpp:401-460): no temporary files and no reorder buffer
- * (host memory is the arena), output order is (chunk by first arrival, block arrival, order inside the block) exactly
- * as the device sink's (mesher.hip), so the two sinks can be compared element for element.
+ * What the reference does per block on its ONE mesher thread (OOCMesher::add, :370-469) -- union-find over two edges per
+ * triangle for the block's local components ("clumps", computeLocalComponents :220-236, updateGlobalClumps :238-281),
+ * and for every external key seen before a merge of the two clumps and one vertex un-counted (updateClumpKeyMap :286-311)
+ * -- is here a TASK per block on a pool of threads (the reference parallelises its heavy rewrite with OpenMP,
+ * src/mesher.cpp:597-600; with eight GPUs behind one welder a single thread is the whole job's limit, as its manual says,
+ * doc/mlsgpu-user-manual.xml:508-511).  add() copies the block out of the caller's memory (the farm's ring slot is free
+ * again when it returns), checks its indices and queues the task; nothing a task does depends on another block:
+ *   - the block's components and their vertex / triangle counts are local;
+ *   - the key map is SHARDED by key hash (a lock per shard): the first clump seen for a key, every later occurrence as a
+ *     (clump, clump) record -- one union and one un-counted vertex each, applied in finalize -- and per (key, chunk) the
+ *     first occurrence in ARRIVAL order, which is the vertex externalRemap (:538-567) keeps in that chunk's file.
+ * Clump ids, union records and owners are expressed in (arrival number, index inside the block), so the result does not
+ * depend on which thread ran what when.  finalize() is the part of MesherBase::write that precedes the file output
+ * (:763-852): the unions, component sizes, the prune threshold uint64(total * threshold) with the `>=` keep test
+ * (getStatistics :491-536), and one mesh per chunk in which a key occurs once, built by the pool block by block (three
+ * passes: what is emitted, vertex ranks and copies, aliases and triangles).  Differences from the reference, all invisible
+ * up to the isomorphism its own tests compare by (test/test_mesher.cpp:401-460): no temporary files and no reorder buffer
+ * (host memory is the arena), output order is (chunk by first arrival, block arrival, order inside the block) exactly as
+ * the device sink's (mesher.hip), so the two sinks can be compared element for element.
  *
  * Host code only; it lives in the HIP library because the farm's mesher thread calls it.
  */
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdlib>
+#include <deque>
+#include <functional>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
+
+#include <sys/mman.h>
 
 using namespace mlsgpu;
 
 namespace
 {
 
-struct Block
+/* ---------------------------------------------------------------- memory
+ *
+ * A job moves hundreds of MB per step through the welder (the shells cloud of BASELINE configs[2]: 17 M vertices and 35 M
+ * triangles, 0.6 GB in and as much out), and freshly mapped memory costs a page fault per 4 KB -- about 1 GB/s per thread,
+ * several times the copies themselves.  Everything large therefore comes from slabs (mmap, transparent huge pages asked
+ * for) that a bump allocator hands out and that go back to a process-wide cache when the mesher is destroyed: the next
+ * job's welder writes into memory that is already mapped. */
+struct Slab
 {
-    uint32_t chunk;             /* dense chunk index */
-    uint64_t vBase, nv, nInternal;
-    uint64_t tBase, nt;
-    uint64_t eBase;
+    char *base = nullptr;
+    size_t cap = 0;
 };
 
-struct Clump                    /* OOCMesher::Clump, src/mesher.h:~395: a union-find node with vertex / triangle counts */
+class SlabCache
 {
-    int64_t parent = -1;        /* -1: root */
-    uint64_t vertices = 0, triangles = 0;
-};
-
-} // namespace
-
-struct mlsgpu_host_mesher
-{
-    std::mutex mutex;
-    double pruneThreshold = 0.0;
-    std::vector<float> vertices;            /* 3 per vertex, arrival order */
-    std::vector<uint32_t> triangles;        /* 3 per triangle, block-local indices */
-    std::vector<uint64_t> extKeys;
-    std::vector<uint32_t> clumpOf;          /* per vertex: its clump */
-    std::vector<Block> blocks;
-    std::vector<uint64_t> chunkIds;
-    std::unordered_map<uint64_t, uint32_t> chunkIndex;
-    std::vector<Clump> clumps;
-    std::unordered_map<uint64_t, uint32_t> clumpIdMap;      /* key -> a clump that holds the vertex (clumpIdMap) */
-    std::vector<int32_t> uf;                /* scratch: the block's union-find */
-    bool finalized = false;
-
-    std::vector<float> outVertices;
-    std::vector<uint32_t> outTriangles;
-    std::vector<uint64_t> chunkVStart, chunkTStart;
-    std::vector<uint32_t> outChunks;
-    uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-
-    uint32_t clumpRoot(uint32_t c)
+public:
+    static SlabCache &instance()
     {
-        uint32_t r = c;
-        while (clumps[r].parent >= 0)
-            r = (uint32_t) clumps[r].parent;
-        while (clumps[c].parent >= 0)       /* path compression */
+        static SlabCache c;
+        return c;
+    }
+    Slab take(size_t atLeast)
+    {
         {
-            const uint32_t next = (uint32_t) clumps[c].parent;
-            clumps[c].parent = r;
-            c = next;
+            std::lock_guard<std::mutex> l(mutex);
+            for (size_t i = 0; i < free.size(); i++)
+                if (free[i].cap >= atLeast)
+                {
+                    Slab s = free[i];
+                    free.erase(free.begin() + (long) i);
+                    held -= s.cap;
+                    return s;
+                }
         }
-        return r;
+        Slab s;
+        s.cap = (atLeast + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
+        void *p = mmap(nullptr, s.cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED)
+            return Slab();
+        (void) madvise(p, s.cap, MADV_HUGEPAGE);
+        s.base = static_cast<char *>(p);
+        return s;
+    }
+    void give(Slab s)
+    {
+        if (s.base == nullptr)
+            return;
+        {
+            std::lock_guard<std::mutex> l(mutex);
+            if (held + s.cap <= limit)
+            {
+                free.push_back(s);
+                held += s.cap;
+                return;
+            }
+        }
+        munmap(s.base, s.cap);
+    }
+    ~SlabCache()
+    {
+        for (Slab &s : free)
+            munmap(s.base, s.cap);
+    }
+
+private:
+    std::mutex mutex;
+    std::vector<Slab> free;
+    size_t held = 0;
+    const size_t limit = size_t(16) << 30;      /* mapped memory kept between jobs */
+};
+
+class Arena
+{
+public:
+    ~Arena() { release(); }
+    void release()
+    {
+        for (Slab &s : slabs)
+            SlabCache::instance().give(s);
+        slabs.clear();
+        used = 0;
+    }
+    /* 64-byte aligned, uninitialised; nullptr when the system has no memory left */
+    void *alloc(size_t bytes)
+    {
+        bytes = (bytes + 63) & ~size_t(63);
+        std::lock_guard<std::mutex> l(mutex);
+        if (slabs.empty() || used + bytes > slabs.back().cap)
+        {
+            Slab s = SlabCache::instance().take(std::max(bytes, size_t(256) << 20));
+            if (s.base == nullptr)
+                return nullptr;
+            slabs.push_back(s);
+            used = 0;
+        }
+        void *p = slabs.back().base + used;
+        used += bytes;
+        return p;
+    }
+    template<typename T>
+    T *array(size_t n) { return static_cast<T *>(alloc(std::max<size_t>(n, 1) * sizeof(T))); }
+
+private:
+    std::mutex mutex;
+    std::vector<Slab> slabs;
+    size_t used = 0;
+};
+
+/* ---------------------------------------------------------------- a small pool: tasks and parallel loops */
+
+class Pool
+{
+public:
+    explicit Pool(unsigned threads)
+    {
+        for (unsigned i = 0; i < threads; i++)
+            workers.emplace_back([this] { run(); });
+    }
+    ~Pool()
+    {
+        {
+            std::lock_guard<std::mutex> l(mutex);
+            stopping = true;
+        }
+        wake.notify_all();
+        for (std::thread &t : workers)
+            t.join();
+    }
+    unsigned size() const { return (unsigned) workers.size(); }
+    void submit(std::function<void()> fn)
+    {
+        {
+            std::lock_guard<std::mutex> l(mutex);
+            queue.push_back(std::move(fn));
+            pending++;
+        }
+        wake.notify_one();
+    }
+    void drain()
+    {
+        std::unique_lock<std::mutex> l(mutex);
+        idle.wait(l, [this] { return pending == 0; });
+    }
+    /* fn(i) for i in [0, n), dynamically scheduled; returns when all are done.  Must not be called from a pool thread. */
+    void parallelFor(size_t n, const std::function<void(size_t)> &fn)
+    {
+        if (n == 0)
+            return;
+        if (workers.empty() || n == 1)
+        {
+            for (size_t i = 0; i < n; i++)
+                fn(i);
+            return;
+        }
+        std::atomic<size_t> next{0};
+        const size_t lanes = std::min<size_t>(workers.size(), n);
+        for (size_t t = 0; t < lanes; t++)
+            submit([&next, n, &fn] {
+                for (size_t i = next.fetch_add(1); i < n; i = next.fetch_add(1))
+                    fn(i);
+            });
+        drain();
+    }
+
+    /* The same for a caller that must not wait for unrelated tasks (add() copies a block while older blocks' tasks are
+     * queued): the pieces go to the FRONT of the queue, the caller works on them too and waits for these pieces only. */
+    void parallelForNow(size_t n, const std::function<void(size_t)> &fn)
+    {
+        if (n == 0)
+            return;
+        struct Shared
+        {
+            std::atomic<size_t> next{0}, done{0};
+        };
+        auto sh = std::make_shared<Shared>();
+        const size_t helpers = std::min<size_t>(workers.size(), n > 1 ? n - 1 : 0);
+        const std::function<void(size_t)> *fnp = &fn;
+        auto body = [sh, n, fnp] {
+            for (size_t i = sh->next.fetch_add(1); i < n; i = sh->next.fetch_add(1))
+            {
+                (*fnp)(i);          /* i < n: the caller is still waiting for this piece, fn is alive */
+                sh->done.fetch_add(1);
+            }
+        };
+        {
+            std::lock_guard<std::mutex> l(mutex);
+            for (size_t t = 0; t < helpers; t++)
+            {
+                queue.push_front(body);     /* a helper that arrives late finds no piece left and never touches fn */
+                pending++;
+            }
+        }
+        wake.notify_all();
+        body();
+        while (sh->done.load() < n)
+            std::this_thread::yield();
+    }
+
+private:
+    void run()
+    {
+        for (;;)
+        {
+            std::function<void()> fn;
+            {
+                std::unique_lock<std::mutex> l(mutex);
+                wake.wait(l, [this] { return stopping || !queue.empty(); });
+                if (queue.empty())
+                    return;
+                fn = std::move(queue.front());
+                queue.pop_front();
+            }
+            fn();
+            {
+                std::lock_guard<std::mutex> l(mutex);
+                pending--;
+                if (pending == 0)
+                    idle.notify_all();
+            }
+        }
+    }
+    std::vector<std::thread> workers;
+    std::deque<std::function<void()> > queue;
+    std::mutex mutex;
+    std::condition_variable wake, idle;
+    size_t pending = 0;
+    bool stopping = false;
+};
+
+/* ---------------------------------------------------------------- open-addressing tables (one per shard) */
+
+static inline uint64_t mix64(uint64_t x)
+{
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+/* a vertex of the job: block (arrival number) and index inside it -- or a clump: block and local clump number */
+struct Ref
+{
+    uint32_t seq, idx;
+};
+static inline bool refLess(Ref a, Ref b) { return a.seq != b.seq ? a.seq < b.seq : a.idx < b.idx; }
+
+const uint64_t EMPTY_KEY = ~uint64_t(0);    /* never a vertex key: the fields are 21 bits each */
+
+/* key -> the first clump seen holding the vertex (clumpIdMap, src/mesher.h) */
+struct ClumpTable
+{
+    struct Slot { uint64_t key; Ref clump; };
+    std::vector<Slot> slots;
+    size_t used = 0;
+    ClumpTable() : slots(1024, Slot{EMPTY_KEY, Ref{0, 0}}) {}
+    void grow()
+    {
+        std::vector<Slot> old;
+        old.swap(slots);
+        slots.assign(old.size() * 2, Slot{EMPTY_KEY, Ref{0, 0}});
+        for (const Slot &s : old)
+            if (s.key != EMPTY_KEY)
+                *find(s.key) = s;
+    }
+    Slot *find(uint64_t key)        /* the key's slot, or the empty one it belongs in */
+    {
+        const size_t mask = slots.size() - 1;
+        size_t i = (size_t) (mix64(key) >> 7) & mask;
+        while (slots[i].key != EMPTY_KEY && slots[i].key != key)
+            i = (i + 1) & mask;
+        return &slots[i];
+    }
+    /* true: the key was new */
+    bool insert(uint64_t key, Ref clump, Ref *existing)
+    {
+        if ((used + 1) * 10 > slots.size() * 7)
+            grow();
+        Slot *s = find(key);
+        if (s->key == key)
+        {
+            *existing = s->clump;
+            return false;
+        }
+        s->key = key;
+        s->clump = clump;
+        used++;
+        return true;
     }
 };
 
-MLSGPU_API int mlsgpu_hip_host_mesher_create(mlsgpu_host_mesher **out)
+/* (key, chunk) -> the key's first vertex of that chunk in arrival order: the one externalRemap keeps (src/mesher.cpp:538-567) */
+struct OwnerTable
 {
-    REQUIRE(out != nullptr, MLSGPU_ERR_INVALID);
-    *out = new mlsgpu_host_mesher;
-    return MLSGPU_OK;
-}
+    struct Slot { uint64_t key; uint32_t chunk; Ref owner; };
+    std::vector<Slot> slots;
+    size_t used = 0;
+    OwnerTable() : slots(1024, Slot{EMPTY_KEY, 0, Ref{0, 0}}) {}
+    static size_t hash(uint64_t key, uint32_t chunk) { return (size_t) (mix64(key ^ (uint64_t(chunk) * 0x9E3779B97F4A7C15ULL)) >> 7); }
+    Slot *find(uint64_t key, uint32_t chunk)
+    {
+        const size_t mask = slots.size() - 1;
+        size_t i = hash(key, chunk) & mask;
+        while (slots[i].key != EMPTY_KEY && !(slots[i].key == key && slots[i].chunk == chunk))
+            i = (i + 1) & mask;
+        return &slots[i];
+    }
+    void grow()
+    {
+        std::vector<Slot> old;
+        old.swap(slots);
+        slots.assign(old.size() * 2, Slot{EMPTY_KEY, 0, Ref{0, 0}});
+        for (const Slot &s : old)
+            if (s.key != EMPTY_KEY)
+                *find(s.key, s.chunk) = s;
+    }
+    void note(uint64_t key, uint32_t chunk, Ref vertex)
+    {
+        if ((used + 1) * 10 > slots.size() * 7)
+            grow();
+        Slot *s = find(key, chunk);
+        if (s->key == EMPTY_KEY)
+        {
+            *s = Slot{key, chunk, vertex};
+            used++;
+        }
+        else if (refLess(vertex, s->owner))
+            s->owner = vertex;
+    }
+    Ref owner(uint64_t key, uint32_t chunk) { return find(key, chunk)->owner; }
+};
 
-MLSGPU_API void mlsgpu_hip_host_mesher_destroy(mlsgpu_host_mesher *m) { delete m; }
-
-MLSGPU_API int mlsgpu_hip_host_mesher_set_prune_threshold(mlsgpu_host_mesher *m, double threshold)
+struct UnionRecord      /* one later occurrence of a key: unite the clumps, un-count one vertex (updateClumpKeyMap) */
 {
-    REQUIRE(m != nullptr && threshold >= 0.0 && threshold <= 1.0, MLSGPU_ERR_INVALID);
-    m->pruneThreshold = threshold;
-    return MLSGPU_OK;
-}
+    Ref a, b;
+};
 
-static int32_t ufRoot(std::vector<int32_t> &uf, int32_t v)
+enum { NUM_SHARDS = 64 };
+
+struct Shard
+{
+    std::mutex mutex;
+    ClumpTable clumps;
+    OwnerTable owners;
+    std::vector<UnionRecord> unions;
+};
+
+struct Block
+{
+    uint32_t seq = 0;           /* arrival number */
+    uint32_t chunk = 0;         /* dense chunk index */
+    uint64_t nv = 0, nInternal = 0, nt = 0;
+    /* in the mesher's arena */
+    float *vertices = nullptr;
+    uint32_t *triangles = nullptr;          /* block-local indices */
+    uint64_t *keys = nullptr;               /* of the external vertices */
+    uint32_t *clumpOf = nullptr;            /* per vertex: local clump number; filled by the block's task */
+    uint32_t *remap = nullptr;              /* finalize's scratch, kept for the next finalize */
+    std::vector<uint64_t> clumpVertices, clumpTriangles;    /* per local clump */
+    /* finalize */
+    uint64_t clumpBase = 0;                 /* global id of local clump 0 */
+    uint64_t emitted = 0, keptTriangles = 0, vOut = 0, tOut = 0;
+};
+
+static inline int32_t ufRoot(int32_t *uf, int32_t v)
 {
     int32_t r = v;
     while (uf[r] >= 0)
@@ -109,25 +423,90 @@ static int32_t ufRoot(std::vector<int32_t> &uf, int32_t v)
     return r;
 }
 
-MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkId, const mlsgpu_host_mesh *mesh)
+} // namespace
+
+struct mlsgpu_host_mesher
 {
-    REQUIRE(m != nullptr && mesh != nullptr, MLSGPU_ERR_INVALID);
-    REQUIRE(mesh->numInternalVertices <= mesh->numVertices, MLSGPU_ERR_INVALID);
-    REQUIRE(mesh->numVertices < (uint64_t(1) << 31), MLSGPU_ERR_LENGTH);
-    const uint64_t nv = mesh->numVertices, nt = mesh->numTriangles, ni = mesh->numInternalVertices, ne = nv - ni;
-    REQUIRE((nv == 0 || mesh->vertices != nullptr) && (nt == 0 || mesh->triangles != nullptr)
-            && (ne == 0 || mesh->vertexKeys != nullptr), MLSGPU_ERR_INVALID);
-    for (uint64_t t = 0; t < 3 * nt; t++)       /* before anything is appended: a bad mesh leaves the sink unchanged */
-        REQUIRE(mesh->triangles[t] < nv, MLSGPU_ERR_INVALID);
-    std::lock_guard<std::mutex> lock(m->mutex);
-    /* computeLocalComponents, src/mesher.cpp:220-236: union by size, negative value = -(size) at a root.  It only reads
-     * the incoming mesh, so it runs -- with the "too many connected components" check (:252) -- before anything is appended:
-     * a mesh that cannot be taken leaves the sink unchanged. */
-    std::vector<int32_t> &uf = m->uf;
-    uf.assign(nv, -1);
+    std::mutex mutex;                       /* add / finalize / boundary from different threads */
+    double pruneThreshold = 0.0;
+    std::vector<std::unique_ptr<Block> > blocks;            /* in arrival order: blocks[i]->seq == i */
+    std::vector<uint64_t> chunkIds;
+    std::unordered_map<uint64_t, uint32_t> chunkIndex;
+    Shard shards[NUM_SHARDS];
+    std::unique_ptr<Pool> pool;
+    unsigned threads = 0;
+    std::mutex errorMutex;
+    int taskError = MLSGPU_OK;
+    std::string taskErrorText;
+    bool finalized = false;
+
+    /* resolved in finalize / boundary */
+    std::vector<int64_t> parent;            /* per global clump: -1 = root */
+    std::vector<uint64_t> compVertices, compTriangles;      /* valid at roots */
+    uint64_t numKeys = 0;
+
+    Arena arena;                            /* blocks, scratch and outputs */
+    float *outVertices = nullptr;
+    uint32_t *outTriangles = nullptr;
+    uint64_t outVCap = 0, outTCap = 0;
+    std::vector<uint64_t> chunkVStart, chunkTStart;
+    std::vector<uint32_t> outChunks;
+    uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+
+    Pool &getPool()
+    {
+        if (!pool)
+        {
+            unsigned n = threads;
+            if (n == 0)
+            {
+                const char *e = getenv("MLSGPU_HIP_HOST_MESHER_THREADS");
+                n = e != nullptr ? (unsigned) std::max(1, atoi(e)) : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+            }
+            pool.reset(new Pool(n));
+            threads = n;
+        }
+        return *pool;
+    }
+    void fail(int code, const char *text)
+    {
+        std::lock_guard<std::mutex> l(errorMutex);
+        if (taskError == MLSGPU_OK)
+        {
+            taskError = code;
+            taskErrorText = text;
+        }
+    }
+    uint64_t rootOf(uint64_t c)
+    {
+        uint64_t r = c;
+        while (parent[r] >= 0)
+            r = (uint64_t) parent[r];
+        while (parent[c] >= 0)       /* path compression */
+        {
+            const uint64_t next = (uint64_t) parent[c];
+            parent[c] = (int64_t) r;
+            c = next;
+        }
+        return r;
+    }
+    void processBlock(Block *b);
+    int resolve();
+    int finalizeWith(const uint8_t *keepClump, uint32_t *numChunks);
+};
+
+/* the block's task: computeLocalComponents + updateGlobalClumps + updateClumpKeyMap (src/mesher.cpp:220-311) */
+void mlsgpu_host_mesher::processBlock(Block *b)
+{
+    const uint64_t nv = b->nv, nt = b->nt, ni = b->nInternal, ne = nv - ni;
+    /* union by size, negative value = -(size) at a root */
+    static thread_local std::vector<int32_t> ufv;           /* a pool thread's scratch, reused from block to block */
+    ufv.assign(nv, -1);
+    int32_t *uf = ufv.data();
+    const uint32_t *tris = b->triangles;
     for (uint64_t t = 0; t < nt; t++)
     {
-        const uint32_t *tri = mesh->triangles + 3 * t;
+        const uint32_t *tri = tris + 3 * t;
         for (int e = 0; e < 2; e++)
         {
             int32_t a = ufRoot(uf, (int32_t) tri[e]), c = ufRoot(uf, (int32_t) tri[e + 1]);
@@ -139,67 +518,156 @@ MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkI
             uf[c] = a;
         }
     }
-    uint64_t roots = 0;
-    for (uint64_t i = 0; i < nv; i++)
-        roots += uf[i] < 0;
-    REQUIRE(m->clumps.size() + roots < 0x7FFFFFFFu, MLSGPU_ERR_LENGTH);
-    m->finalized = false;
-    Block b;
-    auto it = m->chunkIndex.find(chunkId);
-    if (it == m->chunkIndex.end())
+    b->clumpOf = arena.array<uint32_t>(nv);
+    if (b->clumpOf == nullptr)
     {
-        b.chunk = (uint32_t) m->chunkIds.size();
-        m->chunkIndex.emplace(chunkId, b.chunk);
-        m->chunkIds.push_back(chunkId);
+        fail(MLSGPU_ERR_NOMEM, "host mesher: out of memory");
+        return;
     }
-    else
-        b.chunk = it->second;
-    b.vBase = m->vertices.size() / 3;
-    b.nv = nv;
-    b.nInternal = ni;
-    b.tBase = m->triangles.size() / 3;
-    b.nt = nt;
-    b.eBase = m->extKeys.size();
-    m->vertices.insert(m->vertices.end(), mesh->vertices, mesh->vertices + 3 * nv);
-    m->triangles.insert(m->triangles.end(), mesh->triangles, mesh->triangles + 3 * nt);
-    m->extKeys.insert(m->extKeys.end(), mesh->vertexKeys, mesh->vertexKeys + ne);
-
-    /* updateGlobalClumps, :238-281 */
-    const uint64_t cBase = m->clumpOf.size();
-    m->clumpOf.resize(cBase + nv);
+    uint32_t numLocal = 0;
     for (uint64_t i = 0; i < nv; i++)
         if (uf[i] < 0)
         {
-            m->clumpOf[cBase + i] = (uint32_t) m->clumps.size();
-            Clump c;
-            c.vertices = (uint64_t) -(int64_t) uf[i];
-            m->clumps.push_back(c);
+            b->clumpOf[i] = numLocal++;
+            b->clumpVertices.push_back((uint64_t) -(int64_t) uf[i]);
         }
     for (uint64_t i = 0; i < nv; i++)
         if (uf[i] >= 0)
-            m->clumpOf[cBase + i] = m->clumpOf[cBase + ufRoot(uf, (int32_t) i)];
+            b->clumpOf[i] = b->clumpOf[ufRoot(uf, (int32_t) i)];
+    b->clumpTriangles.assign(numLocal, 0);
     for (uint64_t t = 0; t < nt; t++)
-        m->clumps[m->clumpOf[cBase + mesh->triangles[3 * t]]].triangles++;
-    /* updateClumpKeyMap, :286-311 */
+        b->clumpTriangles[b->clumpOf[tris[3 * t]]]++;
+    /* the external keys, shard by shard */
     for (uint64_t i = 0; i < ne; i++)
     {
-        const uint32_t cid = m->clumpOf[cBase + ni + i];
-        auto added = m->clumpIdMap.emplace(mesh->vertexKeys[i], cid);
-        if (!added.second)
+        const uint64_t key = b->keys[i];
+        if (key == EMPTY_KEY)
         {
-            uint32_t a = m->clumpRoot(cid), c = m->clumpRoot(added.first->second);
-            if (a != c)
-            {
-                if (m->clumps[a].vertices < m->clumps[c].vertices)
-                    std::swap(a, c);
-                m->clumps[c].parent = a;
-                m->clumps[a].vertices += m->clumps[c].vertices;
-                m->clumps[a].triangles += m->clumps[c].triangles;
-            }
-            m->clumps[a].vertices--;        /* both counted the common vertex */
+            fail(MLSGPU_ERR_INVALID, "host mesher: an external vertex key is all ones");
+            return;
         }
+        const Ref clump{b->seq, b->clumpOf[ni + i]};
+        Shard &s = shards[mix64(key) >> 58];
+        std::lock_guard<std::mutex> l(s.mutex);
+        Ref first;
+        if (!s.clumps.insert(key, clump, &first))
+            s.unions.push_back(UnionRecord{clump, first});
+        s.owners.note(key, b->chunk, Ref{b->seq, (uint32_t) (ni + i)});
     }
-    m->blocks.push_back(b);
+}
+
+MLSGPU_API int mlsgpu_hip_host_mesher_create(mlsgpu_host_mesher **out)
+{
+    REQUIRE(out != nullptr, MLSGPU_ERR_INVALID);
+    *out = new mlsgpu_host_mesher;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API void mlsgpu_hip_host_mesher_destroy(mlsgpu_host_mesher *m)
+{
+    if (m == nullptr)
+        return;
+    if (m->pool)
+        m->pool->drain();
+    delete m;
+}
+
+MLSGPU_API int mlsgpu_hip_host_mesher_set_prune_threshold(mlsgpu_host_mesher *m, double threshold)
+{
+    REQUIRE(m != nullptr && threshold >= 0.0 && threshold <= 1.0, MLSGPU_ERR_INVALID);
+    m->pruneThreshold = threshold;
+    return MLSGPU_OK;
+}
+
+/* Threads of the welder (block tasks and the output passes); 0 = the default: MLSGPU_HIP_HOST_MESHER_THREADS, else
+ * min(32, hardware threads).  Before the first add. */
+MLSGPU_API int mlsgpu_hip_host_mesher_set_threads(mlsgpu_host_mesher *m, uint32_t threads)
+{
+    REQUIRE(m != nullptr && threads <= 1024, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    REQUIRE(!m->pool, MLSGPU_ERR_INVALID);
+    m->threads = threads;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API uint32_t mlsgpu_hip_host_mesher_threads(mlsgpu_host_mesher *m)
+{
+    if (m == nullptr)
+        return 0;
+    std::lock_guard<std::mutex> lock(m->mutex);
+    return m->getPool().size();
+}
+
+MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkId, const mlsgpu_host_mesh *mesh)
+{
+    REQUIRE(m != nullptr && mesh != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(mesh->numInternalVertices <= mesh->numVertices, MLSGPU_ERR_INVALID);
+    REQUIRE(mesh->numVertices < (uint64_t(1) << 31), MLSGPU_ERR_LENGTH);
+    const uint64_t nv = mesh->numVertices, nt = mesh->numTriangles, ni = mesh->numInternalVertices, ne = nv - ni;
+    REQUIRE((nv == 0 || mesh->vertices != nullptr) && (nt == 0 || mesh->triangles != nullptr)
+            && (ne == 0 || mesh->vertexKeys != nullptr), MLSGPU_ERR_INVALID);
+    std::unique_ptr<Block> b(new Block);
+    b->nv = nv;
+    b->nInternal = ni;
+    b->nt = nt;
+    /* the caller's memory (a slot of the farm's ring) is free again when this call returns */
+    b->vertices = m->arena.array<float>(3 * nv);
+    b->triangles = m->arena.array<uint32_t>(3 * nt);
+    b->keys = m->arena.array<uint64_t>(ne);
+    if (b->vertices == nullptr || b->triangles == nullptr || b->keys == nullptr)
+        return setError(MLSGPU_ERR_NOMEM, "host mesher: out of memory");
+    std::lock_guard<std::mutex> lock(m->mutex);
+    {
+        /* a block of tens of MB leaves the caller's memory on several threads at once */
+        struct Piece { char *dst; const char *src; size_t bytes; bool indices; };
+        std::vector<Piece> pieces;
+        auto cut = [&](void *dst, const void *src, size_t bytes, bool indices) {
+            const size_t step = size_t(4) << 20;
+            for (size_t o = 0; o < bytes; o += step)
+                pieces.push_back(Piece{static_cast<char *>(dst) + o, static_cast<const char *>(src) + o, std::min(step, bytes - o),
+                                       indices});
+        };
+        cut(b->vertices, mesh->vertices, 3 * nv * sizeof(float), false);
+        cut(b->triangles, mesh->triangles, 3 * nt * sizeof(uint32_t), true);
+        cut(b->keys, mesh->vertexKeys, ne * sizeof(uint64_t), false);
+        std::atomic<uint32_t> badIndex{0};
+        auto copyPiece = [&](size_t i) {
+            const Piece &p = pieces[i];
+            std::memcpy(p.dst, p.src, p.bytes);
+            if (p.indices)
+            {
+                /* the check of the triangle indices rides on the copy */
+                const uint32_t *t = reinterpret_cast<const uint32_t *>(p.dst);
+                uint32_t most = 0;
+                for (size_t k = 0; k < p.bytes / 4; k++)
+                    most = t[k] > most ? t[k] : most;
+                if (most >= nv)
+                    badIndex.store(1);
+            }
+        };
+        if (pieces.size() <= 2)
+            for (size_t i = 0; i < pieces.size(); i++)
+                copyPiece(i);
+        else
+            m->getPool().parallelForNow(pieces.size(), copyPiece);
+        /* a bad mesh leaves the sink unchanged (its copy stays behind in the arena, unused) */
+        REQUIRE(badIndex.load() == 0, MLSGPU_ERR_INVALID);
+    }
+    REQUIRE(m->blocks.size() < 0xFFFFFFFFu, MLSGPU_ERR_LENGTH);
+    m->finalized = false;
+    auto it = m->chunkIndex.find(chunkId);
+    if (it == m->chunkIndex.end())
+    {
+        b->chunk = (uint32_t) m->chunkIds.size();
+        m->chunkIndex.emplace(chunkId, b->chunk);
+        m->chunkIds.push_back(chunkId);
+    }
+    else
+        b->chunk = it->second;
+    b->seq = (uint32_t) m->blocks.size();
+    Block *raw = b.get();
+    m->blocks.push_back(std::move(b));
+    m->getPool().submit([m, raw] { m->processBlock(raw); });
     return MLSGPU_OK;
 }
 
@@ -209,100 +677,237 @@ MLSGPU_API int mlsgpu_hip_host_mesher_farm_output(void *mesher, int device, uint
     return mlsgpu_hip_host_mesher_add(static_cast<mlsgpu_host_mesher *>(mesher), chunkId, mesh);
 }
 
+/* every block's task has run: global clump numbers (block by block in arrival order), the unions the key map recorded, and
+ * the components' vertex / triangle counts -- a vertex seen k times was counted k times, each record takes one back */
+int mlsgpu_host_mesher::resolve()
+{
+    getPool().drain();
+    {
+        std::lock_guard<std::mutex> l(errorMutex);
+        if (taskError != MLSGPU_OK)
+            return setError(taskError, "%s", taskErrorText.c_str());
+    }
+    uint64_t total = 0;
+    for (auto &b : blocks)
+    {
+        b->clumpBase = total;
+        total += b->clumpVertices.size();
+    }
+    REQUIRE(total < 0x7FFFFFFFu, MLSGPU_ERR_LENGTH);            /* "too many connected components", src/mesher.cpp:252 */
+    parent.assign(total, -1);
+    compVertices.resize(total);
+    compTriangles.resize(total);
+    for (auto &b : blocks)
+        for (size_t c = 0; c < b->clumpVertices.size(); c++)
+        {
+            compVertices[b->clumpBase + c] = b->clumpVertices[c];
+            compTriangles[b->clumpBase + c] = b->clumpTriangles[c];
+        }
+    numKeys = 0;
+    for (Shard &s : shards)
+    {
+        numKeys += s.clumps.used;
+        for (const UnionRecord &u : s.unions)
+        {
+            uint64_t a = rootOf(blocks[u.a.seq]->clumpBase + u.a.idx), c = rootOf(blocks[u.b.seq]->clumpBase + u.b.idx);
+            if (a != c)
+            {
+                if (compVertices[a] < compVertices[c])
+                    std::swap(a, c);
+                parent[c] = (int64_t) a;
+                compVertices[a] += compVertices[c];
+                compTriangles[a] += compTriangles[c];
+            }
+            compVertices[a]--;          /* both counted the common vertex */
+        }
+    }
+    /* Which member ended up as a component's root depends on the order the tasks reached the key map; the component's
+     * LOWEST clump number becomes its root, so that ids (boundary export, verdicts) are the same whatever the threads did.
+     * Every chain is one step afterwards: the output passes only read. */
+    std::vector<uint64_t> lowest(total, ~uint64_t(0));
+    for (uint64_t c = 0; c < total; c++)
+    {
+        const uint64_t r = rootOf(c);
+        if (lowest[r] == ~uint64_t(0))
+            lowest[r] = c;              /* ascending c: the first member seen is the lowest */
+    }
+    std::vector<int64_t> np(total);
+    std::vector<uint64_t> nv(total, 0), nt(total, 0);
+    for (uint64_t c = 0; c < total; c++)
+    {
+        const uint64_t r = rootOf(c), low = lowest[r];
+        np[c] = c == low ? -1 : (int64_t) low;
+        if (c == low)
+        {
+            nv[c] = compVertices[r];
+            nt[c] = compTriangles[r];
+        }
+    }
+    parent.swap(np);
+    compVertices.swap(nv);
+    compTriangles.swap(nt);
+    return MLSGPU_OK;
+}
+
 /* keepClump == nullptr: the prune rule on this mesher's own counts (getStatistics, src/mesher.cpp:491-536);
  * otherwise keepClump[root clump] decides (the caller merged the clumps of several meshers, see
  * mlsgpu_hip_host_mesher_boundary) */
-static int finalizeWith(mlsgpu_host_mesher *m, const uint8_t *keepClump, uint32_t *numChunks)
+int mlsgpu_host_mesher::finalizeWith(const uint8_t *keepClump, uint32_t *numChunks)
 {
-    const uint64_t nv = m->vertices.size() / 3, nt = m->triangles.size() / 3;
-    const uint32_t nc = (uint32_t) m->chunkIds.size();
+    PROPAGATE(resolve());
+    const uint32_t nc = (uint32_t) chunkIds.size();
+    const uint64_t numClumps = parent.size();
     uint64_t total = 0, components = 0;
-    for (size_t c = 0; c < m->clumps.size(); c++)
-        if (m->clumps[c].parent < 0)
+    for (uint64_t c = 0; c < numClumps; c++)
+        if (parent[c] < 0)
         {
-            total += m->clumps[c].vertices;
+            total += compVertices[c];
             components++;
         }
-    const uint64_t threshold = (uint64_t) ((double) total * m->pruneThreshold);
-    auto kept = [&](uint32_t root) { return keepClump ? keepClump[root] != 0 : m->clumps[root].vertices >= threshold; };
+    const uint64_t threshold = (uint64_t) ((double) total * pruneThreshold);
+    std::vector<uint8_t> keptRoot(numClumps, 0);
     uint64_t keptComponents = 0, keptVertices = 0, keptTriangles = 0;
-    for (size_t c = 0; c < m->clumps.size(); c++)
-        if (m->clumps[c].parent < 0 && kept((uint32_t) c))
+    for (uint64_t c = 0; c < numClumps; c++)
+        if (parent[c] < 0 && (keepClump ? keepClump[c] != 0 : compVertices[c] >= threshold))
         {
+            keptRoot[c] = 1;
             keptComponents++;
-            keptVertices += m->clumps[c].vertices;
-            keptTriangles += m->clumps[c].triangles;
+            keptVertices += compVertices[c];
+            keptTriangles += compTriangles[c];
         }
+    auto keptClump = [&](uint64_t c) { return keptRoot[parent[c] < 0 ? c : (uint64_t) parent[c]] != 0; };
     /* blocks in (chunk by first arrival, arrival) order; a key is emitted once per chunk (externalRemap, :538-567) */
-    std::vector<uint32_t> order(m->blocks.size());
+    std::vector<uint32_t> order(blocks.size());
     for (uint32_t i = 0; i < order.size(); i++)
         order[i] = i;
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return m->blocks[a].chunk < m->blocks[b].chunk; });
-    m->outVertices.clear();
-    m->outTriangles.clear();
-    m->outVertices.reserve(3 * nv);
-    m->outTriangles.reserve(3 * nt);
-    m->chunkVStart.assign(nc + 1, 0);
-    m->chunkTStart.assign(nc + 1, 0);
-    m->outChunks.clear();
-    std::vector<uint32_t> remap;
-    std::unordered_map<uint64_t, uint32_t> chunkKeys;       /* key -> index inside the current chunk's output */
-    size_t k = 0;
-    for (uint32_t c = 0; c < nc; c++)
-    {
-        m->chunkVStart[c] = m->outVertices.size() / 3;
-        m->chunkTStart[c] = m->outTriangles.size() / 3;
-        chunkKeys.clear();
-        for (; k < order.size() && m->blocks[order[k]].chunk == c; k++)
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return blocks[a]->chunk < blocks[b]->chunk; });
+    Pool &P = getPool();
+    const uint32_t ALIAS = 0xFFFFFFFEu, PRUNED = 0xFFFFFFFFu;
+    for (auto &b : blocks)
+        if (b->remap == nullptr)
         {
-            const Block &b = m->blocks[order[k]];
-            remap.assign(b.nv, 0xFFFFFFFFu);
-            const uint64_t first = m->chunkVStart[c];
-            for (uint64_t i = 0; i < b.nv; i++)
+            b->remap = arena.array<uint32_t>(b->nv);
+            REQUIRE(b->remap != nullptr, MLSGPU_ERR_NOMEM);
+        }
+    /* pass 1: which vertices a block emits (kept, and for an external vertex: the key's first of its chunk) */
+    P.parallelFor(blocks.size(), [&](size_t bi) {
+        Block &b = *blocks[bi];
+        std::fill(b.remap, b.remap + b.nv, PRUNED);
+        uint64_t emitted = 0;
+        for (uint64_t i = 0; i < b.nv; i++)
+        {
+            if (!keptClump(b.clumpBase + b.clumpOf[i]))
+                continue;
+            if (i >= b.nInternal)
             {
-                const uint32_t root = m->clumpRoot(m->clumpOf[b.vBase + i]);
-                if (!kept(root))
-                    continue;
-                if (i >= b.nInternal)
+                const uint64_t key = b.keys[i - b.nInternal];
+                const Ref o = shards[mix64(key) >> 58].owners.owner(key, b.chunk);
+                if (o.seq != b.seq || o.idx != (uint32_t) i)
                 {
-                    auto added = chunkKeys.emplace(m->extKeys[b.eBase + (i - b.nInternal)], 0u);
-                    if (!added.second)
-                    {
-                        remap[i] = added.first->second;
-                        continue;
-                    }
-                    added.first->second = (uint32_t) (m->outVertices.size() / 3 - first);
+                    b.remap[i] = ALIAS;
+                    continue;
                 }
-                remap[i] = (uint32_t) (m->outVertices.size() / 3 - first);
-                const float *v = &m->vertices[3 * (b.vBase + i)];
-                m->outVertices.insert(m->outVertices.end(), v, v + 3);
             }
-            for (uint64_t t = 0; t < b.nt; t++)
+            b.remap[i] = 0;
+            emitted++;
+        }
+        b.emitted = emitted;
+        uint64_t kt = 0;
+        for (uint64_t t = 0; t < b.nt; t++)
+            kt += b.remap[b.triangles[3 * t]] != PRUNED;
+        b.keptTriangles = kt;
+    });
+    chunkVStart.assign(nc + 1, 0);
+    chunkTStart.assign(nc + 1, 0);
+    uint64_t vAll = 0, tAll = 0;
+    {
+        size_t k = 0;
+        for (uint32_t c = 0; c < nc; c++)
+        {
+            chunkVStart[c] = vAll;
+            chunkTStart[c] = tAll;
+            for (; k < order.size() && blocks[order[k]]->chunk == c; k++)
             {
-                const uint32_t *tri = &m->triangles[3 * (b.tBase + t)];
-                if (remap[tri[0]] == 0xFFFFFFFFu)
-                    continue;               /* the whole clump was pruned */
-                for (int j = 0; j < 3; j++)
-                    m->outTriangles.push_back(remap[tri[j]]);
+                Block &b = *blocks[order[k]];
+                b.vOut = vAll;
+                b.tOut = tAll;
+                vAll += b.emitted;
+                tAll += b.keptTriangles;
             }
         }
+        chunkVStart[nc] = vAll;
+        chunkTStart[nc] = tAll;
     }
-    m->chunkVStart[nc] = m->outVertices.size() / 3;
-    m->chunkTStart[nc] = m->outTriangles.size() / 3;
+    if (vAll > outVCap || outVertices == nullptr)
+    {
+        outVertices = arena.array<float>(3 * vAll);
+        outVCap = vAll;
+    }
+    if (tAll > outTCap || outTriangles == nullptr)
+    {
+        outTriangles = arena.array<uint32_t>(3 * tAll);
+        outTCap = tAll;
+    }
+    REQUIRE(outVertices != nullptr && outTriangles != nullptr, MLSGPU_ERR_NOMEM);
+    /* pass 2: output indices (relative to the chunk's first vertex) and the vertex copies */
+    P.parallelFor(blocks.size(), [&](size_t bi) {
+        Block &b = *blocks[bi];
+        uint64_t at = b.vOut;
+        const uint64_t first = chunkVStart[b.chunk];
+        for (uint64_t i = 0; i < b.nv; i++)
+            if (b.remap[i] == 0)
+            {
+                b.remap[i] = (uint32_t) (at - first);
+                const float *v = &b.vertices[3 * i];
+                outVertices[3 * at] = v[0];
+                outVertices[3 * at + 1] = v[1];
+                outVertices[3 * at + 2] = v[2];
+                at++;
+            }
+    });
+    /* pass 3: a later occurrence of a key points at the chunk's copy; then the triangles */
+    P.parallelFor(blocks.size(), [&](size_t bi) {
+        Block &b = *blocks[bi];
+        for (uint64_t i = b.nInternal; i < b.nv; i++)
+            if (b.remap[i] == ALIAS)
+            {
+                const uint64_t key = b.keys[i - b.nInternal];
+                const Ref o = shards[mix64(key) >> 58].owners.owner(key, b.chunk);
+                b.remap[i] = blocks[o.seq]->remap[o.idx];      /* an owner is never an alias: written in pass 2 */
+            }
+        uint64_t at = 3 * b.tOut;
+        for (uint64_t t = 0; t < b.nt; t++)
+        {
+            const uint32_t *tri = &b.triangles[3 * t];
+            if (b.remap[tri[0]] == PRUNED)
+                continue;               /* the whole clump was pruned */
+            outTriangles[at] = b.remap[tri[0]];
+            outTriangles[at + 1] = b.remap[tri[1]];
+            outTriangles[at + 2] = b.remap[tri[2]];
+            at += 3;
+        }
+    });
+    uint64_t nvAdded = 0, ntAdded = 0;
+    for (auto &b : blocks)
+    {
+        nvAdded += b->nv;
+        ntAdded += b->nt;
+    }
+    outChunks.clear();
     for (uint32_t c = 0; c < nc; c++)
-        if (m->chunkTStart[c + 1] > m->chunkTStart[c])      /* no output for a chunk without triangles, :820 */
-            m->outChunks.push_back(c);
-    m->stats[0] = total;
-    m->stats[1] = threshold;
-    m->stats[2] = components;
-    m->stats[3] = keptComponents;
-    m->stats[4] = keptVertices;
-    m->stats[5] = keptTriangles;
-    m->stats[6] = nv;
-    m->stats[7] = nt;
-    m->finalized = true;
+        if (chunkTStart[c + 1] > chunkTStart[c])      /* no output for a chunk without triangles, :820 */
+            outChunks.push_back(c);
+    stats[0] = total;
+    stats[1] = threshold;
+    stats[2] = components;
+    stats[3] = keptComponents;
+    stats[4] = keptVertices;
+    stats[5] = keptTriangles;
+    stats[6] = nvAdded;
+    stats[7] = ntAdded;
+    finalized = true;
     if (numChunks)
-        *numChunks = (uint32_t) m->outChunks.size();
+        *numChunks = (uint32_t) outChunks.size();
     return MLSGPU_OK;
 }
 
@@ -310,7 +915,7 @@ MLSGPU_API int mlsgpu_hip_host_mesher_finalize(mlsgpu_host_mesher *m, uint32_t *
 {
     REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
     std::lock_guard<std::mutex> lock(m->mutex);
-    return finalizeWith(m, nullptr, numChunks);
+    return m->finalizeWith(nullptr, numChunks);
 }
 
 /* ---- several meshers, one job (one process per GPU: every rank welds its own buckets; components that cross rank
@@ -323,8 +928,9 @@ MLSGPU_API int mlsgpu_hip_host_mesher_boundary(mlsgpu_host_mesher *m, uint64_t *
 {
     REQUIRE(m != nullptr && numKeys != nullptr && numClumps != nullptr, MLSGPU_ERR_INVALID);
     std::lock_guard<std::mutex> lock(m->mutex);
-    *numKeys = m->clumpIdMap.size();
-    *numClumps = m->clumps.size();
+    PROPAGATE(m->resolve());
+    *numKeys = m->numKeys;
+    *numClumps = m->parent.size();
     return MLSGPU_OK;
 }
 
@@ -334,18 +940,24 @@ MLSGPU_API int mlsgpu_hip_host_mesher_boundary_read(mlsgpu_host_mesher *m, uint6
     REQUIRE(m != nullptr && keys != nullptr && keyClump != nullptr && clumpVertices != nullptr && clumpTriangles != nullptr,
             MLSGPU_ERR_INVALID);
     std::lock_guard<std::mutex> lock(m->mutex);
-    std::vector<std::pair<uint64_t, uint32_t> > sorted(m->clumpIdMap.begin(), m->clumpIdMap.end());
+    PROPAGATE(m->resolve());
+    std::vector<std::pair<uint64_t, uint32_t> > sorted;
+    sorted.reserve(m->numKeys);
+    for (Shard &s : m->shards)
+        for (const ClumpTable::Slot &slot : s.clumps.slots)
+            if (slot.key != EMPTY_KEY)
+                sorted.emplace_back(slot.key, (uint32_t) m->rootOf(m->blocks[slot.clump.seq]->clumpBase + slot.clump.idx));
     std::sort(sorted.begin(), sorted.end());        /* by key: the same order on every rank, whatever the hash map did */
     for (size_t i = 0; i < sorted.size(); i++)
     {
         keys[i] = sorted[i].first;
-        keyClump[i] = m->clumpRoot(sorted[i].second);
+        keyClump[i] = sorted[i].second;
     }
-    for (size_t c = 0; c < m->clumps.size(); c++)
+    for (size_t c = 0; c < m->parent.size(); c++)
     {
-        const bool root = m->clumps[c].parent < 0;
-        clumpVertices[c] = root ? m->clumps[c].vertices : 0;
-        clumpTriangles[c] = root ? m->clumps[c].triangles : 0;
+        const bool root = m->parent[c] < 0;
+        clumpVertices[c] = root ? m->compVertices[c] : 0;
+        clumpTriangles[c] = root ? m->compTriangles[c] : 0;
     }
     return MLSGPU_OK;
 }
@@ -355,8 +967,9 @@ MLSGPU_API int mlsgpu_hip_host_mesher_finalize_with(mlsgpu_host_mesher *m, const
 {
     REQUIRE(m != nullptr && keepClump != nullptr, MLSGPU_ERR_INVALID);
     std::lock_guard<std::mutex> lock(m->mutex);
-    REQUIRE(numClumps == m->clumps.size(), MLSGPU_ERR_LENGTH);
-    return finalizeWith(m, keepClump, numChunks);
+    PROPAGATE(m->resolve());
+    REQUIRE(numClumps == m->parent.size(), MLSGPU_ERR_LENGTH);
+    return m->finalizeWith(keepClump, numChunks);
 }
 
 MLSGPU_API int mlsgpu_hip_host_mesher_chunk(mlsgpu_host_mesher *m, uint32_t i, uint64_t *chunkId, uint64_t *numVertices,
@@ -368,8 +981,8 @@ MLSGPU_API int mlsgpu_hip_host_mesher_chunk(mlsgpu_host_mesher *m, uint32_t i, u
     if (chunkId) *chunkId = m->chunkIds[c];
     if (numVertices) *numVertices = m->chunkVStart[c + 1] - m->chunkVStart[c];
     if (numTriangles) *numTriangles = m->chunkTStart[c + 1] - m->chunkTStart[c];
-    if (vertices) *vertices = m->outVertices.data() + 3 * m->chunkVStart[c];
-    if (triangles) *triangles = m->outTriangles.data() + 3 * m->chunkTStart[c];
+    if (vertices) *vertices = m->outVertices + 3 * m->chunkVStart[c];
+    if (triangles) *triangles = m->outTriangles + 3 * m->chunkTStart[c];
     return MLSGPU_OK;
 }
 

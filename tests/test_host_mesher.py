@@ -100,3 +100,39 @@ def test_bad_mesh_leaves_the_sink_unchanged_and_empty_sinks_finalize():
     with pytest.raises(m.LengthError):
         mesher.finalize_with(np.ones(len(cv) + 1, np.uint8))
     assert mesher.finalize_with(np.zeros(len(cv), np.uint8)) == 0                   # everything pruned by verdict
+
+
+@pytest.mark.parametrize("prune", [0.0, 0.05])
+def test_thread_count_does_not_change_the_output(prune):
+    """add() queues a block's work on the welder's pool and finalize builds the output on it; clump numbers, union
+    records and the vertex a chunk keeps for a key are expressed in arrival order, so 1, 3 or 16 threads give the same
+    arrays element for element (and the same as the oracle up to isomorphism)."""
+    import mlsgpu_amd as m
+    meshes = random_meshes(11, blocks=24, chunks=3)
+    order = [3, 0, 9, 1, 17, 4, 2, 10, 23, 5, 6, 11, 7, 8, 12, 13, 20, 14, 15, 16, 18, 19, 21, 22]   # chunks interleaved
+    mixed = [meshes[i] for i in order]
+    outs = []
+    for threads in (1, 3, 16):
+        mesher = m.HostMesher(prune, threads=threads)
+        assert mesher.threads() == threads
+        seen = {}
+        for mesh in mixed:
+            mesher.add(seen.setdefault(mesh["chunk"], len(seen)), mesh["vertices"], mesh["num_internal"], mesh["keys"],
+                       mesh["triangles"])
+        n = mesher.finalize()
+        outs.append(([mesher.chunk(i) for i in range(n)], mesher.stats(), mesher.boundary()))
+        mesher.close()
+    exp, exp_stats = mo.mesh_sink(mixed, prune)
+    first, stats0, b0 = outs[0]
+    for k in ("total_vertices", "threshold", "components", "kept_components", "kept_vertices", "kept_triangles"):
+        assert stats0[k] == exp_stats[k], k
+    for (c, v, t), (_, ev, et) in zip(first, exp):
+        assert mo.isomorphic(v, t, ev, et)
+    for other, stats, b in outs[1:]:
+        assert stats == stats0 and len(other) == len(first)
+        for (c0, v0, t0), (c1, v1, t1) in zip(first, other):
+            assert c0 == c1
+            np.testing.assert_array_equal(v0.view(np.uint32), v1.view(np.uint32))
+            np.testing.assert_array_equal(t0, t1)
+        for x, y in zip(b0, b):
+            np.testing.assert_array_equal(x, y)
