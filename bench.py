@@ -512,7 +512,11 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     hi = [torch.cuda.Stream(device=device_index, priority=int(os.environ.get("MLSGPU_BENCH_SINK_PRIORITY", "-1"))) for _ in range(NS)]
     fctx = [m.Context(device_index, stream=s_.cuda_stream) for s_ in hi]
     sinks = [m.Mesher(c, 0.02) for c in fctx]
-    farms = [m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
+    # spare device items beyond one per worker: the previous job's weld shares the GPU with this job's kernels, and with
+    # one spare item every delayed bucket stalls the host-to-device copies behind it (shells cloud, steady state: 47 ms per
+    # job with 1 spare item, 42 with 4, 44 with 12)
+    sink_spare = int(os.environ.get("MLSGPU_BENCH_FARM_SPARE", "4"))
+    farms = [m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=sink_spare, max_cells=max_cells,
                           mesh_memory=args.mesh_memory_mb << 20, sink=s_, copy_threads=args.copy_threads) for s_ in sinks]
     pins = [m.binding.PinnedBuffer(1) for _ in range(NS)]
     got_bytes = [0] * NS

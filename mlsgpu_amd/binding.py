@@ -446,10 +446,15 @@ def download_into_pinned(ctx, chunk, pinned):
     if nv + nt > pinned.nbytes:
         ctx.synchronize()
         pinned.ensure(int((nv + nt) * 1.1) + 4096)
-    if nv:
-        check(lib().mlsgpu_hip_memcpy_d2h(ctx.h, pinned.ptr, chunk["d_vertices"], nv, 1))
-    if nt:
-        check(lib().mlsgpu_hip_memcpy_d2h(ctx.h, pinned.ptr + nv, chunk["d_triangles"], nt, 1))
+    # in pieces: one copy command of hundreds of MB holds its DMA engine until it is done, and the host-to-device copies of
+    # the NEXT job's splats wait behind it; pieces let them interleave (what the ring route's 23 MB read-backs do by nature)
+    piece = int(os.environ.get("MLSGPU_HIP_READBACK_PIECE_MB", "32")) << 20
+    for base, src, n in ((0, chunk["d_vertices"], nv), (nv, chunk["d_triangles"], nt)):
+        o = 0
+        while o < n:
+            k = min(piece, n - o) if piece > 0 else n
+            check(lib().mlsgpu_hip_memcpy_d2h(ctx.h, pinned.ptr + base + o, src + o, k, 1))
+            o += k
     return nv + nt
 
 

@@ -559,10 +559,15 @@ struct mlsgpu_mesher
     std::vector<uint64_t> chunkIds;             /* dense index -> caller's id, arrival order */
     bool finalized = false;
     bool peerEnabled[16] = {};                  /* peer access towards the GPUs whose workers have appended */
-    /* boundary() leaves the weld and the components in the slab (representatives, roots, sizes, the dense root numbering);
-     * a finalize_with() right behind it -- same arenas, nothing added -- starts from them instead of sorting and uniting
-     * again.  One use: the verdict overwrites the sizes. */
-    bool cacheValid = false;
+    /* What the last analysis left in the slab, valid while nothing is added (same arenas):
+     *   1  after boundary(): the weld and the components (representatives, roots, sizes) AND the dense root numbering -- a
+     *      finalize_with() right behind it starts from them instead of sorting and uniting again (one use: the verdict
+     *      overwrites the sizes);
+     *   2  after a plain finalize(): the weld and the components (the output pass only rewrote the vertex index array) -- a
+     *      boundary() behind it numbers the roots and exports, without the key sort and the union-find;
+     *   0  nothing. */
+    int cacheKind = 0;
+    bool cacheSortedInA = false;                /* which of the sort's two buffers holds the sorted external keys */
     uint64_t cacheDims[3] = {0, 0, 0};
     uint32_t cacheRootCount = 0;
     /* results */
@@ -585,6 +590,7 @@ struct mlsgpu_mesher
     {
         if (bytes <= slabCap)
             return MLSGPU_OK;
+        cacheKind = 0;          /* whatever an analysis left in the old slab is gone */
         hipFree(slab);
         slab = nullptr;
         slabCap = 0;
@@ -838,7 +844,7 @@ MLSGPU_API int mlsgpu_hip_mesher_add(mlsgpu_mesher *m, mlsgpu_ctx *from, uint64_
         m->chunkIds.push_back(chunkId);
     m->blocks.push_back(r);
     m->analyzed = false;
-    m->cacheValid = false;
+    m->cacheKind = 0;
     return MLSGPU_OK;
 }
 
@@ -862,7 +868,7 @@ MLSGPU_API int mlsgpu_hip_mesher_reset(mlsgpu_mesher *m)
     m->outChunks.clear();
     m->finalized = false;
     m->analyzed = false;
-    m->cacheValid = false;
+    m->cacheKind = 0;
     return MLSGPU_OK;
 }
 
@@ -956,9 +962,12 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
     const uint64_t nv = m->vertices.used / 3, nt = m->triangles.used / 3, ne = m->extKeys.used;
     const uint32_t nb = (uint32_t) m->blocks.size(), nc = (uint32_t) m->chunkIds.size();
     /* the verdict pass right behind an export: weld, components and root numbering are still in the slab */
-    const bool reuse = keepRoots != nullptr && !analyzeOnly && m->cacheValid && m->cacheDims[0] == nv && m->cacheDims[1] == nt
-        && m->cacheDims[2] == ne;
-    m->cacheValid = false;
+    const bool sameArenas = m->cacheDims[0] == nv && m->cacheDims[1] == nt && m->cacheDims[2] == ne;
+    bool reuseDense = keepRoots != nullptr && !analyzeOnly && m->cacheKind == 1 && sameArenas;
+    /* the weld and the components are in the slab: after an export (for the verdict pass) or after a plain finalize (for an
+     * export) */
+    bool reuse = reuseDense || (analyzeOnly && m->cacheKind == 2 && sameArenas);
+    m->cacheKind = 0;
     m->chunkVStart.assign(nc + 1, 0);
     m->chunkTStart.assign(nc + 1, 0);
     m->outChunks.clear();
@@ -978,7 +987,12 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
             *numChunks = 0;
         return MLSGPU_OK;
     }
-    PROPAGATE(m->ensureSlab(scratchBytes(nv, nt, ne, nb, nc)));
+    {
+        const void *const slabBefore = m->slab;
+        PROPAGATE(m->ensureSlab(scratchBytes(nv, nt, ne, nb, nc)));
+        if (m->slab != slabBefore)
+            reuse = reuseDense = false;         /* (cannot happen for unchanged arenas; the cached analysis lived there) */
+    }
     PROPAGATE(m->ensureOutputs(nv, nt));
     Scratch S(m->slab, m->slabCap);
     uint32_t *compRep, *outRep, *parent, *root, *size, *vIndex;
@@ -1014,8 +1028,14 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
         {
             HIP_CHECK(hipMemcpyAsync(keysA, m->extKeys.ptr, ne * 8, hipMemcpyDeviceToDevice, ctx->stream));
             PROPAGATE(radixSort<uint64_t>(ctx, "mesher.weld.time", keysA, slotsA, keysB, slotsB, ne, 64, true, hist, tileSums, &sorted));
+            m->cacheSortedInA = sorted.keys == keysA;
             LAUNCH(ctx, "mesher.weld.time", externalRepsKernel, dim3(divUp(ne, 256)), B, (const uint64_t *) sorted.keys,
                    (const uint32_t *) sorted.vals, (const uint32_t *) m->extGid.ptr, (const uint32_t *) m->extChunk.ptr, ne, compRep, outRep);
+        }
+        else
+        {
+            sorted.keys = m->cacheSortedInA ? keysA : keysB;
+            sorted.vals = m->cacheSortedInA ? slotsA : slotsB;
         }
     }
 
@@ -1041,7 +1061,7 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
         uint32_t *dRootTotal, *rootTiles;
         PROPAGATE(S.get(&dRootTotal, 1));
         PROPAGATE(S.get(&rootTiles, scanTiles(nv)));
-        if (reuse)
+        if (reuseDense)
             rootCount = m->cacheRootCount;
         else
         {
@@ -1097,7 +1117,7 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
         HIP_CHECK(hipStreamSynchronize(ctx->stream));
         m->bRootVertices.assign(hv.begin(), hv.end());
         m->bRootTriangles.assign(ht.begin(), ht.end());
-        m->cacheValid = true;
+        m->cacheKind = 1;
         m->cacheDims[0] = nv; m->cacheDims[1] = nt; m->cacheDims[2] = ne;
         m->cacheRootCount = rootCount;
         if (numChunks)
@@ -1227,6 +1247,12 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
     m->stats[5] = totals[1];
     m->stats[6] = nv;
     m->stats[7] = nt;
+    if (keepRoots == nullptr)
+    {
+        /* the weld and the components stay in the slab for an export that may follow (boundary) */
+        m->cacheKind = 2;
+        m->cacheDims[0] = nv; m->cacheDims[1] = nt; m->cacheDims[2] = ne;
+    }
     m->finalized = true;
     if (numChunks)
         *numChunks = (uint32_t) m->outChunks.size();

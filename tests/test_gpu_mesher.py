@@ -232,3 +232,51 @@ def test_boundary_api_edge_cases():
     np.testing.assert_array_equal(kept["triangles"], same["triangles"])
     sink.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("seed,prune", [(5, 0.0), (6, 0.05)])
+def test_boundary_after_finalize_reuses_the_analysis(seed, prune):
+    """finalize() leaves the weld and the components in the sink's scratch; a boundary() behind it only numbers the roots and
+    exports (no key sort, no union-find), and the verdict pass behind THAT starts from the same state.  Same export, same
+    meshes as a sink that went add -> boundary -> finalize_with; an add in between invalidates everything."""
+    import mlsgpu_amd as m
+    meshes = random_meshes(seed, blocks=10, chunks=2)
+    ctx = m.Context(0)
+
+    def fill(sink, upto=None):
+        seen = {}
+        for mesh in meshes[:upto]:
+            sink.add(chunk_number(mesh["chunk"], seen), mesh["vertices"], mesh["num_internal"], mesh["keys"], mesh["triangles"])
+
+    fresh = m.Mesher(ctx, prune)
+    fill(fresh)
+    exp_boundary = fresh.boundary()
+    keep = (exp_boundary[2] >= 3).astype(np.uint8)              # some verdict: components of at least three vertices
+    n_exp = fresh.finalize_with(keep)
+    exp_chunks = [fresh.chunk(i) for i in range(n_exp)]
+
+    sink = m.Mesher(ctx, prune)
+    fill(sink)
+    n_plain = sink.finalize()
+    plain = [sink.chunk(i) for i in range(n_plain)]
+    got_boundary = sink.boundary()                               # reuses finalize's weld and components
+    for a, b in zip(exp_boundary, got_boundary):
+        np.testing.assert_array_equal(a, b)
+    assert sink.finalize_with(keep) == n_exp
+    for e, g in zip(exp_chunks, [sink.chunk(i) for i in range(n_exp)]):
+        np.testing.assert_array_equal(e["vertices"].view(np.uint32), g["vertices"].view(np.uint32))
+        np.testing.assert_array_equal(e["triangles"], g["triangles"])
+    # ... and a plain finalize again gives what it gave before
+    assert sink.finalize() == n_plain
+    for e, g in zip(plain, [sink.chunk(i) for i in range(n_plain)]):
+        np.testing.assert_array_equal(e["vertices"].view(np.uint32), g["vertices"].view(np.uint32))
+        np.testing.assert_array_equal(e["triangles"], g["triangles"])
+    # two boundaries in a row, then the verdict
+    b1 = sink.boundary()
+    b2 = sink.boundary()
+    for a, b in zip(b1, b2):
+        np.testing.assert_array_equal(a, b)
+    assert sink.finalize_with(keep) == n_exp
+    fresh.close()
+    sink.close()
+    ctx.close()

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Per-stage times of the device sink's finalize on one synthetic cloud (HIP events around every launch)."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    dist = sys.argv[1] if len(sys.argv) > 1 else "shells"
+    import torch
+
+    import mlsgpu_amd as m
+    from mlsgpu_amd import synth
+    device = torch.device("cuda", 0)
+    cloud, g = synth.make_cloud_device("cfg3", device, scale=1.0, dist=dist)
+    sb_t, buckets = synth.bucketize_device(cloud, synth.grid_buckets((g, g, g), 255))
+    del cloud
+    torch.cuda.synchronize()
+    ctx = m.Context(0)
+    smax = max(b.count for b in buckets)
+    scells = max(max(b.num_vertices) for b in buckets) - 1
+    w = m.Worker(ctx, smax, max_cells=scells, mesh_memory=4096 << 20)
+    w.set_keep_splats(True)
+    w.set_batch(4)
+    buf = m.DeviceBuffer(ctx, nbytes=sb_t.numel() * 4, borrow=sb_t.data_ptr())
+    sink = m.Mesher(ctx, 0.02)
+    for rep in range(3):
+        sink.reset()
+        w.process_batch(buf, buckets, collector=sink.collector(ctx, 0))
+        ctx.synchronize()
+        ctx.reset_stats()
+        ctx.set_timing(rep == 2)
+        t0 = time.perf_counter()
+        n = sink.finalize()
+        ctx.synchronize()
+        dt = time.perf_counter() - t0
+        ctx.set_timing(False)
+    st = {k: (round(v[0], 3), v[1]) for k, v in ctx.stats().items() if k.startswith("mesher")}
+    print(json.dumps({"finalize_ms_instrumented": round(dt * 1e3, 2), "chunks": n, "stats": sink.stats(), "stages_ms_launches": st}))
+    ctx.set_timing(False)
+    for rep in range(3):
+        sink.reset()
+        w.process_batch(buf, buckets, collector=sink.collector(ctx, 0))
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        sink.finalize()
+        ctx.synchronize()
+        print("finalize alone ms", round((time.perf_counter() - t0) * 1e3, 2))
+
+
+if __name__ == "__main__":
+    main()
