@@ -34,6 +34,8 @@ struct mlsgpu_tree
     int32_t *dStart = nullptr, *dJumpPos = nullptr, *dCommands = nullptr;
     uint32_t *dKeysA = nullptr, *dKeysB = nullptr, *dValsA = nullptr, *dValsB = nullptr;
     uint32_t *dHist = nullptr, *dTileSums = nullptr, *dNumEntries = nullptr;
+    uint32_t *dNodeCounts = nullptr, *dNodeBase = nullptr;     /* per node: entries, and twice the non-empty nodes before it */
+    U3 *dNodeTiles = nullptr;           /* tile sums of the scan over the nodes */
     HostMailbox entryBox;               /* the entry count comes back to the host once per build */
     uint8_t *dSlotMasks = nullptr;      /* per splat: which of its 8 candidate slots are real entries */
     mlsgpu_splat *dSplats = nullptr;   /* borrowed between build and clear_splats */
@@ -553,6 +555,46 @@ struct SplatIdsOut
  * or -1.  start[] of a non-empty node is written by writeSplatIds and never changes, so every node
  * can fetch it independently.
  */
+/*
+ * The command list without a pass over the entries (round 4).  In the sorted entry list a node's ids are one run, and
+ * writeSplatIds (kernels/octree.cl:256-279) puts the id of sorted rank r at command position 1 + r + 2 * (non-empty nodes
+ * before the id's node): the scan of countCommands' 1 / 3 indicators (src/splat_tree_cl.cpp:310-317) is that sum, entry by
+ * entry.  With the number of entries of every node at hand -- the last pass's histogram kernel counts whole keys on the way
+ * (sortHistKernel<KEY_COUNTS>) -- a scan over the NODES (37 449 of them for the default tree, not 7 million entries) gives
+ * each node its first rank and the number of non-empty nodes before it, hence start[] and the jump slots of the non-empty
+ * nodes (NodeOut below), and the last scatter pass of the sort writes every id straight to its command position
+ * (sortScatterKernel<SPREAD>): the sorted (key, id) arrays are never written and countCommands / scan / writeSplatIds do
+ * not run.  `commands` and `start` are the reference's, word for word (tests/test_gpu_tree.py).
+ */
+struct NodeIn
+{
+    const uint32_t *counts;
+    __device__ __forceinline__ U3 operator()(uint64_t i) const
+    {
+        const uint32_t c = counts[i];
+        return U3{c, c != 0 ? 1u : 0u, 0u};
+    }
+};
+
+struct NodeOut
+{
+    int32_t *start, *jumpPos;
+    uint32_t *nodeBase;
+    __device__ __forceinline__ void operator()(uint64_t i, U3 excl, U3 val) const
+    {
+        if (val.a != 0)
+        {
+            /* first id at 1 + excl.a + 2 excl.b: start = that - 1 (octree.cl:272-274), the jump slot behind the last id (:275-277) */
+            const uint32_t first = excl.a + 2 * excl.b;
+            start[i] = (int32_t) first;
+            jumpPos[i] = (int32_t) (first + val.a + 1);
+            nodeBase[i] = 2 * excl.b;
+        }
+        else
+            jumpPos[i] = -1;            /* fill(jumpPos, -1), kernels/octree.cl:346 */
+    }
+};
+
 struct WriteStartArgs
 {
     int32_t *start, *commands;
@@ -652,7 +694,7 @@ MLSGPU_API uint64_t mlsgpu_hip_tree_resource_usage(uint64_t maxLevels, uint64_t 
     uint64_t maxStart, commandsSize;
     treeSizes(maxLevels, maxSplats, &maxStart, &commandsSize);
     const uint64_t entries = maxSplats * 8;
-    return maxStart * 4 * 2 + commandsSize * 4 + entries * 4 * 4
+    return maxStart * 4 * 4 + commandsSize * 4 + entries * 4 * 4
         + sortHistElems(entries) * 4 + (uint64_t) scanTiles(sortHistElems(entries) > entries ? sortHistElems(entries) : entries) * 4;
 }
 
@@ -686,6 +728,9 @@ MLSGPU_API int mlsgpu_hip_tree_create(mlsgpu_ctx *ctx, uint64_t maxLevels, uint6
     alloc((void **) &t->dTileSums, tileSums * 4);
     alloc((void **) &t->dNumEntries, 4);
     alloc((void **) &t->dSlotMasks, maxSplats);
+    alloc((void **) &t->dNodeCounts, t->maxStart * 4);
+    alloc((void **) &t->dNodeBase, t->maxStart * 4);
+    alloc((void **) &t->dNodeTiles, ((uint64_t) scanTiles(t->maxStart) + 1) * sizeof(U3));
     if (rc == MLSGPU_OK)
         rc = t->entryBox.create();
     if (rc != MLSGPU_OK)
@@ -705,6 +750,7 @@ MLSGPU_API void mlsgpu_hip_tree_destroy(mlsgpu_tree *t)
     hipFree(t->dStart); hipFree(t->dJumpPos); hipFree(t->dCommands);
     hipFree(t->dKeysA); hipFree(t->dKeysB); hipFree(t->dValsA); hipFree(t->dValsB);
     hipFree(t->dHist); hipFree(t->dTileSums); hipFree(t->dNumEntries); hipFree(t->dSlotMasks);
+    hipFree(t->dNodeCounts); hipFree(t->dNodeBase); hipFree(t->dNodeTiles);
     t->entryBox.destroy();
     delete t;
 }
@@ -752,6 +798,8 @@ static int treeBuildBatch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *re
     static const bool fusedOff = getenv("MLSGPU_HIP_OCTREE_FUSED") != nullptr && atoi(getenv("MLSGPU_HIP_OCTREE_FUSED")) == 0;
     const bool fused = perPass <= ENT_BIN_BITS && !fusedOff;      /* wider digits (deep trees) take the separate passes */
 
+    /* the command list straight from the sort's last pass (NodeIn / NodeOut above): for the fused front end with ONE pass left */
+    const bool direct = fused && keyBits <= 2 * perPass;
     Lanes<int32_t *> jump;
     Lanes<WriteStartArgs> ws;
     for (uint32_t k = 0; k < MAX_LANES; k++)
@@ -763,17 +811,20 @@ static int treeBuildBatch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *re
             t->numLevels = (uint32_t) (maxShift - minShift + 1);
             t->dSplats = reqs[k].dSplats;
         }
-        jump.a[k] = t->dJumpPos;
+        jump.a[k] = direct ? reinterpret_cast<int32_t *>(t->dNodeCounts) : t->dJumpPos;
         ws.a[k] = WriteStartArgs{t->dStart, t->dCommands, t->dJumpPos};
     }
-    /* fill(jumpPos, -1), kernels/octree.cl:346 */
-    LAUNCH(ctx, "kernel.octree.fill.time", fillKernel, dim3(divUp(numStart, 256), count), dim3(256), jump, numStart, (int32_t) -1);
+    /* fill(jumpPos, -1), kernels/octree.cl:346 -- or, on the direct route, the node counters (NodeOut writes jumpPos) */
+    LAUNCH(ctx, "kernel.octree.fill.time", fillKernel, dim3(divUp(numStart, 256), count), dim3(256), jump, numStart,
+           (int32_t) (direct ? 0 : -1));
 
     /* the lanes that hold splats */
     uint32_t act[MAX_LANES], na = 0;
     for (uint32_t k = 0; k < count; k++)
         if (reqs[k].numSplats > 0)
             act[na++] = k;
+    SortJob<uint32_t> sortJobs[MAX_LANES];
+    uint64_t sortN[MAX_LANES];
     if (na > 0)
     {
         auto params = [&](uint32_t k) {
@@ -781,8 +832,6 @@ static int treeBuildBatch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *re
             return EntryParams{r.dSplats, r.offset[0], r.offset[1], r.offset[2], lo, minShift, maxShift, (uint32_t) r.firstSplat,
                                trees[k]->mutate ? 1u : 0u};
         };
-        SortJob<uint32_t> sortJobs[MAX_LANES];
-        uint64_t sortN[MAX_LANES];
         if (fused)
         {
             /* writeEntries + the sort's first pass as one count / digit scan / scatter, see entryScatterKernel */
@@ -820,7 +869,8 @@ static int treeBuildBatch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *re
                 sortJobs[a] = SortJob<uint32_t>{t->dKeysB, t->dValsB, t->dKeysA, t->dValsA, sortN[a], t->dHist, t->dNumEntries,
                                                 SortResult<uint32_t>{nullptr, nullptr}};
             }
-            PROPAGATE(radixSortBatch<uint32_t>(ctx, "kernel.octree.sort.time", sortJobs, na, keyBits, false, perPass));
+            if (!direct)
+                PROPAGATE(radixSortBatch<uint32_t>(ctx, "kernel.octree.sort.time", sortJobs, na, keyBits, false, perPass));
         }
         else
         {
@@ -851,18 +901,79 @@ static int treeBuildBatch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *re
             }
             PROPAGATE(radixSortBatch<uint32_t>(ctx, "kernel.octree.sort.time", sortJobs, na, keyBits, false));
         }
-        /* countCommands + scan(seed 1) + writeSplatIds, src/splat_tree_cl.cpp:310-317 */
-        typedef ScanJob<uint32_t, IndicatorIn, IndicatorIn, SplatIdsOut> CommandJob;
-        CommandJob cj[MAX_LANES];
-        for (uint32_t a = 0; a < na; a++)
+        if (direct)
         {
-            mlsgpu_tree *t = trees[act[a]];
-            const SortResult<uint32_t> &sorted = sortJobs[a].result;
-            const IndicatorIn in{sorted.keys, t->dNumEntries};
-            cj[a] = CommandJob{in, in, SplatIdsOut{t->dCommands, t->dStart, t->dJumpPos, sorted.keys, sorted.vals, t->dNumEntries},
-                               sortN[a], 1u, t->dTileSums, (uint32_t *) nullptr, t->dNumEntries};
+            /* the sort's last pass: histogram + whole-key counts */
+            const uint32_t shift = perPass, digitBits = keyBits - perPass;
+            Lanes<SortHistArgs<uint32_t> > h;
+            Lanes<SortDigitScanArgs> d;
+            uint32_t maxTiles = 0;
+            for (uint32_t a = 0; a < MAX_LANES; a++)
+            {
+                const SortJob<uint32_t> &j = sortJobs[a < na ? a : 0];
+                mlsgpu_tree *t = trees[act[a < na ? a : 0]];
+                const uint32_t tiles = a < na ? sortTiles(j.n) : 0u;
+                uint32_t *const dDigitTotals = j.dHist + (uint64_t) SORT_MAX_BINS * sortTiles(j.n);
+                h.a[a] = SortHistArgs<uint32_t>{j.keysA, j.dHist, j.n, j.nDev, tiles, t->dNodeCounts};
+                d.a[a] = SortDigitScanArgs{j.dHist, dDigitTotals, tiles};
+                maxTiles = std::max(maxTiles, tiles);
+            }
+            if (maxTiles > 0)
+            {
+                LAUNCH(ctx, "kernel.octree.sort.time", (sortHistKernel<uint32_t, true>), dim3(maxTiles, na), dim3(PRIM_BLOCK), h, shift,
+                       digitBits);
+                LAUNCH(ctx, "kernel.octree.sort.time", (sortDigitScanKernel<uint32_t>), dim3(1u << digitBits, na), dim3(PRIM_BLOCK), d);
+            }
         }
-        PROPAGATE((exclusiveScanBatch<uint32_t, IndicatorIn, IndicatorIn, SplatIdsOut>(ctx, "kernel.octree.scan.time", cj, na)));
+        else
+        {
+            /* countCommands + scan(seed 1) + writeSplatIds, src/splat_tree_cl.cpp:310-317 */
+            typedef ScanJob<uint32_t, IndicatorIn, IndicatorIn, SplatIdsOut> CommandJob;
+            CommandJob cj[MAX_LANES];
+            for (uint32_t a = 0; a < na; a++)
+            {
+                mlsgpu_tree *t = trees[act[a]];
+                const SortResult<uint32_t> &sorted = sortJobs[a].result;
+                const IndicatorIn in{sorted.keys, t->dNumEntries};
+                cj[a] = CommandJob{in, in, SplatIdsOut{t->dCommands, t->dStart, t->dJumpPos, sorted.keys, sorted.vals, t->dNumEntries},
+                                   sortN[a], 1u, t->dTileSums, (uint32_t *) nullptr, t->dNumEntries};
+            }
+            PROPAGATE((exclusiveScanBatch<uint32_t, IndicatorIn, IndicatorIn, SplatIdsOut>(ctx, "kernel.octree.scan.time", cj, na)));
+        }
+    }
+    if (direct)
+    {
+        /* the scan over the NODES of every lane (a lane without splats has no entries anywhere: jumpPos = -1 throughout) */
+        typedef ScanJob<U3, NodeIn, NodeIn, NodeOut> NodeJob;
+        NodeJob nj[MAX_LANES];
+        for (uint32_t k = 0; k < count; k++)
+        {
+            mlsgpu_tree *t = trees[k];
+            const NodeIn in{t->dNodeCounts};
+            nj[k] = NodeJob{in, in, NodeOut{t->dStart, t->dJumpPos, t->dNodeBase}, numStart, U3{0, 0, 0}, t->dNodeTiles, (U3 *) nullptr,
+                            nullptr};
+        }
+        PROPAGATE((exclusiveScanBatch<U3, NodeIn, NodeIn, NodeOut>(ctx, "kernel.octree.scan.time", nj, count)));
+        if (na > 0)
+        {
+            /* ... and the last scatter: every id to its command position */
+            const uint32_t shift = perPass, digitBits = keyBits - perPass;
+            Lanes<SortScatterArgs<uint32_t> > sc;
+            uint32_t maxTiles = 0;
+            for (uint32_t a = 0; a < MAX_LANES; a++)
+            {
+                const SortJob<uint32_t> &j = sortJobs[a < na ? a : 0];
+                mlsgpu_tree *t = trees[act[a < na ? a : 0]];
+                const uint32_t tiles = a < na ? sortTiles(j.n) : 0u;
+                uint32_t *const dDigitTotals = j.dHist + (uint64_t) SORT_MAX_BINS * sortTiles(j.n);
+                sc.a[a] = SortScatterArgs<uint32_t>{j.keysA, j.valsA, (uint32_t *) nullptr, reinterpret_cast<uint32_t *>(t->dCommands), j.dHist,
+                                                   dDigitTotals, j.n, j.nDev, tiles, t->dNodeBase};
+                maxTiles = std::max(maxTiles, tiles);
+            }
+            if (maxTiles > 0)
+                LAUNCH(ctx, "kernel.octree.sort.time", (sortScatterKernel<uint32_t, false, 8, true>), dim3(maxTiles, na), dim3(PRIM_BLOCK), sc,
+                       shift, digitBits);
+        }
     }
     LAUNCH(ctx, "kernel.octree.writeStart.time", writeStartKernel, dim3(divUp(numStart, 256), count), dim3(256),
            ws, lo, minShift, maxShift, numStart);

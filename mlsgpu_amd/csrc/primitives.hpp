@@ -405,9 +405,20 @@ struct SortHistArgs
     uint64_t n;
     const uint32_t *nDev;
     uint32_t numTiles;
+    uint32_t *keyCounts;        /* KEY_COUNTS: occurrences of every whole key (the pass's digit is the key's top digit) */
 };
 
-template<typename K>
+enum { KEY_COUNT_SLOTS = 4 };   /* low parts of the key a tile may span and still count in LDS */
+
+/*
+ * Histogram of one digit per tile.  KEY_COUNTS (the LAST pass of a sort whose keys have `shift + digitBits` bits, 256 bins at
+ * most): the kernel also counts the occurrences of every whole key, keyCounts[key].  The input is sorted by the low `shift`
+ * bits already, so a tile of 4096 keys holds one low part, sometimes two: the counts are gathered in LDS per (low part, top
+ * digit) and leave as one global atomic per non-empty bin -- a sixteenth of the atomics a key-by-key count would take
+ * (~16 keys per bin on the octree's entries).  Keys of a tile beyond KEY_COUNT_SLOTS low parts (tiny groups) go straight
+ * to memory.
+ */
+template<typename K, bool KEY_COUNTS = false>
 __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(Lanes<SortHistArgs<K> > lanes, uint32_t shift, uint32_t digitBits)
 {
     const SortHistArgs<K> &A = lanes.a[blockIdx.y];
@@ -417,26 +428,54 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(Lanes<SortHistArgs<
     if (A.nDev != nullptr && *A.nDev < n)
         n = *A.nDev;
     __shared__ uint32_t bins[SORT_MAX_BINS];
+    __shared__ uint32_t keyBins[KEY_COUNTS ? KEY_COUNT_SLOTS * 256 : 1];
     const uint32_t numBins = 1u << digitBits;
     const K mask = (K) (numBins - 1);
     for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
         bins[d] = 0;
+    if (KEY_COUNTS)
+        for (uint32_t d = threadIdx.x; d < KEY_COUNT_SLOTS * 256; d += PRIM_BLOCK)
+            keyBins[d] = 0;
     __syncthreads();
     const K *const keys = A.keys;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t base = (uint64_t) blockIdx.x * SORT_TILE + (uint64_t) wave * SORT_WAVE_SPAN + lane;
+    const uint64_t tileFirst = (uint64_t) blockIdx.x * SORT_TILE;
+    const uint64_t base = tileFirst + (uint64_t) wave * SORT_WAVE_SPAN + lane;
+    const K lowMask = (K) (((K) 1 << shift) - 1);
+    uint32_t lowFirst = 0;
+    if (KEY_COUNTS && tileFirst < n)
+        lowFirst = (uint32_t) (keys[tileFirst] & lowMask);
 #pragma unroll 4
     for (int j = 0; j < SORT_ITEMS; j++)
     {
         uint64_t i = base + (uint64_t) j * 64;
         if (i < n)
-            atomicAdd(&bins[(uint32_t) ((keys[i] >> shift) & mask)], 1u);
+        {
+            const K key = keys[i];
+            const uint32_t digit = (uint32_t) ((key >> shift) & mask);
+            atomicAdd(&bins[digit], 1u);
+            if (KEY_COUNTS)
+            {
+                const uint32_t slot = (uint32_t) (key & lowMask) - lowFirst;
+                if (slot < KEY_COUNT_SLOTS)
+                    atomicAdd(&keyBins[slot * 256 + digit], 1u);
+                else
+                    atomicAdd(&A.keyCounts[(uint32_t) key], 1u);
+            }
+        }
     }
     __syncthreads();
     uint32_t *const hist = A.hist;
     const uint32_t numTiles = A.numTiles;
     for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
         hist[(uint64_t) d * numTiles + blockIdx.x] = bins[d];
+    if (KEY_COUNTS)
+        for (uint32_t d = threadIdx.x; d < KEY_COUNT_SLOTS * 256; d += PRIM_BLOCK)
+        {
+            const uint32_t c = keyBins[d];
+            if (c != 0)
+                atomicAdd(&A.keyCounts[((d & 255u) << shift) | (lowFirst + (d >> 8))], c);
+        }
 }
 
 struct SortDigitScanArgs
@@ -499,6 +538,7 @@ struct SortScatterArgs
     uint64_t n;
     const uint32_t *nDev;
     uint32_t numTiles;
+    const uint32_t *keyBase;    /* SPREAD: the value of sorted rank r with key k goes to valsOut[1 + r + keyBase[k]] */
 };
 
 /*
@@ -512,8 +552,12 @@ struct SortScatterArgs
  *      position inside the TILE-LOCALLY SORTED sequence;
  *   4. the tile is assembled in that order in LDS and copied out by consecutive threads, so each
  *      digit's run leaves as one contiguous, coalesced burst instead of 64 scattered dwords per store.
+ *
+ * SPREAD (the last pass of the octree's entry sort): the sorted keys are not written at all, and a value does not go to its
+ * sorted rank r but to 1 + r + keyBase[key] -- the runs of equal keys keep their order and open up by keyBase, which is how
+ * the octree's command list interleaves its per-node markers with the splat ids (octree.hip).
  */
-template<typename K, bool IOTA, int BIN_BITS>
+template<typename K, bool IOTA, int BIN_BITS, bool SPREAD = false>
 __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatterArgs<K> > lanes, uint32_t shift, uint32_t digitBits)
 {
     enum { BINS = 1 << BIN_BITS };
@@ -642,7 +686,10 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
         {
             const K key = sTile[p];
             out[k] = tileBase[(uint32_t) ((key >> shift) & mask)] + p;
-            keysOut[out[k]] = key;
+            if (SPREAD)
+                out[k] += 1u + A.keyBase[(uint32_t) key];
+            else
+                keysOut[out[k]] = key;
         }
     }
     __syncthreads();
