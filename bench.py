@@ -77,7 +77,7 @@ def parse_args():
     p.add_argument("--farm-workers", type=int, default=4,
                    help="device workers per GPU of the farm legs (host splats in, meshes out): transfers want more in flight "
                         "(shells cloud, 8d region: 2 971 Mvoxels/s with 2, 3 719 with 4)")
-    p.add_argument("--batch", type=int, default=4,
+    p.add_argument("--batch", type=int, default=2,
                    help="buckets a device worker takes through the path in lock-step (mlsgpu_hip_worker_process_batch: every "
                         "kernel has a bucket dimension, one set of launches and three host decisions per batch); 1 = bucket by "
                         "bucket (mlsgpu_hip_worker_process)")

@@ -175,6 +175,9 @@ struct HostMailbox
  * array passed by value in the kernel-argument segment (read through the scalar cache, no upload of a parameter block),
  * grid.x covers the largest lane and the workgroups beyond a smaller lane's own extent leave at once.  A single bucket is a
  * batch of one: same kernels, same results.
+ * A kernel COPIES its lane's element (`const Args A = lanes.a[blockIdx.y];`): the fields then live in scalar registers as
+ * those of a by-value parameter do.  Through a reference the compiler re-loads a field wherever it is used under a condition
+ * -- latticeMask, bound by scalar / vector issue, ran 18 % slower with ~100 kernel-argument loads in its loop.
  */
 enum { MAX_LANES = MLSGPU_MAX_BATCH };
 template<typename A>

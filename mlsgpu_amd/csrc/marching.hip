@@ -253,14 +253,14 @@ struct CellCodeArgs
 
 __global__ __launch_bounds__(256) void cellCodeKernel(Lanes<CellCodeArgs> lanes)
 {
-    const CellCodeArgs &A = lanes.a[blockIdx.y];
+    const CellCodeArgs A = lanes.a[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= A.numRows)
         return;
     uint8_t *const codes = A.codes;
     U3 *const rowCounts = A.rowCounts;
-    const FieldView &F = A.F;
+    const FieldView F = A.F;
     const uint32_t cw = A.cw, ch = A.ch, zFirst = A.zFirst;
     const uchar2 *const countTable = A.countTable;
     const uint32_t y = row % ch, z = row / ch + zFirst;
@@ -376,7 +376,7 @@ struct CompactRowCellsArgs
 
 __global__ __launch_bounds__(256) void compactRowCellsKernel(Lanes<CompactRowCellsArgs> lanes)
 {
-    const CompactRowCellsArgs &A = lanes.a[blockIdx.y];
+    const CompactRowCellsArgs A = lanes.a[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= A.numRows)
@@ -722,13 +722,13 @@ struct LatticeMaskArgs
 
 __global__ __launch_bounds__(256) void latticeMaskKernel(Lanes<LatticeMaskArgs> lanes)
 {
-    const LatticeMaskArgs &A = lanes.a[blockIdx.y];
+    const LatticeMaskArgs A = lanes.a[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t cr = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (cr >= A.numCornerRows)
         return;
-    const Lattice &L = A.L;
-    const CodeView &C = A.C;
+    const Lattice L = A.L;            /* a copy: the fields live in scalar registers, not behind kernel-argument loads */
+    const CodeView C = A.C;
     const U3 *const cellRowCounts = A.cellRowCounts;
     const uint32_t zCellFirst = A.zCellFirst, zCellLast = A.zCellLast, H = A.H;
     const uint32_t y = cr % H, z = cr / H + zCellFirst;
@@ -879,11 +879,11 @@ struct LatticePatchArgs
 
 __global__ __launch_bounds__(256) void latticePatchKernel(Lanes<LatticePatchArgs> lanes)
 {
-    const LatticePatchArgs &A = lanes.a[blockIdx.y];
+    const LatticePatchArgs A = lanes.a[blockIdx.y];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.numWords)
         return;
-    const Lattice &L = A.L;
+    const Lattice L = A.L;            /* a copy: the fields live in scalar registers, not behind kernel-argument loads */
     const uint32_t row = i / L.nw;
     const uint32_t z2 = row / L.rowsPerLayer + L.z2First, y2 = row % L.rowsPerLayer;
     const uint32_t rc = L.rowClass(y2, z2);
@@ -915,18 +915,18 @@ struct LatticeVerticesArgs
 
 __global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVerticesArgs> lanes)
 {
-    const LatticeVerticesArgs &A = lanes.a[blockIdx.y];
+    const LatticeVerticesArgs A = lanes.a[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (row >= A.numRows)
         return;
-    const Lattice &L = A.L;
-    const FieldView &F = A.F;
+    const Lattice L = A.L;            /* a copy: the fields live in scalar registers, not behind kernel-argument loads */
+    const FieldView F = A.F;
     float *const outVertices = A.outVertices;
     uint64_t *const outKeys = A.outKeys;
     const uint32_t gox = A.gox, goy = A.goy, goz = A.goz;
     const uint64_t keyOffset = A.keyOffset;
-    const VertexTransform &X = A.X;
+    const VertexTransform X = A.X;
     const uint32_t z2 = row / L.rowsPerLayer + L.z2First, y2 = row % L.rowsPerLayer;
     const uint32_t cz = z2 >> 1, pz = z2 & 1, cy = y2 >> 1, py = y2 & 1;
     const bool rowExternal = L.rowClass(y2, z2) != 0;
@@ -1024,9 +1024,9 @@ __global__ __launch_bounds__(256) void latticeTrianglesKernel(Lanes<LatticeTrian
     __shared__ uint32_t sIdx[256][MAX_CELL_VERTICES];
     __shared__ uint16_t sRef[256 * MAX_CELL_INDICES];   /* thread * 13 + vertex slot: 18 KB instead of 36 KB of indices */
     __shared__ uint32_t sSpan;
-    const LatticeTrianglesArgs &A = lanes.a[blockIdx.y];
-    const Lattice &L = A.L;
-    const DevTables &T = A.T;
+    const LatticeTrianglesArgs A = lanes.a[blockIdx.y];
+    const Lattice L = A.L;            /* a copy: the fields live in scalar registers, not behind kernel-argument loads */
+    const DevTables T = A.T;
     const uint2 *const cells = A.cells, *const viStart = A.viStart;
     uint32_t *const indices = A.indices;
     const uint32_t numCells = A.batchTotals->a;         /* grid covers the host's count; the device value rules */
@@ -1143,10 +1143,10 @@ struct LatticeTrianglesRowArgs
 
 __global__ __launch_bounds__(256) void latticeTrianglesRowKernel(Lanes<LatticeTrianglesRowArgs> lanes)
 {
-    const LatticeTrianglesRowArgs &A = lanes.a[blockIdx.y];
-    const Lattice &L = A.L;
-    const CodeView &C = A.C;
-    const DevTables &T = A.T;
+    const LatticeTrianglesRowArgs A = lanes.a[blockIdx.y];
+    const Lattice L = A.L;            /* a copy: the fields live in scalar registers, not behind kernel-argument loads */
+    const CodeView C = A.C;
+    const DevTables T = A.T;
     const U3 *const rowCounts = A.rowCounts, *const rowStarts = A.rowStarts;
     const uint32_t zFirst = A.zFirst, numRows = A.numRows;
     uint32_t *const indices = A.indices;

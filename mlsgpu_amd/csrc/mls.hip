@@ -263,7 +263,7 @@ __global__ __launch_bounds__(512) void processCornersKernel(Lanes<MlsArgs> lanes
     __shared__ float4 sPosRad[STAGE];
     __shared__ float4 sNormQ[STAGE];
 
-    const MlsArgs &A = lanes.a[blockIdx.y];
+    const MlsArgs A = lanes.a[blockIdx.y];
     if (blockIdx.x >= A.numBlocks)
         return;
     const uint32_t bid = xcdRemap(blockIdx.x, A.numBlocks, A.xcdChunk);
@@ -376,7 +376,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                                                 * of 64 staged splats adds beyond a full window */
     __shared__ uint16_t sList[8][8][64];       /* per wave and cube: byte offsets of the splats that can reach the cube */
 
-    const MlsArgs &A = lanes.a[blockIdx.y];
+    const MlsArgs A = lanes.a[blockIdx.y];
     if (blockIdx.x >= A.numBlocks)
         return;
     const uint32_t bid = xcdRemap(blockIdx.x, A.numBlocks, A.xcdChunk);

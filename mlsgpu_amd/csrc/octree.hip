@@ -239,7 +239,8 @@ struct EntryHistArgs
 
 __global__ __launch_bounds__(ENT_TILE) void entryHistKernel(Lanes<EntryHistArgs> lanes, uint32_t digitBits)
 {
-    const EntryHistArgs &A = lanes.a[blockIdx.y];
+    const EntryHistArgs &A = lanes.a[blockIdx.y];     /* by reference: the level offsets are indexed dynamically and stay
+                                                         * in the kernel-argument segment (a copy would live in scratch) */
     if (blockIdx.x >= A.numTiles)
         return;
     __shared__ uint32_t bins[1 << ENT_BIN_BITS];
@@ -317,7 +318,7 @@ struct EntryScatterArgs
 __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void entryScatterKernel(Lanes<EntryScatterArgs> lanes, uint32_t digitBits)
 {
     enum { BINS = 1 << ENT_BIN_BITS, WAVES = ENT_TILE / 64, MAX_ROUNDS = ENT_CAP / ENT_TILE };
-    const EntryScatterArgs &A = lanes.a[blockIdx.y];
+    const EntryScatterArgs &A = lanes.a[blockIdx.y];  /* by reference, as in entryHistKernel */
     if (blockIdx.x >= A.numTiles)
         return;
     const EntryParams &P = A.P;
@@ -604,7 +605,7 @@ struct WriteStartArgs
 __global__ __launch_bounds__(256) void writeStartKernel(Lanes<WriteStartArgs> lanes, LevelOffsets levelOffsets, int minShift,
                                                         int maxShift, uint32_t numStart)
 {
-    const WriteStartArgs &A = lanes.a[blockIdx.y];
+    const WriteStartArgs A = lanes.a[blockIdx.y];
     int32_t *const start = A.start, *const commands = A.commands;
     const int32_t *const jumpPos = A.jumpPos;
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;

@@ -85,7 +85,7 @@ struct ScanReduceArgs
 template<typename T, typename In>
 __global__ __launch_bounds__(PRIM_BLOCK) void scanReduceKernel(Lanes<ScanReduceArgs<T, In> > lanes)
 {
-    const ScanReduceArgs<T, In> &A = lanes.a[blockIdx.y];
+    const ScanReduceArgs<T, In> A = lanes.a[blockIdx.y];
     if (blockIdx.x >= A.numTiles)
         return;
     uint64_t n = A.n;
@@ -128,7 +128,7 @@ struct ScanTileSumsArgs
 template<typename T>
 __global__ __launch_bounds__(PRIM_BLOCK) void scanTileSumsKernel(Lanes<ScanTileSumsArgs<T> > lanes)
 {
-    const ScanTileSumsArgs<T> &A = lanes.a[blockIdx.y];
+    const ScanTileSumsArgs<T> A = lanes.a[blockIdx.y];
     __shared__ T waveTotals[PRIM_WAVES];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t numTiles = A.numTiles;
@@ -181,7 +181,7 @@ struct ScanApplyArgs
 template<typename T, typename In, typename Out, bool FUSED>
 __global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(Lanes<ScanApplyArgs<T, In, Out> > lanes)
 {
-    const ScanApplyArgs<T, In, Out> &A = lanes.a[blockIdx.y];
+    const ScanApplyArgs<T, In, Out> A = lanes.a[blockIdx.y];
     if (blockIdx.x >= A.numTiles)
         return;
     uint64_t n = A.n;
@@ -421,7 +421,7 @@ enum { KEY_COUNT_SLOTS = 4 };   /* low parts of the key a tile may span and stil
 template<typename K, bool KEY_COUNTS = false>
 __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(Lanes<SortHistArgs<K> > lanes, uint32_t shift, uint32_t digitBits)
 {
-    const SortHistArgs<K> &A = lanes.a[blockIdx.y];
+    const SortHistArgs<K> A = lanes.a[blockIdx.y];
     if (blockIdx.x >= A.numTiles)
         return;
     uint64_t n = A.n;
@@ -443,8 +443,13 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(Lanes<SortHistArgs<
     const uint64_t base = tileFirst + (uint64_t) wave * SORT_WAVE_SPAN + lane;
     const K lowMask = (K) (((K) 1 << shift) - 1);
     uint32_t lowFirst = 0;
+    bool oneLow = false;        /* the whole tile has one low part: the digit bins ARE the key counts (six tiles of seven) */
     if (KEY_COUNTS && tileFirst < n)
+    {
+        const uint64_t tileLast = tileFirst + SORT_TILE - 1 < n ? tileFirst + SORT_TILE - 1 : n - 1;
         lowFirst = (uint32_t) (keys[tileFirst] & lowMask);
+        oneLow = (uint32_t) (keys[tileLast] & lowMask) == lowFirst;      /* sorted by the low part */
+    }
 #pragma unroll 4
     for (int j = 0; j < SORT_ITEMS; j++)
     {
@@ -454,7 +459,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(Lanes<SortHistArgs<
             const K key = keys[i];
             const uint32_t digit = (uint32_t) ((key >> shift) & mask);
             atomicAdd(&bins[digit], 1u);
-            if (KEY_COUNTS)
+            if (KEY_COUNTS && !oneLow)
             {
                 const uint32_t slot = (uint32_t) (key & lowMask) - lowFirst;
                 if (slot < KEY_COUNT_SLOTS)
@@ -469,7 +474,13 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(Lanes<SortHistArgs<
     const uint32_t numTiles = A.numTiles;
     for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
         hist[(uint64_t) d * numTiles + blockIdx.x] = bins[d];
-    if (KEY_COUNTS)
+    if (KEY_COUNTS && oneLow)
+    {
+        for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
+            if (bins[d] != 0)
+                atomicAdd(&A.keyCounts[(d << shift) | lowFirst], bins[d]);
+    }
+    else if (KEY_COUNTS)
         for (uint32_t d = threadIdx.x; d < KEY_COUNT_SLOTS * 256; d += PRIM_BLOCK)
         {
             const uint32_t c = keyBins[d];
@@ -491,7 +502,7 @@ struct SortDigitScanArgs
 template<typename T>    /* T = uint32_t; a template only so that the header can be included by several translation units */
 __global__ __launch_bounds__(PRIM_BLOCK) void sortDigitScanKernel(Lanes<SortDigitScanArgs> lanes)
 {
-    const SortDigitScanArgs &A = lanes.a[blockIdx.y];
+    const SortDigitScanArgs A = lanes.a[blockIdx.y];
     __shared__ T waveTotals[PRIM_WAVES];
     const uint32_t numTiles = A.numTiles;
     T *row = A.hist + (uint64_t) blockIdx.x * numTiles;
@@ -567,7 +578,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
     /* the tile is reordered in two phases through ONE buffer (keys, then values): half the LDS, twice the
      * resident workgroups, which is what this latency-bound kernel needs */
     __shared__ K sTile[SORT_TILE];
-    const SortScatterArgs<K> &A = lanes.a[blockIdx.y];
+    const SortScatterArgs<K> A = lanes.a[blockIdx.y];
     if (blockIdx.x >= A.numTiles)
         return;
     uint64_t n = A.n;
