@@ -107,6 +107,9 @@ def parse_args():
                    help="threads of the host welder (0: the library's default, min(32, hardware threads))")
     p.add_argument("--no-sink", action="store_true", help="skip the device mesh-sink leg (weld / components / prune)")
     p.add_argument("--no-timing", action="store_true", help="do not time individual kernels with HIP events")
+    p.add_argument("--no-cross-check", action="store_true",
+                   help="skip the bucket-by-bucket pass whose digest is held against the batched passes' (profiling runs: every "
+                        "launch of the run is then a batched one)")
     p.add_argument("--headline-only", action="store_true", help="only the timed region and the roofline")
     a = p.parse_args()
     if a.legs == "none":
@@ -1022,25 +1025,28 @@ def main():
     work.copy_from(pristine)
     corners = entries = 0
     check = m.binding.ChecksumCollector(ctx)
-    for b in buckets:
-        w0.process(work, b.first, b.count, b.low, b.num_vertices, collector=check)
-        entries += w0.tree_num_entries()
-        corners += int(np.prod([-(-n // 8) * 8 for n in b.num_vertices]))
+    for g0 in range(0, len(buckets), batch):
+        group = buckets[g0:g0 + batch]
+        run_buckets(w0, ctx, group, check)                  # the path the timed region runs
+        for lane, b in enumerate(group):
+            entries += w0.tree_num_entries(lane)
+            corners += int(np.prod([-(-n // 8) * 8 for n in b.num_vertices]))
     ctx.synchronize()
     listed, tests, hits = (int(x) for x in counters.download(np.uint64))
     w0.set_mls_stats(None)
     after = w0.marching_counters()
     mc = {k: after[k] - before[k] for k in after}
     digest = check.digest()
-    if batch > 1:
-        # ... and the batched path the timed region runs: the same meshes, ship-out by ship-out
-        check_b = m.binding.ChecksumCollector(ctx)
-        run_buckets(w0, ctx, buckets, check_b)
+    if batch > 1 and not args.no_cross_check:
+        # ... and bucket by bucket (mlsgpu_hip_worker_process): the same meshes, ship-out by ship-out
+        check_1 = m.binding.ChecksumCollector(ctx)
+        for b in buckets:
+            fresh(ctx, b)
+            w0.process(work, b.first, b.count, b.low, b.num_vertices, collector=check_1)
         ctx.synchronize()
-        if check_b.digest() != digest:
+        if check_1.digest() != digest:
             raise SystemExit("batched passes (batch %d) produce digest %s, bucket-by-bucket passes %s"
-                             % (batch, check_b.digest(), digest))
-
+                             % (batch, digest, check_1.digest()))
 
     for _ in range(args.warmup):
         step()
@@ -1207,15 +1213,22 @@ def main():
         # MLSGPU_HIP_OCTREE_FUSED=0, so the sort stage proper is one pass
         sort_passes = 2 if os.environ.get("MLSGPU_HIP_OCTREE_FUSED") == "0" else 1
         we_name = "writeEntries (count+scan+write%s)" % (", first sort pass fused" if sort_passes == 1 else "")
-        sort_name = "sortHist+sortScatter (octree entries, %d pass)" % sort_passes
+        # round 4: on the default route the sort's last pass writes the ids straight to their command positions (whole-key
+        # counts ride on its histogram kernel, a scan over the NODES replaces the scan over the entries): per entry the
+        # histogram reads its key (4), the scatter reads key + id (8) and writes the id (4)
+        direct = sort_passes == 1
+        sort_name = ("sortHist(+key counts)+sortScatter (last pass, ids to command positions)" if direct
+                     else "sortHist+sortScatter (octree entries, %d pass)" % sort_passes)
+        scan_name = "scan over the nodes: start / jump slots / command bases" if direct else "countCommands+scan+writeSplatIds"
         nb_splats = int(bucketed_t.shape[0])
+        num_start = 37449 * len(buckets)                   # nodes of the default six-level tree, per bucket
         models = {
             # stat name: (kernel, algorithmic bytes per step)
             "kernel.mls.processCorners.time": ("processCorners", 36 * listed + 4 * corners),
-            "kernel.octree.sort.time": (sort_name, sort_passes * 20 * entries),
+            "kernel.octree.sort.time": (sort_name, 16 * entries if direct else sort_passes * 20 * entries),
             # 16 N read + 16 N written back (1 / r^2) + 8 E' of entries
             "kernel.octree.writeEntries.time": (we_name, 32 * nb_splats + 8 * entries),
-            "kernel.octree.scan.time": ("countCommands+scan+writeSplatIds", 2 * 4 * entries + 8 * entries + 4 * entries),
+            "kernel.octree.scan.time": (scan_name, 20 * num_start if direct else 2 * 4 * entries + 8 * entries + 4 * entries),
             "kernel.marching.generateElements.time": ("latticeTriangles", 4 * T + 16 * O + O),
             "kernel.marching.compactVertices.time": ("latticeVertices", 12 * Vw + 8 * external + 8 * Vw),
             "kernel.marching.countUniqueVertices.time": ("latticeMask", C + 8 * 12 * (corners // 64)),
@@ -1231,7 +1244,7 @@ def main():
         traffic_of = {"processCorners": ["processCorners"], "latticeTriangles": ["latticeTriangles"],
                       "latticeVertices": ["latticeVertices"], "latticeMask": ["latticeMask"],
                       "cellCode+classify": ["cellCode"], we_name: ["writeEntries"],
-                      "countCommands+scan+writeSplatIds": ["writeSplatIds"],
+                      scan_name: ["writeSplatIds"] if not direct else [],
                       sort_name: ["sortHist", "sortScatter"]}
         stages = []
         for stat, (kname, nb) in models.items():
@@ -1376,7 +1389,11 @@ def main():
             from mlsgpu_amd import dist_sink
             t0 = time.perf_counter()
             part = sink.boundary()
+            b_first_s = time.perf_counter() - t0          # the first export of the process: host vectors are mapped on the way
+            t0 = time.perf_counter()
+            part = sink.boundary()
             b_s = time.perf_counter() - t0
+            dist_sink.merge_boundaries([part], 0.02)        # (numpy / scipy warm up)
             t0 = time.perf_counter()
             keep, dstats = dist_sink.merge_boundaries([part], 0.02)
             m_s = time.perf_counter() - t0
@@ -1385,7 +1402,11 @@ def main():
             ctx.synchronize()
             f_s = time.perf_counter() - t0
             result["mesh_sink"]["distributed"] = {
-                "boundary_ms": round(b_s * 1e3, 3), "merge_ms": round(m_s * 1e3, 3), "finalize_with_ms": round(f_s * 1e3, 3),
+                "boundary_ms": round(b_s * 1e3, 3), "boundary_first_call_ms": round(b_first_s * 1e3, 3),
+                "merge_ms": round(m_s * 1e3, 3), "finalize_with_ms": round(f_s * 1e3, 3),
+                "what": "behind a finalize(): the export numbers the roots, counts triangles per component and compacts the "
+                        "distinct keys (the weld and the components are reused); then the merge of the exports and the output "
+                        "pass with the merged verdict",
                 "keys": int(len(part[0])), "components": int(len(part[2])), "export_bytes": int(sum(a.nbytes for a in part)),
                 "same_verdict": dstats["kept_triangles"] == st["kept_triangles"] and dstats["total_vertices"] == st["total_vertices"]}
             sink.close()

@@ -29,6 +29,8 @@ int main(int argc, char **argv)
         return 2;
     }
     const int numWorkers = argc > 4 ? atoi(argv[4]) : 2;
+    /* optional: buckets per work item, which the workers then take through the device path in lock-step (setBatch) */
+    const std::size_t lanes = argc > 5 ? (std::size_t) std::max(1, atoi(argv[5])) : 1;
     std::vector<Splat> splats;
     {
         std::ifstream in(argv[1], std::ios::binary | std::ios::ate);
@@ -83,16 +85,27 @@ int main(int argc, char **argv)
                 totalT += mesh.numTriangles;
             };
         };
-        DeviceWorkerGroup group(numWorkers, 1, outputGenerator, 0, maxSplats, 63, 0, 6, 3, 1.0f, MLS_SHAPE_SPHERE);
+        DeviceWorkerGroup group(numWorkers, 1, outputGenerator, 0, lanes * maxSplats, 63, 0, 6, 3, 1.0f, MLS_SHAPE_SPHERE);
+        group.setBatch((std::uint32_t) lanes);
         const float origin[3] = {0.0f, 0.0f, 0.0f};
         group.start(1.0f, origin);
-        for (std::size_t i = 0; i < buckets.size(); i++)
+        for (std::size_t i = 0; i < buckets.size(); i += lanes)
         {
-            std::shared_ptr<DeviceWorkerGroup::WorkItem> item = group.get(buckets[i].numSplats);
-            DeviceWorkerGroup::SubItem sub = buckets[i];
-            item->splats->write(splats.data() + sub.firstSplat, sub.numSplats, 0, false);
-            sub.firstSplat = 0;
-            item->subItems.push_back(sub);
+            /* a work item of up to `lanes` buckets (CopyGroup batches buckets the same way, src/workers.cpp:377-418) */
+            const std::size_t last = std::min(buckets.size(), i + lanes);
+            std::size_t total = 0;
+            for (std::size_t k = i; k < last; k++)
+                total += buckets[k].numSplats;
+            std::shared_ptr<DeviceWorkerGroup::WorkItem> item = group.get(total);
+            std::size_t at = 0;
+            for (std::size_t k = i; k < last; k++)
+            {
+                DeviceWorkerGroup::SubItem sub = buckets[k];
+                item->splats->write(splats.data() + sub.firstSplat, sub.numSplats, at, false);
+                sub.firstSplat = at;
+                at += sub.numSplats;
+                item->subItems.push_back(sub);
+            }
             group.push(item);
         }
         group.stop();

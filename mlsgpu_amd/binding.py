@@ -1154,9 +1154,9 @@ class Worker:
         names = ["overflows", "shipouts", "nonempty", "occupied", "unwelded", "indices", "welded", "external"]
         return dict(zip(names, [int(x) for x in out]))
 
-    def tree_num_entries(self):
+    def tree_num_entries(self, lane=0):
         n = C.c_uint64()
-        check(lib().mlsgpu_hip_tree_num_entries(lib().mlsgpu_hip_worker_tree(self.h), C.byref(n)))
+        check(lib().mlsgpu_hip_tree_num_entries(lib().mlsgpu_hip_worker_lane_tree(self.h, lane), C.byref(n)))
         return n.value
 
     def tree_arrays(self, lane=0):

@@ -964,9 +964,9 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
     /* the verdict pass right behind an export: weld, components and root numbering are still in the slab */
     const bool sameArenas = m->cacheDims[0] == nv && m->cacheDims[1] == nt && m->cacheDims[2] == ne;
     bool reuseDense = keepRoots != nullptr && !analyzeOnly && m->cacheKind == 1 && sameArenas;
-    /* the weld and the components are in the slab: after an export (for the verdict pass) or after a plain finalize (for an
-     * export) */
-    bool reuse = reuseDense || (analyzeOnly && m->cacheKind == 2 && sameArenas);
+    /* the weld and the components are in the slab: after an export (for the verdict pass, or for another export) or after a
+     * plain finalize (for an export) */
+    bool reuse = reuseDense || (analyzeOnly && m->cacheKind != 0 && sameArenas);
     m->cacheKind = 0;
     m->chunkVStart.assign(nc + 1, 0);
     m->chunkTStart.assign(nc + 1, 0);

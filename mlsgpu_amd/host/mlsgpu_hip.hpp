@@ -387,6 +387,9 @@ public:
         for (std::size_t i = 0; i < numWorkers; i++)
             threads.push_back(std::thread(&DeviceWorkerGroup::run, this));
     }
+    /// Buckets of a work item the workers take through the device path in lock-step (1 .. MLSGPU_MAX_BATCH; default 1 =
+    /// the reference's loop over the SubItems, src/workers.cpp:232-286).  Before start(); the outputs do not change.
+    void setBatch(std::uint32_t lanes) { batch = lanes; }
     bool canGet() { std::lock_guard<std::mutex> l(mutex); return !itemPool.empty(); }
     std::shared_ptr<WorkItem> get(std::size_t numSplats)                    // src/workers.cpp:135-146
     {
@@ -423,6 +426,13 @@ private:
         poolCond.notify_one();
     }
     struct OutputUser { const MeshFilterChain *chain; std::exception_ptr error; };
+    struct BatchUser { std::vector<MeshFilterChain> chains; std::exception_ptr error; };
+    static int batchThunk(void *user, std::uint32_t index, void *stream, const mlsgpu_mesh *mesh)
+    {
+        BatchUser *u = static_cast<BatchUser *>(user);
+        try { u->chains[index](stream, *static_cast<const DeviceKeyMesh *>(mesh)); return 0; }
+        catch (...) { u->error = std::current_exception(); return MLSGPU_ERR_CALLBACK; }
+    }
     static int outputThunk(void *user, void *stream, const mlsgpu_mesh *mesh)
     {
         OutputUser *u = static_cast<OutputUser *>(user);
@@ -437,6 +447,8 @@ private:
             mlsgpu_worker *w = NULL;
             check(mlsgpu_hip_worker_create(ctx.get(), &cfg, &w));
             std::shared_ptr<mlsgpu_worker> guard(w, mlsgpu_hip_worker_destroy);
+            if (batch > 1)
+                check(mlsgpu_hip_worker_set_batch(w, batch));
             for (;;)
             {
                 std::shared_ptr<WorkItem> item;
@@ -448,6 +460,36 @@ private:
                     item = queue.front();
                     queue.pop_front();
                 }
+                if (batch > 1 && item->subItems.size() > 1)
+                {
+                    // the SubItems `batch` at a time through one set of launches (mlsgpu_hip_worker_process_batch)
+                    BatchUser user;
+                    std::vector<mlsgpu_subitem> subs(item->subItems.size());
+                    user.chains.resize(subs.size());
+                    std::size_t splats = 0;
+                    for (std::size_t i = 0; i < subs.size(); i++)
+                    {
+                        const SubItem &sub = item->subItems[i];
+                        user.chains[i].setOutput(outputGenerator(sub.chunkId));
+                        subs[i].firstSplat = sub.firstSplat;
+                        subs[i].numSplats = sub.numSplats;
+                        for (int a = 0; a < 3; a++)
+                        {
+                            subs[i].lowExtent[a] = sub.grid.low[a];
+                            subs[i].numVertices[a] = sub.grid.numVertices[a];
+                        }
+                        subs[i].dSplats = NULL;
+                        splats += sub.numSplats;
+                    }
+                    const int rc = mlsgpu_hip_worker_process_batch(w, item->splats->get(), subs.data(), (std::uint32_t) subs.size(),
+                                                                   &batchThunk, &user);
+                    if (user.error)
+                        std::rethrow_exception(user.error);
+                    check(rc);
+                    std::lock_guard<std::mutex> l(mutex);
+                    unallocated_ += splats;
+                }
+                else
                 for (std::size_t i = 0; i < item->subItems.size(); i++)
                 {
                     const SubItem &sub = item->subItems[i];
@@ -480,6 +522,7 @@ private:
     int device;
     mlsgpu_worker_config cfg;
     std::size_t maxItemSplats, numWorkers;
+    std::uint32_t batch = 1;
     bool stopping;
     std::size_t unallocated_;
     Context itemCtx;
@@ -562,6 +605,8 @@ public:
     ~OOCMesher() { mlsgpu_hip_host_mesher_destroy(h); }
     mlsgpu_host_mesher *get() const { return h; }
     void setPruneThreshold(double t) { check(mlsgpu_hip_host_mesher_set_prune_threshold(h, t)); }
+    /// threads of the welder (0 = default); before the first add
+    void setThreads(std::uint32_t threads) { check(mlsgpu_hip_host_mesher_set_threads(h, threads)); }
     void add(std::uint64_t chunkId, const mlsgpu_host_mesh &mesh) { check(mlsgpu_hip_host_mesher_add(h, chunkId, &mesh)); }
     std::size_t write(const Namer &namer, const std::vector<std::string> &comments = std::vector<std::string>())
     {

@@ -117,3 +117,17 @@ def test_argument_checks(ctx):
         tree.enqueue_build(buf, 0, 101, (8, 8, 8), (0, 0, 0), 3)        # numSplats > maxSplats
     with pytest.raises(m.LengthError):
         tree.enqueue_build(buf, 0, 8, (257, 8, 8), (0, 0, 0), 3)        # size > 2^(levels+sub-1)
+
+
+@pytest.mark.parametrize("levels", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_every_tree_depth(ctx, levels):
+    """Every route of the build: one-digit keys whose only pass is the fused one (levels <= 3: the last pass has nothing left
+    to sort, only the command positions to hand out), two digits (the default: whole-key counts in the last pass's histogram
+    kernel, a scan over the nodes, ids scattered to their command positions), and deeper trees that keep the scan over the
+    entries.  `start` / `commands` equal the oracle's word for word."""
+    from mlsgpu_amd import synth
+    side = min(1 << (levels + 2), 256)
+    cloud = synth.uniform_cloud(30_000, float(side - 1), 0.5, 6.0, seed=1000 + levels)
+    size = (side, side - 5, side - 8) if side > 8 else (side, side, side)
+    commands, start, num_levels, mutated = gpu_build(ctx, cloud, 0, len(cloud), size, (2, 0, 1), 3, levels)
+    compare_with_oracle(commands, start, mutated, cloud, 0, len(cloud), size, (2, 0, 1), 3, levels)

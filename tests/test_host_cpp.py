@@ -28,8 +28,10 @@ def test_host_header_compiles_and_links(tmp_path):
 
 
 @pytest.mark.gpu
-def test_device_worker_group_matches_oracle(tmp_path):
-    """27 buckets through a 2-thread DeviceWorkerGroup from C++; every ship-out equals the oracle's."""
+@pytest.mark.parametrize("lanes", [1, 4])
+def test_device_worker_group_matches_oracle(tmp_path, lanes):
+    """27 buckets through a 2-thread DeviceWorkerGroup from C++; every ship-out equals the oracle's -- one bucket per work
+    item, or four per item taken through the device path in lock-step (DeviceWorkerGroup::setBatch)."""
     import oracle_binding as ob
     from mlsgpu_amd import synth
     exe = build_example(tmp_path)
@@ -40,7 +42,7 @@ def test_device_worker_group_matches_oracle(tmp_path):
         for b in buckets:
             f.write("%d %d %d %d %d %d %d %d\n" % ((b.first, b.count) + tuple(b.low) + tuple(b.num_vertices)))
     out = subprocess.check_output([exe, str(tmp_path / "splats.bin"), str(tmp_path / "buckets.txt"),
-                                   str(tmp_path / "out.bin"), "2"], timeout=300).decode()
+                                   str(tmp_path / "out.bin"), "2", str(lanes)], timeout=300).decode()
     assert out.startswith("buckets 27")
     raw = np.fromfile(str(tmp_path / "out.bin"), np.uint8)
     got = {}

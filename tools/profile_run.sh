@@ -8,8 +8,8 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/profiles_$tag
 mkdir -p "$out"
-cmd="bench.py --headline-only --no-timing --workers 1 --steps 5 --warmup 1"
-one="bench.py --headline-only --no-timing --workers 1 --steps 1 --warmup 0"
+cmd="bench.py --headline-only --no-timing --no-cross-check --workers 1 --steps 5 --warmup 1"
+one="bench.py --headline-only --no-timing --no-cross-check --workers 1 --steps 1 --warmup 0"
 rm -rf /tmp/prof_$tag /tmp/pmc_rd_$tag /tmp/pmc_wr_$tag /tmp/pmc_fetch_$tag
 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o run -- python3 $cmd > "$out/stats_run.log" 2>&1
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d /tmp/pmc_rd_$tag -o run -- python3 $one > "$out/rd_run.log" 2>&1

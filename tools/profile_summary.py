@@ -36,7 +36,7 @@ TRACKED = {
     "sortHist": "sortHistKernel",
     "cellCode": "cellCodeKernel",
     "writeEntries": "entryScatterKernel",
-    "writeSplatIds": "SplatIdsOut",
+    "writeSplatIds": "SplatIdsOut",             # rounds 1-3 and the deep-tree route; gone from the default route in round 4
 }
 
 
