@@ -1387,12 +1387,12 @@ def main():
             # what one rank of a one-process-per-GPU job pays instead of finalize: the boundary export, the merge of all ranks'
             # exports (here: its own) and the output pass with the merged verdict (mlsgpu_amd/dist_sink.py)
             from mlsgpu_amd import dist_sink
-            t0 = time.perf_counter()
-            part = sink.boundary()
-            b_first_s = time.perf_counter() - t0          # the first export of the process: host vectors are mapped on the way
-            t0 = time.perf_counter()
-            part = sink.boundary()
-            b_s = time.perf_counter() - t0
+            b_calls = []
+            for _ in range(3):                             # the first export of a process maps its host vectors on the way
+                t0 = time.perf_counter()
+                part = sink.boundary()
+                b_calls.append(time.perf_counter() - t0)
+            b_s = min(b_calls)
             dist_sink.merge_boundaries([part], 0.02)        # (numpy / scipy warm up)
             t0 = time.perf_counter()
             keep, dstats = dist_sink.merge_boundaries([part], 0.02)
@@ -1402,7 +1402,7 @@ def main():
             ctx.synchronize()
             f_s = time.perf_counter() - t0
             result["mesh_sink"]["distributed"] = {
-                "boundary_ms": round(b_s * 1e3, 3), "boundary_first_call_ms": round(b_first_s * 1e3, 3),
+                "boundary_ms": round(b_s * 1e3, 3), "boundary_calls_ms": [round(x * 1e3, 3) for x in b_calls],
                 "merge_ms": round(m_s * 1e3, 3), "finalize_with_ms": round(f_s * 1e3, 3),
                 "what": "behind a finalize(): the export numbers the roots, counts triangles per component and compacts the "
                         "distinct keys (the weld and the components are reused); then the merge of the exports and the output "

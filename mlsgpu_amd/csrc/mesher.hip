@@ -138,17 +138,16 @@ __device__ __forceinline__ uint32_t findRoot(const uint32_t *parent, uint32_t v)
     return v;
 }
 
-/* findRoot that shortens LONG walks: a start vertex more than UF_SHORTCUT steps from its root is re-parented to the root.
+/* findRoot that shortens LONG walks: a start vertex more than `shortcut` steps from its root is re-parented to the root.
  * Parents only ever point to SMALLER ids and hooks re-parent roots only, so an ancestor stays an ancestor whatever the other
  * workgroups do meanwhile: a stale or lost store costs time, never correctness, and the root of a finished component is its
  * smallest id either way (the result does not depend on the schedule).  Measured: unconditional pointer jumping (a store
  * per step) takes the shells cloud's finalize from 17.4 to 14.3 ms but the noise cloud's from 96.5 to 115.9 (its chains are
  * short already: the stores are pure cost there); the shortcut beyond 1 / 3 / 8 steps: shells 13.3 / 12.8 / 14.1 ms, noise
- * 113.9 / 103.9 / 96.3 against 17.9 and 97.4 without. */
-#ifndef UF_SHORTCUT
-#define UF_SHORTCUT 8
-#endif
-__device__ __forceinline__ uint32_t findRootHalving(uint32_t *parent, uint32_t v)
+ * 113.9 / 103.9 / 96.3 against 17.9 and 97.4 without.
+ * Round 4: the threshold is a launch parameter chosen by the size of the mesh (unionShortcut below): surface-like jobs (tens of
+ * millions of vertices in a handful of sheets: long chains) take 3, the hundreds of millions of vertices of a noise cloud 8. */
+__device__ __forceinline__ uint32_t findRootHalving(uint32_t *parent, uint32_t v, uint32_t shortcut)
 {
     const uint32_t start = v;
     uint32_t steps = 0;
@@ -159,13 +158,14 @@ __device__ __forceinline__ uint32_t findRootHalving(uint32_t *parent, uint32_t v
         p = loadParent(parent, v);
         steps++;
     }
-    if (steps > UF_SHORTCUT)
+    if (steps > shortcut)
         __hip_atomic_store(&parent[start], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return v;
 }
 
 /* union of the endpoints of two edges per triangle (the third is redundant, src/mesher.cpp:231-234) */
-__global__ void unionKernel(const uint32_t *tri, uint64_t nt, const uint32_t *compRep, uint32_t *parent, uint32_t *failed)
+__global__ void unionKernel(const uint32_t *tri, uint64_t nt, const uint32_t *compRep, uint32_t *parent, uint32_t *failed,
+                            uint32_t shortcut)
 {
     const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nt)
@@ -182,8 +182,8 @@ __global__ void unionKernel(const uint32_t *tri, uint64_t nt, const uint32_t *co
                 *failed = 1;
                 break;
             }
-            a = findRootHalving(parent, a);
-            b = findRootHalving(parent, b);
+            a = findRootHalving(parent, a, shortcut);
+            b = findRootHalving(parent, b, shortcut);
             if (a == b)
                 break;
             if (a < b)
@@ -1045,8 +1045,12 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
     HIP_CHECK(hipMemsetAsync(dFailed, 0, 4, ctx->stream));
     if (!reuse)
     {
+        /* measured in round 3 (ms per finalize, shortcut beyond 1 / 3 / 8 steps): shells cloud (17.8 M vertices) 13.3 / 12.8 /
+         * 14.1, noise cloud (378 M) 113.9 / 103.9 / 96.3 */
+        static const int forced = getenv("MLSGPU_HIP_UF_SHORTCUT") ? atoi(getenv("MLSGPU_HIP_UF_SHORTCUT")) : -1;
+        const uint32_t unionShortcut = forced >= 0 ? (uint32_t) forced : (nv < (uint64_t(100) << 20) ? 3u : 8u);
         LAUNCH(ctx, "mesher.components.time", unionKernel, dim3(divUp(nt, 256)), B, (const uint32_t *) m->triangles.ptr, nt,
-               (const uint32_t *) compRep, parent, dFailed);
+               (const uint32_t *) compRep, parent, dFailed, unionShortcut);
         LAUNCH(ctx, "mesher.components.time", compressKernel, dim3(divUp(nv, 256)), B, parent, (const uint32_t *) compRep, nv, root);
         LAUNCH(ctx, "mesher.components.time", componentSizeKernel, dim3(divUp(divUp(nv, 64 * SIZE_SPAN), 4)), B,
                (const uint32_t *) compRep, (const uint32_t *) root, nv, size);

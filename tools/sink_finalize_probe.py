@@ -97,6 +97,9 @@ def sequence():
         keep = np.ones(len(part[2]), np.uint8)
         timed("finalize_with after that", lambda: sink.finalize_with(keep))
         from mlsgpu_amd import dist_sink
+        timed("boundary again (behind a finalize_with: nothing cached)", sink.boundary)
+        timed("boundary a third time (behind a boundary)", sink.boundary)
+        timed("boundary a fourth time", sink.boundary)
         timed("finalize again", sink.finalize)
         part = timed("boundary after finalize", sink.boundary)
         keep2, _ = dist_sink.merge_boundaries([part], 0.02)
