@@ -214,10 +214,10 @@ def sq(dirs, label, out):
     new = not os.path.exists(out)
     with open(out, "a") as f:
         if new:
-            f.write("# rocprofv3 --pmc (passes of <= 8 SQ counters each, no tracing), bench.py --workload cfg2 --headline-only --no-timing "
-                    "--workers 1 --steps 1 --warmup 0 --variant N\n")
-            f.write("# sums over the processCorners launches of the run (one launch of 32768 workgroups per pass over the 256^3 / 5 M-splat "
-                    "bucket); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in quad-cycles (MI355X_MICROARCH.md)\n")
+            f.write("# rocprofv3 --pmc (passes of <= 8 SQ counters each, no tracing) over bench.py --headline-only --no-timing "
+                    "--workers 1 --steps 1 --warmup 0 [workload given in the label; tools/sq_counters*.sh]\n")
+            f.write("# sums over the launches of the named kernel(s) in the run (`launches`); SQ_WAVE_CYCLES / SQ_WAIT_* / "
+                    "SQ_ACTIVE_INST_* are in quad-cycles (MI355X_MICROARCH.md)\n")
             f.write("variant,launches,counter,value\n")
         for c in sorted(rows):
             if isinstance(c, tuple):
