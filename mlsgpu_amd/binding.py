@@ -1011,6 +1011,34 @@ class Marching:
         check(rc)
         return col.batches if isinstance(col, MeshCollector) else col
 
+    @staticmethod
+    def generate_batch(marchings, generators, sizes, key_offsets=None):
+        """Marching::generate for several buckets in lock-step (mlsgpu_hip_marching_generate_batch): marchings[k] takes
+        generators[k] and sizes[k]; returns the ship-outs per bucket (read back), in order."""
+        n = len(marchings)
+        ctx = marchings[0].ctx
+        hs = (C.c_void_p * n)(*[m.h for m in marchings])
+        gens = (Generator * n)()
+        for k, g in enumerate(generators):
+            src = g if isinstance(g, Generator) else g.struct
+            C.memmove(C.byref(gens[k]), C.byref(src), C.sizeof(Generator))
+        sz = np.ascontiguousarray(sizes, np.uint32).reshape(n, 3)
+        ko = np.zeros((n, 3), np.uint32) if key_offsets is None else np.ascontiguousarray(key_offsets, np.uint32).reshape(n, 3)
+        cols = [MeshCollector(ctx) for _ in range(n)]
+
+        def cb(user, index, stream, meshp):
+            return cols[index].cb(user, stream, meshp)
+        fn = BATCH_OUTPUT_FN(cb)
+        rc = lib().mlsgpu_hip_marching_generate_batch(hs, gens, n, fn, None, _p(sz), _p(ko))
+        for c in cols:
+            if c.error is not None:
+                raise c.error
+        for g in generators:
+            if getattr(g, "error", None) is not None:
+                raise g.error
+        check(rc)
+        return [c.batches for c in cols]
+
     def counters(self):
         out = np.zeros(8, np.uint64)
         check(lib().mlsgpu_hip_marching_counters(self.h, _p(out)))

@@ -239,3 +239,35 @@ def test_noise_fields_with_holes(ctx, size, swathe, weld, monkeypatch):
         st, cnt = oracle.stats(), mc.counters()
         for k in ("shipouts", "overflows", "occupied", "unwelded", "indices", "welded", "external"):
             assert st[k] == cnt[k], k
+
+
+@pytest.mark.parametrize("mem_slices", [300, 2])
+def test_generate_batch_with_host_generators(ctx, mem_slices):
+    """mlsgpu_hip_marching_generate_batch with generators that are NOT MlsFunctors (host-filled fields): the three
+    reference cases of TestMarching::testGenerate as ONE batch over three Marching objects -- one set of launches with a
+    bucket dimension, the swathe totals and welded counts of all three read back together -- at different sizes and key
+    offsets.  Every bucket's ship-outs equal the oracle's run for that bucket alone, bit for bit; with two slices' worth of
+    mesh memory the buckets overflow and take the one-bucket path behind the shared launches (same batch structure)."""
+    import mlsgpu_amd as m
+    alignment = (8, 8, 8)
+    names = sorted(GENERATE_CASES)
+    dims = (88, 80, 72)
+    mesh_memory = (dims[0] - 1) * (dims[1] - 1) * 872 * mem_slices
+    marchings = [m.Marching(ctx, dims[0], dims[1], dims[2], 72, mesh_memory, alignment) for _ in names]
+    gens = [m.binding.HostGenerator(ctx, GENERATE_CASES[n][2], alignment) for n in names]
+    sizes = [GENERATE_CASES[n][1] for n in names]
+    offsets = [(3 * k, 100 + k, 7 * k) for k in range(len(names))]
+    got = m.Marching.generate_batch(marchings, gens, sizes, offsets)
+    splits = 0
+    for k, n in enumerate(names):
+        oracle = ob.MarchingOracle(dims[0], dims[1], dims[2], 72, mesh_memory, alignment)
+        exp = oracle.generate(host_generator(GENERATE_CASES[n][2]), sizes[k], offsets[k])
+        assert_batches_equal(got[k], exp)
+        st, cnt = oracle.stats(), marchings[k].counters()
+        for key in ("shipouts", "overflows", "occupied", "unwelded", "indices", "welded", "external"):
+            assert st[key] == cnt[key], (n, key)
+        splits += st["shipouts"] > 1
+    assert (splits > 0) == (mem_slices == 2)
+    # a batch of one is the one-bucket entry point
+    one = m.Marching.generate_batch(marchings[:1], gens[:1], sizes[:1], offsets[:1])
+    assert_batches_equal(one[0], got[0])
