@@ -578,8 +578,39 @@ struct mlsgpu_mesher
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     /* boundary export (mlsgpu_hip_mesher_boundary): valid until the next add */
     bool analyzed = false;
-    std::vector<uint64_t> bKeys, bRootVertices, bRootTriangles;
-    std::vector<uint32_t> bKeyRoot;
+    /* the export's keys and their roots land in PINNED memory (tens of MB: a copy into pageable memory goes through the
+     * runtime's staging buffers and took anything from 5 to 80 ms) */
+    template<typename T>
+    struct PinnedArray
+    {
+        T *p = nullptr;
+        size_t n = 0, cap = 0;
+        ~PinnedArray() { if (p) hipHostFree(p); }
+        int resize(size_t count)
+        {
+            if (count > cap)
+            {
+                if (p) hipHostFree(p);
+                p = nullptr;
+                cap = 0;
+                const size_t want = count + count / 4 + 1024;
+                if (hipHostMalloc((void **) &p, want * sizeof(T)) != hipSuccess)
+                    return setError(MLSGPU_ERR_NOMEM, "mesher: cannot allocate %zu bytes of pinned export buffer", want * sizeof(T));
+                cap = want;
+            }
+            n = count;
+            return MLSGPU_OK;
+        }
+        void clear() { n = 0; }
+        size_t size() const { return n; }
+        bool empty() const { return n == 0; }
+        T *data() { return p; }
+        const T *begin() const { return p; }
+        const T *end() const { return p + n; }
+    };
+    PinnedArray<uint64_t> bKeys;
+    PinnedArray<uint32_t> bKeyRoot;
+    std::vector<uint64_t> bRootVertices, bRootTriangles;
 
     /* kept between finalize calls; grown on demand (or up front by reserve) */
     void *slab = nullptr;
@@ -1113,8 +1144,8 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
                                                ne, 0u, keyTiles, dKeyTotal)));
             HIP_CHECK(hipMemcpyAsync(&keyCount, dKeyTotal, 4, hipMemcpyDeviceToHost, ctx->stream));
             HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            m->bKeys.resize(keyCount);
-            m->bKeyRoot.resize(keyCount);
+            PROPAGATE(m->bKeys.resize(keyCount));
+            PROPAGATE(m->bKeyRoot.resize(keyCount));
             HIP_CHECK(hipMemcpyAsync(m->bKeys.data(), keyOut, (size_t) keyCount * 8, hipMemcpyDeviceToHost, ctx->stream));
             HIP_CHECK(hipMemcpyAsync(m->bKeyRoot.data(), rootOut, (size_t) keyCount * 4, hipMemcpyDeviceToHost, ctx->stream));
         }
