@@ -21,6 +21,7 @@
  *  - host synchronisations per bucket: one per swathe (totals) + one per ship-out (welded sizes).
  */
 #include "common.hpp"
+#include <type_traits>
 #include "primitives.hpp"
 
 #include <algorithm>
@@ -173,7 +174,10 @@ struct DevTables
     const uint8_t *data;     /* [8192] */
     const uint32_t *key;     /* [2432] kx | ky<<8 | kz<<16 */
     const uint32_t *rec;     /* [256][16] per-code record for the lattice weld: words 0-1 = 6-bit keys (kx | ky<<2 | kz<<4) of
-                              * vertices 0..9, word 2 = vertices 10..12, word 3 = nv | ni << 8, words 4..12 = index bytes */
+                              * vertices 0..9, word 2 = vertices 10..12, word 3 = nv | ni << 8, words 4..12 = index bytes,
+                              * word 13 = the index word that is only partly used (0 if ni % 4 == 0), word 14 = the edges
+                              * that carry a vertex (bit e), word 15 = word 3 again (so that words 4..15 are all the
+                              * triangle emission reads) */
 };
 
 struct FieldView
@@ -937,7 +941,7 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVertic
     const float *fieldB = F.field + (uint64_t) rowB * F.pitch;
     const uint32_t px = lane & 1;
     const LatWord *rowWords = L.words + (uint64_t) row * L.nw;
-    constexpr int G = 4;
+    constexpr int G = 8;              /* a row of up to 512 lattice points (255 cells) in one trip: no load behind a store */
     for (uint32_t w0 = 0; w0 < L.nw; w0 += G)
     {
         LatWord wd[G];
@@ -1139,131 +1143,189 @@ struct LatticeTrianglesRowArgs
     uint32_t zFirst;
     uint32_t *indices;
     uint32_t numRows;
+    uint32_t *trash;         /* a word nobody reads: where the stores of a chunk without indices go */
 };
 
+/* Software-pipelined over the chunks of a row: nothing chunk n + 1 needs is requested after chunk n's stores.  Vector loads
+ * and stores retire in order (one counter, vmcnt), so a load issued behind a chunk's stores is usable only when all of them
+ * have reached the L2.  Here the loads of chunk n + 1 (its code records; the code bytes of chunk n + 2) are issued BEFORE the
+ * stores of chunk n, and every chunk issues a number of stores the compiler can count (12, or 16; a chunk with more than 1024
+ * indices drains), so the wait in front of chunk n + 1 is `vmcnt(12)`: chunk n's stores stay in flight.  (A path through the
+ * loop without stores -- an empty chunk skipped, a predicated store -- would make that wait a full one again, which is why
+ * positions past the span store the span's last index once more and an empty chunk stores to a word nobody reads.)  The
+ * lattice words of the row's nine lattice rows are staged once in LDS (dynamic: 4 x 9 x nw x 16 bytes) instead of nine
+ * 16-byte loads per cell; a vertex index is its row's word prefix plus the mask bits below its x2, counted once per row
+ * (not per edge); the references go out four bytes at a time.  Measured on cfg3 (two buckets per launch): 216 -> 195 us,
+ * 3.16 -> 2.90 ms per step (profiles/NOTES_r04.md section 9). */
 __global__ __launch_bounds__(256) void latticeTrianglesRowKernel(Lanes<LatticeTrianglesRowArgs> lanes)
 {
     const LatticeTrianglesRowArgs A = lanes.a[blockIdx.y];
-    const Lattice L = A.L;            /* a copy: the fields live in scalar registers, not behind kernel-argument loads */
+    const Lattice L = A.L;
     const CodeView C = A.C;
     const DevTables T = A.T;
     const U3 *const rowCounts = A.rowCounts, *const rowStarts = A.rowStarts;
     const uint32_t zFirst = A.zFirst, numRows = A.numRows;
-    uint32_t *const indices = A.indices;
+    uint32_t *const indices = A.indices, *const trash = A.trash;
     __shared__ uint32_t sIdx[4][64][MAX_CELL_VERTICES];
-    /* (lane % 16) * 13 + vertex slot: a byte, because the write-out knows which QUARTER of the wave (16 cells) a position
-     * belongs to from three wave-uniform bounds.  5.6 instead of 7.9 KB of LDS per wave: seven workgroups per CU, not five. */
     __shared__ uint8_t sRef[4][64 * MAX_CELL_INDICES];
+    extern __shared__ uint4 sLat[];                 /* [4][9][nw] */
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const uint32_t r = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
     if (r >= numRows)
         return;
-    if (rowCounts[r].a == 0)
-        return;
+    /* everything the row needs that does not depend on another load is requested at once: the row's totals, its first
+     * code bytes and the lattice words (an empty row returns with those requests in flight; the rows route is the dense one) */
     const uint32_t y = r % L.ch, z = r / L.ch + zFirst;
-    uint32_t indexBase = rowStarts[r].c;
     const uint8_t *codeRow = C.codes + ((uint64_t) (z - C.z0) * C.ch + y) * C.cw;
-    const LatWord *rowWords[9];
+    const uint32_t nw = L.nw, cw = L.cw;
+    const uint32_t occupied = rowCounts[r].a;
+    uint32_t indexBase = rowStarts[r].c;
+    uint32_t c0 = lane < cw ? codeRow[lane] : 0u;
+    uint32_t c1 = lane + 64 < cw ? codeRow[lane + 64] : 0u;
+    uint4 *const myLat = sLat + wv * 9 * nw;
     bool rowFlagged[9];
 #pragma unroll
     for (int q = 0; q < 9; q++)
     {
         const uint32_t y2 = 2 * y + (q % 3), z2 = 2 * z + (q / 3);
-        rowWords[q] = L.words + (uint64_t) ((z2 - L.z2First) * L.rowsPerLayer + y2) * L.nw;
         rowFlagged[q] = y2 == 0 || y2 == L.topy || z2 == L.z2First;
     }
+    /* the 9 x nw lattice words, 64 per request: entry e is word e % nw of row e / nw (nw <= 64: the division is a multiply) */
+    const uint32_t entries = 9 * nw, recip = (65536u + nw - 1) / nw;
+    auto latWord = [&](const uint32_t e) -> const uint4 *
+    {
+        const uint32_t q = (e * recip) >> 16, w = e - q * nw;
+        const uint32_t qz = (q * 11u) >> 5, qy = q - 3u * qz;
+        return (const uint4 *) (L.words + (uint64_t) ((2 * z + qz - L.z2First) * L.rowsPerLayer + 2 * y + qy) * nw + w);
+    };
+    const uint32_t e0 = min(lane, entries - 1), e1 = min(lane + 64, entries - 1);
+    const uint4 w0 = *latWord(e0), w1 = *latWord(e1);
+    if (__builtin_amdgcn_readfirstlane(occupied) == 0)
+        return;
+    const uint4 *rec4 = (const uint4 *) T.rec;
+    uint4 n1 = rec4[c0 * 4 + 1], n2 = rec4[c0 * 4 + 2], n3 = rec4[c0 * 4 + 3];
+    myLat[e0] = w0;
+    myLat[e1] = w1;
+    for (uint32_t e = 128 + lane; e < entries; e += 64)
+        myLat[e] = *latWord(e);
     uint32_t (*myIdx)[MAX_CELL_VERTICES] = sIdx[wv];
     uint8_t *myRef = sRef[wv];
-    const uint4 *rec4 = (const uint4 *) T.rec;                 /* a code's record is four aligned 16-byte words */
-    uint32_t nextCode = lane < L.cw ? codeRow[lane] : 0u;
-    for (uint32_t x0 = 0; x0 < L.cw; x0 += 64)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    /* a class-0/1 row's flag word is the same in all of its words (latticePatchKernel) */
+    uint32_t rowFlag[9];
+#pragma unroll
+    for (int q = 0; q < 9; q++)
+        rowFlag[q] = __builtin_amdgcn_readfirstlane(myLat[q * nw].w);
+    __builtin_amdgcn_s_waitcnt(0x0F70);            /* vmcnt(0): the loop is entered with nothing in flight, so that the waits
+                                                    * inside it are the steady state's, not the first chunk's */
+    for (uint32_t x0 = 0; x0 < cw; x0 += 64)
     {
         const uint32_t x = x0 + lane;
-        const uint32_t code = nextCode;
-        nextCode = x + 64 < L.cw ? codeRow[x + 64] : 0u;
-        /* everything this chunk reads from memory is requested here, before the first use: the record (index count in
-         * word 3, index bytes in words 4..12) and the nine lattice words do not depend on one another.  (Requesting them one
-         * chunk ahead, between the previous chunk's LDS writes and its write-out, was measured: no change.) */
-        const uint4 r0 = rec4[code * 4], r1 = rec4[code * 4 + 1], r2 = rec4[code * 4 + 2];
-        const uint32_t r12 = T.rec[code * 16 + 12];
-        const uint32_t xc = min(x, L.cw - 1);
-        const uint32_t wIdx = (2 * xc) >> 6, sh = (2 * xc) & 63;
-        LatWord wd[9];
-#pragma unroll
-        for (int q = 0; q < 9; q++)
-            wd[q] = rowWords[q][wIdx];
-        const uint32_t ni = code != 0 ? r0.w >> 8 : 0u;
+        const uint32_t code = c0;
+        const uint4 r1 = n1, r2 = n2, r3 = n3;
+        /* the next chunk's records and the code bytes of the one after it */
+        c0 = c1;
+        c1 = x + 128 < cw ? codeRow[x + 128] : 0u;
+        n1 = rec4[c0 * 4 + 1];
+        n2 = rec4[c0 * 4 + 2];
+        n3 = rec4[c0 * 4 + 3];
+        const uint32_t ni = r3.w >> 8;             /* code 0 (not occupied, or past the row's end): an all-zero record */
         const uint32_t incl = waveInclusiveScan(ni);
         const uint32_t span = readLane(incl, 63);
-        if (span == 0)
-            continue;
         const uint32_t local = incl - ni;
         if (code != 0)
         {
-            uint64_t below[3];
-            below[0] = (1ull << sh) - 1;
-            below[1] = (2ull << sh) - 1;
-            below[2] = sh == 62 ? ~0ull : (4ull << sh) - 1;
+            const uint32_t wIdx = (2 * x) >> 6, sh = (2 * x) & 63;
+            const uint64_t below0 = (1ull << sh) - 1, below1 = (2ull << sh) - 1;
             const bool atX0 = x == 0, atTop = 2 * x + 2 == L.topx;
-            uint32_t slot = 0;
+            uint32_t base[9], two[9];
+#pragma unroll
+            for (int q = 0; q < 9; q++)
+            {
+                const bool throughCorners = (q % 3) != 1 && (q / 3) != 1;
+                const uint4 wd = myLat[q * nw + wIdx];
+                const uint64_t mask = (uint64_t) wd.x | (uint64_t) wd.y << 32;
+                base[q] = wd.z + (uint32_t) __popcll(mask & (throughCorners ? below1 : below0));
+                two[q] = throughCorners ? 0u : (uint32_t) (mask >> sh) & 3u;
+            }
+            const uint32_t used = r3.z;
+            uint32_t *dst = myIdx[lane];
 #pragma unroll
             for (int e = 0; e < NUM_EDGES; e++)
             {
                 const int a = edgeIndices[e][0], b = edgeIndices[e][1];
                 const int px = (a & 1) + (b & 1), py = ((a >> 1) & 1) + ((b >> 1) & 1), pz = ((a >> 2) & 1) + ((b >> 2) & 1);
                 const int q = py + 3 * pz;
-                if (((code >> a) ^ (code >> b)) & 1u)
+                const bool throughCorners = (q % 3) != 1 && (q / 3) != 1;
+                if (used & (1u << e))
                 {
-                    uint32_t idx = wd[q].prefix + (uint32_t) __popcll(wd[q].mask & below[px]);
+                    uint32_t idx = base[q];
+                    if (!throughCorners && px == 1)
+                        idx += two[q] & 1u;
+                    if (!throughCorners && px == 2)
+                        idx += (uint32_t) __popc(two[q]);
                     if (px == 0 && atX0 && !rowFlagged[q])
-                        idx = wd[q].flag & LAT_FLAG_INDEX;
+                        idx = rowFlag[q] & LAT_FLAG_INDEX;
                     if (px == 2 && atTop && !rowFlagged[q])
-                        idx = (wd[q].flag & LAT_FLAG_INDEX) + (wd[q].flag >> 31);
-                    myIdx[lane][slot++] = idx;
+                        idx = (rowFlag[q] & LAT_FLAG_INDEX) + (rowFlag[q] >> 31);
+                    *dst++ = idx;
                 }
             }
-            const uint32_t first = (lane & 15u) * MAX_CELL_VERTICES;
-            const uint32_t iws[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r12};
+            const uint32_t first4 = (lane & 15u) * (MAX_CELL_VERTICES * 0x01010101u);
+            const uint32_t iws[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
+            uint8_t *const ref = myRef + local;
+            const uint32_t whole = ni >> 2;
 #pragma unroll
             for (uint32_t q = 0; q < 9; q++)
-            {
-                if (4 * q >= ni)
-                    break;
-                const uint32_t iw = iws[q];
-                const uint32_t left = ni - 4 * q;
-                myRef[local + 4 * q] = (uint8_t) (first + (iw & 0xFF));
-                if (left > 1) myRef[local + 4 * q + 1] = (uint8_t) (first + ((iw >> 8) & 0xFF));
-                if (left > 2) myRef[local + 4 * q + 2] = (uint8_t) (first + ((iw >> 16) & 0xFF));
-                if (left > 3) myRef[local + 4 * q + 3] = (uint8_t) (first + (iw >> 24));
-            }
+                if (q < whole)
+                {
+                    const uint32_t v = iws[q] + first4;
+                    __builtin_memcpy(ref + 4 * q, &v, 4);
+                }
+            const uint32_t rest = ni & 3u, tail = r3.y + first4;
+            if (rest > 0) ref[4 * whole] = (uint8_t) tail;
+            if (rest > 1) ref[4 * whole + 1] = (uint8_t) (tail >> 8);
+            if (rest > 2) ref[4 * whole + 2] = (uint8_t) (tail >> 16);
         }
-        /* the wave's LDS operations execute in order: the reads below see the writes above without a barrier */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        /* four positions per lane and trip, so that the two dependent LDS reads of a position overlap the others' */
         const uint32_t *flat = &myIdx[0][0];
         const uint32_t q1 = readLane(incl, 15), q2 = readLane(incl, 31), q3 = readLane(incl, 47);   /* ends of the quarters' spans */
-        for (uint32_t k0 = 0; k0 < span; k0 += 256)
+        /* 256 positions: every lane stores -- a position past the span is the span's last once more (same value, same
+         * address), and a chunk without indices stores to a word nobody reads -- so that the number of stores does not
+         * depend on the data */
+        const uint32_t last = span != 0 ? span - 1 : 0u;
+        uint32_t *const out = span != 0 ? indices + indexBase : trash;
+        auto emitN = [&](const uint32_t k0, auto count)
         {
-            uint32_t ref[4], val[4];
+            constexpr int N = decltype(count)::value;
+            uint32_t k[N], val[N];
 #pragma unroll
-            for (int u = 0; u < 4; u++)
+            for (int u = 0; u < N; u++)
             {
-                const uint32_t k = k0 + 64 * u + lane;
-                const uint32_t quarter = (k >= q1 ? 1u : 0u) + (k >= q2 ? 1u : 0u) + (k >= q3 ? 1u : 0u);
-                ref[u] = k < span ? myRef[k] + quarter * (16 * MAX_CELL_VERTICES) : 0u;
+                k[u] = min(k0 + 64 * u + lane, last);
+                const uint32_t quarter = (k[u] >= q1 ? 1u : 0u) + (k[u] >= q2 ? 1u : 0u) + (k[u] >= q3 ? 1u : 0u);
+                val[u] = myRef[k[u]] + quarter * (16 * MAX_CELL_VERTICES);
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-                val[u] = flat[ref[u]];
+            for (int u = 0; u < N; u++)
+                val[u] = flat[val[u]];
 #pragma unroll
-            for (int u = 0; u < 4; u++)
-            {
-                const uint32_t k = k0 + 64 * u + lane;
-                if (k < span)
-                    indices[indexBase + k] = val[u];
-            }
+            for (int u = 0; u < N; u++)
+                out[k[u]] = val[u];
+        };
+        auto emit = [&](const uint32_t k0) { emitN(k0, std::integral_constant<int, 4>()); };
+        emitN(0, std::integral_constant<int, 12>());
+        if (span > 768)
+            emit(768);
+        if (span > 1024)
+        {
+            for (uint32_t k0 = 1024; k0 < span; k0 += 256)
+                emit(k0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): the count of these stores is not known at compile time */
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1480,7 +1542,7 @@ MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, ui
     alloc((void **) &m->dIndices, is * 4);
     alloc((void **) &m->dWelded, vs * 12);
     alloc((void **) &m->dWeldedKeys, vs * 8);
-    alloc((void **) &m->dReadback, sizeof(Readback));
+    alloc((void **) &m->dReadback, sizeof(Readback) + 64);        /* + the word latticeTrianglesRowKernel's idle stores hit */
     if (rc == MLSGPU_OK && hipHostMalloc((void **) &m->hReadback, sizeof(Readback)) != hipSuccess)
         rc = setError(MLSGPU_ERR_NOMEM, "Marching: cannot allocate pinned readback");
     if (rc == MLSGPU_OK && hipHostMalloc((void **) &m->hHistogram, (uint64_t) maxDepth * 8) != hipSuccess)
@@ -1513,6 +1575,11 @@ MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, ui
         rec[0] = (uint32_t) klo; rec[1] = (uint32_t) (klo >> 32); rec[2] = khi; rec[3] = nv | (ni << 8);
         for (uint32_t i = 0; i < ni; i++)
             rec[4 + i / 4] |= (uint32_t) m->tables.data[si + i] << (8 * (i % 4));
+        rec[13] = (ni & 3u) != 0 ? rec[4 + ni / 4] : 0u;
+        if (nv != 0)
+            for (uint32_t e = 0; e < NUM_EDGES; e++)
+                rec[14] |= (((uint32_t) c >> edgeIndices[e][0] ^ (uint32_t) c >> edgeIndices[e][1]) & 1u) << e;
+        rec[15] = rec[3];
     }
     hipError_t e = hipMemcpy(m->dCount, m->tables.count, 512, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->dCodeRec, codeRec.data(), codeRec.size() * 4, hipMemcpyHostToDevice);
@@ -1780,8 +1847,11 @@ static int shipOutLatticeLanes(ShipLane *lanes, uint32_t count)
             const uint32_t cellsInBatch = lanes[k].m->bufferedCells;
             if (cellRows[k] == 0 || cellsInBatch == 0)
                 continue;
-            const bool cellsRoute = routeEnv != nullptr ? routeEnv[0] != '0'
-                                                        : (uint64_t) cellsInBatch * 2 < (uint64_t) cellRows[k] * Ls[k].cw;
+            /* (the rows kernel stages 9 x nw lattice words per wave in LDS and divides by nw with a 16-bit reciprocal:
+             * a lattice wider than 64 words -- 2047 cells -- takes the cells route whatever its density) */
+            const bool cellsRoute = Ls[k].nw > 64
+                                    || (routeEnv != nullptr ? routeEnv[0] != '0'
+                                                            : (uint64_t) cellsInBatch * 2 < (uint64_t) cellRows[k] * Ls[k].cw);
             if (cellsRoute) byCells[nc++] = k; else byRows[nr++] = k;
         }
         if (nc > 0)
@@ -1814,10 +1884,16 @@ static int shipOutLatticeLanes(ShipLane *lanes, uint32_t count)
                 const uint32_t k = byRows[j < nr ? j : 0];
                 mlsgpu_marching *m = lanes[k].m;
                 A.a[j] = LatticeTrianglesRowArgs{Ls[k], Cs[k], m->devTables(), firstRow[k], (const U3 *) m->dRowStarts,
-                                                 lanes[k].zTop, m->dIndices, j < nr ? cellRows[k] : 0u};
+                                                 lanes[k].zTop, m->dIndices, j < nr ? cellRows[k] : 0u,
+                                                 (uint32_t *) (m->dReadback + 1)};
                 most = std::max(most, A.a[j].numRows);
             }
-            LAUNCH(ctx, "kernel.marching.generateElements.time", latticeTrianglesRowKernel, dim3(divUp(most, 4), nr), dim3(256), A);
+            uint32_t nwMax = 0;
+            for (uint32_t j = 0; j < nr; j++)
+                nwMax = std::max(nwMax, A.a[j].L.nw);
+            /* dynamic LDS: the nine lattice rows of each of the four waves' rows of cells */
+            LAUNCH_LDS(ctx, "kernel.marching.generateElements.time", latticeTrianglesRowKernel, dim3(divUp(most, 4), nr), dim3(256),
+                       4 * 9 * nwMax * 16, A);
         }
     }
     /* the welded counts of every bucket, one publication (classTotals and batchTotals are adjacent) */

@@ -194,7 +194,8 @@ def sq(dirs, label, out):
     rows = {}
     launches = 0
     # MLSGPU_SQ_KERNELS=a,b,c: other kernels (substrings of the name), one block of rows per kernel
-    kernels = [k for k in os.environ.get("MLSGPU_SQ_KERNELS", "processCorners").split(",") if k]
+    spec = os.environ.get("MLSGPU_SQ_KERNELS", "processCorners")
+    kernels = [k for k in spec.split(";" if ";" in spec else ",") if k]      # "a;" = the one substring "a" (it may hold commas)
     for d in dirs:
         db = database(d)
         if db is not None:
