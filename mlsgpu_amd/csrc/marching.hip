@@ -1292,41 +1292,49 @@ __global__ __launch_bounds__(256) void latticeTrianglesRowKernel(Lanes<LatticeTr
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t *flat = &myIdx[0][0];
-        const uint32_t q1 = readLane(incl, 15), q2 = readLane(incl, 31), q3 = readLane(incl, 47);   /* ends of the quarters' spans */
-        /* 256 positions: every lane stores -- a position past the span is the span's last once more (same value, same
-         * address), and a chunk without indices stores to a word nobody reads -- so that the number of stores does not
-         * depend on the data */
-        const uint32_t last = span != 0 ? span - 1 : 0u;
-        uint32_t *const out = span != 0 ? indices + indexBase : trash;
-        auto emitN = [&](const uint32_t k0, auto count)
-        {
-            constexpr int N = decltype(count)::value;
-            uint32_t k[N], val[N];
+        /* The write-out, one QUARTER of the wave (16 cells, whose 16 x 13 slots a reference byte can address) at a time: a
+         * quarter's positions are the interval between two wave-uniform bounds, so a position costs an add, a clamp and the
+         * two LDS reads.  Every lane stores in the three trips every quarter makes (192 positions; 16 cells hold 189 on the
+         * uniform cloud): a position past the quarter's end is its last once more (same value, same address), an empty
+         * quarter stores to a word nobody reads -- so that the number of stores does not depend on the data. */
+        const uint32_t bound[5] = {0u, readLane(incl, 15), readLane(incl, 31), readLane(incl, 47), span};
+        uint32_t *const out = indices + indexBase;
+        bool drain = false;
 #pragma unroll
-            for (int u = 0; u < N; u++)
+        for (int i = 0; i < 4; i++)
+        {
+            const uint32_t lo = bound[i], hi = bound[i + 1];
+            const uint32_t *const slots = &myIdx[16 * i][0];
+            const uint32_t last = hi != lo ? hi - 1 : lo;
+            uint32_t *const dstq = hi != lo ? out : trash - lo;
+            uint32_t k[3], val[3];
+#pragma unroll
+            for (int u = 0; u < 3; u++)
             {
-                k[u] = min(k0 + 64 * u + lane, last);
-                const uint32_t quarter = (k[u] >= q1 ? 1u : 0u) + (k[u] >= q2 ? 1u : 0u) + (k[u] >= q3 ? 1u : 0u);
-                val[u] = myRef[k[u]] + quarter * (16 * MAX_CELL_VERTICES);
+                k[u] = min(lo + 64 * u + lane, last);
+                val[u] = myRef[k[u]];
             }
 #pragma unroll
-            for (int u = 0; u < N; u++)
-                val[u] = flat[val[u]];
+            for (int u = 0; u < 3; u++)
+                val[u] = slots[val[u]];
 #pragma unroll
-            for (int u = 0; u < N; u++)
-                out[k[u]] = val[u];
-        };
-        auto emit = [&](const uint32_t k0) { emitN(k0, std::integral_constant<int, 4>()); };
-        emitN(0, std::integral_constant<int, 12>());
-        if (span > 768)
-            emit(768);
-        if (span > 1024)
-        {
-            for (uint32_t k0 = 1024; k0 < span; k0 += 256)
-                emit(k0);
-            __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): the count of these stores is not known at compile time */
+            for (int u = 0; u < 3; u++)
+                dstq[k[u]] = val[u];
+            if (hi - lo > 192)
+            {
+                const uint32_t k3 = min(lo + 192 + lane, last);
+                dstq[k3] = slots[myRef[k3]];
+            }
+            if (hi - lo > 256)
+            {
+#pragma unroll 1
+                for (uint32_t k0 = lo + 256 + lane; k0 < hi; k0 += 64)
+                    out[k0] = slots[myRef[k0]];
+                drain = true;
+            }
         }
+        if (drain)
+            __builtin_amdgcn_s_waitcnt(0x0F70);    /* vmcnt(0): the count of those stores is not known at compile time */
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         indexBase += span;

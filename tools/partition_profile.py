@@ -13,7 +13,6 @@ leaves = mb.bucket_cloud(ctx, raw, len(cloud), (0., 0., 0.), 1.0, ext, on_bucket
 pmax = max(l["num_splats"] for l in leaves)
 pcells = max(max(l["extents"][2*i+1]-l["extents"][2*i] for i in range(3)) for l in leaves)
 w = m.Worker(ctx, pmax, max_cells=pcells, mesh_memory=4096 << 20)
-w.set_mls_variant(2)
 staged = m.DeviceBuffer(ctx, nbytes=pmax * 32)
 col = m.binding.SizeCollector()
 sizes = {}
