@@ -269,33 +269,55 @@ __global__ __launch_bounds__(256) void cellCodeKernel(Lanes<CellCodeArgs> lanes)
     const uchar2 *const countTable = A.countTable;
     const uint32_t y = row % ch, z = row / ch + zFirst;
     U3 sum{0u, 0u, 0u};
-    for (uint32_t x0 = 0; x0 < cw; x0 += 64)
+    const uint32_t r0 = y + F.zStride * z + (uint32_t) F.zBias, r1 = r0 + F.zStride;
+    const uint32_t rows[4] = {r0, r0 + 1, r1, r1 + 1};
+    /* 256 cells at a time: the corner values of all four chunks are requested before the first code byte is stored (a load
+     * issued behind a store waits for that store: loads and stores retire in order) */
+    for (uint32_t x0 = 0; x0 < cw; x0 += 256)
     {
-        const uint32_t x = x0 + lane;
-        /* corner x of the four corner rows of this cell row; corner x + 1 is the next lane's (lane 63 loads its own) */
-        const uint32_t r0 = y + F.zStride * z + (uint32_t) F.zBias, r1 = r0 + F.zStride;
-        const uint32_t xc = min(x, cw);
-        const float a0 = F.at(xc, r0), a1 = F.at(xc, r0 + 1), a2 = F.at(xc, r1), a3 = F.at(xc, r1 + 1);
-        float b0 = __uint_as_float(waveShiftDown1(__float_as_uint(a0))), b1 = __uint_as_float(waveShiftDown1(__float_as_uint(a1)));
-        float b2 = __uint_as_float(waveShiftDown1(__float_as_uint(a2))), b3 = __uint_as_float(waveShiftDown1(__float_as_uint(a3)));
-        if (lane == 63 && x < cw)
+        /* corner x of the four corner rows of this cell row; corner x + 1 is the next lane's, and lane 63's is lane 0's of the
+         * next chunk (the corner after the fourth chunk is one more load) */
+        float a[5][4];
+#pragma unroll
+        for (int c = 0; c < 4; c++)
         {
-            b0 = F.at(x + 1, r0); b1 = F.at(x + 1, r0 + 1); b2 = F.at(x + 1, r1); b3 = F.at(x + 1, r1 + 1);
+            const uint32_t xc = min(x0 + 64 * c + lane, cw);
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                a[c][k] = F.at(xc, rows[k]);
         }
-        if (x < cw)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            a[4][k] = F.at(min(x0 + 256, cw), rows[k]);
+#pragma unroll
+        for (int c = 0; c < 4; c++)
         {
-            const float iso[8] = {a0, b0, a1, b1, a2, b2, a3, b3};       /* loadIso's order, kernels/marching.cl:95-107 */
-            bool valid;
-            uint32_t code = cellCode(iso, valid);
-            if (!valid || code == 255)
-                code = 0;
-            codes[(uint64_t) row * cw + x] = (uint8_t) code;
-            if (code != 0)
+            if (x0 + 64 * c >= cw)
+                break;
+            const uint32_t x = x0 + 64 * c + lane;
+            float b[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
             {
-                const uchar2 c = countTable[code];
-                sum.a += 1;
-                sum.b += c.x;
-                sum.c += c.y;
+                const uint32_t next = c < 3 ? readLane(__float_as_uint(a[c + 1][k]), 0) : __float_as_uint(a[4][k]);
+                const uint32_t down = waveShiftDown1(__float_as_uint(a[c][k]));
+                b[k] = __uint_as_float(lane == 63 ? next : down);
+            }
+            if (x < cw)
+            {
+                const float iso[8] = {a[c][0], b[0], a[c][1], b[1], a[c][2], b[2], a[c][3], b[3]};   /* loadIso's order, kernels/marching.cl:95-107 */
+                bool valid;
+                uint32_t code = cellCode(iso, valid);
+                if (!valid || code == 255)
+                    code = 0;
+                codes[(uint64_t) row * cw + x] = (uint8_t) code;
+                if (code != 0)
+                {
+                    const uchar2 cnt = countTable[code];
+                    sum.a += 1;
+                    sum.b += cnt.x;
+                    sum.c += cnt.y;
+                }
             }
         }
     }
