@@ -746,8 +746,11 @@ struct LatticeMaskArgs
     uint32_t zCellFirst, zCellLast, H, numCornerRows;
 };
 
-__global__ __launch_bounds__(256) void latticeMaskKernel(Lanes<LatticeMaskArgs> lanes)
+__global__ __launch_bounds__(256) void latticeMaskKernel(Lanes<LatticeMaskArgs> lanes, const uint64_t *edgeLut)
 {
+    __shared__ uint64_t sLut[256];
+    sLut[threadIdx.x] = edgeLut[threadIdx.x];
+    __syncthreads();
     const LatticeMaskArgs A = lanes.a[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t cr = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -806,7 +809,7 @@ __global__ __launch_bounds__(256) void latticeMaskKernel(Lanes<LatticeMaskArgs> 
         }
         return;
     }
-    uint32_t prev[2][2] = {{0, 0}, {0, 0}};
+    uint32_t prevLeft = 0;
     /* the code bytes of the next 64 corners are requested before this chunk's ballots, so the loop is not one
      * memory latency per chunk */
     uint32_t next[2][2];
@@ -817,44 +820,31 @@ __global__ __launch_bounds__(256) void latticeMaskKernel(Lanes<LatticeMaskArgs> 
             next[dy][dz] = (rowOk[dy][dz] && lane < L.cw) ? rowPtr[dy][dz][lane] : 0u;
     for (uint32_t x0 = 0; x0 < W; x0 += 64)
     {
-        uint32_t c[2][2], m[2][2];
+        /* What the cell at (x - ox, y - dy, z - dz) gives the corner's seven points depends on its code byte alone: a table
+         * (makeEdgeLut) holds, per code, the bits of each of the four (dy, dz) as the corner's own cell (ox = 0, bytes 0-3)
+         * and as the cell to its left (ox = 1, bytes 4-7).  The left cell of lane i is lane i - 1's own, so its bits come
+         * with one lane shift; 64 corners further the carry is lane 63's. */
+        uint32_t own = 0, left = 0;
 #pragma unroll
         for (int dy = 0; dy < 2; dy++)
 #pragma unroll
             for (int dz = 0; dz < 2; dz++)
             {
-                c[dy][dz] = next[dy][dz];
+                const uint32_t c = next[dy][dz];
                 const uint32_t xn = x0 + 64 + lane;
                 next[dy][dz] = (rowOk[dy][dz] && xn < L.cw) ? rowPtr[dy][dz][xn] : 0u;
-                const uint32_t up = waveShiftUp1(c[dy][dz]);
-                m[dy][dz] = lane == 0 ? prev[dy][dz] : up;
-                prev[dy][dz] = readLane(c[dy][dz], 63);
+                const uint64_t v = sLut[c];
+                const int r = dy | (dz << 1);
+                own |= ((uint32_t) v >> (8 * r)) & 0xFFu;
+                left |= ((uint32_t) (v >> 32) >> (8 * r)) & 0xFFu;
             }
-        /* edge from the corner = local corner (ox, oy, oz) of cell (x-ox, y-oy, z-oz); a = ox | oy<<1 | oz<<2 */
-        uint32_t ex = 0, ey = 0, ez = 0, exy = 0, exz = 0;
-#pragma unroll
-        for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-            for (int dz = 0; dz < 2; dz++)
-                ex |= edgeBit(c[dy][dz], (dy << 1) | (dz << 2), (dy << 1) | (dz << 2) | 1);
-#pragma unroll
-        for (int dz = 0; dz < 2; dz++)
-        {
-            ey |= edgeBit(c[0][dz], dz << 2, (dz << 2) | 2) | edgeBit(m[0][dz], 1 | (dz << 2), 1 | (dz << 2) | 2);
-            exy |= edgeBit(c[0][dz], dz << 2, (dz << 2) | 3);
-        }
-#pragma unroll
-        for (int dy = 0; dy < 2; dy++)
-        {
-            ez |= edgeBit(c[dy][0], dy << 1, (dy << 1) | 4) | edgeBit(m[dy][0], 1 | (dy << 1), 1 | (dy << 1) | 4);
-            exz |= edgeBit(c[dy][0], dy << 1, (dy << 1) | 5);
-        }
-        const uint32_t eyz = edgeBit(c[0][0], 0, 6) | edgeBit(m[0][0], 1, 7);
-        const uint32_t exyz = edgeBit(c[0][0], 0, 7);
+        const uint32_t up = waveShiftUp1(left);
+        /* bit 0 +x, 1 +xy, 2 +xz, 3 +xyz (odd x2 of rows h = 0..3), 5 +y, 6 +z, 7 +yz (even x2 of rows 1..3) */
+        const uint32_t pk = own | (lane == 0 ? prevLeft : up);
+        prevLeft = readLane(left, 63);
         /* Interleave (even x2 = 2x, odd x2 = 2x+1) by lane permutation instead of bit spreading: lane i of word
          * `half` takes corner 32*half + i/2 and its even (i even) or odd (i odd) point, so one ballot per row and
          * half IS the 64-bit word. */
-        const uint32_t pk = ex | (exy << 1) | (exz << 2) | (exyz << 3) | (ey << 5) | (ez << 6) | (eyz << 7);
         const uint32_t from[2] = {(uint32_t) __shfl(pk, lane >> 1, 64), (uint32_t) __shfl(pk, 32 + (lane >> 1), 64)};
         const uint32_t sel = (lane & 1) ? 0u : 4u;
 #pragma unroll
@@ -1371,6 +1361,31 @@ uint32_t bitsFor(uint32_t maxValue)
     return b;
 }
 
+/* latticeMaskKernel's table.  A corner (x, y, z) owns the lattice points towards +x, +y, +z, +xy, +xz, +yz, +xyz; the point on
+ * an edge exists iff an occupied cell containing the edge sees different signs at its ends.  The cells are the eight around
+ * the corner, (x - ox, y - dy, z - dz), in which the corner is local corner a = ox | dy << 1 | dz << 2.  Byte dy | dz << 1 of an
+ * entry: what the cell gives as the corner's own cell (ox = 0); byte 4 + (dy | dz << 1): as the cell to its left (ox = 1),
+ * which only holds the edges without an x component.  Bits: 0 +x, 1 +xy, 2 +xz, 3 +xyz, 5 +y, 6 +z, 7 +yz. */
+std::vector<uint64_t> makeEdgeLut()
+{
+    std::vector<uint64_t> lut(256, 0);
+    const int dir[7] = {1, 3, 5, 7, 2, 4, 6};          /* the edge's direction as a corner offset: +x, +xy, +xz, +xyz, +y, +z, +yz */
+    const int bit[7] = {0, 1, 2, 3, 5, 6, 7};
+    for (uint32_t code = 1; code < 255; code++)
+        for (int ox = 0; ox < 2; ox++)
+            for (int dy = 0; dy < 2; dy++)
+                for (int dz = 0; dz < 2; dz++)
+                {
+                    const int a = ox | (dy << 1) | (dz << 2);
+                    uint32_t bits = 0;
+                    for (int e = 0; e < 7; e++)
+                        if ((a & dir[e]) == 0)          /* the other end, a + dir, is a corner of the same cell */
+                            bits |= (((code >> a) ^ (code >> (a | dir[e]))) & 1u) << bit[e];
+                    lut[code] |= (uint64_t) bits << (8 * ((dy | (dz << 1)) + 4 * ox));
+                }
+    return lut;
+}
+
 struct Readback
 {
     U3 totals;              /* occupied cells, vertices, indices of the (sub-)swathe */
@@ -1398,6 +1413,7 @@ struct mlsgpu_marching
     uint8_t *dData = nullptr;
     uint32_t *dKey = nullptr;
     uint32_t *dCodeRec = nullptr;
+    uint64_t *dEdgeLut = nullptr;           /* latticeMaskKernel: per code byte, the lattice points a cell gives a corner */
     uint2 *dCells = nullptr, *dViStart = nullptr, *dHistogram = nullptr;
     U3 *dTileSums3 = nullptr;
     float4 *dVertices = nullptr;
@@ -1546,6 +1562,7 @@ MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, ui
     alloc((void **) &m->dData, 8192);
     alloc((void **) &m->dKey, 2432 * 4);
     alloc((void **) &m->dCodeRec, 256 * 16 * 4);
+    alloc((void **) &m->dEdgeLut, 256 * 8);
     alloc((void **) &m->dCells, sc * 8);
     alloc((void **) &m->dViStart, sc * 8);
     alloc((void **) &m->dHistogram, (uint64_t) maxDepth * 8);
@@ -1613,6 +1630,8 @@ MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, ui
     }
     hipError_t e = hipMemcpy(m->dCount, m->tables.count, 512, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->dCodeRec, codeRec.data(), codeRec.size() * 4, hipMemcpyHostToDevice);
+    const std::vector<uint64_t> edgeLut = makeEdgeLut();
+    if (e == hipSuccess) e = hipMemcpy(m->dEdgeLut, edgeLut.data(), edgeLut.size() * 8, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->dStart, m->tables.start, 257 * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->dData, m->tables.data.data(), 8192, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->dKey, packedKey.data(), 2432 * 4, hipMemcpyHostToDevice);
@@ -1630,7 +1649,7 @@ MLSGPU_API void mlsgpu_hip_marching_destroy(mlsgpu_marching *m)
     if (!m)
         return;
     hipSetDevice(m->ctx->device);
-    hipFree(m->dField); hipFree(m->dCount); hipFree(m->dStart); hipFree(m->dData); hipFree(m->dKey); hipFree(m->dCodeRec);
+    hipFree(m->dField); hipFree(m->dCount); hipFree(m->dStart); hipFree(m->dData); hipFree(m->dKey); hipFree(m->dCodeRec); hipFree(m->dEdgeLut);
     hipFree(m->dCells); hipFree(m->dViStart); hipFree(m->dHistogram); hipFree(m->dTileSums3);
     hipFree(m->dVertices); hipFree(m->dKeysA); hipFree(m->dKeysB); hipFree(m->dValsA); hipFree(m->dValsB);
     hipFree(m->dIndices); hipFree(m->dIndexRemap); hipFree(m->dWelded); hipFree(m->dWeldedKeys);
@@ -1816,7 +1835,8 @@ static int shipOutLatticeLanes(ShipLane *lanes, uint32_t count)
                                      lanes[k].sw.height, j < count ? cornerRows[k] : 0u};
             most = std::max(most, A.a[j].numCornerRows);
         }
-        LAUNCH(ctx, "kernel.marching.countUniqueVertices.time", latticeMaskKernel, dim3(divUp(most, 4), count), dim3(256), A);
+        LAUNCH(ctx, "kernel.marching.countUniqueVertices.time", latticeMaskKernel, dim3(divUp(most, 4), count), dim3(256), A,
+               (const uint64_t *) lanes[0].m->dEdgeLut);
     }
     typedef ScanJob<U3, ArrayIn<U3>, ArrayIn<U3>, ArrayOut<U3> > RowJob;
     {
