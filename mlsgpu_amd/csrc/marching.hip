@@ -786,6 +786,13 @@ __global__ __launch_bounds__(256) void latticeMaskKernel(Lanes<LatticeMaskArgs> 
         rowCls[h] = L.rowClass(y2, z2);
         running[h] = nFlag[h] = 0;
     }
+    /* (the first code bytes are requested before the rows' totals are looked at: one latency, not two) */
+    uint32_t next[2][2];
+#pragma unroll
+    for (int dy = 0; dy < 2; dy++)
+#pragma unroll
+        for (int dz = 0; dz < 2; dz++)
+            next[dy][dz] = (rowOk[dy][dz] && lane < L.cw) ? rowPtr[dy][dz][lane] : 0u;
     /* Surface-like data leaves most of a bucket empty: if none of the adjacent cell rows holds an occupied cell (their
      * totals come from cellCodeKernel) the four rows are all zeros, written by 16-byte stores of the first lanes. */
     uint32_t occupied = 0;
@@ -810,14 +817,6 @@ __global__ __launch_bounds__(256) void latticeMaskKernel(Lanes<LatticeMaskArgs> 
         return;
     }
     uint32_t prevLeft = 0;
-    /* the code bytes of the next 64 corners are requested before this chunk's ballots, so the loop is not one
-     * memory latency per chunk */
-    uint32_t next[2][2];
-#pragma unroll
-    for (int dy = 0; dy < 2; dy++)
-#pragma unroll
-        for (int dz = 0; dz < 2; dz++)
-            next[dy][dz] = (rowOk[dy][dz] && lane < L.cw) ? rowPtr[dy][dz][lane] : 0u;
     for (uint32_t x0 = 0; x0 < W; x0 += 64)
     {
         /* What the cell at (x - ox, y - dy, z - dz) gives the corner's seven points depends on its code byte alone: a table
