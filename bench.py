@@ -77,10 +77,13 @@ def parse_args():
     p.add_argument("--farm-workers", type=int, default=4,
                    help="device workers per GPU of the farm legs (host splats in, meshes out): transfers want more in flight "
                         "(shells cloud, 8d region: 2 971 Mvoxels/s with 2, 3 719 with 4)")
-    p.add_argument("--batch", type=int, default=2,
+    p.add_argument("--batch", type=int, default=4,
                    help="buckets a device worker takes through the path in lock-step (mlsgpu_hip_worker_process_batch: every "
                         "kernel has a bucket dimension, one set of launches and three host decisions per batch); 1 = bucket by "
                         "bucket (mlsgpu_hip_worker_process)")
+    p.add_argument("--marching-group", type=int, default=2,
+                   help="of a batch's buckets, how many share one set of processCorners / marching launches (the octree build "
+                        "takes the whole batch); 0 = all (mlsgpu_hip_worker_set_marching_group)")
     p.add_argument("--variant", type=int, default=4, choices=[1, 4],
                    help="MLS kernel: 4 sub-block culling + cube streams (default), 1 the reference's structure")
     p.add_argument("--leg-steps", type=int, default=3, help="passes of every secondary leg")
@@ -947,6 +950,7 @@ def main():
         w.set_mls_variant(args.variant)
         w.set_keep_splats(not mutating[0])
         w.set_batch(batch)
+        w.set_marching_group(max(0, min(args.marching_group, m.binding.MAX_BATCH)))
     pool = ThreadPoolExecutor(nworkers)
     collectors = [m.binding.SizeCollector() for _ in range(nworkers)]
 
@@ -1143,7 +1147,7 @@ def main():
             "bucket_splats_total": int(bucketed_t.shape[0]),
             "mesh_memory_mb": args.mesh_memory_mb,
             "device_workers": nworkers,
-            "batch": batch,
+            "batch": batch, "marching_group": args.marching_group,
             "resident_splats": ("restored by a device-to-device copy before every bucket, inside the timed region (the tree build "
                                 "mutates them, as the reference's does)" if args.restore_splats else
                                 "processed in place: the workers keep them intact (non-mutating tree build, processCorners takes "

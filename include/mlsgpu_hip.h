@@ -300,6 +300,10 @@ typedef struct mlsgpu_subitem
  * owns a tree, a distance field, a lattice and a mesh arena (mlsgpu_hip_worker_resource_usage bytes per lane). */
 int mlsgpu_hip_worker_set_batch(mlsgpu_worker *w, uint32_t lanes);
 uint32_t mlsgpu_hip_worker_batch(const mlsgpu_worker *w);
+/* Buckets per set of processCorners / marching launches inside a group of lanes (0: all lanes; default 2).  The octree
+ * build always spans all lanes.  Results do not depend on it. */
+int mlsgpu_hip_worker_set_marching_group(mlsgpu_worker *w, uint32_t buckets);
+uint32_t mlsgpu_hip_worker_marching_group(const mlsgpu_worker *w);
 /* The loop over the SubItems of a WorkItem (src/workers.cpp:232-286) with the buckets taken `lanes` at a time: per group
  * one set of launches (octree build, processCorners, marching, each with a bucket dimension) and three host decisions.
  * Every bucket's meshes equal mlsgpu_hip_worker_process's bit for bit; `output` receives them bucket by bucket, in order,

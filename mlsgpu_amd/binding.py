@@ -204,6 +204,8 @@ def lib():
     sig("mlsgpu_hip_worker_process", C.c_int, vp, vp, u64, u64, vp, vp, OUTPUT_FN, vp)
     sig("mlsgpu_hip_worker_set_batch", C.c_int, vp, u32)
     sig("mlsgpu_hip_worker_batch", u32, vp)
+    sig("mlsgpu_hip_worker_set_marching_group", C.c_int, vp, u32)
+    sig("mlsgpu_hip_worker_marching_group", u32, vp)
     sig("mlsgpu_hip_worker_process_batch", C.c_int, vp, vp, P(SubItem), u32, BATCH_OUTPUT_FN, vp)
     sig("mlsgpu_hip_worker_lane_tree", vp, vp, u32)
     sig("mlsgpu_hip_worker_lane_marching", vp, vp, u32)
@@ -1135,6 +1137,10 @@ class Worker:
     def set_batch(self, lanes):
         """Room for `lanes` buckets in lock-step (process_batch); every lane owns a tree, a field and a mesh arena."""
         check(lib().mlsgpu_hip_worker_set_batch(self.h, lanes))
+
+    def set_marching_group(self, buckets):
+        """Buckets per set of processCorners / marching launches within the lanes (0: all lanes; default 2)."""
+        check(lib().mlsgpu_hip_worker_set_marching_group(self.h, buckets))
 
     def process_batch(self, splats, items, collector=None):
         """The SubItems of a WorkItem (src/workers.cpp:232-286) through mlsgpu_hip_worker_process_batch: `items` is a list

@@ -406,6 +406,7 @@ struct mlsgpu_worker
     mlsgpu_worker_config cfg;
     std::vector<WorkerLane> lanes;          /* lanes[0] is the worker of the reference */
     bool keepSplats = false;
+    uint32_t marchingGroup = 2;     /* buckets per processCorners / marching launch; 0: all the lanes (see set_marching_group) */
     mlsgpu_output_fn userOutput = nullptr;
     void *userOutputData = nullptr;
     mlsgpu_batch_output_fn batchOutput = nullptr;
@@ -524,6 +525,20 @@ MLSGPU_API int mlsgpu_hip_worker_set_batch(mlsgpu_worker *w, uint32_t lanes)
 
 MLSGPU_API uint32_t mlsgpu_hip_worker_batch(const mlsgpu_worker *w) { return w ? (uint32_t) w->lanes.size() : 0; }
 
+/* How many of the lanes' buckets share one set of processCorners / marching launches (0: all of them).  The octree build
+ * always takes all lanes together: its kernels are mid-sized (tens of microseconds per bucket) and gain from every bucket
+ * added to a launch, while the large kernels behind it lose the Infinity Cache between producer and consumer when more than
+ * two buckets' fields and lattices are in flight (profiles/NOTES_r04.md).  Default 2. */
+MLSGPU_API int mlsgpu_hip_worker_set_marching_group(mlsgpu_worker *w, uint32_t buckets)
+{
+    REQUIRE(w != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(buckets <= MLSGPU_MAX_BATCH, MLSGPU_ERR_LENGTH);
+    w->marchingGroup = buckets;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API uint32_t mlsgpu_hip_worker_marching_group(const mlsgpu_worker *w) { return w ? w->marchingGroup : 0; }
+
 /* MeshFilterChain::operator() with the one ScaleBiasFilter the worker installs
  * (src/workers.cpp:226-230, src/mesh_filter.cpp:45-66): filter, then the user's output functor.
  * (Scale / bias is folded into Marching's vertex emission, mlsgpu_hip_marching_set_vertex_transform.) */
@@ -629,7 +644,16 @@ MLSGPU_API int mlsgpu_hip_worker_process_batch(mlsgpu_worker *w, mlsgpu_splat *d
             PROPAGATE(mlsgpu_hip_mls_set(w->lanes[k].mls, items[base + k].lowExtent, w->lanes[k].tree, w->cfg.subsampling));
             PROPAGATE(mlsgpu_hip_mls_generator(w->lanes[k].mls, &gens[k]));
         }
-        PROPAGATE(mlsgpu_hip_marching_generate_batch(marchings, gens, count, workerBatchOutput, w, sizes, keyOffsets));
+        /* the octree of all `count` buckets in one set of launches, processCorners and marching `marchingGroup` buckets at a
+         * time (mlsgpu_hip_worker_set_marching_group) */
+        const uint32_t sub = w->marchingGroup != 0 ? std::min(w->marchingGroup, count) : count;
+        for (uint32_t k0 = 0; k0 < count; k0 += sub)
+        {
+            const uint32_t n = std::min(sub, count - k0);
+            w->batchBase = base + k0;
+            PROPAGATE(mlsgpu_hip_marching_generate_batch(marchings + k0, gens + k0, n, workerBatchOutput, w, sizes + 3 * k0,
+                                                         keyOffsets + 3 * k0));
+        }
         if (pend >= 0) w->ctx->endTiming(pend);
         for (uint32_t k = 0; k < count; k++)
             mlsgpu_hip_tree_clear_splats(w->lanes[k].tree);

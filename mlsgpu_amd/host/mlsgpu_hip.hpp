@@ -390,6 +390,8 @@ public:
     /// Buckets of a work item the workers take through the device path in lock-step (1 .. MLSGPU_MAX_BATCH; default 1 =
     /// the reference's loop over the SubItems, src/workers.cpp:232-286).  Before start(); the outputs do not change.
     void setBatch(std::uint32_t lanes) { batch = lanes; }
+    /// of a batch's buckets, how many share one set of processCorners / marching launches (0: all; the octree takes the batch)
+    void setMarchingGroup(std::uint32_t buckets) { marchingGroup = buckets; }
     bool canGet() { std::lock_guard<std::mutex> l(mutex); return !itemPool.empty(); }
     std::shared_ptr<WorkItem> get(std::size_t numSplats)                    // src/workers.cpp:135-146
     {
@@ -449,6 +451,7 @@ private:
             std::shared_ptr<mlsgpu_worker> guard(w, mlsgpu_hip_worker_destroy);
             if (batch > 1)
                 check(mlsgpu_hip_worker_set_batch(w, batch));
+            check(mlsgpu_hip_worker_set_marching_group(w, marchingGroup));
             for (;;)
             {
                 std::shared_ptr<WorkItem> item;
@@ -523,6 +526,7 @@ private:
     mlsgpu_worker_config cfg;
     std::size_t maxItemSplats, numWorkers;
     std::uint32_t batch = 1;
+    std::uint32_t marchingGroup = 2;
     bool stopping;
     std::size_t unallocated_;
     Context itemCtx;

@@ -241,11 +241,12 @@ def _oracle_bucket(ref, b, **kw):
     return ob.bucket(ref, b.first, b.count, b.num_vertices, b.low, **args)
 
 
-@pytest.mark.parametrize("variant,lanes", [(4, 4), (4, 8), (1, 3), (4, 2)])
-def test_process_batch_equals_oracle_per_bucket(ctx, variant, lanes):
-    """27 buckets of a shells cloud as ONE call: groups of `lanes` buckets share every launch (octree build,
-    processCorners, marching, each with a bucket dimension).  Every bucket's ship-outs equal the oracle's bit for bit --
-    and therefore mlsgpu_hip_worker_process's -- and the tree of every lane of the last group equals the oracle's."""
+@pytest.mark.parametrize("variant,lanes,group", [(4, 4, 0), (4, 8, 2), (1, 3, 2), (4, 2, 0), (4, 8, 3), (4, 4, 1)])
+def test_process_batch_equals_oracle_per_bucket(ctx, variant, lanes, group):
+    """27 buckets of a shells cloud as ONE call: groups of `lanes` buckets share every launch of the octree build, and
+    `group` of them (0: all) every launch of processCorners and marching (each kernel has a bucket dimension).  Every
+    bucket's ship-outs equal the oracle's bit for bit -- and therefore mlsgpu_hip_worker_process's -- and the tree of every
+    lane of the last group equals the oracle's."""
     import mlsgpu_amd as m
     from mlsgpu_amd import synth
     cloud = synth.shells_cloud(120_000, 95.0, 16.0, 1.5, 2.5, seed=321)
@@ -254,6 +255,7 @@ def test_process_batch_equals_oracle_per_bucket(ctx, variant, lanes):
     w = m.Worker(ctx, max(b.count for b in buckets), max_cells=63)
     w.set_mls_variant(variant)
     w.set_batch(lanes)
+    w.set_marching_group(group)
     buf = m.DeviceBuffer(ctx, array=allb)
     before = w.marching_counters()
     got = w.process_batch(buf, buckets)
