@@ -913,9 +913,13 @@ __global__ __launch_bounds__(256) void latticePatchKernel(Lanes<LatticePatchArgs
     L.words[i].flag = (off2 + rs.c) | x0 | top;
 }
 
-/* One wave per row: positions (interp, kernels/marching.cl:130-138) and external keys of the existing points.
- * The row's words come through the scalar unit; the field values of up to four words are requested before the
- * first is used (the kernel is bound by memory latency, not bytes). */
+/* Positions (interp, kernels/marching.cl:130-138) and external keys of the existing points.  One wave per PAIR of lattice
+ * rows (y2 = 2 cy and 2 cy + 1 of one layer: the two rows whose points hang off the corner row (cy, cz)), lane = x2 within a
+ * word.  The kernel is bound by memory latency times resident waves, not by bytes or instructions, so a wave carries as much
+ * independent work as its registers allow: both rows share the values of the corner row (three field loads per pair of
+ * points instead of four), the lattice words of both rows (8 words of each per trip) arrive with ONE coalesced load -- lanes
+ * 0-31 hold row A's dwords, lanes 32-63 row B's -- and are read out of it lane by lane into scalar registers, and all the
+ * trip's loads are requested before the first point is computed (a trip is 512 points: 255 cells). */
 struct LatticeVerticesArgs
 {
     Lattice L;
@@ -925,15 +929,15 @@ struct LatticeVerticesArgs
     uint32_t gox, goy, goz;
     uint64_t keyOffset;
     VertexTransform X;
-    uint32_t numRows;
+    uint32_t numPairs;       /* layers x ceil(rowsPerLayer / 2) */
 };
 
 __global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVerticesArgs> lanes)
 {
     const LatticeVerticesArgs A = lanes.a[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t row = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (row >= A.numRows)
+    const uint32_t pairId = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (pairId >= A.numPairs)
         return;
     const Lattice L = A.L;            /* a copy: the fields live in scalar registers, not behind kernel-argument loads */
     const FieldView F = A.F;
@@ -942,31 +946,36 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVertic
     const uint32_t gox = A.gox, goy = A.goy, goz = A.goz;
     const uint64_t keyOffset = A.keyOffset;
     const VertexTransform X = A.X;
-    const uint32_t z2 = row / L.rowsPerLayer + L.z2First, y2 = row % L.rowsPerLayer;
-    const uint32_t cz = z2 >> 1, pz = z2 & 1, cy = y2 >> 1, py = y2 & 1;
-    const bool rowExternal = L.rowClass(y2, z2) != 0;
-    const bool rowFlagged = L.rowClass(y2, z2) == 2;
-    const uint32_t rowA = cy + F.zStride * cz + (uint32_t) F.zBias;
-    const uint32_t rowB = (cy + py) + F.zStride * (cz + pz) + (uint32_t) F.zBias;
-    const float *fieldA = F.field + (uint64_t) rowA * F.pitch;
-    const float *fieldB = F.field + (uint64_t) rowB * F.pitch;
+    const uint32_t pairsPerLayer = (L.rowsPerLayer + 1) / 2;
+    const uint32_t layer = pairId / pairsPerLayer, cy = pairId % pairsPerLayer;
+    const uint32_t z2 = layer + L.z2First, cz = z2 >> 1, pz = z2 & 1;
+    const uint32_t y2s[2] = {2 * cy, 2 * cy + 1};
+    const bool hasB = y2s[1] < L.rowsPerLayer;          /* a layer's last row (y2 = top.y) is alone */
+    const uint32_t rowA = layer * L.rowsPerLayer + y2s[0];
+    /* endpoint A of every point of the pair is a corner of the row (cy, cz); endpoint B is A + (px, py, pz) */
+    const float *const field0 = F.field + (uint64_t) (cy + F.zStride * cz + (uint32_t) F.zBias) * F.pitch;
+    const float *const field1[2] = {F.field + (uint64_t) (cy + F.zStride * (cz + pz) + (uint32_t) F.zBias) * F.pitch,
+                                    F.field + (uint64_t) (cy + (hasB ? 1u : 0u) + F.zStride * (cz + pz) + (uint32_t) F.zBias) * F.pitch};
     const uint32_t px = lane & 1;
-    const LatWord *rowWords = L.words + (uint64_t) row * L.nw;
-    constexpr int G = 8;              /* a row of up to 512 lattice points (255 cells) in one trip: no load behind a store */
+    const uint32_t *const wordsA = (const uint32_t *) (L.words + (uint64_t) rowA * L.nw);      /* row B's follow row A's */
+    const uint32_t rowDwords = 4 * L.nw;
+    constexpr int G = 8;
     for (uint32_t w0 = 0; w0 < L.nw; w0 += G)
     {
-        LatWord wd[G];
-        float iso0[G], iso1[G];
+        /* dword (lane % 32) of the trip's eight words of row A (lanes 0-31) and row B (lanes 32-63), clamped into the row */
+        const uint32_t dw = min(4 * w0 + (lane & 31u), rowDwords - 1) + ((lane >> 5) != 0 && hasB ? rowDwords : 0u);
+        const uint32_t latDword = wordsA[dw];
+        float iso0[G], iso1[2][G];
 #pragma unroll
         for (int j = 0; j < G; j++)
         {
-            const uint32_t w = w0 + j < L.nw ? w0 + j : L.nw - 1;
-            wd[j] = rowWords[w];
             /* every lane loads (clamped inside the row), so the loads do not wait on the masks; checking the words for
              * emptiness first was measured: -7 % on surface-like data, +8 % on the noise cloud (exposed latency) */
+            const uint32_t w = min(w0 + j, L.nw - 1);
             const uint32_t cx = min(w * 32 + (lane >> 1), L.cw - px);
-            iso0[j] = fieldA[cx];
-            iso1[j] = fieldB[cx + px];
+            iso0[j] = field0[cx];
+            iso1[0][j] = field1[0][cx + px];
+            iso1[1][j] = field1[1][cx + px];
         }
 #pragma unroll
         for (int j = 0; j < G; j++)
@@ -974,43 +983,52 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVertic
             if (w0 + j >= L.nw)
                 break;
             const uint32_t x2 = (w0 + j) * 64 + lane;
-            uint64_t exists = wd[j].mask;
-            bool column = false;
-            uint32_t idx = wd[j].prefix + (uint32_t) __popcll(exists & ((1ull << lane) - 1));
-            if (!rowFlagged)
-            {
-                /* the row's two class-2 points are not in the mask */
-                if (x2 == 0 && (wd[j].flag & LAT_FLAG_X0))
-                {
-                    column = true;
-                    idx = wd[j].flag & LAT_FLAG_INDEX;
-                }
-                else if (x2 == L.topx && (wd[j].flag & LAT_FLAG_TOP))
-                {
-                    column = true;
-                    idx = (wd[j].flag & LAT_FLAG_INDEX) + (wd[j].flag >> 31);
-                }
-            }
-            if (!(((exists >> lane) & 1) || column))
-                continue;
             const uint32_t cx = x2 >> 1;
-            /* endpoint A = owner corner, B = A + (px,py,pz): A has the lower local corner id in every cell */
-            const float inv = 1.0f / (iso0[j] - iso1[j]);
-            const float t = iso0[j] * inv;
-            float vx = fmaf(t, (float) px, (float) (cx + gox));
-            float vy = fmaf(t, (float) py, (float) (cy + goy));
-            float vz = fmaf(t, (float) pz, (float) (cz + goz));
-            if (X.enabled)
+#pragma unroll
+            for (int r = 0; r < 2; r++)
             {
-                vx = fmaf(vx, X.scale, X.bx);
-                vy = fmaf(vy, X.scale, X.by);
-                vz = fmaf(vz, X.scale, X.bz);
+                if (r == 1 && !hasB)
+                    break;
+                const uint32_t y2 = y2s[r], py = (uint32_t) r;
+                const uint32_t cls = L.rowClass(y2, z2);
+                const uint64_t exists = (uint64_t) readLane(latDword, 32 * r + 4 * j) | (uint64_t) readLane(latDword, 32 * r + 4 * j + 1) << 32;
+                const uint32_t prefix = readLane(latDword, 32 * r + 4 * j + 2), flag = readLane(latDword, 32 * r + 4 * j + 3);
+                bool column = false;
+                uint32_t idx = prefix + (uint32_t) __popcll(exists & ((1ull << lane) - 1));
+                if (cls != 2)
+                {
+                    /* the row's two class-2 points are not in the mask */
+                    if (x2 == 0 && (flag & LAT_FLAG_X0))
+                    {
+                        column = true;
+                        idx = flag & LAT_FLAG_INDEX;
+                    }
+                    else if (x2 == L.topx && (flag & LAT_FLAG_TOP))
+                    {
+                        column = true;
+                        idx = (flag & LAT_FLAG_INDEX) + (flag >> 31);
+                    }
+                }
+                if (!(((exists >> lane) & 1) || column))
+                    continue;
+                /* endpoint A = owner corner, B = A + (px,py,pz): A has the lower local corner id in every cell */
+                const float inv = 1.0f / (iso0[j] - iso1[r][j]);
+                const float t = iso0[j] * inv;
+                float vx = fmaf(t, (float) px, (float) (cx + gox));
+                float vy = fmaf(t, (float) py, (float) (cy + goy));
+                float vz = fmaf(t, (float) pz, (float) (cz + goz));
+                if (X.enabled)
+                {
+                    vx = fmaf(vx, X.scale, X.bx);
+                    vy = fmaf(vy, X.scale, X.by);
+                    vz = fmaf(vz, X.scale, X.bz);
+                }
+                outVertices[3 * (uint64_t) idx + 0] = vx;
+                outVertices[3 * (uint64_t) idx + 1] = vy;
+                outVertices[3 * (uint64_t) idx + 2] = vz;
+                if (cls != 0 || column)
+                    outKeys[idx] = (((uint64_t) z2 << (2 * KEY_AXIS_BITS)) | ((uint64_t) y2 << KEY_AXIS_BITS) | (uint64_t) x2) + keyOffset;
             }
-            outVertices[3 * (uint64_t) idx + 0] = vx;
-            outVertices[3 * (uint64_t) idx + 1] = vy;
-            outVertices[3 * (uint64_t) idx + 2] = vz;
-            if (rowExternal || column)
-                outKeys[idx] = (((uint64_t) z2 << (2 * KEY_AXIS_BITS)) | ((uint64_t) y2 << KEY_AXIS_BITS) | (uint64_t) x2) + keyOffset;
         }
     }
 }
@@ -1867,8 +1885,9 @@ static int shipOutLatticeLanes(ShipLane *lanes, uint32_t count)
             const uint32_t k = lane(j);
             mlsgpu_marching *m = lanes[k].m;
             A.a[j] = LatticeVerticesArgs{Ls[k], m->view(lanes[k].sw), m->dWelded, m->dWeldedKeys, m->keyOffset[0], m->keyOffset[1],
-                                         m->keyOffset[2], keyOffsetL[k], m->transform, j < count ? numRows[k] : 0u};
-            most = std::max(most, A.a[j].numRows);
+                                         m->keyOffset[2], keyOffsetL[k], m->transform,
+                                         j < count ? numRows[k] / Ls[k].rowsPerLayer * ((Ls[k].rowsPerLayer + 1) / 2) : 0u};
+            most = std::max(most, A.a[j].numPairs);
         }
         LAUNCH(ctx, "kernel.marching.compactVertices.time", latticeVerticesKernel, dim3(divUp(most, 4), count), dim3(256), A);
     }
