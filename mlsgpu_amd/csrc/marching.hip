@@ -913,13 +913,14 @@ __global__ __launch_bounds__(256) void latticePatchKernel(Lanes<LatticePatchArgs
     L.words[i].flag = (off2 + rs.c) | x0 | top;
 }
 
-/* Positions (interp, kernels/marching.cl:130-138) and external keys of the existing points.  One wave per PAIR of lattice
- * rows (y2 = 2 cy and 2 cy + 1 of one layer: the two rows whose points hang off the corner row (cy, cz)), lane = x2 within a
- * word.  The kernel is bound by memory latency times resident waves, not by bytes or instructions, so a wave carries as much
- * independent work as its registers allow: both rows share the values of the corner row (three field loads per pair of
- * points instead of four), the lattice words of both rows (8 words of each per trip) arrive with ONE coalesced load -- lanes
- * 0-31 hold row A's dwords, lanes 32-63 row B's -- and are read out of it lane by lane into scalar registers, and all the
- * trip's loads are requested before the first point is computed (a trip is 512 points: 255 cells). */
+/* Positions (interp, kernels/marching.cl:130-138) and external keys of the existing points.  One wave per QUAD of lattice
+ * rows -- (z2, y2) = (2 cz + pz, 2 cy + py): the four rows whose points hang off the corner row (cy, cz) -- lane = x2 within
+ * a word.  The kernel was bound by memory latency times resident waves, not by bytes or instructions, so a wave carries as
+ * much independent work as its registers allow: the four rows share the values of the corner row (five field loads per four
+ * points instead of eight), the lattice words of a layer's two rows (8 words of each per trip) arrive with ONE coalesced load
+ * -- lanes 0-31 hold row 2 cy's dwords, lanes 32-63 row 2 cy + 1's -- and are read out of it lane by lane into scalar
+ * registers, and all of a trip's loads are requested before the first point is computed (a trip is 512 points: 255 cells).
+ * Measured on cfg3, two buckets per launch: one row per wave 144 us, a pair 107, the quad 101 -- 517 MB of traffic at 5.1 TB/s. */
 struct LatticeVerticesArgs
 {
     Lattice L;
@@ -929,15 +930,15 @@ struct LatticeVerticesArgs
     uint32_t gox, goy, goz;
     uint64_t keyOffset;
     VertexTransform X;
-    uint32_t numPairs;       /* layers x ceil(rowsPerLayer / 2) */
+    uint32_t numPairs;       /* quads: ceil(layers / 2) x ceil(rowsPerLayer / 2) */
 };
 
 __global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVerticesArgs> lanes)
 {
     const LatticeVerticesArgs A = lanes.a[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t pairId = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (pairId >= A.numPairs)
+    const uint32_t quadId = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (quadId >= A.numPairs)
         return;
     const Lattice L = A.L;            /* a copy: the fields live in scalar registers, not behind kernel-argument loads */
     const FieldView F = A.F;
@@ -947,25 +948,32 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVertic
     const uint64_t keyOffset = A.keyOffset;
     const VertexTransform X = A.X;
     const uint32_t pairsPerLayer = (L.rowsPerLayer + 1) / 2;
-    const uint32_t layer = pairId / pairsPerLayer, cy = pairId % pairsPerLayer;
-    const uint32_t z2 = layer + L.z2First, cz = z2 >> 1, pz = z2 & 1;
-    const uint32_t y2s[2] = {2 * cy, 2 * cy + 1};
-    const bool hasB = y2s[1] < L.rowsPerLayer;          /* a layer's last row (y2 = top.y) is alone */
-    const uint32_t rowA = layer * L.rowsPerLayer + y2s[0];
-    /* endpoint A of every point of the pair is a corner of the row (cy, cz); endpoint B is A + (px, py, pz) */
-    const float *const field0 = F.field + (uint64_t) (cy + F.zStride * cz + (uint32_t) F.zBias) * F.pitch;
-    const float *const field1[2] = {F.field + (uint64_t) (cy + F.zStride * (cz + pz) + (uint32_t) F.zBias) * F.pitch,
-                                    F.field + (uint64_t) (cy + (hasB ? 1u : 0u) + F.zStride * (cz + pz) + (uint32_t) F.zBias) * F.pitch};
+    const uint32_t layers = L.z2Last - L.z2First + 1;
+    const uint32_t slab = quadId / pairsPerLayer, cy = quadId % pairsPerLayer;      /* slab: the layers z2 = 2 cz and 2 cz + 1 */
+    const uint32_t cz = (L.z2First >> 1) + slab;
+    const bool hasY = 2 * cy + 1 < L.rowsPerLayer;      /* a layer's last row (y2 = top.y) is alone ... */
+    const bool hasZ = 2 * slab + 1 < layers;            /* ... and so is the last layer */
+    /* endpoint A of every point of the quad is a corner of the row (cy, cz); endpoint B is A + (px, py, pz) */
+    const float *fieldB[2][2];
+#pragma unroll
+    for (int pz = 0; pz < 2; pz++)
+#pragma unroll
+        for (int py = 0; py < 2; py++)
+            fieldB[pz][py] = F.field + (uint64_t) (cy + (hasY ? py : 0) + F.zStride * (cz + (hasZ ? pz : 0)) + (uint32_t) F.zBias) * F.pitch;
+    const float *const field0 = fieldB[0][0];
     const uint32_t px = lane & 1;
-    const uint32_t *const wordsA = (const uint32_t *) (L.words + (uint64_t) rowA * L.nw);      /* row B's follow row A's */
     const uint32_t rowDwords = 4 * L.nw;
+    const uint32_t *wordsOf[2];      /* per layer: row y2 = 2 cy's dwords; row 2 cy + 1's follow */
+#pragma unroll
+    for (int pz = 0; pz < 2; pz++)
+        wordsOf[pz] = (const uint32_t *) (L.words + (uint64_t) ((2 * slab + (hasZ ? pz : 0)) * L.rowsPerLayer + 2 * cy) * L.nw);
     constexpr int G = 8;
     for (uint32_t w0 = 0; w0 < L.nw; w0 += G)
     {
-        /* dword (lane % 32) of the trip's eight words of row A (lanes 0-31) and row B (lanes 32-63), clamped into the row */
-        const uint32_t dw = min(4 * w0 + (lane & 31u), rowDwords - 1) + ((lane >> 5) != 0 && hasB ? rowDwords : 0u);
-        const uint32_t latDword = wordsA[dw];
-        float iso0[G], iso1[2][G];
+        /* dword (lane % 32) of the trip's eight words of row y2 = 2 cy (lanes 0-31) and 2 cy + 1 (lanes 32-63), clamped */
+        const uint32_t dw = min(4 * w0 + (lane & 31u), rowDwords - 1) + ((lane >> 5) != 0 && hasY ? rowDwords : 0u);
+        const uint32_t latDword[2] = {wordsOf[0][dw], wordsOf[1][dw]};
+        float iso0[G], iso1[2][2][G];
 #pragma unroll
         for (int j = 0; j < G; j++)
         {
@@ -974,8 +982,11 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVertic
             const uint32_t w = min(w0 + j, L.nw - 1);
             const uint32_t cx = min(w * 32 + (lane >> 1), L.cw - px);
             iso0[j] = field0[cx];
-            iso1[0][j] = field1[0][cx + px];
-            iso1[1][j] = field1[1][cx + px];
+#pragma unroll
+            for (int pz = 0; pz < 2; pz++)
+#pragma unroll
+                for (int py = 0; py < 2; py++)
+                    iso1[pz][py][j] = fieldB[pz][py][cx + px];
         }
 #pragma unroll
         for (int j = 0; j < G; j++)
@@ -985,49 +996,56 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVertic
             const uint32_t x2 = (w0 + j) * 64 + lane;
             const uint32_t cx = x2 >> 1;
 #pragma unroll
-            for (int r = 0; r < 2; r++)
+            for (int pz = 0; pz < 2; pz++)
             {
-                if (r == 1 && !hasB)
+                if (pz == 1 && !hasZ)
                     break;
-                const uint32_t y2 = y2s[r], py = (uint32_t) r;
-                const uint32_t cls = L.rowClass(y2, z2);
-                const uint64_t exists = (uint64_t) readLane(latDword, 32 * r + 4 * j) | (uint64_t) readLane(latDword, 32 * r + 4 * j + 1) << 32;
-                const uint32_t prefix = readLane(latDword, 32 * r + 4 * j + 2), flag = readLane(latDword, 32 * r + 4 * j + 3);
-                bool column = false;
-                uint32_t idx = prefix + (uint32_t) __popcll(exists & ((1ull << lane) - 1));
-                if (cls != 2)
+#pragma unroll
+                for (int py = 0; py < 2; py++)
                 {
-                    /* the row's two class-2 points are not in the mask */
-                    if (x2 == 0 && (flag & LAT_FLAG_X0))
+                    if (py == 1 && !hasY)
+                        break;
+                    const uint32_t y2 = 2 * cy + py, z2 = 2 * cz + pz;
+                    const uint32_t cls = L.rowClass(y2, z2);
+                    const uint32_t at = 32 * py + 4 * j;
+                    const uint64_t exists = (uint64_t) readLane(latDword[pz], at) | (uint64_t) readLane(latDword[pz], at + 1) << 32;
+                    const uint32_t prefix = readLane(latDword[pz], at + 2), flag = readLane(latDword[pz], at + 3);
+                    bool column = false;
+                    uint32_t idx = prefix + (uint32_t) __popcll(exists & ((1ull << lane) - 1));
+                    if (cls != 2)
                     {
-                        column = true;
-                        idx = flag & LAT_FLAG_INDEX;
+                        /* the row's two class-2 points are not in the mask */
+                        if (x2 == 0 && (flag & LAT_FLAG_X0))
+                        {
+                            column = true;
+                            idx = flag & LAT_FLAG_INDEX;
+                        }
+                        else if (x2 == L.topx && (flag & LAT_FLAG_TOP))
+                        {
+                            column = true;
+                            idx = (flag & LAT_FLAG_INDEX) + (flag >> 31);
+                        }
                     }
-                    else if (x2 == L.topx && (flag & LAT_FLAG_TOP))
+                    if (!(((exists >> lane) & 1) || column))
+                        continue;
+                    /* endpoint A = owner corner, B = A + (px,py,pz): A has the lower local corner id in every cell */
+                    const float inv = 1.0f / (iso0[j] - iso1[pz][py][j]);
+                    const float t = iso0[j] * inv;
+                    float vx = fmaf(t, (float) px, (float) (cx + gox));
+                    float vy = fmaf(t, (float) py, (float) (cy + goy));
+                    float vz = fmaf(t, (float) pz, (float) (cz + goz));
+                    if (X.enabled)
                     {
-                        column = true;
-                        idx = (flag & LAT_FLAG_INDEX) + (flag >> 31);
+                        vx = fmaf(vx, X.scale, X.bx);
+                        vy = fmaf(vy, X.scale, X.by);
+                        vz = fmaf(vz, X.scale, X.bz);
                     }
+                    outVertices[3 * (uint64_t) idx + 0] = vx;
+                    outVertices[3 * (uint64_t) idx + 1] = vy;
+                    outVertices[3 * (uint64_t) idx + 2] = vz;
+                    if (cls != 0 || column)
+                        outKeys[idx] = (((uint64_t) z2 << (2 * KEY_AXIS_BITS)) | ((uint64_t) y2 << KEY_AXIS_BITS) | (uint64_t) x2) + keyOffset;
                 }
-                if (!(((exists >> lane) & 1) || column))
-                    continue;
-                /* endpoint A = owner corner, B = A + (px,py,pz): A has the lower local corner id in every cell */
-                const float inv = 1.0f / (iso0[j] - iso1[r][j]);
-                const float t = iso0[j] * inv;
-                float vx = fmaf(t, (float) px, (float) (cx + gox));
-                float vy = fmaf(t, (float) py, (float) (cy + goy));
-                float vz = fmaf(t, (float) pz, (float) (cz + goz));
-                if (X.enabled)
-                {
-                    vx = fmaf(vx, X.scale, X.bx);
-                    vy = fmaf(vy, X.scale, X.by);
-                    vz = fmaf(vz, X.scale, X.bz);
-                }
-                outVertices[3 * (uint64_t) idx + 0] = vx;
-                outVertices[3 * (uint64_t) idx + 1] = vy;
-                outVertices[3 * (uint64_t) idx + 2] = vz;
-                if (cls != 0 || column)
-                    outKeys[idx] = (((uint64_t) z2 << (2 * KEY_AXIS_BITS)) | ((uint64_t) y2 << KEY_AXIS_BITS) | (uint64_t) x2) + keyOffset;
             }
         }
     }
@@ -1886,7 +1904,7 @@ static int shipOutLatticeLanes(ShipLane *lanes, uint32_t count)
             mlsgpu_marching *m = lanes[k].m;
             A.a[j] = LatticeVerticesArgs{Ls[k], m->view(lanes[k].sw), m->dWelded, m->dWeldedKeys, m->keyOffset[0], m->keyOffset[1],
                                          m->keyOffset[2], keyOffsetL[k], m->transform,
-                                         j < count ? numRows[k] / Ls[k].rowsPerLayer * ((Ls[k].rowsPerLayer + 1) / 2) : 0u};
+                                         j < count ? (numRows[k] / Ls[k].rowsPerLayer + 1) / 2 * ((Ls[k].rowsPerLayer + 1) / 2) : 0u};
             most = std::max(most, A.a[j].numPairs);
         }
         LAUNCH(ctx, "kernel.marching.compactVertices.time", latticeVerticesKernel, dim3(divUp(most, 4), count), dim3(256), A);
