@@ -243,9 +243,11 @@ struct CodeView
     }
 };
 
-/* One wave per row of cells (fixed y, z): code bytes plus the row's (occupied, vertices, indices) totals.
- * The row totals feed the swathe totals, the per-slice histogram and, in the lattice weld, each row's first
- * cell / index slot -- a 256x smaller scan than one over cells. */
+/* Code bytes plus each row's (occupied, vertices, indices) totals.  One wave per 2 x 2 group of rows of cells -- rows (y, z),
+ * (y + 1, z), (y, z + 1), (y + 1, z + 1) -- lane = cell x: the four rows need nine rows of corners between them, not
+ * sixteen, and (the kernel is bound by latency times resident waves, as latticeVerticesKernel) a wave has four rows' worth
+ * of independent work behind one round of loads.  The row totals feed the swathe totals, the per-slice histogram and, in the
+ * lattice weld, each row's first cell / index slot -- a 256x smaller scan than one over cells. */
 struct CellCodeArgs
 {
     uint8_t *codes;
@@ -259,73 +261,107 @@ __global__ __launch_bounds__(256) void cellCodeKernel(Lanes<CellCodeArgs> lanes)
 {
     const CellCodeArgs A = lanes.a[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= A.numRows)
+    const uint32_t group = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const uint32_t cw = A.cw, ch = A.ch, zFirst = A.zFirst;
+    const uint32_t slices = ch > 0 ? A.numRows / ch : 0u;
+    const uint32_t groupsY = (ch + 1) / 2, groupsZ = (slices + 1) / 2;
+    if (group >= groupsY * groupsZ)
         return;
     uint8_t *const codes = A.codes;
     U3 *const rowCounts = A.rowCounts;
     const FieldView F = A.F;
-    const uint32_t cw = A.cw, ch = A.ch, zFirst = A.zFirst;
     const uchar2 *const countTable = A.countTable;
-    const uint32_t y = row % ch, z = row / ch + zFirst;
-    U3 sum{0u, 0u, 0u};
-    const uint32_t r0 = y + F.zStride * z + (uint32_t) F.zBias, r1 = r0 + F.zStride;
-    const uint32_t rows[4] = {r0, r0 + 1, r1, r1 + 1};
-    /* 256 cells at a time: the corner values of all four chunks are requested before the first code byte is stored (a load
+    const uint32_t y0 = 2 * (group % groupsY), zs0 = 2 * (group / groupsY);     /* zs: slice within the swathe */
+    const bool hasY = y0 + 1 < ch, hasZ = zs0 + 1 < slices;
+    /* the corner rows (y0 + a, z0 + b), a, b = 0..2, clamped into the rows the group uses */
+    uint32_t corner[3][3];
+#pragma unroll
+    for (int b = 0; b < 3; b++)
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+            corner[b][a] = (y0 + min((uint32_t) a, hasY ? 2u : 1u)) + F.zStride * (zs0 + zFirst + min((uint32_t) b, hasZ ? 2u : 1u))
+                           + (uint32_t) F.zBias;
+    U3 sum[2][2] = {{U3{0u, 0u, 0u}, U3{0u, 0u, 0u}}, {U3{0u, 0u, 0u}, U3{0u, 0u, 0u}}};
+    /* 192 cells at a time: the corner values of the three chunks are requested before the first code byte is stored (a load
      * issued behind a store waits for that store: loads and stores retire in order) */
-    for (uint32_t x0 = 0; x0 < cw; x0 += 256)
+    constexpr int C = 3;
+    for (uint32_t x0 = 0; x0 < cw; x0 += 64 * C)
     {
-        /* corner x of the four corner rows of this cell row; corner x + 1 is the next lane's, and lane 63's is lane 0's of the
-         * next chunk (the corner after the fourth chunk is one more load) */
-        float a[5][4];
+        /* corner x of the nine corner rows; corner x + 1 is the next lane's, and lane 63's is lane 0's of the next chunk (the
+         * corner after the last chunk is one more load) */
+        float v[C + 1][3][3];
 #pragma unroll
-        for (int c = 0; c < 4; c++)
+        for (int c = 0; c <= C; c++)
         {
-            const uint32_t xc = min(x0 + 64 * c + lane, cw);
+            const uint32_t xc = min(x0 + 64 * c + (c < C ? lane : 0u), cw);
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                a[c][k] = F.at(xc, rows[k]);
+            for (int b = 0; b < 3; b++)
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+                    v[c][b][a] = F.at(xc, corner[b][a]);
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-            a[4][k] = F.at(min(x0 + 256, cw), rows[k]);
-#pragma unroll
-        for (int c = 0; c < 4; c++)
+        for (int c = 0; c < C; c++)
         {
             if (x0 + 64 * c >= cw)
                 break;
             const uint32_t x = x0 + 64 * c + lane;
-            float b[4];
+            float n[3][3];      /* the same corners at x + 1 */
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-            {
-                const uint32_t next = c < 3 ? readLane(__float_as_uint(a[c + 1][k]), 0) : __float_as_uint(a[4][k]);
-                const uint32_t down = waveShiftDown1(__float_as_uint(a[c][k]));
-                b[k] = __uint_as_float(lane == 63 ? next : down);
-            }
-            if (x < cw)
-            {
-                const float iso[8] = {a[c][0], b[0], a[c][1], b[1], a[c][2], b[2], a[c][3], b[3]};   /* loadIso's order, kernels/marching.cl:95-107 */
-                bool valid;
-                uint32_t code = cellCode(iso, valid);
-                if (!valid || code == 255)
-                    code = 0;
-                codes[(uint64_t) row * cw + x] = (uint8_t) code;
-                if (code != 0)
+            for (int b = 0; b < 3; b++)
+#pragma unroll
+                for (int a = 0; a < 3; a++)
                 {
-                    const uchar2 cnt = countTable[code];
-                    sum.a += 1;
-                    sum.b += cnt.x;
-                    sum.c += cnt.y;
+                    const uint32_t next = readLane(__float_as_uint(v[c + 1][b][a]), 0);
+                    const uint32_t down = waveShiftDown1(__float_as_uint(v[c][b][a]));
+                    n[b][a] = __uint_as_float(lane == 63 ? next : down);
+                }
+#pragma unroll
+            for (int dz = 0; dz < 2; dz++)
+            {
+                if (dz == 1 && !hasZ)
+                    break;
+#pragma unroll
+                for (int dy = 0; dy < 2; dy++)
+                {
+                    if (dy == 1 && !hasY)
+                        break;
+                    if (x < cw)
+                    {
+                        /* loadIso's order, kernels/marching.cl:95-107 */
+                        const float iso[8] = {v[c][dz][dy], n[dz][dy], v[c][dz][dy + 1], n[dz][dy + 1],
+                                              v[c][dz + 1][dy], n[dz + 1][dy], v[c][dz + 1][dy + 1], n[dz + 1][dy + 1]};
+                        bool valid;
+                        uint32_t code = cellCode(iso, valid);
+                        if (!valid || code == 255)
+                            code = 0;
+                        codes[((uint64_t) (zs0 + dz) * ch + (y0 + dy)) * cw + x] = (uint8_t) code;
+                        if (code != 0)
+                        {
+                            const uchar2 cnt = countTable[code];
+                            sum[dz][dy].a += 1;
+                            sum[dz][dy].b += cnt.x;
+                            sum[dz][dy].c += cnt.y;
+                        }
+                    }
                 }
             }
         }
     }
-    sum.a = waveSum(sum.a);
-    sum.b = waveSum(sum.b);
-    sum.c = waveSum(sum.c);
-    if (lane == 0)
-        rowCounts[row] = sum;
+#pragma unroll
+    for (int dz = 0; dz < 2; dz++)
+#pragma unroll
+        for (int dy = 0; dy < 2; dy++)
+        {
+            if ((dz == 1 && !hasZ) || (dy == 1 && !hasY))
+                continue;
+            U3 t = sum[dz][dy];
+            t.a = waveSum(t.a);
+            t.b = waveSum(t.b);
+            t.c = waveSum(t.c);
+            if (lane == 0)
+                rowCounts[(uint64_t) (zs0 + dz) * ch + (y0 + dy)] = t;
+        }
 }
 
 /* ... step 2: the producer of the compaction scan */
@@ -1781,7 +1817,14 @@ static int computeCodesLanes(mlsgpu_marching *const *ms, const mlsgpu_swathe *sw
             L.a[k] = L.a[0];
     }
     if (maxRows > 0)
-        LAUNCH(ctx, "kernel.marching.genOccupied.time", cellCodeKernel, dim3(divUp(maxRows, 4), count), dim3(256), L);
+    {
+        /* a wave per 2 x 2 group of rows: the grid covers the lane with the most groups */
+        uint32_t maxGroups = 0;
+        for (uint32_t k = 0; k < count; k++)
+            if (L.a[k].ch > 0)
+                maxGroups = std::max(maxGroups, (L.a[k].ch + 1) / 2 * ((L.a[k].numRows / L.a[k].ch + 1) / 2));
+        LAUNCH(ctx, "kernel.marching.genOccupied.time", cellCodeKernel, dim3(divUp(maxGroups, 4), count), dim3(256), L);
+    }
     return MLSGPU_OK;
 }
 
