@@ -1325,10 +1325,16 @@ def main():
             result["roofline"]["hbm_stages"] = stages
             result["roofline"]["traffic_source"] = ("profiles/traffic.json: rocprofv3 --pmc passes of this commit's kernels, "
                                                     "corrected as MI355X_MICROARCH.md prescribes (tools/profile_summary.py)")
-        if tj and "roofline" in result:
-            per_bucket = {"processCorners": 1, "latticeTriangles": 1, "latticeVertices": 1, "latticeMask": 1, "cellCode": 1,
-                          "writeEntries": 1, "writeSplatIds": 1, "sortScatter": sort_passes, "sortHist": sort_passes}
-            moved = sum(tj[k] * n * len(buckets) for k, n in per_bucket.items() if k in tj)
+        tpp = {}
+        if tj:
+            try:
+                tpp = json.load(open(tpath)).get("%s/%s/per_pass" % (W["name"], args.dist), {})
+            except Exception:
+                tpp = {}
+        if tpp and "roofline" in result:
+            # bytes of all of a kernel's launches over one pass of the workload (the profile's own batching: a launch covers
+            # several buckets), so this holds for the full-size workload the profile was taken on
+            moved = sum(tpp.values()) if args.scale == 1.0 else 0
             result["roofline"]["pipeline_hbm"] = {
                 "traffic_bytes_per_step": int(moved), "achieved_GBps": round(moved / (ms_per_step * 1e-3) / 1e9, 1),
                 "peak_GBps": HBM_PEAK_GBS, "frac": round(moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

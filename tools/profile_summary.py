@@ -27,6 +27,8 @@ from collections import defaultdict
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # kernels of the bench's per-stage table -> substring of the demangled kernel name
+PMC_PASSES = 2      # tools/profile_run.sh's counter passes run `--steps 1 --warmup 0`: the counting pass and one timed pass
+PMC_PASSES_OF = {"processCorners": 1}       # ... and the counting pass runs the instrumented processCorners (<0, true>), not the tracked one
 TRACKED = {
     "processCorners": "processCornersCubeKernel<0, false>",
     "latticeTriangles": "latticeTriangles",      # by rows (noise cloud) or by cells (surface-like data)
@@ -124,6 +126,10 @@ def traffic(fetch_dir, write_dir, out):
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     doc = json.load(open(tpath)) if os.path.exists(tpath) else {}
     doc["cfg3/uniform"] = per_launch
+    doc["cfg3/uniform/per_pass"] = per_pass
+    doc["_note_per_pass"] = ("bytes of all the kernel's launches in one pass over the workload's buckets (a launch covers the "
+                             "buckets of a batch -- two for processCorners and the marching kernels, four for the octree's, by "
+                             "default): the profiled command runs %d passes" % PMC_PASSES)
     doc["_note"] = ("HBM bytes per launch = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 fetch correction), from "
                     + os.path.relpath(out, ROOT))
     json.dump(doc, open(tpath, "w"), indent=1)
@@ -168,7 +174,7 @@ def traffic_resolved(rd_dir, wr_dir, out):
             f.write('"%s",%d,%.0f,%.0f,%.0f,%.0f,%s,%.0f,%.0f,%.3f,%.0f,%.0f,%.0f\n'
                     % (k, n, r, r32, r64, r128, "yes" if abs(r - r32 - r64 - r128) <= 1e-6 * max(r, 1) else "no", fetch / n,
                        formula / n, fetch / formula if formula else 0.0, w, w64, write / n))
-    per_launch, factors = {}, {}
+    per_launch, per_pass, factors = {}, {}, {}
     for label, needle in TRACKED.items():
         fk = [k for k in names if needle in k]
         if not fk:
@@ -176,11 +182,16 @@ def traffic_resolved(rd_dir, wr_dir, out):
         n = sum(max(calls.get(k, 0), wcalls.get(k, 0)) for k in fk)
         rows = [row(k) for k in fk]
         per_launch[label] = int((sum(x[6] for x in rows) + sum(x[8] for x in rows)) / max(n, 1))
+        per_pass[label] = int((sum(x[6] for x in rows) + sum(x[8] for x in rows)) / PMC_PASSES_OF.get(label, PMC_PASSES))
         factors[label] = round(sum(x[6] for x in rows) / max(sum(x[7] for x in rows), 1), 3)
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     doc = json.load(open(tpath)) if os.path.exists(tpath) else {}
     doc["cfg3/uniform"] = per_launch
+    doc["cfg3/uniform/per_pass"] = per_pass
     doc["_fetch_correction_per_kernel"] = factors
+    doc["_note_per_pass"] = ("bytes of all the kernel's launches in one pass over the workload's buckets (a launch covers the "
+                             "buckets of a batch -- two for processCorners and the marching kernels, four for the octree's, by "
+                             "default): the profiled command runs %d passes" % PMC_PASSES)
     doc["_note"] = ("HBM bytes per launch = 32*RDREQ_32B + 64*RDREQ_64B + 128*RDREQ_128B + 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B), every "
                     "request at its own width, from " + os.path.relpath(out, ROOT) + ".  _fetch_correction_per_kernel is what a "
                     "FETCH_SIZE reading of that kernel would have to be multiplied by (2.0 = all reads are 128-byte requests, the "
