@@ -450,13 +450,21 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(Lanes<SortHistArgs<
         lowFirst = (uint32_t) (keys[tileFirst] & lowMask);
         oneLow = (uint32_t) (keys[tileLast] & lowMask) == lowFirst;      /* sorted by the low part */
     }
-#pragma unroll 4
+    /* all of the thread's keys are requested before the first is counted (one round of memory latency, not four) */
+    K mine[SORT_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j++)
+    {
+        const uint64_t i = base + (uint64_t) j * 64;
+        mine[j] = i < n ? keys[i] : (K) 0;
+    }
+#pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++)
     {
         uint64_t i = base + (uint64_t) j * 64;
         if (i < n)
         {
-            const K key = keys[i];
+            const K key = mine[j];
             const uint32_t digit = (uint32_t) ((key >> shift) & mask);
             atomicAdd(&bins[digit], 1u);
             if (KEY_COUNTS && !oneLow)
@@ -606,25 +614,45 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
     }
     __syncthreads();
     const uint64_t base = tileFirst + (uint64_t) wave * SORT_WAVE_SPAN + lane;
+    /* Everything the workgroup reads that does not depend on another read is requested here, together: its keys, their
+     * values, and the digit totals and tile offsets of the bins this thread will own in the scan below.  (The kernel waits
+     * four fifths of its time: one round of memory latency instead of three.) */
+    enum { MAX_PER = BINS > PRIM_BLOCK ? BINS / PRIM_BLOCK : 1 };
+    const uint32_t per = numBins > PRIM_BLOCK ? numBins / PRIM_BLOCK : 1;
+    const uint32_t d0 = threadIdx.x * per;
     K keys[SORT_ITEMS];
+    uint32_t vals[SORT_ITEMS];
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++)
     {
-        uint64_t i = base + (uint64_t) j * 64;
+        const uint64_t i = base + (uint64_t) j * 64;
         keys[j] = i < n ? keysIn[i] : (K) 0;
+        vals[j] = IOTA ? (uint32_t) i : (i < n ? valsIn[i] : 0u);
+    }
+    uint32_t totalOf[MAX_PER], histOf[MAX_PER];
+#pragma unroll
+    for (int k = 0; k < MAX_PER; k++)
+    {
+        const bool mineToo = (uint32_t) k < per && d0 + k < numBins;
+        totalOf[k] = mineToo ? digitTotals[d0 + k] : 0u;
+        histOf[k] = mineToo ? hist[(uint64_t) (d0 + k) * numTiles + blockIdx.x] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < SORT_ITEMS; j++)
+    {
+        const uint64_t i = base + (uint64_t) j * 64;
         if (i < n)
             atomicAdd(&waveBins[wave][(uint32_t) ((keys[j] >> shift) & mask)], 1u);
     }
     __syncthreads();
     /* tile-local exclusive prefix over the digits: thread t owns the `per` consecutive bins from t * per */
     {
-        const uint32_t per = numBins > PRIM_BLOCK ? numBins / PRIM_BLOCK : 1;
-        const uint32_t d0 = threadIdx.x * per;
         uint32_t mine = 0, mineAll = 0;         /* this tile's / the whole input's keys in my bins */
-        if (d0 < numBins)
-            for (uint32_t k = 0; k < per; k++)
+#pragma unroll
+        for (int k = 0; k < MAX_PER; k++)
+            if ((uint32_t) k < per && d0 + k < numBins)
             {
-                mineAll += digitTotals[d0 + k];
+                mineAll += totalOf[k];
 #pragma unroll
                 for (int w = 0; w < PRIM_WAVES; w++)
                     mine += waveBins[w][d0 + k];
@@ -642,12 +670,13 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
             run += waveTotals[w];
             base += waveTotalsAll[w];
         }
-        if (d0 < numBins)
-            for (uint32_t k = 0; k < per; k++)
+#pragma unroll
+        for (int k = 0; k < MAX_PER; k++)
+            if ((uint32_t) k < per && d0 + k < numBins)
             {
                 const uint32_t d = d0 + k;
-                tileBase[d] = base + hist[(uint64_t) d * numTiles + blockIdx.x] - run;
-                base += digitTotals[d];
+                tileBase[d] = base + histOf[k] - run;
+                base += totalOf[k];
 #pragma unroll
                 for (int w = 0; w < PRIM_WAVES; w++)
                 {
@@ -711,7 +740,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
     {
         const uint64_t i = base + (uint64_t) j * 64;
         if (i < n)
-            sVals[dst[j]] = IOTA ? (uint32_t) i : valsIn[i];
+            sVals[dst[j]] = vals[j];
     }
     __syncthreads();
 #pragma unroll
