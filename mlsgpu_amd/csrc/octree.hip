@@ -342,9 +342,17 @@ __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))
         for (int w = 0; w < WAVES; w++)
             waveBins[w][d] = 0;
     }
-    /* 1. the tile's entries, lined up in (splat, slot) order */
+    /* 1. the tile's entries, lined up in (splat, slot) order.  What the thread reads that does not depend on another read is
+     * requested here, together: its slot mask, its splat, and the digit totals and tile offsets of the bins it owns in the
+     * scan further down (one round of memory latency instead of three). */
     const uint64_t i = (uint64_t) blockIdx.x * ENT_TILE + threadIdx.x;
     const uint32_t mask = i < n ? (uint32_t) slotMasks[i] : 0u;
+    float4 *const sp = reinterpret_cast<float4 *>(P.splats + ((uint32_t) (i < n ? i : 0) + P.firstSplat));
+    const float4 pr = sp[0];
+    const uint32_t per = numBins > ENT_TILE ? numBins / ENT_TILE : 1;
+    const uint32_t d0 = threadIdx.x * per;
+    const uint32_t totalOfBin = d0 < numBins ? digitTotals[d0] : 0u;
+    const uint32_t histOfBin = d0 < numBins ? hist[(uint64_t) d0 * numTiles + blockIdx.x] : 0u;
     const uint32_t cnt = (uint32_t) __popc(mask);
     const uint32_t incl = waveInclusiveScan(cnt);
     if (lane == 63)
@@ -360,9 +368,6 @@ __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
     if (i < n)
     {
-        const uint32_t gid = (uint32_t) i + P.firstSplat;
-        float4 *sp = reinterpret_cast<float4 *>(P.splats + gid);
-        const float4 pr = sp[0];
         if (P.mutate)
             reinterpret_cast<float *>(sp)[3] = 1.0f / (pr.w * pr.w);    /* kernels/octree.cl:193 */
         if (mask != 0)
@@ -404,13 +409,11 @@ __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))
     }
     __syncthreads();
     {
-        const uint32_t per = numBins > ENT_TILE ? numBins / ENT_TILE : 1;
-        const uint32_t d0 = threadIdx.x * per;
         uint32_t mine = 0, mineAll = 0;
         if (d0 < numBins)
             for (uint32_t k = 0; k < per; k++)
             {
-                mineAll += digitTotals[d0 + k];
+                mineAll += k == 0 ? totalOfBin : digitTotals[d0 + k];
 #pragma unroll
                 for (int w = 0; w < WAVES; w++)
                     mine += waveBins[w][d0 + k];
@@ -432,8 +435,8 @@ __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))
             for (uint32_t k = 0; k < per; k++)
             {
                 const uint32_t d = d0 + k;
-                tileBase[d] = base + hist[(uint64_t) d * numTiles + blockIdx.x] - run;
-                base += digitTotals[d];
+                tileBase[d] = base + (k == 0 ? histOfBin : hist[(uint64_t) d * numTiles + blockIdx.x]) - run;
+                base += k == 0 ? totalOfBin : digitTotals[d];
 #pragma unroll
                 for (int w = 0; w < WAVES; w++)
                 {
