@@ -530,6 +530,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         };
 
         int32_t end = A.commands[pos++];
+        /* a round's splat ids are requested while the round before it is processed */
+        int32_t idAhead = pos + (int32_t) tid < end ? A.commands[pos + (int32_t) tid] : -1;
         while (pos < end)
         {
 #pragma unroll
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     continue;
                 uint32_t mask = 0;
                 const int32_t lpos = pos + (int32_t) slot;
-                const int32_t mine = lpos < end ? A.commands[lpos] : -1;
+                const int32_t mine = part == 0 ? idAhead : (lpos < end ? A.commands[lpos] : -1);
                 if (mine >= 0)
                 {
                     const float4 pr = stagedPosRad(A, mine);
@@ -581,6 +583,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                 pos = A.commands[end];
                 end = (pos >= 0) ? A.commands[pos++] : INT32_MIN;
             }
+            idAhead = pos + (int32_t) tid < end ? A.commands[pos + (int32_t) tid] : -1;
             __syncthreads();
 
             for (int32_t g = 0; g < staged; g += 64)
