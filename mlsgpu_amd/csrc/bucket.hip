@@ -54,6 +54,8 @@ struct RegionView
     __device__ __forceinline__ bool range(uint32_t id, uint32_t lo[3], uint32_t hi[3]) const
     {
         const mlsgpu_splat s = splats[id];
+        /* 32-bit cell arithmetic is exact when the grid's lower ends and the microblock size leave room */
+        const bool narrow = microSize <= (1u << 27) && abs(first[0]) < (1 << 29) && abs(first[1]) < (1 << 29) && abs(first[2]) < (1 << 29);
         if (!(isfinite(s.position[0]) && isfinite(s.position[1]) && isfinite(s.position[2]) && isfinite(s.radius)
               && isfinite(s.normal[0]) && isfinite(s.normal[1]) && isfinite(s.normal[2]) && isfinite(s.quality)))
             return false;       /* never enumerated by a splat set, src/splat_set.h:191 */
@@ -61,11 +63,25 @@ struct RegionView
         for (int a = 0; a < 3; a++)
         {
             const float loWorld = s.position[a] - s.radius, hiWorld = s.position[a] + s.radius;
-            const long long cl = (long long) floorf((loWorld - ref[a]) * invSpacing) - first[a];
-            const long long ch = (long long) floorf((hiWorld - ref[a]) * invSpacing) - first[a];
-            const long long m = (long long) microSize;
-            long long l = (cl >= 0 ? cl / m : -((-cl + m - 1) / m)) - bias[a];      /* divDown */
-            long long h = (ch >= 0 ? ch / m : -((-ch + m - 1) / m)) - bias[a];
+            const float fl = floorf((loWorld - ref[a]) * invSpacing), fh = floorf((hiWorld - ref[a]) * invSpacing);
+            long long l, h;
+            if (fabsf(fl) < 1.0e9f && fabsf(fh) < 1.0e9f && narrow)
+            {
+                /* the same floor division in 32 bits (|cell - first| < 2^31): a 64-bit division is ~150 instructions, six
+                 * of them per splat made the three passes over the cloud compute-bound */
+                const int32_t cl = (int32_t) fl - first[a], ch = (int32_t) fh - first[a];
+                const int32_t m = (int32_t) microSize;
+                l = (long long) (cl >= 0 ? cl / m : -((-cl + m - 1) / m)) - bias[a];
+                h = (long long) (ch >= 0 ? ch / m : -((-ch + m - 1) / m)) - bias[a];
+            }
+            else
+            {
+                const long long cl = (long long) fl - first[a];
+                const long long ch = (long long) fh - first[a];
+                const long long m = (long long) microSize;
+                l = (cl >= 0 ? cl / m : -((-cl + m - 1) / m)) - bias[a];      /* divDown */
+                h = (ch >= 0 ? ch / m : -((-ch + m - 1) / m)) - bias[a];
+            }
             if (l < 0) l = 0;
             if (h >= (long long) dims[a]) h = (long long) dims[a] - 1;
             if (l > h)
