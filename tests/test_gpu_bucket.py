@@ -340,3 +340,30 @@ def test_process_batch_overflow_and_multi_swathe_fallbacks(ctx):
             splits += st["shipouts"] > 1
         assert splits > 0           # the case is exercised
         del w, buf
+
+
+@pytest.mark.parametrize("group", [2, 0])
+def test_process_batch_thin_and_odd_shapes(ctx, group):
+    """Buckets as a partition's slabs make them: one block thick along each axis in turn, widths that are not multiples of
+    the 64-cell chunks or of the 2 x 2 row groups, a single cell, a row of cells -- the edges of the row-pair / row-quad
+    kernels (a layer's last row and the last layer alone, one word per lattice row, a chunk with one corner) -- in one batch,
+    against the oracle bit for bit."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import synth
+    cloud = synth.shells_cloud(60_000, 70.0, 12.0, 1.5, 2.5, seed=77)
+    shapes = [((20, 20, 20), (8, 8, 120)), ((20, 20, 20), (120, 8, 8)), ((20, 20, 20), (8, 120, 8)),
+              ((30, 30, 30), (2, 2, 2)), ((25, 31, 28), (130, 2, 2)), ((10, 12, 14), (66, 3, 65)),
+              ((33, 35, 30), (9, 65, 66)), ((28, 28, 28), (129, 5, 3)), ((16, 24, 20), (67, 66, 2))]
+    items = [(0, len(cloud), low, nv) for low, nv in shapes]
+    w = m.Worker(ctx, len(cloud), max_cells=135)
+    w.set_batch(4)
+    w.set_marching_group(group)
+    w.set_keep_splats(True)
+    buf = m.DeviceBuffer(ctx, array=cloud)
+    got = w.process_batch(buf, items)
+    nonempty = 0
+    for (first, count, low, nv), gb in zip(items, got):
+        exp, _ = ob.bucket(cloud.copy(), first, count, nv, low, max_cells=135, max_swathe=136, mesh_memory=135 * 135 * 2 * 872)
+        assert_batches_equal(gb, exp)
+        nonempty += len(gb) > 0
+    assert nonempty >= 6            # the shapes do cut the shells
