@@ -409,20 +409,6 @@ struct Block
     uint64_t emitted = 0, keptTriangles = 0, vOut = 0, tOut = 0;
 };
 
-static inline int32_t ufRoot(int32_t *uf, int32_t v)
-{
-    int32_t r = v;
-    while (uf[r] >= 0)
-        r = uf[r];
-    while (uf[v] >= 0)
-    {
-        const int32_t next = uf[v];
-        uf[v] = r;
-        v = next;
-    }
-    return r;
-}
-
 } // namespace
 
 struct mlsgpu_host_mesher
@@ -499,41 +485,84 @@ struct mlsgpu_host_mesher
 void mlsgpu_host_mesher::processBlock(Block *b)
 {
     const uint64_t nv = b->nv, nt = b->nt, ni = b->nInternal, ne = nv - ni;
-    /* union by size, negative value = -(size) at a root */
-    static thread_local std::vector<int32_t> ufv;           /* a pool thread's scratch, reused from block to block */
-    ufv.assign(nv, -1);
-    int32_t *uf = ufv.data();
-    const uint32_t *tris = b->triangles;
-    for (uint64_t t = 0; t < nt; t++)
-    {
-        const uint32_t *tri = tris + 3 * t;
-        for (int e = 0; e < 2; e++)
-        {
-            int32_t a = ufRoot(uf, (int32_t) tri[e]), c = ufRoot(uf, (int32_t) tri[e + 1]);
-            if (a == c)
-                continue;
-            if (uf[a] > uf[c])          /* a is the smaller tree */
-                std::swap(a, c);
-            uf[a] += uf[c];
-            uf[c] = a;
-        }
-    }
+    /* Local components by a union-find that several threads work on at once (the pieces go to the front of the pool's queue:
+     * whoever is idle helps, and behind the job's last mesh everybody is): parents only ever point to SMALLER indices and a
+     * hook re-parents roots only (compare-and-swap), so an ancestor stays an ancestor whatever the other threads do, a
+     * shortened path is always valid, and a finished component's root is its smallest vertex whatever the schedule was.
+     * One thread used to take ~35 ms for a bucket's 1.3 M triangles -- the tail of every job. */
+    uint32_t *const parent = arena.array<uint32_t>(nv);
     b->clumpOf = arena.array<uint32_t>(nv);
-    if (b->clumpOf == nullptr)
+    if ((parent == nullptr || b->clumpOf == nullptr) && nv != 0)
     {
         fail(MLSGPU_ERR_NOMEM, "host mesher: out of memory");
         return;
     }
+    const uint32_t *tris = b->triangles;
+    const uint64_t SLICE = 1 << 16;
+    Pool &P = getPool();
+    auto load = [parent](uint32_t v) { return __atomic_load_n(&parent[v], __ATOMIC_RELAXED); };
+    auto find = [parent, &load](uint32_t v) {
+        for (;;)
+        {
+            const uint32_t p = load(v);
+            if (p == v)
+                return v;
+            const uint32_t g = load(p);
+            if (g == p)
+                return p;
+            __atomic_store_n(&parent[v], g, __ATOMIC_RELAXED);      /* path halving */
+            v = g;
+        }
+    };
+    for (uint64_t i = 0; i < nv; i++)
+        parent[i] = (uint32_t) i;
+    /* a few large pieces: at most PIECES - 1 helpers per block (threads of another socket make the shared array slow) */
+    static const uint64_t PIECES = getenv("MLSGPU_HIP_HOST_MESHER_PIECES") ? (uint64_t) atoi(getenv("MLSGPU_HIP_HOST_MESHER_PIECES")) : 4;
+    const uint64_t USLICE = std::max<uint64_t>(SLICE, (nt + PIECES - 1) / std::max<uint64_t>(PIECES, 1));
+    P.parallelForNow((size_t) ((nt + USLICE - 1) / USLICE), [&](size_t s) {
+        for (uint64_t t = s * USLICE, e = std::min(nt, t + USLICE); t < e; t++)
+        {
+            const uint32_t *tri = tris + 3 * t;
+            for (int k = 0; k < 2; k++)         /* the third edge is redundant, src/mesher.cpp:231-234 */
+            {
+                uint32_t x = tri[k], y = tri[k + 1];
+                for (;;)
+                {
+                    x = find(x);
+                    y = find(y);
+                    if (x == y)
+                        break;
+                    if (x < y)
+                        std::swap(x, y);
+                    uint32_t expected = x;      /* hook the larger root under the smaller; retry if it was re-parented */
+                    if (__atomic_compare_exchange_n(&parent[x], &expected, y, false, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED))
+                        break;
+                }
+            }
+        }
+    });
+    /* every vertex straight under its root */
+    for (uint64_t i = 0; i < nv; i++)
+    {
+        uint32_t r = parent[i];
+        while (parent[r] != r)
+            r = parent[r];
+        b->clumpOf[i] = r;                  /* the root for now */
+    }
+    /* clumps numbered by their smallest vertex, ascending */
     uint32_t numLocal = 0;
     for (uint64_t i = 0; i < nv; i++)
-        if (uf[i] < 0)
+        if (b->clumpOf[i] == (uint32_t) i)
         {
-            b->clumpOf[i] = numLocal++;
-            b->clumpVertices.push_back((uint64_t) -(int64_t) uf[i]);
+            parent[i] = numLocal++;             /* the forest is not needed any more: the root's clump number */
+            b->clumpVertices.push_back(0);
         }
     for (uint64_t i = 0; i < nv; i++)
-        if (uf[i] >= 0)
-            b->clumpOf[i] = b->clumpOf[ufRoot(uf, (int32_t) i)];
+    {
+        const uint32_t c = parent[b->clumpOf[i]];
+        b->clumpVertices[c]++;
+        b->clumpOf[i] = c;
+    }
     b->clumpTriangles.assign(numLocal, 0);
     for (uint64_t t = 0; t < nt; t++)
         b->clumpTriangles[b->clumpOf[tris[3 * t]]]++;
@@ -789,13 +818,36 @@ int mlsgpu_host_mesher::finalizeWith(const uint8_t *keepClump, uint32_t *numChun
             b->remap = arena.array<uint32_t>(b->nv);
             REQUIRE(b->remap != nullptr, MLSGPU_ERR_NOMEM);
         }
-    /* pass 1: which vertices a block emits (kept, and for an external vertex: the key's first of its chunk) */
-    P.parallelFor(blocks.size(), [&](size_t bi) {
-        Block &b = *blocks[bi];
-        std::fill(b.remap, b.remap + b.nv, PRUNED);
+    /* The passes below run over SLICES of the blocks' vertex and triangle arrays, not over blocks: a job of a few dozen large
+     * blocks (27 buckets: 0.65 M vertices and 1.3 M triangles each) keeps every thread of the pool busy. */
+    const uint64_t SLICE = 1 << 16;
+    struct Piece
+    {
+        uint32_t block;
+        uint64_t begin, end, count, out;
+    };
+    std::vector<Piece> vPieces, tPieces;
+    std::vector<size_t> vFirst(blocks.size() + 1, 0), tFirst(blocks.size() + 1, 0);
+    for (size_t bi = 0; bi < blocks.size(); bi++)
+    {
+        const Block &b = *blocks[bi];
+        vFirst[bi] = vPieces.size();
+        tFirst[bi] = tPieces.size();
+        for (uint64_t i = 0; i < b.nv; i += SLICE)
+            vPieces.push_back(Piece{(uint32_t) bi, i, std::min(i + SLICE, b.nv), 0, 0});
+        for (uint64_t t = 0; t < b.nt; t += SLICE)
+            tPieces.push_back(Piece{(uint32_t) bi, t, std::min(t + SLICE, b.nt), 0, 0});
+    }
+    vFirst[blocks.size()] = vPieces.size();
+    tFirst[blocks.size()] = tPieces.size();
+    /* pass 1: which vertices a block emits (kept, and for an external vertex: the key's first of its chunk) ... */
+    P.parallelFor(vPieces.size(), [&](size_t pi) {
+        Piece &pc = vPieces[pi];
+        Block &b = *blocks[pc.block];
         uint64_t emitted = 0;
-        for (uint64_t i = 0; i < b.nv; i++)
+        for (uint64_t i = pc.begin; i < pc.end; i++)
         {
+            b.remap[i] = PRUNED;
             if (!keptClump(b.clumpBase + b.clumpOf[i]))
                 continue;
             if (i >= b.nInternal)
@@ -811,11 +863,16 @@ int mlsgpu_host_mesher::finalizeWith(const uint8_t *keepClump, uint32_t *numChun
             b.remap[i] = 0;
             emitted++;
         }
-        b.emitted = emitted;
+        pc.count = emitted;
+    });
+    /* ... and how many of its triangles stay (a triangle's clump is its first corner's) */
+    P.parallelFor(tPieces.size(), [&](size_t pi) {
+        Piece &pc = tPieces[pi];
+        const Block &b = *blocks[pc.block];
         uint64_t kt = 0;
-        for (uint64_t t = 0; t < b.nt; t++)
+        for (uint64_t t = pc.begin; t < pc.end; t++)
             kt += b.remap[b.triangles[3 * t]] != PRUNED;
-        b.keptTriangles = kt;
+        pc.count = kt;
     });
     chunkVStart.assign(nc + 1, 0);
     chunkTStart.assign(nc + 1, 0);
@@ -828,11 +885,22 @@ int mlsgpu_host_mesher::finalizeWith(const uint8_t *keepClump, uint32_t *numChun
             chunkTStart[c] = tAll;
             for (; k < order.size() && blocks[order[k]]->chunk == c; k++)
             {
-                Block &b = *blocks[order[k]];
+                const uint32_t bi = order[k];
+                Block &b = *blocks[bi];
                 b.vOut = vAll;
                 b.tOut = tAll;
-                vAll += b.emitted;
-                tAll += b.keptTriangles;
+                for (size_t pi = vFirst[bi]; pi < vFirst[bi + 1]; pi++)
+                {
+                    vPieces[pi].out = vAll;
+                    vAll += vPieces[pi].count;
+                }
+                for (size_t pi = tFirst[bi]; pi < tFirst[bi + 1]; pi++)
+                {
+                    tPieces[pi].out = tAll;
+                    tAll += tPieces[pi].count;
+                }
+                b.emitted = vAll - b.vOut;
+                b.keptTriangles = tAll - b.tOut;
             }
         }
         chunkVStart[nc] = vAll;
@@ -850,11 +918,12 @@ int mlsgpu_host_mesher::finalizeWith(const uint8_t *keepClump, uint32_t *numChun
     }
     REQUIRE(outVertices != nullptr && outTriangles != nullptr, MLSGPU_ERR_NOMEM);
     /* pass 2: output indices (relative to the chunk's first vertex) and the vertex copies */
-    P.parallelFor(blocks.size(), [&](size_t bi) {
-        Block &b = *blocks[bi];
-        uint64_t at = b.vOut;
+    P.parallelFor(vPieces.size(), [&](size_t pi) {
+        const Piece &pc = vPieces[pi];
+        Block &b = *blocks[pc.block];
+        uint64_t at = pc.out;
         const uint64_t first = chunkVStart[b.chunk];
-        for (uint64_t i = 0; i < b.nv; i++)
+        for (uint64_t i = pc.begin; i < pc.end; i++)
             if (b.remap[i] == 0)
             {
                 b.remap[i] = (uint32_t) (at - first);
@@ -865,18 +934,24 @@ int mlsgpu_host_mesher::finalizeWith(const uint8_t *keepClump, uint32_t *numChun
                 at++;
             }
     });
-    /* pass 3: a later occurrence of a key points at the chunk's copy; then the triangles */
-    P.parallelFor(blocks.size(), [&](size_t bi) {
-        Block &b = *blocks[bi];
-        for (uint64_t i = b.nInternal; i < b.nv; i++)
+    /* pass 3: a later occurrence of a key points at the chunk's copy (an owner is never an alias: written in pass 2) ... */
+    P.parallelFor(vPieces.size(), [&](size_t pi) {
+        const Piece &pc = vPieces[pi];
+        Block &b = *blocks[pc.block];
+        for (uint64_t i = std::max(pc.begin, b.nInternal); i < pc.end; i++)
             if (b.remap[i] == ALIAS)
             {
                 const uint64_t key = b.keys[i - b.nInternal];
                 const Ref o = shards[mix64(key) >> 58].owners.owner(key, b.chunk);
-                b.remap[i] = blocks[o.seq]->remap[o.idx];      /* an owner is never an alias: written in pass 2 */
+                b.remap[i] = blocks[o.seq]->remap[o.idx];
             }
-        uint64_t at = 3 * b.tOut;
-        for (uint64_t t = 0; t < b.nt; t++)
+    });
+    /* ... then the triangles */
+    P.parallelFor(tPieces.size(), [&](size_t pi) {
+        const Piece &pc = tPieces[pi];
+        const Block &b = *blocks[pc.block];
+        uint64_t at = 3 * pc.out;
+        for (uint64_t t = pc.begin; t < pc.end; t++)
         {
             const uint32_t *tri = &b.triangles[3 * t];
             if (b.remap[tri[0]] == PRUNED)
