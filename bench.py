@@ -518,6 +518,8 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     hi = [torch.cuda.Stream(device=device_index, priority=int(os.environ.get("MLSGPU_BENCH_SINK_PRIORITY", "-1"))) for _ in range(NS)]
     fctx = [m.Context(device_index, stream=s_.cuda_stream) for s_ in hi]
     sinks = [m.Mesher(c, 0.02) for c in fctx]
+    for s_ in sinks:
+        s_.set_background(True)     # their welds run while the next job's buckets are on the GPU
     # spare device items beyond one per worker: the previous job's weld shares the GPU with this job's kernels, and with
     # one spare item every delayed bucket stalls the host-to-device copies behind it (shells cloud, steady state: 47 ms per
     # job with 1 spare item, 42 with 4, 44 with 12)

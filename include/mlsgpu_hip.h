@@ -464,6 +464,9 @@ int mlsgpu_hip_mesher_create(mlsgpu_ctx *ctx, mlsgpu_mesher **out);
 void mlsgpu_hip_mesher_destroy(mlsgpu_mesher *mesher);
 /* MesherBase::setPruneThreshold: components with fewer vertices than uint64(total * threshold) are dropped */
 int mlsgpu_hip_mesher_set_prune_threshold(mlsgpu_mesher *mesher, double threshold);
+/* on = 1: finalize runs beside other GPU work (the next job's buckets) and holds its union-find pass back to a quarter of
+ * the wave slots -- no slower for surface-like meshes, and the other kernels keep their speed.  Default 0. */
+int mlsgpu_hip_mesher_set_background(mlsgpu_mesher *mesher, int on);
 /* Optional: room for this many vertices / triangles / external vertices in total (the arenas grow by reallocation
  * otherwise). */
 int mlsgpu_hip_mesher_reserve(mlsgpu_mesher *mesher, uint64_t numVertices, uint64_t numTriangles, uint64_t numExternal);

@@ -262,6 +262,7 @@ def lib():
     sig("mlsgpu_hip_mesher_create", C.c_int, vp, P(vp))
     sig("mlsgpu_hip_mesher_destroy", None, vp)
     sig("mlsgpu_hip_mesher_set_prune_threshold", C.c_int, vp, C.c_double)
+    sig("mlsgpu_hip_mesher_set_background", C.c_int, vp, C.c_int)
     sig("mlsgpu_hip_mesher_add", C.c_int, vp, vp, u64, vp)
     sig("mlsgpu_hip_mesher_reserve", C.c_int, vp, u64, u64, u64)
     sig("mlsgpu_hip_mesher_farm_output", C.c_int, vp, C.c_int, u64, vp, P(Mesh))
@@ -694,6 +695,10 @@ class Mesher:
 
     def set_prune_threshold(self, threshold):
         check(lib().mlsgpu_hip_mesher_set_prune_threshold(self.h, float(threshold)))
+
+    def set_background(self, on=True):
+        """finalize runs beside other GPU work (the next job's buckets) and holds back: mlsgpu_hip_mesher_set_background."""
+        check(lib().mlsgpu_hip_mesher_set_background(self.h, 1 if on else 0))
 
     def reserve(self, num_vertices, num_triangles, num_external):
         check(lib().mlsgpu_hip_mesher_reserve(self.h, num_vertices, num_triangles, num_external))

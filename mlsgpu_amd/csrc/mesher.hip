@@ -551,6 +551,7 @@ struct mlsgpu_mesher
     mlsgpu_ctx *ctx = nullptr;
     std::mutex mutex;
     double pruneThreshold = 0.0;
+    bool background = false;        /* finalize shares the GPU with other work: see the union-find launch */
     Arena<float> vertices;          /* 3 per vertex */
     Arena<uint32_t> triangles;      /* 3 per triangle, global vertex ids */
     Arena<uint64_t> extKeys;
@@ -716,6 +717,17 @@ MLSGPU_API int mlsgpu_hip_mesher_create(mlsgpu_ctx *ctx, mlsgpu_mesher **out)
 }
 
 MLSGPU_API void mlsgpu_hip_mesher_destroy(mlsgpu_mesher *m) { delete m; }
+
+/* on = 1: this sink's finalize usually runs while other work (the next job's buckets) is on the GPU: its union-find pass
+ * holds back to a quarter of the wave slots.  Shells cloud, jobs in rotation: 40.6 -> 37.1 ms per job (the ship-out route:
+ * 36.3); a finalize that has the GPU to itself takes 11-14 ms either way, the noise cloud's (378 M vertices) 97 -> 108 ms. */
+MLSGPU_API int mlsgpu_hip_mesher_set_background(mlsgpu_mesher *m, int on)
+{
+    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    m->background = on != 0;
+    return MLSGPU_OK;
+}
 
 MLSGPU_API int mlsgpu_hip_mesher_set_prune_threshold(mlsgpu_mesher *m, double threshold)
 {
@@ -1080,8 +1092,12 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
          * 14.1, noise cloud (378 M) 113.9 / 103.9 / 96.3 */
         static const int forced = getenv("MLSGPU_HIP_UF_SHORTCUT") ? atoi(getenv("MLSGPU_HIP_UF_SHORTCUT")) : -1;
         const uint32_t unionShortcut = forced >= 0 ? (uint32_t) forced : (nv < (uint64_t(100) << 20) ? 3u : 8u);
-        LAUNCH(ctx, "mesher.components.time", unionKernel, dim3(divUp(nt, 256)), B, (const uint32_t *) m->triangles.ptr, nt,
-               (const uint32_t *) compRep, parent, dFailed, unionShortcut);
+        /* background (mlsgpu_hip_mesher_set_background): dynamic LDS the kernel never touches leaves it four workgroups per
+         * CU.  The pass waits on L2 atomics, not on wave slots -- a surface-like mesh takes as long either way -- but at full
+         * occupancy it slows the kernels of the job that is streaming in behind it. */
+        const uint32_t ufPad = m->background ? 40000u : 0u;
+        LAUNCH_LDS(ctx, "mesher.components.time", unionKernel, dim3(divUp(nt, 256)), B, ufPad, (const uint32_t *) m->triangles.ptr, nt,
+                   (const uint32_t *) compRep, parent, dFailed, unionShortcut);
         LAUNCH(ctx, "mesher.components.time", compressKernel, dim3(divUp(nv, 256)), B, parent, (const uint32_t *) compRep, nv, root);
         LAUNCH(ctx, "mesher.components.time", componentSizeKernel, dim3(divUp(divUp(nv, 64 * SIZE_SPAN), 4)), B,
                (const uint32_t *) compRep, (const uint32_t *) root, nv, size);

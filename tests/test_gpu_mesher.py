@@ -17,10 +17,12 @@ def chunk_number(chunk, seen):
     return seen.setdefault(chunk, len(seen))
 
 
-def run_hip(meshes, prune=0.0):
+def run_hip(meshes, prune=0.0, background=False):
     import mlsgpu_amd as m
     ctx = m.Context(0)
     mesher = m.Mesher(ctx, prune)
+    if background:
+        mesher.set_background(True)
     seen = {}
     for mesh in meshes:
         mesher.add(chunk_number(mesh["chunk"], seen), mesh["vertices"], mesh["num_internal"], mesh["keys"], mesh["triangles"])
@@ -115,7 +117,7 @@ def test_peer_route_appends(monkeypatch):
 def test_random_sheets_match_oracle(seed, prune):
     meshes = random_meshes(seed)
     exp, exp_stats = mo.mesh_sink(meshes, prune)
-    out, stats = run_hip(meshes, prune)
+    out, stats = run_hip(meshes, prune, background=seed % 2 == 0)     # the background mode (held-back union-find) too
     for k in ("total_vertices", "threshold", "components", "kept_components", "kept_vertices", "kept_triangles"):
         assert stats[k] == exp_stats[k], k
     assert [c for c, _, _ in out] == [c for c, _, _ in exp]
