@@ -473,6 +473,9 @@ def cpu_baseline(sample_host, sample_buckets, max_cells):
     }
 
 
+_SINK_PINS = []
+
+
 def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_cells, voxels, steps, with_sink=True):
     """SURVEY 8(d)'s timed region: host splats of every bucket in -> last byte of mesh back in host memory.
     route "shipouts": every ship-out read back asynchronously through the farm's pinned circular buffer, overlapped with
@@ -526,7 +529,11 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     sink_spare = int(os.environ.get("MLSGPU_BENCH_FARM_SPARE", "4"))
     farms = [m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=sink_spare, max_cells=max_cells,
                           mesh_memory=args.mesh_memory_mb << 20, sink=s_, copy_threads=args.copy_threads) for s_ in sinks]
-    pins = [m.binding.PinnedBuffer(1) for _ in range(NS)]
+    # the pinned landing buffers are kept from leg to leg: buffers allocated afresh after a leg that had pinned (and freed)
+    # tens of GB land on slower memory (read-back 12.9 -> 17.6 ms for the shells mesh, and the job 37.6 -> 47.8 ms)
+    while len(_SINK_PINS) < NS:
+        _SINK_PINS.append(m.binding.PinnedBuffer(1))
+    pins = _SINK_PINS[:NS]
     got_bytes = [0] * NS
     errors = []
 
@@ -591,7 +598,6 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
                 "weld and read-back overlap the following jobs' transfer and compute (ms_per_step is the steady state over %d "
                 "jobs; one_job_alone_ms is a single job's latency)" % (NS, jobs)}
     for k in range(NS):
-        pins[k].free()
         farms[k].close()
         sinks[k].close()
         fctx[k].close()
