@@ -1500,13 +1500,15 @@ def main():
     del workers, work, pristine, bucketed_t, W
     torch.cuda.empty_cache()
 
-    # ---- transfer-inclusive legs (never `value`): SURVEY 8(d)'s region, host splats in -> last mesh byte out ----
-    if secondary and not args.no_transfer:
-        try:     # a secondary leg never costs the line its headline
-            result["transfer_inclusive"] = transfer_legs(m, args, local_rank, bucketed_host, buckets, max_count, max_cells, voxels, L)
-            result["transfer_inclusive"]["distribution"] = args.dist
-        except Exception as e:      # noqa: BLE001 - reported in the line
-            result.setdefault("leg_errors", {})['transfer_inclusive'] = "%s: %s" % (type(e).__name__, e)
+    # the sink route's pinned landing buffers, sized once for the larger of the meshes (this workload's): allocated now, before
+    # any leg has pinned and freed host memory, and kept to the end
+    if secondary and not args.no_transfer and rank == 0 and world == 1:
+        try:
+            need = int(1.02 * 12 * (triangles + vertices)) + (1 << 20)
+            while len(_SINK_PINS) < 3:
+                _SINK_PINS.append(m.binding.PinnedBuffer(need))
+        except Exception:      # noqa: BLE001 - the legs grow their buffers themselves
+            pass
 
     # ---- D1 ("shells", SURVEY 8d: report both): resident rate and the same transfer-inclusive legs ----
     if secondary and not args.no_shells and args.dist == "uniform" and args.workload in ("auto", "cfg3"):
@@ -1554,6 +1556,16 @@ def main():
             result["shells"] = shells
         except Exception as e:      # noqa: BLE001 - reported in the line
             result.setdefault("leg_errors", {})['shells'] = "%s: %s" % (type(e).__name__, e)
+
+    # (the shells legs run BEFORE the noise cloud's transfer legs: those pin and free tens of GB of host memory, after which
+    # freshly allocated host arrays are slower to copy from -- profiles/NOTES_r04.md section 9.10)
+    # ---- transfer-inclusive legs (never `value`): SURVEY 8(d)'s region, host splats in -> last mesh byte out ----
+    if secondary and not args.no_transfer:
+        try:     # a secondary leg never costs the line its headline
+            result["transfer_inclusive"] = transfer_legs(m, args, local_rank, bucketed_host, buckets, max_count, max_cells, voxels, L)
+            result["transfer_inclusive"]["distribution"] = args.dist
+        except Exception as e:      # noqa: BLE001 - reported in the line
+            result.setdefault("leg_errors", {})['transfer_inclusive'] = "%s: %s" % (type(e).__name__, e)
 
     # ---- CPU baseline: the oracle ("port") parallel over buckets on the host cores, rank 0 at N = 1 only ----
     # ---- SURVEY 8(d)'s own timed region at the top level of the line (never `value`: the contract wants inputs resident) ----
