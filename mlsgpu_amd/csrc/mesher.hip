@@ -1095,7 +1095,8 @@ int mlsgpu_mesher::finalizeImpl(uint32_t *numChunks, bool analyzeOnly, const uin
         /* background (mlsgpu_hip_mesher_set_background): dynamic LDS the kernel never touches leaves it four workgroups per
          * CU.  The pass waits on L2 atomics, not on wave slots -- a surface-like mesh takes as long either way -- but at full
          * occupancy it slows the kernels of the job that is streaming in behind it. */
-        const uint32_t ufPad = m->background ? 40000u : 0u;
+        const uint32_t ufPad = m->background && nv < (uint64_t(100) << 20) ? 40000u : 0u;     /* (a mesh of hundreds of millions
+                                                                                                * of vertices does need the slots) */
         LAUNCH_LDS(ctx, "mesher.components.time", unionKernel, dim3(divUp(nt, 256)), B, ufPad, (const uint32_t *) m->triangles.ptr, nt,
                    (const uint32_t *) compRep, parent, dFailed, unionShortcut);
         LAUNCH(ctx, "mesher.components.time", compressKernel, dim3(divUp(nv, 256)), B, parent, (const uint32_t *) compRep, nv, root);
