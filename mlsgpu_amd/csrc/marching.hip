@@ -1360,13 +1360,26 @@ __global__ __launch_bounds__(256) void latticeTrianglesRowKernel(Lanes<LatticeTr
             const uint32_t iws[9] = {r1.x, r1.y, r1.z, r1.w, r2.x, r2.y, r2.z, r2.w, r3.x};
             uint8_t *const ref = myRef + local;
             const uint32_t whole = ni >> 2;
+            /* two words per store where two are whole (an unaligned 8-byte LDS store costs what a 4-byte one does) */
 #pragma unroll
-            for (uint32_t q = 0; q < 9; q++)
-                if (q < whole)
+            for (uint32_t q = 0; q < 8; q += 2)
+            {
+                if (q + 1 < whole)
+                {
+                    const uint64_t v = (uint64_t) (iws[q] + first4) | (uint64_t) (iws[q + 1] + first4) << 32;
+                    __builtin_memcpy(ref + 4 * q, &v, 8);
+                }
+                else if (q < whole)
                 {
                     const uint32_t v = iws[q] + first4;
                     __builtin_memcpy(ref + 4 * q, &v, 4);
                 }
+            }
+            if (8 < whole)
+            {
+                const uint32_t v = iws[8] + first4;
+                __builtin_memcpy(ref + 32, &v, 4);
+            }
             const uint32_t rest = ni & 3u, tail = r3.y + first4;
             if (rest > 0) ref[4 * whole] = (uint8_t) tail;
             if (rest > 1) ref[4 * whole + 1] = (uint8_t) (tail >> 8);
