@@ -1232,13 +1232,14 @@ struct LatticeTrianglesRowArgs
 /* Software-pipelined over the chunks of a row: nothing chunk n + 1 needs is requested after chunk n's stores.  Vector loads
  * and stores retire in order (one counter, vmcnt), so a load issued behind a chunk's stores is usable only when all of them
  * have reached the L2.  Here the loads of chunk n + 1 (its code records; the code bytes of chunk n + 2) are issued BEFORE the
- * stores of chunk n, and every chunk issues a number of stores the compiler can count (12, or 16; a chunk with more than 1024
- * indices drains), so the wait in front of chunk n + 1 is `vmcnt(12)`: chunk n's stores stay in flight.  (A path through the
- * loop without stores -- an empty chunk skipped, a predicated store -- would make that wait a full one again, which is why
- * positions past the span store the span's last index once more and an empty chunk stores to a word nobody reads.)  The
+ * stores of chunk n, and every chunk issues a number of stores the compiler can count (three per quarter of the wave, a fourth
+ * for a quarter of more than 192 indices; one of more than 256 drains), so the wait in front of chunk n + 1 is `vmcnt(12)`:
+ * chunk n's stores stay in flight.  (A path through the loop without stores -- an empty chunk skipped, a predicated store --
+ * would make that wait a full one again, which is why positions past a quarter's end store its last index once more and an
+ * empty quarter stores to a word nobody reads.)  The
  * lattice words of the row's nine lattice rows are staged once in LDS (dynamic: 4 x 9 x nw x 16 bytes) instead of nine
  * 16-byte loads per cell; a vertex index is its row's word prefix plus the mask bits below its x2, counted once per row
- * (not per edge); the references go out four bytes at a time.  Measured on cfg3 (two buckets per launch): 216 -> 195 us,
+ * (not per edge); the references go out four or eight bytes at a time.  Measured on cfg3 (two buckets per launch): 216 -> 195 us,
  * 3.16 -> 2.90 ms per step (profiles/NOTES_r04.md section 9). */
 __global__ __launch_bounds__(256) void latticeTrianglesRowKernel(Lanes<LatticeTrianglesRowArgs> lanes)
 {
