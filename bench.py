@@ -44,17 +44,18 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
 FP32_VALU_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: peak FP32 vector (counts packed FMA: 2 flops x 2 per lane per clock)
-SLAB = 128                     # corner slices per GPU of the N > 1 workload
+from mlsgpu_amd.synth import SLAB  # noqa: E402 - corner slices per GPU of the N > 1 workload
 # digest of the meshes of the default N = 1 workload (cfg3 uniform): the value tests/test_gpu_configs.py pins next to
 # oracle bit-parity on three of the 27 buckets (a data fixture, tests/golden/cfg3_uniform.json)
 try:
     CFG3_UNIFORM_DIGEST = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg3_uniform.json")))["digest"]
 except Exception:   # noqa: BLE001 - the fixture is optional for the benchmark
     CFG3_UNIFORM_DIGEST = None
-try:    # rank 0's slab of the N > 1 workload (tests/test_gpu_configs.py::test_cfg4_slab_full_density)
-    CFG4SLAB_DIGEST = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg4slab_uniform.json")))["digest"]
+try:    # EVERY slab of the N > 1 workload, as an inner and as a last slab: {slab: {"inner" | "last": totals + digest}}
+    # (tests/test_gpu_configs.py::test_cfg4_slab_full_density runs all of them on one GPU next to oracle parity)
+    CFG4SLAB_PINS = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg4slab_uniform.json")))["slabs"]
 except Exception:   # noqa: BLE001
-    CFG4SLAB_DIGEST = None
+    CFG4SLAB_PINS = None
 
 
 def parse_args():
@@ -165,10 +166,9 @@ def build_workload(args, rank, world, device):
         raise SystemExit("the cfg4 slab family is defined on the uniform cloud")
     cloud, g = synth.make_cloud_device("cfg4", device, scale=args.scale)
     dims = (g, g, SLAB * world)
-    boxes = synth.grid_buckets(dims, 255, runs=(0, 0, world))
-    per = len(boxes) // world
-    assert per * world == len(boxes)
-    bucketed, buckets = synth.bucketize_device(cloud, boxes[rank * per:(rank + 1) * per])
+    mine_boxes = synth.slab_boxes(g, world, rank, SLAB)
+    per = len(mine_boxes)
+    bucketed, buckets = synth.bucketize_device(cloud, mine_boxes)
     # splats this rank accounts for in Msplats/s: centres inside its slab (the halo copies are not counted twice)
     z0 = buckets[0].low[2]
     z1 = z0 + buckets[0].num_vertices[2] - 1
@@ -183,7 +183,7 @@ def build_workload(args, rank, world, device):
                " (= BASELINE configs[3] in full)" if world * SLAB == g else ""))
     del zc
     return dict(bucketed=bucketed, buckets=buckets, n_splats=mine, text=text, cloud=None, grid=dims, name="cfg4slab",
-                all_buckets=len(boxes))
+                all_buckets=per * world)
 
 
 # ---------------------------------------------------------------------------------------------------- cfg5
@@ -1187,13 +1187,35 @@ def main():
         if digest != CFG3_UNIFORM_DIGEST:
             raise SystemExit("output digest %s differs from the pinned %s: the timed pipeline did not produce the meshes "
                              "the parity tests check" % (digest, CFG3_UNIFORM_DIGEST))
-    # rank 0's slab of a SHARDED run (N >= 2: 128 cell slices; the one-slab grid of N = 1 has 127) is the pinned one
-    if W["name"] == "cfg4slab" and world > 1 and rank == 0 and args.scale == 1.0 and CFG4SLAB_DIGEST is not None:
-        result["output_digest"]["expected"] = CFG4SLAB_DIGEST
-        result["output_digest"]["ok"] = digest == CFG4SLAB_DIGEST
-        if digest != CFG4SLAB_DIGEST:
-            raise SystemExit("output digest %s of rank 0's slab differs from the pinned %s (tests/golden/cfg4slab_uniform.json)"
-                             % (digest, CFG4SLAB_DIGEST))
+    # EVERY rank's slab is pinned (slab r as an inner slab of 128 cell slices, or as the job's last one of 127): each rank holds
+    # its own digest against its pin, the verdicts are gathered, and one mismatch anywhere fails the whole run
+    digest_failure = None
+    if W["name"] == "cfg4slab" and args.scale == 1.0 and CFG4SLAB_PINS is not None:
+        from mlsgpu_amd import synth
+        pin = CFG4SLAB_PINS.get(str(rank), {}).get(synth.slab_variant(world, rank))
+        mine_ok = pin is not None and digest == pin["digest"] and check.vertices == pin["vertices"] \
+            and check.triangles == pin["triangles"]
+        verdicts = [bool(mine_ok)]
+        digests = [digest]
+        if dist is not None:
+            d = torch.zeros((world, 3), dtype=torch.int64, device=reduce_device)
+            d[rank, 0], d[rank, 1], d[rank, 2] = int(mine_ok), int(digest[:8], 16), int(digest[8:], 16)
+            dist.all_reduce(d)
+            d = d.cpu().numpy()
+            verdicts = [bool(x) for x in d[:, 0]]
+            digests = ["%08x%08x" % (int(a), int(b)) for a, b in d[:, 1:3]]
+        expected = [CFG4SLAB_PINS.get(str(r), {}).get(synth.slab_variant(world, r), {}).get("digest") for r in range(world)]
+        result["output_digest"].update(expected=expected[0], ok=verdicts[0], per_rank_digest=digests, per_rank_expected=expected,
+                                       per_rank_ok=verdicts, all_ok=all(verdicts))
+        if not all(verdicts):
+            digest_failure = ("output digests %s of the ranks' slabs differ from the pinned %s (tests/golden/cfg4slab_uniform.json)"
+                              % (digests, expected))
+    if digest_failure is not None:
+        if rank == 0:
+            print("bench.py: " + digest_failure, file=sys.stderr, flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        raise SystemExit(3)
     if force_dist:
         result["debug_forced_dist"] = "ONE rank with the N > 1 code path (MLSGPU_BENCH_FORCE_DIST=1): a check of that code, not a measurement"
     if world > ndev:
@@ -1203,6 +1225,7 @@ def main():
             "buckets": [int(x) for x in per_rank[:, 1]],
             "ms_per_step": [round(x / args.steps * 1e3, 3) for x in per_rank[:, 0]],
             "mvoxels_per_s": [round(v * args.steps / e / 1e6, 1) for e, v in zip(per_rank[:, 0], per_rank[:, 2])],
+            "digest_ok": result["output_digest"].get("per_rank_ok"),
             "note": "every rank is one GPU working on its own slab; value = sum of voxels / slowest rank's time",
             "reading_the_scaling_curve": "the N = 1 point of the driver's curve is cfg3 (0.37 splats per voxel); the N > 1 "
                                          "points are slabs of cfg4 (0.19 splats per voxel, the density BASELINE names), a lighter "

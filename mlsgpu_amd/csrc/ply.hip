@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <algorithm>
 #include <fstream>
+#include <iterator>
 #include <memory>
 #include <sstream>
 #include <thread>
@@ -23,28 +24,27 @@ namespace
 
 enum FieldType { INT8, UINT8, INT16, UINT16, INT32, UINT32, FLOAT32, FLOAT64, BAD_TYPE };
 
-FieldType parseType(const std::string &t)
+/* the scalar types of the format: spelling -> (type, bytes, may count a list) */
+struct TypeRow
 {
-    if (t == "int8" || t == "char") return INT8;
-    if (t == "uint8" || t == "uchar") return UINT8;
-    if (t == "int16") return INT16;
-    if (t == "uint16") return UINT16;
-    if (t == "int32" || t == "int") return INT32;
-    if (t == "uint32" || t == "uint") return UINT32;
-    if (t == "float32" || t == "float") return FLOAT32;
-    if (t == "float64") return FLOAT64;
-    return BAD_TYPE;
-}
+    const char *spelling;
+    FieldType type;
+    uint64_t bytes;
+    bool integral;
+};
+const TypeRow typeRows[] = {
+    {"int8", INT8, 1, true},       {"char", INT8, 1, true},     {"uint8", UINT8, 1, true},    {"uchar", UINT8, 1, true},
+    {"int16", INT16, 2, true},     {"uint16", UINT16, 2, true}, {"int32", INT32, 4, true},    {"int", INT32, 4, true},
+    {"uint32", UINT32, 4, true},   {"uint", UINT32, 4, true},   {"float32", FLOAT32, 4, false}, {"float", FLOAT32, 4, false},
+    {"float64", FLOAT64, 8, false},
+};
 
-uint64_t fieldSize(FieldType f)
+const TypeRow *findType(const std::string &spelling)
 {
-    switch (f)
-    {
-    case INT8: case UINT8: return 1;
-    case INT16: case UINT16: return 2;
-    case INT32: case UINT32: case FLOAT32: return 4;
-    default: return 8;
-    }
+    for (const TypeRow &row : typeRows)
+        if (spelling == row.spelling)
+            return &row;
+    return nullptr;
 }
 
 enum { X, Y, Z, NX, NY, NZ, RADIUS, NUM_PROPERTIES };
@@ -69,130 +69,154 @@ int formatError(const mlsgpu_ply_reader &r, const std::string &what)
     return setError(MLSGPU_ERR_FORMAT, "%s: %s", r.path.c_str(), what.c_str());
 }
 
-/* Reader::readHeader, src/fast_ply.cpp:180-330 */
+/*
+ * The header (what Reader::readHeader accepts, src/fast_ply.cpp:180-330, with its FormatError texts) as a table:
+ * a line is `keyword words...`; a keyword's handler folds the line into a HeaderScan and returns an empty string or
+ * the complaint.  Unknown keywords (comment, obj_info, ...) fold into nothing.
+ */
+using Words = std::vector<std::string>;
+
+struct HeaderScan
+{
+    static constexpr const char *wanted[NUM_PROPERTIES] = {"x", "y", "z", "nx", "ny", "nz", "radius"};
+    unsigned found = 0;                 /* bit i: wanted[i] has been declared */
+    uint64_t declared = 0;              /* element lines so far; the properties that follow belong to the last one */
+    bool format = false;
+    uint64_t vertexCount = 0, vertexSize = 0;
+    uint64_t offsets[NUM_PROPERTIES] = {};
+};
+constexpr const char *HeaderScan::wanted[NUM_PROPERTIES];
+
+/* `property <type> <name>` or `property list <count type> <value type> <name>`, by word count */
+struct PropertyDecl
+{
+    const TypeRow *value = nullptr, *length = nullptr;
+    std::string name;
+
+    std::string parse(const Words &w)
+    {
+        const bool list = w.size() >= 2 && w[1] == "list";
+        if (w.size() != (list ? 5u : 3u))
+            return "Malformed property line";
+        const std::string *spell[2] = {&w[list ? 3 : 1], list ? &w[2] : nullptr};
+        const TypeRow **slot[2] = {&value, &length};
+        for (int k = 1; k >= 0; k--)                    /* the count type is complained about first */
+            if (spell[k] != nullptr && (*slot[k] = findType(*spell[k])) == nullptr)
+                return "Unknown type `" + *spell[k] + "'";
+        if (length != nullptr && !length->integral)
+            return "List cannot have floating-point count";
+        name = w.back();
+        return "";
+    }
+};
+
+std::string foldFormat(HeaderScan &h, const Words &w)
+{
+    static const struct { const char *encoding, *complaint; } refused[] = {
+        {"ascii", "PLY ASCII format not supported"},
+        {"binary_big_endian", "PLY big endian format not supported on this CPU"},
+    };
+    if (w.size() != 3)
+        return "Malformed format line";
+    for (const auto &no : refused)
+        if (w[1] == no.encoding)
+            return no.complaint;
+    if (w[1] != "binary_little_endian")
+        return "Unknown PLY format " + w[1];
+    if (w[2] != "1.0")
+        return "Unknown PLY version " + w[2];
+    h.format = true;
+    return "";
+}
+
+std::string foldElement(HeaderScan &h, const Words &w)
+{
+    if (w.size() != 3)
+        return "Malformed element line";
+    /* a count is decimal digits that fit 64 bits, nothing else (boost::lexical_cast<size_type> in the reference) */
+    uint64_t count = 0;
+    bool fits = !w[2].empty() && w[2].find_first_not_of("0123456789") == std::string::npos;
+    for (size_t i = 0; fits && i < w[2].size(); i++)
+    {
+        const uint64_t digit = (uint64_t) (w[2][i] - '0');
+        fits = count <= (UINT64_MAX - digit) / 10;
+        count = count * 10 + digit;
+    }
+    if (!fits)
+        return "Malformed element line or too many elements";
+    if (h.declared == 0)
+    {
+        if (w[1] != "vertex")
+            return "First element is not vertex";
+        h.vertexCount = count;
+    }
+    h.declared++;
+    return "";
+}
+
+std::string foldProperty(HeaderScan &h, const Words &w)
+{
+    PropertyDecl p;
+    const std::string bad = p.parse(w);
+    if (!bad.empty())
+        return bad;
+    if (h.declared == 0)
+        return "Property `" + p.name + "' appears before any element declaration";
+    if (h.declared != 1)
+        return "";                                      /* another element's: nothing to lay out */
+    if (p.length != nullptr)
+        return "Lists in a vertex are not supported";
+    const int which = (int) (std::find(HeaderScan::wanted, HeaderScan::wanted + NUM_PROPERTIES, p.name) - HeaderScan::wanted);
+    if (which < NUM_PROPERTIES)
+    {
+        if (h.found >> which & 1)
+            return "Duplicate property " + p.name;
+        if (p.value->type != FLOAT32)
+            return "Property " + p.name + " must be FLOAT32";
+        h.found |= 1u << which;
+        h.offsets[which] = h.vertexSize;
+    }
+    h.vertexSize += p.value->bytes;
+    return "";
+}
+
+const struct { const char *keyword; std::string (*fold)(HeaderScan &, const Words &); } headerLines[] = {
+    {"format", foldFormat}, {"element", foldElement}, {"property", foldProperty},
+};
+
 int readHeader(mlsgpu_ply_reader &r)
 {
-    static const char *const names[NUM_PROPERTIES] = {"x", "y", "z", "nx", "ny", "nz", "radius"};
-    bool have[NUM_PROPERTIES] = {false, false, false, false, false, false, false};
-    uint64_t elements = 0;
-    bool haveFormat = false;
+    HeaderScan h;
     std::string line;
-    auto getLine = [&]() -> bool { return (bool) std::getline(r.in, line); };
-    if (!getLine() || line != "ply")
+    if (!std::getline(r.in, line) || line != "ply")
         return formatError(r, "PLY signature missing");
-    while (true)
+    for (bool ended = false; !ended;)
     {
-        if (!getLine())
+        if (!std::getline(r.in, line))
             return formatError(r, "End of file in PLY header");
-        std::istringstream split(line);
-        std::vector<std::string> tokens;
-        for (std::string t; split >> t;)
-            tokens.push_back(t);
-        if (tokens.empty())
+        std::istringstream cut(line);
+        const Words w{std::istream_iterator<std::string>(cut), std::istream_iterator<std::string>()};
+        if (w.empty())
             continue;
-        if (tokens[0] == "end_header")
-            break;
-        if (tokens[0] == "format")
-        {
-            if (tokens.size() != 3)
-                return formatError(r, "Malformed format line");
-            if (tokens[1] == "ascii")
-                return formatError(r, "PLY ASCII format not supported");
-            if (tokens[1] == "binary_big_endian")
-                return formatError(r, "PLY big endian format not supported on this CPU");
-            if (tokens[1] != "binary_little_endian")
-                return formatError(r, "Unknown PLY format " + tokens[1]);
-            if (tokens[2] != "1.0")
-                return formatError(r, "Unknown PLY version " + tokens[2]);
-            haveFormat = true;
-        }
-        else if (tokens[0] == "element")
-        {
-            if (tokens.size() != 3)
-                return formatError(r, "Malformed element line");
-            /* boost::lexical_cast<size_type>: decimal digits only, no overflow */
-            const std::string &c = tokens[2];
-            uint64_t count = 0;
-            bool ok = !c.empty();
-            for (char ch : c)
+        ended = w[0] == "end_header";
+        for (const auto &row : headerLines)
+            if (w[0] == row.keyword)
             {
-                if (ch < '0' || ch > '9' || count > (UINT64_MAX - (uint64_t) (ch - '0')) / 10)
-                {
-                    ok = false;
-                    break;
-                }
-                count = count * 10 + (uint64_t) (ch - '0');
+                const std::string complaint = row.fold(h, w);
+                if (!complaint.empty())
+                    return formatError(r, complaint);
             }
-            if (!ok)
-                return formatError(r, "Malformed element line or too many elements");
-            if (elements == 0)
-            {
-                if (tokens[1] != "vertex")
-                    return formatError(r, "First element is not vertex");
-                r.vertexCount = count;
-            }
-            elements++;
-        }
-        else if (tokens[0] == "property")
-        {
-            if (tokens.size() < 3)
-                return formatError(r, "Malformed property line");
-            bool isList = false;
-            FieldType valueType;
-            std::string name;
-            if (tokens[1] == "list")
-            {
-                if (tokens.size() != 5)
-                    return formatError(r, "Malformed property line");
-                isList = true;
-                const FieldType lengthType = parseType(tokens[2]);
-                valueType = parseType(tokens[3]);
-                if (lengthType == BAD_TYPE)
-                    return formatError(r, "Unknown type `" + tokens[2] + "'");
-                if (valueType == BAD_TYPE)
-                    return formatError(r, "Unknown type `" + tokens[3] + "'");
-                if (lengthType == FLOAT32 || lengthType == FLOAT64)
-                    return formatError(r, "List cannot have floating-point count");
-                name = tokens[4];
-            }
-            else
-            {
-                if (tokens.size() != 3)
-                    return formatError(r, "Malformed property line");
-                valueType = parseType(tokens[1]);
-                if (valueType == BAD_TYPE)
-                    return formatError(r, "Unknown type `" + tokens[1] + "'");
-                name = tokens[2];
-            }
-            if (elements == 0)
-                return formatError(r, "Property `" + name + "' appears before any element declaration");
-            if (elements == 1)
-            {
-                if (isList)
-                    return formatError(r, "Lists in a vertex are not supported");
-                for (int i = 0; i < NUM_PROPERTIES; i++)
-                    if (name == names[i])
-                    {
-                        if (have[i])
-                            return formatError(r, "Duplicate property " + name);
-                        if (valueType != FLOAT32)
-                            return formatError(r, "Property " + name + " must be FLOAT32");
-                        have[i] = true;
-                        r.offsets[i] = r.vertexSize;
-                        break;
-                    }
-                r.vertexSize += fieldSize(valueType);
-            }
-        }
-        /* other header lines (comment, obj_info, ...) are skipped, as by the reference's reader */
     }
-    if (!haveFormat)
+    if (!h.format)
         return formatError(r, "No format line found");
-    if (elements < 1)
+    if (h.declared == 0)
         return formatError(r, "No elements found");
     for (int i = 0; i < NUM_PROPERTIES; i++)
-        if (!have[i])
-            return formatError(r, std::string("Property ") + names[i] + " not found");
+        if (!(h.found >> i & 1))
+            return formatError(r, std::string("Property ") + HeaderScan::wanted[i] + " not found");
+    r.vertexCount = h.vertexCount;
+    r.vertexSize = h.vertexSize;
+    std::copy(h.offsets, h.offsets + NUM_PROPERTIES, r.offsets);
     r.headerSize = (uint64_t) r.in.tellg();
     return MLSGPU_OK;
 }

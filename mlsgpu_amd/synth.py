@@ -284,6 +284,25 @@ def grid_buckets(dims, max_cells=255, runs=None):
     return out
 
 
+SLAB = 128     # corner slices per GPU of the sharded cfg4 workload (bench.py --gpus N)
+
+
+def slab_boxes(grid, world, rank, slab=SLAB):
+    """Rank `rank`'s buckets when the first `world` slabs of a grid x grid x ... cloud are dealt one per GPU: the grid
+    is grid x grid x (slab * world) corners, cut `world` ways along z (all slabs but the last have `slab` cell slices,
+    the last slab - 1), each slab cut into 255-cell runs along x and y."""
+    boxes = grid_buckets((grid, grid, slab * world), 255, runs=(0, 0, world))
+    per = len(boxes) // world
+    assert per * world == len(boxes)
+    return boxes[rank * per:(rank + 1) * per]
+
+
+def slab_variant(world, rank):
+    """A slab's geometry depends on the job only through being its last slab or not: "last" (slab - 1 cell slices: the
+    grid ends there) or "inner" (slab cell slices, the next slab starts on its top corner slice)."""
+    return "last" if rank == world - 1 else "inner"
+
+
 def bucketize_device(cloud, boxes):
     """bucketize() for a cloud resident on a torch device and an explicit list of boxes [(low, num_vertices)] (a
     rank's share of grid_buckets): every box receives, in global order, all splats whose bounding box [p - r, p + r]

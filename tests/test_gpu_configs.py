@@ -4,8 +4,10 @@ cfg3  512^3 grid, 50 M uniform splats, 27 buckets: the cloud bench.py times.  Or
       face, centre), size-independent properties on all 27 (bucket tiling, cross-bucket agreement of shared vertices bit
       for bit, key multiplicity), and the totals + digest that bench.py prints for its timed passes, pinned in
       tests/golden/cfg3_uniform.json.
-cfg4s rank 0's slab of the sharded cfg4 cloud at FULL density (what bench.py --gpus N runs on every GPU): totals + digest
-      pinned in tests/golden/cfg4slab_uniform.json, which bench.py compares at N > 1 as it does cfg3 at N = 1.
+cfg4s ALL EIGHT slabs of the sharded cfg4 cloud at FULL density (what bench.py --gpus N runs, one slab per GPU), one after
+      the other on this GPU, as an inner and as a last slab: totals + digest of every rank of an N = 2 / 4 / 8 job pinned in
+      tests/golden/cfg4slab_uniform.json (bench.py compares every rank's digest with its pin), oracle bit-parity on a
+      bucket of slabs 0, 3 and 7, and the seven slab seams bit-identical from both sides.
 cfg5  2048^3 grid, 10^9 splats (a smaller count only if the box lacks the RAM) written as 8 PLY files by the device
       generator -> FileSet reader threads -> HBM -> Bucket::bucket on the device -> eight device groups by device-side
       gathers: partition properties on all ~730 buckets, oracle bit-parity on three leaves, cross-bucket agreement on a
@@ -22,6 +24,7 @@ import numpy as np
 import pytest
 
 import oracle_binding as ob
+from conftest import record_size
 from gpu_common import assert_batches_equal, ctx  # noqa: F401
 
 pytestmark = pytest.mark.gpu
@@ -74,6 +77,7 @@ def test_cfg3_full_size(ctx):
     dev = torch.device("cuda", 0)
     cloud, g = synth.make_cloud_device("cfg3", dev)
     assert len(cloud) == 50_000_000 and g == 512
+    record_size("cfg3", "%d splats, 27 buckets" % len(cloud))
     bucketed, buckets = synth.bucketize_device(cloud, synth.grid_buckets((g, g, g), 255))
     del cloud
     torch.cuda.synchronize()
@@ -220,52 +224,98 @@ def test_cfg4_shape_eight_device_groups():
 
 
 def test_cfg4_slab_full_density(ctx):
-    """The per-GPU unit of bench.py --gpus N: slab 0 (128 corner slices, 25 buckets) of BASELINE configs[3]'s 200 M-splat
-    uniform cloud, generated in HBM exactly as bench.py does.  Totals and digest are pinned; oracle bit-parity on the
-    corner bucket."""
+    """The per-GPU units of bench.py --gpus N: ALL EIGHT slabs (128 corner slices, 25 buckets each) of BASELINE
+    configs[3]'s 200 M-splat uniform cloud at full density, one after the other on this GPU, generated in HBM exactly as
+    bench.py does.  A slab's geometry depends on the job only through being its last slab (127 cell slices) or not
+    (128): both variants of every slab are run, so every rank of an N = 2 / 4 / 8 job (and the one-slab N = 1 workload)
+    has its totals and digest pinned in tests/golden/cfg4slab_uniform.json -- bench.py compares every rank's digest with
+    them.  Oracle bit-parity on a bucket of slabs 0, 3 and 7; every one of the seven seams of the eight-GPU job checked:
+    the external vertices two neighbouring slabs share (equal keys) are bit-identical from both sides."""
     import torch
     import mlsgpu_amd as m
     from mlsgpu_amd import binding as mb, synth
     dev = torch.device("cuda", 0)
     cloud, g = synth.make_cloud_device("cfg4", dev)
     assert len(cloud) == 200_000_000 and g == 1024
-    slab = 128
-    boxes = synth.grid_buckets((g, g, slab * 8), 255, runs=(0, 0, 8))
-    per = len(boxes) // 8
-    bucketed, buckets = synth.bucketize_device(cloud, boxes[:per])
-    del cloud
-    torch.cuda.synchronize()
-    assert len(buckets) == 25 and sum(b.cells for b in buckets) == 1023 * 1023 * (buckets[0].num_vertices[2] - 1)
-    max_cells = max(max(b.num_vertices) for b in buckets) - 1
-    max_count = max(b.count for b in buckets)
-    nbytes = bucketed.numel() * 4
-    pristine = m.DeviceBuffer(ctx, nbytes=nbytes, borrow=bucketed.data_ptr())
-    work = m.DeviceBuffer(ctx, nbytes=nbytes)
-    w = m.Worker(ctx, max_count, max_cells=max_cells, mesh_memory=4096 << 20)
-    work.copy_from(pristine)
-    col = mb.ChecksumCollector(ctx)
-    for b in buckets:
-        w.process(work, b.first, b.count, b.low, b.num_vertices, collector=col)
-    got = dict(splats=int(bucketed.shape[0]), triangles=int(col.triangles), vertices=int(col.vertices),
-               external=int(col.external), shipouts=col.batches, digest=col.digest())
+    record_size("cfg4 slabs", "8 slabs x 2 variants of the %d-splat cloud at full density" % len(cloud))
     path = os.path.join(os.path.dirname(GOLDEN), "cfg4slab_uniform.json")
-    if os.environ.get("MLSGPU_WRITE_GOLDEN"):
+    writing = bool(os.environ.get("MLSGPU_WRITE_GOLDEN"))
+    pinned = {} if writing else json.load(open(path))["slabs"]
+    got_all = {}
+    seam = {}                    # slab -> (keys, vertices) of the externals on its bottom / top corner slices (8-GPU job)
+    parity = {0: 0, 3: 12, 7: 24}     # slab -> bucket for the oracle (a corner, the centre, the far corner)
+    work = None
+    for r in range(8):
+        for variant, world in (("inner", 8), ("last", r + 1)):
+            if synth.slab_variant(world, r) != variant:
+                continue                                           # slab 7 of 8 is a last slab only
+            boxes = synth.slab_boxes(g, world, r)
+            bucketed, buckets = synth.bucketize_device(cloud, boxes)
+            torch.cuda.synchronize()
+            cz = buckets[0].num_vertices[2] - 1
+            assert len(buckets) == 25 and cz == (127 if variant == "last" else 128) and buckets[0].low[2] == 128 * r
+            assert sum(b.cells for b in buckets) == 1023 * 1023 * cz
+            max_cells = max(max(b.num_vertices) for b in buckets) - 1
+            max_count = max(b.count for b in buckets)
+            nbytes = bucketed.numel() * 4
+            pristine = m.DeviceBuffer(ctx, nbytes=nbytes, borrow=bucketed.data_ptr())
+            if work is None or work.nbytes < nbytes:
+                work = m.DeviceBuffer(ctx, nbytes=nbytes + (64 << 20))
+            w = m.Worker(ctx, max_count, max_cells=max_cells, mesh_memory=4096 << 20)
+            work.copy_from(pristine, nbytes)
+            in_job = world == 8                                    # the eight-GPU job's slabs feed the seam check
+            col = mb.ExternalCollector(ctx) if in_job else mb.ChecksumCollector(ctx)
+            for b in buckets:
+                w.process(work, b.first, b.count, b.low, b.num_vertices, collector=col)
+            assert col.error is None
+            got = dict(splats=int(bucketed.shape[0]), triangles=int(col.triangles), vertices=int(col.vertices),
+                       external=int(col.external), shipouts=col.batches, digest=col.digest())
+            got_all.setdefault(str(r), {})[variant] = got
+            if not writing:
+                assert got == pinned[str(r)][variant], (r, variant, got, pinned[str(r)][variant])
+            if in_job:
+                keys = np.concatenate(col.ext_keys)
+                verts = np.concatenate(col.ext_vertices).view(np.uint32)
+                z2 = (keys >> np.uint64(42)) & np.uint64((1 << 21) - 1)      # half-lattice z of the welding key
+                edge = (z2 == np.uint64(256 * r)) | (z2 == np.uint64(256 * (r + 1)))
+                seam[r] = (keys[edge], verts[edge])
+                del keys, verts, col
+            if in_job and r in parity:
+                b = buckets[parity[r]]
+                host = bucketed[b.first:b.first + b.count].cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
+                del w
+                mm = 1 << 30
+                w = m.Worker(ctx, max_count, max_cells=max_cells, mesh_memory=mm)
+                work.copy_from(pristine, nbytes)
+                batches = w.process(work, b.first, b.count, b.low, b.num_vertices)
+                exp_b, st = ob.bucket(host, 0, b.count, b.num_vertices, b.low, max_cells=max_cells, max_swathe=max_cells + 1,
+                                      mesh_memory=mm)
+                assert st["shipouts"] == len(batches) >= 1
+                assert_batches_equal(batches, exp_b)
+                del batches, exp_b
+            del w, pristine, bucketed
+    # ---- the seven seams: what slab r emits on its top corner slice and slab r + 1 on its bottom one ----
+    for r in range(7):
+        z = np.uint64(256 * (r + 1))
+        lo_k, lo_v = seam[r]
+        hi_k, hi_v = seam[r + 1]
+        sel = ((lo_k >> np.uint64(42)) & np.uint64((1 << 21) - 1)) == z
+        a_k, a_v = lo_k[sel], lo_v[sel]
+        sel = ((hi_k >> np.uint64(42)) & np.uint64((1 << 21) - 1)) == z
+        b_k, b_v = hi_k[sel], hi_v[sel]
+        # a slab's own buckets share edges of the seam plane: one copy of every key per side
+        a_k, ia = np.unique(a_k, return_index=True)
+        b_k, ib = np.unique(b_k, return_index=True)
+        # (a cell with a non-finite corner emits nothing, so a seam vertex may come from one side only: the shared ones count)
+        both, ja, jb = np.intersect1d(a_k, b_k, assume_unique=True, return_indices=True)
+        assert len(both) > 100_000 and len(both) > 0.9 * max(len(a_k), len(b_k)), (r, len(a_k), len(b_k), len(both))
+        assert np.array_equal(a_v[ia][ja], b_v[ib][jb]), r                                   # the same vertices, bit for bit
+    if writing:
         out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "cfg4slab_uniform.json")
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        json.dump(got, open(out, "w"), indent=1)
-    else:
-        exp = json.load(open(path))
-        assert got == {k: exp[k] for k in got}, (got, exp)
-    b = buckets[0]
-    host = bucketed[b.first:b.first + b.count].cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
-    del w
-    mm = 1 << 30
-    w = m.Worker(ctx, max_count, max_cells=max_cells, mesh_memory=mm)
-    work.copy_from(pristine)
-    batches = w.process(work, b.first, b.count, b.low, b.num_vertices)
-    exp_b, st = ob.bucket(host, 0, b.count, b.num_vertices, b.low, max_cells=max_cells, max_swathe=max_cells + 1, mesh_memory=mm)
-    assert st["shipouts"] == len(batches) >= 1
-    assert_batches_equal(batches, exp_b)
+        doc = dict(got_all["0"]["inner"])
+        doc["slabs"] = got_all
+        json.dump(doc, open(out, "w"), indent=1)
 
 
 def cfg5_count():
@@ -289,6 +339,8 @@ def test_cfg5_full_shape_from_files():
     import mlsgpu_amd as m
     from mlsgpu_amd import binding as mb, farm as fm, synth
     n = cfg5_count()
+    record_size("cfg5", "%d splats%s" % (n, "" if n == 1_000_000_000 else " (NOT the full 10^9: the box lacks the RAM / "
+                                                                          "/dev/shm for 28 GB of files, or MLSGPU_CFG5_SPLATS is set)"))
     g = synth.CONFIGS["cfg5"]["grid"]
     assert g == 2048
     dev = torch.device("cuda", 0)
