@@ -281,7 +281,10 @@ typedef struct mlsgpu_worker_config
 
 int mlsgpu_hip_worker_create(mlsgpu_ctx *ctx, const mlsgpu_worker_config *cfg, mlsgpu_worker **out);
 void mlsgpu_hip_worker_destroy(mlsgpu_worker *w);
+/* DeviceWorkerGroup::resourceUsage (src/workers.cpp:184-205) per worker with ONE lane, without the item pool; a worker that
+ * takes `lanes` buckets in lock-step (mlsgpu_hip_worker_set_batch) holds _lanes(cfg, lanes) = lanes times that. */
 uint64_t mlsgpu_hip_worker_resource_usage(const mlsgpu_worker_config *cfg);
+uint64_t mlsgpu_hip_worker_resource_usage_lanes(const mlsgpu_worker_config *cfg, uint32_t lanes);
 /* One SubItem of a WorkItem (src/workers.cpp:235-285): lowExtent = sub.grid.getExtent(i).first,
  * numVertices = sub.grid.numVertices(i).  dSplats is the WorkItem's device splat buffer. */
 int mlsgpu_hip_worker_process(mlsgpu_worker *w, mlsgpu_splat *dSplats, uint64_t firstSplat, uint64_t numSplats,
@@ -310,6 +313,10 @@ uint32_t mlsgpu_hip_worker_marching_group(const mlsgpu_worker *w);
  * with the bucket's index in `items`. */
 int mlsgpu_hip_worker_process_batch(mlsgpu_worker *w, mlsgpu_splat *dSplats, const mlsgpu_subitem *items, uint32_t numItems,
                                     mlsgpu_batch_output_fn output, void *outputUser);
+/* How many leading items of the last _process_batch call had delivered all their meshes when it returned (numItems after a
+ * success; after a failure in mid-batch the rest of the items were not processed): src/workers.cpp:281-284 accounts per
+ * bucket, and so can a caller of the batch. */
+uint32_t mlsgpu_hip_worker_batch_completed(const mlsgpu_worker *w);
 mlsgpu_tree *mlsgpu_hip_worker_lane_tree(mlsgpu_worker *w, uint32_t lane);
 mlsgpu_marching *mlsgpu_hip_worker_lane_marching(mlsgpu_worker *w, uint32_t lane);
 /* keep = 1: the worker does not modify dSplats (non-mutating tree build + raw-radius processCorners, see

@@ -412,6 +412,7 @@ struct mlsgpu_worker
     mlsgpu_batch_output_fn batchOutput = nullptr;
     void *batchOutputData = nullptr;
     uint32_t batchBase = 0;                 /* index of the first bucket of the group that is being processed */
+    uint32_t batchCompleted = 0;            /* leading buckets of the last batch call with all their meshes delivered */
 };
 
 static void resolveConfig(mlsgpu_worker_config &c)
@@ -435,6 +436,11 @@ MLSGPU_API uint64_t mlsgpu_hip_worker_resource_usage(const mlsgpu_worker_config 
     const uint32_t block = c.maxCells + 1;
     return mlsgpu_hip_marching_resource_usage(block, block, roundUp(block, 8), c.maxSwathe, c.meshMemory, wgs)
         + mlsgpu_hip_tree_resource_usage(c.levels, c.maxBucketSplats);
+}
+
+MLSGPU_API uint64_t mlsgpu_hip_worker_resource_usage_lanes(const mlsgpu_worker_config *cfg, uint32_t lanes)
+{
+    return mlsgpu_hip_worker_resource_usage(cfg) * std::max(lanes, 1u);
 }
 
 static void destroyLane(WorkerLane &l)
@@ -577,14 +583,15 @@ MLSGPU_API int mlsgpu_hip_worker_process(mlsgpu_worker *w, mlsgpu_splat *dSplats
     w->userOutputData = outputUser;
     int pend = -1;
     if (w->ctx->timing) pend = w->ctx->beginTiming(w->ctx->statId("device.compute"));
-    PROPAGATE(mlsgpu_hip_tree_build(l.tree, dSplats, firstSplat, numSplats, expanded, lowExtent, w->cfg.subsampling));
-    PROPAGATE(mlsgpu_hip_mls_set(l.mls, lowExtent, l.tree, w->cfg.subsampling));
+    /* a failing step skips the rest, never the end of the timing region or the release of the borrowed splats */
     mlsgpu_generator gen;
-    PROPAGATE(mlsgpu_hip_mls_generator(l.mls, &gen));
-    PROPAGATE(mlsgpu_hip_marching_generate(l.marching, &gen, workerOutput, w, size, keyOffset));
+    int rc = mlsgpu_hip_tree_build(l.tree, dSplats, firstSplat, numSplats, expanded, lowExtent, w->cfg.subsampling);
+    if (rc == MLSGPU_OK) rc = mlsgpu_hip_mls_set(l.mls, lowExtent, l.tree, w->cfg.subsampling);
+    if (rc == MLSGPU_OK) rc = mlsgpu_hip_mls_generator(l.mls, &gen);
+    if (rc == MLSGPU_OK) rc = mlsgpu_hip_marching_generate(l.marching, &gen, workerOutput, w, size, keyOffset);
     if (pend >= 0) w->ctx->endTiming(pend);
     mlsgpu_hip_tree_clear_splats(l.tree);
-    return MLSGPU_OK;
+    return rc;
 }
 
 /*
@@ -606,8 +613,10 @@ MLSGPU_API int mlsgpu_hip_worker_process_batch(mlsgpu_worker *w, mlsgpu_splat *d
     }
     w->batchOutput = output;
     w->batchOutputData = outputUser;
+    w->batchCompleted = 0;
     const uint32_t width = (uint32_t) w->lanes.size();
-    for (uint32_t base = 0; base < numItems; base += width)
+    int rc = MLSGPU_OK;
+    for (uint32_t base = 0; base < numItems && rc == MLSGPU_OK; base += width)
     {
         const uint32_t count = std::min(width, numItems - base);
         w->batchBase = base;
@@ -633,33 +642,43 @@ MLSGPU_API int mlsgpu_hip_worker_process_batch(mlsgpu_worker *w, mlsgpu_splat *d
                 builds[k].size[a] = roundUp(it.numVertices[a], 8);
                 builds[k].offset[a] = it.lowExtent[a];
             }
-            if (k > 0)
-                PROPAGATE(mlsgpu_hip_mls_copy_settings(l.mls, w->lanes[0].mls));
+            if (k > 0 && rc == MLSGPU_OK)
+                rc = mlsgpu_hip_mls_copy_settings(l.mls, w->lanes[0].mls);
         }
+        /* a failing step skips the rest of the batch, never the end of the timing region or the release of the borrowed
+         * splats; batchCompleted tells the caller how many leading buckets had delivered all their meshes by then */
         int pend = -1;
         if (w->ctx->timing) pend = w->ctx->beginTiming(w->ctx->statId("device.compute"));
-        PROPAGATE(mlsgpu_hip_tree_build_batch(trees, builds, count, w->cfg.subsampling));
-        for (uint32_t k = 0; k < count; k++)
+        if (rc == MLSGPU_OK)
+            rc = mlsgpu_hip_tree_build_batch(trees, builds, count, w->cfg.subsampling);
+        for (uint32_t k = 0; k < count && rc == MLSGPU_OK; k++)
         {
-            PROPAGATE(mlsgpu_hip_mls_set(w->lanes[k].mls, items[base + k].lowExtent, w->lanes[k].tree, w->cfg.subsampling));
-            PROPAGATE(mlsgpu_hip_mls_generator(w->lanes[k].mls, &gens[k]));
+            rc = mlsgpu_hip_mls_set(w->lanes[k].mls, items[base + k].lowExtent, w->lanes[k].tree, w->cfg.subsampling);
+            if (rc == MLSGPU_OK)
+                rc = mlsgpu_hip_mls_generator(w->lanes[k].mls, &gens[k]);
         }
         /* the octree of all `count` buckets in one set of launches, processCorners and marching `marchingGroup` buckets at a
          * time (mlsgpu_hip_worker_set_marching_group) */
         const uint32_t sub = w->marchingGroup != 0 ? std::min(w->marchingGroup, count) : count;
-        for (uint32_t k0 = 0; k0 < count; k0 += sub)
+        for (uint32_t k0 = 0; k0 < count && rc == MLSGPU_OK; k0 += sub)
         {
             const uint32_t n = std::min(sub, count - k0);
             w->batchBase = base + k0;
-            PROPAGATE(mlsgpu_hip_marching_generate_batch(marchings + k0, gens + k0, n, workerBatchOutput, w, sizes + 3 * k0,
-                                                         keyOffsets + 3 * k0));
+            rc = mlsgpu_hip_marching_generate_batch(marchings + k0, gens + k0, n, workerBatchOutput, w, sizes + 3 * k0,
+                                                    keyOffsets + 3 * k0);
+            if (rc == MLSGPU_OK)
+                w->batchCompleted = base + k0 + n;
         }
         if (pend >= 0) w->ctx->endTiming(pend);
         for (uint32_t k = 0; k < count; k++)
             mlsgpu_hip_tree_clear_splats(w->lanes[k].tree);
     }
-    return MLSGPU_OK;
+    return rc;
 }
+
+/* Of the last mlsgpu_hip_worker_process_batch call's items, how many leading ones had delivered all their meshes when it
+ * returned (numItems after a success): what a caller that accounts per bucket needs after a failure in mid-batch. */
+MLSGPU_API uint32_t mlsgpu_hip_worker_batch_completed(const mlsgpu_worker *w) { return w ? w->batchCompleted : 0; }
 
 /* DeviceWorkerGroup's item buffer is rewritten by every H2D copy, so nothing downstream reads the splats the build has
  * mutated; a caller whose splats are RESIDENT (several passes over the same buffer) keeps them intact with this: the tree

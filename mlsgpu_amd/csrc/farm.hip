@@ -349,6 +349,7 @@ void workerMain(Farm *farm, DeviceGroup *g)
         if (ctx) mlsgpu_hip_ctx_destroy(ctx);
         ctx = nullptr;
     }
+    bool lanesRefused = false;          /* the device had no room for the lanes of a batch: bucket by bucket from then on */
     for (;;)
     {
         /* One item, or -- with lanes -- as many queued items as fit a batch: device-side leaves arrive one bucket per item
@@ -387,11 +388,22 @@ void workerMain(Farm *farm, DeviceGroup *g)
         size_t numSubs = 0;
         for (WorkItem *item : taken)
             numSubs += item->subItems.size();
-        if (run && e == hipSuccess && lanes > 1 && numSubs > 1)
+        /* the lanes' buffers (a tree, a field, a lattice and a mesh arena each) are allocated on first use; a device that
+         * cannot hold them keeps the worker on the bucket-by-bucket path instead of failing the farm */
+        bool batched = run && e == hipSuccess && lanes > 1 && numSubs > 1 && !lanesRefused;
+        if (batched && mlsgpu_hip_worker_batch(worker) < lanes)
+        {
+            rc = mlsgpu_hip_worker_set_batch(worker, lanes);
+            if (rc == MLSGPU_ERR_NOMEM)
+                lanesRefused = true, batched = false;
+            else if (rc != MLSGPU_OK)
+                farm->fail(rc, mlsgpu_hip_last_error()), batched = false, run = false;
+        }
+        if (batched)
         {
             /* the SubItems `lanes` at a time through ONE set of launches (mlsgpu_hip_worker_process_batch); meshes still
              * arrive bucket by bucket, in order */
-            rc = mlsgpu_hip_worker_set_batch(worker, lanes);
+            rc = MLSGPU_OK;
             std::vector<mlsgpu_subitem> subs;
             BatchThunk thunk = {farm, g, ctx, {}};
             for (WorkItem *item : taken)
@@ -413,19 +425,20 @@ void workerMain(Farm *farm, DeviceGroup *g)
                 rc = mlsgpu_hip_worker_process_batch(worker, nullptr, subs.data(), (uint32_t) subs.size(), batchOutputThunk, &thunk);
             if (rc != MLSGPU_OK)
                 farm->fail(rc, mlsgpu_hip_last_error());
-            else
-            {
-                std::lock_guard<std::mutex> l(farm->mutex);
-                for (size_t t = 0; t < taken.size(); t++)
+            /* per bucket, as src/workers.cpp:281-284: after a failure in mid-batch the buckets that had delivered all their
+             * meshes count as done, the others go back unprocessed below */
+            size_t done = rc == MLSGPU_OK ? subs.size() : mlsgpu_hip_worker_batch_completed(worker);
+            std::lock_guard<std::mutex> l(farm->mutex);
+            for (size_t t = 0; t < taken.size() && done > 0; t++)
+                for (const SubItem &sub : taken[t]->subItems)
                 {
-                    processed[t] = taken[t]->subItems.size();
-                    for (const SubItem &sub : taken[t]->subItems)
-                    {
-                        g->unallocated += sub.numSplats;         /* src/workers.cpp:281-284 */
-                        g->bucketsDone++;
-                    }
+                    if (done == 0)
+                        break;
+                    done--;
+                    processed[t]++;
+                    g->unallocated += sub.numSplats;
+                    g->bucketsDone++;
                 }
-            }
         }
         else
             for (size_t t = 0; t < taken.size(); t++)

@@ -698,8 +698,10 @@ MLSGPU_API uint64_t mlsgpu_hip_tree_resource_usage(uint64_t maxLevels, uint64_t 
     uint64_t maxStart, commandsSize;
     treeSizes(maxLevels, maxSplats, &maxStart, &commandsSize);
     const uint64_t entries = maxSplats * 8;
+    /* start, jumpPos, node counts and bases; commands; keys and values x2; histogram, tile sums; slot masks; node tiles */
     return maxStart * 4 * 4 + commandsSize * 4 + entries * 4 * 4
-        + sortHistElems(entries) * 4 + (uint64_t) scanTiles(sortHistElems(entries) > entries ? sortHistElems(entries) : entries) * 4;
+        + sortHistElems(entries) * 4 + ((uint64_t) scanTiles(sortHistElems(entries) > entries ? sortHistElems(entries) : entries) + 1) * 4
+        + 4 + maxSplats + ((uint64_t) scanTiles(maxStart) + 1) * sizeof(U3);
 }
 
 MLSGPU_API int mlsgpu_hip_tree_create(mlsgpu_ctx *ctx, uint64_t maxLevels, uint64_t maxSplats, mlsgpu_tree **out)

@@ -370,13 +370,16 @@ public:
     }
     ~DeviceWorkerGroup() { if (!threads.empty()) stop(); }
 
+    /// src/workers.cpp:184-205.  `lanes`: what setBatch() will be given -- every worker then holds that many sets of tree,
+    /// field, lattice and mesh arena.
     static std::uint64_t resourceUsage(std::size_t numWorkers, std::size_t spare, std::size_t maxBucketSplats,
-                                       std::uint32_t maxCells, std::size_t meshMemory, int levels)
+                                       std::uint32_t maxCells, std::size_t meshMemory, int levels, std::uint32_t lanes = 1)
     {
         mlsgpu_worker_config c;
         std::memset(&c, 0, sizeof(c));
         c.maxBucketSplats = maxBucketSplats; c.maxCells = maxCells; c.meshMemory = meshMemory; c.levels = levels;
-        return mlsgpu_hip_worker_resource_usage(&c) * numWorkers + maxBucketSplats * sizeof(Splat) * (numWorkers + spare);
+        return mlsgpu_hip_worker_resource_usage_lanes(&c, lanes) * numWorkers
+            + maxBucketSplats * sizeof(Splat) * (numWorkers + spare);
     }
 
     /// start(fullGrid): spacing and world position of vertex (0,0,0) feed ScaleBiasFilter (src/workers.cpp:124-128,227-230)

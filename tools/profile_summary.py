@@ -116,13 +116,15 @@ def traffic(fetch_dir, write_dir, out):
             n = max(calls.get(k, 0), wcalls.get(k, 0), 1)
             f.write('"%s",%d,%.1f,%.1f,%.0f,%.0f\n' % (k, n, fetch.get(k, 0), write.get(k, 0),
                                                        2 * 1024 * fetch.get(k, 0) / n, 1024 * write.get(k, 0) / n))
-    per_launch = {}
+    per_launch, per_pass = {}, {}
     for label, needle in TRACKED.items():
         fk = [k for k in names if needle in k]
         if not fk:
             continue
         n = sum(max(calls.get(k, 0), wcalls.get(k, 0)) for k in fk)
-        per_launch[label] = int((2 * 1024 * sum(fetch.get(k, 0) for k in fk) + 1024 * sum(write.get(k, 0) for k in fk)) / max(n, 1))
+        moved = 2 * 1024 * sum(fetch.get(k, 0) for k in fk) + 1024 * sum(write.get(k, 0) for k in fk)
+        per_launch[label] = int(moved / max(n, 1))
+        per_pass[label] = int(moved / PMC_PASSES_OF.get(label, PMC_PASSES))
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     doc = json.load(open(tpath)) if os.path.exists(tpath) else {}
     doc["cfg3/uniform"] = per_launch
