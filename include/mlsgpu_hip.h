@@ -520,6 +520,11 @@ int mlsgpu_hip_mesher_stats(mlsgpu_mesher *mesher, uint64_t out[8]);
  *      buffer; chunk ids may arrive interleaved.  add() is serialised by an internal mutex. ---- */
 typedef struct mlsgpu_host_mesher mlsgpu_host_mesher;
 int mlsgpu_hip_host_mesher_create(mlsgpu_host_mesher **out);
+/* The welders' memory is mapped in slabs that the PROCESS keeps when a welder is destroyed (up to 16 GiB, or
+ * MLSGPU_HIP_WELDER_CACHE_MB), because freshly mapped memory faults in slowly; the memory a welder gets is uninitialised.
+ * _trim_cache sets that limit and returns what is held beyond it to the system at once (0: keep nothing); it returns the
+ * bytes released.  The reference's mesher allocates per job (src/mesher.cpp:220-306) and has no counterpart. */
+uint64_t mlsgpu_hip_host_mesher_trim_cache(uint64_t keepBytes);
 void mlsgpu_hip_host_mesher_destroy(mlsgpu_host_mesher *mesher);
 int mlsgpu_hip_host_mesher_set_prune_threshold(mlsgpu_host_mesher *mesher, double threshold);
 /* Threads of the welder: add() copies the block and queues its work (local components, key map: OOCMesher::add,

@@ -201,9 +201,11 @@ def lib():
     sig("mlsgpu_hip_worker_create", C.c_int, vp, P(WorkerConfig), P(vp))
     sig("mlsgpu_hip_worker_destroy", None, vp)
     sig("mlsgpu_hip_worker_resource_usage", u64, P(WorkerConfig))
+    sig("mlsgpu_hip_worker_resource_usage_lanes", u64, P(WorkerConfig), u32)
     sig("mlsgpu_hip_worker_process", C.c_int, vp, vp, u64, u64, vp, vp, OUTPUT_FN, vp)
     sig("mlsgpu_hip_worker_set_batch", C.c_int, vp, u32)
     sig("mlsgpu_hip_worker_batch", u32, vp)
+    sig("mlsgpu_hip_worker_batch_completed", u32, vp)
     sig("mlsgpu_hip_worker_set_marching_group", C.c_int, vp, u32)
     sig("mlsgpu_hip_worker_marching_group", u32, vp)
     sig("mlsgpu_hip_worker_process_batch", C.c_int, vp, vp, P(SubItem), u32, BATCH_OUTPUT_FN, vp)
@@ -231,6 +233,7 @@ def lib():
     sig("mlsgpu_hip_mesher_write_ply", C.c_int, vp, C.c_uint32, C.c_char_p, vp, C.c_uint32, u64)
     sig("mlsgpu_hip_farm_set_host_output", C.c_int, vp, u64, vp, vp)
     sig("mlsgpu_hip_farm_host_stats", C.c_int, vp, vp)
+    sig("mlsgpu_hip_host_mesher_trim_cache", u64, u64)
     sig("mlsgpu_hip_host_mesher_create", C.c_int, P(vp))
     sig("mlsgpu_hip_host_mesher_destroy", None, vp)
     sig("mlsgpu_hip_host_mesher_set_prune_threshold", C.c_int, vp, C.c_double)
@@ -1128,7 +1131,8 @@ class Worker:
         self.h = h
 
     def resource_usage(self):
-        return lib().mlsgpu_hip_worker_resource_usage(C.byref(self.cfg))
+        """Device bytes of the worker's buffers: one set per lane (set_batch)."""
+        return lib().mlsgpu_hip_worker_resource_usage_lanes(C.byref(self.cfg), max(1, lib().mlsgpu_hip_worker_batch(self.h)))
 
     def process(self, splats, first_splat, num_splats, low_extent, num_vertices, collector=None):
         col = collector or MeshCollector(self.ctx)

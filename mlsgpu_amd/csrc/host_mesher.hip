@@ -107,12 +107,45 @@ public:
         for (Slab &s : free)
             munmap(s.base, s.cap);
     }
+    /* how much mapped memory stays with the process between jobs; what is held beyond the new limit goes back now */
+    size_t setLimit(size_t bytes)
+    {
+        std::vector<Slab> drop;
+        {
+            std::lock_guard<std::mutex> l(mutex);
+            limit = bytes;
+            while (held > limit && !free.empty())
+            {
+                drop.push_back(free.back());
+                held -= free.back().cap;
+                free.pop_back();
+            }
+        }
+        size_t released = 0;
+        for (Slab &s : drop)
+        {
+            released += s.cap;
+            munmap(s.base, s.cap);
+        }
+        return released;
+    }
+    size_t getLimit()
+    {
+        std::lock_guard<std::mutex> l(mutex);
+        return limit;
+    }
 
 private:
+    SlabCache()
+    {
+        /* MLSGPU_HIP_WELDER_CACHE_MB: the limit of a process that cannot call mlsgpu_hip_host_mesher_trim_cache */
+        if (const char *e = getenv("MLSGPU_HIP_WELDER_CACHE_MB"))
+            limit = (size_t) strtoull(e, nullptr, 10) << 20;
+    }
     std::mutex mutex;
     std::vector<Slab> free;
     size_t held = 0;
-    const size_t limit = size_t(16) << 30;      /* mapped memory kept between jobs */
+    size_t limit = size_t(16) << 30;            /* mapped memory kept between jobs */
 };
 
 class Arena
@@ -583,6 +616,15 @@ void mlsgpu_host_mesher::processBlock(Block *b)
             s.unions.push_back(UnionRecord{clump, first});
         s.owners.note(key, b->chunk, Ref{b->seq, (uint32_t) (ni + i)});
     }
+}
+
+/* The welders' memory comes from mapped slabs that are kept, up to a limit (16 GiB, or MLSGPU_HIP_WELDER_CACHE_MB), when a
+ * welder is destroyed: a fresh mapping faults at ~1 GB/s per thread, a kept one is reused at once (but is NOT zero-filled:
+ * Arena memory is uninitialised).  This sets the limit and gives what is held beyond it back to the system; 0 = keep
+ * nothing.  Returns the bytes released. */
+MLSGPU_API uint64_t mlsgpu_hip_host_mesher_trim_cache(uint64_t keepBytes)
+{
+    return SlabCache::instance().setLimit((size_t) keepBytes);
 }
 
 MLSGPU_API int mlsgpu_hip_host_mesher_create(mlsgpu_host_mesher **out)

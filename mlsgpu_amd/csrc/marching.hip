@@ -1404,12 +1404,13 @@ __global__ __launch_bounds__(256) void latticeTrianglesRowKernel(Lanes<LatticeTr
             const uint32_t *const slots = &myIdx[16 * i][0];
             const uint32_t last = hi != lo ? hi - 1 : lo;
             uint32_t *const dstq = hi != lo ? out : trash - lo;
+            const uint32_t refMask = hi != lo ? 0xFFu : 0u;      /* an empty quarter's reference byte is stale: slot 0 then */
             uint32_t k[3], val[3];
 #pragma unroll
             for (int u = 0; u < 3; u++)
             {
                 k[u] = min(lo + 64 * u + lane, last);
-                val[u] = myRef[k[u]];
+                val[u] = myRef[k[u]] & refMask;
             }
 #pragma unroll
             for (int u = 0; u < 3; u++)

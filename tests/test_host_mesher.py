@@ -136,3 +136,33 @@ def test_thread_count_does_not_change_the_output(prune):
             np.testing.assert_array_equal(t0, t1)
         for x, y in zip(b0, b):
             np.testing.assert_array_equal(x, y)
+
+
+def test_slab_cache_can_be_trimmed():
+    """The process keeps the welders' mapped slabs between jobs; mlsgpu_hip_host_mesher_trim_cache gives them back
+    (a second job after the trim still welds the same mesh: reused or fresh slabs, the result does not depend on it)."""
+    import mlsgpu_amd as m
+    L = m.lib()
+    rng = np.random.default_rng(11)
+    v = rng.random((3000, 3)).astype(np.float32)
+    t = rng.integers(0, 3000, (5000, 3)).astype(np.uint32)
+    k = np.arange(1000, dtype=np.uint64)                      # the keys of the 1000 external vertices
+
+    def job():
+        w = m.HostMesher(0.0, threads=2)
+        w.add(0, v, 2000, k, t)
+        w.finalize()
+        out = w.chunk(0)
+        w.close()
+        return out
+    first = job()
+    released = L.mlsgpu_hip_host_mesher_trim_cache(0)
+    assert released > 0                                       # the job's slabs were being kept
+    assert L.mlsgpu_hip_host_mesher_trim_cache(0) == 0        # ... and are gone
+    job()
+    assert L.mlsgpu_hip_host_mesher_trim_cache(0) == 0        # limit 0: nothing is kept any more
+    L.mlsgpu_hip_host_mesher_trim_cache(16 << 30)
+    second = job()
+    assert L.mlsgpu_hip_host_mesher_trim_cache(16 << 30) == 0
+    for a, b in zip(first[1:], second[1:]):
+        assert np.array_equal(a, b)
