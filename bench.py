@@ -75,9 +75,10 @@ def parse_args():
                    help="device worker threads per GPU for the resident-input passes (round 3, cfg3 uniform: 1 / 2 / 3 / 4 / 6 workers "
                         "23.1 / 21.2-21.6 / 21.6-22.2 / 22.2-22.5 / 22.1 ms per step -- every kernel fills the GPU, a second worker "
                         "hides the host's gaps and more only interleave)")
-    p.add_argument("--farm-workers", type=int, default=4,
-                   help="device workers per GPU of the farm legs (host splats in, meshes out): transfers want more in flight "
-                        "(shells cloud, 8d region: 2 971 Mvoxels/s with 2, 3 719 with 4)")
+    p.add_argument("--farm-workers", type=int, default=2,
+                   help="device workers per GPU of the farm legs (host splats in, meshes out).  Round 5, shells cloud, 8d region with "
+                        "six spare items: 2 workers 33.5-34 ms per job (the host-to-device copies busy 0.90-0.92 of it), 4 workers "
+                        "36.5-38 (0.80), 8 workers 41 (0.74): the link is the floor, and fewer streams queue less in front of it")
     p.add_argument("--batch", type=int, default=4,
                    help="buckets a device worker takes through the path in lock-step (mlsgpu_hip_worker_process_batch: every "
                         "kernel has a bucket dimension, one set of launches and three host decisions per batch); 1 = bucket by "
@@ -99,7 +100,17 @@ def parse_args():
                         "reference's does) and every bucket starts with a device-to-device restore of its splats inside the timed "
                         "region.  Default since round 3: the workers keep the splats intact (mlsgpu_hip_worker_set_keep_splats), so "
                         "the resident input needs no restoring; the line reports this mode's step beside the headline")
-    p.add_argument("--copy-threads", type=int, default=8, help="host threads copying one bucket into pinned staging (transfer legs)")
+    p.add_argument("--farm-spare", type=int, default=6,
+                   help="device items per GPU beyond one per worker in the transfer legs (62 MB each here).  With the reference's one "
+                        "spare item the copy side waits 4-6 ms per job for a worker to hand an item back and the link idles meanwhile")
+    p.add_argument("--staging-buffers", type=int, default=0, help="pinned staging buffers per copy side (0: the side's GPUs + 2)")
+    p.add_argument("--copy-threads", type=int, default=16,
+                   help="host threads (a persistent pool per copy side, bound to the GPU's NUMA node) copying one bucket into pinned "
+                        "staging.  The copies must outrun the link: 1.68 GB per job in 11-16 ms with a source on the GPU's node, 21-31 "
+                        "ms with a source on the other socket (8 threads: 30)")
+    p.add_argument("--no-bind", action="store_true",
+                   help="leave the process where the scheduler puts it (default: the process -- every thread, every first touch of "
+                        "host memory -- is bound to the CPUs of its GPU's NUMA node before anything is allocated)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-transfer", action="store_true", help="skip the transfer-inclusive legs (SURVEY 8d timed region)")
     p.add_argument("--no-shells", action="store_true", help="skip the D1 (shells) secondary measurement")
@@ -409,7 +420,12 @@ def cpu_baseline(sample_host, sample_buckets, max_cells):
     -march=native for this machine's CPU.  The boxes are `side`-cell cubes rather than whole 170-cell buckets so that the
     leg takes seconds, not minutes (a whole cfg3 bucket is about 145 s of one core); the cloud is uniform, so the rate is
     the rate of whole buckets."""
-    cores = os.cpu_count() or 1
+    # every host core, whatever the process was bound to for the GPU legs (the children inherit this thread's mask)
+    try:
+        os.sched_setaffinity(0, range(os.cpu_count() or 1))
+    except OSError:
+        pass
+    cores = len(os.sched_getaffinity(0))
     try:
         import psutil
         mem_gb = psutil.virtual_memory().available / 2 ** 30
@@ -484,8 +500,8 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     out = {}
     views = [bucketed_host[b.first:b.first + b.count] for b in buckets]
     nworkers = max(1, min(args.farm_workers, len(buckets)))
-    farm = m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
-                        mesh_memory=args.mesh_memory_mb << 20, copy_threads=args.copy_threads)
+    farm = m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=args.farm_spare, max_cells=max_cells,
+                        mesh_memory=args.mesh_memory_mb << 20, copy_threads=args.copy_threads, staging_buffers=args.staging_buffers)
     farm.set_host_output(6 << 30, None)
 
     def stream_pass():
@@ -494,19 +510,44 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
         farm.finish()
     stream_pass()
     before = farm.host_stats()
+    c0 = farm.copy_clock()
     t0 = time.perf_counter()
     for _ in range(steps):
         stream_pass()
     dt = (time.perf_counter() - t0) / steps
     hs = farm.host_stats()
+    c1 = farm.copy_clock()
     d2h = (hs["bytes"] - before["bytes"]) / steps
+    per = {k: (c1[k] - c0[k]) / steps for k in ("fill_s", "wait_staging_s", "wait_item_s", "h2d_s", "enqueue_s")}
+    # ... and the same passes as ONE stream of buckets (no drain between jobs): what the link sustains when the next job's
+    # splats follow the last bucket of this one, as they do when jobs queue up
+    c2 = farm.copy_clock()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        for i, (b, v) in enumerate(zip(buckets, views)):
+            farm.submit(v, b.low, b.num_vertices, i)
+    farm.finish()
+    dt_stream = (time.perf_counter() - t0) / steps
+    c3 = farm.copy_clock()
     out["shipouts"] = {
         "value": round(voxels / dt / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(dt * 1e3, 3),
         "h2d_GB_per_step": round(bucketed_host.nbytes / 1e9, 3), "d2h_GB_per_step": round(d2h / 1e9, 3),
         "link_GBps": round((bucketed_host.nbytes + d2h) / dt / 1e9, 2), "ring_waits": hs["ring_waits"] - before["ring_waits"],
-        "note": "pageable host splats -> pinned staging (%d copy threads) -> H2D -> %d device workers -> every ship-out "
-                "read back through a 6 GiB pinned circular buffer, consumed (dropped) by the farm's mesher thread"
-                % (args.copy_threads, nworkers)}
+        # the copy side's clock: the link is the floor of this region, so the figure to watch is how busy it is
+        "h2d_busy_frac": round(per["h2d_s"] / dt, 3), "h2d_GBps_while_copying": round(bucketed_host.nbytes / max(per["h2d_s"], 1e-9) / 1e9, 1),
+        "copy_side_ms_per_step": {"fill_staging": round(per["fill_s"] * 1e3, 2), "wait_for_staging": round(per["wait_staging_s"] * 1e3, 2),
+                                  "wait_for_device_item": round(per["wait_item_s"] * 1e3, 2), "enqueue_calls": round(per["enqueue_s"] * 1e3, 2),
+                                  "h2d_copies": round(per["h2d_s"] * 1e3, 2)},
+        "streamed": {"ms_per_step": round(dt_stream * 1e3, 3), "value": round(voxels / dt_stream / 1e6, 3),
+                     "h2d_busy_frac": round((c3["h2d_s"] - c2["h2d_s"]) / steps / dt_stream, 3),
+                     "what": "%d jobs submitted back to back, one wait at the end: no pipeline drain between jobs" % steps},
+        "link_floor_ms": round(per["h2d_s"] * 1e3, 2),
+        "placement": farm.placement(),
+        "note": "per job (ms_per_step): pageable host splats -> pinned staging (%d copy threads) -> H2D -> %d device workers (+ %d "
+                "spare items) -> every ship-out read back through a 6 GiB pinned circular buffer, consumed (dropped) by the farm's "
+                "mesher thread -> wait for the last byte.  link_floor_ms = the job's host-to-device copies alone, at the rate the "
+                "link gave them next to the read-backs: the floor of this region"
+                % (args.copy_threads, nworkers, args.farm_spare)}
     farm.close()
     if not with_sink:
         return out
@@ -609,43 +650,85 @@ def host_weld_leg(m, args, device_index, bucketed_host, buckets, max_count, max_
     -> the mesher thread hands it to the host welder (OOCMesher's weld: local components, key map, union-find;
     src/mesher.cpp:220-311 -- a task per block on the welder's pool of threads, where the reference has one thread and an
     OpenMP rewrite, src/mesher.cpp:597-600) -> finalize (components, prune, one mesh per chunk).  One job = one fresh welder;
-    a warm-up job first (the welder's memory comes from a cache of mapped slabs), then `steps` timed jobs."""
+    a warm-up job first (the welder's memory comes from a cache of mapped slabs).  Two figures: a job ALONE (its latency: pass,
+    then finalize), and a STREAM of jobs in which job k's finalize runs on its own thread while job k + 1's buckets are already
+    going through the farm into the next welder -- the steady state `value` is quoted on."""
+    import threading
     nworkers = max(1, min(args.farm_workers, len(buckets)))
-    farm = m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
-                        mesh_memory=args.mesh_memory_mb << 20, copy_threads=args.copy_threads)
+    farm = m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=args.farm_spare, max_cells=max_cells,
+                        mesh_memory=args.mesh_memory_mb << 20, copy_threads=args.copy_threads, staging_buffers=args.staging_buffers)
     views = [bucketed_host[b.first:b.first + b.count] for b in buckets]
-    jobs = []
+    last = {}
 
-    def job():
-        welder = m.HostMesher(0.02, threads=args.weld_threads)
+    def stream_in(welder):
         farm.set_host_output(2 << 30, welder)
-        t0 = time.perf_counter()
         for b, v in zip(buckets, views):
             farm.submit(v, b.low, b.num_vertices, 0)
         farm.finish()
-        t1 = time.perf_counter()
+
+    def finish(welder, times=None):
+        t = time.perf_counter()
         n = welder.finalize()
-        t2 = time.perf_counter()
-        st = welder.stats()
-        threads = welder.threads()
+        if times is not None:
+            times.append(time.perf_counter() - t)
+        last.update(n=n, st=welder.stats(), threads=welder.threads())
         welder.close()
-        jobs.append((t1 - t0, t2 - t1))
-        return n, st, threads
-    job()                                                   # warm-up: arenas, pinned ring, the welder's slabs
-    jobs.clear()
-    n = st = threads = None
-    for _ in range(max(1, steps)):
-        n, st, threads = job()
+
+    def job_alone():
+        welder = m.HostMesher(0.02, threads=args.weld_threads)
+        t0 = time.perf_counter()
+        stream_in(welder)
+        t1 = time.perf_counter()
+        finish(welder)
+        return t1 - t0, time.perf_counter() - t1
+    job_alone()                                             # warm-up: arenas, pinned ring, the welder's slabs
+    alone = [job_alone() for _ in range(max(1, steps))]
+    # the stream: at most one finalize in flight behind the job that is streaming in.  TWO welders are alive at a time, so
+    # the stream has its own warm-up (the second set of slabs is mapped and faulted in once)
+    in_times, join_times = [], []
+
+    alt = os.environ.get("MLSGPU_BENCH_WELD_ALTERNATE_NODES") == "1"
+    jobno = [0]
+
+    def stream(count, times):
+        pending = None
+        for _ in range(count):
+            welder = m.HostMesher(0.02, threads=args.weld_threads)
+            if alt:
+                welder.set_node(jobno[0] % 2)
+            jobno[0] += 1
+            t = time.perf_counter()
+            stream_in(welder)
+            in_times.append(time.perf_counter() - t)
+            t = time.perf_counter()
+            if pending is not None:
+                pending.join()
+            join_times.append(time.perf_counter() - t)
+            pending = threading.Thread(target=finish, args=(welder, times))
+            pending.start()
+        pending.join()
+    stream(3, None)
+    jobs = max(2 * steps, 6)
+    fin_times = []
+    t0 = time.perf_counter()
+    stream(jobs, fin_times)
+    per_job = (time.perf_counter() - t0) / jobs
     hs = farm.host_stats()
     farm.close()
-    total = sum(a + b for a, b in jobs) / len(jobs)
-    return {"value": round(voxels / total / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(total * 1e3, 1), "steps": len(jobs),
-            "pass_until_last_mesh_welded_ms": round(sum(a for a, _ in jobs) / len(jobs) * 1e3, 1),
-            "finalize_ms": round(sum(b for _, b in jobs) / len(jobs) * 1e3, 1),
-            "vertices_welded_per_s": round(st["vertices_added"] / total), "weld_threads": threads, "chunks": n,
+    st = last["st"]
+    total = sum(a + b for a, b in alone) / len(alone)
+    return {"value": round(voxels / per_job / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(per_job * 1e3, 1), "steps": jobs,
+            "finalize_ms_in_the_stream": round(sum(fin_times) / len(fin_times) * 1e3, 1),
+            "stream_in_ms": round(sum(in_times[-jobs:]) / jobs * 1e3, 1), "wait_for_previous_finalize_ms": round(sum(join_times[-jobs:]) / jobs * 1e3, 1),
+            "one_job_alone": {"ms": round(total * 1e3, 1), "value": round(voxels / total / 1e6, 3), "jobs": len(alone),
+                              "pass_until_last_mesh_welded_ms": round(sum(a for a, _ in alone) / len(alone) * 1e3, 1),
+                              "finalize_ms": round(sum(b for _, b in alone) / len(alone) * 1e3, 1)},
+            "vertices_welded_per_s": round(st["vertices_added"] / per_job), "weld_threads": last["threads"], "chunks": last["n"],
             "ring_waits": hs["ring_waits"], "welded_vertices": st["total_vertices"], "kept_triangles": st["kept_triangles"],
-            "note": "per job: host splats in -> farm -> ring read-backs -> host welder (a task per block on weld_threads threads) "
-                    "-> finalize; the reference welds on one mesher thread (doc/mlsgpu-user-manual.xml:508-511)"}
+            "note": "per job in a stream of jobs: host splats in -> farm -> ring read-backs -> host welder (a task per block on "
+                    "weld_threads threads) -> finalize on its own thread while the next job streams in; one_job_alone = the same job "
+                    "with nothing overlapped (its latency); the reference welds on one mesher thread "
+                    "(doc/mlsgpu-user-manual.xml:508-511)"}
 
 
 def multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, local_rank, ndev, ctx, bucketed_t, buckets, max_count,
@@ -915,6 +998,10 @@ def main():
     import mlsgpu_amd as m
     from mlsgpu_amd import farm
 
+    # one process per GPU: next to its GPU, before any host memory is touched (rank r of an 8-GPU node lands on the socket
+    # GPU r hangs off; the pinned staging, the read-back ring, the copy threads and the welder follow)
+    process_placement = ({"bound": False, "why": "--no-bind"} if args.no_bind else farm.bind_process_to_device_node(local_rank))
+
     if args.workload == "cfg5":
         run_cfg5(args, rank, world, local_rank, device, dist, reduce_device)
         if dist is not None:
@@ -1181,6 +1268,15 @@ def main():
                      "rounds 1-2's protocol (--restore-splats): mutating tree build + a device-to-device restore of every bucket's "
                      "splats inside the step")}
     result["_grid"] = W["grid"]
+    result["placement"] = process_placement
+    if dist is not None:
+        pl = torch.zeros((world, 3), dtype=torch.int64, device=reduce_device)
+        pl[rank, 0], pl[rank, 1], pl[rank, 2] = process_placement.get("gpu_node", -1), int(process_placement.get("bound", False)), \
+            process_placement.get("cpus", 0)
+        dist.all_reduce(pl)
+        pl = pl.cpu().numpy()
+        result["placement"]["per_rank"] = {"gpu_node": [int(x) for x in pl[:, 0]], "bound": [bool(x) for x in pl[:, 1]],
+                                           "cpus": [int(x) for x in pl[:, 2]]}
     if W["name"] == "cfg3" and args.dist == "uniform" and args.scale == 1.0 and CFG3_UNIFORM_DIGEST is not None:
         result["output_digest"]["expected"] = CFG3_UNIFORM_DIGEST
         result["output_digest"]["ok"] = digest == CFG3_UNIFORM_DIGEST

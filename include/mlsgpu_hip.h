@@ -343,7 +343,9 @@ typedef struct mlsgpu_farm_config
     uint32_t workersPerDevice;     /* default 1 */
     uint32_t spare;                /* extra device items per GPU beyond one per worker; default 1 */
     mlsgpu_worker_config worker;   /* maxBucketSplats is also the capacity of a device item */
-    uint32_t copyThreads;          /* host threads mlsgpu_hip_farm_submit copies a bucket with; 0 = 4 */
+    uint32_t copyThreads;          /* host threads (per copy side) mlsgpu_hip_farm_submit copies a bucket with; 0 = 4 */
+    uint32_t stagingBuffers;       /* pinned staging buffers per copy side; 0 = the side's GPUs + 2 (the reference has one,
+                                    * src/workers.cpp:367-372) */
 } mlsgpu_farm_config;
 /* Output functor with the chunk it belongs to (OutputGenerator, src/workers.h:225).  Called on the worker's
  * thread; `ctx` is that worker's context (use it for mlsgpu_hip_mesh_read).  NULL: meshes are only counted. */
@@ -367,6 +369,32 @@ int mlsgpu_hip_farm_finish(mlsgpu_farm *farm);
 /* out[0] buckets, [1] splats copied, [2] H2D bytes, [3] device items, [4] ship-outs, [5] vertices, [6] triangles,
  * [7] external vertices; per device d: out[8 + d] = buckets processed there (up to 16 devices). */
 int mlsgpu_hip_farm_stats(mlsgpu_farm *farm, uint64_t out[24]);
+/* ---- placement: where the farm's host threads and pinned memory live relative to the GPUs.  The reference places
+ *      nothing (src/workers.cpp:320-351 chooses a device by free capacity only; its threads run where the scheduler puts
+ *      them).  Here a GPU's NUMA node is read from sysfs (hipDeviceGetPCIBusId -> /sys/bus/pci/devices/<bdf>/numa_node) and
+ *      the farm keeps one COPY SIDE per node that has one of its GPUs: a ring of pinned staging buffers allocated on that
+ *      node, copy threads bound to it, feeding that node's GPUs; device worker threads are bound to their GPU's node, the
+ *      read-back ring and the mesher thread to the first GPU's.  A batch is staged on the side of the GPU it would go to
+ *      (most unallocated capacity) and sent to a GPU of that side -- to another side's only when none of its own can take
+ *      an item.  On a one-node machine, or when sysfs does not say, there is one unbound side.  MLSGPU_HIP_SYSFS_ROOT
+ *      (default /sys) and MLSGPU_HIP_DEVICE_NODES ("0,0,1,1") describe another machine to a test. ---- */
+int mlsgpu_hip_device_node(int device);                                    /* -1: unknown */
+int mlsgpu_hip_topology(uint32_t *numNodes, uint32_t cpusPerNode[16]);
+/* the plan alone: deviceNodes[i] -> sideOfDevice[i] (sides numbered by first appearance), nodeOfSide[k], *numSides */
+int mlsgpu_hip_plan_copy_sides(const int32_t *deviceNodes, uint32_t numDevices, uint32_t numNodes, int32_t *sideOfDevice,
+                               int32_t *nodeOfSide, uint32_t *numSides);
+/* test hook: copies through the farm's pool of copy threads compared with their sources; returns the mismatches */
+int mlsgpu_hip_test_copy_pool(uint32_t threads, uint32_t rounds, uint64_t bytes, int node);
+int mlsgpu_hip_bind_thread_to_node(int node);                              /* the calling thread; 1 = bound, 0 = left alone */
+/* out[0] copy sides, [1] node the read-back ring's memory is on, [2] NUMA nodes, [3] devices; per device d < 16:
+ * out[4 + 3d] ordinal, [5 + 3d] node, [6 + 3d] side; per side k < 12: out[52 + 4k] node, [53 + 4k] node its staging memory
+ * is on (queried), [54 + 4k] staging buffers, [55 + 4k] copy threads.  -1 = unknown / unused. */
+int mlsgpu_hip_farm_placement(mlsgpu_farm *farm, int32_t out[100]);
+/* The copy side's clock, seconds since the farm was created: out[0] filling staging (mlsgpu_hip_farm_submit's memcpy),
+ * [1] waiting for a staging buffer, [2] waiting for a device item, [3] host-to-device copies (timed event pairs on the copy
+ * streams), [4] first submit .. last flush, [5] copies, [6] batches sent to another side's GPU, [7] inside the runtime's
+ * enqueue calls (event records + hipMemcpyAsync).  h2d_busy = [3] / [4]. */
+int mlsgpu_hip_farm_copy_clock(mlsgpu_farm *farm, double out[8]);
 /* The most device items (DeviceWorkerGroup::WorkItem, src/workers.h:165-181) that were in flight at once since the farm
  * was created: taken from a group's pool by the copy side and not yet returned by a device worker. */
 int mlsgpu_hip_farm_in_flight_max(mlsgpu_farm *farm, uint64_t *out);
@@ -533,6 +561,11 @@ int mlsgpu_hip_host_mesher_set_prune_threshold(mlsgpu_host_mesher *mesher, doubl
  * MLSGPU_HIP_HOST_MESHER_THREADS, else min(32, hardware threads).  Before the first add; results do not depend on it. */
 int mlsgpu_hip_host_mesher_set_threads(mlsgpu_host_mesher *mesher, uint32_t threads);
 uint32_t mlsgpu_hip_host_mesher_threads(mlsgpu_host_mesher *mesher);
+/* The welder's threads bound to the CPUs of ONE NUMA node -- the node its meshes arrive on (mlsgpu_hip_farm_placement
+ * out[1]: the read-back ring is next to the farm's first GPU), so that a block's pieces are welded within one socket's
+ * caches.  -1 (default): unbound.  Before the first add.  The reference's mesher thread is not placed. */
+int mlsgpu_hip_host_mesher_set_node(mlsgpu_host_mesher *mesher, int node);
+int mlsgpu_hip_host_mesher_node(mlsgpu_host_mesher *mesher);
 int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *mesher, uint64_t chunkId, const mlsgpu_host_mesh *mesh);
 /* a mlsgpu_farm_host_output_fn whose `user` is the mlsgpu_host_mesher */
 int mlsgpu_hip_host_mesher_farm_output(void *mesher, int device, uint64_t chunkId, const mlsgpu_host_mesh *mesh);

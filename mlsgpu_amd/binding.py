@@ -110,7 +110,7 @@ BUCKET_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(BucketStruct)
 
 class FarmConfig(C.Structure):
     _fields_ = [("numDevices", C.c_uint32), ("devices", C.POINTER(C.c_int32)), ("workersPerDevice", C.c_uint32),
-                ("spare", C.c_uint32), ("worker", WorkerConfig), ("copyThreads", C.c_uint32)]
+                ("spare", C.c_uint32), ("worker", WorkerConfig), ("copyThreads", C.c_uint32), ("stagingBuffers", C.c_uint32)]
 
 
 FARM_OUTPUT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_uint64, C.c_void_p, C.POINTER(Mesh))
@@ -233,7 +233,16 @@ def lib():
     sig("mlsgpu_hip_mesher_write_ply", C.c_int, vp, C.c_uint32, C.c_char_p, vp, C.c_uint32, u64)
     sig("mlsgpu_hip_farm_set_host_output", C.c_int, vp, u64, vp, vp)
     sig("mlsgpu_hip_farm_host_stats", C.c_int, vp, vp)
+    sig("mlsgpu_hip_device_node", C.c_int, C.c_int)
+    sig("mlsgpu_hip_topology", C.c_int, vp, vp)
+    sig("mlsgpu_hip_plan_copy_sides", C.c_int, vp, u32, u32, vp, vp, vp)
+    sig("mlsgpu_hip_bind_thread_to_node", C.c_int, C.c_int)
+    sig("mlsgpu_hip_test_copy_pool", C.c_int, u32, u32, u64, C.c_int)
+    sig("mlsgpu_hip_farm_placement", C.c_int, vp, vp)
+    sig("mlsgpu_hip_farm_copy_clock", C.c_int, vp, vp)
     sig("mlsgpu_hip_host_mesher_trim_cache", u64, u64)
+    sig("mlsgpu_hip_host_mesher_set_node", C.c_int, vp, C.c_int)
+    sig("mlsgpu_hip_host_mesher_node", C.c_int, vp)
     sig("mlsgpu_hip_host_mesher_create", C.c_int, P(vp))
     sig("mlsgpu_hip_host_mesher_destroy", None, vp)
     sig("mlsgpu_hip_host_mesher_set_prune_threshold", C.c_int, vp, C.c_double)
@@ -840,6 +849,10 @@ class HostMesher:
     def threads(self):
         return lib().mlsgpu_hip_host_mesher_threads(self.h)
 
+    def set_node(self, node):
+        """Bind the welder's threads to a NUMA node's CPUs (before the first add); -1 = unbound."""
+        check(lib().mlsgpu_hip_host_mesher_set_node(self.h, int(node)))
+
     def add(self, chunk_id, vertices, num_internal, keys, triangles):
         """keys: the external vertices' keys (len(vertices) - num_internal of them)."""
         v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
@@ -1236,6 +1249,7 @@ class BucketFarm:
         cfg.workersPerDevice = workers_per_device
         cfg.spare = spare
         cfg.copyThreads = worker_kw.get("copy_threads", 0)      # host threads of one bucket's copy into pinned staging; 0 = 4
+        cfg.stagingBuffers = worker_kw.get("staging_buffers", 0)  # pinned staging buffers per copy side; 0 = its GPUs + 2
         w = cfg.worker
         w.maxBucketSplats = max_bucket_splats
         w.maxCells = worker_kw.get("max_cells", 255)
@@ -1347,6 +1361,29 @@ class BucketFarm:
             self._host_cb = FARM_HOST_OUTPUT_FN(cb)
             fn = C.cast(self._host_cb, C.c_void_p)
         check(lib().mlsgpu_hip_farm_set_host_output(self.h, ring_bytes, fn, user))
+        if isinstance(sink, HostMesher) and lib().mlsgpu_hip_host_mesher_node(sink.h) < 0:
+            # a welder that has not been placed joins the ring's NUMA node (refused, and ignored, once its threads exist)
+            node = self.placement()["ring_node"]
+            if node >= 0:
+                lib().mlsgpu_hip_host_mesher_set_node(sink.h, node)
+
+    def placement(self):
+        """Where the farm put things: {"nodes", "ring_node", "devices": [{device, node, side}], "sides": [{node,
+        staging_node, staging_buffers, copy_threads}]} (mlsgpu_hip_farm_placement)."""
+        out = np.zeros(100, np.int32)
+        check(lib().mlsgpu_hip_farm_placement(self.h, _p(out)))
+        return {"nodes": int(out[2]), "ring_node": int(out[1]),
+                "devices": [dict(device=int(out[4 + 3 * d]), node=int(out[5 + 3 * d]), side=int(out[6 + 3 * d]))
+                            for d in range(min(int(out[3]), 16))],
+                "sides": [dict(node=int(out[52 + 4 * k]), staging_node=int(out[53 + 4 * k]), staging_buffers=int(out[54 + 4 * k]),
+                               copy_threads=int(out[55 + 4 * k])) for k in range(min(int(out[0]), 12))]}
+
+    def copy_clock(self):
+        """Seconds the copy side spent (mlsgpu_hip_farm_copy_clock): fill, wait_staging, wait_item, h2d, span; counts."""
+        out = np.zeros(8, np.float64)
+        check(lib().mlsgpu_hip_farm_copy_clock(self.h, _p(out)))
+        return dict(fill_s=float(out[0]), wait_staging_s=float(out[1]), wait_item_s=float(out[2]), h2d_s=float(out[3]),
+                    span_s=float(out[4]), copies=int(out[5]), cross_side=int(out[6]), enqueue_s=float(out[7]))
 
     def host_stats(self):
         out = np.zeros(4, np.uint64)

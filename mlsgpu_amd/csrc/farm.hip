@@ -7,9 +7,11 @@
  * stream and a worker's stream is a hipEvent (WorkItem::copyEvent in the reference).
  */
 #include "common.hpp"
+#include "placement.hpp"
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
@@ -35,6 +37,9 @@ struct WorkItem                  /* DeviceWorkerGroupBase::WorkItem, src/workers
     std::vector<SubItem> subItems;
     mlsgpu_splat *dSplats = nullptr;
     hipEvent_t copyEvent = nullptr;
+    hipEvent_t copyStart = nullptr;  /* timed pair around the item's last host-to-device copy: read when the item is next */
+    hipEvent_t copyStop = nullptr;   /* taken from the pool (the copy is long done then) into the copy side's busy time */
+    bool copyTimed = false;
     uint64_t numSplats = 0;
 };
 
@@ -47,6 +52,8 @@ struct DeviceGroup               /* DeviceWorkerGroup, src/workers.h:214-350 */
     Farm *farm = nullptr;
     int device = 0;
     uint32_t index = 0;
+    int node = -1;                       /* NUMA node the GPU hangs off (-1: unknown or a one-node machine) */
+    uint32_t side = 0;                   /* the copy side (staging ring + copy threads of that node) that serves it */
     hipStream_t copyStream = nullptr;
     mlsgpu_ctx *copyCtx = nullptr;       /* the copy stream as a context, for device-side loads */
     std::vector<std::unique_ptr<WorkItem> > items;
@@ -109,13 +116,31 @@ struct Farm
         mlsgpu_splat *ptr = nullptr;
         hipEvent_t busy = nullptr;       /* WorkItem::copyEvent of the last copy out of this buffer, or null */
     };
-    std::vector<Staging> staging;
-    size_t cur = 0;
+    /* One COPY SIDE per NUMA node that has a GPU of the farm (placement.hpp): its ring of pinned buffers is allocated on
+     * that node, its copy threads run there, and it feeds that node's GPUs -- the DMA engines read local memory and the
+     * socket interconnect carries only what the caller's source array forces over it.  A one-socket machine has one. */
+    struct CopySide
+    {
+        int node = -1;
+        std::vector<Staging> staging;
+        size_t cur = 0;
+        std::vector<DeviceGroup *> groups;
+        placement::CopyPool pool;
+        int stagingNode = -1;            /* where the first staging buffer's memory really is (move_pages query) */
+    };
+    std::vector<std::unique_ptr<CopySide> > sides;
+    CopySide *active = nullptr;          /* the side whose current buffer holds the batch being assembled */
     std::vector<SubItem> bufferedItems;
     uint64_t bufferedSplats = 0;
     uint64_t acquired = 0;          /* splats handed out by acquire and not pushed yet */
 
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    /* the copy side's clock (seconds): filling staging, waiting for a staging buffer, waiting for a device item, the
+     * host-to-device copies themselves (timed event pairs), first submit .. last flush; [5] copies, [6] batches sent to a
+     * GPU of another side because no own one had a free item, [7] inside the runtime's enqueue calls */
+    double copyClock[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::chrono::steady_clock::time_point firstSubmit, lastFlush;
+    bool clockRunning = false;
 
     /* host output: ship-outs are read back asynchronously on the worker's stream into a pinned circular buffer
      * (MesherGroup::meshBuffer, --mem-mesh) and consumed in arrival order by ONE mesher thread
@@ -124,6 +149,7 @@ struct Farm
     mlsgpu_farm_host_output_fn hostFn = nullptr;
     void *hostUser = nullptr;
     char *ring = nullptr;
+    int ringNode = -1;                   /* where the ring's memory really is (move_pages query) */
     uint64_t ringBytes = 0, ringHead = 0, ringUsed = 0;   /* in use: the ringUsed bytes that end at ringHead */
     std::deque<HostSlot *> hostQueue;
     std::condition_variable hostCond;    /* a slot became ready / stopping */
@@ -338,6 +364,8 @@ int batchOutputThunk(void *user, uint32_t index, void *stream, const mlsgpu_mesh
 /* DeviceWorkerGroupBase::Worker::operator(), src/workers.cpp:232-286 */
 void workerMain(Farm *farm, DeviceGroup *g)
 {
+    /* a device worker's host side -- launches, mailbox polls in pinned memory, the output functor -- next to its GPU */
+    placement::bindThisThread(placement::cpusOfNode(g->node));
     mlsgpu_ctx *ctx = nullptr;
     mlsgpu_worker *worker = nullptr;
     int rc = mlsgpu_hip_ctx_create(g->device, nullptr, &ctx);
@@ -516,19 +544,39 @@ int abandonItem(Farm *f, DeviceGroup *g, WorkItem *item, uint64_t splats, int rc
 }
 
 /* among the groups that can take an item now, the one with the most unallocated capacity (flush, src/workers.cpp:
- * 320-351); `prefer` >= 0 breaks ties in favour of that device.  Called with the mutex held; null if none. */
-DeviceGroup *pickGroup(Farm *f, int prefer)
+ * 320-351); `prefer` >= 0 breaks ties in favour of that device; `side` non-null restricts the choice to the GPUs that copy
+ * side serves.  Called with the mutex held; null if none. */
+DeviceGroup *pickGroup(Farm *f, int prefer, const Farm::CopySide *side = nullptr)
 {
     DeviceGroup *out = nullptr;
     uint64_t best = 0;
     for (auto &g : f->groups)
-        if (!g->pool.empty()
+        if (!g->pool.empty() && (side == nullptr || f->sides[g->side].get() == side)
             && (out == nullptr || g->unallocated > best || (g->unallocated == best && g->device == prefer && out->device != prefer)))
         {
             best = g->unallocated;
             out = g.get();
         }
     return out;
+}
+
+/* the side the next batch is staged on: the one of the group the batch would go to if it were flushed now -- the most
+ * unallocated capacity, a group that can take an item before one that cannot.  Called with the mutex held. */
+Farm::CopySide *pickSide(Farm *f)
+{
+    if (f->sides.size() == 1)
+        return f->sides[0].get();
+    DeviceGroup *out = pickGroup(f, -1);
+    if (out == nullptr)
+        for (auto &g : f->groups)
+            if (out == nullptr || g->unallocated > out->unallocated)
+                out = g.get();
+    return f->sides[out->side].get();
+}
+
+double secondsSince(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 /* CopyGroupBase::Worker::flush, src/workers.cpp:315-375 */
@@ -539,13 +587,19 @@ int flushBatch(Farm *f)
     DeviceGuard restore;
     DeviceGroup *out = nullptr;
     WorkItem *item = nullptr;
+    Farm::CopySide *side = f->active;
+    const auto tWait = std::chrono::steady_clock::now();
     {
         std::unique_lock<std::mutex> l(f->mutex);
         for (;;)
         {
             if (f->error != MLSGPU_OK)
                 return setError(f->error, "%s", f->errorText.c_str());
-            out = pickGroup(f, -1);
+            /* a GPU of the side the batch was staged on; when none of them can take an item and another side's can, the
+             * batch goes there (the reference's greedy choice never waits while some device is free) */
+            out = pickGroup(f, -1, side);
+            if (out == nullptr && (out = pickGroup(f, -1)) != nullptr)
+                f->copyClock[6] += 1;
             if (out != nullptr)
                 break;
             f->popCond.wait(l);
@@ -556,15 +610,30 @@ int flushBatch(Farm *f)
         f->inFlightItems++;
         f->inFlightMax = std::max(f->inFlightMax, f->inFlightItems);
     }
+    f->copyClock[2] += secondsSince(tWait);
     const uint64_t splats = f->bufferedSplats;
     item->subItems.swap(f->bufferedItems);
     item->numSplats = splats;
     f->bufferedItems.clear();
     f->bufferedSplats = 0;
-    Farm::Staging &st = f->staging[f->cur];
+    Farm::Staging &st = side->staging[side->cur];
+    const auto tEnqueue = std::chrono::steady_clock::now();
     hipError_t e = hipSetDevice(out->device);
+    if (e == hipSuccess && item->copyTimed)
+    {
+        /* the item's previous copy ended long ago (a worker has processed the item since): its duration */
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, item->copyStart, item->copyStop) == hipSuccess)
+            f->copyClock[3] += ms * 1e-3;
+        item->copyTimed = false;
+        (void) hipGetLastError();
+    }
+    if (e == hipSuccess)
+        e = hipEventRecord(item->copyStart, out->copyStream);
     if (e == hipSuccess)
         e = hipMemcpyAsync(item->dSplats, st.ptr, splats * sizeof(mlsgpu_splat), hipMemcpyHostToDevice, out->copyStream);
+    if (e == hipSuccess)
+        e = hipEventRecord(item->copyStop, out->copyStream);
     if (e == hipSuccess)
         e = hipEventRecord(item->copyEvent, out->copyStream);
     if (e != hipSuccess)
@@ -573,20 +642,32 @@ int flushBatch(Farm *f)
         hipStreamSynchronize(out->copyStream);
         return abandonItem(f, out, item, splats, MLSGPU_ERR_HIP);
     }
+    item->copyTimed = true;
+    f->copyClock[7] += secondsSince(tEnqueue);
     st.busy = item->copyEvent;          /* this buffer is free again once that copy is done */
     {
         std::lock_guard<std::mutex> l(f->mutex);
         f->stats[2] += splats * sizeof(mlsgpu_splat);
         f->stats[3]++;
+        f->copyClock[5] += 1;
         out->queue.push_back(item);                 /* DeviceWorkerGroup::push */
     }
     f->queueCond.notify_all();
-    /* fill the next buffer of the ring meanwhile; it may still be the source of an older copy */
-    f->cur = (f->cur + 1) % f->staging.size();
-    Farm::Staging &next = f->staging[f->cur];
+    f->lastFlush = std::chrono::steady_clock::now();
+    side->cur = (side->cur + 1) % side->staging.size();
+    f->active = nullptr;                /* the next bucket chooses its side (and waits for that side's next buffer) */
+    return MLSGPU_OK;
+}
+
+/* the buffer of `side` the next batch is assembled in: it may still be the source of an older copy */
+int claimStaging(Farm *f, Farm::CopySide *side)
+{
+    Farm::Staging &next = side->staging[side->cur];
     if (next.busy != nullptr)
     {
-        e = hipEventSynchronize(next.busy);         /* copyEvent.wait(), src/workers.cpp:367-372 */
+        const auto t0 = std::chrono::steady_clock::now();
+        const hipError_t e = hipEventSynchronize(next.busy);         /* copyEvent.wait(), src/workers.cpp:367-372 */
+        f->copyClock[1] += secondsSince(t0);
         next.busy = nullptr;
         if (e != hipSuccess)
         {
@@ -594,6 +675,7 @@ int flushBatch(Farm *f)
             return setError(MLSGPU_ERR_HIP, "farm: waiting for a staging buffer failed: %s", hipGetErrorString(e));
         }
     }
+    f->active = side;
     return MLSGPU_OK;
 }
 
@@ -615,10 +697,6 @@ MLSGPU_API int mlsgpu_hip_farm_create(const mlsgpu_farm_config *cfg, mlsgpu_farm
     f->user = user;
     const uint64_t cap = cfg->worker.maxBucketSplats;
     int rc = MLSGPU_OK;
-    f->staging.resize(std::max<uint32_t>(2, cfg->numDevices + 1));
-    for (size_t b = 0; b < f->staging.size() && rc == MLSGPU_OK; b++)
-        if (hipHostMalloc((void **) &f->staging[b].ptr, cap * sizeof(mlsgpu_splat), hipHostMallocPortable) != hipSuccess)
-            rc = setError(MLSGPU_ERR_NOMEM, "farm: cannot allocate pinned staging of %llu splats", (unsigned long long) cap);
     for (uint32_t d = 0; d < cfg->numDevices && rc == MLSGPU_OK; d++)
     {
         const int dev = cfg->devices ? cfg->devices[d] : (int) d;
@@ -631,6 +709,7 @@ MLSGPU_API int mlsgpu_hip_farm_create(const mlsgpu_farm_config *cfg, mlsgpu_farm
         g->farm = f;
         g->device = dev;
         g->index = d;
+        g->node = mlsgpu_hip_device_node(dev);
         /* everything below belongs to `dev`: streams, events and items are created with it current */
         if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&g->copyStream, hipStreamNonBlocking) != hipSuccess)
             rc = setError(MLSGPU_ERR_HIP, "farm: cannot create the copy stream on device %d", dev);
@@ -641,13 +720,63 @@ MLSGPU_API int mlsgpu_hip_farm_create(const mlsgpu_farm_config *cfg, mlsgpu_farm
         {
             std::unique_ptr<WorkItem> item(new WorkItem);
             if (hipMalloc((void **) &item->dSplats, cap * sizeof(mlsgpu_splat)) != hipSuccess
-                || hipEventCreateWithFlags(&item->copyEvent, hipEventDisableTiming) != hipSuccess)
+                || hipEventCreateWithFlags(&item->copyEvent, hipEventDisableTiming) != hipSuccess
+                || hipEventCreate(&item->copyStart) != hipSuccess || hipEventCreate(&item->copyStop) != hipSuccess)
                 rc = setError(MLSGPU_ERR_NOMEM, "farm: cannot allocate a device item of %llu splats", (unsigned long long) cap);
             g->pool.push_back(item.get());
             g->items.push_back(std::move(item));
         }
         g->unallocated = cap * nItems;              /* src/workers.cpp:116 */
         f->groups.push_back(std::move(g));
+    }
+    /* ---- copy sides: one per NUMA node with a GPU of the farm.  A side's pinned ring is allocated with one of its GPUs
+     * current, on a thread bound to the node (the runtime places pinned memory next to the current device; the binding
+     * covers a runtime that places it next to the caller); depth = its GPUs + 2, so that while one buffer is being filled
+     * one copy per GPU can be in flight and one more is queued behind them; its copy threads are bound to the node. ---- */
+    if (rc == MLSGPU_OK)
+    {
+        std::vector<int> nodes, sideOf, nodeOfSide;
+        for (auto &g : f->groups)
+            nodes.push_back(g->node);
+        placement::planSides(nodes.data(), nodes.size(), placement::numNodes(), sideOf, nodeOfSide);
+        for (size_t k = 0; k < nodeOfSide.size(); k++)
+        {
+            f->sides.emplace_back(new Farm::CopySide);
+            f->sides.back()->node = nodeOfSide[k];
+        }
+        for (size_t i = 0; i < f->groups.size(); i++)
+        {
+            f->groups[i]->side = (uint32_t) sideOf[i];
+            f->sides[(size_t) sideOf[i]]->groups.push_back(f->groups[i].get());
+        }
+        const uint32_t copyThreads = f->cfg.copyThreads == 0 ? 4u : f->cfg.copyThreads;
+        for (auto &sp : f->sides)
+        {
+            Farm::CopySide *side = sp.get();
+            const std::vector<int> cpus = placement::cpusOfNode(side->node);
+            const uint32_t depth = f->cfg.stagingBuffers != 0 ? std::max(2u, f->cfg.stagingBuffers)
+                                                              : (uint32_t) side->groups.size() + 2;
+            side->staging.resize(depth);
+            int arc = MLSGPU_OK;
+            std::thread allocator([&] {
+                placement::bindThisThread(cpus);
+                if (hipSetDevice(side->groups[0]->device) != hipSuccess)
+                    arc = MLSGPU_ERR_HIP;
+                for (size_t b = 0; b < side->staging.size() && arc == MLSGPU_OK; b++)
+                    if (hipHostMalloc((void **) &side->staging[b].ptr, cap * sizeof(mlsgpu_splat), hipHostMallocPortable) != hipSuccess)
+                        arc = MLSGPU_ERR_NOMEM;
+                    else
+                        std::memset(side->staging[b].ptr, 0, std::min<uint64_t>(cap * sizeof(mlsgpu_splat), 4096));
+            });
+            allocator.join();
+            if (arc != MLSGPU_OK)
+            {
+                rc = setError(arc, "farm: cannot allocate pinned staging of %llu splats x %u", (unsigned long long) cap, depth);
+                break;
+            }
+            side->stagingNode = placement::nodeOfAddress(side->staging[0].ptr);
+            side->pool.start(copyThreads, cpus);
+        }
     }
     if (rc != MLSGPU_OK)
     {
@@ -681,12 +810,29 @@ MLSGPU_API int mlsgpu_hip_farm_set_host_output(mlsgpu_farm *f, uint64_t ringByte
     }
     REQUIRE(f->stats[0] == 0, MLSGPU_ERR_INVALID);          /* before the first bucket */
     ringBytes = (ringBytes + 63) & ~uint64_t(63);
-    if (hipHostMalloc((void **) &f->ring, ringBytes, hipHostMallocPortable) != hipSuccess)
-        return setError(MLSGPU_ERR_NOMEM, "farm: cannot allocate %llu bytes of pinned mesh buffer", (unsigned long long) ringBytes);
+    {
+        /* ONE ring and ONE mesher thread, as the reference (src/workers.cpp:47-85): next to the first GPU */
+        const std::vector<int> cpus = placement::cpusOfNode(f->groups[0]->node);
+        hipError_t e = hipSuccess;
+        std::thread allocator([&] {
+            placement::bindThisThread(cpus);
+            e = hipSetDevice(f->groups[0]->device);
+            if (e == hipSuccess)
+                e = hipHostMalloc((void **) &f->ring, ringBytes, hipHostMallocPortable);
+        });
+        allocator.join();
+        if (e != hipSuccess)
+            return setError(MLSGPU_ERR_NOMEM, "farm: cannot allocate %llu bytes of pinned mesh buffer", (unsigned long long) ringBytes);
+        f->ring[0] = 0;
+        f->ringNode = placement::nodeOfAddress(f->ring);
+    }
     f->ringBytes = ringBytes;
     f->hostFn = fn;
     f->hostUser = user;
-    f->mesherThread = std::thread(mesherMain, static_cast<Farm *>(f));
+    f->mesherThread = std::thread([f] {
+        placement::bindThisThread(placement::cpusOfNode(f->groups[0]->node));
+        mesherMain(static_cast<Farm *>(f));
+    });
     f->hostOutput = true;
     return MLSGPU_OK;
 }
@@ -714,6 +860,8 @@ MLSGPU_API void mlsgpu_hip_farm_destroy(mlsgpu_farm *f)
         {
             hipFree(item->dSplats);
             if (item->copyEvent) hipEventDestroy(item->copyEvent);
+            if (item->copyStart) hipEventDestroy(item->copyStart);
+            if (item->copyStop) hipEventDestroy(item->copyStop);
         }
         for (hipEvent_t e : g->eventPool)
             hipEventDestroy(e);
@@ -725,8 +873,12 @@ MLSGPU_API void mlsgpu_hip_farm_destroy(mlsgpu_farm *f)
         if (g->copyCtx) mlsgpu_hip_ctx_destroy(g->copyCtx);
         if (g->copyStream) hipStreamDestroy(g->copyStream);
     }
-    for (auto &st : f->staging)
-        if (st.ptr) hipHostFree(st.ptr);
+    for (auto &side : f->sides)
+    {
+        side->pool.stop();
+        for (auto &st : side->staging)
+            if (st.ptr) hipHostFree(st.ptr);
+    }
     if (f->ring) hipHostFree(f->ring);
     delete f;
 }
@@ -737,10 +889,24 @@ MLSGPU_API int mlsgpu_hip_farm_acquire(mlsgpu_farm *f, uint64_t numSplats, mlsgp
 {
     REQUIRE(f != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
     REQUIRE(numSplats <= f->cfg.worker.maxBucketSplats, MLSGPU_ERR_LENGTH);
+    if (!f->clockRunning)
+    {
+        f->firstSubmit = std::chrono::steady_clock::now();
+        f->clockRunning = true;
+    }
     if (f->bufferedSplats + numSplats > f->cfg.worker.maxBucketSplats)
         PROPAGATE(flushBatch(f));
+    if (f->active == nullptr)
+    {
+        Farm::CopySide *side;
+        {
+            std::lock_guard<std::mutex> l(f->mutex);
+            side = pickSide(f);
+        }
+        PROPAGATE(claimStaging(f, side));
+    }
     f->acquired = numSplats;
-    *out = f->staging[f->cur].ptr + f->bufferedSplats;
+    *out = f->active->staging[f->active->cur].ptr + f->bufferedSplats;
     return MLSGPU_OK;
 }
 
@@ -767,31 +933,6 @@ MLSGPU_API int mlsgpu_hip_farm_push(mlsgpu_farm *f, uint64_t numSplats, const in
     return MLSGPU_OK;
 }
 
-/* one host thread moves ~10 GB/s; a bucket of 2 M splats (64 MB) is split over a few so that staging keeps up
- * with the PCIe link */
-static void parallelCopy(void *dst, const void *src, size_t bytes, unsigned threads)
-{
-    const size_t minChunk = size_t(4) << 20;
-    if (threads <= 1 || bytes < 2 * minChunk)
-    {
-        std::memcpy(dst, src, bytes);
-        return;
-    }
-    const size_t parts = std::min<size_t>(threads, bytes / minChunk);
-    const size_t chunk = (bytes / parts + 4095) & ~size_t(4095);
-    std::vector<std::thread> pool;
-    for (size_t p = 1; p < parts; p++)
-    {
-        const size_t off = p * chunk;
-        if (off >= bytes)
-            break;
-        pool.emplace_back([=] { std::memcpy((char *) dst + off, (const char *) src + off, std::min(chunk, bytes - off)); });
-    }
-    std::memcpy(dst, src, std::min(chunk, bytes));
-    for (std::thread &t : pool)
-        t.join();
-}
-
 MLSGPU_API int mlsgpu_hip_farm_submit(mlsgpu_farm *f, const mlsgpu_splat *hSplats, uint64_t numSplats,
                                       const int32_t lowExtent[3], const uint32_t numVertices[3], uint64_t chunkId)
 {
@@ -799,7 +940,11 @@ MLSGPU_API int mlsgpu_hip_farm_submit(mlsgpu_farm *f, const mlsgpu_splat *hSplat
     REQUIRE(numSplats == 0 || hSplats != nullptr, MLSGPU_ERR_INVALID);
     mlsgpu_splat *dst = nullptr;
     PROPAGATE(mlsgpu_hip_farm_acquire(f, numSplats, &dst));
-    parallelCopy(dst, hSplats, numSplats * sizeof(mlsgpu_splat), f->cfg.copyThreads == 0 ? 4u : f->cfg.copyThreads);
+    /* one host thread moves ~10 GB/s: a bucket of 2 M splats (64 MB) is split over the side's copy threads so that
+     * staging keeps up with the PCIe link */
+    const auto t0 = std::chrono::steady_clock::now();
+    f->active->pool.copy(dst, hSplats, numSplats * sizeof(mlsgpu_splat));
+    f->copyClock[0] += secondsSince(t0);
     return mlsgpu_hip_farm_push(f, numSplats, lowExtent, numVertices, chunkId);
 }
 
@@ -987,6 +1132,119 @@ MLSGPU_API int mlsgpu_hip_farm_in_flight_max(mlsgpu_farm *f, uint64_t *out)
     REQUIRE(f != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
     std::lock_guard<std::mutex> l(f->mutex);
     *out = f->inFlightMax;
+    return MLSGPU_OK;
+}
+
+/* ---- placement (placement.hpp) ---- */
+
+MLSGPU_API int mlsgpu_hip_device_node(int device)
+{
+    const int forced = placement::overriddenDeviceNode(device);
+    if (forced != -2)
+        return forced;
+    char bdf[64] = {0};
+    if (hipDeviceGetPCIBusId(bdf, (int) sizeof(bdf), device) != hipSuccess)
+    {
+        (void) hipGetLastError();
+        return -1;
+    }
+    return placement::pciNode(placement::sysfsRoot(), bdf);
+}
+
+MLSGPU_API int mlsgpu_hip_topology(uint32_t *numNodes, uint32_t cpusPerNode[16])
+{
+    REQUIRE(numNodes != nullptr, MLSGPU_ERR_INVALID);
+    const std::vector<std::vector<int> > nodes = placement::readNodes(placement::sysfsRoot());
+    *numNodes = (uint32_t) nodes.size();
+    for (size_t i = 0; cpusPerNode != nullptr && i < 16; i++)
+        cpusPerNode[i] = i < nodes.size() ? (uint32_t) nodes[i].size() : 0;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_plan_copy_sides(const int32_t *deviceNodes, uint32_t numDevices, uint32_t numNodes,
+                                          int32_t *sideOfDevice, int32_t *nodeOfSide, uint32_t *numSides)
+{
+    REQUIRE(deviceNodes != nullptr && sideOfDevice != nullptr && nodeOfSide != nullptr && numSides != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(numDevices >= 1 && numDevices <= 16, MLSGPU_ERR_INVALID);
+    std::vector<int> sideOf, nodeOf;
+    placement::planSides(deviceNodes, numDevices, numNodes, sideOf, nodeOf);
+    for (uint32_t i = 0; i < numDevices; i++)
+        sideOfDevice[i] = sideOf[i];
+    for (size_t k = 0; k < nodeOf.size(); k++)
+        nodeOfSide[k] = nodeOf[k];
+    *numSides = (uint32_t) nodeOf.size();
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_bind_thread_to_node(int node)
+{
+    return placement::bindThisThread(placement::cpusOfNode(node)) ? 1 : 0;
+}
+
+/* test hook: `rounds` copies of varying sizes up to `bytes` through a CopyPool of `threads` threads bound to `node`'s CPUs,
+ * each compared with its source; returns the number of mismatching copies */
+MLSGPU_API int mlsgpu_hip_test_copy_pool(uint32_t threads, uint32_t rounds, uint64_t bytes, int node)
+{
+    placement::CopyPool pool;
+    pool.start(threads, placement::cpusOfNode(node));
+    std::vector<unsigned char> src(bytes), dst(bytes);
+    int bad = 0;
+    uint64_t x = 0x9E3779B97F4A7C15ull;
+    for (uint32_t r = 0; r < rounds; r++)
+    {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        const uint64_t n = bytes == 0 ? 0 : (r % 3 == 0 ? bytes : x % (bytes + 1));
+        for (uint64_t i = 0; i < n; i += 509)
+            src[i] = (unsigned char) (x + i + r);
+        std::fill(dst.begin(), dst.begin() + (long) n, (unsigned char) 0xA5);
+        pool.copy(dst.data(), src.data(), n);
+        bad += std::memcmp(dst.data(), src.data(), n) != 0;
+    }
+    return bad;
+}
+
+MLSGPU_API int mlsgpu_hip_farm_placement(mlsgpu_farm *f, int32_t out[100])
+{
+    REQUIRE(f != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    for (int i = 0; i < 100; i++)
+        out[i] = -1;
+    out[0] = (int32_t) f->sides.size();
+    out[1] = f->ringNode;
+    out[2] = (int32_t) placement::numNodes();
+    out[3] = (int32_t) f->groups.size();
+    for (size_t d = 0; d < f->groups.size() && d < 16; d++)
+    {
+        out[4 + 3 * d] = f->groups[d]->device;
+        out[5 + 3 * d] = f->groups[d]->node;
+        out[6 + 3 * d] = (int32_t) f->groups[d]->side;
+    }
+    for (size_t k = 0; k < f->sides.size() && k < 12; k++)
+    {
+        out[52 + 4 * k] = f->sides[k]->node;
+        out[53 + 4 * k] = f->sides[k]->stagingNode;
+        out[54 + 4 * k] = (int32_t) f->sides[k]->staging.size();
+        out[55 + 4 * k] = (int32_t) f->sides[k]->pool.threads();
+    }
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_farm_copy_clock(mlsgpu_farm *f, double out[8])
+{
+    REQUIRE(f != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    /* the copies still attached to items are added without being consumed: the caller has finished the farm */
+    std::lock_guard<std::mutex> l(f->mutex);
+    for (int i = 0; i < 8; i++)
+        out[i] = f->copyClock[i];
+    for (auto &g : f->groups)
+        for (auto &item : g->items)
+            if (item->copyTimed && hipEventQuery(item->copyStop) == hipSuccess)
+            {
+                float ms = 0.0f;
+                if (hipEventElapsedTime(&ms, item->copyStart, item->copyStop) == hipSuccess)
+                    out[3] += ms * 1e-3;
+            }
+    (void) hipGetLastError();
+    out[4] = f->clockRunning ? std::chrono::duration<double>(f->lastFlush - f->firstSubmit).count() : 0.0;
     return MLSGPU_OK;
 }
 

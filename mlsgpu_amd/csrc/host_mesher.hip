@@ -26,9 +26,11 @@
  * Host code only; it lives in the HIP library because the farm's mesher thread calls it.
  */
 #include "common.hpp"
+#include "placement.hpp"
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <deque>
@@ -80,6 +82,8 @@ public:
         }
         Slab s;
         s.cap = (atLeast + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
+        freshSlabs++;
+        freshBytes += s.cap;
         void *p = mmap(nullptr, s.cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
         if (p == MAP_FAILED)
             return Slab();
@@ -134,6 +138,7 @@ public:
         std::lock_guard<std::mutex> l(mutex);
         return limit;
     }
+    std::atomic<uint64_t> freshSlabs{0}, freshBytes{0};     /* mappings made because no kept slab was large enough */
 
 private:
     SlabCache()
@@ -190,10 +195,14 @@ private:
 class Pool
 {
 public:
-    explicit Pool(unsigned threads)
+    /* `cpus`: the CPUs the pool's threads are bound to (empty: wherever the scheduler puts them) */
+    explicit Pool(unsigned threads, const std::vector<int> &cpus = std::vector<int>())
     {
         for (unsigned i = 0; i < threads; i++)
-            workers.emplace_back([this] { run(); });
+            workers.emplace_back([this, cpus] {
+                placement::bindThisThread(cpus);
+                run();
+            });
     }
     ~Pool()
     {
@@ -454,6 +463,17 @@ struct mlsgpu_host_mesher
     Shard shards[NUM_SHARDS];
     std::unique_ptr<Pool> pool;
     unsigned threads = 0;
+    int node = -1;                          /* NUMA node the pool's threads are bound to (-1: none) */
+    /* MLSGPU_HIP_WELDER_TRACE=1: where a job's time went, one line on stderr when the welder is destroyed */
+    struct Trace
+    {
+        bool on = getenv("MLSGPU_HIP_WELDER_TRACE") != nullptr;
+        std::chrono::steady_clock::time_point firstAdd, lastAdd;
+        double addS = 0, copyS = 0, drainS = 0, resolveS = 0, passesS = 0;
+        uint64_t adds = 0, pieces = 0;
+        std::atomic<uint64_t> callerPieces{0}, taskNs{0};
+        uint64_t slabs0 = 0, bytes0 = 0;
+    } trace;
     std::mutex errorMutex;
     int taskError = MLSGPU_OK;
     std::string taskErrorText;
@@ -472,6 +492,17 @@ struct mlsgpu_host_mesher
     std::vector<uint32_t> outChunks;
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
+    placement::CopyPool copiers;
+    bool copiersStarted = false;
+    placement::CopyPool &getCopiers()
+    {
+        if (!copiersStarted)
+        {
+            copiers.start(std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 4)), placement::cpusOfNode(node));
+            copiersStarted = true;
+        }
+        return copiers;
+    }
     Pool &getPool()
     {
         if (!pool)
@@ -482,7 +513,7 @@ struct mlsgpu_host_mesher
                 const char *e = getenv("MLSGPU_HIP_HOST_MESHER_THREADS");
                 n = e != nullptr ? (unsigned) std::max(1, atoi(e)) : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
             }
-            pool.reset(new Pool(n));
+            pool.reset(new Pool(n, placement::cpusOfNode(node)));
             threads = n;
         }
         return *pool;
@@ -640,6 +671,16 @@ MLSGPU_API void mlsgpu_hip_host_mesher_destroy(mlsgpu_host_mesher *m)
         return;
     if (m->pool)
         m->pool->drain();
+    if (m->trace.on && m->trace.adds > 0)
+        fprintf(stderr, "mlsgpu_hip welder: %llu adds in %.1f ms (first add .. last add returned), add() %.1f ms of which copies %.1f "
+                        "(%llu of %llu pieces by the caller), block tasks %.1f ms of thread time; finalize: drain %.1f, resolve %.1f, "
+                        "passes %.1f ms; fresh slabs %llu (%.0f MB)\n",
+                (unsigned long long) m->trace.adds,
+                std::chrono::duration<double>(m->trace.lastAdd - m->trace.firstAdd).count() * 1e3, m->trace.addS * 1e3,
+                m->trace.copyS * 1e3, (unsigned long long) m->trace.callerPieces.load(), (unsigned long long) m->trace.pieces,
+                m->trace.taskNs.load() * 1e-6, m->trace.drainS * 1e3, (m->trace.resolveS - m->trace.drainS) * 1e3,
+                m->trace.passesS * 1e3, (unsigned long long) (SlabCache::instance().freshSlabs.load() - m->trace.slabs0),
+                (SlabCache::instance().freshBytes.load() - m->trace.bytes0) / 1048576.0);
     delete m;
 }
 
@@ -661,6 +702,21 @@ MLSGPU_API int mlsgpu_hip_host_mesher_set_threads(mlsgpu_host_mesher *m, uint32_
     return MLSGPU_OK;
 }
 
+/* The welder's threads on ONE NUMA node: the one the meshes arrive on (the farm's read-back ring is next to its first GPU,
+ * mlsgpu_hip_farm_placement out[1]).  A block's pieces are then welded by threads that share a socket's caches -- a block
+ * whose pieces were spread over two sockets took the pass from 39 to 54-65 ms (profiles/NOTES_r04.md 9.9).  -1 = unbound
+ * (the default).  Before the first add. */
+MLSGPU_API int mlsgpu_hip_host_mesher_set_node(mlsgpu_host_mesher *m, int node)
+{
+    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    REQUIRE(!m->pool, MLSGPU_ERR_INVALID);
+    m->node = node;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_host_mesher_node(mlsgpu_host_mesher *m) { return m ? m->node : -1; }
+
 MLSGPU_API uint32_t mlsgpu_hip_host_mesher_threads(mlsgpu_host_mesher *m)
 {
     if (m == nullptr)
@@ -681,6 +737,13 @@ MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkI
     b->nv = nv;
     b->nInternal = ni;
     b->nt = nt;
+    const auto tAdd0 = std::chrono::steady_clock::now();
+    if (m->trace.on && m->trace.adds == 0)
+    {
+        m->trace.firstAdd = tAdd0;
+        m->trace.slabs0 = SlabCache::instance().freshSlabs.load();
+        m->trace.bytes0 = SlabCache::instance().freshBytes.load();
+    }
     /* the caller's memory (a slot of the farm's ring) is free again when this call returns */
     b->vertices = m->arena.array<float>(3 * nv);
     b->triangles = m->arena.array<uint32_t>(3 * nt);
@@ -702,8 +765,12 @@ MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkI
         cut(b->triangles, mesh->triangles, 3 * nt * sizeof(uint32_t), true);
         cut(b->keys, mesh->vertexKeys, ne * sizeof(uint64_t), false);
         std::atomic<uint32_t> badIndex{0};
+        const std::thread::id caller = std::this_thread::get_id();
+        const auto tCopy0 = std::chrono::steady_clock::now();
         auto copyPiece = [&](size_t i) {
             const Piece &p = pieces[i];
+            if (m->trace.on && std::this_thread::get_id() == caller)
+                m->trace.callerPieces++;
             std::memcpy(p.dst, p.src, p.bytes);
             if (p.indices)
             {
@@ -716,11 +783,17 @@ MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkI
                     badIndex.store(1);
             }
         };
+        /* on the welder's own few copy threads, not on the pool of the block tasks: a mesh must leave the ring at the rate
+         * meshes arrive whatever the pool is busy with (and the caller -- the farm's ONE mesher thread -- sleeps on a
+         * condition variable meanwhile; spinning on yield() cost it whole time slices when another welder's finalize ran
+         * beside this one: 0.8 -> 2.7 ms per block) */
         if (pieces.size() <= 2)
             for (size_t i = 0; i < pieces.size(); i++)
                 copyPiece(i);
         else
-            m->getPool().parallelForNow(pieces.size(), copyPiece);
+            m->getCopiers().run(pieces.size(), copyPiece);
+        m->trace.copyS += std::chrono::duration<double>(std::chrono::steady_clock::now() - tCopy0).count();
+        m->trace.pieces += pieces.size();
         /* a bad mesh leaves the sink unchanged (its copy stays behind in the arena, unused) */
         REQUIRE(badIndex.load() == 0, MLSGPU_ERR_INVALID);
     }
@@ -738,7 +811,15 @@ MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkI
     b->seq = (uint32_t) m->blocks.size();
     Block *raw = b.get();
     m->blocks.push_back(std::move(b));
-    m->getPool().submit([m, raw] { m->processBlock(raw); });
+    m->getPool().submit([m, raw] {
+        const auto t0 = std::chrono::steady_clock::now();
+        m->processBlock(raw);
+        if (m->trace.on)
+            m->trace.taskNs += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    });
+    m->trace.adds++;
+    m->trace.lastAdd = std::chrono::steady_clock::now();
+    m->trace.addS += std::chrono::duration<double>(m->trace.lastAdd - tAdd0).count();
     return MLSGPU_OK;
 }
 
@@ -752,7 +833,9 @@ MLSGPU_API int mlsgpu_hip_host_mesher_farm_output(void *mesher, int device, uint
  * the components' vertex / triangle counts -- a vertex seen k times was counted k times, each record takes one back */
 int mlsgpu_host_mesher::resolve()
 {
+    const auto tDrain0 = std::chrono::steady_clock::now();
     getPool().drain();
+    trace.drainS += std::chrono::duration<double>(std::chrono::steady_clock::now() - tDrain0).count();
     {
         std::lock_guard<std::mutex> l(errorMutex);
         if (taskError != MLSGPU_OK)
@@ -825,7 +908,10 @@ int mlsgpu_host_mesher::resolve()
  * mlsgpu_hip_host_mesher_boundary) */
 int mlsgpu_host_mesher::finalizeWith(const uint8_t *keepClump, uint32_t *numChunks)
 {
+    const auto tRes0 = std::chrono::steady_clock::now();
     PROPAGATE(resolve());
+    const auto tPass0 = std::chrono::steady_clock::now();
+    trace.resolveS += std::chrono::duration<double>(tPass0 - tRes0).count();
     const uint32_t nc = (uint32_t) chunkIds.size();
     const uint64_t numClumps = parent.size();
     uint64_t total = 0, components = 0;
@@ -1023,6 +1109,7 @@ int mlsgpu_host_mesher::finalizeWith(const uint8_t *keepClump, uint32_t *numChun
     stats[6] = nvAdded;
     stats[7] = ntAdded;
     finalized = true;
+    trace.passesS += std::chrono::duration<double>(std::chrono::steady_clock::now() - tPass0).count();
     if (numChunks)
         *numChunks = (uint32_t) outChunks.size();
     return MLSGPU_OK;

@@ -37,7 +37,7 @@ struct mlsgpu_mls
 {
     mlsgpu_ctx *ctx = nullptr;
     int shape = MLSGPU_SHAPE_SPHERE;
-    int variant = 4;             /* culled + cube streams: the fastest on both BASELINE clouds (round 3); 0-3 stay selectable */
+    int variant = 4;             /* culled + cube streams: the fastest on both BASELINE clouds; 1 = the reference's loop structure (variants 0, 2, 3 were removed in round 4) */
     const mlsgpu_splat *dSplats = nullptr;
     const int32_t *dCommands = nullptr;
     const int32_t *dStart = nullptr;

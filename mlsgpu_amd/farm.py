@@ -66,3 +66,43 @@ def partition_to_farm(ctx, bucket_farm, device, raw, num_splats, reference, spac
 def leaf_cells(leaf):
     e = leaf["extents"]
     return (e[1] - e[0]) * (e[3] - e[2]) * (e[5] - e[4])
+
+
+def node_cpus(node, root=None):
+    """CPUs of a NUMA node from sysfs ([] when the node is not listed)."""
+    import os
+    root = root or os.environ.get("MLSGPU_HIP_SYSFS_ROOT") or "/sys"
+    try:
+        text = open("%s/devices/system/node/node%d/cpulist" % (root, node)).read().strip()
+    except OSError:
+        return []
+    out = []
+    for part in text.split(","):
+        if part:
+            lo, _, hi = part.partition("-")
+            out += range(int(lo), int(hi or lo) + 1)
+    return out
+
+
+def bind_process_to_device_node(device):
+    """One process per GPU: the process -- every thread it starts from now on, every first touch of host memory -- on the
+    CPUs of the NUMA node its GPU hangs off (what `numactl --cpunodebind` does for a launcher that knows the topology;
+    torch.distributed.run does not).  Call it before anything is allocated.  Returns what was done, for the bench line:
+    {"numa_nodes", "gpu_node", "bound", "cpus"}.  A one-node machine, an unknown node or an affinity mask that excludes the
+    node's CPUs leaves the process alone.  The library's own threads (the farm's copy sides, device workers, the host
+    welder) place themselves per GPU either way (csrc/placement.hpp)."""
+    import os
+    from . import binding as mb
+    import numpy as np
+    n = np.zeros(1, np.uint32)
+    mb.check(mb.lib().mlsgpu_hip_topology(n.ctypes.data, None))
+    node = int(mb.lib().mlsgpu_hip_device_node(int(device)))
+    out = {"numa_nodes": int(n[0]), "gpu_node": node, "bound": False, "cpus": len(os.sched_getaffinity(0))}
+    if n[0] < 2 or node < 0:
+        return out
+    want = set(node_cpus(node)) & os.sched_getaffinity(0)
+    if not want:
+        return out
+    os.sched_setaffinity(0, want)
+    out.update(bound=True, cpus=len(want))
+    return out

@@ -614,6 +614,9 @@ public:
     void setPruneThreshold(double t) { check(mlsgpu_hip_host_mesher_set_prune_threshold(h, t)); }
     /// threads of the welder (0 = default); before the first add
     void setThreads(std::uint32_t threads) { check(mlsgpu_hip_host_mesher_set_threads(h, threads)); }
+    /// the welder's threads on one NUMA node (the one its meshes arrive on); -1 = unbound.  Before the first add.
+    void setNode(int node) { check(mlsgpu_hip_host_mesher_set_node(h, node)); }
+    int node() const { return mlsgpu_hip_host_mesher_node(h); }
     void add(std::uint64_t chunkId, const mlsgpu_host_mesh &mesh) { check(mlsgpu_hip_host_mesher_add(h, chunkId, &mesh)); }
     std::size_t write(const Namer &namer, const std::vector<std::string> &comments = std::vector<std::string>())
     {
@@ -697,6 +700,10 @@ public:
     void setHostOutput(std::uint64_t ringBytes, OOCMesher &mesher)
     {
         check(mlsgpu_hip_farm_set_host_output(h, ringBytes, &mlsgpu_hip_host_mesher_farm_output, mesher.get()));
+        // a welder that has not been placed joins the ring's NUMA node (ignored once its threads exist)
+        std::int32_t where[100];
+        if (mesher.node() < 0 && mlsgpu_hip_farm_placement(h, where) == MLSGPU_OK && where[1] >= 0)
+            (void) mlsgpu_hip_host_mesher_set_node(mesher.get(), where[1]);
     }
     Splat *acquire(std::uint64_t numSplats)                                 // CopyGroup::get
     {
