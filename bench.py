@@ -687,16 +687,10 @@ def host_weld_leg(m, args, device_index, bucketed_host, buckets, max_count, max_
     # the stream has its own warm-up (the second set of slabs is mapped and faulted in once)
     in_times, join_times = [], []
 
-    alt = os.environ.get("MLSGPU_BENCH_WELD_ALTERNATE_NODES") == "1"
-    jobno = [0]
-
     def stream(count, times):
         pending = None
         for _ in range(count):
             welder = m.HostMesher(0.02, threads=args.weld_threads)
-            if alt:
-                welder.set_node(jobno[0] % 2)
-            jobno[0] += 1
             t = time.perf_counter()
             stream_in(welder)
             in_times.append(time.perf_counter() - t)
@@ -717,18 +711,19 @@ def host_weld_leg(m, args, device_index, bucketed_host, buckets, max_count, max_
     farm.close()
     st = last["st"]
     total = sum(a + b for a, b in alone) / len(alone)
-    return {"value": round(voxels / per_job / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(per_job * 1e3, 1), "steps": jobs,
-            "finalize_ms_in_the_stream": round(sum(fin_times) / len(fin_times) * 1e3, 1),
-            "stream_in_ms": round(sum(in_times[-jobs:]) / jobs * 1e3, 1), "wait_for_previous_finalize_ms": round(sum(join_times[-jobs:]) / jobs * 1e3, 1),
-            "one_job_alone": {"ms": round(total * 1e3, 1), "value": round(voxels / total / 1e6, 3), "jobs": len(alone),
-                              "pass_until_last_mesh_welded_ms": round(sum(a for a, _ in alone) / len(alone) * 1e3, 1),
-                              "finalize_ms": round(sum(b for _, b in alone) / len(alone) * 1e3, 1)},
-            "vertices_welded_per_s": round(st["vertices_added"] / per_job), "weld_threads": last["threads"], "chunks": last["n"],
+    return {"value": round(voxels / total / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(total * 1e3, 1), "steps": len(alone),
+            "pass_until_last_mesh_welded_ms": round(sum(a for a, _ in alone) / len(alone) * 1e3, 1),
+            "finalize_ms": round(sum(b for _, b in alone) / len(alone) * 1e3, 1),
+            "streamed": {"ms_per_step": round(per_job * 1e3, 1), "value": round(voxels / per_job / 1e6, 3), "jobs": jobs,
+                         "finalize_ms": round(sum(fin_times) / len(fin_times) * 1e3, 1),
+                         "stream_in_ms": round(sum(in_times[-jobs:]) / jobs * 1e3, 1),
+                         "wait_for_previous_finalize_ms": round(sum(join_times[-jobs:]) / jobs * 1e3, 1),
+                         "what": "job k's finalize on its own thread while job k + 1 streams into the next welder"},
+            "vertices_welded_per_s": round(st["vertices_added"] / total), "weld_threads": last["threads"], "chunks": last["n"],
             "ring_waits": hs["ring_waits"], "welded_vertices": st["total_vertices"], "kept_triangles": st["kept_triangles"],
-            "note": "per job in a stream of jobs: host splats in -> farm -> ring read-backs -> host welder (a task per block on "
-                    "weld_threads threads) -> finalize on its own thread while the next job streams in; one_job_alone = the same job "
-                    "with nothing overlapped (its latency); the reference welds on one mesher thread "
-                    "(doc/mlsgpu-user-manual.xml:508-511)"}
+            "note": "per job, jobs one after the other: host splats in -> farm -> ring read-backs -> host welder (a task per block on "
+                    "weld_threads threads) -> finalize; streamed = the same jobs with a job's finalize overlapping the next job's "
+                    "transfer; the reference welds on one mesher thread (doc/mlsgpu-user-manual.xml:508-511)"}
 
 
 def multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, local_rank, ndev, ctx, bucketed_t, buckets, max_count,

@@ -825,6 +825,13 @@ MLSGPU_API int mlsgpu_hip_farm_set_host_output(mlsgpu_farm *f, uint64_t ringByte
             return setError(MLSGPU_ERR_NOMEM, "farm: cannot allocate %llu bytes of pinned mesh buffer", (unsigned long long) ringBytes);
         f->ring[0] = 0;
         f->ringNode = placement::nodeOfAddress(f->ring);
+        if (getenv("MLSGPU_HIP_FARM_TRACE") != nullptr)
+        {
+            std::string where;
+            for (int k = 0; k < 32; k++)
+                where += std::to_string(placement::nodeOfAddress(f->ring + (ringBytes / 32) * k)) + " ";
+            fprintf(stderr, "mlsgpu_hip farm: the ring's %llu MB, node of every 32nd part: %s\n", (unsigned long long) (ringBytes >> 20), where.c_str());
+        }
     }
     f->ringBytes = ringBytes;
     f->hostFn = fn;

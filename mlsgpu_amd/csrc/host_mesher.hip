@@ -88,6 +88,7 @@ public:
         if (p == MAP_FAILED)
             return Slab();
         (void) madvise(p, s.cap, MADV_HUGEPAGE);
+        placement::preferNodeOfThisThread(p, s.cap);
         s.base = static_cast<char *>(p);
         return s;
     }
@@ -278,7 +279,8 @@ public:
                 pending++;
             }
         }
-        wake.notify_all();
+        for (size_t t = 0; t < helpers; t++)
+            wake.notify_one();              /* as many threads as there are pieces for, not the whole pool */
         body();
         while (sh->done.load() < n)
             std::this_thread::yield();
@@ -756,7 +758,7 @@ MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkI
         struct Piece { char *dst; const char *src; size_t bytes; bool indices; };
         std::vector<Piece> pieces;
         auto cut = [&](void *dst, const void *src, size_t bytes, bool indices) {
-            const size_t step = size_t(4) << 20;
+            const size_t step = size_t(1) << 20;
             for (size_t o = 0; o < bytes; o += step)
                 pieces.push_back(Piece{static_cast<char *>(dst) + o, static_cast<const char *>(src) + o, std::min(step, bytes - o),
                                        indices});
