@@ -784,10 +784,10 @@ def multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, loca
     host = views = sink = bfarm = pinned = None
     run_transfer = in_budget("transfer_inclusive")
     try:
-        host = bucketed_t.cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
+        host = synth.to_host_splats(bucketed_t)
         views = [host[b.first:b.first + b.count] for b in buckets]
         sink = m.Mesher(ctx, 0.02)
-        bfarm = m.BucketFarm([local_rank], max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
+        bfarm = m.BucketFarm([local_rank], max_count, workers_per_device=nworkers, spare=args.farm_spare, max_cells=max_cells,
                              mesh_memory=args.mesh_memory_mb << 20, sink=sink)
         pinned = m.binding.PinnedBuffer(1)
     except Exception as e:      # noqa: BLE001
@@ -878,7 +878,7 @@ def multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, loca
 def single_process_leg(m, args, result, ctx, local_rank, devices, bucketed_t, buckets, views, max_count, max_cells, voxels, L,
                        nworkers, world, deadline=None):
     """The reference's own shape (src/mlsgpu_core.cpp:704-741) on rank 0: one farm over every GPU, N x rank 0's slab."""
-    sfarm = m.BucketFarm(devices, max_count, workers_per_device=nworkers, spare=1, max_cells=max_cells,
+    sfarm = m.BucketFarm(devices, max_count, workers_per_device=nworkers, spare=args.farm_spare, max_cells=max_cells,
                          mesh_memory=args.mesh_memory_mb << 20)
 
     def host_fed():
@@ -1610,7 +1610,7 @@ def main():
     # the remaining legs start from HOST memory: one copy of the bucketed splats
     bucketed_host = None
     if secondary and not args.no_transfer:
-        bucketed_host = bucketed_t.cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
+        bucketed_host = synth.to_host_splats(bucketed_t)
     del workers, work, pristine, bucketed_t, W
     torch.cuda.empty_cache()
 
@@ -1661,7 +1661,7 @@ def main():
                       "workload": "cfg3 grid, %d splats on concentric shells (D1 of SURVEY 8d), %d buckets" % (int(50_000_000 * args.scale), len(sbuckets)),
                       "triangles_per_step": sum(c.triangles for c in scol) // ssteps,
                       "vertices_per_step": sum(c.vertices for c in scol) // ssteps}
-            sb_host = sb_t.cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1) if not args.no_transfer else None
+            sb_host = synth.to_host_splats(sb_t) if not args.no_transfer else None
             del sworkers, swork, sprist, sb_t
             torch.cuda.empty_cache()
             if not args.no_transfer:

@@ -395,3 +395,24 @@ def bucketize(splats, grid, max_cells=255):
                 buckets.append(Bucket((x0, y0, z0), (x1 - x0 + 1, y1 - y0 + 1, z1 - z0 + 1), first, len(idx)))
                 first += len(idx)
     return np.concatenate(pieces), buckets
+
+
+def to_host_splats(bucketed_t):
+    """A (n, 8) float32 splat tensor on a GPU -> a host array of SPLAT_DTYPE in memory of its own mapping, advised to use
+    huge pages and touched here (so on the caller's NUMA node): the stand-in for what a loader has in memory when it
+    hands buckets to the farm.  An ordinary allocation made late in a long-lived process sits on whatever 4 KB pages the
+    allocator has left, and copying out of it runs at half the rate (profiles/NOTES_r04.md 9.10)."""
+    import mmap
+    import torch
+    n = int(bucketed_t.shape[0])
+    nbytes = max(n * 32, 1)
+    mem = mmap.mmap(-1, (nbytes + (2 << 20) - 1) & ~((2 << 20) - 1))
+    try:
+        mem.madvise(mmap.MADV_HUGEPAGE)
+    except (AttributeError, OSError, ValueError):
+        pass
+    flat = np.frombuffer(mem, dtype=np.float32, count=n * 8).reshape(n, 8)
+    step = 8_000_000
+    for lo in range(0, n, step):
+        torch.from_numpy(flat[lo:lo + step]).copy_(bucketed_t[lo:lo + step])
+    return flat.view(SPLAT_DTYPE).reshape(-1)

@@ -71,7 +71,7 @@ def main():
     smax = max(b.count for b in sbuckets)
     scells = max(max(b.num_vertices) for b in sbuckets) - 1
     svox = sum(b.cells for b in sbuckets)
-    host = sb_t.cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
+    host = synth.to_host_splats(sb_t)
     del sb_t
     torch.cuda.empty_cache()
     res = {"gpu_node": node, "bound_to": bound, "copy_threads": a.copy_threads, "spare": a.spare, "staging": a.staging,
