@@ -403,6 +403,25 @@ def run_cfg5(args, rank, world, local_rank, device, dist, reduce_device):
 
 # ---------------------------------------------------------------------------------------------------- legs
 
+def drain_utilisation(c):
+    """How the accumulation loops of processCorners use a wave's 64 lanes (mlsgpu_hip_mls_set_stats): a drain call runs as
+    many iterations as the longest of its lanes' hit lists, so utilisation = hits / (64 x iterations)."""
+    hits, calls, it = c[2], c[3], c[4]
+    if calls == 0 or it == 0:
+        return None
+    hist = c[8:41]
+    lanes = sum(hist)
+    return {"drain_calls": calls, "iterations": it, "mean_hits_per_lane_per_call": round(hits / max(lanes, 1), 3),
+            "mean_longest_list": round(it / calls, 3), "utilisation": round(hits / (64.0 * it), 4),
+            "if_two_calls_were_one": round(hits / (64.0 * c[5]), 4) if c[5] else None,
+            "if_a_round_were_one_call": round(hits / (64.0 * c[6]), 4) if c[6] else None,
+            "if_a_block_were_one_call": round(hits / (64.0 * c[7]), 4) if c[7] else None,
+            "lanes_by_hits_per_call": {str(n): hist[n] for n in range(33) if hist[n]},
+            "what": "the accumulation order per corner is fixed (bit-identical sums), so a lane's hits cannot move to another "
+                    "lane: utilisation is bounded by how unevenly a call's hits fall on the 64 corners; merging calls "
+                    "evens them out at the price of LDS for the lists that must stay alive"}
+
+
 def cpu_sample_boxes(grid, side=63):
     """Where the CPU baseline samples the cloud: cubes of `side` cells on a regular lattice through the whole grid, in an
     order that visits distant places first, so that any prefix is spread over the cloud."""
@@ -1112,7 +1131,7 @@ def main():
         single_worker_ms = (time.perf_counter() - t0) / sw_steps * 1e3
 
     # ---- algorithmic work + output digest (one instrumented, untimed pass on worker 0) ----
-    counters = m.DeviceBuffer(ctx, array=np.zeros(3, np.uint64))
+    counters = m.DeviceBuffer(ctx, array=np.zeros(m.binding.MLS_STATS_WORDS, np.uint64))
     w0 = workers[0]
     before = w0.marching_counters()
     w0.set_mls_stats(counters)
@@ -1126,7 +1145,8 @@ def main():
             entries += w0.tree_num_entries(lane)
             corners += int(np.prod([-(-n // 8) * 8 for n in b.num_vertices]))
     ctx.synchronize()
-    listed, tests, hits = (int(x) for x in counters.download(np.uint64))
+    mls_counters = [int(x) for x in counters.download(np.uint64)]
+    listed, tests, hits = mls_counters[:3]
     w0.set_mls_stats(None)
     after = w0.marching_counters()
     mc = {k: after[k] - before[k] for k in after}
@@ -1423,6 +1443,7 @@ def main():
                                      "splat loop, most of which sub-block culling never executes",
                 "hbm_algorithmic_GBps": round((36 * listed + 4 * corners) / (ms * 1e-3) / 1e9, 1),
                 "sigma_L": listed, "tests": tests, "hits": hits, "corners": corners,
+                "drain_lane_utilisation": drain_utilisation(mls_counters),
                 "share_of_kernel_time": round(stages[0]["ms_per_step"] / sum(s_["ms_per_step"] for s_ in stages), 3),
                 "measured": measured,
             }

@@ -194,9 +194,14 @@ int mlsgpu_hip_mls_generator(mlsgpu_mls *mls, mlsgpu_generator *gen);
  * reference's structure (every corner walks every listed splat), kept for A/B.  Bit-identical results.  Other values are
  * MLSGPU_ERR_INVALID (0, 2 and 3 were intermediate designs of earlier rounds). */
 int mlsgpu_hip_mls_set_variant(mlsgpu_mls *mls, int variant);
-/* Measurement aid: with a non-NULL device array of 3 uint64 the next enqueues run an instrumented kernel that
- * adds [0] listed splats (Sigma L of SURVEY 8d), [1] (corner, splat) distance tests executed, [2] hits (H).
- * Results are unchanged; NULL switches back to the production kernel. */
+/* Measurement aid: with a non-NULL device array of MLSGPU_MLS_STATS_WORDS uint64 the next enqueues run an instrumented
+ * kernel that adds [0] listed splats (Sigma L of SURVEY 8d), [1] (corner, splat) distance tests executed, [2] hits (H);
+ * and, for the default kernel, how its accumulation ("drain") loops use the 64 lanes of a wave -- a drain call runs as many
+ * iterations as the LONGEST of its 64 lanes' hit lists: [3] drain calls, [4] iterations they ran (sum of the longest
+ * list), [5] the iterations if every two consecutive calls of a wave were one call, [6] if a whole round of staged splats
+ * were one call, [7] if a whole block were; [8 + n], n = 0 .. 32: lanes that had n hits in a drain call.  Lane
+ * utilisation of the drain = [2] / (64 x [4]).  Results are unchanged; NULL switches back to the production kernel. */
+#define MLSGPU_MLS_STATS_WORDS 41
 int mlsgpu_hip_mls_set_stats(mlsgpu_mls *mls, uint64_t *dCounters);
 
 /* ---- Marching (src/marching.h:494-608) ---- */

@@ -16,6 +16,9 @@ SPLAT_DTYPE = np.dtype([("position", np.float32, 3), ("radius", np.float32),
 SHAPE_SPHERE, SHAPE_PLANE = 0, 1
 
 
+MLS_STATS_WORDS = 41       # MLSGPU_MLS_STATS_WORDS
+
+
 class MlsError(Exception):
     """Base class of errors raised through the C-ABI."""
 
@@ -1196,7 +1199,7 @@ class Worker:
         check(lib().mlsgpu_hip_worker_set_keep_splats(self.h, 1 if keep else 0))
 
     def set_mls_stats(self, counters):
-        """counters: DeviceBuffer of 3 uint64 (or None): see mlsgpu_hip_mls_set_stats."""
+        """counters: DeviceBuffer of MLS_STATS_WORDS uint64 (or None): see mlsgpu_hip_mls_set_stats."""
         check(lib().mlsgpu_hip_mls_set_stats(lib().mlsgpu_hip_worker_mls(self.h), counters.ptr if counters else None))
 
     def marching_counters(self, lane=None):

@@ -217,7 +217,7 @@ struct MlsArgs
     float boundaryFactor;
     uint32_t xcdChunk;           /* see xcdRemap */
     uint32_t rawRadius;          /* splat.w is the radius, not 1/radius^2 */
-    unsigned long long *stats;   /* [0] listed splats, [1] (corner, splat) distance tests, [2] hits */
+    unsigned long long *stats;   /* MLSGPU_MLS_STATS_WORDS counters, see mlsgpu_hip_mls_set_stats */
 };
 
 /* position and 1/radius^2 of a listed splat.  A tree built without mutation leaves the radius in the splat; the same
@@ -375,10 +375,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     __shared__ uint16_t sSlot[8][128];         /* per wave: byte offsets of the window's relevant splats (64) + what a group
                                                 * of 64 staged splats adds beyond a full window */
     __shared__ uint16_t sList[8][8][64];       /* per wave and cube: byte offsets of the splats that can reach the cube */
+    __shared__ uint32_t sHist[STATS ? 33 : 1];  /* instrumented build: lanes per number of hits in a drain call */
 
     const MlsArgs A = lanes.a[blockIdx.y];
     if (blockIdx.x >= A.numBlocks)
         return;
+    if (STATS)
+    {
+        if (threadIdx.x < 33)
+            sHist[threadIdx.x] = 0;
+        __syncthreads();
+    }
     const uint32_t bid = xcdRemap(blockIdx.x, A.numBlocks, A.xcdChunk);
     const uint32_t gx = bid % A.blocksX, gy = (bid / A.blocksX) % A.blocksY, gz = bid / (A.blocksX * A.blocksY);
     const int wx = (int) (gx * 8), wy = (int) (gy * 8), wz = (int) (gz * 8 + A.zFirst);
@@ -402,6 +409,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         Fit fit;
         fitInit(fit);
         unsigned long long nListed = 0, nTests = 0;
+        /* instrumented build: how evenly the hits of a drain call are spread over the wave's lanes, and what merging drain
+         * calls would make of it (the iterations of a drain = the LONGEST of 64 lists) */
+        uint32_t drainCalls = 0, sumMost = 0, sumMostPairs = 0, sumMostRound = 0, prevCnt = 0, roundCnt = 0;
+        bool havePrev = false;
         typedef __attribute__((address_space(3))) uint16_t LdsSlot;
         LdsSlot *const mySlots = (LdsSlot *) sSlot[wave];
         const uint32_t myCube = ((lane >> 1) & 1u) | (((lane >> 3) & 1u) << 1) | (((lane >> 5) & 1u) << 2);
@@ -421,6 +432,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             const uint32_t cnt = (uint32_t) __popc(cur);
             const uint32_t most = waveMax(cnt);
             fit.hits += cnt;
+            if (STATS)
+            {
+                drainCalls++;
+                sumMost += most;
+                atomicAdd(&sHist[cnt], 1u);
+                roundCnt += cnt;
+                if (havePrev)
+                    sumMostPairs += waveMax(prevCnt + cnt);
+                else
+                    prevCnt = cnt;
+                havePrev = !havePrev;
+            }
             for (uint32_t j = 0; j < most; j++)
             {
                 if (j < cnt)
@@ -612,6 +635,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
             if (nt != 0)
                 processWindow(nt);          /* the offsets point into this round's staging buffers */
             nt = 0;
+            if (STATS)
+            {
+                if (havePrev)
+                    sumMostPairs += waveMax(prevCnt);       /* an odd call out: it stays alone */
+                havePrev = false;
+                sumMostRound += waveMax(roundCnt);
+                roundCnt = 0;
+            }
             __syncthreads();
         }
         fit.sumWpx = sWpxy.x;
@@ -622,12 +653,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         if (STATS)
         {
             const unsigned long long hits = waveSum(fit.hits);
+            const uint32_t mostBlock = waveMax(fit.hits);
             if (lane == 0)
             {
                 atomicAdd(&A.stats[0], nListed);
                 atomicAdd(&A.stats[1], nTests);
                 atomicAdd(&A.stats[2], hits);
+                atomicAdd(&A.stats[3], (unsigned long long) drainCalls);
+                atomicAdd(&A.stats[4], (unsigned long long) sumMost);
+                atomicAdd(&A.stats[5], (unsigned long long) sumMostPairs);
+                atomicAdd(&A.stats[6], (unsigned long long) sumMostRound);
+                atomicAdd(&A.stats[7], (unsigned long long) mostBlock);
             }
+            __syncthreads();
+            if (tid < 33 && sHist[tid] != 0)
+                atomicAdd(&A.stats[8 + tid], (unsigned long long) sHist[tid]);
         }
     }
 
