@@ -1590,7 +1590,10 @@ def main():
             # device item, then the farm's worker threads), as CopyGroup does with host buckets
             # the leaves arrive one per device item; with lanes a worker takes as many queued items as fit a batch
             # through one set of launches (mlsgpu_hip_farm_set_batch), so fewer workers and more spare items
-            pbatch = max(1, min(args.batch, m.binding.MAX_BATCH))
+            # the reference partition's buckets are small (126-cell cubes where the 27-bucket split has 170-cell ones): a worker
+            # takes up to MAX_BATCH of them through one set of octree launches, and as many as hold two full buckets' corners
+            # through one set of processCorners / marching launches (mlsgpu_hip_worker_set_marching_group)
+            pbatch = 1 if args.batch == 1 else m.binding.MAX_BATCH
             pworkers = max(1, args.farm_workers) if pbatch == 1 else max(1, args.partition_workers)
             pfarm = m.BucketFarm([local_rank], pmax, workers_per_device=pworkers, spare=1 if pbatch == 1 else pbatch * pworkers,
                                  max_cells=pcells, mesh_memory=args.mesh_memory_mb << 20)
@@ -1600,17 +1603,31 @@ def main():
             def leaf_work(leaf, d_ids):
                 low = leaf["extents"][0::2]
                 nv = [leaf["extents"][2 * i + 1] - leaf["extents"][2 * i] + 1 for i in range(3)]
-                pfarm.submit_device(local_rank, raw, d_ids, leaf["num_splats"], (0.0, 0.0, 0.0), 1.0, ext, low, nv, leaf_no[0])
                 leaf_no[0] += 1
+                return pfarm.submit_device(local_rank, raw, d_ids, leaf["num_splats"], (0.0, 0.0, 0.0), 1.0, ext, low, nv,
+                                           leaf_no[0] - 1, wait=False)
 
             def partition_pass():
                 mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=leaf_work, **bp)
                 pfarm.finish()
             partition_pass()                            # warm-up
+            wc0 = pfarm.worker_clock()
+            feed_s = 0.0
             t0 = time.perf_counter()
             for _ in range(L):
-                partition_pass()
+                t1 = time.perf_counter()
+                mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=leaf_work, **bp)
+                feed_s += time.perf_counter() - t1
+                pfarm.finish()
             pipe_s = (time.perf_counter() - t0) / L
+            wc1 = pfarm.worker_clock()
+            # ... and as a stream of jobs: the bucketing of job k + 1 (on this context's stream, between its host decisions)
+            # shares the GPU with the workers still on job k's buckets
+            t0 = time.perf_counter()
+            for _ in range(L):
+                mb.bucket_cloud(ctx, raw, n_splats, (0.0, 0.0, 0.0), 1.0, ext, on_bucket=leaf_work, **bp)
+            pfarm.finish()
+            stream_s = (time.perf_counter() - t0) / L
             pvox = sum((l["extents"][1] - l["extents"][0]) * (l["extents"][3] - l["extents"][2]) * (l["extents"][5] - l["extents"][4])
                        for l in leaves)
             result["device_partition"] = {
@@ -1618,6 +1635,11 @@ def main():
                 "max_bucket_cells": int(pcells), "bucketing_ms": round(part_s * 1e3, 3),
                 "bucketing_msplats_per_s": round(n_splats / part_s / 1e6, 1),
                 "pipeline_ms_per_step": round(pipe_s * 1e3, 3), "pipeline_mvoxels_per_s": round(pvox / pipe_s / 1e6, 3),
+                "streamed_ms_per_step": round(stream_s * 1e3, 3), "streamed_mvoxels_per_s": round(pvox / stream_s / 1e6, 3),
+                "bucketing_and_feeding_ms": round(feed_s / L * 1e3, 3),
+                "buckets_per_launch_set": round((wc1["buckets"] - wc0["buckets"]) / max(wc1["launch_sets"] - wc0["launch_sets"], 1), 2),
+                "workers_idle_ms_per_step": round((wc1["idle_s"] - wc0["idle_s"]) / L * 1e3, 2),
+                "workers_busy_ms_per_step": round((wc1["busy_s"] - wc0["busy_s"]) / L * 1e3, 2),
                 "device_workers": pworkers, "batch": pbatch,
                 "note": "raw cloud resident in HBM -> mlsgpu_hip_bucket (reference partition) -> mlsgpu_hip_farm_submit_device "
                         "(device gather + transform) -> the farm's device workers; bucketing is inside the pipeline time",

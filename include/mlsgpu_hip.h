@@ -308,8 +308,9 @@ typedef struct mlsgpu_subitem
  * owns a tree, a distance field, a lattice and a mesh arena (mlsgpu_hip_worker_resource_usage bytes per lane). */
 int mlsgpu_hip_worker_set_batch(mlsgpu_worker *w, uint32_t lanes);
 uint32_t mlsgpu_hip_worker_batch(const mlsgpu_worker *w);
-/* Buckets per set of processCorners / marching launches inside a group of lanes (0: all lanes; default 2).  The octree
- * build always spans all lanes.  Results do not depend on it. */
+/* How much shares one set of processCorners / marching launches inside a batch: as many consecutive buckets as hold the
+ * corners of `buckets` buckets of the worker's full size, (maxCells + 1)^3 each -- `buckets` full-size ones, or more small
+ * ones (0: the whole batch; default 2).  The octree build always spans all lanes.  Results do not depend on it. */
 int mlsgpu_hip_worker_set_marching_group(mlsgpu_worker *w, uint32_t buckets);
 uint32_t mlsgpu_hip_worker_marching_group(const mlsgpu_worker *w);
 /* The loop over the SubItems of a WorkItem (src/workers.cpp:232-286) with the buckets taken `lanes` at a time: per group
@@ -400,6 +401,10 @@ int mlsgpu_hip_farm_placement(mlsgpu_farm *farm, int32_t out[100]);
  * streams), [4] first submit .. last flush, [5] copies, [6] batches sent to another side's GPU, [7] inside the runtime's
  * enqueue calls (event records + hipMemcpyAsync).  h2d_busy = [3] / [4]. */
 int mlsgpu_hip_farm_copy_clock(mlsgpu_farm *farm, double out[8]);
+/* The device workers' clock since the farm was created: out[0] sets of launches they ran (a batch of buckets in lock-step,
+ * or one bucket), [1] buckets in them ([1] / [0] = buckets per set of launches), [2] seconds the workers waited for an item,
+ * [3] seconds they spent processing, both summed over the workers. */
+int mlsgpu_hip_farm_worker_clock(mlsgpu_farm *farm, double out[4]);
 /* The most device items (DeviceWorkerGroup::WorkItem, src/workers.h:165-181) that were in flight at once since the farm
  * was created: taken from a group's pool by the copy side and not yet returned by a device worker. */
 int mlsgpu_hip_farm_in_flight_max(mlsgpu_farm *farm, uint64_t *out);
@@ -456,9 +461,18 @@ typedef struct mlsgpu_bucket        /* what ProcessorType's callback receives, s
     uint64_t chunk[3];              /* Recursion::chunk */
     uint32_t depth;                 /* Recursion::depth */
     uint64_t numSplats;
-    const uint32_t *dIds;           /* device: ids of the bucket's splats, ascending; valid during the callback */
+    const uint32_t *dIds;           /* device: ids of the bucket's splats, ascending; valid during the callback -- or, for a
+                                     * callback that reads them asynchronously, until the event it leaves in *consumed */
     const mlsgpu_splat *dSplats;    /* device: the array the ids index -- the caller's cloud (mlsgpu_hip_bucket) or the batch
                                      * of the streamed set that is resident during the callback (mlsgpu_hip_bucket_stream) */
+    void **consumed;                /* out, optional: a hipEvent_t the callback recorded behind its last read of dIds (on any
+                                     * stream of any device).  The bucketer orders whatever overwrites the list behind that
+                                     * event ON THE GPU, so a callback that only ENQUEUES its gather (mlsgpu_hip_farm_submit_
+                                     * device_async) need not wait for it: the leaves of a level are handed over back to back.
+                                     * Left NULL: the list may be reused as soon as the callback returns.  The event must stay
+                                     * alive until the next mlsgpu_hip_bucket call on this context has returned.  With
+                                     * mlsgpu_hip_bucket_stream the resident batch (dSplats) is NOT covered: read it before
+                                     * returning. */
 } mlsgpu_bucket;
 typedef int (*mlsgpu_bucket_fn)(void *user, mlsgpu_ctx *ctx, const mlsgpu_bucket *bucket);
 /* Splits `region` into buckets of at most maxCells cells per side and maxSplats splats and calls fn for each non-empty
@@ -491,6 +505,13 @@ int mlsgpu_hip_bucket_load(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, const u
 int mlsgpu_hip_farm_submit_device(mlsgpu_farm *farm, int device, const mlsgpu_splat *dSplats, const uint32_t *dIds,
                                   uint64_t numSplats, const mlsgpu_grid *fullGrid, const int32_t lowExtent[3],
                                   const uint32_t numVertices[3], uint64_t chunkId);
+/* The same without the wait: the call returns when the gather has been ENQUEUED; *consumed is a hipEvent_t (owned by the
+ * farm, alive as long as it is) that fires when the gather has read dSplats and dIds -- what a bucketer's callback leaves in
+ * mlsgpu_bucket::consumed.  A farm worker that finds several such buckets queued takes them through one set of launches
+ * (mlsgpu_hip_farm_set_batch), which it rarely does when every leaf costs the feeder a round trip to a busy GPU. */
+int mlsgpu_hip_farm_submit_device_async(mlsgpu_farm *farm, int device, const mlsgpu_splat *dSplats, const uint32_t *dIds,
+                                        uint64_t numSplats, const mlsgpu_grid *fullGrid, const int32_t lowExtent[3],
+                                        const uint32_t numVertices[3], uint64_t chunkId, void **consumed);
 
 /* The buckets of a device item (the SubItems of a WorkItem) are taken through the path `lanes` at a time by
  * mlsgpu_hip_worker_process_batch instead of one by one (src/workers.cpp:232-286); 1 .. MLSGPU_MAX_BATCH, default 1.

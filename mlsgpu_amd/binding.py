@@ -105,7 +105,7 @@ class BucketParams(C.Structure):
 
 class BucketStruct(C.Structure):
     _fields_ = [("extents", C.c_int32 * 6), ("chunk", C.c_uint64 * 3), ("depth", C.c_uint32), ("numSplats", C.c_uint64),
-                ("dIds", C.c_void_p), ("dSplats", C.c_void_p)]
+                ("dIds", C.c_void_p), ("dSplats", C.c_void_p), ("consumed", C.POINTER(C.c_void_p))]
 
 
 BUCKET_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(BucketStruct))
@@ -243,6 +243,8 @@ def lib():
     sig("mlsgpu_hip_test_copy_pool", C.c_int, u32, u32, u64, C.c_int)
     sig("mlsgpu_hip_farm_placement", C.c_int, vp, vp)
     sig("mlsgpu_hip_farm_copy_clock", C.c_int, vp, vp)
+    sig("mlsgpu_hip_farm_submit_device_async", C.c_int, vp, C.c_int, vp, vp, u64, vp, vp, vp, u64, vp)
+    sig("mlsgpu_hip_farm_worker_clock", C.c_int, vp, vp)
     sig("mlsgpu_hip_host_mesher_trim_cache", u64, u64)
     sig("mlsgpu_hip_host_mesher_set_node", C.c_int, vp, C.c_int)
     sig("mlsgpu_hip_host_mesher_node", C.c_int, vp)
@@ -1337,11 +1339,19 @@ class BucketFarm:
         check(lib().mlsgpu_hip_farm_push(self.h, num_splats, _p(_i3(low_extent)), _p(_u3(num_vertices)), chunk_id))
 
     def submit_device(self, device, d_splats, d_ids_ptr, num_splats, reference, spacing, extents, low_extent, num_vertices,
-                      chunk_id):
-        """A bucket whose splats are on the device already (the bucketer's callback): loaded by a device kernel."""
+                      chunk_id, wait=True):
+        """A bucket whose splats are on the device already (the bucketer's callback): loaded by a device kernel.
+        wait=False: returns as soon as the load is enqueued, with the event (an integer handle) that fires when the load has
+        read d_splats and the id list -- what bucket_cloud's on_bucket returns to the bucketer."""
         g = _grid_struct(reference, spacing, extents)
-        check(lib().mlsgpu_hip_farm_submit_device(self.h, device, d_splats.ptr, d_ids_ptr, num_splats, C.byref(g),
-                                                  _p(_i3(low_extent)), _p(_u3(num_vertices)), chunk_id))
+        if wait:
+            check(lib().mlsgpu_hip_farm_submit_device(self.h, device, d_splats.ptr, d_ids_ptr, num_splats, C.byref(g),
+                                                      _p(_i3(low_extent)), _p(_u3(num_vertices)), chunk_id))
+            return None
+        event = C.c_void_p()
+        check(lib().mlsgpu_hip_farm_submit_device_async(self.h, device, d_splats.ptr, d_ids_ptr, num_splats, C.byref(g),
+                                                        _p(_i3(low_extent)), _p(_u3(num_vertices)), chunk_id, C.byref(event)))
+        return event.value
 
     def set_host_output(self, ring_bytes, sink=None):
         """Every ship-out is read back through a pinned circular buffer of `ring_bytes` and handed to ONE mesher thread
@@ -1387,6 +1397,12 @@ class BucketFarm:
         check(lib().mlsgpu_hip_farm_copy_clock(self.h, _p(out)))
         return dict(fill_s=float(out[0]), wait_staging_s=float(out[1]), wait_item_s=float(out[2]), h2d_s=float(out[3]),
                     span_s=float(out[4]), copies=int(out[5]), cross_side=int(out[6]), enqueue_s=float(out[7]))
+
+    def worker_clock(self):
+        """The device workers' clock (mlsgpu_hip_farm_worker_clock): launch sets, buckets, idle and busy seconds."""
+        out = np.zeros(4, np.float64)
+        check(lib().mlsgpu_hip_farm_worker_clock(self.h, _p(out)))
+        return dict(launch_sets=int(out[0]), buckets=int(out[1]), idle_s=float(out[2]), busy_s=float(out[3]))
 
     def host_stats(self):
         out = np.zeros(4, np.uint64)
@@ -1448,7 +1464,9 @@ def bucket_cloud(ctx, d_splats, num_splats, reference, spacing, extents, max_spl
     """Bucket::bucket (src/bucket.h:170-180) over a cloud resident on the device.
 
     on_bucket(leaf, d_ids_ptr) is called for every bucket while its id list is valid on the device; without it the
-    ids are copied to the host.  Returns the list of leaves dict(extents, chunk, depth, num_splats[, ids])."""
+    ids are copied to the host.  An on_bucket that only ENQUEUES its read of the list returns the event behind that read
+    (BucketFarm.submit_device(..., wait=False)): the bucketer orders the list's reuse behind it on the GPU
+    (mlsgpu_bucket::consumed).  Returns the list of leaves dict(extents, chunk, depth, num_splats[, ids])."""
     leaves = []
     failure = []
 
@@ -1458,7 +1476,9 @@ def bucket_cloud(ctx, d_splats, num_splats, reference, spacing, extents, max_spl
             leaf = dict(extents=tuple(int(b.extents[i]) for i in range(6)), chunk=tuple(int(b.chunk[i]) for i in range(3)),
                         depth=int(b.depth), num_splats=int(b.numSplats))
             if on_bucket is not None:
-                on_bucket(leaf, b.dIds)
+                event = on_bucket(leaf, b.dIds)
+                if event:
+                    b.consumed[0] = event
             else:
                 ids = np.empty(leaf["num_splats"], np.uint32)
                 if len(ids):

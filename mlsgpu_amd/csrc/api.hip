@@ -213,6 +213,26 @@ MLSGPU_API int mlsgpu_hip_ctx_create(int device, void *stream, mlsgpu_ctx **out)
     return MLSGPU_OK;
 }
 
+int mlsgpu_ctx::scanFlags(uint32_t **flags, uint32_t *epoch)
+{
+    if (dScanFlags == nullptr)
+    {
+        const size_t bytes = (size_t) MLSGPU_MAX_BATCH * 1024 * sizeof(uint32_t);      /* MAX_LANES x SCAN_ONEPASS_MAX_TILES */
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipMalloc((void **) &dScanFlags, bytes));
+        HIP_CHECK(hipMemsetAsync(dScanFlags, 0, bytes, stream));
+    }
+    if (++scanEpoch == 0)
+    {
+        /* wrapped: a flag left by the launch of 2^32 launches ago would match again.  Fresh flags hold 0, which is never an epoch. */
+        HIP_CHECK(hipMemsetAsync(dScanFlags, 0, (size_t) MLSGPU_MAX_BATCH * 1024 * sizeof(uint32_t), stream));
+        scanEpoch = 1;
+    }
+    *flags = dScanFlags;
+    *epoch = scanEpoch;
+    return MLSGPU_OK;
+}
+
 MLSGPU_API void mlsgpu_hip_ctx_destroy(mlsgpu_ctx *ctx)
 {
     if (!ctx)
@@ -220,6 +240,7 @@ MLSGPU_API void mlsgpu_hip_ctx_destroy(mlsgpu_ctx *ctx)
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     ctx->scratchCache.clear();
+    hipFree(ctx->dScanFlags);
     for (const PendingTiming &p : ctx->pending)
     {
         hipEventDestroy(p.start);
@@ -657,12 +678,21 @@ MLSGPU_API int mlsgpu_hip_worker_process_batch(mlsgpu_worker *w, mlsgpu_splat *d
             if (rc == MLSGPU_OK)
                 rc = mlsgpu_hip_mls_generator(w->lanes[k].mls, &gens[k]);
         }
-        /* the octree of all `count` buckets in one set of launches, processCorners and marching `marchingGroup` buckets at a
-         * time (mlsgpu_hip_worker_set_marching_group) */
-        const uint32_t sub = w->marchingGroup != 0 ? std::min(w->marchingGroup, count) : count;
-        for (uint32_t k0 = 0; k0 < count && rc == MLSGPU_OK; k0 += sub)
+        /* the octree of all `count` buckets in one set of launches, processCorners and marching a GROUP of buckets at a time
+         * (mlsgpu_hip_worker_set_marching_group): as many consecutive buckets as hold the corners of `marchingGroup` buckets
+         * of the worker's full size -- two full buckets, or the eight small ones of a partition that cost what two do */
+        const uint64_t side = (uint64_t) w->cfg.maxCells + 1;
+        const uint64_t budget = w->marchingGroup != 0 ? (uint64_t) w->marchingGroup * side * side * side : UINT64_MAX;
+        for (uint32_t k0 = 0, n = 0; k0 < count && rc == MLSGPU_OK; k0 += n)
         {
-            const uint32_t n = std::min(sub, count - k0);
+            uint64_t corners = 0;
+            for (n = 0; k0 + n < count; n++)
+            {
+                const uint32_t *nv = sizes + 3 * (k0 + n);
+                corners += (uint64_t) nv[0] * nv[1] * nv[2];
+                if (n > 0 && corners > budget)
+                    break;
+            }
             w->batchBase = base + k0;
             rc = mlsgpu_hip_marching_generate_batch(marchings + k0, gens + k0, n, workerBatchOutput, w, sizes + 3 * k0,
                                                     keyOffsets + 3 * k0);

@@ -348,6 +348,9 @@ struct DepthBuffers
     uint32_t *total = nullptr;
     uint32_t *scanSums = nullptr;
     uint64_t scanCap = 0;
+    /* events of callbacks that still read member lists of this level (mlsgpu_bucket::consumed): whatever overwrites the
+     * level's buffers is ordered behind them on the GPU */
+    std::vector<hipEvent_t> readers;
     ~DepthBuffers()
     {
         hipFree(scanSums);
@@ -369,6 +372,17 @@ struct Bucketer
     typedef std::vector<std::unique_ptr<DepthBuffers> > DepthList;
     DepthList *depthList = nullptr;     /* lives in the context's scratch cache: allocating ~1 GB per call costs more than the kernels */
 
+    /* the callbacks' read events (mlsgpu_bucket::consumed) of every level: this context's stream goes on behind them, and
+     * the handles are forgotten -- the callers' events need not outlive the call */
+    void settleReaders()
+    {
+        for (auto &level : *depthList)
+        {
+            for (hipEvent_t ev : level->readers)
+                (void) hipStreamWaitEvent(ctx->stream, ev, 0);
+            level->readers.clear();
+        }
+    }
     int ensure(uint32_t **p, size_t elems)
     {
         hipFree(*p);
@@ -405,9 +419,14 @@ int Bucketer::recurse(const uint32_t *dIds, uint64_t n, bool isSubset, const Gri
         b.numSplats = n;
         b.dIds = dIds;
         b.dSplats = dSplats;
+        void *consumed = nullptr;
+        b.consumed = &consumed;
         const int rc = fn(user, ctx, &b);
         if (rc != 0)
             return setError(MLSGPU_ERR_CALLBACK, "bucket callback failed with %d", rc);
+        /* the list lives in the buffers of the level above (a leaf at depth 0 is the caller's own list) */
+        if (consumed != nullptr && depth > 0 && depth - 1 < depthList->size())
+            (*depthList)[depth - 1]->readers.push_back(static_cast<hipEvent_t>(consumed));
         return MLSGPU_OK;
     }
     if (maxCellDim == 1)
@@ -503,6 +522,10 @@ int Bucketer::recurse(const uint32_t *dIds, uint64_t n, bool isSubset, const Gri
                     PROPAGATE(ensure(&B.table, totalNodes));
                     B.nodeCap = (uint32_t) totalNodes;
                 }
+                /* the level's buffers are about to be overwritten: behind the callbacks that still read its lists */
+                for (hipEvent_t ev : B.readers)
+                    HIP_CHECK(hipStreamWaitEvent(ctx->stream, ev, 0));
+                B.readers.clear();
                 /* 1. counts */
                 HIP_CHECK(hipMemsetAsync(B.counts, 0, totalNodes * 4, ctx->stream));
                 if (n > 0)
@@ -1020,6 +1043,7 @@ MLSGPU_API int mlsgpu_hip_bucket(mlsgpu_ctx *ctx, const mlsgpu_splat *dSplats, u
     const int rc = b.recurse(nullptr, numSplats, false, g, params->chunkCells, params->microCells, 0, chunk);
     if (cellSplats != nullptr)
         *cellSplats = b.cellSplats;
+    b.settleReaders();
     hipStreamSynchronize(ctx->stream);
     return rc;
 }
@@ -1155,6 +1179,7 @@ MLSGPU_API int mlsgpu_hip_bucket_stream(mlsgpu_ctx *ctx, mlsgpu_fileset *files, 
         : b.recurseStream(files, b.numSplats, g, budgetSplats, chunkSplats, readerThreads, stats != nullptr ? stats : local);
     if (cellSplats != nullptr)
         *cellSplats = b.cellSplats;
+    b.settleReaders();
     hipStreamSynchronize(ctx->stream);
     return rc;
 }

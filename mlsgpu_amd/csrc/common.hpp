@@ -108,6 +108,11 @@ struct mlsgpu_ctx
      * released with the context */
     std::map<std::string, std::shared_ptr<void> > scratchCache;
 
+    /* one-launch scans (primitives.hpp): a flag word per (lane, tile), never cleared -- a launch's flags carry its epoch */
+    uint32_t *dScanFlags = nullptr;
+    uint32_t scanEpoch = 0;
+    int scanFlags(uint32_t **flags, uint32_t *epoch);
+
     int statId(const char *name);
     int beginTiming(int id);          /* returns index into pending or -1 */
     void endTiming(int pendingIdx);

@@ -139,6 +139,9 @@ struct Farm
      * host-to-device copies themselves (timed event pairs), first submit .. last flush; [5] copies, [6] batches sent to a
      * GPU of another side because no own one had a free item, [7] inside the runtime's enqueue calls */
     double copyClock[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    /* the device workers' clock: [0] sets of launches (batches, or single buckets), [1] buckets in them, [2] seconds the
+     * workers waited for an item, [3] seconds they spent processing (summed over the workers) */
+    double workerClock[4] = {0, 0, 0, 0};
     std::chrono::steady_clock::time_point firstSubmit, lastFlush;
     bool clockRunning = false;
 
@@ -345,6 +348,11 @@ void mesherMain(Farm *f)
     }
 }
 
+double secondsSince(std::chrono::steady_clock::time_point t0)
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+
 struct BatchThunk
 {
     Farm *farm;
@@ -384,9 +392,11 @@ void workerMain(Farm *farm, DeviceGroup *g)
          * (mlsgpu_hip_farm_submit_device), and the buckets of several such items share one set of launches. */
         std::vector<WorkItem *> taken;
         const uint32_t lanes = farm->batch.load();
+        const auto tIdle = std::chrono::steady_clock::now();
         {
             std::unique_lock<std::mutex> l(farm->mutex);
             farm->queueCond.wait(l, [&] { return farm->stopping || !g->queue.empty(); });
+            farm->workerClock[2] += secondsSince(tIdle);
             if (g->queue.empty())
                 break;
             size_t subs = 0;
@@ -416,6 +426,7 @@ void workerMain(Farm *farm, DeviceGroup *g)
         size_t numSubs = 0;
         for (WorkItem *item : taken)
             numSubs += item->subItems.size();
+        const auto tWork = std::chrono::steady_clock::now();
         /* the lanes' buffers (a tree, a field, a lattice and a mesh arena each) are allocated on first use; a device that
          * cannot hold them keeps the worker on the bucket-by-bucket path instead of failing the farm */
         bool batched = run && e == hipSuccess && lanes > 1 && numSubs > 1 && !lanesRefused;
@@ -490,6 +501,12 @@ void workerMain(Farm *farm, DeviceGroup *g)
                     g->bucketsDone++;
                 }
             }
+        {
+            std::lock_guard<std::mutex> l(farm->mutex);
+            farm->workerClock[0] += 1;
+            farm->workerClock[1] += (double) numSubs;
+            farm->workerClock[3] += secondsSince(tWork);
+        }
         for (size_t t = 0; t < taken.size(); t++)
         {
             WorkItem *item = taken[t];
@@ -572,11 +589,6 @@ Farm::CopySide *pickSide(Farm *f)
             if (out == nullptr || g->unallocated > out->unallocated)
                 out = g.get();
     return f->sides[out->side].get();
-}
-
-double secondsSince(std::chrono::steady_clock::time_point t0)
-{
-    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
 }
 
 /* CopyGroupBase::Worker::flush, src/workers.cpp:315-375 */
@@ -964,6 +976,24 @@ MLSGPU_API int mlsgpu_hip_farm_submit_device(mlsgpu_farm *f, int device, const m
                                              uint64_t numSplats, const mlsgpu_grid *fullGrid, const int32_t lowExtent[3],
                                              const uint32_t numVertices[3], uint64_t chunkId)
 {
+    void *consumed = nullptr;
+    PROPAGATE(mlsgpu_hip_farm_submit_device_async(f, device, dSplats, dIds, numSplats, fullGrid, lowExtent, numVertices, chunkId,
+                                                  &consumed));
+    /* the caller's id list is free again once the gather has run */
+    if (consumed != nullptr && hipEventSynchronize(static_cast<hipEvent_t>(consumed)) != hipSuccess)
+    {
+        f->fail(MLSGPU_ERR_HIP, "farm: the device-side load failed");
+        return setError(MLSGPU_ERR_HIP, "farm: the device-side load failed");
+    }
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_farm_submit_device_async(mlsgpu_farm *f, int device, const mlsgpu_splat *dSplats, const uint32_t *dIds,
+                                                   uint64_t numSplats, const mlsgpu_grid *fullGrid, const int32_t lowExtent[3],
+                                                   const uint32_t numVertices[3], uint64_t chunkId, void **consumed)
+{
+    REQUIRE(consumed != nullptr, MLSGPU_ERR_INVALID);
+    *consumed = nullptr;
     REQUIRE(f != nullptr && fullGrid != nullptr && lowExtent != nullptr && numVertices != nullptr, MLSGPU_ERR_INVALID);
     REQUIRE(numSplats == 0 || dSplats != nullptr, MLSGPU_ERR_INVALID);
     REQUIRE(numSplats <= f->cfg.worker.maxBucketSplats, MLSGPU_ERR_LENGTH);
@@ -1017,10 +1047,8 @@ MLSGPU_API int mlsgpu_hip_farm_submit_device(mlsgpu_farm *f, int device, const m
         rc = mlsgpu_hip_bucket_load(out->copyCtx, dSplats, dIds, numSplats, fullGrid, item->dSplats);
         if (rc == MLSGPU_OK && hipEventRecord(item->copyEvent, out->copyStream) != hipSuccess)
             rc = setError(MLSGPU_ERR_HIP, "farm: cannot record the load event");
-        /* the id list belongs to the caller (the bucketer reuses it after its callback returns): wait for the gather,
-         * the only work on this copy stream */
-        if (rc == MLSGPU_OK && hipEventSynchronize(item->copyEvent) != hipSuccess)
-            rc = setError(MLSGPU_ERR_HIP, "farm: the device-side load failed");
+        /* the id list belongs to the caller: it is free again when this event has fired */
+        *consumed = item->copyEvent;
     }
     else
     {
@@ -1066,7 +1094,7 @@ MLSGPU_API int mlsgpu_hip_farm_submit_device(mlsgpu_farm *f, int device, const m
         {
             ps->busy = item->copyEvent;
             /* the caller's id list is free again once the gather has run; the peer copy goes on without the host */
-            e = hipEventSynchronize(ps->loaded);
+            *consumed = ps->loaded;
         }
         if (rc == MLSGPU_OK && e != hipSuccess)
         {
@@ -1232,6 +1260,15 @@ MLSGPU_API int mlsgpu_hip_farm_placement(mlsgpu_farm *f, int32_t out[100])
         out[54 + 4 * k] = (int32_t) f->sides[k]->staging.size();
         out[55 + 4 * k] = (int32_t) f->sides[k]->pool.threads();
     }
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_farm_worker_clock(mlsgpu_farm *f, double out[4])
+{
+    REQUIRE(f != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> l(f->mutex);
+    for (int i = 0; i < 4; i++)
+        out[i] = f->workerClock[i];
     return MLSGPU_OK;
 }
 

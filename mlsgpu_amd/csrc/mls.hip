@@ -430,12 +430,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
         auto drain = [&](uint32_t cur, LdsSlot *chunk)
         {
             const uint32_t cnt = (uint32_t) __popc(cur);
-            const uint32_t most = waveMax(cnt);
             fit.hits += cnt;
             if (STATS)
             {
                 drainCalls++;
-                sumMost += most;
+                sumMost += waveMax(cnt);
                 atomicAdd(&sHist[cnt], 1u);
                 roundCnt += cnt;
                 if (havePrev)
@@ -444,11 +443,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
                     prevCnt = cnt;
                 havePrev = !havePrev;
             }
-            for (uint32_t j = 0; j < most; j++)
+            /* a lane leaves the loop with its last hit; the wave runs as many iterations as its longest list (no wave-wide
+             * maximum is computed for a counted loop: 577 -> 572.5 us per launch) */
+            while (cur != 0)
             {
-                if (j < cnt)
                 {
-                    const uint32_t t = (uint32_t) __builtin_clz(cur);      /* cur != 0: this lane still has a hit to take */
+                    const uint32_t t = (uint32_t) __builtin_clz(cur);
                     cur ^= 0x80000000u >> t;
                     const uint32_t off = chunk[t];
                     const float4 pr = *(const float4 *) ((const char *) sPosRad + off);

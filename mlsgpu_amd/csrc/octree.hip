@@ -225,7 +225,8 @@ enum
 {
     ENT_TILE = 512,                 /* splats per workgroup, one per thread (measured 256: 94 us per bucket in the scatter) */
     ENT_CAP = 8 * ENT_TILE,         /* at most eight entries per splat */
-    ENT_BIN_BITS = 8                /* the fused pass handles digits of up to 8 bits */
+    ENT_BIN_BITS = 8,               /* the fused pass handles digits of up to 8 bits */
+    ENT_KEY_BITS = 23               /* ... of keys that leave nine bits of a word for the thread that holds the splat */
 };
 
 struct EntryHistArgs
@@ -331,9 +332,10 @@ __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))
     __shared__ uint32_t waveBins[WAVES][BINS];
     __shared__ uint32_t tileBase[BINS];
     __shared__ uint32_t waveTotals[WAVES], waveTotalsAll[WAVES], waveCnt[WAVES];
-    __shared__ uint32_t sKeys[ENT_CAP];         /* the tile's keys in (splat, slot) order; afterwards the reorder buffer */
-    __shared__ uint16_t sVals[ENT_CAP];         /* ... and their splats, as the thread that holds the splat (the id is the
-                                                 * tile's first id + that): 33 instead of 41 KB, four workgroups per CU */
+    /* An entry in LDS is ONE word: its key (ENT_KEY_BITS at most on this route) below the thread that holds its splat (the
+     * id is the tile's first id + that).  Key and id travel together through the reorder, so the ids need no pass of their
+     * own: 25 KB of LDS and six workgroup barriers (33 KB and eight with the ids in an array of their own). */
+    __shared__ uint32_t sEnt[ENT_CAP];          /* the tile's entries in (splat, slot) order; afterwards in the pass's order */
     const uint32_t numBins = 1u << digitBits, dmask = numBins - 1;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t d = threadIdx.x; d < numBins; d += ENT_TILE)
@@ -381,14 +383,11 @@ __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))
             const int ily = max(loy - P.by, 0) >> shift;
             const int ilz = max(loz - P.bz, 0) >> shift;
             const uint32_t levelOffset = P.levelOffsets.v[shift];
+            const uint32_t holder = threadIdx.x << ENT_KEY_BITS;
 #pragma unroll
             for (int o = 0; o < 8; o++)
                 if (mask & (1u << o))
-                {
-                    sKeys[pos] = makeCode(ilx + (o & 1), ily + ((o >> 1) & 1), ilz + (o >> 2)) + levelOffset;
-                    sVals[pos] = (uint16_t) threadIdx.x;
-                    pos++;
-                }
+                    sEnt[pos++] = (makeCode(ilx + (o & 1), ily + ((o >> 1) & 1), ilz + (o >> 2)) + levelOffset) | holder;
         }
     }
     __syncthreads();
@@ -397,15 +396,15 @@ __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))
     /* 2. one stable LSD pass over the tile, as sortScatterKernel: wave w owns `rounds` x 64 consecutive elements */
     const uint32_t rounds = (tileCount + ENT_TILE - 1) / ENT_TILE;
     const uint32_t first = wave * rounds * 64 + lane;
-    uint32_t keys[MAX_ROUNDS];
+    uint32_t ent[MAX_ROUNDS];
 #pragma unroll
     for (int j = 0; j < MAX_ROUNDS; j++)
     {
         const uint32_t e = first + j * 64;
         const bool valid = (uint32_t) j < rounds && e < tileCount;
-        keys[j] = valid ? sKeys[e] : 0u;
+        ent[j] = valid ? sEnt[e] : 0u;
         if (valid)
-            atomicAdd(&waveBins[wave][keys[j] & dmask], 1u);
+            atomicAdd(&waveBins[wave][ent[j] & dmask], 1u);
     }
     __syncthreads();
     {
@@ -447,16 +446,14 @@ __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))
             }
     }
     __syncthreads();
-    uint32_t dst[MAX_ROUNDS];
 #pragma unroll
     for (int j = 0; j < MAX_ROUNDS; j++)
     {
-        dst[j] = 0;
         if ((uint32_t) j >= rounds)     /* uniform: a tile holds 3.8 entries per splat on average, 8 at most */
             continue;
         const uint32_t e = first + j * 64;
         const bool valid = e < tileCount;
-        const uint32_t digit = keys[j] & dmask;
+        const uint32_t digit = ent[j] & dmask;
         uint64_t peers = __ballot(valid);
         for (uint32_t b = 0; b < digitBits; b++)
         {
@@ -464,55 +461,31 @@ __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))
             const uint64_t m = __ballot(bit);
             peers &= bit ? m : ~m;
         }
-        dst[j] = 0;
         if (valid)
         {
             const uint32_t rank = popcBelow(peers);
-            dst[j] = waveBins[wave][digit] + rank;
-            sKeys[dst[j]] = keys[j];
+            const uint32_t dst = waveBins[wave][digit] + rank;
+            sEnt[dst] = ent[j];          /* (every wave took its elements into registers before the last two barriers) */
             if (rank == 0)
-                waveBins[wave][digit] = dst[j] + (uint32_t) __popcll(peers);
+                waveBins[wave][digit] = dst + (uint32_t) __popcll(peers);
         }
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
-    uint32_t out[MAX_ROUNDS];
+    /* 3. out, in the order of the pass: the run of a digit is contiguous in the tile and in memory */
+    const uint32_t tileFirstId = blockIdx.x * ENT_TILE + P.firstSplat;
 #pragma unroll
     for (int k = 0; k < MAX_ROUNDS; k++)
     {
         const uint32_t p = threadIdx.x + k * ENT_TILE;
-        out[k] = 0;
         if (p < tileCount)
         {
-            const uint32_t key = sKeys[p];
-            out[k] = tileBase[key & dmask] + p;
-            keysOut[out[k]] = key;
+            const uint32_t e = sEnt[p];
+            const uint32_t key = e & ((1u << ENT_KEY_BITS) - 1u);
+            const uint32_t out = tileBase[key & dmask] + p;
+            keysOut[out] = key;
+            valsOut[out] = tileFirstId + (e >> ENT_KEY_BITS);
         }
-    }
-    /* the ids take the same route: every thread fetches the ids of ITS elements before anything is overwritten */
-    const uint32_t tileFirstId = blockIdx.x * ENT_TILE + P.firstSplat;
-    uint16_t vals[MAX_ROUNDS];
-#pragma unroll
-    for (int j = 0; j < MAX_ROUNDS; j++)
-    {
-        const uint32_t e = first + j * 64;
-        vals[j] = ((uint32_t) j < rounds && e < tileCount) ? sVals[e] : (uint16_t) 0;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < MAX_ROUNDS; j++)
-    {
-        const uint32_t e = first + j * 64;
-        if ((uint32_t) j < rounds && e < tileCount)
-            sVals[dst[j]] = vals[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < MAX_ROUNDS; k++)
-    {
-        const uint32_t p = threadIdx.x + k * ENT_TILE;
-        if (p < tileCount)
-            valsOut[out[k]] = tileFirstId + sVals[p];
     }
 }
 
@@ -802,7 +775,8 @@ static int treeBuildBatch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *re
     const uint32_t passes = sortPasses(keyBits, SortCaps<uint32_t>::MAX_DIGIT_BITS);
     const uint32_t perPass = (keyBits + passes - 1) / passes;
     static const bool fusedOff = getenv("MLSGPU_HIP_OCTREE_FUSED") != nullptr && atoi(getenv("MLSGPU_HIP_OCTREE_FUSED")) == 0;
-    const bool fused = perPass <= ENT_BIN_BITS && !fusedOff;      /* wider digits (deep trees) take the separate passes */
+    /* wider digits (deep trees) take the separate passes */
+    const bool fused = perPass <= ENT_BIN_BITS && keyBits <= ENT_KEY_BITS && !fusedOff;
 
     /* the command list straight from the sort's last pass (NodeIn / NodeOut above): for the fused front end with ONE pass left */
     const bool direct = fused && keyBits <= 2 * perPass;

@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace mlsgpu
 {
@@ -252,13 +253,124 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(Lanes<ScanApplyArg
     }
 }
 
+/* ---- the scan in ONE launch.  A workgroup publishes its tile's sum (value, then a flag behind a release), and adds up
+ * the sums of ALL its predecessors as they appear -- no chain from tile to tile: a workgroup waits for the slowest of the
+ * earlier tiles' loads, not for a sequence of look-backs.  The flag is the launch's EPOCH (the context counts its one-pass
+ * launches), so flags are never cleared: what an earlier launch left behind does not match.  Workgroups are dispatched in
+ * order of blockIdx.x within a lane, so the ones a workgroup waits for are running or done (up to SCAN_ONEPASS_MAX_TILES
+ * tiles; longer scans take the two-launch form above).  The waits and the sums' loads are agent-scope atomics: they see
+ * what another XCD's workgroup published. ---- */
+__device__ __forceinline__ uint32_t loadAgent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ U3 loadAgent(const U3 *p) { return U3{loadAgent(&p->a), loadAgent(&p->b), loadAgent(&p->c)}; }
+__device__ __forceinline__ void storeAgent(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void storeAgent(U3 *p, U3 v)
+{
+    storeAgent(&p->a, v.a);
+    storeAgent(&p->b, v.b);
+    storeAgent(&p->c, v.c);
+}
+
+template<typename T, typename In, typename Out>
+struct ScanOnePassArgs
+{
+    In in;
+    Out out;
+    T *tileSums;
+    uint32_t *flags;            /* one word per tile of this lane */
+    uint64_t n;
+    const uint32_t *nDev;
+    T seed;
+    T *total;
+    uint32_t numTiles;
+};
+
+template<typename T, typename In, typename Out>
+__global__ __launch_bounds__(PRIM_BLOCK) void scanOnePassKernel(Lanes<ScanOnePassArgs<T, In, Out> > lanes, uint32_t epoch)
+{
+    const ScanOnePassArgs<T, In, Out> A = lanes.a[blockIdx.y];
+    if (blockIdx.x >= A.numTiles)
+        return;
+    uint64_t n = A.n;
+    if (A.nDev != nullptr && *A.nDev < n)
+        n = *A.nDev;
+    /* the tile holding the last element (tile 0 of an empty scan) reports the total; later tiles are empty, publish nothing
+     * and nobody waits for them */
+    const uint32_t lastTile = n > 0 ? (uint32_t) ((n - 1) / PRIM_TILE) : 0u;
+    if (blockIdx.x > lastTile)
+        return;
+    __shared__ T waveTotals[PRIM_WAVES];
+    __shared__ T wavePrefix[PRIM_WAVES];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t) blockIdx.x * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
+    T vals[PRIM_ITEMS];
+    T excl[PRIM_ITEMS];
+    T running = zeroOf(T());        /* wave-uniform: sum of the previous rounds of this wave */
+#pragma unroll
+    for (int j = 0; j < PRIM_ITEMS; j++)
+    {
+        uint64_t i = base + (uint64_t) j * 64;
+        vals[j] = i < n ? A.in(i) : zeroOf(T());
+        T incl = waveInclusiveScanT(vals[j]);
+        excl[j] = running + waveShiftUpT(incl);
+        running = running + readLaneT(incl, 63);
+    }
+    if (lane == 0)
+        waveTotals[wave] = running;
+    __syncthreads();
+    T mine = waveTotals[0];
+#pragma unroll
+    for (int w = 1; w < PRIM_WAVES; w++)
+        mine = mine + waveTotals[w];
+    if (threadIdx.x == 0 && blockIdx.x < lastTile)
+    {
+        storeAgent(&A.tileSums[blockIdx.x], mine);
+        __hip_atomic_store(&A.flags[blockIdx.x], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    T before = zeroOf(T());
+    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += PRIM_BLOCK)
+    {
+        while (__hip_atomic_load(&A.flags[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
+            __builtin_amdgcn_s_sleep(2);
+        before = before + loadAgent(&A.tileSums[t]);
+    }
+    const T inclBefore = waveInclusiveScanT(before);
+    if (lane == 63)
+        wavePrefix[wave] = inclBefore;
+    __syncthreads();
+    before = A.seed;
+#pragma unroll
+    for (int w = 0; w < PRIM_WAVES; w++)
+        before = before + wavePrefix[w];
+    if (A.total != nullptr && blockIdx.x == lastTile && threadIdx.x == 0)
+        *A.total = before + mine;
+    for (uint32_t w = 0; w < wave; w++)
+        before = before + waveTotals[w];
+#pragma unroll
+    for (int j = 0; j < PRIM_ITEMS; j++)
+    {
+        uint64_t i = base + (uint64_t) j * 64;
+        if (i < n)
+            A.out(i, before + excl[j], vals[j]);
+    }
+}
+
 #endif /* __HIPCC__ */
+
+/* largest scan (in tiles) that runs as one launch */
+#define SCAN_ONEPASS_MAX_TILES 1024u
 
 /* Host drivers.  Workspace: dTileSums must hold scanTiles(n) + 1 elements of T. */
 static inline uint32_t scanTiles(uint64_t n) { return divUp(n, PRIM_TILE); }
 
 /* largest scan (in tiles) whose workgroups add up their predecessors' tile sums themselves */
 #define SCAN_FUSED_MAX_TILES 4096u
+
+/* MLSGPU_HIP_SCAN_ONEPASS=0: every scan in the two- or three-launch form (A/B runs) */
+static inline bool scanOnePassOff()
+{
+    static const bool off = getenv("MLSGPU_HIP_SCAN_ONEPASS") != nullptr && atoi(getenv("MLSGPU_HIP_SCAN_ONEPASS")) == 0;
+    return off;
+}
 
 #ifdef __HIPCC__
 /* One scan of a batch: in1 feeds the tile sums, in2 the scan proper (they must agree; a first pass may cache what the
@@ -325,6 +437,23 @@ static int exclusiveScanBatch(mlsgpu_ctx *ctx, const char *statName, const ScanJ
     uint32_t maxTiles = 0;
     for (uint32_t k = 0; k < count; k++)
         maxTiles = std::max(maxTiles, scanTiles(jobs[k].n));
+    if (std::is_same<In1, In2>::value && maxTiles <= SCAN_ONEPASS_MAX_TILES && !scanOnePassOff())
+    {
+        /* one launch (scanOnePassKernel).  An empty lane still runs its tile 0, which reports the total. */
+        uint32_t *flags = nullptr, epoch = 0;
+        PROPAGATE(ctx->scanFlags(&flags, &epoch));
+        Lanes<ScanOnePassArgs<T, In2, Out> > a;
+        for (uint32_t k = 0; k < MAX_LANES; k++)
+        {
+            const ScanJob<T, In1, In2, Out> &j = jobs[k < count ? k : 0];
+            const uint32_t tiles = k < count ? std::max(scanTiles(j.n), 1u) : 0u;
+            a.a[k] = ScanOnePassArgs<T, In2, Out>{j.in2, j.out, j.dTileSums, flags + (uint64_t) k * SCAN_ONEPASS_MAX_TILES, j.n, j.nDev,
+                                                  j.seed, j.dTotal, tiles};
+        }
+        maxTiles = std::max(maxTiles, 1u);
+        LAUNCH(ctx, statName, (scanOnePassKernel<T, In2, Out>), dim3(maxTiles, count), dim3(PRIM_BLOCK), a, epoch);
+        return MLSGPU_OK;
+    }
     if (maxTiles <= SCAN_FUSED_MAX_TILES)
     {
         /* two launches: raw tile sums, then the scan proper.  An empty lane still runs its tile 0, which reports the total. */

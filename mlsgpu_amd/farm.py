@@ -56,10 +56,11 @@ def partition_to_farm(ctx, bucket_farm, device, raw, num_splats, reference, spac
         i = count[0]
         count[0] += 1
         if keep is not None and not keep(i):
-            return
+            return None
         low, nv = leaf_geometry(leaf, ext)
-        bucket_farm.submit_device(device, raw, d_ids, leaf["num_splats"], reference, spacing, ext, low, nv,
-                                  i if chunk_of is None else chunk_of(i))
+        # only enqueued: the bucketer orders the reuse of the id list behind the returned event, on the GPU
+        return bucket_farm.submit_device(device, raw, d_ids, leaf["num_splats"], reference, spacing, ext, low, nv,
+                                         i if chunk_of is None else chunk_of(i), wait=False)
     return mb.bucket_cloud(ctx, raw, num_splats, reference, spacing, ext, on_bucket=leaf_work, **params)
 
 

@@ -724,8 +724,14 @@ public:
             g.low[i] = bin.extents[2 * i] - fullGrid.extents[2 * i];
             g.numVertices[i] = (std::uint32_t) (bin.extents[2 * i + 1] - bin.extents[2 * i] + 1);
         }
-        check(mlsgpu_hip_farm_submit_device(h, device, cloud.get(), bin.dIds, bin.numSplats, &fullGrid, g.low, g.numVertices,
-                                            chunkId));
+        // a resident cloud: only enqueued -- the bucketer orders the reuse of the bin's id list behind the gather on the GPU
+        // (mlsgpu_bucket::consumed), so the leaves of a level reach the farm back to back and its workers batch them
+        if (bin.consumed != NULL)
+            check(mlsgpu_hip_farm_submit_device_async(h, device, cloud.get(), bin.dIds, bin.numSplats, &fullGrid, g.low,
+                                                      g.numVertices, chunkId, bin.consumed));
+        else
+            check(mlsgpu_hip_farm_submit_device(h, device, cloud.get(), bin.dIds, bin.numSplats, &fullGrid, g.low, g.numVertices,
+                                                chunkId));
     }
     /// the same for a bin of Bucket::bucketStream: its splats are in the batch that is resident during the callback
     void submitDevice(int device, const mlsgpu_bucket &bin, const mlsgpu_grid &fullGrid, std::uint64_t chunkId)

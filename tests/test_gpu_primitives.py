@@ -9,7 +9,9 @@ from gpu_common import ctx  # noqa: F401
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("n,seed", [(0, 5), (1, 0), (63, 1), (64, 7), (4096, 0), (4097, 3), (1_000_003, 1)])
+# one launch up to 1024 tiles of 2048 elements, two up to 4096 tiles, three beyond
+@pytest.mark.parametrize("n,seed", [(0, 5), (1, 0), (63, 1), (64, 7), (4096, 0), (4097, 3), (1_000_003, 1), (2_097_152, 2),
+                                    (2_097_153, 9), (5_000_000, 4), (9_000_001, 6)])
 def test_scan_u32(ctx, n, seed):
     import mlsgpu_amd as m
     rng = np.random.RandomState(n + 1)
@@ -19,6 +21,27 @@ def test_scan_u32(ctx, n, seed):
     got = buf.download(np.uint32, n)
     exp = (np.concatenate([[0], np.cumsum(data[:-1], dtype=np.uint64)]) + seed).astype(np.uint32) if n else data
     np.testing.assert_array_equal(got, exp)
+
+
+def test_scan_launches_back_to_back(ctx):
+    """The one-launch scan's flags are never cleared (a launch's flags carry its epoch): scans of changing sizes, one
+    behind the other on one stream, each see only their own."""
+    import mlsgpu_amd as m
+    rng = np.random.RandomState(77)
+    sizes = [int(x) for x in rng.randint(1, 600_000, size=40)] + [2_097_152, 5, 2_000_000, 2049, 2048, 1]
+    bufs, datas = [], []
+    for n in sizes:
+        data = rng.randint(0, 5, size=n).astype(np.uint32)
+        datas.append(data)
+        bufs.append(m.DeviceBuffer(ctx, array=data))
+    for rep in range(3):
+        for k, (n, buf) in enumerate(zip(sizes, bufs)):
+            if rep:
+                buf.upload(datas[k])
+            m.binding.check(m.lib().mlsgpu_hip_test_scan_u32(ctx.h, buf.ptr, n, k))
+        for k, (n, buf) in enumerate(zip(sizes, bufs)):
+            exp = (np.concatenate([[0], np.cumsum(datas[k][:-1], dtype=np.uint64)]) + k).astype(np.uint32)
+            np.testing.assert_array_equal(buf.download(np.uint32, n), exp)
 
 
 @pytest.mark.parametrize("n,bits", [(1, 17), (1000, 1), (4096, 8), (5000, 10), (70_001, 17), (300_000, 28), (300_000, 32)])
