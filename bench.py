@@ -108,6 +108,9 @@ def parse_args():
                    help="host threads (a persistent pool per copy side, bound to the GPU's NUMA node) copying one bucket into pinned "
                         "staging.  The copies must outrun the link: 1.68 GB per job in 11-16 ms with a source on the GPU's node, 21-31 "
                         "ms with a source on the other socket (8 threads: 30)")
+    p.add_argument("--sink-rotation", type=int, default=3,
+                   help="device sinks a stream of jobs rotates through in the device-sink transfer leg (a job's weld and read-back "
+                        "overlap the following jobs)")
     p.add_argument("--no-bind", action="store_true",
                    help="leave the process where the scheduler puts it (default: the process -- every thread, every first touch of "
                         "host memory -- is bound to the CPUs of its GPU's NUMA node before anything is allocated)")
@@ -577,7 +580,9 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     # every sink welds and reads back on a stream of its own, of HIGH priority: the weld of job k competes with the
     # kernels of job k + 1 for the GPU, and it is the weld that is on the critical path of the steady state
     import torch
-    NS = 3      # sinks in rotation: two welds may be in flight while the next job streams in (two sinks: 47-54 ms per job)
+    # sinks in rotation: NS - 1 welds / read-backs may be in flight while the next job streams in (two sinks: 47-54 ms per job
+    # on the shells cloud, three 38-40)
+    NS = max(2, args.sink_rotation)
     hi = [torch.cuda.Stream(device=device_index, priority=int(os.environ.get("MLSGPU_BENCH_SINK_PRIORITY", "-1"))) for _ in range(NS)]
     fctx = [m.Context(device_index, stream=s_.cuda_stream) for s_ in hi]
     sinks = [m.Mesher(c, 0.02) for c in fctx]

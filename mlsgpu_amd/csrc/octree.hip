@@ -223,10 +223,15 @@ struct EntryWriteOut
  */
 enum
 {
-    ENT_TILE = 512,                 /* splats per workgroup, one per thread (measured 256: 94 us per bucket in the scatter) */
+    ENT_THREADS = 512,              /* threads per workgroup */
+    ENT_PER = 2,                    /* consecutive splats per thread.  entryScatter per launch of four buckets (cfg3): 1 splat
+                                     * per thread 193.5 us, 2: 170.0, 3: 208.6, 4: 211.9 -- twice the entries between two
+                                     * barriers and twice as long a run of every digit in memory, while three workgroups still
+                                     * fit a CU's LDS (two at 3 and 4) */
+    ENT_TILE = ENT_THREADS * ENT_PER,   /* splats per workgroup */
     ENT_CAP = 8 * ENT_TILE,         /* at most eight entries per splat */
     ENT_BIN_BITS = 8,               /* the fused pass handles digits of up to 8 bits */
-    ENT_KEY_BITS = 23               /* ... of keys that leave nine bits of a word for the thread that holds the splat */
+    ENT_KEY_BITS = 22               /* ... of keys that leave ten bits of a word for the splat's place in the tile */
 };
 
 struct EntryHistArgs
@@ -238,7 +243,7 @@ struct EntryHistArgs
     uint64_t n;
 };
 
-__global__ __launch_bounds__(ENT_TILE) void entryHistKernel(Lanes<EntryHistArgs> lanes, uint32_t digitBits)
+__global__ __launch_bounds__(ENT_THREADS) void entryHistKernel(Lanes<EntryHistArgs> lanes, uint32_t digitBits)
 {
     const EntryHistArgs &A = lanes.a[blockIdx.y];     /* by reference: the level offsets are indexed dynamically and stay
                                                          * in the kernel-argument segment (a copy would live in scratch) */
@@ -246,25 +251,32 @@ __global__ __launch_bounds__(ENT_TILE) void entryHistKernel(Lanes<EntryHistArgs>
         return;
     __shared__ uint32_t bins[1 << ENT_BIN_BITS];
     const uint32_t numBins = 1u << digitBits, dmask = numBins - 1;
-    for (uint32_t d = threadIdx.x; d < numBins; d += ENT_TILE)
+    for (uint32_t d = threadIdx.x; d < numBins; d += ENT_THREADS)
         bins[d] = 0;
     __syncthreads();
-    const uint64_t i = (uint64_t) blockIdx.x * ENT_TILE + threadIdx.x;
-    if (i < A.n)
-    {
-        const float4 pr = reinterpret_cast<const float4 *>(A.P.splats + (i + A.P.firstSplat))[0];
-        uint32_t k[8];
-        const uint32_t mask = splatEntries(A.P, pr, k);
-        A.slotMasks[i] = (uint8_t) mask;
+    /* a thread's splats are neighbours in the cloud (one 32 x ENT_PER-byte stretch): both records are requested before the
+     * first is looked at */
+    const uint64_t i0 = (uint64_t) blockIdx.x * ENT_TILE + (uint64_t) threadIdx.x * ENT_PER;
+    float4 pr[ENT_PER];
 #pragma unroll
-        for (int o = 0; o < 8; o++)
-            if (mask & (1u << o))
-                atomicAdd(&bins[k[o] & dmask], 1u);
-    }
+    for (int s_ = 0; s_ < ENT_PER; s_++)
+        pr[s_] = reinterpret_cast<const float4 *>(A.P.splats + ((i0 + s_ < A.n ? i0 + s_ : 0) + A.P.firstSplat))[0];
+#pragma unroll
+    for (int s_ = 0; s_ < ENT_PER; s_++)
+        if (i0 + s_ < A.n)
+        {
+            uint32_t k[8];
+            const uint32_t mask = splatEntries(A.P, pr[s_], k);
+            A.slotMasks[i0 + s_] = (uint8_t) mask;
+#pragma unroll
+            for (int o = 0; o < 8; o++)
+                if (mask & (1u << o))
+                    atomicAdd(&bins[k[o] & dmask], 1u);
+        }
     __syncthreads();
     uint32_t *const hist = A.hist;
     const uint32_t numTiles = A.numTiles;
-    for (uint32_t d = threadIdx.x; d < numBins; d += ENT_TILE)
+    for (uint32_t d = threadIdx.x; d < numBins; d += ENT_THREADS)
         hist[(uint64_t) d * numTiles + blockIdx.x] = bins[d];
 }
 
@@ -316,9 +328,9 @@ struct EntryScatterArgs
     uint32_t *keysOut, *valsOut;
 };
 
-__global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))) void entryScatterKernel(Lanes<EntryScatterArgs> lanes, uint32_t digitBits)
+__global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void entryScatterKernel(Lanes<EntryScatterArgs> lanes, uint32_t digitBits)
 {
-    enum { BINS = 1 << ENT_BIN_BITS, WAVES = ENT_TILE / 64, MAX_ROUNDS = ENT_CAP / ENT_TILE };
+    enum { BINS = 1 << ENT_BIN_BITS, WAVES = ENT_THREADS / 64, MAX_ROUNDS = ENT_CAP / ENT_THREADS };
     const EntryScatterArgs &A = lanes.a[blockIdx.y];  /* by reference, as in entryHistKernel */
     if (blockIdx.x >= A.numTiles)
         return;
@@ -334,11 +346,11 @@ __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))
     __shared__ uint32_t waveTotals[WAVES], waveTotalsAll[WAVES], waveCnt[WAVES];
     /* An entry in LDS is ONE word: its key (ENT_KEY_BITS at most on this route) below the thread that holds its splat (the
      * id is the tile's first id + that).  Key and id travel together through the reorder, so the ids need no pass of their
-     * own: 25 KB of LDS and six workgroup barriers (33 KB and eight with the ids in an array of their own). */
+     * own: six workgroup barriers instead of eight, and 41 KB of LDS for a tile of 1024 splats (three workgroups per CU). */
     __shared__ uint32_t sEnt[ENT_CAP];          /* the tile's entries in (splat, slot) order; afterwards in the pass's order */
     const uint32_t numBins = 1u << digitBits, dmask = numBins - 1;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint32_t d = threadIdx.x; d < numBins; d += ENT_TILE)
+    for (uint32_t d = threadIdx.x; d < numBins; d += ENT_THREADS)
     {
 #pragma unroll
         for (int w = 0; w < WAVES; w++)
@@ -347,15 +359,24 @@ __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))
     /* 1. the tile's entries, lined up in (splat, slot) order.  What the thread reads that does not depend on another read is
      * requested here, together: its slot mask, its splat, and the digit totals and tile offsets of the bins it owns in the
      * scan further down (one round of memory latency instead of three). */
-    const uint64_t i = (uint64_t) blockIdx.x * ENT_TILE + threadIdx.x;
-    const uint32_t mask = i < n ? (uint32_t) slotMasks[i] : 0u;
-    float4 *const sp = reinterpret_cast<float4 *>(P.splats + ((uint32_t) (i < n ? i : 0) + P.firstSplat));
-    const float4 pr = sp[0];
-    const uint32_t per = numBins > ENT_TILE ? numBins / ENT_TILE : 1;
+    const uint64_t i0 = (uint64_t) blockIdx.x * ENT_TILE + (uint64_t) threadIdx.x * ENT_PER;
+    uint32_t masks[ENT_PER];
+    float4 prs[ENT_PER];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int s_ = 0; s_ < ENT_PER; s_++)
+    {
+        const bool in = i0 + s_ < n;
+        masks[s_] = in ? (uint32_t) slotMasks[i0 + s_] : 0u;
+        prs[s_] = reinterpret_cast<const float4 *>(P.splats + ((uint32_t) (in ? i0 + s_ : 0) + P.firstSplat))[0];
+    }
+    const uint32_t per = numBins > ENT_THREADS ? numBins / ENT_THREADS : 1;
     const uint32_t d0 = threadIdx.x * per;
     const uint32_t totalOfBin = d0 < numBins ? digitTotals[d0] : 0u;
     const uint32_t histOfBin = d0 < numBins ? hist[(uint64_t) d0 * numTiles + blockIdx.x] : 0u;
-    const uint32_t cnt = (uint32_t) __popc(mask);
+#pragma unroll
+    for (int s_ = 0; s_ < ENT_PER; s_++)
+        cnt += (uint32_t) __popc(masks[s_]);
     const uint32_t incl = waveInclusiveScan(cnt);
     if (lane == 63)
         waveCnt[wave] = incl;
@@ -368,33 +389,37 @@ __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))
             pos += waveCnt[w];
         tileCount += waveCnt[w];
     }
-    if (i < n)
-    {
-        if (P.mutate)
-            reinterpret_cast<float *>(sp)[3] = 1.0f / (pr.w * pr.w);    /* kernels/octree.cl:193 */
-        if (mask != 0)
-        {
-            /* prepare (octree.cl:79-90) again for the node coordinates; the box tests are not repeated */
-            const int lox = floorToInt(pr.x - pr.w), loy = floorToInt(pr.y - pr.w), loz = floorToInt(pr.z - pr.w);
-            const int hix = floorToInt(pr.x + pr.w), hiy = floorToInt(pr.y + pr.w), hiz = floorToInt(pr.z + pr.w);
-            int shift = levelShift(lox, loy, loz, hix, hiy, hiz);
-            shift = min(max(shift, P.minShift), P.maxShift);
-            const int ilx = max(lox - P.bx, 0) >> shift;
-            const int ily = max(loy - P.by, 0) >> shift;
-            const int ilz = max(loz - P.bz, 0) >> shift;
-            const uint32_t levelOffset = P.levelOffsets.v[shift];
-            const uint32_t holder = threadIdx.x << ENT_KEY_BITS;
 #pragma unroll
-            for (int o = 0; o < 8; o++)
-                if (mask & (1u << o))
-                    sEnt[pos++] = (makeCode(ilx + (o & 1), ily + ((o >> 1) & 1), ilz + (o >> 2)) + levelOffset) | holder;
+    for (int s_ = 0; s_ < ENT_PER; s_++)
+        if (i0 + s_ < n)
+        {
+            const float4 pr = prs[s_];
+            const uint32_t mask = masks[s_];
+            if (P.mutate)       /* kernels/octree.cl:193 */
+                reinterpret_cast<float *>(P.splats + ((uint32_t) (i0 + s_) + P.firstSplat))[3] = 1.0f / (pr.w * pr.w);
+            if (mask != 0)
+            {
+                /* prepare (octree.cl:79-90) again for the node coordinates; the box tests are not repeated */
+                const int lox = floorToInt(pr.x - pr.w), loy = floorToInt(pr.y - pr.w), loz = floorToInt(pr.z - pr.w);
+                const int hix = floorToInt(pr.x + pr.w), hiy = floorToInt(pr.y + pr.w), hiz = floorToInt(pr.z + pr.w);
+                int shift = levelShift(lox, loy, loz, hix, hiy, hiz);
+                shift = min(max(shift, P.minShift), P.maxShift);
+                const int ilx = max(lox - P.bx, 0) >> shift;
+                const int ily = max(loy - P.by, 0) >> shift;
+                const int ilz = max(loz - P.bz, 0) >> shift;
+                const uint32_t levelOffset = P.levelOffsets.v[shift];
+                const uint32_t holder = (threadIdx.x * ENT_PER + (uint32_t) s_) << ENT_KEY_BITS;
+#pragma unroll
+                for (int o = 0; o < 8; o++)
+                    if (mask & (1u << o))
+                        sEnt[pos++] = (makeCode(ilx + (o & 1), ily + ((o >> 1) & 1), ilz + (o >> 2)) + levelOffset) | holder;
+            }
         }
-    }
     __syncthreads();
     if (tileCount == 0)
         return;
     /* 2. one stable LSD pass over the tile, as sortScatterKernel: wave w owns `rounds` x 64 consecutive elements */
-    const uint32_t rounds = (tileCount + ENT_TILE - 1) / ENT_TILE;
+    const uint32_t rounds = (tileCount + ENT_THREADS - 1) / ENT_THREADS;
     const uint32_t first = wave * rounds * 64 + lane;
     uint32_t ent[MAX_ROUNDS];
 #pragma unroll
@@ -477,7 +502,7 @@ __global__ __launch_bounds__(ENT_TILE) __attribute__((amdgpu_waves_per_eu(8, 8))
 #pragma unroll
     for (int k = 0; k < MAX_ROUNDS; k++)
     {
-        const uint32_t p = threadIdx.x + k * ENT_TILE;
+        const uint32_t p = threadIdx.x + k * ENT_THREADS;
         if (p < tileCount)
         {
             const uint32_t e = sEnt[p];
@@ -834,13 +859,13 @@ static int treeBuildBatch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *re
                 es.a[a] = EntryScatterArgs{P, t->dSlotMasks, t->dHist, dDigitTotals, tilesE, reqs[k].numSplats, t->dKeysB, t->dValsB};
                 maxTiles = std::max(maxTiles, tilesE);
             }
-            LAUNCH(ctx, stat, entryHistKernel, dim3(maxTiles, na), dim3(ENT_TILE), eh, perPass);
+            LAUNCH(ctx, stat, entryHistKernel, dim3(maxTiles, na), dim3(ENT_THREADS), eh, perPass);
             LAUNCH(ctx, stat, (sortDigitScanKernel<uint32_t>), dim3(1u << perPass, na), dim3(PRIM_BLOCK), ds);
             /* The entry counts (2.4 .. 3.8 per splat on the BASELINE clouds, 8 at most) come back to the host: the remaining
              * sort pass and the command scan launch on n instead of 8N elements. */
             const uint32_t seq = t0->entryBox.reserve();
             LAUNCH(ctx, stat, entryTotalKernel, dim3(1), dim3(256), et, na, 1u << perPass, t0->entryBox.dev, seq);
-            LAUNCH(ctx, stat, entryScatterKernel, dim3(maxTiles, na), dim3(ENT_TILE), es, perPass);
+            LAUNCH(ctx, stat, entryScatterKernel, dim3(maxTiles, na), dim3(ENT_THREADS), es, perPass);
             PROPAGATE(t0->entryBox.wait(ctx->stream));
             for (uint32_t a = 0; a < na; a++)
             {

@@ -15,13 +15,15 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--dist", default="shells")
+    ap.add_argument("--rotation", type=int, default=3)
     a = ap.parse_args()
-    sys.argv = [sys.argv[0]]
+    sys.argv = [sys.argv[0], "--sink-rotation", str(a.rotation)]
     args = bench.parse_args()
     import torch
 
     import mlsgpu_amd as m
-    from mlsgpu_amd import synth
+    from mlsgpu_amd import farm as fm, synth
+    fm.bind_process_to_device_node(0)
     device = torch.device("cuda", 0)
     cloud, g = synth.make_cloud_device("cfg3", device, scale=1.0, dist=a.dist)
     sb_t, sbuckets = synth.bucketize_device(cloud, synth.grid_buckets((g, g, g), 255))
@@ -30,11 +32,11 @@ def main():
     smax = max(b.count for b in sbuckets)
     scells = max(max(b.num_vertices) for b in sbuckets) - 1
     svox = sum(b.cells for b in sbuckets)
-    host = sb_t.cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
+    host = synth.to_host_splats(sb_t)
     del sb_t
     torch.cuda.empty_cache()
     out = bench.transfer_legs(m, args, 0, host, sbuckets, smax, scells, svox, a.steps)
-    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk != "note"} for k, v in out.items()}))
+    print(json.dumps({k: {kk: vv for kk, vv in v.items() if kk not in ("note", "placement")} for k, v in out.items()}))
 
 
 if __name__ == "__main__":
