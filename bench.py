@@ -103,6 +103,9 @@ def parse_args():
     p.add_argument("--farm-spare", type=int, default=6,
                    help="device items per GPU beyond one per worker in the transfer legs (62 MB each here).  With the reference's one "
                         "spare item the copy side waits 4-6 ms per job for a worker to hand an item back and the link idles meanwhile")
+    p.add_argument("--farm-batch", type=int, default=1,
+                   help="buckets a farm worker of the transfer legs takes through one set of launches when that many are queued "
+                        "(mlsgpu_hip_farm_set_batch)")
     p.add_argument("--staging-buffers", type=int, default=0, help="pinned staging buffers per copy side (0: the side's GPUs + 2)")
     p.add_argument("--copy-threads", type=int, default=16,
                    help="host threads (a persistent pool per copy side, bound to the GPU's NUMA node) copying one bucket into pinned "
@@ -525,20 +528,36 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     farm = m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=args.farm_spare, max_cells=max_cells,
                         mesh_memory=args.mesh_memory_mb << 20, copy_threads=args.copy_threads, staging_buffers=args.staging_buffers)
     farm.set_host_output(6 << 30, None)
+    if args.farm_batch > 1:
+        farm.set_batch(min(args.farm_batch, m.binding.MAX_BATCH))
+
+    drain = [0.0]
 
     def stream_pass():
         for i, (b, v) in enumerate(zip(buckets, views)):
             farm.submit(v, b.low, b.num_vertices, i)
+        t = time.perf_counter()
         farm.finish()
+        drain[0] += time.perf_counter() - t
+    # the first passes of a process through this route run 20-30 % slower than the ones that follow, whatever farm they go
+    # through (a fresh farm in a warm process is fast at once: the probe of tools/transfer_probe.py reads 42-47 ms per job in
+    # its first call and 33.5 in the second): about half a second of untimed passes first
+    t0 = time.perf_counter()
     stream_pass()
+    first_s = time.perf_counter() - t0
+    for _ in range(max(2, min(12, int(0.5 / max(first_s, 1e-3))))):
+        stream_pass()
     before = farm.host_stats()
     c0 = farm.copy_clock()
+    w0 = farm.worker_clock()
+    drain[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
         stream_pass()
     dt = (time.perf_counter() - t0) / steps
     hs = farm.host_stats()
     c1 = farm.copy_clock()
+    w1 = farm.worker_clock()
     d2h = (hs["bytes"] - before["bytes"]) / steps
     per = {k: (c1[k] - c0[k]) / steps for k in ("fill_s", "wait_staging_s", "wait_item_s", "h2d_s", "enqueue_s")}
     # ... and the same passes as ONE stream of buckets (no drain between jobs): what the link sustains when the next job's
@@ -564,6 +583,9 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
                      "h2d_busy_frac": round((c3["h2d_s"] - c2["h2d_s"]) / steps / dt_stream, 3),
                      "what": "%d jobs submitted back to back, one wait at the end: no pipeline drain between jobs" % steps},
         "link_floor_ms": round(per["h2d_s"] * 1e3, 2),
+        "drain_ms_per_job": round(drain[0] / steps * 1e3, 2),
+        "workers_ms_per_step": {"busy": round((w1["busy_s"] - w0["busy_s"]) / steps * 1e3, 2),
+                                "idle": round((w1["idle_s"] - w0["idle_s"]) / steps * 1e3, 2), "threads": nworkers},
         "placement": farm.placement(),
         "note": "per job (ms_per_step): pageable host splats -> pinned staging (%d copy threads) -> H2D -> %d device workers (+ %d "
                 "spare items) -> every ship-out read back through a 6 GiB pinned circular buffer, consumed (dropped) by the farm's "
@@ -762,7 +784,7 @@ def multi_gpu_legs(m, args, result, dist, park, reduce_device, rank, world, loca
         copies over xGMI)."""
     import torch
 
-    from mlsgpu_amd import dist_sink
+    from mlsgpu_amd import dist_sink, synth
 
     class LegFailed(Exception):
         pass
@@ -984,7 +1006,15 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d: refusing to report a number for a different device count"
                          % (args.gpus, world))
 
+    # one process per GPU: next to its GPU, before any host memory is touched and before the HIP runtime starts its threads
+    # (rank r of an 8-GPU node lands on the socket GPU r hangs off; the pinned staging, the read-back ring, the copy threads,
+    # the runtime's event threads and the welder follow).  torch.cuda.device_count() does not initialise HIP on this image.
     import torch
+    from mlsgpu_amd import farm as _farm
+    if args.no_bind:
+        process_placement = {"bound": False, "why": "--no-bind"}
+    else:
+        process_placement = _farm.bind_process_to_device_node(local_rank % max(torch.cuda.device_count(), 1), before_hip=True)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # one process per GPU; MLSGPU_BENCH_BACKEND=gloo lets several ranks share one GPU (a single-GPU check of the
@@ -1015,11 +1045,7 @@ def main():
     reduce_device = "cuda" if (dist is not None and backend == "nccl") else None
 
     import mlsgpu_amd as m
-    from mlsgpu_amd import farm
-
-    # one process per GPU: next to its GPU, before any host memory is touched (rank r of an 8-GPU node lands on the socket
-    # GPU r hangs off; the pinned staging, the read-back ring, the copy threads and the welder follow)
-    process_placement = ({"bound": False, "why": "--no-bind"} if args.no_bind else farm.bind_process_to_device_node(local_rank))
+    from mlsgpu_amd import farm, synth
 
     if args.workload == "cfg5":
         run_cfg5(args, rank, world, local_rank, device, dist, reduce_device)
@@ -1040,7 +1066,6 @@ def main():
     # the CPU baseline's sample: small cubes all over the same cloud, cut while the raw cloud is in HBM
     cpu_sample = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.headline_only and W["cloud"] is not None:
-        from mlsgpu_amd import synth
         boxes = cpu_sample_boxes(W["grid"][0])[:os.cpu_count() or 1]
         st, sb = synth.bucketize_device(W["cloud"], boxes)
         cpu_sample = (st.cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1), sb)
@@ -1307,7 +1332,6 @@ def main():
     # its own digest against its pin, the verdicts are gathered, and one mismatch anywhere fails the whole run
     digest_failure = None
     if W["name"] == "cfg4slab" and args.scale == 1.0 and CFG4SLAB_PINS is not None:
-        from mlsgpu_amd import synth
         pin = CFG4SLAB_PINS.get(str(rank), {}).get(synth.slab_variant(world, rank))
         mine_ok = pin is not None and digest == pin["digest"] and check.vertices == pin["vertices"] \
             and check.triangles == pin["triangles"]
@@ -1675,7 +1699,6 @@ def main():
     # ---- D1 ("shells", SURVEY 8d: report both): resident rate and the same transfer-inclusive legs ----
     if secondary and not args.no_shells and args.dist == "uniform" and args.workload in ("auto", "cfg3"):
         try:     # a secondary leg never costs the line its headline
-            from mlsgpu_amd import synth
             cloud, g = synth.make_cloud_device("cfg3", device, scale=args.scale, dist="shells")
             sb_t, sbuckets = synth.bucketize_device(cloud, synth.grid_buckets((g, g, g), 255))
             del cloud

@@ -85,21 +85,50 @@ def node_cpus(node, root=None):
     return out
 
 
-def bind_process_to_device_node(device):
+def device_node_out_of_process(device):
+    """The NUMA node of HIP device `device`, asked of a CHILD process (same environment, same device enumeration): this
+    process's HIP runtime stays untouched, so that it can be bound before the runtime starts its own threads."""
+    import subprocess
+    import sys
+    code = ("import ctypes,sys\n"
+            "hip=ctypes.CDLL('libamdhip64.so')\n"
+            "b=ctypes.create_string_buffer(64)\n"
+            "sys.exit(9) if hip.hipDeviceGetPCIBusId(b,64,%d)!=0 else print(b.value.decode().lower())" % int(device))
+    try:
+        bdf = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1]
+        import os
+        root = os.environ.get("MLSGPU_HIP_SYSFS_ROOT") or "/sys"
+        return int(open("%s/bus/pci/devices/%s/numa_node" % (root, bdf)).read())
+    except Exception:   # noqa: BLE001 - no GPU, no sysfs entry: unknown
+        return -1
+
+
+def bind_process_to_device_node(device, before_hip=False):
     """One process per GPU: the process -- every thread it starts from now on, every first touch of host memory -- on the
     CPUs of the NUMA node its GPU hangs off (what `numactl --cpunodebind` does for a launcher that knows the topology;
-    torch.distributed.run does not).  Call it before anything is allocated.  Returns what was done, for the bench line:
+    torch.distributed.run does not).  Call it before anything is allocated; with before_hip=True even before the HIP
+    runtime is initialised (the node is asked of a child process), so that the runtime's own threads -- the ones that
+    wake a host thread waiting for an event -- start on the GPU's socket too.  Returns what was done, for the bench line:
     {"numa_nodes", "gpu_node", "bound", "cpus"}.  A one-node machine, an unknown node or an affinity mask that excludes the
     node's CPUs leaves the process alone.  The library's own threads (the farm's copy sides, device workers, the host
     welder) place themselves per GPU either way (csrc/placement.hpp)."""
     import os
-    from . import binding as mb
-    import numpy as np
-    n = np.zeros(1, np.uint32)
-    mb.check(mb.lib().mlsgpu_hip_topology(n.ctypes.data, None))
-    node = int(mb.lib().mlsgpu_hip_device_node(int(device)))
-    out = {"numa_nodes": int(n[0]), "gpu_node": node, "bound": False, "cpus": len(os.sched_getaffinity(0))}
-    if n[0] < 2 or node < 0:
+    root = os.environ.get("MLSGPU_HIP_SYSFS_ROOT") or "/sys"
+    nodes = 0
+    while os.path.exists("%s/devices/system/node/node%d/cpulist" % (root, nodes)):
+        nodes += 1
+    forced = os.environ.get("MLSGPU_HIP_DEVICE_NODES")
+    if forced:
+        listed = [int(x) for x in forced.split(",") if x.strip()]
+        node = listed[int(device)] if int(device) < len(listed) else -1
+    elif before_hip:
+        node = device_node_out_of_process(device) if nodes >= 2 else -1
+    else:
+        from . import binding as mb
+        node = int(mb.lib().mlsgpu_hip_device_node(int(device)))
+    out = {"numa_nodes": nodes, "gpu_node": node, "bound": False, "cpus": len(os.sched_getaffinity(0)),
+           "before_hip_runtime": bool(before_hip)}
+    if nodes < 2 or node < 0:
         return out
     want = set(node_cpus(node)) & os.sched_getaffinity(0)
     if not want:

@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--farm-workers", type=int, default=4)
     ap.add_argument("--weld", action="store_true")
     ap.add_argument("--weld-threads", type=int, default=0)
+    ap.add_argument("--farm-batch", type=int, default=1)
     ap.add_argument("--spare", type=int, default=1)
     ap.add_argument("--staging", type=int, default=0)
     ap.add_argument("--repeat", type=int, default=3)
@@ -58,7 +59,7 @@ def main():
         bound = node if a.bind == "node" else (node + 1) % nodes
         os.sched_setaffinity(0, node_cpus(bound))
     sys.argv = [sys.argv[0], "--copy-threads", str(a.copy_threads), "--farm-workers", str(a.farm_workers), "--farm-spare", str(a.spare),
-                "--staging-buffers", str(a.staging), "--weld-threads", str(a.weld_threads)]
+                "--staging-buffers", str(a.staging), "--weld-threads", str(a.weld_threads), "--farm-batch", str(a.farm_batch)]
     import bench
     args = bench.parse_args()
     import mlsgpu_amd as m
