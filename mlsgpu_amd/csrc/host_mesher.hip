@@ -88,7 +88,6 @@ public:
         if (p == MAP_FAILED)
             return Slab();
         (void) madvise(p, s.cap, MADV_HUGEPAGE);
-        placement::preferNodeOfThisThread(p, s.cap);
         s.base = static_cast<char *>(p);
         return s;
     }
@@ -279,8 +278,7 @@ public:
                 pending++;
             }
         }
-        for (size_t t = 0; t < helpers; t++)
-            wake.notify_one();              /* as many threads as there are pieces for, not the whole pool */
+        wake.notify_all();
         body();
         while (sh->done.load() < n)
             std::this_thread::yield();
@@ -494,17 +492,6 @@ struct mlsgpu_host_mesher
     std::vector<uint32_t> outChunks;
     uint64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
-    placement::CopyPool copiers;
-    bool copiersStarted = false;
-    placement::CopyPool &getCopiers()
-    {
-        if (!copiersStarted)
-        {
-            copiers.start(std::min(8u, std::max(2u, std::thread::hardware_concurrency() / 4)), placement::cpusOfNode(node));
-            copiersStarted = true;
-        }
-        return copiers;
-    }
     Pool &getPool()
     {
         if (!pool)
@@ -758,7 +745,7 @@ MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkI
         struct Piece { char *dst; const char *src; size_t bytes; bool indices; };
         std::vector<Piece> pieces;
         auto cut = [&](void *dst, const void *src, size_t bytes, bool indices) {
-            const size_t step = size_t(1) << 20;
+            const size_t step = size_t(4) << 20;
             for (size_t o = 0; o < bytes; o += step)
                 pieces.push_back(Piece{static_cast<char *>(dst) + o, static_cast<const char *>(src) + o, std::min(step, bytes - o),
                                        indices});
@@ -785,15 +772,11 @@ MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkI
                     badIndex.store(1);
             }
         };
-        /* on the welder's own few copy threads, not on the pool of the block tasks: a mesh must leave the ring at the rate
-         * meshes arrive whatever the pool is busy with (and the caller -- the farm's ONE mesher thread -- sleeps on a
-         * condition variable meanwhile; spinning on yield() cost it whole time slices when another welder's finalize ran
-         * beside this one: 0.8 -> 2.7 ms per block) */
         if (pieces.size() <= 2)
             for (size_t i = 0; i < pieces.size(); i++)
                 copyPiece(i);
         else
-            m->getCopiers().run(pieces.size(), copyPiece);
+            m->getPool().parallelForNow(pieces.size(), copyPiece);
         m->trace.copyS += std::chrono::duration<double>(std::chrono::steady_clock::now() - tCopy0).count();
         m->trace.pieces += pieces.size();
         /* a bad mesh leaves the sink unchanged (its copy stays behind in the arena, unused) */

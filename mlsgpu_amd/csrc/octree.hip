@@ -38,6 +38,7 @@ struct mlsgpu_tree
     U3 *dNodeTiles = nullptr;           /* tile sums of the scan over the nodes */
     HostMailbox entryBox;               /* the entry count comes back to the host once per build */
     uint8_t *dSlotMasks = nullptr;      /* per splat: which of its 8 candidate slots are real entries */
+    uint64_t *dEntryNotes = nullptr;    /* per splat, the fused front end: slot mask, level, node coordinates (packNote) */
     mlsgpu_splat *dSplats = nullptr;   /* borrowed between build and clear_splats */
     bool mutate = true;                 /* radius -> 1/radius^2 in place (the reference); false: the splats stay as they came */
 };
@@ -115,7 +116,13 @@ struct EntryParams
     uint32_t mutate;            /* write 1/r^2 into the radius slot (kernels/octree.cl:193), or leave the splats untouched */
 };
 
-__device__ __forceinline__ uint32_t splatEntries(const EntryParams &P, const float4 pr, uint32_t k[8])
+/* ... and where its 2 x 2 x 2 candidate nodes are: level and lowest node coordinates (what a key is made of) */
+struct EntryPlace
+{
+    int shift, ilx, ily, ilz;
+};
+
+__device__ __forceinline__ uint32_t splatEntries(const EntryParams &P, const float4 pr, uint32_t k[8], EntryPlace *place = nullptr)
 {
     /* prepare, octree.cl:79-90 */
     const int lox = floorToInt(pr.x - pr.w), loy = floorToInt(pr.y - pr.w), loz = floorToInt(pr.z - pr.w);
@@ -129,6 +136,8 @@ __device__ __forceinline__ uint32_t splatEntries(const EntryParams &P, const flo
     radius2 *= 1.00001f;
     const uint32_t levelOffset = P.levelOffsets.v[shift];
     const int bound = 1 << (P.maxShift - shift);
+    if (place != nullptr)
+        *place = EntryPlace{shift, ilx, ily, ilz};
     uint32_t mask = 0;
 #pragma unroll
     for (int o = 0; o < 8; o++)
@@ -234,10 +243,22 @@ enum
     ENT_KEY_BITS = 22               /* ... of keys that leave ten bits of a word for the splat's place in the tile */
 };
 
+/* What entryHist leaves entryScatter per splat, 8 bytes: low word = slot mask (bits 0-7), level (8-12), lowest node x
+ * (13-22); high word = lowest node y (0-9) and z (10-19); ten bits per coordinate inside the bounds -- so the scatter reads
+ * 8 bytes per splat instead of the 32-byte record (of which it needed 16) and repeats none of the arithmetic.  0 = no entry. */
+__device__ __forceinline__ uint64_t packNote(uint32_t mask, const EntryPlace &pl)
+{
+    if (mask == 0)
+        return 0;
+    const uint32_t lo = mask | (uint32_t) pl.shift << 8 | ((uint32_t) pl.ilx & 0x3FFu) << 13;
+    const uint32_t hi = ((uint32_t) pl.ily & 0x3FFu) | ((uint32_t) pl.ilz & 0x3FFu) << 10;
+    return (uint64_t) lo | (uint64_t) hi << 32;
+}
+
 struct EntryHistArgs
 {
     EntryParams P;
-    uint8_t *slotMasks;
+    uint64_t *notes;
     uint32_t *hist;
     uint32_t numTiles;
     uint64_t n;
@@ -266,8 +287,11 @@ __global__ __launch_bounds__(ENT_THREADS) void entryHistKernel(Lanes<EntryHistAr
         if (i0 + s_ < A.n)
         {
             uint32_t k[8];
-            const uint32_t mask = splatEntries(A.P, pr[s_], k);
-            A.slotMasks[i0 + s_] = (uint8_t) mask;
+            EntryPlace pl;
+            const uint32_t mask = splatEntries(A.P, pr[s_], k, &pl);
+            A.notes[i0 + s_] = packNote(mask, pl);
+            if (A.P.mutate)     /* kernels/octree.cl:193; nothing behind this kernel reads the radius */
+                reinterpret_cast<float *>(A.P.splats + ((i0 + s_) + A.P.firstSplat))[3] = 1.0f / (pr[s_].w * pr[s_].w);
 #pragma unroll
             for (int o = 0; o < 8; o++)
                 if (mask & (1u << o))
@@ -320,7 +344,7 @@ __global__ __launch_bounds__(256) void entryTotalKernel(Lanes<EntryTotalArgs> la
 struct EntryScatterArgs
 {
     EntryParams P;
-    const uint8_t *slotMasks;
+    const uint64_t *notes;
     const uint32_t *hist;
     const uint32_t *digitTotals;
     uint32_t numTiles;
@@ -335,7 +359,7 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     if (blockIdx.x >= A.numTiles)
         return;
     const EntryParams &P = A.P;
-    const uint8_t *const slotMasks = A.slotMasks;
+    const uint64_t *const notes = A.notes;
     const uint32_t *const hist = A.hist;
     const uint32_t *const digitTotals = A.digitTotals;
     const uint32_t numTiles = A.numTiles;
@@ -360,23 +384,18 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
      * requested here, together: its slot mask, its splat, and the digit totals and tile offsets of the bins it owns in the
      * scan further down (one round of memory latency instead of three). */
     const uint64_t i0 = (uint64_t) blockIdx.x * ENT_TILE + (uint64_t) threadIdx.x * ENT_PER;
-    uint32_t masks[ENT_PER];
-    float4 prs[ENT_PER];
+    uint64_t note[ENT_PER];
     uint32_t cnt = 0;
 #pragma unroll
     for (int s_ = 0; s_ < ENT_PER; s_++)
-    {
-        const bool in = i0 + s_ < n;
-        masks[s_] = in ? (uint32_t) slotMasks[i0 + s_] : 0u;
-        prs[s_] = reinterpret_cast<const float4 *>(P.splats + ((uint32_t) (in ? i0 + s_ : 0) + P.firstSplat))[0];
-    }
+        note[s_] = i0 + s_ < n ? notes[i0 + s_] : 0ull;
     const uint32_t per = numBins > ENT_THREADS ? numBins / ENT_THREADS : 1;
     const uint32_t d0 = threadIdx.x * per;
     const uint32_t totalOfBin = d0 < numBins ? digitTotals[d0] : 0u;
     const uint32_t histOfBin = d0 < numBins ? hist[(uint64_t) d0 * numTiles + blockIdx.x] : 0u;
 #pragma unroll
     for (int s_ = 0; s_ < ENT_PER; s_++)
-        cnt += (uint32_t) __popc(masks[s_]);
+        cnt += (uint32_t) __popc((uint32_t) note[s_] & 0xFFu);
     const uint32_t incl = waveInclusiveScan(cnt);
     if (lane == 63)
         waveCnt[wave] = incl;
@@ -391,30 +410,21 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     }
 #pragma unroll
     for (int s_ = 0; s_ < ENT_PER; s_++)
-        if (i0 + s_ < n)
+    {
+        const uint32_t mask = (uint32_t) note[s_] & 0xFFu;
+        if (mask != 0)
         {
-            const float4 pr = prs[s_];
-            const uint32_t mask = masks[s_];
-            if (P.mutate)       /* kernels/octree.cl:193 */
-                reinterpret_cast<float *>(P.splats + ((uint32_t) (i0 + s_) + P.firstSplat))[3] = 1.0f / (pr.w * pr.w);
-            if (mask != 0)
-            {
-                /* prepare (octree.cl:79-90) again for the node coordinates; the box tests are not repeated */
-                const int lox = floorToInt(pr.x - pr.w), loy = floorToInt(pr.y - pr.w), loz = floorToInt(pr.z - pr.w);
-                const int hix = floorToInt(pr.x + pr.w), hiy = floorToInt(pr.y + pr.w), hiz = floorToInt(pr.z + pr.w);
-                int shift = levelShift(lox, loy, loz, hix, hiy, hiz);
-                shift = min(max(shift, P.minShift), P.maxShift);
-                const int ilx = max(lox - P.bx, 0) >> shift;
-                const int ily = max(loy - P.by, 0) >> shift;
-                const int ilz = max(loz - P.bz, 0) >> shift;
-                const uint32_t levelOffset = P.levelOffsets.v[shift];
-                const uint32_t holder = (threadIdx.x * ENT_PER + (uint32_t) s_) << ENT_KEY_BITS;
+            const uint32_t lo32 = (uint32_t) note[s_], hi32 = (uint32_t) (note[s_] >> 32);
+            const int shift = (int) ((lo32 >> 8) & 0x1Fu);
+            const int ilx = (int) ((lo32 >> 13) & 0x3FFu), ily = (int) (hi32 & 0x3FFu), ilz = (int) ((hi32 >> 10) & 0x3FFu);
+            const uint32_t levelOffset = P.levelOffsets.v[shift];
+            const uint32_t holder = (threadIdx.x * ENT_PER + (uint32_t) s_) << ENT_KEY_BITS;
 #pragma unroll
-                for (int o = 0; o < 8; o++)
-                    if (mask & (1u << o))
-                        sEnt[pos++] = (makeCode(ilx + (o & 1), ily + ((o >> 1) & 1), ilz + (o >> 2)) + levelOffset) | holder;
-            }
+            for (int o = 0; o < 8; o++)
+                if (mask & (1u << o))
+                    sEnt[pos++] = (makeCode(ilx + (o & 1), ily + ((o >> 1) & 1), ilz + (o >> 2)) + levelOffset) | holder;
         }
+    }
     __syncthreads();
     if (tileCount == 0)
         return;
@@ -699,7 +709,7 @@ MLSGPU_API uint64_t mlsgpu_hip_tree_resource_usage(uint64_t maxLevels, uint64_t 
     /* start, jumpPos, node counts and bases; commands; keys and values x2; histogram, tile sums; slot masks; node tiles */
     return maxStart * 4 * 4 + commandsSize * 4 + entries * 4 * 4
         + sortHistElems(entries) * 4 + ((uint64_t) scanTiles(sortHistElems(entries) > entries ? sortHistElems(entries) : entries) + 1) * 4
-        + 4 + maxSplats + ((uint64_t) scanTiles(maxStart) + 1) * sizeof(U3);
+        + 4 + maxSplats * 9 + ((uint64_t) scanTiles(maxStart) + 1) * sizeof(U3);
 }
 
 MLSGPU_API int mlsgpu_hip_tree_create(mlsgpu_ctx *ctx, uint64_t maxLevels, uint64_t maxSplats, mlsgpu_tree **out)
@@ -732,6 +742,7 @@ MLSGPU_API int mlsgpu_hip_tree_create(mlsgpu_ctx *ctx, uint64_t maxLevels, uint6
     alloc((void **) &t->dTileSums, tileSums * 4);
     alloc((void **) &t->dNumEntries, 4);
     alloc((void **) &t->dSlotMasks, maxSplats);
+    alloc((void **) &t->dEntryNotes, maxSplats * 8);
     alloc((void **) &t->dNodeCounts, t->maxStart * 4);
     alloc((void **) &t->dNodeBase, t->maxStart * 4);
     alloc((void **) &t->dNodeTiles, ((uint64_t) scanTiles(t->maxStart) + 1) * sizeof(U3));
@@ -753,7 +764,7 @@ MLSGPU_API void mlsgpu_hip_tree_destroy(mlsgpu_tree *t)
     hipSetDevice(t->ctx->device);
     hipFree(t->dStart); hipFree(t->dJumpPos); hipFree(t->dCommands);
     hipFree(t->dKeysA); hipFree(t->dKeysB); hipFree(t->dValsA); hipFree(t->dValsB);
-    hipFree(t->dHist); hipFree(t->dTileSums); hipFree(t->dNumEntries); hipFree(t->dSlotMasks);
+    hipFree(t->dHist); hipFree(t->dTileSums); hipFree(t->dNumEntries); hipFree(t->dSlotMasks); hipFree(t->dEntryNotes);
     hipFree(t->dNodeCounts); hipFree(t->dNodeBase); hipFree(t->dNodeTiles);
     t->entryBox.destroy();
     delete t;
@@ -853,10 +864,10 @@ static int treeBuildBatch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *re
                 const uint32_t tilesE = a < na ? divUp(reqs[k].numSplats, ENT_TILE) : 0u;
                 uint32_t *const dDigitTotals = t->dHist + (uint64_t) (1u << perPass) * divUp(reqs[k].numSplats, ENT_TILE);
                 const EntryParams P = params(k);
-                eh.a[a] = EntryHistArgs{P, t->dSlotMasks, t->dHist, tilesE, reqs[k].numSplats};
+                eh.a[a] = EntryHistArgs{P, t->dEntryNotes, t->dHist, tilesE, reqs[k].numSplats};
                 ds.a[a] = SortDigitScanArgs{t->dHist, dDigitTotals, tilesE};
                 et.a[a] = EntryTotalArgs{dDigitTotals, t->dNumEntries};
-                es.a[a] = EntryScatterArgs{P, t->dSlotMasks, t->dHist, dDigitTotals, tilesE, reqs[k].numSplats, t->dKeysB, t->dValsB};
+                es.a[a] = EntryScatterArgs{P, t->dEntryNotes, t->dHist, dDigitTotals, tilesE, reqs[k].numSplats, t->dKeysB, t->dValsB};
                 maxTiles = std::max(maxTiles, tilesE);
             }
             LAUNCH(ctx, stat, entryHistKernel, dim3(maxTiles, na), dim3(ENT_THREADS), eh, perPass);

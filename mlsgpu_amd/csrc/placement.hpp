@@ -194,28 +194,6 @@ inline int nodeOfAddress(const void *p)
     return -1;
 }
 
-/* Gives a fresh mapping an explicit memory policy: "prefer the node the calling thread runs on".  The pages land where
- * first touch would have put them, but a mapping with a policy of its own is left alone by the kernel's automatic NUMA
- * balancing, whose periodic scans unmap a process's pages to sample who touches them -- every touch of a multi-GB arena
- * then takes a hinting fault.  A no-op where the calls are missing or the machine has one node.  MLSGPU_HIP_NO_MBIND=1
- * leaves mappings alone (A/B runs). */
-inline void preferNodeOfThisThread(void *p, size_t bytes)
-{
-#if defined(SYS_mbind) && defined(SYS_getcpu)
-    static const bool off = getenv("MLSGPU_HIP_NO_MBIND") != nullptr;
-    if (off || numNodes() < 2)
-        return;
-    unsigned cpu = 0, node = 0;
-    if (syscall(SYS_getcpu, &cpu, &node, nullptr) != 0 || node >= 64)
-        return;
-    unsigned long mask = 1UL << node;
-    (void) syscall(SYS_mbind, p, bytes, 1 /* MPOL_PREFERRED */, &mask, 65UL, 0U);
-#else
-    (void) p;
-    (void) bytes;
-#endif
-}
-
 /*
  * A memcpy spread over a few persistent threads (bound to the CPUs of a node if given): one bucket's 64 MB into pinned
  * staging at the rate the PCIe link drains it, without a thread creation per bucket.
