@@ -406,6 +406,50 @@ struct CompactCellsOut
 
 /* per-slice (vertices, indices) histogram, only needed by the overflow path (src/marching.cpp:652-701):
  * one wave per slice sums that slice's row totals */
+/* The swathe totals of every bucket of a batch -- the sum of its row totals -- and their way to the host in ONE launch: a
+ * workgroup per bucket adds up the bucket's rows, the last one to finish (a counter that wraps by itself) writes all the
+ * totals and the sequence number into the mailbox.  (Before: a reduction, a scan of its tile sums and the mailbox kernel,
+ * three launches of a few microseconds each behind one another.) */
+struct RowTotalsArgs
+{
+    const U3 *rowCounts;
+    uint64_t rows;
+    U3 *total;
+};
+
+__global__ __launch_bounds__(1024) void rowTotalsKernel(Lanes<RowTotalsArgs> lanes, uint32_t count, uint32_t *gate,
+                                                        uint32_t *box, uint32_t seq)
+{
+    const RowTotalsArgs A = lanes.a[blockIdx.x];
+    __shared__ U3 waveTotals[16];
+    U3 sum{0u, 0u, 0u};
+    for (uint64_t i = threadIdx.x; i < A.rows; i += 1024)
+        sum = sum + A.rowCounts[i];
+    const U3 incl = waveInclusiveScanT(sum);
+    if ((threadIdx.x & 63) == 63)
+        waveTotals[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    if (threadIdx.x != 0)
+        return;
+    U3 total = waveTotals[0];
+    for (int w = 1; w < 16; w++)
+        total = total + waveTotals[w];
+    storeAgent(A.total, total);
+    __threadfence();
+    if (atomicInc(gate, count - 1) != count - 1)
+        return;
+    __threadfence();
+    for (uint32_t k = 0; k < count; k++)
+    {
+        const U3 t = loadAgent(lanes.a[k].total);
+        __hip_atomic_store(box + 1 + 3 * k, t.a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(box + 2 + 3 * k, t.b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(box + 3 + 3 * k, t.c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __hip_atomic_store(box, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ __launch_bounds__(64) void sliceHistogramKernel(const U3 *rowCounts, uint32_t ch, uint32_t zFirst, uint32_t z0,
                                                            uint2 *histogram)
 {
@@ -1675,7 +1719,10 @@ MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, ui
     alloc((void **) &m->dIndices, is * 4);
     alloc((void **) &m->dWelded, vs * 12);
     alloc((void **) &m->dWeldedKeys, vs * 8);
-    alloc((void **) &m->dReadback, sizeof(Readback) + 64);        /* + the word latticeTrianglesRowKernel's idle stores hit */
+    /* + the word latticeTrianglesRowKernel's idle stores hit, + the gate of rowTotalsKernel (zero between launches) */
+    alloc((void **) &m->dReadback, sizeof(Readback) + 128);
+    if (rc == MLSGPU_OK && hipMemset(m->dReadback, 0, sizeof(Readback) + 128) != hipSuccess)
+        rc = setError(MLSGPU_ERR_HIP, "Marching: cannot clear the read-back words");
     if (rc == MLSGPU_OK && hipHostMalloc((void **) &m->hReadback, sizeof(Readback)) != hipSuccess)
         rc = setError(MLSGPU_ERR_NOMEM, "Marching: cannot allocate pinned readback");
     if (rc == MLSGPU_OK && hipHostMalloc((void **) &m->hHistogram, (uint64_t) maxDepth * 8) != hipSuccess)
@@ -2373,23 +2420,18 @@ MLSGPU_API int mlsgpu_hip_marching_generate_batch(mlsgpu_marching *const *ms, co
     PROPAGATE(computeCodesLanes(ms, sws, count));
     /* generateCells (src/marching.cpp:500-551): the swathe totals of every bucket, one read-back */
     {
-        typedef ScanJob<U3, ArrayIn<U3>, NoIn, NoOut> TotalsJob;
-        TotalsJob jobs[MAX_LANES];
-        const void *srcs[MAX_LANES];
-        for (uint32_t k = 0; k < count; k++)
+        Lanes<RowTotalsArgs> rt;
+        for (uint32_t k = 0; k < MAX_LANES; k++)
         {
-            mlsgpu_marching *m = ms[k];
-            const uint32_t cw = sws[k].width - 1, ch = sws[k].height - 1;
-            const uint64_t rows = cw > 0 ? (uint64_t) ch * (sws[k].zLast - sws[k].zFirst) : 0;
-            jobs[k] = TotalsJob{ArrayIn<U3>{m->dRowCounts}, NoIn(), NoOut(), rows, U3{0, 0, 0}, m->dTileSums3,
-                                &m->dReadback->totals, nullptr};
-            srcs[k] = &m->dReadback->totals;
+            mlsgpu_marching *m = ms[k < count ? k : 0];
+            const mlsgpu_swathe &sw = sws[k < count ? k : 0];
+            const uint32_t cw = sw.width - 1, ch = sw.height - 1;
+            const uint64_t rows = cw > 0 ? (uint64_t) ch * (sw.zLast - sw.zFirst) : 0;
+            rt.a[k] = RowTotalsArgs{m->dRowCounts, rows, &m->dReadback->totals};
         }
-        PROPAGATE((scanPhase1Batch<U3, ArrayIn<U3>, NoIn, NoOut>(ctx, "kernel.marching.genOccupied.time", jobs, count)));
-        int pend = -1;
-        if (ctx->timing) pend = ctx->beginTiming(ctx->statId("kernel.marching.readback.time"));
-        PROPAGATE(ms[0]->box.publishGather(ctx->stream, srcs, count, 3));
-        if (pend >= 0) ctx->endTiming(pend);
+        uint32_t *const gate = reinterpret_cast<uint32_t *>(reinterpret_cast<char *>(ms[0]->dReadback) + sizeof(Readback) + 64);
+        const uint32_t seq = ms[0]->box.reserve();
+        LAUNCH(ctx, "kernel.marching.genOccupied.time", rowTotalsKernel, dim3(count), dim3(1024), rt, count, gate, ms[0]->box.dev, seq);
         PROPAGATE(ms[0]->box.wait(ctx->stream));                 /* the reference's queue.finish(), :548 */
     }
     /* addSlices (src/marching.cpp:627-743) for a bucket that is one swathe with nothing buffered: it either fits the mesh
