@@ -33,6 +33,9 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
+#include <cstdio>
+#include <cstring>
+#include <string>
 #include <deque>
 #include <functional>
 #include <mutex>
@@ -183,6 +186,40 @@ public:
     }
     template<typename T>
     T *array(size_t n) { return static_cast<T *>(alloc(std::max<size_t>(n, 1) * sizeof(T))); }
+    /* trace: where the arena's slabs are and how much of each the kernel backs with huge pages (/proc/self/smaps) */
+    std::string describe()
+    {
+        std::lock_guard<std::mutex> l(mutex);
+        std::string out;
+        for (const Slab &s : slabs)
+        {
+            unsigned long huge = 0;
+            FILE *f = fopen("/proc/self/smaps", "r");
+            if (f != nullptr)
+            {
+                char line[256];
+                bool mine = false;
+                while (fgets(line, sizeof(line), f) != nullptr)
+                {
+                    unsigned long lo, hi;
+                    if (sscanf(line, "%lx-%lx ", &lo, &hi) == 2 && strchr(line, '-') != nullptr && line[0] != ' ' && strstr(line, "kB") == nullptr)
+                        mine = lo <= (unsigned long) (uintptr_t) s.base && (unsigned long) (uintptr_t) s.base < hi;
+                    else if (mine && strncmp(line, "AnonHugePages:", 14) == 0)
+                    {
+                        unsigned long kb = 0;
+                        sscanf(line + 14, "%lu", &kb);
+                        huge += kb;
+                    }
+                }
+                fclose(f);
+            }
+            char text[96];
+            snprintf(text, sizeof(text), " [%zu MB node %d/%d huge %lu MB]", s.cap >> 20, placement::nodeOfAddress(s.base),
+                     placement::nodeOfAddress(s.base + s.cap / 2), huge >> 10);
+            out += text;
+        }
+        return out;
+    }
 
 private:
     std::mutex mutex;
@@ -278,7 +315,8 @@ public:
                 pending++;
             }
         }
-        wake.notify_all();
+        for (size_t t = 0; t < helpers; t++)
+            wake.notify_one();              /* as many threads as there are pieces for, not the whole pool */
         body();
         while (sh->done.load() < n)
             std::this_thread::yield();
@@ -670,6 +708,8 @@ MLSGPU_API void mlsgpu_hip_host_mesher_destroy(mlsgpu_host_mesher *m)
                 m->trace.taskNs.load() * 1e-6, m->trace.drainS * 1e3, (m->trace.resolveS - m->trace.drainS) * 1e3,
                 m->trace.passesS * 1e3, (unsigned long long) (SlabCache::instance().freshSlabs.load() - m->trace.slabs0),
                 (SlabCache::instance().freshBytes.load() - m->trace.bytes0) / 1048576.0);
+    if (m->trace.on && m->trace.adds > 0)
+        fprintf(stderr, "mlsgpu_hip welder slabs:%s\n", m->arena.describe().c_str());
     delete m;
 }
 
