@@ -352,3 +352,34 @@ def test_farm_on_two_real_devices():
         assert mo.isomorphic(v, t, exp[0][1], exp[0][2]), route
         welder.close()
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_farm_reports_placement_and_clocks():
+    """mlsgpu_hip_farm_placement / _copy_clock / _worker_clock on a real device: one copy side for one GPU, its staging where
+    the GPU's node is (when sysfs says), and clocks that add up to what was submitted."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import synth
+    cloud = synth.shells_cloud(200_000, 95.0, 16.0, 1.5, 2.5, seed=5)
+    allb, buckets = synth.bucketize(cloud, 96, 32)
+    cap = max(b.count for b in buckets)
+    farm = m.BucketFarm([0], cap, workers_per_device=2, spare=3, max_cells=63, copy_threads=4, staging_buffers=3)
+    farm.set_host_output(64 << 20, None)
+    pl = farm.placement()
+    assert len(pl["sides"]) == 1 and pl["devices"] == [dict(device=0, node=pl["devices"][0]["node"], side=0)]
+    side = pl["sides"][0]
+    assert side["staging_buffers"] == 3 and side["copy_threads"] == 4
+    node = m.lib().mlsgpu_hip_device_node(0)
+    assert pl["devices"][0]["node"] == node
+    if pl["nodes"] > 1 and node >= 0:
+        assert side["node"] == node and side["staging_node"] == node and pl["ring_node"] == node
+    n = 0
+    for b in buckets:
+        if b.count:
+            farm.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, n)
+            n += 1
+    farm.finish()
+    cc, wc = farm.copy_clock(), farm.worker_clock()
+    assert cc["copies"] == farm.stats()["items"] >= 1 and cc["h2d_s"] > 0 and cc["fill_s"] > 0 and cc["span_s"] >= cc["h2d_s"] * 0.5
+    assert wc["buckets"] == n and 1 <= wc["launch_sets"] <= n and wc["busy_s"] > 0
+    farm.close()

@@ -367,3 +367,47 @@ def test_process_batch_thin_and_odd_shapes(ctx, group):
         assert_batches_equal(gb, exp)
         nonempty += len(gb) > 0
     assert nonempty >= 6            # the shapes do cut the shells
+
+
+def test_process_batch_failure_in_the_middle(ctx):
+    """An output functor that fails at bucket 5 of 9 (lanes 4, groups of 2): the call reports the callback error, says that
+    the four buckets of the groups before it delivered everything (mlsgpu_hip_worker_batch_completed), has released every
+    lane's splats, and the worker goes on to process the same buckets correctly."""
+    import ctypes as C
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as mb, synth
+    cloud = synth.shells_cloud(60_000, 95.0, 16.0, 1.5, 2.5, seed=77)
+    allb, buckets = synth.bucketize(cloud, 96, 32)
+    some = [b for b in buckets if b.count > 0][:9]
+    assert len(some) == 9
+    w = m.Worker(ctx, max(b.count for b in buckets), max_cells=63)
+    w.set_batch(4)
+    w.set_marching_group(2)
+    buf = m.DeviceBuffer(ctx, array=allb)
+    arr = (mb.SubItem * len(some))()
+    for i, b in enumerate(some):
+        arr[i].firstSplat, arr[i].numSplats = b.first, b.count
+        for a in range(3):
+            arr[i].lowExtent[a] = int(b.low[a])
+            arr[i].numVertices[a] = int(b.num_vertices[a])
+    seen = []
+
+    def cb(user, index, stream, meshp):
+        seen.append(int(index))
+        return 1 if index == 5 else 0
+    fn = mb.BATCH_OUTPUT_FN(cb)
+    ctx.set_timing(True)
+    rc = m.lib().mlsgpu_hip_worker_process_batch(w.h, buf.ptr, arr, len(some), fn, None)
+    ctx.set_timing(False)
+    assert rc != 0
+    assert 5 in seen and max(seen) == 5
+    done = m.lib().mlsgpu_hip_worker_batch_completed(w.h)
+    assert done == 4                         # lanes 0-3 finished as groups (0,1) and (2,3); group (4,5) failed at 5
+    assert "device.compute" in ctx.stats()   # the timing region of the failed group was closed
+    # the worker is usable: the same buckets again, against the oracle
+    buf.upload(allb)
+    got = w.process_batch(buf, some)
+    ref = allb.copy()
+    for b, batches in zip(some, got):
+        exp, _ = _oracle_bucket(ref, b)
+        assert_batches_equal(batches, exp)
