@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--spare", type=int, default=1)
     ap.add_argument("--staging", type=int, default=0)
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--pin-gb", type=float, default=0.0, help="pinned host memory allocated (and kept) before the legs, as bench.py's landing buffers are")
+    ap.add_argument("--preload-s", type=float, default=0.0, help="seconds of resident-input passes on the GPU before the legs")
     a = ap.parse_args()
     import torch  # noqa: F401  (its HIP runtime first, see tests/conftest.py)
     node = gpu_node(0)
@@ -75,7 +77,24 @@ def main():
     host = synth.to_host_splats(sb_t)
     del sb_t
     torch.cuda.empty_cache()
-    res = {"gpu_node": node, "bound_to": bound, "copy_threads": a.copy_threads, "spare": a.spare, "staging": a.staging,
+    pins = []
+    if a.pin_gb > 0:
+        for _ in range(3):
+            pins.append(m.binding.PinnedBuffer(int(a.pin_gb * (1 << 30) / 3)))
+    if a.preload_s > 0:
+        import time
+        ctx = m.Context(0)
+        dbuf = m.DeviceBuffer(ctx, array=host)
+        w = m.Worker(ctx, smax, max_cells=scells, mesh_memory=4096 << 20)
+        w.set_keep_splats(True)
+        col = m.binding.SizeCollector()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < a.preload_s:
+            for b in sbuckets:
+                w.process(dbuf, b.first, b.count, b.low, b.num_vertices, collector=col)
+        ctx.synchronize()
+        del w, dbuf
+    res = {"gpu_node": node, "bound_to": bound, "pin_gb": a.pin_gb, "preload_s": a.preload_s, "copy_threads": a.copy_threads, "spare": a.spare, "staging": a.staging,
            "farm_workers": a.farm_workers, "runs": []}
     for _ in range(a.repeat):
         out = bench.transfer_legs(m, args, 0, host, sbuckets, smax, scells, svox, a.steps, with_sink=False)
