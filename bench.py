@@ -547,24 +547,12 @@ def main():
     # its own digest against its pin, the verdicts are gathered, and one mismatch anywhere fails the whole run
     digest_failure = None
     if W["name"] == "cfg4slab" and args.scale == 1.0 and CFG4SLAB_PINS is not None:
-        pin = CFG4SLAB_PINS.get(str(rank), {}).get(synth.slab_variant(world, rank))
-        mine_ok = pin is not None and digest == pin["digest"] and check.vertices == pin["vertices"] \
-            and check.triangles == pin["triangles"]
-        verdicts = [bool(mine_ok)]
-        digests = [digest]
-        if dist is not None:
-            d = torch.zeros((world, 3), dtype=torch.int64, device=reduce_device)
-            d[rank, 0], d[rank, 1], d[rank, 2] = int(mine_ok), int(digest[:8], 16), int(digest[8:], 16)
-            dist.all_reduce(d)
-            d = d.cpu().numpy()
-            verdicts = [bool(x) for x in d[:, 0]]
-            digests = ["%08x%08x" % (int(a), int(b)) for a, b in d[:, 1:3]]
-        expected = [CFG4SLAB_PINS.get(str(r), {}).get(synth.slab_variant(world, r), {}).get("digest") for r in range(world)]
-        result["output_digest"].update(expected=expected[0], ok=verdicts[0], per_rank_digest=digests, per_rank_expected=expected,
-                                       per_rank_ok=verdicts, all_ok=all(verdicts))
-        if not all(verdicts):
+        v = farm.slab_verdicts(CFG4SLAB_PINS, world, rank, digest, check.vertices, check.triangles, dist, reduce_device)
+        result["output_digest"].update(expected=v["expected"][0], ok=v["ok"][0], per_rank_digest=v["digests"],
+                                       per_rank_expected=v["expected"], per_rank_ok=v["ok"], all_ok=v["all_ok"])
+        if not v["all_ok"]:
             digest_failure = ("output digests %s of the ranks' slabs differ from the pinned %s (tests/golden/cfg4slab_uniform.json)"
-                              % (digests, expected))
+                              % (v["digests"], v["expected"]))
     if digest_failure is not None:
         if rank == 0:
             print("bench.py: " + digest_failure, file=sys.stderr, flush=True)

@@ -136,3 +136,24 @@ def bind_process_to_device_node(device, before_hip=False):
     os.sched_setaffinity(0, want)
     out.update(bound=True, cpus=len(want))
     return out
+
+
+def slab_verdicts(pins, world, rank, digest, vertices, triangles, dist=None, device=None):
+    """Every rank of the sharded cfg4 workload holds the digest of its slab's meshes against the pin of THAT slab (slab
+    `rank` as an inner slab, or as the job's last one: synth.slab_variant); the verdicts and digests are gathered, so that
+    rank 0 can report all of them and every rank knows whether ANY slab differed.  `pins`: the "slabs" table of
+    tests/golden/cfg4slab_uniform.json.  Returns dict(ok=[...], digests=[...], expected=[...], all_ok=bool)."""
+    from . import synth
+    pin = (pins or {}).get(str(rank), {}).get(synth.slab_variant(world, rank))
+    mine_ok = pin is not None and digest == pin["digest"] and vertices == pin["vertices"] and triangles == pin["triangles"]
+    ok, digests = [bool(mine_ok)], [digest]
+    if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
+        import torch
+        d = torch.zeros((world, 3), dtype=torch.int64, device=device)
+        d[rank, 0], d[rank, 1], d[rank, 2] = int(mine_ok), int(digest[:8], 16), int(digest[8:], 16)
+        dist.all_reduce(d)
+        d = d.cpu().numpy()
+        ok = [bool(x) for x in d[:, 0]]
+        digests = ["%08x%08x" % (int(a), int(b)) for a, b in d[:, 1:3]]
+    expected = [(pins or {}).get(str(r), {}).get(synth.slab_variant(world, r), {}).get("digest") for r in range(world)]
+    return dict(ok=ok, digests=digests, expected=expected, all_ok=all(ok))

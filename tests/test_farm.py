@@ -138,3 +138,56 @@ def test_shares():
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
     assert farm.combine(1.5, 10) == (1.5, 10, 1)
     assert farm.throughput(2_000_000, 2.0) == 1.0
+
+
+def _verdict_main(rank, world, port, out, wrong_rank):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import json
+        from mlsgpu_amd import farm, synth
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        pins = json.load(open(os.path.join(root, "tests", "golden", "cfg4slab_uniform.json")))["slabs"]
+        pin = pins[str(rank)][synth.slab_variant(world, rank)]
+        digest = pin["digest"] if rank != wrong_rank else "0123456789abcdef"
+        v = farm.slab_verdicts(pins, world, rank, digest, pin["vertices"], pin["triangles"], dist)
+        out.put((rank, v))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wrong_rank", [-1, 1])
+def test_every_rank_checks_its_own_slab(wrong_rank):
+    """bench.py --gpus N: rank r holds its digest against slab r's pin (inner slab, or the job's last), the verdicts are
+    gathered: every rank sees every rank's verdict, and one wrong slab anywhere fails the run on all of them."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_verdict_main, args=(r, 2, port, out, wrong_rank)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]                                     # the same picture on every rank
+    v = res[0]
+    assert v["ok"] == [True, wrong_rank != 1] and v["all_ok"] == (wrong_rank < 0)
+    assert v["expected"][0] != v["expected"][1] and None not in v["expected"]      # slab 0 inner, slab 1 as the last slab
+    assert v["digests"][0] == v["expected"][0]
+    assert (v["digests"][1] == v["expected"][1]) == (wrong_rank != 1)
+
+
+def test_slab_variants_cover_every_job_size():
+    """Every (slab, variant) an N = 1 / 2 / 4 / 8 job contains is pinned."""
+    import json
+    from mlsgpu_amd import synth
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pins = json.load(open(os.path.join(root, "tests", "golden", "cfg4slab_uniform.json")))["slabs"]
+    for world in (1, 2, 4, 8):
+        for rank in range(world):
+            pin = pins[str(rank)][synth.slab_variant(world, rank)]
+            assert len(pin["digest"]) == 16 and pin["triangles"] > 0 and pin["shipouts"] >= 25

@@ -112,3 +112,39 @@ def test_copy_pool_is_exact_at_every_thread_count():
     for threads in (1, 2, 3, 8):
         assert m.lib().mlsgpu_hip_test_copy_pool(threads, 60, 11 << 20, -1) == 0
     assert m.lib().mlsgpu_hip_test_copy_pool(4, 5, 0, -1) == 0
+
+
+BIND = r'''
+import json, os, sys
+sys.path.insert(0, %(root)r)
+from mlsgpu_amd import farm
+out = {"before": sorted(os.sched_getaffinity(0))}
+out["r0"] = farm.bind_process_to_device_node(0, before_hip=True)
+out["after0"] = sorted(os.sched_getaffinity(0))
+os.sched_setaffinity(0, out["before"])
+out["r5"] = farm.bind_process_to_device_node(5, before_hip=True)
+out["after5"] = sorted(os.sched_getaffinity(0))
+os.sched_setaffinity(0, out["before"])
+out["r8"] = farm.bind_process_to_device_node(8, before_hip=True)      # no such GPU in the table: left alone
+out["after8"] = sorted(os.sched_getaffinity(0))
+print(json.dumps(out))
+'''
+
+
+def test_rank_binds_itself_to_its_gpus_socket(tmp_path):
+    """bench.py's ranks: rank r (GPU r) ends up on the CPUs of the node GPU r hangs off -- GPUs 0-3 on node 0, 4-7 on node 1
+    of the fake machine -- before HIP is touched; an unknown GPU leaves the process where it was."""
+    avail = sorted(os.sched_getaffinity(0))
+    if len(avail) < 4:
+        import pytest
+        pytest.skip("needs four CPUs")
+    a, b = avail[:2], avail[2:4]
+    for node, cpus in ((0, a), (1, b)):
+        d = tmp_path / "devices" / "system" / "node" / ("node%d" % node)
+        d.mkdir(parents=True)
+        (d / "cpulist").write_text(",".join(str(c) for c in cpus) + "\n")
+    env = dict(os.environ, MLSGPU_HIP_SYSFS_ROOT=str(tmp_path), MLSGPU_HIP_DEVICE_NODES="0,0,0,0,1,1,1,1")
+    out = json.loads(subprocess.check_output([sys.executable, "-c", BIND % dict(root=ROOT)], env=env).decode().strip().splitlines()[-1])
+    assert out["r0"]["bound"] and out["r0"]["gpu_node"] == 0 and out["r0"]["numa_nodes"] == 2 and out["after0"] == a
+    assert out["r5"]["bound"] and out["r5"]["gpu_node"] == 1 and out["after5"] == b and out["r5"]["cpus"] == 2
+    assert not out["r8"]["bound"] and out["after8"] == out["before"]
