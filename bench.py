@@ -71,6 +71,8 @@ def parse_args():
                         "BASELINE configs[4], 2048^3 grid, 10^9 splats read from PLY files (written to --cfg5-dir first)")
     p.add_argument("--cfg5-dir", default="/dev/shm", help="where cfg5's PLY files are written (28 GB at scale 1)")
     p.add_argument("--cfg5-files", type=int, default=8)
+    p.add_argument("--cfg5-spare", type=int, default=1, help="device items beyond one per worker in cfg5's farm")
+    p.add_argument("--cfg5-batch", type=int, default=1, help="buckets per launch set in cfg5's farm")
     p.add_argument("--dist", default="uniform", choices=["uniform", "shells"])
     p.add_argument("--scale", type=float, default=1.0, help="splat-count scale (debug only; 1.0 = BASELINE size)")
     p.add_argument("--mesh-memory-mb", type=int, default=4096, help="Marching mesh arena per worker")

@@ -78,8 +78,10 @@ def run_cfg5(args, rank, world, local_rank, device, dist, reduce_device):
     voxels = sum(farm.leaf_cells(leaves[i]) for i in mine)
     pmax = max(l["num_splats"] for l in leaves)
     pcells = max(max(l["extents"][2 * a + 1] - l["extents"][2 * a] for a in range(3)) for l in leaves)
-    bfarm = m.BucketFarm([local_rank], pmax, workers_per_device=nworkers, spare=1, max_cells=pcells,
+    bfarm = m.BucketFarm([local_rank], pmax, workers_per_device=nworkers, spare=max(1, args.cfg5_spare), max_cells=pcells,
                          mesh_memory=args.mesh_memory_mb << 20, collect="checksum")
+    if args.cfg5_batch > 1:
+        bfarm.set_batch(args.cfg5_batch)
 
     def resident_pass():
         farm.partition_to_farm(ctx, bfarm, local_rank, raw, n, ref0, 1.0, ext, CFG5_PARTITION,

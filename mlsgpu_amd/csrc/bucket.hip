@@ -44,16 +44,67 @@ struct RegionView
     float invSpacing;
     int32_t first[3];           /* grid extents' lower ends (the grid being split, not the chunk) */
     uint32_t microSize;
+    uint32_t divMagic, divShift;    /* x / microSize == (uint64_t) x * divMagic >> divShift for every x < 2^31 (setMicroSize) */
     int32_t bias[3];            /* chunk coordinate * chunkRatio, in microblocks */
     uint32_t dims[3];           /* microblocks of this chunk's region */
+    const uint2 *notes = nullptr;   /* element i's microblock range as the counting pass packed it (packNote), or nullptr */
 
     __device__ __forceinline__ uint32_t splatId(uint64_t i) const { return ids ? ids[i] : (uint32_t) i; }
+
+    /* Division by an invariant (Granlund & Montgomery): with L = ceil(log2 m) and M = ceil(2^(31 + L) / m) < 2^32,
+     * M * m - 2^(31 + L) < m <= 2^L, which makes floor(x * M / 2^(31 + L)) the exact quotient for x < 2^31. */
+    void setMicroSize(uint32_t m)
+    {
+        microSize = m;
+        uint32_t L = 0;
+        while (((uint64_t) 1 << L) < m)
+            L++;
+        divShift = 31 + L;
+        divMagic = (uint32_t) ((((uint64_t) 1 << divShift) + m - 1) / m);
+    }
+    __device__ __forceinline__ uint32_t divMicro(uint32_t x) const { return (uint32_t) (((uint64_t) x * divMagic) >> divShift); }
+
+    /* The counting pass reads every splat (32 B) and works its range out with six floor divisions; the two passes behind it
+     * (how many regions does element i join; which) need the range only, so it is kept: 8 B per element, valid in bit 63,
+     * lo in 16 bits and hi - lo in 5 bits per axis.  A range that does not fit is marked and worked out again. */
+    static __device__ __forceinline__ uint2 packNote(bool ok, const uint32_t lo[3], const uint32_t hi[3])
+    {
+        if (!ok)
+            return make_uint2(0u, 0u);
+        const uint32_t s0 = hi[0] - lo[0], s1 = hi[1] - lo[1], s2 = hi[2] - lo[2];
+        if ((lo[0] | lo[1] | lo[2]) > 0xFFFFu || (s0 | s1 | s2) > 31u)
+            return make_uint2(0u, 0xFFFFFFFFu);
+        return make_uint2(lo[0] | lo[1] << 16, lo[2] | s0 << 16 | s1 << 21 | s2 << 26 | 0x80000000u);
+    }
+    __device__ __forceinline__ bool rangeAt(uint64_t i, uint32_t lo[3], uint32_t hi[3]) const
+    {
+        if (notes != nullptr)
+        {
+            const uint2 w = notes[i];
+            if (w.y != 0xFFFFFFFFu)
+            {
+                if (!(w.y >> 31))
+                    return false;
+                lo[0] = w.x & 0xFFFFu;
+                lo[1] = w.x >> 16;
+                lo[2] = w.y & 0xFFFFu;
+                hi[0] = lo[0] + ((w.y >> 16) & 31u);
+                hi[1] = lo[1] + ((w.y >> 21) & 31u);
+                hi[2] = lo[2] + ((w.y >> 26) & 31u);
+                return true;
+            }
+        }
+        return range(splatId(i), lo, hi);
+    }
 
     /* splatToBuckets (src/splat_set.cpp:52-72, Grid::worldToCell src/grid.cpp:108-129) + BucketStateSet's chunk
      * bias (bucket_impl.h:318-323) + BucketState::clamp (src/bucket.cpp:176-194) */
     __device__ __forceinline__ bool range(uint32_t id, uint32_t lo[3], uint32_t hi[3]) const
     {
-        const mlsgpu_splat s = splats[id];
+        return rangeOf(splats[id], lo, hi);
+    }
+    __device__ __forceinline__ bool rangeOf(const mlsgpu_splat s, uint32_t lo[3], uint32_t hi[3]) const
+    {
         /* 32-bit cell arithmetic is exact when the grid's lower ends and the microblock size leave room */
         const bool narrow = microSize <= (1u << 27) && abs(first[0]) < (1 << 29) && abs(first[1]) < (1 << 29) && abs(first[2]) < (1 << 29);
         if (!(isfinite(s.position[0]) && isfinite(s.position[1]) && isfinite(s.position[2]) && isfinite(s.radius)
@@ -70,9 +121,9 @@ struct RegionView
                 /* the same floor division in 32 bits (|cell - first| < 2^31): a 64-bit division is ~150 instructions, six
                  * of them per splat made the three passes over the cloud compute-bound */
                 const int32_t cl = (int32_t) fl - first[a], ch = (int32_t) fh - first[a];
-                const int32_t m = (int32_t) microSize;
-                l = (long long) (cl >= 0 ? cl / m : -((-cl + m - 1) / m)) - bias[a];
-                h = (long long) (ch >= 0 ? ch / m : -((-ch + m - 1) / m)) - bias[a];
+                const uint32_t m = microSize;       /* |cl|, |ch| < 2^30 + 2^29 and m <= 2^27: every dividend below 2^31 */
+                l = (long long) (cl >= 0 ? (int32_t) divMicro((uint32_t) cl) : -(int32_t) divMicro((uint32_t) -cl + m - 1)) - bias[a];
+                h = (long long) (ch >= 0 ? (int32_t) divMicro((uint32_t) ch) : -(int32_t) divMicro((uint32_t) -ch + m - 1)) - bias[a];
             }
             else
             {
@@ -104,7 +155,8 @@ struct LevelLayout
  * Levels >= ldsFrom (the coarse ones: few nodes, every splat of the cloud lands on them -- 10^9 atomic adds on ONE word for
  * the root of BASELINE configs[4]) are counted in LDS and flushed once per workgroup; the finer levels below, whose nodes
  * do not fit, take one global atomic per (splat, node), spread over tens of thousands of words. */
-__global__ __launch_bounds__(256) void bucketCountKernel(RegionView V, LevelLayout L, uint32_t *counts, uint64_t n, uint32_t ldsFrom)
+__global__ __launch_bounds__(256) void bucketCountKernel(RegionView V, LevelLayout L, uint32_t *counts, uint64_t n, uint32_t ldsFrom,
+                                                         uint2 *notesOut)
 {
     __shared__ uint32_t local[LDS_NODES];
     const uint32_t total = L.offset[L.levels];
@@ -115,7 +167,10 @@ __global__ __launch_bounds__(256) void bucketCountKernel(RegionView V, LevelLayo
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
     {
         uint32_t lo[3], hi[3];
-        if (!V.range(V.splatId(i), lo, hi))
+        const bool ok = V.range(V.splatId(i), lo, hi);
+        if (notesOut != nullptr)
+            notesOut[i] = RegionView::packNote(ok, lo, hi);
+        if (!ok)
             continue;
         for (uint32_t l = 0; l < L.levels; l++)
         {
@@ -138,6 +193,211 @@ __global__ __launch_bounds__(256) void bucketCountKernel(RegionView V, LevelLayo
             atomicAdd(&counts[ldsBase + i], local[i]);
 }
 
+/*
+ * The same counters for a big cloud whose finest level does not fit the LDS table above: 10^9 splats in random order make
+ * 1.25 * 10^9 scattered global atomic adds on the finest level alone, and scattered atomics execute at the memory side, one
+ * 64-B request each (~18 * 10^9 / s: 56 ms for BASELINE configs[4]).  Here no counter leaves the workgroup before the end:
+ *   - a workgroup takes a SPAN of at most 65535 consecutive elements, so a finest-level counter (at most one add per
+ *     element) fits 16 bits: two counters per LDS word, 35 937 microblocks in 72 KB;
+ *   - the coarser levels are not counted at all but CORRECTED, as the reference's delta-encoded counters are
+ *     (src/bucket.cpp:207-246): the sum of a node's children counts a splat once per child it touches, so the node keeps
+ *     sum(children touched - 1) over its splats, and count = sum of the children's counts - that.  Only a splat that
+ *     straddles a boundary of the level below adds anything (2-3 cell radii against 63-cell microblocks: one in five at
+ *     the first coarser level, almost none above), where the plain count takes one LDS add per level, all lanes on the
+ *     same few words at the top;
+ *   - the workgroup's LDS image goes out as one slice (coalesced stores, 1.5 B per element); bucketSliceSumKernel adds the
+ *     slices up and bucketUpsweepKernel turns corrections into counts, level by level.
+ * The counters are the same integers whichever way they are added up.
+ */
+enum { PRIV_THREADS = 1024, PRIV_SPAN = 63 * PRIV_THREADS, PRIV_LDS_BYTES = 160 * 1024 };
+
+__global__ __launch_bounds__(PRIV_THREADS) void bucketCountPrivateKernel(RegionView V, LevelLayout L, uint32_t *slices, uint64_t n,
+                                                                         uint2 *notesOut, uint32_t words0, uint32_t imageWords)
+{
+    extern __shared__ uint32_t image[];     /* [words0] finest level, 16 bits a counter; then the corrections of levels 1.. */
+    for (uint32_t i = threadIdx.x; i < imageWords; i += PRIV_THREADS)
+        image[i] = 0;
+    __syncthreads();
+    const uint32_t n0 = L.offset[1];        /* levels >= 2 on this path */
+    const uint64_t first = (uint64_t) blockIdx.x * PRIV_SPAN;
+    const uint64_t last = first + PRIV_SPAN < n ? first + PRIV_SPAN : n;
+    /* the next round's splat is requested before this round's is looked at: 16 waves a CU, two 32-B loads a lane in flight */
+    mlsgpu_splat cur = {}, next = {};
+    if (first + threadIdx.x < last)
+        cur = V.splats[V.splatId(first + threadIdx.x)];
+    for (uint64_t i = first + threadIdx.x; i < last; i += PRIV_THREADS, cur = next)
+    {
+        if (i + PRIV_THREADS < last)
+            next = V.splats[V.splatId(i + PRIV_THREADS)];
+        uint32_t lo[3], hi[3];
+        const bool ok = V.rangeOf(cur, lo, hi);
+        if (notesOut != nullptr)
+            notesOut[i] = RegionView::packNote(ok, lo, hi);
+        if (!ok)
+            continue;
+        const uint32_t sx = hi[0] - lo[0], sy = hi[1] - lo[1], sz = hi[2] - lo[2];
+        if ((sx | sy | sz) <= 1u)
+        {
+            /* at most two nodes per axis, at every level: no loops over nodes, whose trip counts differ from lane to lane
+             * (one lane in five straddles a microblock boundary -- some lane of nearly every wave does, at most levels) */
+            uint32_t dx = L.dims[0][0], dxy = dx * L.dims[0][1];
+            uint32_t base = (lo[2] * L.dims[0][1] + lo[1]) * dx + lo[0];
+#pragma unroll
+            for (uint32_t c = 0; c < 8; c++)
+                if ((c & 1u) <= sx && ((c >> 1) & 1u) <= sy && (c >> 2) <= sz)
+                {
+                    const uint32_t node = base + (c & 1u) + ((c >> 1) & 1u) * dx + (c >> 2) * dxy;
+                    atomicAdd(&image[node >> 1], 1u << ((node & 1u) * 16u));
+                }
+            /* two children along an axis either share their parent (it keeps a correction, and the splat is one node wide
+             * from there up) or not (nothing to correct along this axis yet: two nodes wide at the next level too); every
+             * parent in the range sees the same number of children, so they all take the same correction */
+            uint32_t cx = lo[0], cy = lo[1], cz = lo[2];
+            uint32_t tx = sx, ty = sy, tz = sz;
+            for (uint32_t l = 1; l < L.levels && (tx | ty | tz) != 0; l++)
+            {
+                const uint32_t px = tx & cx, py = ty & cy, pz = tz & cz;        /* 1: the two children have different parents */
+                const uint32_t extra = (1u + (tx & ~px)) * (1u + (ty & ~py)) * (1u + (tz & ~pz)) - 1u;
+                cx >>= 1;
+                cy >>= 1;
+                cz >>= 1;
+                if (extra != 0)
+                {
+                    dx = L.dims[l][0];
+                    dxy = dx * L.dims[l][1];
+                    base = words0 + (L.offset[l] - n0) + (cz * L.dims[l][1] + cy) * dx + cx;
+#pragma unroll
+                    for (uint32_t c = 0; c < 8; c++)
+                        if ((c & 1u) <= px && ((c >> 1) & 1u) <= py && (c >> 2) <= pz)
+                            atomicAdd(&image[base + (c & 1u) + ((c >> 1) & 1u) * dx + (c >> 2) * dxy], extra);
+                }
+                tx = px;
+                ty = py;
+                tz = pz;
+            }
+            continue;
+        }
+        {
+            const uint32_t dx = L.dims[0][0], dy = L.dims[0][1];
+            for (uint32_t z = lo[2]; z <= hi[2]; z++)
+                for (uint32_t y = lo[1]; y <= hi[1]; y++)
+                    for (uint32_t x = lo[0]; x <= hi[0]; x++)
+                    {
+                        const uint32_t node = (z * dy + y) * dx + x;
+                        atomicAdd(&image[node >> 1], 1u << ((node & 1u) * 16u));
+                    }
+        }
+        for (uint32_t l = 1; l < L.levels; l++)
+        {
+            const uint32_t s = l - 1;
+            const uint32_t cl[3] = {lo[0] >> s, lo[1] >> s, lo[2] >> s}, ch[3] = {hi[0] >> s, hi[1] >> s, hi[2] >> s};
+            if (cl[0] == ch[0] && cl[1] == ch[1] && cl[2] == ch[2])
+                break;          /* one node at the level below: one node from here up, nothing to correct */
+            const uint32_t dx = L.dims[l][0], dy = L.dims[l][1];
+            for (uint32_t z = cl[2] >> 1; z <= (ch[2] >> 1); z++)
+                for (uint32_t y = cl[1] >> 1; y <= (ch[1] >> 1); y++)
+                    for (uint32_t x = cl[0] >> 1; x <= (ch[0] >> 1); x++)
+                    {
+                        const uint32_t kx = min(ch[0], 2 * x + 1) - max(cl[0], 2 * x) + 1;
+                        const uint32_t ky = min(ch[1], 2 * y + 1) - max(cl[1], 2 * y) + 1;
+                        const uint32_t kz = min(ch[2], 2 * z + 1) - max(cl[2], 2 * z) + 1;
+                        const uint32_t extra = kx * ky * kz - 1;
+                        if (extra != 0)
+                            atomicAdd(&image[words0 + (L.offset[l] - n0) + (z * dy + y) * dx + x], extra);
+                    }
+        }
+    }
+    __syncthreads();
+    uint32_t *const out = slices + (uint64_t) blockIdx.x * imageWords;
+    for (uint32_t i = threadIdx.x; i < imageWords; i += PRIV_THREADS)
+        out[i] = image[i];
+}
+
+/* counts[finest level] and the corrections of the levels above it, summed over the slices: a workgroup takes 256 words of
+ * SLICE_GROUP slices and adds its sums to the counters (consecutive words: coalesced atomics) */
+enum { SLICE_GROUP = 64 };
+__global__ __launch_bounds__(256) void bucketSliceSumKernel(const uint32_t *slices, uint32_t numSlices, uint32_t words0, uint32_t imageWords,
+                                                            uint32_t n0, uint32_t *counts)
+{
+    const uint32_t w = blockIdx.x * 256 + threadIdx.x;
+    if (w >= imageWords)
+        return;
+    const uint32_t s0 = blockIdx.y * SLICE_GROUP, s1 = min(numSlices, s0 + SLICE_GROUP);
+    uint32_t a = 0, b = 0;
+    if (w < words0)
+    {
+        for (uint32_t s = s0; s < s1; s++)
+        {
+            const uint32_t v = slices[(uint64_t) s * imageWords + w];
+            a += v & 0xFFFFu;
+            b += v >> 16;
+        }
+        if (a != 0)
+            atomicAdd(&counts[2 * w], a);
+        if (b != 0 && 2 * w + 1 < n0)
+            atomicAdd(&counts[2 * w + 1], b);
+    }
+    else
+    {
+        for (uint32_t s = s0; s < s1; s++)
+            a += slices[(uint64_t) s * imageWords + w];
+        if (a != 0)
+            atomicAdd(&counts[n0 + (w - words0)], a);
+    }
+}
+
+/* one workgroup: count = sum of the children's counts - the node's correction, coarser level by coarser level */
+__global__ __launch_bounds__(1024) void bucketUpsweepKernel(LevelLayout L, uint32_t *counts)
+{
+    for (uint32_t l = 1; l < L.levels; l++)
+    {
+        const uint32_t dx = L.dims[l][0], dy = L.dims[l][1], dz = L.dims[l][2];
+        const uint32_t cx = L.dims[l - 1][0], cy = L.dims[l - 1][1], cz = L.dims[l - 1][2];
+        const uint32_t *const below = counts + L.offset[l - 1];
+        uint32_t *const here = counts + L.offset[l];
+        for (uint32_t node = threadIdx.x; node < dx * dy * dz; node += blockDim.x)
+        {
+            const uint32_t x = node % dx, y = node / dx % dy, z = node / (dx * dy);
+            uint32_t sum = 0;
+            for (uint32_t k = 0; k < 8; k++)
+            {
+                const uint32_t X = 2 * x + (k & 1u), Y = 2 * y + ((k >> 1) & 1u), Z = 2 * z + (k >> 2);
+                if (X < cx && Y < cy && Z < cz)
+                    sum += below[(Z * cy + Y) * cx + X];
+            }
+            here[node] = sum - here[node];
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
+/* the table entries of the (at most) 2 x 2 x 2 microblocks of a range: candidate c = bit 0 x, bit 1 y, bit 2 z */
+__device__ __forceinline__ void corner8(const RegionView &V, const uint32_t *table, const uint32_t lo[3], const uint32_t hi[3],
+                                        uint32_t t[8])
+{
+    const uint32_t base = (lo[2] * V.dims[1] + lo[1]) * V.dims[0] + lo[0];
+    const uint32_t sx = hi[0] - lo[0], sy = hi[1] - lo[1], sz = hi[2] - lo[2];
+#pragma unroll
+    for (uint32_t c = 0; c < 8; c++)
+    {
+        const bool need = ((c & 1u) <= sx) && (((c >> 1) & 1u) <= sy) && ((c >> 2) <= sz);
+        const uint32_t at = base + (c & 1u) + ((c >> 1) & 1u) * V.dims[0] + (c >> 2) * V.dims[0] * V.dims[1];
+        t[c] = table[need ? at : 0u];
+    }
+}
+/* does the splat join candidate c's region THROUGH candidate c (a region is joined once: through its first microblock in
+ * the range along every axis, src/bucket.cpp:291-301)? */
+__device__ __forceinline__ bool joins8(uint32_t c, uint32_t t, const uint32_t lo[3], const uint32_t hi[3], uint32_t rFirst, uint32_t rEnd)
+{
+    const uint32_t cx = c & 1u, cy = (c >> 1) & 1u, cz = c >> 2;
+    if (cx > hi[0] - lo[0] || cy > hi[1] - lo[1] || cz > hi[2] - lo[2])
+        return false;
+    const uint32_t mask = (1u << (t & 31u)) - 1;
+    return (t >> 5) - rFirst < rEnd - rFirst
+        && (cx == 0 || ((lo[0] + 1) & mask) == 0) && (cy == 0 || ((lo[1] + 1) & mask) == 0) && (cz == 0 || ((lo[2] + 1) & mask) == 0);
+}
+
 /* bucketSplats, src/bucket.cpp:271-302: table[microblock] = region id << 5 | node level */
 struct RegionCountIn
 {
@@ -147,9 +407,21 @@ struct RegionCountIn
     __device__ __forceinline__ uint32_t operator()(uint64_t i) const
     {
         uint32_t lo[3], hi[3];
-        if (!V.range(V.splatId(i), lo, hi))
+        if (!V.rangeAt(i, lo, hi))
             return 0;
         uint32_t k = 0;
+        if (((hi[0] - lo[0]) | (hi[1] - lo[1]) | (hi[2] - lo[2])) <= 1u)
+        {
+            /* at most two microblocks per axis (a splat is small against a microblock): the eight candidates' entries are
+             * requested together -- one memory latency, where the loop below waits for each entry in turn.  A candidate
+             * outside the range reads entry 0 instead (one cache line for all such lanes) and is not counted. */
+            uint32_t t[8];
+            corner8(V, table, lo, hi, t);
+#pragma unroll
+            for (uint32_t c = 0; c < 8; c++)
+                k += joins8(c, t[c], lo, hi, rFirst, rEnd) ? 1u : 0u;
+            return k;
+        }
         for (uint32_t x = lo[0]; x <= hi[0]; x++)
             for (uint32_t y = lo[1]; y <= hi[1]; y++)
                 for (uint32_t z = lo[2]; z <= hi[2]; z++)
@@ -176,7 +448,24 @@ struct RegionEmitOut
             return;
         const uint32_t id = V.splatId(i);
         uint32_t lo[3], hi[3];
-        V.range(id, lo, hi);
+        V.rangeAt(i, lo, hi);
+        if (((hi[0] - lo[0]) | (hi[1] - lo[1]) | (hi[2] - lo[2])) <= 1u)
+        {
+            uint32_t t[8];
+            corner8(V, table, lo, hi, t);
+#pragma unroll
+            for (uint32_t j = 0; j < 8; j++)
+            {
+                const uint32_t c = (j & 1u) << 2 | (j & 2u) | (j & 4u) >> 2;       /* x outermost, z innermost, as the loop below */
+                if (joins8(c, t[c], lo, hi, rFirst, rEnd))
+                {
+                    keys[excl] = (t[c] >> 5) - rFirst;
+                    vals[excl] = id;
+                    excl++;
+                }
+            }
+            return;
+        }
         for (uint32_t x = lo[0]; x <= hi[0]; x++)
             for (uint32_t y = lo[1]; y <= hi[1]; y++)
                 for (uint32_t z = lo[2]; z <= hi[2]; z++)
@@ -295,6 +584,20 @@ __global__ __launch_bounds__(256) void bboxKernel(const mlsgpu_splat *splats, ui
     }
 }
 
+/* levels with fewer elements than this go the plain way (tuning / test aids: MLSGPU_HIP_BUCKET_NOTES_FROM,
+ * MLSGPU_HIP_BUCKET_PRIVATE_FROM; 0 switches a path on for every level, "off" switches it off) */
+uint64_t thresholdFromEnv(const char *name, uint64_t deflt)
+{
+    const char *e = getenv(name);
+    if (e == nullptr || *e == '\0')
+        return deflt;
+    if (strcmp(e, "off") == 0)
+        return UINT64_MAX;
+    return strtoull(e, nullptr, 10);
+}
+uint64_t notesFrom() { return thresholdFromEnv("MLSGPU_HIP_BUCKET_NOTES_FROM", 1u << 20); }
+uint64_t privateFrom() { return thresholdFromEnv("MLSGPU_HIP_BUCKET_PRIVATE_FROM", 4u << 20); }
+
 uint32_t bitsForCount(uint32_t count)
 {
     uint32_t b = 1;
@@ -348,12 +651,18 @@ struct DepthBuffers
     uint32_t *total = nullptr;
     uint32_t *scanSums = nullptr;
     uint64_t scanCap = 0;
+    uint2 *notes = nullptr;             /* RegionView::packNote of every element of the level being split */
+    uint64_t noteCap = 0;
+    uint32_t *slices = nullptr;         /* bucketCountPrivateKernel's per-workgroup counters */
+    uint64_t sliceCap = 0;
     /* events of callbacks that still read member lists of this level (mlsgpu_bucket::consumed): whatever overwrites the
      * level's buffers is ordered behind them on the GPU */
     std::vector<hipEvent_t> readers;
     ~DepthBuffers()
     {
         hipFree(scanSums);
+        hipFree(notes);
+        hipFree(slices);
         hipFree(keysA); hipFree(valsA); hipFree(keysB); hipFree(valsB); hipFree(hist); hipFree(tileSums);
         hipFree(counts); hipFree(table); hipFree(starts); hipFree(total);
     }
@@ -491,7 +800,7 @@ int Bucketer::recurse(const uint32_t *dIds, uint64_t n, bool isSubset, const Gri
                 V.splats = dSplats;
                 V.ids = dIds;
                 V.invSpacing = 1.0f / full.spacing;
-                V.microSize = microSize;
+                V.setMicroSize(microSize);
                 LevelLayout L;
                 L.levels = macroLevels;
                 for (int i = 0; i < 3; i++)
@@ -535,7 +844,53 @@ int Bucketer::recurse(const uint32_t *dIds, uint64_t n, bool isSubset, const Gri
                     uint32_t ldsFrom = L.levels;
                     while (ldsFrom > 0 && totalNodes - L.offset[ldsFrom - 1] <= LDS_NODES)
                         ldsFrom--;
-                    LAUNCH(ctx, "bucket.count.time", bucketCountKernel, dim3(blocks), dim3(256), V, L, B.counts, n, ldsFrom);
+                    /* what the passes behind the count need of an element, kept by the count (RegionView::packNote) */
+                    uint2 *notes = nullptr;
+                    if (n >= notesFrom() && std::max(std::max(V.dims[0], V.dims[1]), V.dims[2]) <= 65536u)
+                    {
+                        if (B.noteCap < n)
+                        {
+                            hipFree(B.notes);
+                            B.notes = nullptr;
+                            B.noteCap = 0;
+                            if (hipMalloc((void **) &B.notes, n * sizeof(uint2)) == hipSuccess)
+                                B.noteCap = n;
+                            else
+                                (void) hipGetLastError();       /* without them the passes read the splats again */
+                        }
+                        notes = B.notes;
+                    }
+                    /* private counters (bucketCountPrivateKernel): a big level whose finest counters miss the LDS table */
+                    const uint32_t words0 = (n0 + 1) / 2, imageWords = words0 + (uint32_t) (totalNodes - n0);
+                    const uint64_t numSlices = divUp(n, (uint64_t) PRIV_SPAN);
+                    bool privateCounters = (ldsFrom > 0 || privateFrom() == 0) && macroLevels >= 2 && n >= privateFrom()
+                        && (uint64_t) imageWords * 4 <= PRIV_LDS_BYTES && numSlices < (1u << 24);
+                    if (privateCounters && B.sliceCap < numSlices * imageWords)
+                    {
+                        hipFree(B.slices);
+                        B.slices = nullptr;
+                        B.sliceCap = 0;
+                        if (hipMalloc((void **) &B.slices, numSlices * imageWords * 4) == hipSuccess)
+                            B.sliceCap = numSlices * imageWords;
+                        else
+                        {
+                            (void) hipGetLastError();
+                            privateCounters = false;
+                        }
+                    }
+                    if (privateCounters)
+                    {
+                        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(bucketCountPrivateKernel),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, PRIV_LDS_BYTES));
+                        LAUNCH_LDS(ctx, "bucket.count.time", bucketCountPrivateKernel, dim3((uint32_t) numSlices), dim3(PRIV_THREADS),
+                                   imageWords * 4, V, L, B.slices, n, notes, words0, imageWords);
+                        LAUNCH(ctx, "bucket.count.time", bucketSliceSumKernel, dim3(divUp(imageWords, 256), (uint32_t) divUp(numSlices, (uint64_t) SLICE_GROUP)),
+                               dim3(256), (const uint32_t *) B.slices, (uint32_t) numSlices, words0, imageWords, n0, B.counts);
+                        LAUNCH(ctx, "bucket.count.time", bucketUpsweepKernel, dim3(1), dim3(1024), L, B.counts);
+                    }
+                    else
+                        LAUNCH(ctx, "bucket.count.time", bucketCountKernel, dim3(blocks), dim3(256), V, L, B.counts, n, ldsFrom, notes);
+                    V.notes = notes;
                 }
                 std::vector<uint32_t> counts(totalNodes);
                 HIP_CHECK(hipMemcpyAsync(counts.data(), B.counts, totalNodes * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -803,7 +1158,7 @@ int Bucketer::recurseStream(mlsgpu_fileset *files, uint64_t n, const GridBox &gr
                 V.splats = dChunk;
                 V.ids = nullptr;
                 V.invSpacing = 1.0f / full.spacing;
-                V.microSize = microSize;
+                V.setMicroSize(microSize);
                 LevelLayout L;
                 L.levels = macroLevels;
                 for (int i = 0; i < 3; i++)
@@ -842,7 +1197,7 @@ int Bucketer::recurseStream(mlsgpu_fileset *files, uint64_t n, const GridBox &gr
                 PROPAGATE(forEachFileChunk(nullptr, [&](uint64_t cnt) -> int
                 {
                     const uint32_t blocks = (uint32_t) std::min<uint64_t>(divUp(cnt, 256), 4096);
-                    LAUNCH(ctx, "bucket.count.time", bucketCountKernel, dim3(blocks), dim3(256), V, L, B.counts, cnt, ldsFrom);
+                    LAUNCH(ctx, "bucket.count.time", bucketCountKernel, dim3(blocks), dim3(256), V, L, B.counts, cnt, ldsFrom, (uint2 *) nullptr);
                     /* the next load overwrites the chunk buffer on another stream-ordered path: finish first */
                     HIP_CHECK(hipStreamSynchronize(ctx->stream));
                     return MLSGPU_OK;

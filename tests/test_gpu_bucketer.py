@@ -66,6 +66,33 @@ def test_random(seed):
         validate_partition(splats, grid, got, p["max_splats"], p["max_cells"], 0, strict=seed % 4 != 3)
 
 
+@pytest.mark.parametrize("seed", range(0, 30, 3))
+@pytest.mark.parametrize("private", ["0", "off"])
+def test_random_with_kept_ranges_and_private_counters(seed, private, monkeypatch):
+    """The paths big levels take -- the count keeps every element's microblock range for the member-list passes, and counts
+    in per-workgroup LDS counters with corrections for the coarser levels -- forced onto small cases: same leaves."""
+    monkeypatch.setenv("MLSGPU_HIP_BUCKET_NOTES_FROM", "0")
+    monkeypatch.setenv("MLSGPU_HIP_BUCKET_PRIVATE_FROM", private)
+    splats, grid, p = random_case(seed)
+    both(splats, grid, p["max_splats"], p["max_cells"], p["chunk_cells"], p["micro_cells"], p["max_split"])
+    both(create_splats(), GRID, 5, 8, 0, 8, 1000000)
+    both(create_splats(), GRID, 5, 8, 0, 0, 64)
+    both(create_splats(), GRID, 20, 2 ** 31 - 1, 14, 8, 1000000)
+
+
+def test_big_level_takes_the_private_counters():
+    """5 * 10^6 splats whose finest counters (24^3 microblocks) miss the shared LDS table: the level is counted in
+    per-workgroup counters (several spans per node, every coarser level corrected) -- leaves identical to the oracle's."""
+    from conftest import record_size
+    from mlsgpu_amd import synth
+    n, g = 5_000_000, 1500
+    splats = synth.uniform_cloud(n, float(g - 1), 2.0, 3.0, 77)
+    grid = {"reference": (0.0, 0.0, 0.0), "spacing": 1.0, "extents": (0, g - 1, 0, g - 1, 0, g - 1)}
+    got, exp = both(splats, grid, 200_000, 255, 0, 63, 1 << 30)
+    record_size("private-counter bucketing", "%d splats, %d leaves" % (n, len(got)))
+    assert len(got) > 100
+
+
 def test_rejects_an_empty_region():
     import mlsgpu_amd as m
     from mlsgpu_amd import binding as b
