@@ -645,7 +645,7 @@ struct DepthBuffers
 {
     uint32_t *keysA = nullptr, *valsA = nullptr, *keysB = nullptr, *valsB = nullptr;
     uint32_t *hist = nullptr, *tileSums = nullptr;
-    uint64_t pairCap = 0;
+    uint64_t pairCap = 0, keysBCap = 0;
     uint32_t *counts = nullptr, *table = nullptr, *starts = nullptr;
     uint32_t nodeCap = 0, regionCap = 0;
     uint32_t *total = nullptr;
@@ -935,20 +935,24 @@ int Bucketer::recurse(const uint32_t *dIds, uint64_t n, bool isSubset, const Gri
                 if (regions.empty())
                     continue;
                 const uint32_t numRegions = (uint32_t) regions.size();
+                /* a region's counter is the number of splats that join it -- the length of its member list: the lists' starts
+                 * and the level's pair total are known here, without a word from the device.  The (region, id) pairs are
+                 * counted by a 32-bit scan and addressed by 32-bit positions (10^9 uniform splats in 252-cell regions:
+                 * 1.06 * 10^9) */
+                std::vector<uint32_t> starts(numRegions + 1, 0);
                 {
-                    /* a region's counter is the number of splats that join it: the level's (region, id) pairs are counted by
-                     * a 32-bit scan and addressed by 32-bit positions (10^9 uniform splats in 252-cell regions: 1.06 * 10^9) */
                     uint64_t pairs = 0;
-                    for (const Region &r : regions)
-                        pairs += counts[L.offset[r.level] + (r.c[2] * L.dims[r.level][1] + r.c[1]) * L.dims[r.level][0] + r.c[0]];
-                    REQUIRE(pairs < 0xFFFFFFFFull, MLSGPU_ERR_LENGTH);
+                    for (uint32_t r = 0; r < numRegions; r++)
+                    {
+                        const Region &g = regions[r];
+                        starts[r] = (uint32_t) pairs;
+                        pairs += counts[L.offset[g.level] + (g.c[2] * L.dims[g.level][1] + g.c[1]) * L.dims[g.level][0] + g.c[0]];
+                        REQUIRE(pairs < 0xFFFFFFFFull, MLSGPU_ERR_LENGTH);
+                    }
+                    starts[numRegions] = (uint32_t) pairs;
                 }
+                const uint32_t totalPairs = starts[numRegions];
                 HIP_CHECK(hipMemcpyAsync(B.table, table.data(), (size_t) n0 * 4, hipMemcpyHostToDevice, ctx->stream));
-                if (B.regionCap < numRegions + 1)
-                {
-                    PROPAGATE(ensure(&B.starts, numRegions + 1));
-                    B.regionCap = numRegions + 1;
-                }
 
                 /* 3. member lists */
                 const RegionCountIn in{V, B.table};
@@ -958,43 +962,36 @@ int Bucketer::recurse(const uint32_t *dIds, uint64_t n, bool isSubset, const Gri
                     B.scanCap = scanTiles(n);
                 }
                 uint32_t *tileSums = B.scanSums;
-                /* the pair total is needed before the pair buffers can be sized */
-                int rc = scanPhase1<uint32_t, RegionCountIn>(ctx, "bucket.members.time", in, n, 0u, tileSums, B.total);
-                uint32_t totalPairs = 0;
-                if (rc == MLSGPU_OK && hipMemcpyAsync(&totalPairs, B.total, 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
-                    rc = setError(MLSGPU_ERR_HIP, "bucket: readback failed");
-                if (rc == MLSGPU_OK && hipStreamSynchronize(ctx->stream) != hipSuccess)
-                    rc = setError(MLSGPU_ERR_HIP, "bucket: synchronise failed");
-                if (rc == MLSGPU_OK && B.pairCap < totalPairs)
+                if (B.pairCap < totalPairs)
                 {
                     const uint64_t cap = (uint64_t) totalPairs + totalPairs / 8 + 1024;
-                    rc = ensure(&B.keysA, cap);
-                    if (rc == MLSGPU_OK) rc = ensure(&B.valsA, cap);
-                    if (rc == MLSGPU_OK) rc = ensure(&B.keysB, cap);
-                    if (rc == MLSGPU_OK) rc = ensure(&B.valsB, cap);
-                    if (rc == MLSGPU_OK) rc = ensure(&B.hist, sortHistElems(cap));
-                    if (rc == MLSGPU_OK) rc = ensure(&B.tileSums, scanTiles(std::max<uint64_t>(sortHistElems(cap), cap)));
-                    B.pairCap = rc == MLSGPU_OK ? cap : 0;
+                    B.pairCap = 0;
+                    PROPAGATE(ensure(&B.keysA, cap));
+                    PROPAGATE(ensure(&B.valsA, cap));
+                    PROPAGATE(ensure(&B.valsB, cap));
+                    PROPAGATE(ensure(&B.hist, sortHistElems(cap)));
+                    PROPAGATE(ensure(&B.tileSums, scanTiles(std::max<uint64_t>(sortHistElems(cap), cap))));
+                    B.pairCap = cap;
                 }
-                if (rc == MLSGPU_OK)
-                    rc = scanPhase2<uint32_t, RegionCountIn, RegionEmitOut>(ctx, "bucket.members.time", in,
-                                                                           RegionEmitOut{V, B.table, B.keysA, B.valsA}, n,
-                                                                           (const uint32_t *) tileSums);
+                PROPAGATE((scanPhase1<uint32_t, RegionCountIn>(ctx, "bucket.members.time", in, n, 0u, tileSums, B.total)));
+                PROPAGATE((scanPhase2<uint32_t, RegionCountIn, RegionEmitOut>(ctx, "bucket.members.time", in,
+                                                                            RegionEmitOut{V, B.table, B.keysA, B.valsA}, n,
+                                                                            (const uint32_t *) tileSums)));
                 SortResult<uint32_t> sorted{B.keysA, B.valsA};
-                if (rc == MLSGPU_OK)
-                    rc = radixSort<uint32_t>(ctx, "bucket.members.time", B.keysA, B.valsA, B.keysB, B.valsB, totalPairs,
-                                             bitsForCount(numRegions), false, B.hist, B.tileSums, &sorted);
-                std::vector<uint32_t> starts(numRegions + 1, 0);
-                if (rc == MLSGPU_OK && totalPairs > 0)
+                /* one digit (region numbers of up to 10 bits) leaves the values in valsB and needs no sorted keys at all;
+                 * more digits ping-pong the keys, so both key buffers exist then */
+                const uint32_t regionBits = bitsForCount(numRegions);
+                const bool oneDigit = regionBits <= SortCaps<uint32_t>::MAX_DIGIT_BITS && getenv("MLSGPU_HIP_SORT_DIGIT_BITS") == nullptr;
+                if (!oneDigit && B.keysBCap < B.pairCap)
                 {
-                    hipLaunchKernelGGL(regionStartsKernel, dim3(divUp(totalPairs, 256)), dim3(256), 0, ctx->stream,
-                                       (const uint32_t *) sorted.keys, (uint64_t) totalPairs, B.starts);
-                    if (hipMemcpyAsync(starts.data(), B.starts, (size_t) numRegions * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess
-                        || hipStreamSynchronize(ctx->stream) != hipSuccess)
-                        rc = setError(MLSGPU_ERR_HIP, "bucket: region starts failed");
+                    B.keysBCap = 0;
+                    PROPAGATE(ensure(&B.keysB, B.pairCap));
+                    B.keysBCap = B.pairCap;
                 }
-                PROPAGATE(rc);
-                starts[numRegions] = totalPairs;
+                PROPAGATE(radixSort<uint32_t>(ctx, "bucket.members.time", B.keysA, B.valsA, B.keysB, B.valsB, totalPairs,
+                                              regionBits, false, B.hist, B.tileSums, &sorted, nullptr, 0, false));
+                /* the callbacks may read the lists from any stream */
+                HIP_CHECK(hipStreamSynchronize(ctx->stream));
 
                 /* 4. doCallbacks, src/bucket_impl.h:258-294 */
                 const uint64_t chunk[3] = {chunkIn[0] + cx, chunkIn[1] + cy, chunkIn[2] + cz};
@@ -1316,11 +1313,16 @@ int Bucketer::recurseStream(mlsgpu_fileset *files, uint64_t n, const GridBox &gr
                         const uint64_t cap = (uint64_t) totalPairs + totalPairs / 8 + 1024;
                         PROPAGATE(ensure(&B.keysA, cap));
                         PROPAGATE(ensure(&B.valsA, cap));
-                        PROPAGATE(ensure(&B.keysB, cap));
                         PROPAGATE(ensure(&B.valsB, cap));
                         PROPAGATE(ensure(&B.hist, sortHistElems(cap)));
                         PROPAGATE(ensure(&B.tileSums, scanTiles(std::max<uint64_t>(sortHistElems(cap), cap))));
                         B.pairCap = cap;
+                    }
+                    if (B.keysBCap < B.pairCap)
+                    {
+                        B.keysBCap = 0;
+                        PROPAGATE(ensure(&B.keysB, B.pairCap));
+                        B.keysBCap = B.pairCap;
                     }
                     PROPAGATE((scanPhase2<uint32_t, RegionCountIn, RegionEmitOut>(ctx, "bucket.members.time", in,
                                                                                    RegionEmitOut{VB, B.table, B.keysA, B.valsA, r0, r1}, nb,

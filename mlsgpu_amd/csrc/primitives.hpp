@@ -857,7 +857,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
             out[k] = tileBase[(uint32_t) ((key >> shift) & mask)] + p;
             if (SPREAD)
                 out[k] += 1u + A.keyBase[(uint32_t) key];
-            else
+            else if (keysOut != nullptr)
                 keysOut[out[k]] = key;
         }
     }
@@ -918,7 +918,7 @@ struct SortJob
  */
 template<typename K>
 static int radixSortBatch(mlsgpu_ctx *ctx, const char *statName, SortJob<K> *jobs, uint32_t count, uint32_t bits, bool iota,
-                          uint32_t doneBits = 0)
+                          uint32_t doneBits = 0, bool keysWanted = true)
 {
     REQUIRE(count >= 1 && count <= MAX_LANES, MLSGPU_ERR_INVALID);
     uint32_t maxTiles = 0;
@@ -955,7 +955,9 @@ static int radixSortBatch(mlsgpu_ctx *ctx, const char *statName, SortJob<K> *job
         {
             const SortJob<K> &j = jobs[k < count ? k : 0];
             const uint32_t t = k < count ? tiles[k] : 0u;
-            K *const kin = flipped ? j.keysB : j.keysA, *const kout = flipped ? j.keysA : j.keysB;
+            /* keysWanted = false: the caller reads the sorted VALUES only, so the last pass leaves the keys unwritten */
+            const bool lastPass = shift + digitBits >= bits;
+            K *const kin = flipped ? j.keysB : j.keysA, *const kout = !keysWanted && lastPass ? (K *) nullptr : flipped ? j.keysA : j.keysB;
             uint32_t *const vin = flipped ? j.valsB : j.valsA, *const vout = flipped ? j.valsA : j.valsB;
             uint32_t *const dDigitTotals = j.dHist + (uint64_t) SORT_MAX_BINS * sortTiles(j.n);
             h.a[k] = SortHistArgs<K>{kin, j.dHist, j.n, j.nDev, t};
@@ -988,11 +990,11 @@ static int radixSortBatch(mlsgpu_ctx *ctx, const char *statName, SortJob<K> *job
 template<typename K>
 static int radixSort(mlsgpu_ctx *ctx, const char *statName, K *keysA, uint32_t *valsA, K *keysB, uint32_t *valsB,
                      uint64_t n, uint32_t bits, bool iota, uint32_t *dHist, uint32_t *dTileSums,
-                     SortResult<K> *result, const uint32_t *nDev = nullptr, uint32_t doneBits = 0)
+                     SortResult<K> *result, const uint32_t *nDev = nullptr, uint32_t doneBits = 0, bool keysWanted = true)
 {
     (void) dTileSums;
     SortJob<K> job{keysA, valsA, keysB, valsB, n, dHist, nDev, SortResult<K>{keysA, valsA}};
-    PROPAGATE(radixSortBatch<K>(ctx, statName, &job, 1, bits, iota, doneBits));
+    PROPAGATE(radixSortBatch<K>(ctx, statName, &job, 1, bits, iota, doneBits, keysWanted));
     *result = job.result;
     return MLSGPU_OK;
 }
