@@ -128,6 +128,7 @@ def parse_args():
     p.add_argument("--no-partition", action="store_true", help="skip the device-bucketer leg (reference partition)")
     p.add_argument("--partition-max-splats", type=int, default=2097152,
                    help="bucket capacity of the device-bucketer leg (reference default 64 MiB / 32 B)")
+    p.add_argument("--partition-spare", type=int, default=0, help="device items of the device-bucketer leg's farm beyond one per worker (0: 4 x lanes x workers -- the feeder runs far enough ahead for the workers to find full batches: 6.4 buckets per set of launches against 4.6 with lanes x workers items)")
     p.add_argument("--partition-workers", type=int, default=2, help="device workers of the device-bucketer leg when --batch > 1")
     p.add_argument("--weld-threads", type=int, default=0,
                    help="threads of the host welder (0: the library's default, min(32, hardware threads))")
@@ -837,7 +838,7 @@ def main():
             # through one set of processCorners / marching launches (mlsgpu_hip_worker_set_marching_group)
             pbatch = 1 if args.batch == 1 else m.binding.MAX_BATCH
             pworkers = max(1, args.farm_workers) if pbatch == 1 else max(1, args.partition_workers)
-            pfarm = m.BucketFarm([local_rank], pmax, workers_per_device=pworkers, spare=1 if pbatch == 1 else pbatch * pworkers,
+            pfarm = m.BucketFarm([local_rank], pmax, workers_per_device=pworkers, spare=args.partition_spare if args.partition_spare > 0 else 1 if pbatch == 1 else 4 * pbatch * pworkers,
                                  max_cells=pcells, mesh_memory=args.mesh_memory_mb << 20)
             pfarm.set_batch(pbatch)
             leaf_no = [0]
