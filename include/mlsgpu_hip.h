@@ -661,9 +661,14 @@ int mlsgpu_hip_fileset_set_buffer_size(mlsgpu_fileset *files, uint64_t bytes);
 /* splats [first, first + count) of the sequence into host memory (e.g. what mlsgpu_hip_farm_acquire returned) */
 int mlsgpu_hip_fileset_read(mlsgpu_fileset *files, uint64_t first, uint64_t count, mlsgpu_splat *out);
 /* The same range into DEVICE memory with bounded host memory: `readerThreads` host threads (0 = 4; the reference's
- * ReaderThread, src/splat_set.h:560-700) decode consecutive chunks into the quarters of one pinned buffer of the set's
- * buffer size while earlier chunks travel to the GPU on ctx's stream (the role of src/async_io.h:95-140 + CopyGroup for
- * clouds that fit in HBM: 10^9 splats are 32 GB of 288).  Returns when dOut[0 .. count) is complete. */
+ * ReaderThread, src/splat_set.h:560-700) fill the slots of one pinned buffer of the set's buffer size with consecutive
+ * chunks while earlier chunks travel to the GPU on ctx's stream (the role of src/async_io.h:95-140 + CopyGroup for
+ * clouds that fit in HBM: 10^9 splats are 32 GB of 288).  When every file's rows are whole 32-bit words no wider than a
+ * splat (x y z nx ny nz radius as float32: 28 bytes) the threads only READ the rows, the rows cross the link as the file
+ * holds them and a kernel decodes them (Reader::decode, src/fast_ply.cpp:374-400: same splats bit for bit); any other
+ * layout, or MLSGPU_HIP_FILESET_RAW=0, is decoded by the threads.  8-16 threads on the GPU's NUMA node reach the link's
+ * rate (61 GB/s of splats); the staging is kept by the set from call to call.  One load per set at a time.  Returns when
+ * dOut[0 .. count) is complete. */
 int mlsgpu_hip_fileset_load(mlsgpu_fileset *files, mlsgpu_ctx *ctx, uint64_t first, uint64_t count, mlsgpu_splat *dOut,
                             uint32_t readerThreads);
 /* Bucket::bucket over a FileSet that need NOT fit the device -- the role of the reference's blob index and host bucketing

@@ -380,13 +380,45 @@ MLSGPU_API int mlsgpu_hip_ply_load(mlsgpu_ply_reader *r, mlsgpu_ctx *ctx, uint64
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
+#include <fcntl.h>
+#include <unistd.h>
+
+/* where a file keeps what a splat needs: enough to decode its rows without the reader */
+struct FileLayout
+{
+    uint64_t vertexSize = 0, headerSize = 0;
+    uint64_t offsets[NUM_PROPERTIES] = {0, 0, 0, 0, 0, 0, 0};
+    /* rows of whole 32-bit words, no wider than a splat: they can cross the link as they are and be decoded on the device */
+    bool wordRows() const
+    {
+        bool ok = vertexSize % 4 == 0 && vertexSize <= sizeof(mlsgpu_splat);
+        for (int i = 0; i < NUM_PROPERTIES; i++)
+            ok = ok && offsets[i] % 4 == 0;
+        return ok;
+    }
+};
 
 struct mlsgpu_fileset
 {
     float smooth = 1.0f, maxRadius = 0.0f;
     std::vector<std::string> paths;
     std::vector<uint64_t> first;            /* first[i] = linear id of file i's first splat; first[n] = total */
+    std::vector<FileLayout> layouts;
     uint64_t bufferSize = 32u << 20;        /* FileSet::DEFAULT_BUFFER_SIZE, src/splat_set.h:461 */
+    /* mlsgpu_hip_fileset_load's staging, kept from call to call (pinning half a gigabyte costs as much as loading 10^8
+     * splats; mlsgpu_hip_bucket_stream loads chunk after chunk) */
+    std::mutex loadMutex;
+    char *pinned = nullptr, *dRaw = nullptr;
+    uint64_t pinnedBytes = 0, rawBytes = 0;
+    int stagingDevice = -1;
+    void dropStaging()
+    {
+        if (pinned) (void) hipHostFree(pinned);
+        if (dRaw) (void) hipFree(dRaw);
+        pinned = dRaw = nullptr;
+        pinnedBytes = rawBytes = 0;
+    }
+    ~mlsgpu_fileset() { dropStaging(); }
 };
 
 MLSGPU_API int mlsgpu_hip_fileset_create(float smooth, float maxRadius, mlsgpu_fileset **out)
@@ -409,7 +441,13 @@ MLSGPU_API int mlsgpu_hip_fileset_add_file(mlsgpu_fileset *f, const char *path)
     mlsgpu_ply_reader *r = nullptr;
     PROPAGATE(mlsgpu_hip_ply_open(path, f->smooth, f->maxRadius, &r));
     const uint64_t n = r->vertexCount;
+    FileLayout layout;
+    layout.vertexSize = r->vertexSize;
+    layout.headerSize = r->headerSize;
+    for (int i = 0; i < NUM_PROPERTIES; i++)
+        layout.offsets[i] = r->offsets[i];
     mlsgpu_hip_ply_close(r);
+    f->layouts.push_back(layout);
     f->paths.push_back(path);
     f->first.push_back(f->first.back() + n);
     return MLSGPU_OK;
@@ -477,6 +515,74 @@ MLSGPU_API int mlsgpu_hip_fileset_read(mlsgpu_fileset *f, uint64_t first, uint64
  * chunk to dOut on ctx's stream, and a quarter is reused once its copy has completed -- file reads, decoding and PCIe
  * overlap, and the host never holds more than bufferSize bytes of the cloud however many files of whatever size.
  */
+namespace
+{
+
+/* Reader::decode (src/fast_ply.cpp:374-400) on the device, for rows that crossed the link as the file holds them */
+struct RowLayout
+{
+    uint32_t words;                     /* 32-bit words per row */
+    uint32_t at[NUM_PROPERTIES];        /* word of each property inside a row */
+    float smooth, maxRadius;
+};
+
+__global__ __launch_bounds__(256) void decodeRowsKernel(const uint32_t *rows, uint64_t n, RowLayout R, mlsgpu_splat *out)
+{
+    const uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n)
+        return;
+    const uint32_t *const v = rows + i * R.words;
+    float r = __uint_as_float(v[R.at[RADIUS]]);
+    r = R.maxRadius < r ? R.maxRadius : r;                /* std::min(radius, maxRadius): a NaN radius stays */
+    r *= R.smooth;
+    const float q = (float) (1.0 / (double) (r * r));       /* double 1.0 / float product, as the reference */
+    float4 *const o = reinterpret_cast<float4 *>(out + i);
+    o[0] = make_float4(__uint_as_float(v[R.at[X]]), __uint_as_float(v[R.at[Y]]), __uint_as_float(v[R.at[Z]]), r);
+    o[1] = make_float4(__uint_as_float(v[R.at[NX]]), __uint_as_float(v[R.at[NY]]), __uint_as_float(v[R.at[NZ]]), q);
+}
+
+/* a run of rows of ONE file inside a job */
+struct RowPiece
+{
+    size_t file;
+    uint64_t firstRow, rows, byteAt;    /* byteAt: where the run starts in the job's slot */
+};
+
+void piecesOf(const mlsgpu_fileset *f, uint64_t first, uint64_t count, std::vector<RowPiece> &out)
+{
+    out.clear();
+    size_t file = std::upper_bound(f->first.begin(), f->first.end(), first) - f->first.begin() - 1;
+    uint64_t byteAt = 0;
+    while (count > 0)
+    {
+        while (file + 1 < f->first.size() && f->first[file + 1] <= first)
+            file++;
+        const uint64_t n = std::min(count, f->first[file + 1] - first);
+        out.push_back(RowPiece{file, first - f->first[file], n, byteAt});
+        byteAt += n * f->layouts[file].vertexSize;
+        first += n;
+        count -= n;
+    }
+}
+
+bool rawRowsWanted()
+{
+    const char *e = getenv("MLSGPU_HIP_FILESET_RAW");
+    return e == nullptr || e[0] != '0';
+}
+
+} // namespace
+
+/*
+ * Two routes per job (chunk of consecutive splats):
+ *   rows     (every file's rows are whole words, no wider than a splat -- x y z nx ny nz radius as float32 is 28 bytes)
+ *            a reader thread only READS the rows into its pinned slot (pread: one copy by the kernel, no pass of its own
+ *            over the bytes); the rows cross the link as they are and decodeRowsKernel writes the splats: the host touches
+ *            28 bytes per splat once instead of reading 28 and writing 32 behind a scalar decode, the link carries 28
+ *            instead of 32;
+ *   splats   (any other layout, or MLSGPU_HIP_FILESET_RAW=0) the reader threads decode on the host, as Reader::decode.
+ * Same splats either way, bit for bit (tests/test_fileset.py).
+ */
 MLSGPU_API int mlsgpu_hip_fileset_load(mlsgpu_fileset *f, mlsgpu_ctx *ctx, uint64_t first, uint64_t count, mlsgpu_splat *dOut,
                                        uint32_t readerThreads)
 {
@@ -484,6 +590,7 @@ MLSGPU_API int mlsgpu_hip_fileset_load(mlsgpu_fileset *f, mlsgpu_ctx *ctx, uint6
     REQUIRE(first <= f->first.back() && count <= f->first.back() - first, MLSGPU_ERR_LENGTH);
     if (count == 0)
         return MLSGPU_OK;
+    std::lock_guard<std::mutex> oneLoad(f->loadMutex);
     HIP_CHECK(hipSetDevice(ctx->device));
     /* one slot per reader thread, at least four (the reference pipelines reads through a fixed fraction of its buffer,
      * src/splat_set.h:455-462); a host with many cores decodes with as many threads as the caller asks for */
@@ -492,9 +599,35 @@ MLSGPU_API int mlsgpu_hip_fileset_load(mlsgpu_fileset *f, mlsgpu_ctx *ctx, uint6
     const uint64_t chunk = std::max<uint64_t>(1, f->bufferSize / SLOTS / sizeof(mlsgpu_splat));
     const uint64_t jobs = (count + chunk - 1) / chunk;
     const uint32_t threads = (uint32_t) std::min<uint64_t>(wanted, jobs);
-    mlsgpu_splat *pinned = nullptr;
-    if (hipHostMalloc((void **) &pinned, SLOTS * chunk * sizeof(mlsgpu_splat)) != hipSuccess)
-        return setError(MLSGPU_ERR_NOMEM, "fileset load: cannot pin %llu bytes", (unsigned long long) (SLOTS * chunk * sizeof(mlsgpu_splat)));
+    bool rawRows = rawRowsWanted();
+    for (const FileLayout &l : f->layouts)
+        rawRows = rawRows && l.wordRows();
+    const uint64_t slotBytes = chunk * sizeof(mlsgpu_splat);
+    if (f->stagingDevice != ctx->device || f->pinnedBytes < SLOTS * slotBytes)
+    {
+        f->dropStaging();
+        f->stagingDevice = ctx->device;
+        if (hipHostMalloc((void **) &f->pinned, SLOTS * slotBytes) != hipSuccess)
+        {
+            f->pinned = nullptr;
+            return setError(MLSGPU_ERR_NOMEM, "fileset load: cannot pin %llu bytes", (unsigned long long) (SLOTS * slotBytes));
+        }
+        f->pinnedBytes = SLOTS * slotBytes;
+    }
+    if (rawRows && f->rawBytes < SLOTS * slotBytes)
+    {
+        if (f->dRaw) (void) hipFree(f->dRaw);
+        f->dRaw = nullptr;
+        f->rawBytes = 0;
+        if (hipMalloc((void **) &f->dRaw, SLOTS * slotBytes) == hipSuccess)
+            f->rawBytes = SLOTS * slotBytes;
+        else
+        {
+            (void) hipGetLastError();
+            rawRows = false;                /* no room for the rows on the device: decode on the host */
+        }
+    }
+    char *const pinned = f->pinned;
     std::vector<hipEvent_t> copied(SLOTS, nullptr);
     int rc = MLSGPU_OK;
     for (uint64_t s = 0; s < SLOTS && rc == MLSGPU_OK; s++)
@@ -503,15 +636,43 @@ MLSGPU_API int mlsgpu_hip_fileset_load(mlsgpu_fileset *f, mlsgpu_ctx *ctx, uint6
 
     std::mutex mutex;
     std::condition_variable cond;
-    std::vector<char> ready(jobs, 0);           /* job decoded into its slot */
+    std::vector<char> ready(jobs, 0);           /* job decoded (or read) into its slot */
     uint64_t issued = 0;                         /* jobs whose copy has been enqueued (by the calling thread, in order) */
     std::atomic<uint64_t> next(0);
     int failed = MLSGPU_OK;
     std::string failText;
 
+    auto readRows = [&](std::vector<int> &fds, uint64_t at, uint64_t n, char *slot) -> int
+    {
+        std::vector<RowPiece> pieces;
+        piecesOf(f, first + at, n, pieces);
+        for (const RowPiece &p : pieces)
+        {
+            const FileLayout &l = f->layouts[p.file];
+            if (fds[p.file] < 0)
+            {
+                fds[p.file] = open(f->paths[p.file].c_str(), O_RDONLY | O_CLOEXEC);
+                if (fds[p.file] < 0)
+                    return setError(MLSGPU_ERR_INVALID, "%s: could not open file", f->paths[p.file].c_str());
+            }
+            uint64_t done = 0;
+            const uint64_t bytes = p.rows * l.vertexSize;
+            while (done < bytes)
+            {
+                const ssize_t got = pread(fds[p.file], slot + p.byteAt + done, bytes - done,
+                                          (off_t) (l.headerSize + p.firstRow * l.vertexSize + done));
+                if (got <= 0)
+                    return setError(MLSGPU_ERR_FORMAT, "%s: short read", f->paths[p.file].c_str());
+                done += (uint64_t) got;
+            }
+        }
+        return MLSGPU_OK;
+    };
+
     auto readerMain = [&]()
     {
         std::vector<mlsgpu_ply_reader *> readers(f->paths.size(), nullptr);
+        std::vector<int> fds(f->paths.size(), -1);
         for (;;)
         {
             const uint64_t j = next.fetch_add(1);
@@ -528,8 +689,9 @@ MLSGPU_API int mlsgpu_hip_fileset_load(mlsgpu_fileset *f, mlsgpu_ctx *ctx, uint6
             if (j >= SLOTS && hipEventSynchronize(copied[j % SLOTS]) != hipSuccess)
                 r = setError(MLSGPU_ERR_HIP, "fileset load: waiting for a copy failed");
             const uint64_t at = j * chunk, n = std::min(chunk, count - at);
+            char *const slot = pinned + (j % SLOTS) * slotBytes;
             if (r == MLSGPU_OK)
-                r = filesetRead(f, readers, first + at, n, pinned + (j % SLOTS) * chunk);
+                r = rawRows ? readRows(fds, at, n, slot) : filesetRead(f, readers, first + at, n, reinterpret_cast<mlsgpu_splat *>(slot));
             std::lock_guard<std::mutex> l(mutex);
             if (r != MLSGPU_OK && failed == MLSGPU_OK)
             {
@@ -542,11 +704,15 @@ MLSGPU_API int mlsgpu_hip_fileset_load(mlsgpu_fileset *f, mlsgpu_ctx *ctx, uint6
                 break;
         }
         closeAll(readers);
+        for (int fd : fds)
+            if (fd >= 0)
+                close(fd);
     };
     std::vector<std::thread> pool;
     if (rc == MLSGPU_OK)
         for (uint32_t t = 0; t < threads; t++)
             pool.emplace_back(readerMain);
+    std::vector<RowPiece> pieces;
     for (uint64_t j = 0; j < jobs && rc == MLSGPU_OK; j++)
     {
         {
@@ -556,8 +722,34 @@ MLSGPU_API int mlsgpu_hip_fileset_load(mlsgpu_fileset *f, mlsgpu_ctx *ctx, uint6
                 break;
         }
         const uint64_t at = j * chunk, n = std::min(chunk, count - at);
-        hipError_t e = hipMemcpyAsync(dOut + at, pinned + (j % SLOTS) * chunk, n * sizeof(mlsgpu_splat), hipMemcpyHostToDevice,
-                                      ctx->stream);
+        const char *const slot = pinned + (j % SLOTS) * slotBytes;
+        hipError_t e = hipSuccess;
+        if (rawRows)
+        {
+            piecesOf(f, first + at, n, pieces);
+            const uint64_t bytes = pieces.back().byteAt + pieces.back().rows * f->layouts[pieces.back().file].vertexSize;
+            char *const dSlot = f->dRaw + (j % SLOTS) * slotBytes;
+            e = hipMemcpyAsync(dSlot, slot, bytes, hipMemcpyHostToDevice, ctx->stream);
+            uint64_t outAt = at;
+            for (const RowPiece &p : pieces)
+            {
+                if (e != hipSuccess)
+                    break;
+                const FileLayout &l = f->layouts[p.file];
+                RowLayout R;
+                R.words = (uint32_t) (l.vertexSize / 4);
+                for (int i = 0; i < NUM_PROPERTIES; i++)
+                    R.at[i] = (uint32_t) (l.offsets[i] / 4);
+                R.smooth = f->smooth;
+                R.maxRadius = f->maxRadius;
+                hipLaunchKernelGGL(decodeRowsKernel, dim3((uint32_t) ((p.rows + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   reinterpret_cast<const uint32_t *>(dSlot + p.byteAt), p.rows, R, dOut + outAt);
+                e = hipGetLastError();
+                outAt += p.rows;
+            }
+        }
+        else
+            e = hipMemcpyAsync(dOut + at, slot, n * sizeof(mlsgpu_splat), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess)
             e = hipEventRecord(copied[j % SLOTS], ctx->stream);
         std::lock_guard<std::mutex> l(mutex);
@@ -584,7 +776,6 @@ MLSGPU_API int mlsgpu_hip_fileset_load(mlsgpu_fileset *f, mlsgpu_ctx *ctx, uint6
     }
     for (uint64_t s = 0; s < SLOTS; s++)
         if (copied[s]) hipEventDestroy(copied[s]);
-    hipHostFree(pinned);
     if (failed != MLSGPU_OK)
         return setError(failed, "%s", failText.empty() ? mlsgpu_hip_last_error() : failText.c_str());
     return MLSGPU_OK;

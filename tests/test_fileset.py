@@ -97,6 +97,64 @@ def test_fileset_load_with_bounded_buffer(tmp_path, threads):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("raw", ["1", "0"])
+def test_fileset_load_rows_decoded_on_the_device(tmp_path, raw, monkeypatch):
+    """Files whose rows are whole words (the plain 28-byte row; a row with a float32 the reader skips, properties in another
+    order) cross the link as they are and are decoded by a kernel; MLSGPU_HIP_FILESET_RAW=0 decodes on the host.  Same
+    splats bit for bit: clamped and smoothed radii, 1 / r^2 through a double, a NaN radius, file boundaries inside a chunk,
+    a range that starts and ends inside files."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import synth
+    monkeypatch.setenv("MLSGPU_HIP_FILESET_RAW", raw)
+    cloud = synth.sphere_cloud(200_000, (30.0, 20.0, 70.5), 40.0, 0.5, 1.5, seed=12)
+    cloud["radius"][77] = np.nan
+    cloud["radius"][78] = 0.0
+    cloud["radius"][150_000] = np.inf
+    cuts = [70_000, 1, 0, 69_999, 60_000]
+    paths, first = [], 0
+    for k, n in enumerate(cuts):
+        part = cloud[first:first + n]
+        p = tmp_path / ("rows%d.ply" % k)
+        if k % 2 == 0:
+            write_splats(p, part)
+        else:       # radius first, a float32 to skip, normals before positions: 32-byte rows of words
+            rows = np.zeros(n, np.dtype([("radius", "<f4"), ("conf", "<f4"), ("n", "<f4", 3), ("x", "<f4"), ("y", "<f4"), ("z", "<f4")]))
+            rows["radius"], rows["n"], rows["conf"] = part["radius"], part["normal"], 0.5
+            rows["x"], rows["y"], rows["z"] = part["position"][:, 0], part["position"][:, 1], part["position"][:, 2]
+            head = HEAD + "element vertex %d\nproperty float32 radius\nproperty float32 conf\nproperty float32 nx\nproperty float32 ny\n" % n \
+                + "property float32 nz\nproperty float32 x\nproperty float32 y\nproperty float32 z\nend_header\n"
+            with open(p, "wb") as f:
+                f.write(head.encode("ascii"))
+                f.write(rows.tobytes())
+        paths.append(p)
+        first += n
+    fs = m.binding.FileSet(paths, smooth=1.5, max_radius=1.25, buffer_size=64 << 10)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want = decoded(cloud, 1.5, 1.25)
+    ctx = m.Context(0)
+    dev = m.DeviceBuffer(ctx, nbytes=len(cloud) * 32)
+
+    def same(got, exp):
+        """bit for bit, a NaN for a NaN (which NaN a division makes of a NaN is the machine's choice)"""
+        got, exp = got.copy(), exp.copy()
+        for field in ("radius", "quality"):
+            nan = np.isnan(exp[field])
+            assert np.array_equal(np.isnan(got[field]), nan)
+            got[field][nan] = exp[field][nan] = 0
+        np.testing.assert_array_equal(got.view(np.uint32), exp.view(np.uint32))
+    for threads in (1, 4):
+        assert fs.load(ctx, dev, reader_threads=threads) == len(cloud)
+        same(dev.download(m.SPLAT_DTYPE, len(cloud)), want)
+    fs.load(ctx, dev, first=69_990, count=70_030, reader_threads=3)
+    same(dev.download(m.SPLAT_DTYPE, 70_030), want[69_990:140_020])
+    same(fs.read(), want)               # the host route agrees
+    os.remove(paths[3])
+    with pytest.raises(m.MlsError):
+        fs.load(ctx, dev, reader_threads=2)
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_cfg5_shape_files_to_welded_mesh(tmp_path):
     """BASELINE configs[4]'s route at reduced count: splats in several PLY files -> HBM through the bounded buffer ->
     bounding grid -> Bucket::bucket on the device -> the farm's device groups (eight, on GPU 0) by device-side loads ->

@@ -351,10 +351,10 @@ def test_cfg5_full_shape_from_files():
         assert synth.write_cloud_ply(paths, "cfg5", dev, scale=n / synth.CONFIGS["cfg5"]["splats"]) == n
         assert sum(os.path.getsize(p) for p in paths) > 28 * n
         ctx = m.Context(0)
-        fs = mb.FileSet(paths, buffer_size=512 << 20)
+        fs = mb.FileSet(paths, buffer_size=768 << 20)
         assert len(fs) == n
         raw = m.DeviceBuffer(ctx, nbytes=n * 32)
-        fs.load(ctx, raw, reader_threads=32)
+        fs.load(ctx, raw, reader_threads=12)
         ctx.synchronize()
         # what arrived in HBM is the generator's cloud: positions, radii and normals bit for bit, quality = 1 / r^2 as the
         # reader computes it (src/fast_ply.cpp:334-350)
