@@ -480,7 +480,15 @@ int filesetRead(const mlsgpu_fileset *f, std::vector<mlsgpu_ply_reader *> &reade
         const uint64_t inFile = first - f->first[file];
         const uint64_t n = std::min(count, f->first[file + 1] - first);
         if (readers[file] == nullptr)
+        {
+            for (mlsgpu_ply_reader *&other : readers)       /* one open file per caller at a time */
+                if (other != nullptr)
+                {
+                    mlsgpu_hip_ply_close(other);
+                    other = nullptr;
+                }
             PROPAGATE(mlsgpu_hip_ply_open(f->paths[file].c_str(), f->smooth, f->maxRadius, &readers[file]));
+        }
         PROPAGATE(mlsgpu_hip_ply_read(readers[file], inFile, n, out));
         out += n;
         first += n;
@@ -651,6 +659,13 @@ MLSGPU_API int mlsgpu_hip_fileset_load(mlsgpu_fileset *f, mlsgpu_ctx *ctx, uint6
             const FileLayout &l = f->layouts[p.file];
             if (fds[p.file] < 0)
             {
+                /* a thread walks the files in order: one descriptor each at a time, however many files the set has */
+                for (int &fd : fds)
+                    if (fd >= 0)
+                    {
+                        close(fd);
+                        fd = -1;
+                    }
                 fds[p.file] = open(f->paths[p.file].c_str(), O_RDONLY | O_CLOEXEC);
                 if (fds[p.file] < 0)
                     return setError(MLSGPU_ERR_INVALID, "%s: could not open file", f->paths[p.file].c_str());

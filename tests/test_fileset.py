@@ -72,6 +72,27 @@ def test_fileset_reads_files_as_one_sequence(tmp_path):
     assert len(fs) == 10_000                                               # a rejected file leaves the set unchanged
 
 
+def test_a_set_of_many_files_needs_few_descriptors(tmp_path):
+    """The reference's sets are hundreds of scan files: a reader holds ONE of them open at a time (120 files under a limit
+    of 40 descriptors, in a child process so that the limit is its own)."""
+    import subprocess
+    from mlsgpu_amd import synth
+    cloud = synth.sphere_cloud(1200, (3.0, -2.0, 7.5), 4.0, 0.1, 0.3, seed=9)
+    paths = make_files(tmp_path, cloud, [10] * 120)
+    np.save(tmp_path / "want.npy", decoded(cloud).view(np.uint32))
+    code = ("import resource, sys, numpy as np\n"
+            "sys.path.insert(0, %r)\n"
+            "import mlsgpu_amd as m\n"
+            "resource.setrlimit(resource.RLIMIT_NOFILE, (40, 40))\n"
+            "fs = m.binding.FileSet(%r)\n"
+            "got = fs.read().view(np.uint32)\n"
+            "assert np.array_equal(got, np.load(%r)), 'differs'\n"
+            "print('ok', len(fs))\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), [str(p) for p in paths],
+                                       str(tmp_path / "want.npy"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok 1200" in out.stdout, out.stderr[-2000:]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("threads", [1, 4])
 def test_fileset_load_with_bounded_buffer(tmp_path, threads):
