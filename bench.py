@@ -71,7 +71,7 @@ def parse_args():
                         "BASELINE configs[4], 2048^3 grid, 10^9 splats read from PLY files (written to --cfg5-dir first)")
     p.add_argument("--cfg5-dir", default="/dev/shm", help="where cfg5's PLY files are written (28 GB at scale 1)")
     p.add_argument("--cfg5-files", type=int, default=8)
-    p.add_argument("--reader-threads", type=int, default=12,
+    p.add_argument("--reader-threads", type=int, default=16,
                    help="cfg5: host threads reading the PLY files (8-16 reach the link's rate; 24 and 32 were 20-35 %% slower)")
     p.add_argument("--cfg5-spare", type=int, default=1, help="device items beyond one per worker in cfg5's farm")
     p.add_argument("--cfg5-batch", type=int, default=1, help="buckets per launch set in cfg5's farm")

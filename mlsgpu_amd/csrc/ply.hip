@@ -8,6 +8,7 @@
  * its quality 1 / radius^2 (Reader::decode, :334-350).  Errors carry the reference's FormatError texts.
  */
 #include "common.hpp"
+#include "placement.hpp"
 
 #include <cstdio>
 #include <algorithm>
@@ -684,8 +685,12 @@ MLSGPU_API int mlsgpu_hip_fileset_load(mlsgpu_fileset *f, mlsgpu_ctx *ctx, uint6
         return MLSGPU_OK;
     };
 
+    /* the readers run -- and first touch the pinned slots -- on the GPU's NUMA node, whatever the caller is bound to:
+     * the link reads the slots at its own rate only from there (csrc/placement.hpp) */
+    const std::vector<int> nodeCpus = placement::cpusOfNode(mlsgpu_hip_device_node(ctx->device));
     auto readerMain = [&]()
     {
+        placement::bindThisThread(nodeCpus);
         std::vector<mlsgpu_ply_reader *> readers(f->paths.size(), nullptr);
         std::vector<int> fds(f->paths.size(), -1);
         for (;;)

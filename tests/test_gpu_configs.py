@@ -354,7 +354,7 @@ def test_cfg5_full_shape_from_files():
         fs = mb.FileSet(paths, buffer_size=768 << 20)
         assert len(fs) == n
         raw = m.DeviceBuffer(ctx, nbytes=n * 32)
-        fs.load(ctx, raw, reader_threads=12)
+        fs.load(ctx, raw, reader_threads=16)
         ctx.synchronize()
         # what arrived in HBM is the generator's cloud: positions, radii and normals bit for bit, quality = 1 / r^2 as the
         # reader computes it (src/fast_ply.cpp:334-350)

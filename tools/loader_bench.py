@@ -40,7 +40,7 @@ def main():
         ctx = m.Context(0)
         n = per * nfiles
         dev = m.DeviceBuffer(ctx, nbytes=n * 32)
-        for threads, buf in ((4, 32 << 20), (16, 256 << 20), (32, 512 << 20), (64, 1 << 30)):
+        for threads, buf in ((4, 128 << 20), (8, 512 << 20), (12, 768 << 20), (16, 512 << 20), (32, 1 << 30)):
             fs = mb.FileSet(paths, buffer_size=buf)
             fs.load(ctx, dev, count=min(n, 4_000_000), reader_threads=threads)      # warm
             t0 = time.perf_counter()
