@@ -379,6 +379,11 @@ void workerMain(Farm *farm, DeviceGroup *g)
     int rc = mlsgpu_hip_ctx_create(g->device, nullptr, &ctx);
     if (rc == MLSGPU_OK)
         rc = mlsgpu_hip_worker_create(ctx, &farm->cfg.worker, &worker);
+    /* a device item is the farm's own copy, so the tree could turn its radii into 1 / r^2 in place (kernels/octree.cl:193);
+     * taking 1 / r^2 when a splat is staged instead spares the strided 4-byte stores of the build: cfg5 565.5-566.5 -> 555-558 ms
+     * per pass, same meshes */
+    if (rc == MLSGPU_OK)
+        rc = mlsgpu_hip_worker_set_keep_splats(worker, 1);
     if (rc != MLSGPU_OK)
     {
         farm->fail(rc, mlsgpu_hip_last_error());
