@@ -73,8 +73,10 @@ def parse_args():
     p.add_argument("--cfg5-files", type=int, default=8)
     p.add_argument("--reader-threads", type=int, default=16,
                    help="cfg5: host threads reading the PLY files (8-16 reach the link's rate; 24 and 32 were 20-35 %% slower)")
-    p.add_argument("--cfg5-spare", type=int, default=1, help="device items beyond one per worker in cfg5's farm")
-    p.add_argument("--cfg5-batch", type=int, default=1, help="buckets per launch set in cfg5's farm")
+    p.add_argument("--cfg5-spare", type=int, default=10, help="device items beyond one per worker in cfg5's farm")
+    p.add_argument("--cfg5-batch", type=int, default=4,
+                   help="buckets per set of launches in cfg5's farm (ms per pass, same box: 1: 559-563, 2: 540-543, 3: 533-534, 4: 530-533, "
+                        "6: 530-531, 8: 531-532)")
     p.add_argument("--dist", default="uniform", choices=["uniform", "shells"])
     p.add_argument("--scale", type=float, default=1.0, help="splat-count scale (debug only; 1.0 = BASELINE size)")
     p.add_argument("--mesh-memory-mb", type=int, default=4096, help="Marching mesh arena per worker")

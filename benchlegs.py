@@ -187,6 +187,7 @@ def run_cfg5(args, rank, world, local_rank, device, dist, reduce_device):
                         "checksummed in HBM" % (g, n, args.dist, len(paths), len(leaves), pcells, pmax),
             "voxels_per_step": int(total_voxels // args.steps), "buckets": len(leaves), "buckets_this_rank": len(mine),
             "bucket_splats_total": int(sum(l["num_splats"] for l in leaves)), "device_workers": nworkers,
+            "buckets_per_launch_set": max(1, args.cfg5_batch), "device_items": nworkers + max(1, args.cfg5_spare),
             "mesh_memory_mb": args.mesh_memory_mb, "timed_region": "cloud resident in HBM -> Bucket::bucket -> device gathers -> "
             "device workers (the partition is recomputed in every step)",
             "triangles_per_step": st0["triangles"], "vertices_per_step": st0["vertices"], "shipouts_per_step": st0["shipouts"],
