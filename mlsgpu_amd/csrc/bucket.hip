@@ -8,10 +8,16 @@
  *   1. bucketCountKernel   every splat adds 1 to each octree node (all levels) its microblock range meets --
  *                          the values the reference's delta-encoded counters hold after upsweepCounts;
  *                          LDS-privatised when the dense octree fits (it does for the default 63-cell leaves);
- *   2. host: pickNodes on the few hundred counters (same traversal order, so regions are numbered alike);
+ *      bucketCountPrivateKernel (a big level whose finest counters do not fit: 33^3 microblocks for 10^9 splats in 2048^3)
+ *                          per-workgroup LDS counters, 16 bits wide at the finest level, corrections at the coarser ones,
+ *                          summed and swept up by two small kernels -- no scattered global atomics;
+ *      either way the count is the only pass that reads the splats: it leaves every element's microblock range as an
+ *      8-byte note (RegionView::packNote) for step 3;
+ *   2. host: pickNodes on the few hundred counters (same traversal order, so regions are numbered alike); the regions'
+ *      counters are also the lengths of their member lists, so the lists' starts are known here;
  *   3. a scan whose producer counts the regions a splat joins ("once per node", bucket.cpp:291-301) and whose
- *      consumer writes (region, splat id) pairs, a STABLE radix sort by region, and a boundary kernel:
- *      every region's member list, ids ascending -- exactly the reference's subset;
+ *      consumer writes (region, splat id) pairs, and a STABLE radix sort by region (one digit for up to 1024 regions,
+ *      sorted keys not written): every region's member list, ids ascending -- exactly the reference's subset;
  *   4. recursion into each region (depth first, in region order) with its id list in place of all splats.
  * Leaves are handed to the callback with their id list still on the device; mlsgpu_hip_bucket_load gathers
  * them and transforms them into the full grid's vertex coordinates (BucketLoader, src/bucket_loader.cpp:77-85)
