@@ -35,6 +35,7 @@ struct mlsgpu_tree
     uint32_t *dKeysA = nullptr, *dKeysB = nullptr, *dValsA = nullptr, *dValsB = nullptr;
     uint32_t *dHist = nullptr, *dTileSums = nullptr, *dNumEntries = nullptr;
     uint32_t *dNodeCounts = nullptr, *dNodeBase = nullptr;     /* per node: entries, and twice the non-empty nodes before it */
+    uint32_t *dDigitBase = nullptr;     /* 257 words: where the groups of the fused first pass begin (packed entries) */
     U3 *dNodeTiles = nullptr;           /* tile sums of the scan over the nodes */
     HostMailbox entryBox;               /* the entry count comes back to the host once per build */
     uint8_t *dSlotMasks = nullptr;      /* per splat: which of its 8 candidate slots are real entries */
@@ -308,6 +309,7 @@ struct EntryTotalArgs
 {
     const uint32_t *digitTotals;
     uint32_t *total;
+    uint32_t *digitBase;        /* [numBins + 1]: exclusive prefix of the totals -- where every digit's group begins */
 };
 
 /* the number of entries = the sum of the digit totals; one workgroup adds up every lane's in turn */
@@ -318,16 +320,21 @@ __global__ __launch_bounds__(256) void entryTotalKernel(Lanes<EntryTotalArgs> la
     for (uint32_t k = 0; k < count; k++)
     {
         const uint32_t *const digitTotals = lanes.a[k].digitTotals;
-        uint32_t v = 0;
-        for (uint32_t d = threadIdx.x; d < numBins; d += 256)
-            v += digitTotals[d];
-        v = waveSum(v);
-        if ((threadIdx.x & 63) == 0)
-            waveTotals[threadIdx.x >> 6] = v;
+        /* numBins <= 256 (ENT_BIN_BITS): one digit per thread */
+        const uint32_t mine = threadIdx.x < numBins ? digitTotals[threadIdx.x] : 0u;
+        const uint32_t incl = waveInclusiveScan(mine);
+        if ((threadIdx.x & 63) == 63)
+            waveTotals[threadIdx.x >> 6] = incl;
         __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < (threadIdx.x >> 6); w++)
+            before += waveTotals[w];
+        if (threadIdx.x < numBins)
+            lanes.a[k].digitBase[threadIdx.x] = before + incl - mine;
         if (threadIdx.x == 0)
         {
             const uint32_t sum = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
+            lanes.a[k].digitBase[numBins] = sum;
             *lanes.a[k].total = sum;
             /* ... and straight to the host (HostMailbox): the count sizes the launches that follow */
             __hip_atomic_store(box + 1 + k, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -350,6 +357,7 @@ struct EntryScatterArgs
     uint32_t numTiles;
     uint64_t n;
     uint32_t *keysOut, *valsOut;
+    uint32_t idBits;            /* != 0: an entry leaves as ONE word, (key >> digitBits) << idBits | (id - firstSplat), in keysOut */
 };
 
 __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 8))) void entryScatterKernel(Lanes<EntryScatterArgs> lanes, uint32_t digitBits)
@@ -508,7 +516,8 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     }
     __syncthreads();
     /* 3. out, in the order of the pass: the run of a digit is contiguous in the tile and in memory */
-    const uint32_t tileFirstId = blockIdx.x * ENT_TILE + P.firstSplat;
+    const uint32_t idBits = A.idBits;
+    const uint32_t tileFirstId = blockIdx.x * ENT_TILE + (idBits != 0 ? 0u : P.firstSplat);
 #pragma unroll
     for (int k = 0; k < MAX_ROUNDS; k++)
     {
@@ -518,8 +527,14 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
             const uint32_t e = sEnt[p];
             const uint32_t key = e & ((1u << ENT_KEY_BITS) - 1u);
             const uint32_t out = tileBase[key & dmask] + p;
-            keysOut[out] = key;
-            valsOut[out] = tileFirstId + (e >> ENT_KEY_BITS);
+            const uint32_t id = tileFirstId + (e >> ENT_KEY_BITS);
+            if (idBits != 0)
+                keysOut[out] = (key >> digitBits) << idBits | id;     /* the digit is where the entry lies from now on */
+            else
+            {
+                keysOut[out] = key;
+                valsOut[out] = id;
+            }
         }
     }
 }
@@ -745,6 +760,7 @@ MLSGPU_API int mlsgpu_hip_tree_create(mlsgpu_ctx *ctx, uint64_t maxLevels, uint6
     alloc((void **) &t->dEntryNotes, maxSplats * 8);
     alloc((void **) &t->dNodeCounts, t->maxStart * 4);
     alloc((void **) &t->dNodeBase, t->maxStart * 4);
+    alloc((void **) &t->dDigitBase, 257 * 4);
     alloc((void **) &t->dNodeTiles, ((uint64_t) scanTiles(t->maxStart) + 1) * sizeof(U3));
     if (rc == MLSGPU_OK)
         rc = t->entryBox.create();
@@ -765,7 +781,7 @@ MLSGPU_API void mlsgpu_hip_tree_destroy(mlsgpu_tree *t)
     hipFree(t->dStart); hipFree(t->dJumpPos); hipFree(t->dCommands);
     hipFree(t->dKeysA); hipFree(t->dKeysB); hipFree(t->dValsA); hipFree(t->dValsB);
     hipFree(t->dHist); hipFree(t->dTileSums); hipFree(t->dNumEntries); hipFree(t->dSlotMasks); hipFree(t->dEntryNotes);
-    hipFree(t->dNodeCounts); hipFree(t->dNodeBase); hipFree(t->dNodeTiles);
+    hipFree(t->dNodeCounts); hipFree(t->dNodeBase); hipFree(t->dNodeTiles); hipFree(t->dDigitBase);
     t->entryBox.destroy();
     delete t;
 }
@@ -816,6 +832,21 @@ static int treeBuildBatch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *re
 
     /* the command list straight from the sort's last pass (NodeIn / NodeOut above): for the fused front end with ONE pass left */
     const bool direct = fused && keyBits <= 2 * perPass;
+    /* One word per entry between the two passes (entryScatterKernel / SortHistArgs): after the fused pass an entry's low
+     * digit is its position, so the word holds the rest of the key above the splat's number inside the bucket -- when both
+     * fit.  4 bytes less written and read again per entry (8 E of the 24 E the two passes move). */
+    uint32_t idBits = 0;
+    {
+        static const bool packedOff = getenv("MLSGPU_HIP_OCTREE_PACKED") != nullptr && atoi(getenv("MLSGPU_HIP_OCTREE_PACKED")) == 0;
+        uint64_t most = 1;
+        for (uint32_t k = 0; k < count; k++)
+            most = std::max<uint64_t>(most, reqs[k].numSplats);
+        uint32_t bits = 1;
+        while (bits < 32 && ((most - 1) >> bits) != 0)
+            bits++;
+        if (direct && !packedOff && (keyBits - perPass) + bits <= 32)
+            idBits = bits;
+    }
     Lanes<int32_t *> jump;
     Lanes<WriteStartArgs> ws;
     for (uint32_t k = 0; k < MAX_LANES; k++)
@@ -866,8 +897,8 @@ static int treeBuildBatch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *re
                 const EntryParams P = params(k);
                 eh.a[a] = EntryHistArgs{P, t->dEntryNotes, t->dHist, tilesE, reqs[k].numSplats};
                 ds.a[a] = SortDigitScanArgs{t->dHist, dDigitTotals, tilesE};
-                et.a[a] = EntryTotalArgs{dDigitTotals, t->dNumEntries};
-                es.a[a] = EntryScatterArgs{P, t->dEntryNotes, t->dHist, dDigitTotals, tilesE, reqs[k].numSplats, t->dKeysB, t->dValsB};
+                et.a[a] = EntryTotalArgs{dDigitTotals, t->dNumEntries, t->dDigitBase};
+                es.a[a] = EntryScatterArgs{P, t->dEntryNotes, t->dHist, dDigitTotals, tilesE, reqs[k].numSplats, t->dKeysB, t->dValsB, idBits};
                 maxTiles = std::max(maxTiles, tilesE);
             }
             LAUNCH(ctx, stat, entryHistKernel, dim3(maxTiles, na), dim3(ENT_THREADS), eh, perPass);
@@ -930,7 +961,7 @@ static int treeBuildBatch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *re
                 mlsgpu_tree *t = trees[act[a < na ? a : 0]];
                 const uint32_t tiles = a < na ? sortTiles(j.n) : 0u;
                 uint32_t *const dDigitTotals = j.dHist + (uint64_t) SORT_MAX_BINS * sortTiles(j.n);
-                h.a[a] = SortHistArgs<uint32_t>{j.keysA, j.dHist, j.n, j.nDev, tiles, t->dNodeCounts};
+                h.a[a] = SortHistArgs<uint32_t>{j.keysA, j.dHist, j.n, j.nDev, tiles, t->dNodeCounts, t->dDigitBase, idBits};
                 d.a[a] = SortDigitScanArgs{j.dHist, dDigitTotals, tiles};
                 maxTiles = std::max(maxTiles, tiles);
             }
@@ -983,7 +1014,8 @@ static int treeBuildBatch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *re
                 const uint32_t tiles = a < na ? sortTiles(j.n) : 0u;
                 uint32_t *const dDigitTotals = j.dHist + (uint64_t) SORT_MAX_BINS * sortTiles(j.n);
                 sc.a[a] = SortScatterArgs<uint32_t>{j.keysA, j.valsA, (uint32_t *) nullptr, reinterpret_cast<uint32_t *>(t->dCommands), j.dHist,
-                                                   dDigitTotals, j.n, j.nDev, tiles, t->dNodeBase};
+                                                   dDigitTotals, j.n, j.nDev, tiles, t->dNodeBase, t->dDigitBase, idBits,
+                                                   (uint32_t) reqs[act[a < na ? a : 0]].firstSplat};
                 maxTiles = std::max(maxTiles, tiles);
             }
             if (maxTiles > 0)

@@ -535,7 +535,19 @@ struct SortHistArgs
     const uint32_t *nDev;
     uint32_t numTiles;
     uint32_t *keyCounts;        /* KEY_COUNTS: occurrences of every whole key (the pass's digit is the key's top digit) */
+    /* KEY_COUNTS, packed words (idBits != 0): an element is (top digit << idBits | value) -- the low part of its key is not
+     * stored: the input is grouped by it, group g at positions [lowBase[g], lowBase[g + 1]) */
+    const uint32_t *lowBase = nullptr;
+    uint32_t idBits = 0;
 };
+
+/* the group (low part) position i lies in, for groups that begin at lowBase[0 .. numLow]: at or behind `from` */
+__device__ __forceinline__ uint32_t lowPartAt(const uint32_t *lowBase, uint32_t from, uint32_t numLow, uint64_t i)
+{
+    while (from + 1 < numLow && i >= lowBase[from + 1])
+        from++;
+    return from;
+}
 
 enum { KEY_COUNT_SLOTS = 4 };   /* low parts of the key a tile may span and still count in LDS */
 
@@ -558,34 +570,72 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(Lanes<SortHistArgs<
         n = *A.nDev;
     __shared__ uint32_t bins[SORT_MAX_BINS];
     __shared__ uint32_t keyBins[KEY_COUNTS ? KEY_COUNT_SLOTS * 256 : 1];
+    __shared__ uint32_t sLow[KEY_COUNTS ? 256 : 1];
+    __shared__ uint32_t sGroup[PRIM_WAVES][2];
     const uint32_t numBins = 1u << digitBits;
     const K mask = (K) (numBins - 1);
-    for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
-        bins[d] = 0;
-    if (KEY_COUNTS)
-        for (uint32_t d = threadIdx.x; d < KEY_COUNT_SLOTS * 256; d += PRIM_BLOCK)
-            keyBins[d] = 0;
-    __syncthreads();
+    const bool packed = KEY_COUNTS && A.idBits != 0;
+    const uint32_t numLow = 1u << shift;
+    const uint32_t digitShift = packed ? A.idBits : shift;
     const K *const keys = A.keys;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t tileFirst = (uint64_t) blockIdx.x * SORT_TILE;
     const uint64_t base = tileFirst + (uint64_t) wave * SORT_WAVE_SPAN + lane;
     const K lowMask = (K) (((K) 1 << shift) - 1);
-    uint32_t lowFirst = 0;
-    bool oneLow = false;        /* the whole tile has one low part: the digit bins ARE the key counts (six tiles of seven) */
-    if (KEY_COUNTS && tileFirst < n)
-    {
-        const uint64_t tileLast = tileFirst + SORT_TILE - 1 < n ? tileFirst + SORT_TILE - 1 : n - 1;
-        lowFirst = (uint32_t) (keys[tileFirst] & lowMask);
-        oneLow = (uint32_t) (keys[tileLast] & lowMask) == lowFirst;      /* sorted by the low part */
-    }
-    /* all of the thread's keys are requested before the first is counted (one round of memory latency, not four) */
+    /* all of the thread's keys are requested before the first is counted (one round of memory latency, not four) -- and,
+     * with them, the group bounds of packed words */
     K mine[SORT_ITEMS];
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++)
     {
         const uint64_t i = base + (uint64_t) j * 64;
         mine[j] = i < n ? keys[i] : (K) 0;
+    }
+    for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
+        bins[d] = 0;
+    if (KEY_COUNTS)
+    {
+        for (uint32_t d = threadIdx.x; d < KEY_COUNT_SLOTS * 256; d += PRIM_BLOCK)
+            keyBins[d] = 0;
+        if (packed)
+        {
+            /* thread g holds where group g begins (numLow <= 256 = PRIM_BLOCK): the groups the tile's first and last element
+             * lie in are counts of begins at or before them -- two ballots, no search */
+            const uint64_t tileLast = tileFirst + SORT_TILE - 1 < n ? tileFirst + SORT_TILE - 1 : n - 1;
+            const uint32_t myBase = threadIdx.x < numLow ? A.lowBase[threadIdx.x] : 0xFFFFFFFFu;
+            sLow[threadIdx.x] = myBase;
+            const uint32_t c0 = (uint32_t) __popcll(__ballot(threadIdx.x < numLow && myBase <= tileFirst));
+            const uint32_t c1 = (uint32_t) __popcll(__ballot(threadIdx.x < numLow && myBase <= tileLast));
+            if (lane == 0)
+            {
+                sGroup[wave][0] = c0;
+                sGroup[wave][1] = c1;
+            }
+        }
+    }
+    __syncthreads();
+    uint32_t lowFirst = 0;
+    bool oneLow = false;        /* the whole tile has one low part: the digit bins ARE the key counts (six tiles of seven) */
+    if (KEY_COUNTS && tileFirst < n)
+    {
+        const uint64_t tileLast = tileFirst + SORT_TILE - 1 < n ? tileFirst + SORT_TILE - 1 : n - 1;
+        if (packed)
+        {
+            uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+            for (int w = 0; w < PRIM_WAVES; w++)
+            {
+                c0 += sGroup[w][0];
+                c1 += sGroup[w][1];
+            }
+            lowFirst = c0 - 1;          /* group 0 begins at 0 */
+            oneLow = c1 == c0;
+        }
+        else
+        {
+            lowFirst = (uint32_t) (keys[tileFirst] & lowMask);
+            oneLow = (uint32_t) (keys[tileLast] & lowMask) == lowFirst;      /* sorted by the low part */
+        }
     }
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++)
@@ -594,15 +644,16 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(Lanes<SortHistArgs<
         if (i < n)
         {
             const K key = mine[j];
-            const uint32_t digit = (uint32_t) ((key >> shift) & mask);
+            const uint32_t digit = (uint32_t) ((key >> digitShift) & mask);
             atomicAdd(&bins[digit], 1u);
             if (KEY_COUNTS && !oneLow)
             {
-                const uint32_t slot = (uint32_t) (key & lowMask) - lowFirst;
+                const uint32_t low = packed ? lowPartAt(sLow, lowFirst, numLow, i) : (uint32_t) (key & lowMask);
+                const uint32_t slot = low - lowFirst;
                 if (slot < KEY_COUNT_SLOTS)
                     atomicAdd(&keyBins[slot * 256 + digit], 1u);
                 else
-                    atomicAdd(&A.keyCounts[(uint32_t) key], 1u);
+                    atomicAdd(&A.keyCounts[packed ? (digit << shift) | low : (uint32_t) key], 1u);
             }
         }
     }
@@ -687,6 +738,10 @@ struct SortScatterArgs
     const uint32_t *nDev;
     uint32_t numTiles;
     const uint32_t *keyBase;    /* SPREAD: the value of sorted rank r with key k goes to valsOut[1 + r + keyBase[k]] */
+    /* SPREAD over packed words (idBits != 0, see SortHistArgs): keysIn[i] = top digit << idBits | value, the key's low part is
+     * the group position i lies in; what goes out is value + valueBias */
+    const uint32_t *lowBase = nullptr;
+    uint32_t idBits = 0, valueBias = 0;
 };
 
 /*
@@ -715,9 +770,14 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
     /* the tile is reordered in two phases through ONE buffer (keys, then values): half the LDS, twice the
      * resident workgroups, which is what this latency-bound kernel needs */
     __shared__ K sTile[SORT_TILE];
+    __shared__ uint32_t sLow[SPREAD ? 256 : 1];
+    __shared__ uint32_t sGroup[PRIM_WAVES][2];
     const SortScatterArgs<K> A = lanes.a[blockIdx.y];
     if (blockIdx.x >= A.numTiles)
         return;
+    const bool packed = SPREAD && A.idBits != 0;
+    const uint32_t digitShift = packed ? A.idBits : shift;
+    const uint32_t numLow = 1u << shift;
     uint64_t n = A.n;
     if (A.nDev != nullptr && *A.nDev < n)
         n = *A.nDev;
@@ -756,7 +816,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
     {
         const uint64_t i = base + (uint64_t) j * 64;
         keys[j] = i < n ? keysIn[i] : (K) 0;
-        vals[j] = IOTA ? (uint32_t) i : (i < n ? valsIn[i] : 0u);
+        vals[j] = IOTA ? (uint32_t) i : (i < n && !packed ? valsIn[i] : 0u);
     }
     uint32_t totalOf[MAX_PER], histOf[MAX_PER];
 #pragma unroll
@@ -766,14 +826,55 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
         totalOf[k] = mineToo ? digitTotals[d0 + k] : 0u;
         histOf[k] = mineToo ? hist[(uint64_t) (d0 + k) * numTiles + blockIdx.x] : 0u;
     }
+    if (packed)
+    {
+        /* thread g holds where group g begins: see sortHistKernel */
+        const uint32_t myBase = threadIdx.x < numLow ? A.lowBase[threadIdx.x] : 0xFFFFFFFFu;
+        sLow[threadIdx.x] = myBase;
+        const uint32_t c0 = (uint32_t) __popcll(__ballot(threadIdx.x < numLow && myBase <= tileFirst));
+        const uint32_t c1 = (uint32_t) __popcll(__ballot(threadIdx.x < numLow && myBase <= tileFirst + tileCount - 1));
+        if (lane == 0)
+        {
+            sGroup[wave][0] = c0;
+            sGroup[wave][1] = c1;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < SORT_ITEMS; j++)
     {
         const uint64_t i = base + (uint64_t) j * 64;
         if (i < n)
-            atomicAdd(&waveBins[wave][(uint32_t) ((keys[j] >> shift) & mask)], 1u);
+            atomicAdd(&waveBins[wave][(uint32_t) ((keys[j] >> digitShift) & mask)], 1u);
     }
     __syncthreads();
+    uint32_t lowFirst = 0;
+    bool oneLow = false;
+    if (packed)
+    {
+        /* What travels behind the words through the tile's reorder is the low part of every element's key -- nothing at all
+         * where the tile lies inside one group (most do: a group is thousands of entries) */
+        uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+        for (int w = 0; w < PRIM_WAVES; w++)
+        {
+            c0 += sGroup[w][0];
+            c1 += sGroup[w][1];
+        }
+        lowFirst = c0 - 1;              /* group 0 begins at 0 */
+        oneLow = c1 == c0;
+        if (!oneLow)
+        {
+            uint32_t low = lowFirst;
+#pragma unroll
+            for (int j = 0; j < SORT_ITEMS; j++)
+            {
+                const uint64_t i = base + (uint64_t) j * 64;
+                if (i < n)
+                    low = lowPartAt(sLow, low, numLow, i);
+                vals[j] = low;
+            }
+        }
+    }
     /* tile-local exclusive prefix over the digits: thread t owns the `per` consecutive bins from t * per */
     {
         uint32_t mine = 0, mineAll = 0;         /* this tile's / the whole input's keys in my bins */
@@ -823,7 +924,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
     {
         const uint64_t i = base + (uint64_t) j * 64;
         const bool valid = i < n;
-        const uint32_t digit = (uint32_t) ((keys[j] >> shift) & mask);
+        const uint32_t digit = (uint32_t) ((keys[j] >> digitShift) & mask);
         uint64_t peers = __ballot(valid);
         for (uint32_t b = 0; b < digitBits; b++)
         {
@@ -846,38 +947,55 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
     __syncthreads();
     /* keys leave in tile-sorted order: each digit's run is one contiguous, coalesced burst */
     uint32_t out[SORT_ITEMS];
+    K word[SPREAD ? SORT_ITEMS : 1];           /* packed: the element of tile-sorted rank p, kept for its value */
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++)
     {
         const uint32_t p = threadIdx.x + k * PRIM_BLOCK;
         out[k] = 0;
+        if (SPREAD)
+            word[k] = (K) 0;
         if (p < tileCount)
         {
             const K key = sTile[p];
-            out[k] = tileBase[(uint32_t) ((key >> shift) & mask)] + p;
-            if (SPREAD)
+            out[k] = tileBase[(uint32_t) ((key >> digitShift) & mask)] + p;
+            if (SPREAD && packed)
+                word[k] = key;
+            else if (SPREAD)
                 out[k] += 1u + A.keyBase[(uint32_t) key];
             else if (keysOut != nullptr)
                 keysOut[out[k]] = key;
         }
     }
-    __syncthreads();
-    /* the values take the same route through the same buffer */
     uint32_t *sVals = reinterpret_cast<uint32_t *>(sTile);
-#pragma unroll
-    for (int j = 0; j < SORT_ITEMS; j++)
+    if (!(SPREAD && packed && oneLow))          /* (uniform over the workgroup) */
     {
-        const uint64_t i = base + (uint64_t) j * 64;
-        if (i < n)
-            sVals[dst[j]] = vals[j];
+        __syncthreads();
+        /* the values take the same route through the same buffer */
+#pragma unroll
+        for (int j = 0; j < SORT_ITEMS; j++)
+        {
+            const uint64_t i = base + (uint64_t) j * 64;
+            if (i < n)
+                sVals[dst[j]] = vals[j];
+        }
+        __syncthreads();
     }
-    __syncthreads();
 #pragma unroll
     for (int k = 0; k < SORT_ITEMS; k++)
     {
         const uint32_t p = threadIdx.x + k * PRIM_BLOCK;
         if (p < tileCount)
-            valsOut[out[k]] = sVals[p];
+        {
+            if (SPREAD && packed)
+            {
+                const uint32_t w = (uint32_t) word[SPREAD ? k : 0];
+                const uint32_t key = (((w >> digitShift) & (uint32_t) mask) << shift) | (oneLow ? lowFirst : sVals[p]);
+                valsOut[out[k] + 1u + A.keyBase[key]] = (w & ((1u << digitShift) - 1u)) + A.valueBias;
+            }
+            else
+                valsOut[out[k]] = sVals[p];
+        }
     }
 }
 
