@@ -837,7 +837,8 @@ static int treeBuildBatch(mlsgpu_tree *const *trees, const mlsgpu_tree_build *re
      * fit.  4 bytes less written and read again per entry (8 E of the 24 E the two passes move). */
     uint32_t idBits = 0;
     {
-        static const bool packedOff = getenv("MLSGPU_HIP_OCTREE_PACKED") != nullptr && atoi(getenv("MLSGPU_HIP_OCTREE_PACKED")) == 0;
+        const char *const env = getenv("MLSGPU_HIP_OCTREE_PACKED");      /* "0": two words per entry, as before (tests, A/B) */
+        const bool packedOff = env != nullptr && atoi(env) == 0;
         uint64_t most = 1;
         for (uint32_t k = 0; k < count; k++)
             most = std::max<uint64_t>(most, reqs[k].numSplats);

@@ -131,3 +131,17 @@ def test_every_tree_depth(ctx, levels):
     size = (side, side - 5, side - 8) if side > 8 else (side, side, side)
     commands, start, num_levels, mutated = gpu_build(ctx, cloud, 0, len(cloud), size, (2, 0, 1), 3, levels)
     compare_with_oracle(commands, start, mutated, cloud, 0, len(cloud), size, (2, 0, 1), 3, levels)
+
+
+@pytest.mark.parametrize("levels", [2, 6])
+def test_two_words_per_entry_route(ctx, levels, monkeypatch):
+    """The default route keeps ONE word per entry between the two passes of the entry sort (the low digit is the entry's
+    position, the rest of the key sits above the splat's number inside the bucket); MLSGPU_HIP_OCTREE_PACKED=0 is the
+    two-word form it replaced -- and what a bucket whose key and splat number do not fit a word together falls back to."""
+    from mlsgpu_amd import synth
+    monkeypatch.setenv("MLSGPU_HIP_OCTREE_PACKED", "0")
+    side = min(1 << (levels + 2), 256)
+    cloud = synth.uniform_cloud(40_000 + 77, float(side - 1), 0.5, 6.0, seed=2000 + levels)
+    size = (side, side - 5, side - 8) if side > 8 else (side, side, side)
+    commands, start, _, mutated = gpu_build(ctx, cloud, 77, 40_000, size, (2, 0, 1), 3, levels)
+    compare_with_oracle(commands, start, mutated, cloud, 77, 40_000, size, (2, 0, 1), 3, levels)
