@@ -380,13 +380,19 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
      * id is the tile's first id + that).  Key and id travel together through the reorder, so the ids need no pass of their
      * own: six workgroup barriers instead of eight, and 41 KB of LDS for a tile of 1024 splats (three workgroups per CU). */
     __shared__ uint32_t sEnt[ENT_CAP];          /* the tile's entries in (splat, slot) order; afterwards in the pass's order */
+    __shared__ uint32_t sMatch[WAVES][BINS];    /* per wave and digit: the lanes of HALF a wave that hold it (sortScatterKernel's
+                                                 * way of ranking, 32 lanes at a time: 64-bit words would cost the third workgroup
+                                                 * of a CU its LDS) */
     const uint32_t numBins = 1u << digitBits, dmask = numBins - 1;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t d = threadIdx.x; d < numBins; d += ENT_THREADS)
     {
 #pragma unroll
         for (int w = 0; w < WAVES; w++)
+        {
             waveBins[w][d] = 0;
+            sMatch[w][d] = 0u;
+        }
     }
     /* 1. the tile's entries, lined up in (splat, slot) order.  What the thread reads that does not depend on another read is
      * requested here, together: its slot mask, its splat, and the digit totals and tile offsets of the bins it owns in the
@@ -497,20 +503,29 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
         const uint32_t e = first + j * 64;
         const bool valid = e < tileCount;
         const uint32_t digit = ent[j] & dmask;
-        uint64_t peers = __ballot(valid);
-        for (uint32_t b = 0; b < digitBits; b++)
+        /* the lanes with the same digit, through LDS: see sortScatterKernel */
+#pragma unroll
+        for (uint32_t half = 0; half < 2; half++)       /* the lower lanes first: the order of the elements */
         {
-            const bool bit = (digit >> b) & 1u;
-            const uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
-        }
-        if (valid)
-        {
-            const uint32_t rank = popcBelow(peers);
-            const uint32_t dst = waveBins[wave][digit] + rank;
-            sEnt[dst] = ent[j];          /* (every wave took its elements into registers before the last two barriers) */
-            if (rank == 0)
-                waveBins[wave][digit] = dst + (uint32_t) __popcll(peers);
+            const bool mine = valid && (lane >> 5) == half;
+            const uint32_t bit = 1u << (lane & 31u);
+            if (mine)
+                atomicOr(&sMatch[wave][digit], bit);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t peers = mine ? sMatch[wave][digit] : 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (mine)
+            {
+                const uint32_t rank = (uint32_t) __popc(peers & (bit - 1u));
+                const uint32_t dst = waveBins[wave][digit] + rank;
+                sEnt[dst] = ent[j];      /* (every wave took its elements into registers before the last two barriers) */
+                if (rank == 0)
+                {
+                    waveBins[wave][digit] = dst + (uint32_t) __popc(peers);
+                    sMatch[wave][digit] = 0u;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
         __builtin_amdgcn_wave_barrier();
     }

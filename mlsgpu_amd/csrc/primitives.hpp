@@ -770,6 +770,12 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
     /* the tile is reordered in two phases through ONE buffer (keys, then values): half the LDS, twice the
      * resident workgroups, which is what this latency-bound kernel needs */
     __shared__ K sTile[SORT_TILE];
+    /* digits of up to 8 bits: the lanes of a wave that hold the same digit find each other through LDS -- every lane ORs its
+     * bit into the digit's 64-bit word, reads the word back (LDS operations of a wave execute in order) and the first of
+     * them clears it -- instead of one ballot and four vector instructions per digit BIT (the scatter was bound by issuing
+     * vector instructions, half of them these) */
+    enum { LDS_MATCH = BIN_BITS <= 8 };
+    __shared__ unsigned long long sMatch[LDS_MATCH ? PRIM_WAVES : 1][LDS_MATCH ? BINS : 1];
     __shared__ uint32_t sLow[SPREAD ? 256 : 1];
     __shared__ uint32_t sGroup[PRIM_WAVES][2];
     const SortScatterArgs<K> A = lanes.a[blockIdx.y];
@@ -799,7 +805,11 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
     {
 #pragma unroll
         for (int w = 0; w < PRIM_WAVES; w++)
+        {
             waveBins[w][d] = 0;
+            if (LDS_MATCH)
+                sMatch[w][d] = 0ull;
+        }
     }
     __syncthreads();
     const uint64_t base = tileFirst + (uint64_t) wave * SORT_WAVE_SPAN + lane;
@@ -925,12 +935,24 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
         const uint64_t i = base + (uint64_t) j * 64;
         const bool valid = i < n;
         const uint32_t digit = (uint32_t) ((keys[j] >> digitShift) & mask);
-        uint64_t peers = __ballot(valid);
-        for (uint32_t b = 0; b < digitBits; b++)
+        uint64_t peers;
+        if (LDS_MATCH)
         {
-            const bool bit = (digit >> b) & 1u;
-            const uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
+            if (valid)
+                atomicOr(&sMatch[wave][digit], 1ull << lane);
+            __builtin_amdgcn_wave_barrier();
+            peers = valid ? sMatch[wave][digit] : 0ull;
+            __builtin_amdgcn_wave_barrier();
+        }
+        else
+        {
+            peers = __ballot(valid);
+            for (uint32_t b = 0; b < digitBits; b++)
+            {
+                const bool bit = (digit >> b) & 1u;
+                const uint64_t m = __ballot(bit);
+                peers &= bit ? m : ~m;
+            }
         }
         dst[j] = 0;
         if (valid)
@@ -939,7 +961,11 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
             dst[j] = waveBins[wave][digit] + rank;
             sTile[dst[j]] = keys[j];
             if (rank == 0)
+            {
                 waveBins[wave][digit] = dst[j] + (uint32_t) __popcll(peers);
+                if (LDS_MATCH)
+                    sMatch[wave][digit] = 0ull;
+            }
         }
         /* LDS operations of one wave complete in program order, so the next round sees the update */
         __builtin_amdgcn_wave_barrier();
