@@ -774,8 +774,9 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
      * bit into the digit's 64-bit word, reads the word back (LDS operations of a wave execute in order) and the first of
      * them clears it -- instead of one ballot and four vector instructions per digit BIT (the scatter was bound by issuing
      * vector instructions, half of them these) */
-    enum { LDS_MATCH = BIN_BITS <= 8 };
+    enum { LDS_MATCH = BIN_BITS <= 8, HALF_MATCH = !LDS_MATCH };     /* wider digits: 32 lanes at a time, half the LDS */
     __shared__ unsigned long long sMatch[LDS_MATCH ? PRIM_WAVES : 1][LDS_MATCH ? BINS : 1];
+    __shared__ uint32_t sMatch32[HALF_MATCH ? PRIM_WAVES : 1][HALF_MATCH ? BINS : 1];
     __shared__ uint32_t sLow[SPREAD ? 256 : 1];
     __shared__ uint32_t sGroup[PRIM_WAVES][2];
     const SortScatterArgs<K> A = lanes.a[blockIdx.y];
@@ -809,6 +810,8 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
             waveBins[w][d] = 0;
             if (LDS_MATCH)
                 sMatch[w][d] = 0ull;
+            else
+                sMatch32[w][d] = 0u;
         }
     }
     __syncthreads();
@@ -946,13 +949,29 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
         }
         else
         {
-            peers = __ballot(valid);
-            for (uint32_t b = 0; b < digitBits; b++)
-            {
-                const bool bit = (digit >> b) & 1u;
-                const uint64_t m = __ballot(bit);
-                peers &= bit ? m : ~m;
-            }
+            /* two halves of 32 lanes, one after the other, through ONE 32-bit word per digit: a half's lanes OR their bits in,
+             * EVERY lane with the digit reads the word (the other half needs it for its rank and for the run's new end), the
+             * half's first lane with the digit clears it */
+            const uint32_t bit = 1u << (lane & 31u);
+            uint32_t lowerPeers = 0, upperPeers = 0;
+            if (valid && lane < 32)
+                atomicOr(&sMatch32[wave][digit], bit);
+            __builtin_amdgcn_wave_barrier();
+            if (valid)
+                lowerPeers = sMatch32[wave][digit];
+            __builtin_amdgcn_wave_barrier();
+            if (valid && lane < 32 && (lowerPeers & (bit - 1u)) == 0)
+                sMatch32[wave][digit] = 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (valid && lane >= 32)
+                atomicOr(&sMatch32[wave][digit], bit);
+            __builtin_amdgcn_wave_barrier();
+            if (valid)
+                upperPeers = sMatch32[wave][digit];
+            __builtin_amdgcn_wave_barrier();
+            if (valid && lane >= 32 && (upperPeers & (bit - 1u)) == 0)
+                sMatch32[wave][digit] = 0u;
+            peers = (uint64_t) lowerPeers | (uint64_t) upperPeers << 32;
         }
         dst[j] = 0;
         if (valid)
