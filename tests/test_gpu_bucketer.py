@@ -93,6 +93,19 @@ def test_big_level_takes_the_private_counters():
     assert len(got) > 100
 
 
+def test_private_counters_near_the_lds_limit(monkeypatch):
+    """39^3 finest counters (16 bits each) + the corrections of the coarser levels = 155 KB of a CU's 160 KB of LDS in ONE
+    workgroup: the launch works and counts right; one microblock more per axis (40^3: 165 KB) takes the plain kernel."""
+    from mlsgpu_amd import synth
+    monkeypatch.setenv("MLSGPU_HIP_BUCKET_PRIVATE_FROM", "0")
+    for blocks in (39, 40):
+        g = blocks * 63 + 1
+        splats = synth.uniform_cloud(300_000, float(g - 1), 2.0, 3.0, 78 + blocks)
+        grid = {"reference": (0.0, 0.0, 0.0), "spacing": 1.0, "extents": (0, g - 1, 0, g - 1, 0, g - 1)}
+        got, exp = both(splats, grid, 2_000, 255, 0, 63, 1 << 30)
+        assert len(got) > 100
+
+
 def test_rejects_an_empty_region():
     import mlsgpu_amd as m
     from mlsgpu_amd import binding as b
