@@ -88,10 +88,12 @@ def parse_args():
                    help="device workers per GPU of the farm legs (host splats in, meshes out).  Round 5, shells cloud, 8d region with "
                         "six spare items: 2 workers 33.5-34 ms per job (the host-to-device copies busy 0.90-0.92 of it), 4 workers "
                         "36.5-38 (0.80), 8 workers 41 (0.74): the link is the floor, and fewer streams queue less in front of it")
-    p.add_argument("--batch", type=int, default=4,
+    p.add_argument("--batch", type=int, default=6,
                    help="buckets a device worker takes through the path in lock-step (mlsgpu_hip_worker_process_batch: every "
                         "kernel has a bucket dimension, one set of launches and three host decisions per batch); 1 = bucket by "
-                        "bucket (mlsgpu_hip_worker_process)")
+                        "bucket (mlsgpu_hip_worker_process).  With the octree's kernels a quarter shorter than when 4 was chosen, "
+                        "6 or 8 read 1 %% better on every workload (cfg3 16.13 -> 15.9-16.0 ms, shells 11.27 -> 11.09, cfg4 slab "
+                        "10.16 -> 10.0)")
     p.add_argument("--marching-group", type=int, default=2,
                    help="of a batch's buckets, how many share one set of processCorners / marching launches (the octree build "
                         "takes the whole batch); 0 = all (mlsgpu_hip_worker_set_marching_group)")

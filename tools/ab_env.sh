@@ -11,7 +11,7 @@ for spec in "$@"; do
   name="${spec%%=*}"; setting="${spec#*=}"
   rm -rf /tmp/pp_$name
   if [ -n "$setting" ]; then export "$setting"; fi
-  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pp_$name -o run -- python3 bench.py --headline-only --no-timing --no-cross-check --workers 1 --steps 3 --warmup 1 $bargs > /dev/null 2>&1
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/pp_$name -o run -- python3 bench.py --headline-only --no-timing --no-cross-check --workers 1 --batch 4 --steps 3 --warmup 1 $bargs > /dev/null 2>&1
   if [ -n "$setting" ]; then unset "${setting%%=*}"; fi
   python3 tools/profile_summary.py stats /tmp/pp_$name gpurun_out/pp_$name.csv "$name" > /dev/null
   echo "$name: $(grep -i "$pat" gpurun_out/pp_$name.csv | head -3 | tr '\n' ' ')"

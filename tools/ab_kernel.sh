@@ -13,7 +13,7 @@ cp mlsgpu_amd/libmlsgpu_hip.so /tmp/orig.so
 for v in "$@"; do
   cp ab/$v.so mlsgpu_amd/libmlsgpu_hip.so
   rm -rf /tmp/pp_$v
-  timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/pp_$v -o run -- python3 bench.py --headline-only --no-timing --no-cross-check --workers 1 --steps 3 --warmup 1 > /dev/null 2>&1
+  timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/pp_$v -o run -- python3 bench.py --headline-only --no-timing --no-cross-check --workers 1 --batch 4 --steps 3 --warmup 1 > /dev/null 2>&1
   python3 tools/profile_summary.py stats /tmp/pp_$v gpurun_out/pp_$v.csv "$v" > /dev/null
   echo "$v: $(grep -i "$pat" gpurun_out/pp_$v.csv | head -3 | tr '\n' ' ')"
 done

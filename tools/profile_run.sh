@@ -1,5 +1,6 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (gpurun): the rocprofv3 passes DESIGN.md section 7 cites, summarised into gpurun_out/profiles_<tag>/
+# Runs ON THE GPU BOX (gpurun): the rocprofv3 passes DESIGN.md section 7 cites (one worker, FOUR buckets per octree launch: the
+# shape every round's per-launch figures are quoted on, whatever bench.py's default batch is), summarised into gpurun_out/profiles_<tag>/
 # (the raw .db files stay in /tmp: they are tens of MB each).  usage: bash tools/profile_run.sh r03
 # One pass per counter set, never --pmc together with a trace (the pool's rule); python3 itself after `--`.
 set -u
@@ -8,8 +9,8 @@ cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/profiles_$tag
 mkdir -p "$out"
-cmd="bench.py --headline-only --no-timing --no-cross-check --workers 1 --steps 5 --warmup 1"
-one="bench.py --headline-only --no-timing --no-cross-check --workers 1 --steps 1 --warmup 0"
+cmd="bench.py --headline-only --no-timing --no-cross-check --workers 1 --batch 4 --steps 5 --warmup 1"
+one="bench.py --headline-only --no-timing --no-cross-check --workers 1 --batch 4 --steps 1 --warmup 0"
 rm -rf /tmp/prof_$tag /tmp/pmc_rd_$tag /tmp/pmc_wr_$tag /tmp/pmc_fetch_$tag
 rocprofv3 --kernel-trace --stats -d /tmp/prof_$tag -o run -- python3 $cmd > "$out/stats_run.log" 2>&1
 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum -d /tmp/pmc_rd_$tag -o run -- python3 $one > "$out/rd_run.log" 2>&1

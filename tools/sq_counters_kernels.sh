@@ -5,7 +5,7 @@ set -u
 label=$1; out=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
-args="bench.py --headline-only --no-timing --no-cross-check --workers 1 --steps 1 --warmup 0 $*"
+args="bench.py --headline-only --no-timing --no-cross-check --workers 1 --batch 4 --steps 1 --warmup 0 $*"
 rm -rf /tmp/sqk_a /tmp/sqk_b /tmp/sqk_c
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY -d /tmp/sqk_a -o run -- python3 $args > /dev/null 2>&1
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES -d /tmp/sqk_b -o run -- python3 $args > /dev/null 2>&1
