@@ -107,6 +107,11 @@ int mlsgpu_hip_ctx_create(int device, void *stream, mlsgpu_ctx **out);
 void mlsgpu_hip_ctx_destroy(mlsgpu_ctx *ctx);
 void *mlsgpu_hip_ctx_stream(mlsgpu_ctx *ctx);
 int mlsgpu_hip_ctx_synchronize(mlsgpu_ctx *ctx);
+/* Calls that work on the context keep their device scratch from call to call (mlsgpu_hip_bucket: the member lists, the kept
+ * ranges and the counters of every recursion depth -- 24 GB behind a 10^9-splat cloud; the reference's Bucket::bucket
+ * holds its counters and ranges on the host only for the duration of a call, src/bucket_impl.h:439-560).  This waits for the
+ * context's stream and hands that memory back; lists handed to a callback must have been consumed.  Returns the error code. */
+int mlsgpu_hip_ctx_release_scratch(mlsgpu_ctx *ctx);
 int mlsgpu_hip_device_count(int *count);
 
 /* Device / pinned memory helpers (CLH::PinnedMemory, src/clh.h:334-477; cl::Buffer). */

@@ -150,6 +150,7 @@ def lib():
     sig("mlsgpu_hip_ctx_destroy", None, vp)
     sig("mlsgpu_hip_ctx_stream", vp, vp)
     sig("mlsgpu_hip_ctx_synchronize", C.c_int, vp)
+    sig("mlsgpu_hip_ctx_release_scratch", C.c_int, vp)
     sig("mlsgpu_hip_device_count", C.c_int, P(C.c_int))
     sig("mlsgpu_hip_malloc", C.c_int, vp, sz, P(vp))
     sig("mlsgpu_hip_free", C.c_int, vp, vp)
@@ -345,6 +346,10 @@ class Context:
 
     def synchronize(self):
         check(lib().mlsgpu_hip_ctx_synchronize(self.h))
+
+    def release_scratch(self):
+        """Hands back the device scratch calls on this context keep from call to call (the bucketer's lists and counters)."""
+        check(lib().mlsgpu_hip_ctx_release_scratch(self.h))
 
     def set_timing(self, enabled):
         check(lib().mlsgpu_hip_ctx_set_timing(self.h, int(enabled)))

@@ -233,6 +233,15 @@ int mlsgpu_ctx::scanFlags(uint32_t **flags, uint32_t *epoch)
     return MLSGPU_OK;
 }
 
+MLSGPU_API int mlsgpu_hip_ctx_release_scratch(mlsgpu_ctx *ctx)
+{
+    REQUIRE(ctx != nullptr, MLSGPU_ERR_INVALID);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->scratchCache.clear();
+    return MLSGPU_OK;
+}
+
 MLSGPU_API void mlsgpu_hip_ctx_destroy(mlsgpu_ctx *ctx)
 {
     if (!ctx)

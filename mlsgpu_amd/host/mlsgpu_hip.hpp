@@ -65,6 +65,7 @@ public:
     mlsgpu_ctx *get() const { return h; }
     void *stream() const { return mlsgpu_hip_ctx_stream(h); }
     void finish() const { check(mlsgpu_hip_ctx_synchronize(h)); }            // cl::CommandQueue::finish
+    void releaseScratch() const { check(mlsgpu_hip_ctx_release_scratch(h)); }   // what Bucket::bucket keeps between calls
     void setTiming(bool on) const { check(mlsgpu_hip_ctx_set_timing(h, on)); } // --statistics-cl
 };
 

@@ -106,6 +106,31 @@ def test_private_counters_near_the_lds_limit(monkeypatch):
         assert len(got) > 100
 
 
+def test_scratch_can_be_released_between_calls():
+    """The bucketer keeps its lists and counters with the context; release_scratch hands them back (device memory in use
+    drops), and the next call allocates afresh and finds the same leaves."""
+    import torch
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as b, synth
+    n, g = 2_000_000, 700
+    splats = synth.uniform_cloud(n, float(g - 1), 2.0, 3.0, 5)
+    ctx = m.Context(0)
+    dev = m.DeviceBuffer(ctx, array=splats)
+    ext = (0, g - 1, 0, g - 1, 0, g - 1)
+    first = b.bucket_cloud(ctx, dev, n, (0.0, 0.0, 0.0), 1.0, ext, 100_000, 255, 0, 63, 1 << 30)
+    held = torch.cuda.mem_get_info(0)[0]
+    ctx.release_scratch()
+    assert torch.cuda.mem_get_info(0)[0] >= held + n * 8            # at least the kept ranges came back
+    again = b.bucket_cloud(ctx, dev, n, (0.0, 0.0, 0.0), 1.0, ext, 100_000, 255, 0, 63, 1 << 30)
+    assert len(again) == len(first) > 10
+    for x, y in zip(first, again):
+        assert x["extents"] == y["extents"]
+        np.testing.assert_array_equal(x["ids"], y["ids"])
+    ctx.release_scratch()
+    dev.free()
+    ctx.close()
+
+
 def test_rejects_an_empty_region():
     import mlsgpu_amd as m
     from mlsgpu_amd import binding as b
