@@ -278,7 +278,8 @@ __global__ __launch_bounds__(ENT_THREADS) void entryHistKernel(Lanes<EntryHistAr
     __syncthreads();
     /* a thread's splats are neighbours in the cloud (one 32 x ENT_PER-byte stretch): both records are requested before the
      * first is looked at */
-    const uint64_t i0 = (uint64_t) blockIdx.x * ENT_TILE + (uint64_t) threadIdx.x * ENT_PER;
+    const uint32_t tile = tileOfWorkgroup(blockIdx.x, A.numTiles);      /* its counters' lines are completed in one XCD's L2 */
+    const uint64_t i0 = (uint64_t) tile * ENT_TILE + (uint64_t) threadIdx.x * ENT_PER;
     float4 pr[ENT_PER];
 #pragma unroll
     for (int s_ = 0; s_ < ENT_PER; s_++)
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(ENT_THREADS) void entryHistKernel(Lanes<EntryHistAr
     uint32_t *const hist = A.hist;
     const uint32_t numTiles = A.numTiles;
     for (uint32_t d = threadIdx.x; d < numBins; d += ENT_THREADS)
-        hist[(uint64_t) d * numTiles + blockIdx.x] = bins[d];
+        hist[(uint64_t) d * numTiles + tile] = bins[d];
 }
 
 struct EntryTotalArgs
@@ -397,7 +398,8 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     /* 1. the tile's entries, lined up in (splat, slot) order.  What the thread reads that does not depend on another read is
      * requested here, together: its slot mask, its splat, and the digit totals and tile offsets of the bins it owns in the
      * scan further down (one round of memory latency instead of three). */
-    const uint64_t i0 = (uint64_t) blockIdx.x * ENT_TILE + (uint64_t) threadIdx.x * ENT_PER;
+    const uint32_t tile = tileOfWorkgroup(blockIdx.x, numTiles);
+    const uint64_t i0 = (uint64_t) tile * ENT_TILE + (uint64_t) threadIdx.x * ENT_PER;
     uint64_t note[ENT_PER];
     uint32_t cnt = 0;
 #pragma unroll
@@ -406,7 +408,7 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     const uint32_t per = numBins > ENT_THREADS ? numBins / ENT_THREADS : 1;
     const uint32_t d0 = threadIdx.x * per;
     const uint32_t totalOfBin = d0 < numBins ? digitTotals[d0] : 0u;
-    const uint32_t histOfBin = d0 < numBins ? hist[(uint64_t) d0 * numTiles + blockIdx.x] : 0u;
+    const uint32_t histOfBin = d0 < numBins ? hist[(uint64_t) d0 * numTiles + tile] : 0u;
 #pragma unroll
     for (int s_ = 0; s_ < ENT_PER; s_++)
         cnt += (uint32_t) __popc((uint32_t) note[s_] & 0xFFu);
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
             for (uint32_t k = 0; k < per; k++)
             {
                 const uint32_t d = d0 + k;
-                tileBase[d] = base + (k == 0 ? histOfBin : hist[(uint64_t) d * numTiles + blockIdx.x]) - run;
+                tileBase[d] = base + (k == 0 ? histOfBin : hist[(uint64_t) d * numTiles + tile]) - run;
                 base += k == 0 ? totalOfBin : digitTotals[d];
 #pragma unroll
                 for (int w = 0; w < WAVES; w++)
@@ -532,7 +534,7 @@ __global__ __launch_bounds__(ENT_THREADS) __attribute__((amdgpu_waves_per_eu(6, 
     __syncthreads();
     /* 3. out, in the order of the pass: the run of a digit is contiguous in the tile and in memory */
     const uint32_t idBits = A.idBits;
-    const uint32_t tileFirstId = blockIdx.x * ENT_TILE + (idBits != 0 ? 0u : P.firstSplat);
+    const uint32_t tileFirstId = tile * ENT_TILE + (idBits != 0 ? 0u : P.firstSplat);
 #pragma unroll
     for (int k = 0; k < MAX_ROUNDS; k++)
     {

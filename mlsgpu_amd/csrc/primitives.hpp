@@ -67,6 +67,20 @@ __device__ __forceinline__ U3 readLaneT(U3 v, int lane)
     return U3{readLane(v.a, lane), readLane(v.b, lane), readLane(v.c, lane)};
 }
 
+/* Workgroup -> tile for the kernels that write or read ONE word per (digit, tile) of a [digit][tile] array.  Workgroups are
+ * dealt round-robin to the 8 XCDs, each with its own write-back L2: with tile = workgroup id, the 32 words of a 128-byte line
+ * of a digit's row come from 32 workgroups on 8 different XCDs, and every L2 writes its four words back as a masked partial
+ * line (10^9 pairs in 1 024 digits: 11.75 GB of write requests for 2.1 GB of counters).  Here runs of 32 consecutive tiles stay
+ * on one XCD (runs dealt round-robin), so a line is completed in ONE L2.  Any bijection gives the same results. */
+__device__ __forceinline__ uint32_t tileOfWorkgroup(uint32_t id, uint32_t numTiles)
+{
+    const uint32_t full = numTiles / 256u * 256u;
+    if (id >= full)
+        return id;
+    const uint32_t j = id & 255u;
+    return (id - j) + (j & 7u) * 32u + (j >> 3);
+}
+
 /* ------------------------------------------------------------------ scan */
 
 /* Every kernel here has a bucket dimension (common.hpp, Lanes): blockIdx.y is the lane, the lane's arguments are one
@@ -579,7 +593,8 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(Lanes<SortHistArgs<
     const uint32_t digitShift = packed ? A.idBits : shift;
     const K *const keys = A.keys;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t tileFirst = (uint64_t) blockIdx.x * SORT_TILE;
+    const uint32_t tile = tileOfWorkgroup(blockIdx.x, A.numTiles);
+    const uint64_t tileFirst = (uint64_t) tile * SORT_TILE;
     const uint64_t base = tileFirst + (uint64_t) wave * SORT_WAVE_SPAN + lane;
     const K lowMask = (K) (((K) 1 << shift) - 1);
     /* all of the thread's keys are requested before the first is counted (one round of memory latency, not four) -- and,
@@ -661,7 +676,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortHistKernel(Lanes<SortHistArgs<
     uint32_t *const hist = A.hist;
     const uint32_t numTiles = A.numTiles;
     for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
-        hist[(uint64_t) d * numTiles + blockIdx.x] = bins[d];
+        hist[(uint64_t) d * numTiles + tile] = bins[d];
     if (KEY_COUNTS && oneLow)
     {
         for (uint32_t d = threadIdx.x; d < numBins; d += PRIM_BLOCK)
@@ -788,7 +803,8 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
     uint64_t n = A.n;
     if (A.nDev != nullptr && *A.nDev < n)
         n = *A.nDev;
-    const uint64_t tileFirst = (uint64_t) blockIdx.x * SORT_TILE;
+    const uint32_t tile = tileOfWorkgroup(blockIdx.x, A.numTiles);     /* its words of the [digit][tile] array: one L2's */
+    const uint64_t tileFirst = (uint64_t) tile * SORT_TILE;
     if (tileFirst >= n)
         return;
     const K *const keysIn = A.keysIn;
@@ -837,7 +853,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void sortScatterKernel(Lanes<SortScatte
     {
         const bool mineToo = (uint32_t) k < per && d0 + k < numBins;
         totalOf[k] = mineToo ? digitTotals[d0 + k] : 0u;
-        histOf[k] = mineToo ? hist[(uint64_t) (d0 + k) * numTiles + blockIdx.x] : 0u;
+        histOf[k] = mineToo ? hist[(uint64_t) (d0 + k) * numTiles + tile] : 0u;
     }
     if (packed)
     {
