@@ -248,6 +248,10 @@ struct CodeView
  * sixteen, and (the kernel is bound by latency times resident waves, as latticeVerticesKernel) a wave has four rows' worth
  * of independent work behind one round of loads.  The row totals feed the swathe totals, the per-slice histogram and, in the
  * lattice weld, each row's first cell / index slot -- a 256x smaller scan than one over cells. */
+#ifndef CELLCODE_RUN
+#define CELLCODE_RUN 64
+#endif
+/* (the lattice kernels -- mask, vertices, triangle rows -- were tried the same way: no change, they do not wait for those rows) */
 struct CellCodeArgs
 {
     uint8_t *codes;
@@ -261,10 +265,13 @@ __global__ __launch_bounds__(256) void cellCodeKernel(Lanes<CellCodeArgs> lanes)
 {
     const CellCodeArgs A = lanes.a[blockIdx.y];
     const uint32_t lane = threadIdx.x & 63;
-    const uint32_t group = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const uint32_t cw = A.cw, ch = A.ch, zFirst = A.zFirst;
     const uint32_t slices = ch > 0 ? A.numRows / ch : 0u;
     const uint32_t groupsY = (ch + 1) / 2, groupsZ = (slices + 1) / 2;
+    /* a group shares a third of its corner rows with the group one slice pair up, groupsY groups on: runs of CELLCODE_RUN
+     * workgroups (a few slice pairs) stay on one XCD, whose L2 then serves that third */
+    const uint32_t wg = runOfWorkgroup<CELLCODE_RUN>(blockIdx.x, (groupsY * groupsZ + 3) / 4);
+    const uint32_t group = __builtin_amdgcn_readfirstlane(wg * 4 + (threadIdx.x >> 6));
     if (group >= groupsY * groupsZ)
         return;
     uint8_t *const codes = A.codes;

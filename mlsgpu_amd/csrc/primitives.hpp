@@ -72,14 +72,17 @@ __device__ __forceinline__ U3 readLaneT(U3 v, int lane)
  * of a digit's row come from 32 workgroups on 8 different XCDs, and every L2 writes its four words back as a masked partial
  * line (10^9 pairs in 1 024 digits: 11.75 GB of write requests for 2.1 GB of counters).  Here runs of 32 consecutive tiles stay
  * on one XCD (runs dealt round-robin), so a line is completed in ONE L2.  Any bijection gives the same results. */
-__device__ __forceinline__ uint32_t tileOfWorkgroup(uint32_t id, uint32_t numTiles)
+template<uint32_t RUN>
+__device__ __forceinline__ uint32_t runOfWorkgroup(uint32_t id, uint32_t count)
 {
-    const uint32_t full = numTiles / 256u * 256u;
+    /* RUN consecutive work items per XCD, the runs dealt round-robin; the items past the last whole group of 8 runs as they come */
+    const uint32_t full = count / (8u * RUN) * (8u * RUN);
     if (id >= full)
         return id;
-    const uint32_t j = id & 255u;
-    return (id - j) + (j & 7u) * 32u + (j >> 3);
+    const uint32_t j = id % (8u * RUN);
+    return (id - j) + (j & 7u) * RUN + (j >> 3);
 }
+__device__ __forceinline__ uint32_t tileOfWorkgroup(uint32_t id, uint32_t numTiles) { return runOfWorkgroup<32>(id, numTiles); }
 
 /* ------------------------------------------------------------------ scan */
 
