@@ -363,6 +363,9 @@ def main():
     kernel_stats = {}
     ksteps = max(1, min(args.steps, 10))
     if not args.no_timing:
+        # at FOUR buckets per set of launches, the shape every round's per-stage figures are quoted on (with more, a lone
+        # instrumented worker's GPU runs dry between sets and an event pair then times the host's next submission)
+        workers[0].set_batch(min(batch, 4))
         ctx.reset_stats()
         ctx.set_timing(True)
         for _ in range(ksteps):
@@ -370,6 +373,7 @@ def main():
             run_buckets(workers[0], ctx, buckets, m.binding.SizeCollector())
         ctx.set_timing(False)
         kernel_stats = dict(ctx.stats())
+        workers[0].set_batch(batch)
 
     # ---- one worker alone, nothing instrumented: what the host decisions and launch gaps of a bucket cost when no other
     # worker fills them (the instrumented device.compute above carries two event records per launch) ----
