@@ -97,8 +97,8 @@ def parse_args():
     p.add_argument("--marching-group", type=int, default=2,
                    help="of a batch's buckets, how many share one set of processCorners / marching launches (the octree build "
                         "takes the whole batch); 0 = all (mlsgpu_hip_worker_set_marching_group)")
-    p.add_argument("--variant", type=int, default=4, choices=[1, 4],
-                   help="MLS kernel: 4 sub-block culling + cube streams (default), 1 the reference's structure")
+    p.add_argument("--variant", type=int, default=5, choices=[1, 4, 5],
+                   help="MLS kernel: 5 sub-block culling + matrix-core prefilter (default), 4 sub-block culling + cube streams, 1 the reference's structure")
     p.add_argument("--leg-steps", type=int, default=3, help="passes of every secondary leg")
     p.add_argument("--legs", default="all", choices=["all", "none"],
                    help="none: only the timed region, its roofline and (N > 1) the in-run per-GPU reference; all: the secondary legs "
@@ -520,7 +520,7 @@ def main():
                                 "mutates them, as the reference's does)" if args.restore_splats else
                                 "processed in place: the workers keep them intact (non-mutating tree build, processCorners takes "
                                 "1/r^2 while staging; bit-identical output), so nothing is restored"),
-            "mls_variant": {1: "basic", 4: "culled+cube-streams"}[args.variant],
+            "mls_variant": {1: "basic", 4: "culled+cube-streams", 5: "culled+matrix-prefilter"}[args.variant],
             "sharding": "one process per GPU, rank r owns z-slab r (25 buckets); no data-path collective" if world > 1
                         else "single GPU",
             "triangles_per_step": triangles,

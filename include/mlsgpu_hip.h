@@ -195,9 +195,11 @@ int mlsgpu_hip_mls_enqueue(mlsgpu_mls *mls, float *dField, uint64_t pitch, uint6
                            const mlsgpu_swathe *swathe);
 /* Fills *gen so the functor can be passed to mlsgpu_hip_marching_generate (alignment = wgs = {8,8,8}). */
 int mlsgpu_hip_mls_generator(mlsgpu_mls *mls, mlsgpu_generator *gen);
-/* Selects the kernel: 4 = the default (sub-block culling + one splat stream per 2x2x2 cube of corners), 1 = the
- * reference's structure (every corner walks every listed splat), kept for A/B.  Bit-identical results.  Other values are
- * MLSGPU_ERR_INVALID (0, 2 and 3 were intermediate designs of earlier rounds). */
+/* Selects the kernel: 5 = the default (sub-block culling + a bf16 matrix-core prefilter of the distance test; the
+ * accumulation runs under the reference's own test), 4 = round 5's default (sub-block culling + one splat stream per
+ * 2x2x2 cube of corners), 1 = the reference's structure (every corner walks every listed splat); 4 and 1 are kept for
+ * A/B.  Bit-identical results.  Other values are MLSGPU_ERR_INVALID (0, 2 and 3 were intermediate designs of earlier
+ * rounds). */
 int mlsgpu_hip_mls_set_variant(mlsgpu_mls *mls, int variant);
 /* Measurement aid: with a non-NULL device array of MLSGPU_MLS_STATS_WORDS uint64 the next enqueues run an instrumented
  * kernel that adds [0] listed splats (Sigma L of SURVEY 8d), [1] (corner, splat) distance tests executed, [2] hits (H);
@@ -205,8 +207,11 @@ int mlsgpu_hip_mls_set_variant(mlsgpu_mls *mls, int variant);
  * iterations as the LONGEST of its 64 lanes' hit lists: [3] drain calls, [4] iterations they ran (sum of the longest
  * list), [5] the iterations if every two consecutive calls of a wave were one call, [6] if a whole round of staged splats
  * were one call, [7] if a whole block were; [8 + n], n = 0 .. 32: lanes that had n hits in a drain call.  Lane
- * utilisation of the drain = [2] / (64 x [4]).  Results are unchanged; NULL switches back to the production kernel. */
-#define MLSGPU_MLS_STATS_WORDS 41
+ * utilisation of the drain = [2] / (64 x [4]).  Kernel 5: [1] = (corner, splat) pairs the matrix prefilter evaluated,
+ * [5] = 0, n = CANDIDATES of a lane in a drain call, [41] candidates the prefilter handed to the drain, [42] hits of the
+ * reference's test that the prefilter missed (its superset property: must be 0).  Results are unchanged; NULL switches
+ * back to the production kernel. */
+#define MLSGPU_MLS_STATS_WORDS 43
 int mlsgpu_hip_mls_set_stats(mlsgpu_mls *mls, uint64_t *dCounters);
 
 /* ---- Marching (src/marching.h:494-608) ---- */

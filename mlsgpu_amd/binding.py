@@ -16,7 +16,7 @@ SPLAT_DTYPE = np.dtype([("position", np.float32, 3), ("radius", np.float32),
 SHAPE_SPHERE, SHAPE_PLANE = 0, 1
 
 
-MLS_STATS_WORDS = 41       # MLSGPU_MLS_STATS_WORDS
+MLS_STATS_WORDS = 43       # MLSGPU_MLS_STATS_WORDS
 
 
 class MlsError(Exception):
@@ -555,6 +555,10 @@ class MlsFunctor:
 
     def set_variant(self, variant):
         check(lib().mlsgpu_hip_mls_set_variant(self.h, variant))
+
+    def set_stats(self, counters):
+        """counters: DeviceBuffer of MLS_STATS_WORDS uint64 (or None): see mlsgpu_hip_mls_set_stats."""
+        check(lib().mlsgpu_hip_mls_set_stats(self.h, counters.ptr if counters else None))
 
     def alignment(self):
         return self.wgs

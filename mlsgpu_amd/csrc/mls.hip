@@ -37,7 +37,7 @@ struct mlsgpu_mls
 {
     mlsgpu_ctx *ctx = nullptr;
     int shape = MLSGPU_SHAPE_SPHERE;
-    int variant = 4;             /* culled + cube streams: the fastest on both BASELINE clouds; 1 = the reference's loop structure (variants 0, 2, 3 were removed in round 4) */
+    int variant = 5;             /* sub-block culling + matrix-core prefilter; 4 = culled + cube streams (round 5's default); 1 = the reference's loop structure (variants 0, 2, 3 were removed in round 4) */
     const mlsgpu_splat *dSplats = nullptr;
     const int32_t *dCommands = nullptr;
     const int32_t *dStart = nullptr;
@@ -675,6 +675,361 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     A.field[row * (int64_t) A.pitch + (wx + lx)] = f;
 }
 
+/*
+ * Variant 5 ("matrix prefilter").  Variant 4 is bound by issuing vector instructions, and close to half of them only FIND
+ * hits (the per-cube cull and the distance tests); the matrix pipe is idle.  The distance test is a contraction in
+ * disguise: with a = splat position - block origin and c' in {0..7}^3 the corner's coordinates inside the block,
+ *     d - cutoff = invr2 * (|c'|^2 - 2 a.c' + |a|^2) - 0.99
+ * is the dot product of a per-corner row [c'x, c'y, c'z, |c'|^2, 1] (small integers: exact in bf16) with a per-splat
+ * column [-2 invr2 ax, -2 invr2 ay, -2 invr2 az, invr2, invr2 |a|^2 - 0.99 - margin], each f32 of which is the exact sum
+ * of three bf16 pieces (8 + 8 + 8 significand bits): 15 of the 16 k-slots of ONE v_mfma_f32_32x32x16_bf16, every product
+ * exact, f32 accumulation.  One lane per staged splat prepares the column at staging (beside the sub-block masks, as
+ * before); a wave compacts a ROUND's relevant splats into its slot table and walks them in tiles of 32: the splats are the
+ * rows (A), the sub-block's 64 corners the columns of two MFMAs (B: lane constants), a lane receives 16 + 16 results
+ * for its column and packs their sign bits with 32 v_alignbit; one v_permlane32_swap brings the two halves of a corner's 32
+ * bits to the lane that owns the corner.  The rows of a tile are dealt so that splat s of the tile ends up in bit 31 - s:
+ * the drain walks the mask from the top, in list order, as in variant 4.
+ *
+ * The prefilter only has to be a SUPERSET of the reference's hits: the drain recomputes d exactly as the reference does
+ * and accumulates under `d < cutoff` (kernels/mls.cl:371-373), so results are bit-identical by construction.  Superset:
+ * every term of the contraction is bounded by T = |invr2| (|a|_1 + 21)^2 (|c'|_1 <= 21); rounding a, the five column
+ * values, the reference's own d and the matrix unit's f32 accumulation (exact products, <= 16 roundings, each <= one ulp of a
+ * partial sum <= T whether it rounds or truncates) move the difference by less than 40 x 2^-23 T; margin = 2^-16 T =
+ * 128 x 2^-23 T.  (d near the cutoff needs T >= 0.99, so pieces lost to bf16 underflow, < 2^-126, do not count.)  A column
+ * with T >= 1e30 or not finite (which includes 1/r^2 = -inf, never culled) is [0, 0, 0, 0, -1]: a candidate for every
+ * corner.  A record with a NaN keeps its empty sub-block mask.  The instrumented build checks the superset on every tile
+ * (stats word 6: exact hits the mask missed, must be 0).  False positives: 0.1-0.3 % of the candidates.
+ */
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+/* the three bf16 pieces of an f32, most significant first, as the HIGH halves of three words (exact: see above) */
+__device__ __forceinline__ void splitBf16(float x, uint32_t &hi, uint32_t &mid, uint32_t &lo)
+{
+    hi = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(hi);
+    mid = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(mid);
+    lo = __float_as_uint(r2) & 0xFFFF0000u;
+}
+
+/* words of two bf16: element 0 in the low half */
+__device__ __forceinline__ uint32_t packHi(uint32_t e0, uint32_t e1)
+{
+    return __builtin_amdgcn_perm(e1, e0, 0x07060302u);     /* {e1[31:16], e0[31:16]} */
+}
+
+#define MATRIX_STAGE 512
+#define MATRIX_SLOTS 448
+#ifndef MLSGPU_MLS5_WAVES
+#define MLSGPU_MLS5_WAVES 8
+#endif
+
+template<int SHAPE, bool STATS>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MLSGPU_MLS5_WAVES, MLSGPU_MLS5_WAVES)))
+void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
+{
+    __shared__ float4 sPosRad[MATRIX_STAGE];
+    __shared__ float4 sNormQ[MATRIX_STAGE];
+    __shared__ uint4 sColLo[MATRIX_STAGE];      /* k = 0..7 of a splat's column: x pieces, y pieces, constant hi, mid */
+    __shared__ uint4 sColHi[MATRIX_STAGE];      /* k = 8..15: z pieces, 1/r^2 pieces, constant lo, 0 */
+    __shared__ uint8_t sMask[MATRIX_STAGE];
+    __shared__ uint16_t sSlot[8][MATRIX_SLOTS + 32];  /* per wave: byte offsets of the round's relevant splats (flushed when
+                                                       * full), a tile of slack; 40 KB in all: four workgroups per CU */
+    __shared__ uint32_t sHist[STATS ? 33 : 1];
+
+    const MlsArgs A = lanes.a[blockIdx.y];
+    if (blockIdx.x >= A.numBlocks)
+        return;
+    if (STATS)
+    {
+        if (threadIdx.x < 33)
+            sHist[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    const uint32_t bid = xcdRemap(blockIdx.x, A.numBlocks, A.xcdChunk);
+    const uint32_t gx = bid % A.blocksX, gy = (bid / A.blocksX) % A.blocksY, gz = bid / (A.blocksX * A.blocksY);
+    const int wx = (int) (gx * 8), wy = (int) (gy * 8), wz = (int) (gz * 8 + A.zFirst);
+    const uint32_t sub = A.startShift / 3;
+    const uint32_t code = spread3((uint32_t) wx >> sub) | (spread3((uint32_t) wy >> sub) << 1) | (spread3((uint32_t) wz >> sub) << 2);
+    int32_t pos = A.start[code];
+
+    const uint32_t tid = threadIdx.x;
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    const int lx = (int) ((wave & 1) * 4 + (lane & 3));
+    const int ly = (int) (((wave >> 1) & 1) * 4 + ((lane >> 2) & 3));
+    const int lz = (int) ((wave >> 2) * 4 + (lane >> 4));
+
+    float f = __int_as_float(0x7FC00000);
+    if (pos >= 0)       /* uniform over the workgroup */
+    {
+        const float cx = (float) (wx + lx + A.ox), cy = (float) (wy + ly + A.oy), cz = (float) (wz + lz + A.oz);
+        /* wave-uniform floats live in scalar registers (a float made by a vector instruction would be hoisted out of the
+         * loops into a vector register each: twelve of the kernel's 64) */
+        auto uniformFloat = [](int v)
+        {
+            float out;          /* (the builtin is folded away for a value the compiler knows to be uniform) */
+            asm("v_readfirstlane_b32 %0, %1" : "=s"(out) : "v"((float) v));
+            return out;
+        };
+        const float bx0 = uniformFloat(wx + A.ox), by0 = uniformFloat(wy + A.oy), bz0 = uniformFloat(wz + A.oz);
+        const float boxLo[3][2] = {{bx0, uniformFloat(wx + A.ox + 4)}, {by0, uniformFloat(wy + A.oy + 4)}, {bz0, uniformFloat(wz + A.oz + 4)}};
+        const float boxHi[3][2] = {{uniformFloat(wx + A.ox + 3), uniformFloat(wx + A.ox + 7)}, {uniformFloat(wy + A.oy + 3), uniformFloat(wy + A.oy + 7)},
+                                   {uniformFloat(wz + A.oz + 3), uniformFloat(wz + A.oz + 7)}};
+        Fit fit;
+        fitInit(fit);
+        unsigned long long nListed = 0, nTests = 0, nCand = 0, nMissed = 0;
+        uint32_t drainCalls = 0, sumMost = 0, sumMostRound = 0, roundCnt = 0;
+        typedef __attribute__((address_space(3))) uint16_t LdsSlot;
+        LdsSlot *const mySlots = (LdsSlot *) sSlot[wave];
+        f32x2 sWpxy = {0.0f, 0.0f}, sWnxy = {0.0f, 0.0f};
+        const f32x2 cxy = {cx, cy};
+
+        /* B operands: lane l = column n = l & 31 of both MFMAs, k = 8 (l >> 5) + j.  MFMA j covers the corners
+         * n + 32 j of the sub-block (z layers 2 j, 2 j + 1); coordinates relative to the block origin */
+        uint4 bFrag[2];
+        {
+            const uint32_t n = lane & 31u, h = lane >> 5;
+#pragma unroll
+            for (uint32_t j = 0; j < 2; j++)
+            {
+                const uint32_t q = n + 32u * j;
+                const uint32_t qx = (wave & 1u) * 4u + (q & 3u), qy = ((wave >> 1) & 1u) * 4u + ((q >> 2) & 3u), qz = (wave >> 2) * 4u + (q >> 4);
+                const uint32_t u = h ? qz : qx, v = h ? qx * qx + qy * qy + qz * qz : qy;
+                const uint32_t ub = __float_as_uint((float) u), vb = __float_as_uint((float) v);     /* exact in bf16 */
+                bFrag[j] = make_uint4(packHi(ub, ub), packHi(ub, vb), packHi(vb, vb), 0x3F803F80u);
+            }
+        }
+        /* A operand: lane l holds row m = l & 31, which carries splat s(m) of the tile so that the sign bits line up in
+         * list order: row 8 (r >> 2) + 4 half + (r & 3) <-> splat 16 half + r */
+        const uint32_t rowM = lane & 31u;
+        const uint32_t rowSplat = 16u * ((rowM >> 2) & 1u) + 4u * (rowM >> 3) + (rowM & 3u);
+        const char *const colBase = (lane >> 5) ? (const char *) sColHi : (const char *) sColLo;
+
+        /* every slot that is ever read is a valid offset: zero until written */
+        for (uint32_t i = lane; i < MATRIX_SLOTS + 32; i += 64)
+            sSlot[wave][i] = 0;
+
+        /* accumulate this lane's candidates of one tile, in list order, under the reference's own test */
+        auto drain = [&](uint32_t cur, LdsSlot *chunk)
+        {
+            if (STATS)
+            {
+                const uint32_t cnt = (uint32_t) __popc(cur);
+                drainCalls++;
+                sumMost += waveMax(cnt);
+                atomicAdd(&sHist[cnt], 1u);
+                roundCnt += cnt;
+                nCand += waveSum(cnt);
+            }
+            while (cur != 0)
+            {
+                const uint32_t t = (uint32_t) __builtin_clz(cur);
+                cur ^= 0x80000000u >> t;
+                const uint32_t off = chunk[t];
+                const float4 pr = *(const float4 *) ((const char *) sPosRad + off);
+                const float4 nq = *(const float4 *) ((const char *) sNormQ + off);
+                const f32x2 pxy = f32x2{pr.x, pr.y} - cxy;
+                const float pz = pr.z - cz;
+                const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
+                const float d = pp * pr.w;
+                if (d < RADIUS_CUTOFF)
+                {
+                    float w = 1.0f - d;
+                    w *= w;
+                    w *= w;
+                    w *= nq.w;
+                    const f32x2 ww = {w, w};
+                    const f32x2 nxy = {nq.x, nq.y};
+                    const f32x2 wnxy = ww * nxy;
+                    const float wnz = w * nq.z;
+                    fit.sumW = fit.sumW + w;
+                    sWpxy = __builtin_elementwise_fma(ww, pxy, sWpxy);
+                    fit.sumWpz = fmaf(w, pz, fit.sumWpz);
+                    sWnxy = __builtin_elementwise_fma(ww, nxy, sWnxy);
+                    fit.sumWnz = fmaf(w, nq.z, fit.sumWnz);
+                    fit.sumWpp = fmaf(w, pp, fit.sumWpp);
+                    fit.sumWpn = fit.sumWpn + fmaf(wnxy.x, pxy.x, fmaf(wnxy.y, pxy.y, wnz * pz));
+                    fit.hits++;
+                }
+            }
+        };
+
+        int32_t end = A.commands[pos++];
+        /* a round's splat ids are requested while the round before it is processed */
+        int32_t idAhead = pos + (int32_t) tid < end ? A.commands[pos + (int32_t) tid] : -1;
+        while (pos < end)
+        {
+            {
+                uint32_t mask = 0;
+                const int32_t mine = idAhead;
+                if (mine >= 0)
+                {
+                    const float4 pr = stagedPosRad(A, mine);
+                    const float4 nq = A.splats[2 * (int64_t) mine + 1];
+                    sPosRad[tid] = pr;
+                    sNormQ[tid] = nq;
+                    float d[3][2];
+                    const float p[3] = {pr.x, pr.y, pr.z};
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++)
+                            d[a][h] = fmaxf(fmaxf(boxLo[a][h] - p[a], p[a] - boxHi[a][h]), 0.0f);
+#pragma unroll
+                    for (int s_ = 7; s_ >= 0; s_--)
+                    {
+                        const float dx = d[0][s_ & 1], dy = d[1][(s_ >> 1) & 1], dz = d[2][s_ >> 2];
+                        const float dd = dot3(dx, dy, dz, dx, dy, dz) * pr.w;
+                        mask = __builtin_amdgcn_alignbit(mask, __float_as_uint(dd - RADIUS_CUTOFF), 31);   /* hitBit(dd) */
+                    }
+                    if (splatNeverCulled(pr))
+                        mask = 0xFFu;
+                    if (splatIsNan(pr))
+                        mask = 0;       /* no corner accepts it: it never enters a tile */
+
+                    /* the splat's column of the contraction (in stages: the kernel lives in 64 registers) */
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float ax = pr.x - bx0, ay = pr.y - by0, az = pr.z - bz0;
+                    const float s1 = fabsf(ax) + fabsf(ay) + fabsf(az) + 21.0f;
+                    const float T = fabsf(pr.w) * (s1 * s1);
+                    const bool plain = T < 1e30f;                   /* false for NaN and infinities too */
+                    const float m2 = plain ? -2.0f * pr.w : 0.0f;
+                    const float gc = plain ? fmaf(pr.w, dot3(ax, ay, az, ax, ay, az), -RADIUS_CUTOFF) - T * 0x1p-16f : -1.0f;
+                    uint32_t c0, c1, c2;
+                    splitBf16(gc, c0, c1, c2);
+                    {
+                        uint32_t x0, x1, x2, y0, y1, y2;
+                        splitBf16(m2 * ax, x0, x1, x2);
+                        splitBf16(m2 * ay, y0, y1, y2);
+                        sColLo[tid] = make_uint4(packHi(x0, x1), packHi(x2, y0), packHi(y1, y2), packHi(c0, c1));
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        uint32_t z0, z1, z2, q0, q1, q2;
+                        splitBf16(m2 * az, z0, z1, z2);
+                        splitBf16(plain ? pr.w : 0.0f, q0, q1, q2);
+                        sColHi[tid] = make_uint4(packHi(z0, z1), packHi(z2, q0), packHi(q1, q2), c2 >> 16);
+                    }
+                }
+                sMask[tid] = (uint8_t) mask;
+                if (STATS)
+                    nListed += __popcll(__ballot(mine >= 0));
+            }
+            const int32_t staged = min(end - pos, (int32_t) MATRIX_STAGE);
+            pos += MATRIX_STAGE;
+            if (pos >= end)
+            {
+                pos = A.commands[end];
+                end = (pos >= 0) ? A.commands[pos++] : INT32_MIN;
+            }
+            idAhead = pos + (int32_t) tid < end ? A.commands[pos + (int32_t) tid] : -1;
+            __syncthreads();
+
+            /* the round's relevant splats of this wave's sub-block, in list order; a table that cannot take the next group of
+             * 64 is worked off first (no cloud of the BASELINE configs gets there) */
+            int32_t g = 0;
+            do
+            {
+            uint32_t nt = 0;
+            for (; g < staged; g += 64)
+            {
+                const uint32_t m = sMask[g + lane];
+                const uint64_t todo = __ballot((m >> wave) & 1u);
+                const uint32_t n = (uint32_t) __popcll(todo);
+                if (nt + n > MATRIX_SLOTS)
+                    break;
+                if ((todo >> lane) & 1ull)
+                    mySlots[nt + popcBelow(todo)] = (uint16_t) ((g + (int32_t) lane) * (int32_t) sizeof(float4));
+                nt += n;
+            }
+            /* (the table was written by other lanes of this wave: LDS operations of a wave execute in order) */
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+            for (uint32_t t0 = 0; t0 < nt; t0 += 32)
+            {
+                const uint32_t v = nt - t0 < 32u ? nt - t0 : 32u;
+                const uint32_t off = mySlots[t0 + rowSplat];
+                const uint4 aw = *(const uint4 *) (colBase + off);
+                const bf16x8 aFrag = __builtin_bit_cast(bf16x8, aw);
+                const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                /* one MFMA's 16 results at a time: 64 VGPRs, 8 waves per SIMD */
+                uint32_t x0 = 0, x1 = 0;
+                {
+                    const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aFrag, __builtin_bit_cast(bf16x8, bFrag[0]), zero, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        x0 = __builtin_amdgcn_alignbit(x0, __float_as_uint(acc[r]), 31);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(aFrag, __builtin_bit_cast(bf16x8, bFrag[1]), zero, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        x1 = __builtin_amdgcn_alignbit(x1, __float_as_uint(acc[r]), 31);
+                }
+                /* lanes 32-63 of x0 (corner l - 32, splats 16-31) <-> lanes 0-31 of x1 (corner l + 32, splats 0-15):
+                 * afterwards x0 = this lane's corner against splats 0-15, x1 = against splats 16-31 */
+                const auto sw = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);
+                uint32_t cur = (sw[0] << 16) | sw[1];
+                cur &= 0xFFFFFFFFu << (32u - v);          /* rows beyond the tile's end hold somebody's older splat */
+                if (STATS)
+                {
+                    nTests += 64ull * 32ull;
+                    /* the superset check: the reference's test on every (corner, splat) of the tile */
+                    uint32_t exact = 0;
+                    for (uint32_t s = 0; s < v; s++)
+                    {
+                        const float4 pr = *(const float4 *) ((const char *) sPosRad + mySlots[t0 + s]);
+                        const float px = pr.x - cx, py = pr.y - cy, pz = pr.z - cz;
+                        const float d = dot3(px, py, pz, px, py, pz) * pr.w;
+                        exact |= d < RADIUS_CUTOFF ? 0x80000000u >> s : 0u;
+                    }
+                    nMissed += waveSum((uint32_t) __popc(exact & ~cur));
+                }
+                drain(cur, mySlots + t0);
+            }
+            } while (g < staged);
+            if (STATS)
+            {
+                sumMostRound += waveMax(roundCnt);
+                roundCnt = 0;
+            }
+            __syncthreads();
+        }
+        fit.sumWpx = sWpxy.x;
+        fit.sumWpy = sWpxy.y;
+        fit.sumWnx = sWnxy.x;
+        fit.sumWny = sWnxy.y;
+        f = finishCorner<SHAPE>(fit, A.boundaryFactor);
+        if (STATS)
+        {
+            const unsigned long long hits = waveSum(fit.hits);
+            const uint32_t mostBlock = waveMax(fit.hits);
+            if (lane == 0)
+            {
+                atomicAdd(&A.stats[0], nListed);
+                atomicAdd(&A.stats[1], nTests);
+                atomicAdd(&A.stats[2], hits);
+                atomicAdd(&A.stats[3], (unsigned long long) drainCalls);
+                atomicAdd(&A.stats[4], (unsigned long long) sumMost);
+                atomicAdd(&A.stats[6], (unsigned long long) sumMostRound);
+                atomicAdd(&A.stats[7], (unsigned long long) mostBlock);
+                atomicAdd(&A.stats[41], nCand);                         /* candidates the prefilter passed to the drain */
+                atomicAdd(&A.stats[42], nMissed);                       /* hits it missed: must stay 0 */
+            }
+            __syncthreads();
+            if (tid < 33 && sHist[tid] != 0)
+                atomicAdd(&A.stats[8 + tid], (unsigned long long) sHist[tid]);
+        }
+    }
+
+    const int64_t row = (int64_t) (wy + ly) + (int64_t) (wz + lz) * A.zStride + A.zBias;
+    A.field[row * (int64_t) A.pitch + (wx + lx)] = f;
+}
+
 } // namespace
 
 /* ------------------------------------------------------------------ C-ABI */
@@ -738,8 +1093,8 @@ MLSGPU_API int mlsgpu_hip_mls_set_boundary_limit(mlsgpu_mls *m, float limit)
 
 MLSGPU_API int mlsgpu_hip_mls_set_variant(mlsgpu_mls *m, int variant)
 {
-    /* 4 = cube streams (default), 1 = the reference's structure; 0, 2 and 3 were intermediate designs of rounds 1-3 */
-    REQUIRE(m != nullptr && (variant == 1 || variant == 4), MLSGPU_ERR_INVALID);
+    /* 5 = matrix prefilter (default), 4 = cube streams, 1 = the reference's structure; 0, 2 and 3 were intermediate designs of rounds 1-3 */
+    REQUIRE(m != nullptr && (variant == 1 || variant == 4 || variant == 5), MLSGPU_ERR_INVALID);
     m->variant = variant;
     return MLSGPU_OK;
 }
@@ -836,7 +1191,9 @@ static int mlsEnqueueLanes(mlsgpu_mls *const *ms, const MlsArgs *args, uint32_t 
         if (stats) { if (sphere) MLS_LAUNCH(KERNEL, MLSGPU_SHAPE_SPHERE, true); else MLS_LAUNCH(KERNEL, MLSGPU_SHAPE_PLANE, true); } \
         else { if (sphere) MLS_LAUNCH(KERNEL, MLSGPU_SHAPE_SPHERE, false); else MLS_LAUNCH(KERNEL, MLSGPU_SHAPE_PLANE, false); }     \
     } while (0)
-    if (m->variant == 4)
+    if (m->variant == 5)
+        MLS_LAUNCH_ANY(processCornersMatrixKernel);
+    else if (m->variant == 4)
         MLS_LAUNCH_ANY(processCornersCubeKernel);
     else
         MLS_LAUNCH_ANY(processCornersKernel);

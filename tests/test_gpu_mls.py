@@ -44,7 +44,7 @@ def test_fit_sphere(ctx):
     np.testing.assert_array_equal(params.view(np.uint32), exp.view(np.uint32))
 
 
-@pytest.mark.parametrize("variant", [1, 4])
+@pytest.mark.parametrize("variant", [1, 4, 5])
 @pytest.mark.parametrize("shape", [0, 1])
 def test_process_corners(ctx, variant, shape):
     """TestMls::testProcessCorners (hand-built command list: >= 4 hits / < 4 hits / no hits)."""
@@ -98,7 +98,7 @@ NEG_NAN = np.array([0xFFC00000], np.uint32).view(np.float32)[0]
 POS_NAN = np.array([0x7FC00000], np.uint32).view(np.float32)[0]
 
 
-@pytest.mark.parametrize("variant", [1, 4])
+@pytest.mark.parametrize("variant", [1, 4, 5])
 @pytest.mark.parametrize("shape", [0, 1])
 def test_process_corners_non_finite_splats(ctx, variant, shape):
     """The hand-built list of testProcessCorners (test/test_mls.cpp:416-514; the splat slot that holds the radius is taken
@@ -138,6 +138,80 @@ def test_process_corners_non_finite_splats(ctx, variant, shape):
             assert np.array_equal(np.isnan(exp), np.isnan(exp_far))
             same = ~np.isnan(exp_far)
             np.testing.assert_array_equal(got[same].view(np.uint32), exp_far[same].view(np.uint32))
+
+
+def cutoff_fixture(seed=5, n=600):
+    """One command list shared by the eight 8^3 blocks of a 16^3 grid whose splats sit ON the reference's `d < 0.99`
+    (kernels/mls.cl:371) for one corner each: d = |p - c|^2 / r^2 within a few float steps of the cutoff on either side."""
+    rng = np.random.default_rng(seed)
+    offset = (100, 200, 300)
+    splats = np.zeros(n, ob.SPLAT_DTYPE)
+    cut = np.float32(0.99)
+    for i in range(n):
+        c = (rng.integers(0, 16, 3) + np.array(offset)).astype(np.float32)
+        u = rng.normal(size=3)
+        u /= np.linalg.norm(u)
+        r = rng.uniform(1.2, 3.5)
+        invr2 = np.float32(1.0 / (r * r))
+        dist = math.sqrt(0.99 / float(invr2))
+        p = (c.astype(np.float64) + u * dist).astype(np.float32)
+
+        def dof(p):
+            q = p - c
+            return np.float32(np.float32(np.float32(q[0] * q[0]) + np.float32(q[1] * q[1])) + np.float32(q[2] * q[2])) * invr2
+        # walk the largest component of p in single float steps until d crosses the cutoff, then move -2 .. 2 steps on
+        k = int(np.argmax(np.abs(u)))
+        away = np.float32(np.inf) if u[k] > 0 else np.float32(-np.inf)
+        for _ in range(64):
+            if dof(p) >= cut:
+                break
+            p[k] = np.nextafter(p[k], away)
+        for _ in range(64):
+            if dof(p) < cut:
+                break
+            p[k] = np.nextafter(p[k], -away)
+        for _ in range(int(rng.integers(0, 5))):
+            p[k] = np.nextafter(p[k], away)
+        splats["position"][i] = p
+        splats["radius"][i] = invr2
+        nrm = rng.normal(size=3)
+        splats["normal"][i] = (nrm / np.linalg.norm(nrm)).astype(np.float32)
+        splats["quality"][i] = np.float32(rng.uniform(0.5, 2.0))
+    commands = np.array([n + 1] + list(range(n)) + [-1], np.int32)
+    start = np.zeros(8, np.int32)
+    return dict(offset=offset, splats=splats, commands=commands, start=start, subsampling=3, size=(16, 16, 16),
+                image_w=16, rows=16 * 16, z_stride=16, z_bias=0, z_first=0, z_last=15)
+
+
+@pytest.mark.parametrize("variant", [1, 4, 5])
+def test_process_corners_on_the_cutoff(ctx, variant):
+    """Splats within a few float steps of `d < 0.99` on both sides (the matrix prefilter's margin must keep every hit of the
+    reference's test and the drain must drop what the margin lets through): bit-equal to the oracle, and the instrumented
+    kernel's own superset check reads zero misses."""
+    import mlsgpu_amd as m
+    fx = cutoff_fixture()
+    got, exp = _run_process_corners(ctx, fx, variant, 0, fx["splats"])
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))
+    ok = ~np.isnan(exp)
+    np.testing.assert_array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32))
+    # near-cutoff hits exist on both sides: count the reference's test on the fixture itself
+    counters = m.DeviceBuffer(ctx, array=np.zeros(m.binding.MLS_STATS_WORDS, np.uint64))
+    field = m.DeviceBuffer(ctx, array=np.zeros((fx["rows"], fx["image_w"]), np.float32))
+    gen = m.MlsFunctor(ctx, 0)
+    gen.set_variant(variant)
+    ds, dc, dst = (m.DeviceBuffer(ctx, array=fx[k]) for k in ("splats", "commands", "start"))
+    gen.set_buffers(fx["offset"], ds, dc, dst, fx["subsampling"])
+    gen.set_stats(counters)
+    gen.enqueue(field, fx["image_w"], fx["rows"], m.Swathe(16, 16, 16, 0, 0, 15))
+    ctx.synchronize()
+    c = counters.download(np.uint64)
+    got2 = field.download(np.float32).reshape(fx["rows"], fx["image_w"])
+    np.testing.assert_array_equal(got2[ok].view(np.uint32), exp[ok].view(np.uint32))      # the instrumented kernel too
+    assert c[0] == 8 * len(fx["splats"]) and c[2] > 0
+    if variant == 5:
+        assert c[42] == 0, "the prefilter missed %d hits" % c[42]
+        assert c[41] >= c[2]                                            # candidates >= hits
+        assert c[41] <= 1.5 * c[2] + 64                                 # and not many more
 
 
 def test_enqueue_checks(ctx):
