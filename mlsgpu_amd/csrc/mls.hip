@@ -5,18 +5,21 @@
  * One 512-thread workgroup (8 waves) evaluates one 8x8x8 block of grid corners, all of which share
  * one octree leaf and therefore one splat list (src/mls.cpp:53-54: wgs = {8,8,8}, subsamplingMin 3).
  * Per corner the splats are accumulated in LIST ORDER (leaf range first, then each ancestor's),
- * which fixes the floating-point summation order; both kernels below keep that order, so their
+ * which fixes the floating-point summation order; the kernels below keep that order, so their
  * results are bit-identical to each other and to the oracle.
  *
- * Variant 4 (default, "cube streams", processCornersCubeKernel): 512 listed splats per round are staged in LDS and
- * tagged with the 4x4x4 sub-blocks their support can reach; each wave owns a sub-block and gives each of its eight 2x2x2
- * cubes of corners its own stream of candidate splats; hits are accumulated in list order.  See the kernel.
+ * Variant 5 (default, "matrix prefilter", processCornersMatrixKernel): 512 listed splats per round are staged in LDS and
+ * tagged with the 4x4x4 sub-blocks their support can reach; each wave owns a sub-block, finds the candidate (corner, splat)
+ * pairs of 32 relevant splats at a time with two bf16 MFMAs and accumulates them, in list order, under the reference's own
+ * test.  See the kernel.
+ * Variant 4 ("cube streams", processCornersCubeKernel), round 5's default: the same staging; each wave gives each of its
+ * eight 2x2x2 cubes of corners its own stream of candidate splats and tests them on the vector units.  Kept for A/B.
  * Variant 1 ("basic", processCornersKernel): the reference's structure (every thread walks every staged splat), kept as
  * the A/B partner of the parity tests.
  * (Rounds 1-3 carried three intermediate designs -- sub-block culling alone, per-lane hit lists, hit masks -- as variants
  * 0, 2 and 3; they are gone from the product, their measurements are in profiles/NOTES_r0*.md.)
  *
- * Both kernels have a bucket dimension (common.hpp, Lanes): blockIdx.y selects the bucket of a batch.
+ * All kernels have a bucket dimension (common.hpp, Lanes): blockIdx.y selects the bucket of a batch.
  *
  * Floating-point contract: compiled with -ffp-contract=off; fmaf only where written.
  */
@@ -698,7 +701,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
  * 128 x 2^-23 T.  (d near the cutoff needs T >= 0.99, so pieces lost to bf16 underflow, < 2^-126, do not count.)  A column
  * with T >= 1e30 or not finite (which includes 1/r^2 = -inf, never culled) is [0, 0, 0, 0, -1]: a candidate for every
  * corner.  A record with a NaN keeps its empty sub-block mask.  The instrumented build checks the superset on every tile
- * (stats word 6: exact hits the mask missed, must be 0).  False positives: 0.1-0.3 % of the candidates.
+ * (stats word 42: exact hits the mask missed, must be 0; bench.py refuses to report otherwise).  False positives: under one
+ * percent of the candidates.
+ *
+ * The kernel lives in 64 VGPRs and 40 KB of LDS (four workgroups per CU, as variant 4): the two MFMAs of a tile run one after
+ * the other (16 accumulators at a time), wave-uniform floats are kept in scalar registers, the column is built in stages.
+ * At 76 VGPRs / 41 KB (three workgroups per CU) the same code was 4 % SLOWER than variant 4, at 64 / 40 it is 9-10 % faster
+ * (cfg3: 563-576 -> 510-516 us per launch of two buckets; shells cloud 497 -> 411): it executes 19 % fewer vector
+ * instructions and 25 % fewer LDS instructions (profiles/r06_cfg3_processCorners_sq_counters.csv), the matrix pipe is 4 %
+ * busy.  The drain requests the next candidate's records before it works on this one's (-1.5 %).
  */
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -720,7 +731,7 @@ __device__ __forceinline__ uint32_t packHi(uint32_t e0, uint32_t e1)
 }
 
 #define MATRIX_STAGE 512
-#define MATRIX_SLOTS 448
+#define MATRIX_SLOTS 440          /* + 4 entries of leading pad + 36 of slack = 480 per wave */
 #ifndef MLSGPU_MLS5_WAVES
 #define MLSGPU_MLS5_WAVES 8
 #endif
@@ -734,7 +745,7 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
     __shared__ uint4 sColLo[MATRIX_STAGE];      /* k = 0..7 of a splat's column: x pieces, y pieces, constant hi, mid */
     __shared__ uint4 sColHi[MATRIX_STAGE];      /* k = 8..15: z pieces, 1/r^2 pieces, constant lo, 0 */
     __shared__ uint8_t sMask[MATRIX_STAGE];
-    __shared__ uint16_t sSlot[8][MATRIX_SLOTS + 32];  /* per wave: byte offsets of the round's relevant splats (flushed when
+    __shared__ uint16_t sSlot[8][MATRIX_SLOTS + 40];  /* per wave: byte offsets of the round's relevant splats (flushed when
                                                        * full), a tile of slack; 40 KB in all: four workgroups per CU */
     __shared__ uint32_t sHist[STATS ? 33 : 1];
 
@@ -781,7 +792,7 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
         unsigned long long nListed = 0, nTests = 0, nCand = 0, nMissed = 0;
         uint32_t drainCalls = 0, sumMost = 0, sumMostRound = 0, roundCnt = 0;
         typedef __attribute__((address_space(3))) uint16_t LdsSlot;
-        LdsSlot *const mySlots = (LdsSlot *) sSlot[wave];
+        LdsSlot *const mySlots = (LdsSlot *) sSlot[wave] + 4;
         f32x2 sWpxy = {0.0f, 0.0f}, sWnxy = {0.0f, 0.0f};
         const f32x2 cxy = {cx, cy};
 
@@ -807,8 +818,45 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
         const char *const colBase = (lane >> 5) ? (const char *) sColHi : (const char *) sColLo;
 
         /* every slot that is ever read is a valid offset: zero until written */
-        for (uint32_t i = lane; i < MATRIX_SLOTS + 32; i += 64)
+        for (uint32_t i = lane; i < MATRIX_SLOTS + 40; i += 64)
             sSlot[wave][i] = 0;
+
+        /* one candidate: the reference's test and sums (kernels/mls.cl:362-390) */
+        auto accumulate = [&](const float4 pr, const float4 nq)
+        {
+            const f32x2 pxy = f32x2{pr.x, pr.y} - cxy;
+            const float pz = pr.z - cz;
+            const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
+            const float d = pp * pr.w;
+            if (d < RADIUS_CUTOFF)
+            {
+                float w = 1.0f - d;
+                w *= w;
+                w *= w;
+                w *= nq.w;
+                const f32x2 ww = {w, w};
+                const f32x2 nxy = {nq.x, nq.y};
+                const f32x2 wnxy = ww * nxy;
+                const float wnz = w * nq.z;
+                fit.sumW = fit.sumW + w;
+                sWpxy = __builtin_elementwise_fma(ww, pxy, sWpxy);
+                fit.sumWpz = fmaf(w, pz, fit.sumWpz);
+                sWnxy = __builtin_elementwise_fma(ww, nxy, sWnxy);
+                fit.sumWnz = fmaf(w, nq.z, fit.sumWnz);
+                fit.sumWpp = fmaf(w, pp, fit.sumWpp);
+                fit.sumWpn = fit.sumWpn + fmaf(wnxy.x, pxy.x, fmaf(wnxy.y, pxy.y, wnz * pz));
+                fit.hits++;
+            }
+        };
+        /* position of the highest set bit from the top; -1 for 0 (the hardware's answer, which __builtin_clz does not promise) */
+        auto ffbh = [](uint32_t v)
+        {
+            uint32_t t;
+            asm("v_ffbh_u32 %0, %1" : "=v"(t) : "v"(v));
+            return t;
+        };
+        auto posRadAt = [&](uint32_t off) { return *(const float4 *) ((const char *) sPosRad + off); };
+        auto normQAt = [&](uint32_t off) { return *(const float4 *) ((const char *) sNormQ + off); };
 
         /* accumulate this lane's candidates of one tile, in list order, under the reference's own test */
         auto drain = [&](uint32_t cur, LdsSlot *chunk)
@@ -822,35 +870,32 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
                 roundCnt += cnt;
                 nCand += waveSum(cnt);
             }
-            while (cur != 0)
+            /* the next candidate's record is requested before this one is worked on (two copies of the body: the records
+             * change places without register moves).  A mask that has run out reads the entry before the tile's first: a
+             * valid offset (the table's leading pad, or the tile before) */
+            if (cur != 0)
             {
-                const uint32_t t = (uint32_t) __builtin_clz(cur);
-                cur ^= 0x80000000u >> t;
-                const uint32_t off = chunk[t];
-                const float4 pr = *(const float4 *) ((const char *) sPosRad + off);
-                const float4 nq = *(const float4 *) ((const char *) sNormQ + off);
-                const f32x2 pxy = f32x2{pr.x, pr.y} - cxy;
-                const float pz = pr.z - cz;
-                const float pp = fmaf(pxy.x, pxy.x, fmaf(pxy.y, pxy.y, pz * pz));
-                const float d = pp * pr.w;
-                if (d < RADIUS_CUTOFF)
+                uint32_t t = ffbh(cur);
+                uint32_t off = chunk[t];
+                float4 prA = posRadAt(off), nqA = normQAt(off), prB, nqB;
+                for (;;)
                 {
-                    float w = 1.0f - d;
-                    w *= w;
-                    w *= w;
-                    w *= nq.w;
-                    const f32x2 ww = {w, w};
-                    const f32x2 nxy = {nq.x, nq.y};
-                    const f32x2 wnxy = ww * nxy;
-                    const float wnz = w * nq.z;
-                    fit.sumW = fit.sumW + w;
-                    sWpxy = __builtin_elementwise_fma(ww, pxy, sWpxy);
-                    fit.sumWpz = fmaf(w, pz, fit.sumWpz);
-                    sWnxy = __builtin_elementwise_fma(ww, nxy, sWnxy);
-                    fit.sumWnz = fmaf(w, nq.z, fit.sumWnz);
-                    fit.sumWpp = fmaf(w, pp, fit.sumWpp);
-                    fit.sumWpn = fit.sumWpn + fmaf(wnxy.x, pxy.x, fmaf(wnxy.y, pxy.y, wnz * pz));
-                    fit.hits++;
+                    cur ^= 0x80000000u >> t;
+                    t = ffbh(cur);
+                    off = chunk[(int32_t) t];
+                    prB = posRadAt(off);
+                    nqB = normQAt(off);
+                    accumulate(prA, nqA);
+                    if (cur == 0)
+                        break;
+                    cur ^= 0x80000000u >> t;
+                    t = ffbh(cur);
+                    off = chunk[(int32_t) t];
+                    prA = posRadAt(off);
+                    nqA = normQAt(off);
+                    accumulate(prB, nqB);
+                    if (cur == 0)
+                        break;
                 }
             }
         };
@@ -939,7 +984,7 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
                 const uint32_t n = (uint32_t) __popcll(todo);
                 if (nt + n > MATRIX_SLOTS)
                     break;
-                if ((todo >> lane) & 1ull)
+                if ((m >> wave) & 1u)
                     mySlots[nt + popcBelow(todo)] = (uint16_t) ((g + (int32_t) lane) * (int32_t) sizeof(float4));
                 nt += n;
             }
@@ -948,10 +993,11 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-            for (uint32_t t0 = 0; t0 < nt; t0 += 32)
+            LdsSlot *tile = mySlots;        /* the tile's first slot; this lane's row reads tile[rowSplat] */
+            for (uint32_t t0 = 0; t0 < nt; t0 += 32, tile += 32)
             {
                 const uint32_t v = nt - t0 < 32u ? nt - t0 : 32u;
-                const uint32_t off = mySlots[t0 + rowSplat];
+                const uint32_t off = tile[rowSplat];
                 const uint4 aw = *(const uint4 *) (colBase + off);
                 const bf16x8 aFrag = __builtin_bit_cast(bf16x8, aw);
                 const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
@@ -982,14 +1028,14 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
                     uint32_t exact = 0;
                     for (uint32_t s = 0; s < v; s++)
                     {
-                        const float4 pr = *(const float4 *) ((const char *) sPosRad + mySlots[t0 + s]);
+                        const float4 pr = *(const float4 *) ((const char *) sPosRad + tile[s]);
                         const float px = pr.x - cx, py = pr.y - cy, pz = pr.z - cz;
                         const float d = dot3(px, py, pz, px, py, pz) * pr.w;
                         exact |= d < RADIUS_CUTOFF ? 0x80000000u >> s : 0u;
                     }
                     nMissed += waveSum((uint32_t) __popc(exact & ~cur));
                 }
-                drain(cur, mySlots + t0);
+                drain(cur, tile);
             }
             } while (g < staged);
             if (STATS)

@@ -30,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PMC_PASSES = 2      # tools/profile_run.sh's counter passes run `--steps 1 --warmup 0`: the counting pass and one timed pass
 PMC_PASSES_OF = {"processCorners": 1}       # ... and the counting pass runs the instrumented processCorners (<0, true>), not the tracked one
 TRACKED = {
-    "processCorners": "processCornersCubeKernel<0, false>",
+    "processCorners": "processCornersMatrixKernel<0, false>",
     "latticeTriangles": "latticeTriangles",      # by rows (noise cloud) or by cells (surface-like data)
     "latticeVertices": "latticeVerticesKernel",
     "latticeMask": "latticeMaskKernel",
@@ -239,6 +239,33 @@ def sq(dirs, label, out):
             else:
                 f.write('"%s",%d,%s,%.0f\n' % (label, launches, c, rows[c]))
     print("appended", len(rows), "counters for", label, "to", out)
+    # MLSGPU_SQ_JSON=<file>:<key>: the figures bench.py puts into its line (roofline.valu_issue_frac, ...), for ONE kernel
+    spec = os.environ.get("MLSGPU_SQ_JSON")
+    if spec and all(not isinstance(c, tuple) for c in rows) and "GRBM_GUI_ACTIVE" in rows and "SQ_INSTS_VALU" in rows:
+        path, key = spec.rsplit(":", 1)
+        try:
+            doc = json.load(open(path))
+        except Exception:
+            doc = {}
+        cycles = rows["GRBM_GUI_ACTIVE"] / 8.0               # the counter is summed over the 8 XCDs
+        simds, cus = 1024.0, 256.0
+        doc[key] = {
+            "label": label, "launches": launches, "kernel_cycles": int(cycles),
+            "insts_valu": int(rows["SQ_INSTS_VALU"]), "insts_lds": int(rows.get("SQ_INSTS_LDS", 0)),
+            "insts_salu": int(rows.get("SQ_INSTS_SALU", 0)), "insts_mfma": int(rows.get("SQ_INSTS_MFMA", 0)),
+            # a wave's vector instruction occupies its SIMD-32 for 2 cycles (MI355X_MICROARCH.md, wave scheduling); the
+            # shortest interval a SIMD sustained with 8 resident waves was 2.63 (profiles/r03_valu_lds_issue_microbench.txt)
+            "valu_issue_frac": round(rows["SQ_INSTS_VALU"] * 2.0 / (cycles * simds), 4),
+            "valu_issue_frac_of_measured_rate": round(rows["SQ_INSTS_VALU"] * 2.63 / (cycles * simds), 4),
+            "mfma_busy_frac": round(rows.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (cycles * simds), 4),
+            "lds_busy_frac": round(rows.get("SQ_LDS_IDX_ACTIVE", 0) / (cycles * cus), 4),
+            "lds_bank_conflict_frac": round(rows.get("SQ_LDS_BANK_CONFLICT", 0) / max(rows.get("SQ_LDS_IDX_ACTIVE", 0), 1), 4),
+            "active_lane_frac": round(rows.get("SQ_THREAD_CYCLES_VALU", 0) / (64.0 * max(rows["SQ_INSTS_VALU"], 1)), 4),
+            "wave_wait_frac": round(rows.get("SQ_WAIT_ANY", 0) / max(rows.get("SQ_WAVE_CYCLES", 0), 1), 4),
+            "source": os.path.relpath(out, ROOT),
+        }
+        json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
+        print("wrote", key, "to", path)
 
 
 if __name__ == "__main__":

@@ -12,4 +12,4 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INS
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_WAVES -d /tmp/sqm_b -o run -- python3 $args > /dev/null 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_THREAD_CYCLES_VALU SQ_INST_LEVEL_LDS SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 -d /tmp/sqm_c -o run -- python3 $args > /dev/null 2>&1
 rocprofv3 --pmc SQ_BUSY_CU_CYCLES SQ_INST_CYCLES_SALU SQ_INSTS_SMEM SQ_VALU_MFMA_COEXEC_CYCLES SQ_LEVEL_WAVES SQ_INSTS_BRANCH -d /tmp/sqm_d -o run -- python3 $args > /dev/null 2>&1
-MLSGPU_SQ_KERNELS="$k;" python3 tools/profile_summary.py sq "$label" "$out" /tmp/sqm_a /tmp/sqm_b /tmp/sqm_c /tmp/sqm_d
+MLSGPU_SQ_KERNELS="$k;" MLSGPU_SQ_JSON="${MLSGPU_SQ_JSON:-gpurun_out/sq.json:cfg3/uniform/processCorners/variant$v}" python3 tools/profile_summary.py sq "$label" "$out" /tmp/sqm_a /tmp/sqm_b /tmp/sqm_c /tmp/sqm_d
