@@ -399,7 +399,8 @@ int mlsgpu_hip_topology(uint32_t *numNodes, uint32_t cpusPerNode[16]);
 /* the plan alone: deviceNodes[i] -> sideOfDevice[i] (sides numbered by first appearance), nodeOfSide[k], *numSides */
 int mlsgpu_hip_plan_copy_sides(const int32_t *deviceNodes, uint32_t numDevices, uint32_t numNodes, int32_t *sideOfDevice,
                                int32_t *nodeOfSide, uint32_t *numSides);
-/* test hook: copies through the farm's pool of copy threads compared with their sources; returns the mismatches */
+/* test hook: copies through the farm's pool of copy threads compared with their sources (`rounds` copies of pseudo-random sizes up
+ * to `bytes`; rounds = 0: ONE copy of exactly `bytes` bytes); returns the mismatches */
 int mlsgpu_hip_test_copy_pool(uint32_t threads, uint32_t rounds, uint64_t bytes, int node);
 int mlsgpu_hip_bind_thread_to_node(int node);                              /* the calling thread; 1 = bound, 0 = left alone */
 /* out[0] copy sides, [1] node the read-back ring's memory is on, [2] NUMA nodes, [3] devices; per device d < 16:

@@ -1230,6 +1230,15 @@ MLSGPU_API int mlsgpu_hip_test_copy_pool(uint32_t threads, uint32_t rounds, uint
     std::vector<unsigned char> src(bytes), dst(bytes);
     int bad = 0;
     uint64_t x = 0x9E3779B97F4A7C15ull;
+    if (rounds == 0)
+    {
+        /* one copy of exactly `bytes` bytes, every byte distinct from the destination's fill */
+        for (uint64_t i = 0; i < bytes; i++)
+            src[i] = (unsigned char) (1 + i % 151);
+        std::fill(dst.begin(), dst.end(), (unsigned char) 0xA5);
+        pool.copy(dst.data(), src.data(), bytes);
+        return std::memcmp(dst.data(), src.data(), bytes) != 0;
+    }
     for (uint32_t r = 0; r < rounds; r++)
     {
         x ^= x << 13; x ^= x >> 7; x ^= x << 17;

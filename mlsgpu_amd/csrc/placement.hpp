@@ -242,7 +242,7 @@ public:
         j.dst = static_cast<char *>(dst);
         j.src = static_cast<const char *>(src);
         j.bytes = bytes;
-        j.chunk = (bytes / parts + 4095) & ~size_t(4095);
+        j.chunk = ((bytes + parts - 1) / parts + 4095) & ~size_t(4095);   /* parts * chunk >= bytes: the CEILING, rounded up to pages */
         j.parts = parts;
         launch(j);
     }

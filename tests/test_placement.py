@@ -114,6 +114,18 @@ def test_copy_pool_is_exact_at_every_thread_count():
     assert m.lib().mlsgpu_hip_test_copy_pool(4, 5, 0, -1) == 0
 
 
+def test_copy_pool_copies_the_tail():
+    """Sizes whose floor(bytes / parts) is a multiple of the 4 KB chunk granule with a remainder on top (the
+    chunk was the rounded FLOOR, so parts x chunk < bytes and the last bytes % parts bytes were never copied), at thread
+    counts on both sides of 32 (the farm copies 32-byte splats)."""
+    import mlsgpu_amd as m
+    for threads, k in ((8, 512), (3, 700), (33, 520), (40, 600)):
+        for r in sorted({1, 4, 31, 32, threads - 1}):
+            if 0 < r < threads:
+                bytes_ = threads * 4096 * k + r
+                assert m.lib().mlsgpu_hip_test_copy_pool(threads, 0, bytes_, -1) == 0, (threads, k, r)
+
+
 BIND = r'''
 import json, os, sys
 sys.path.insert(0, %(root)r)
