@@ -54,6 +54,12 @@ try:
     CFG3_UNIFORM_DIGEST = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg3_uniform.json")))["digest"]
 except Exception:   # noqa: BLE001 - the fixture is optional for the benchmark
     CFG3_UNIFORM_DIGEST = None
+CFG2_PINS = {}      # --workload cfg2: the one-bucket configuration, pinned next to whole-bucket oracle parity (test_cfg2_full_size)
+for _d in ("uniform", "shells"):
+    try:
+        CFG2_PINS[_d] = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg2_%s.json" % _d)))["digest"]
+    except Exception:   # noqa: BLE001
+        pass
 try:    # EVERY slab of the N > 1 workload, as an inner and as a last slab: {slab: {"inner" | "last": totals + digest}}
     # (tests/test_gpu_configs.py::test_cfg4_slab_full_density runs all of them on one GPU next to oracle parity)
     CFG4SLAB_PINS = json.load(open(os.path.join(ROOT, "tests", "golden", "cfg4slab_uniform.json")))["slabs"]
@@ -558,6 +564,12 @@ def main():
         if digest != CFG3_UNIFORM_DIGEST:
             raise SystemExit("output digest %s differs from the pinned %s: the timed pipeline did not produce the meshes "
                              "the parity tests check" % (digest, CFG3_UNIFORM_DIGEST))
+    if W["name"] == "cfg2" and args.scale == 1.0 and args.dist in CFG2_PINS:
+        result["output_digest"]["expected"] = CFG2_PINS[args.dist]
+        result["output_digest"]["ok"] = digest == CFG2_PINS[args.dist]
+        if digest != CFG2_PINS[args.dist]:
+            raise SystemExit("output digest %s differs from the pinned %s (tests/golden/cfg2_%s.json)"
+                             % (digest, CFG2_PINS[args.dist], args.dist))
     # EVERY rank's slab is pinned (slab r as an inner slab of 128 cell slices, or as the job's last one of 127): each rank holds
     # its own digest against its pin, the verdicts are gathered, and one mismatch anywhere fails the whole run
     digest_failure = None

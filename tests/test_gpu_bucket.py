@@ -158,9 +158,9 @@ def mesh_digest(batches):
 
 
 def test_cfg2_full_size_properties(ctx):
-    """BASELINE config 1 at full size (256^3, 5M uniform-random splats, one bucket).  The oracle is too slow
-    here, so check size-independent properties: structural validity of every batch, idempotence, and that the
-    culled and basic MLS kernels give the same mesh bit for bit."""
+    """BASELINE config 1 at full size (256^3, 5M uniform-random splats, one bucket): size-independent properties --
+    structural validity of every batch, idempotence, and that the three MLS kernels give the same mesh bit for bit.
+    (The whole bucket against the oracle: test_gpu_configs.py::test_cfg2_full_size.)"""
     import mlsgpu_amd as m
     from mlsgpu_amd import synth
     cloud, g = synth.make_cloud("cfg2")

@@ -1,5 +1,9 @@
 """The BASELINE.json configurations that only fit a GPU, at full size (cfg3) or full shape (cfg4), under -m gpu.
 
+cfg2  256^3 grid, 5 M splats, ONE bucket of 255 cells per side (the only configuration with a full-size single bucket and
+      the only one whose bucket exceeds 2 M splats): the WHOLE bucket against the oracle bit for bit with every MLS kernel,
+      on the uniform cloud and on its shells companion of SURVEY 8(d); totals + digest pinned in
+      tests/golden/cfg2_{uniform,shells}.json (bench.py --workload cfg2 checks the same pins).
 cfg3  512^3 grid, 50 M uniform splats, 27 buckets: the cloud bench.py times.  Oracle bit-parity on three buckets (corner,
       face, centre), size-independent properties on all 27 (bucket tiling, cross-bucket agreement of shared vertices bit
       for bit, key multiplicity), and the totals + digest that bench.py prints for its timed passes, pinned in
@@ -128,6 +132,66 @@ def test_cfg3_full_size(ctx):
         assert st["shipouts"] == len(batches) >= 1
         assert_batches_equal(batches, exp_b)
         del batches, exp_b
+
+
+@pytest.mark.parametrize("dist", ["uniform", "shells"])
+def test_cfg2_full_size(ctx, dist):
+    """BASELINE configs[1] at full size against the oracle: one 255-cell bucket of 5 M splats (the oracle's processCorners
+    is OpenMP-parallel; ~3.4 x one of the buckets test_cfg3_full_size runs).  The reference's own expectations at this
+    shape are analytic (test/test_mls.cpp:416-514, test/test_marching.cpp:594-632); here every ship-out -- vertex bits,
+    triangles, keys, the internal / external split, batch boundaries -- equals the oracle's, with each of the three MLS
+    kernels; the totals and the device-side digest that bench.py --workload cfg2 prints are pinned."""
+    import torch
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as mb, synth
+    dev = torch.device("cuda", 0)
+    cloud, g = synth.make_cloud_device("cfg2", dev, dist=dist)
+    assert len(cloud) == 5_000_000 and g == 256
+    record_size("cfg2 %s" % dist, "%d splats, one bucket of 255^3 cells, whole bucket against the oracle" % len(cloud))
+    bucketed, buckets = synth.bucketize_device(cloud, synth.grid_buckets((g, g, g), 255))
+    del cloud
+    assert len(buckets) == 1
+    b = buckets[0]
+    assert b.low == (0, 0, 0) and tuple(b.num_vertices) == (g, g, g)
+    nbytes = bucketed.numel() * 4
+    pristine = m.DeviceBuffer(ctx, nbytes=nbytes, borrow=bucketed.data_ptr())
+    work = m.DeviceBuffer(ctx, nbytes=nbytes)
+
+    # ---- bench.py's settings: totals + digest, the same for every MLS kernel ----
+    got = None
+    for variant in (5, 4, 1):
+        w = m.Worker(ctx, b.count, max_cells=255, mesh_memory=4096 << 20)
+        w.set_mls_variant(variant)
+        work.copy_from(pristine)
+        col = w.process(work, b.first, b.count, b.low, b.num_vertices, collector=mb.ChecksumCollector(ctx))
+        cnt = w.marching_counters()
+        assert cnt["welded"] == col.vertices and cnt["indices"] == 3 * col.triangles
+        this = dict(triangles=int(col.triangles), vertices=int(col.vertices), external=int(col.external), shipouts=col.batches,
+                    digest=col.digest())
+        assert got is None or this == got, (variant, this, got)
+        got = this
+        del w
+    golden = os.path.join(os.path.dirname(GOLDEN), "cfg2_%s.json" % dist)
+    if os.environ.get("MLSGPU_WRITE_GOLDEN"):
+        out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "cfg2_%s.json" % dist)
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        json.dump(got, open(out, "w"), indent=1)         # (the pin is only worth what the oracle parity below says)
+    else:
+        exp = json.load(open(golden))
+        assert got == {k: exp[k] for k in got}, (got, exp)
+
+    # ---- the whole bucket against the oracle, 1 GB of mesh memory (several ship-outs: the overflow splitting at full size) ----
+    mm = 1 << 30
+    host = bucketed[b.first:b.first + b.count].cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
+    exp_b, st = ob.bucket(host, 0, b.count, b.num_vertices, b.low, max_cells=255, max_swathe=256, mesh_memory=mm)
+    for variant in (5, 4):
+        w = m.Worker(ctx, b.count, max_cells=255, mesh_memory=mm)
+        w.set_mls_variant(variant)
+        work.copy_from(pristine)
+        batches = w.process(work, b.first, b.count, b.low, b.num_vertices)
+        assert st["shipouts"] == len(batches) >= 1
+        assert_batches_equal(batches, exp_b)
+        del batches, w
 
 
 def farm_devices(n):
