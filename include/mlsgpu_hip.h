@@ -712,6 +712,10 @@ int mlsgpu_hip_test_fit_sphere(mlsgpu_ctx *ctx, const mlsgpu_splat *hSplats, uin
 int mlsgpu_hip_test_compute_key(mlsgpu_ctx *ctx, const uint32_t coords[3], const uint32_t top[3], uint64_t *out);
 /* primitives: exclusive scan with seed (clogs::Scan) and stable radix sort on the low `bits` (clogs::Radixsort) */
 int mlsgpu_hip_test_scan_u32(mlsgpu_ctx *ctx, uint32_t *dData, uint64_t n, uint32_t seed);
+/* `repeats` scans of `count` (<= MLSGPU_MAX_BATCH) lanes each, dIn[k] -> dOut[k] (n[k] elements from seeds[k]): one set of
+ * launches per repeat, as the buckets of a batch scan (src/marching.cpp:353,583,721 per bucket), back to back */
+int mlsgpu_hip_test_scan_u32_batch(mlsgpu_ctx *ctx, const uint32_t *const *dIn, uint32_t *const *dOut, const uint64_t *n,
+                                   const uint32_t *seeds, uint32_t count, uint32_t repeats);
 int mlsgpu_hip_test_sort_u32(mlsgpu_ctx *ctx, uint32_t *dKeys, uint32_t *dValues, uint64_t n, uint32_t bits);
 int mlsgpu_hip_test_sort_u64(mlsgpu_ctx *ctx, uint64_t *dKeys, uint32_t *dValues, uint64_t n, uint32_t bits);
 

@@ -304,6 +304,7 @@ def lib():
     sig("mlsgpu_hip_test_fit_sphere", C.c_int, vp, vp, u32, vp)
     sig("mlsgpu_hip_test_compute_key", C.c_int, vp, vp, vp, P(u64))
     sig("mlsgpu_hip_test_scan_u32", C.c_int, vp, vp, u64, u32)
+    sig("mlsgpu_hip_test_scan_u32_batch", C.c_int, vp, vp, vp, vp, vp, u32, u32)
     sig("mlsgpu_hip_test_sort_u32", C.c_int, vp, vp, vp, u64, u32)
     sig("mlsgpu_hip_test_sort_u64", C.c_int, vp, vp, vp, u64, u32)
     _lib = L

@@ -213,23 +213,31 @@ MLSGPU_API int mlsgpu_hip_ctx_create(int device, void *stream, mlsgpu_ctx **out)
     return MLSGPU_OK;
 }
 
-int mlsgpu_ctx::scanFlags(uint32_t **flags, uint32_t *epoch)
+int mlsgpu_ctx::scanFlags(uint32_t **flags, uint32_t *epoch, uint32_t **tickets, uint32_t *bases, uint32_t gridX, uint32_t count)
 {
+    const size_t flagWords = (size_t) MLSGPU_MAX_BATCH * 1024;      /* MAX_LANES x SCAN_ONEPASS_MAX_TILES */
+    const size_t ticketWords = (size_t) MLSGPU_MAX_BATCH * 32;      /* MAX_LANES x SCAN_TICKET_STRIDE */
     if (dScanFlags == nullptr)
     {
-        const size_t bytes = (size_t) MLSGPU_MAX_BATCH * 1024 * sizeof(uint32_t);      /* MAX_LANES x SCAN_ONEPASS_MAX_TILES */
         HIP_CHECK(hipSetDevice(device));
-        HIP_CHECK(hipMalloc((void **) &dScanFlags, bytes));
-        HIP_CHECK(hipMemsetAsync(dScanFlags, 0, bytes, stream));
+        HIP_CHECK(hipMalloc((void **) &dScanFlags, (flagWords + ticketWords) * sizeof(uint32_t)));
+        HIP_CHECK(hipMemsetAsync(dScanFlags, 0, (flagWords + ticketWords) * sizeof(uint32_t), stream));
     }
     if (++scanEpoch == 0)
     {
         /* wrapped: a flag left by the launch of 2^32 launches ago would match again.  Fresh flags hold 0, which is never an epoch. */
-        HIP_CHECK(hipMemsetAsync(dScanFlags, 0, (size_t) MLSGPU_MAX_BATCH * 1024 * sizeof(uint32_t), stream));
+        HIP_CHECK(hipMemsetAsync(dScanFlags, 0, flagWords * sizeof(uint32_t), stream));
         scanEpoch = 1;
     }
     *flags = dScanFlags;
     *epoch = scanEpoch;
+    *tickets = dScanFlags + flagWords;
+    for (uint32_t k = 0; k < MLSGPU_MAX_BATCH; k++)
+    {
+        bases[k] = scanTicketBase[k];
+        if (k < count)
+            scanTicketBase[k] += gridX;         /* every workgroup of the lane draws one (wraps with the counter) */
+    }
     return MLSGPU_OK;
 }
 

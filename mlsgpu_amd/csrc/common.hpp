@@ -111,7 +111,10 @@ struct mlsgpu_ctx
     /* one-launch scans (primitives.hpp): a flag word per (lane, tile), never cleared -- a launch's flags carry its epoch */
     uint32_t *dScanFlags = nullptr;
     uint32_t scanEpoch = 0;
-    int scanFlags(uint32_t **flags, uint32_t *epoch);
+    uint32_t scanTicketBase[MLSGPU_MAX_BATCH] = {};     /* what lane k's ticket counter reads when the next launch begins */
+    /* flags + epoch of the next one-launch scan, the lanes' ticket counters and what they read now; a launch of `gridX`
+     * workgroups for each of `count` lanes is accounted for */
+    int scanFlags(uint32_t **flags, uint32_t *epoch, uint32_t **tickets, uint32_t *bases, uint32_t gridX, uint32_t count);
 
     int statId(const char *name);
     int beginTiming(int id);          /* returns index into pending or -1 */

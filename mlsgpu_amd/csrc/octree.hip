@@ -1147,6 +1147,33 @@ MLSGPU_API int mlsgpu_hip_test_scan_u32(mlsgpu_ctx *ctx, uint32_t *dData, uint64
     return rc;
 }
 
+/* `repeats` scans of `count` lanes each (one set of launches per repeat, as the buckets of a batch), dIn[k] -> dOut[k],
+ * enqueued back to back without a host synchronisation in between; returns when the last one has finished */
+MLSGPU_API int mlsgpu_hip_test_scan_u32_batch(mlsgpu_ctx *ctx, const uint32_t *const *dIn, uint32_t *const *dOut, const uint64_t *n,
+                                              const uint32_t *seeds, uint32_t count, uint32_t repeats)
+{
+    REQUIRE(ctx != nullptr && dIn != nullptr && dOut != nullptr && n != nullptr && seeds != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(count >= 1 && count <= MAX_LANES, MLSGPU_ERR_LENGTH);
+    HIP_CHECK(hipSetDevice(ctx->device));
+    uint32_t *dTiles[MAX_LANES] = {};
+    typedef ScanJob<uint32_t, ArrayIn<uint32_t>, ArrayIn<uint32_t>, ArrayOut<uint32_t> > Job;
+    Job jobs[MAX_LANES];
+    int rc = MLSGPU_OK;
+    for (uint32_t k = 0; k < count && rc == MLSGPU_OK; k++)
+    {
+        if (hipMalloc(&dTiles[k], ((uint64_t) scanTiles(n[k]) + 1) * 4) != hipSuccess)
+            rc = setError(MLSGPU_ERR_NOMEM, "hipMalloc failed");
+        jobs[k] = Job{ArrayIn<uint32_t>{dIn[k]}, ArrayIn<uint32_t>{dIn[k]}, ArrayOut<uint32_t>{dOut[k]}, n[k], seeds[k], dTiles[k],
+                      (uint32_t *) nullptr, (const uint32_t *) nullptr};
+    }
+    for (uint32_t r = 0; r < repeats && rc == MLSGPU_OK; r++)
+        rc = exclusiveScanBatch<uint32_t>(ctx, "test.scan", jobs, count);
+    hipStreamSynchronize(ctx->stream);
+    for (uint32_t k = 0; k < count; k++)
+        hipFree(dTiles[k]);
+    return rc;
+}
+
 template<typename K>
 static int testSort(mlsgpu_ctx *ctx, K *dKeys, uint32_t *dValues, uint64_t n, uint32_t bits)
 {

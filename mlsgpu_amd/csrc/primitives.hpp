@@ -273,8 +273,11 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanApplyKernel(Lanes<ScanApplyArg
 /* ---- the scan in ONE launch.  A workgroup publishes its tile's sum (value, then a flag behind a release), and adds up
  * the sums of ALL its predecessors as they appear -- no chain from tile to tile: a workgroup waits for the slowest of the
  * earlier tiles' loads, not for a sequence of look-backs.  The flag is the launch's EPOCH (the context counts its one-pass
- * launches), so flags are never cleared: what an earlier launch left behind does not match.  Workgroups are dispatched in
- * order of blockIdx.x within a lane, so the ones a workgroup waits for are running or done (up to SCAN_ONEPASS_MAX_TILES
+ * launches), so flags are never cleared: what an earlier launch left behind does not match.  A workgroup's TILE is a ticket
+ * it draws when it starts (one returning agent-scope atomic on a counter per lane that is never reset: the host knows what it
+ * read before the launch), not blockIdx.x: HIP promises nothing about the order workgroups are dispatched in, and a
+ * workgroup spinning on a tile whose workgroup is not resident would hang the stream.  With tickets the tiles a workgroup
+ * waits for belong to workgroups that have started, and those publish before they wait (up to SCAN_ONEPASS_MAX_TILES
  * tiles; longer scans take the two-launch form above).  The waits and the sums' loads are agent-scope atomics: they see
  * what another XCD's workgroup published. ---- */
 __device__ __forceinline__ uint32_t loadAgent(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -294,6 +297,8 @@ struct ScanOnePassArgs
     Out out;
     T *tileSums;
     uint32_t *flags;            /* one word per tile of this lane */
+    uint32_t *ticket;           /* this lane's ticket counter ... */
+    uint32_t ticketBase;        /* ... and what it reads when this launch begins */
     uint64_t n;
     const uint32_t *nDev;
     T seed;
@@ -305,7 +310,13 @@ template<typename T, typename In, typename Out>
 __global__ __launch_bounds__(PRIM_BLOCK) void scanOnePassKernel(Lanes<ScanOnePassArgs<T, In, Out> > lanes, uint32_t epoch)
 {
     const ScanOnePassArgs<T, In, Out> A = lanes.a[blockIdx.y];
-    if (blockIdx.x >= A.numTiles)
+    /* every workgroup of the lane draws a ticket (the lane's counter advances by gridDim.x per launch, the host counts on it) */
+    __shared__ uint32_t sTile;
+    if (threadIdx.x == 0)
+        sTile = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - A.ticketBase;
+    __syncthreads();
+    const uint32_t tile = sTile;
+    if (tile >= A.numTiles)
         return;
     uint64_t n = A.n;
     if (A.nDev != nullptr && *A.nDev < n)
@@ -313,12 +324,12 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanOnePassKernel(Lanes<ScanOnePas
     /* the tile holding the last element (tile 0 of an empty scan) reports the total; later tiles are empty, publish nothing
      * and nobody waits for them */
     const uint32_t lastTile = n > 0 ? (uint32_t) ((n - 1) / PRIM_TILE) : 0u;
-    if (blockIdx.x > lastTile)
+    if (tile > lastTile)
         return;
     __shared__ T waveTotals[PRIM_WAVES];
     __shared__ T wavePrefix[PRIM_WAVES];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t base = (uint64_t) blockIdx.x * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
+    const uint64_t base = (uint64_t) tile * PRIM_TILE + (uint64_t) wave * PRIM_WAVE_SPAN + lane;
     T vals[PRIM_ITEMS];
     T excl[PRIM_ITEMS];
     T running = zeroOf(T());        /* wave-uniform: sum of the previous rounds of this wave */
@@ -338,13 +349,13 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanOnePassKernel(Lanes<ScanOnePas
 #pragma unroll
     for (int w = 1; w < PRIM_WAVES; w++)
         mine = mine + waveTotals[w];
-    if (threadIdx.x == 0 && blockIdx.x < lastTile)
+    if (threadIdx.x == 0 && tile < lastTile)
     {
-        storeAgent(&A.tileSums[blockIdx.x], mine);
-        __hip_atomic_store(&A.flags[blockIdx.x], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        storeAgent(&A.tileSums[tile], mine);
+        __hip_atomic_store(&A.flags[tile], epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     T before = zeroOf(T());
-    for (uint32_t t = threadIdx.x; t < blockIdx.x; t += PRIM_BLOCK)
+    for (uint32_t t = threadIdx.x; t < tile; t += PRIM_BLOCK)
     {
         while (__hip_atomic_load(&A.flags[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != epoch)
             __builtin_amdgcn_s_sleep(2);
@@ -358,7 +369,7 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanOnePassKernel(Lanes<ScanOnePas
 #pragma unroll
     for (int w = 0; w < PRIM_WAVES; w++)
         before = before + wavePrefix[w];
-    if (A.total != nullptr && blockIdx.x == lastTile && threadIdx.x == 0)
+    if (A.total != nullptr && tile == lastTile && threadIdx.x == 0)
         *A.total = before + mine;
     for (uint32_t w = 0; w < wave; w++)
         before = before + waveTotals[w];
@@ -375,6 +386,8 @@ __global__ __launch_bounds__(PRIM_BLOCK) void scanOnePassKernel(Lanes<ScanOnePas
 
 /* largest scan (in tiles) that runs as one launch */
 #define SCAN_ONEPASS_MAX_TILES 1024u
+/* words between the lanes' ticket counters (a 128-byte line each) */
+#define SCAN_TICKET_STRIDE 32u
 
 /* Host drivers.  Workspace: dTileSums must hold scanTiles(n) + 1 elements of T. */
 static inline uint32_t scanTiles(uint64_t n) { return divUp(n, PRIM_TILE); }
@@ -457,17 +470,18 @@ static int exclusiveScanBatch(mlsgpu_ctx *ctx, const char *statName, const ScanJ
     if (std::is_same<In1, In2>::value && maxTiles <= SCAN_ONEPASS_MAX_TILES && !scanOnePassOff())
     {
         /* one launch (scanOnePassKernel).  An empty lane still runs its tile 0, which reports the total. */
-        uint32_t *flags = nullptr, epoch = 0;
-        PROPAGATE(ctx->scanFlags(&flags, &epoch));
+        uint32_t *flags = nullptr, *tickets = nullptr, epoch = 0, bases[MAX_LANES];
+        maxTiles = std::max(maxTiles, 1u);
+        PROPAGATE(ctx->scanFlags(&flags, &epoch, &tickets, bases, maxTiles, count));
         Lanes<ScanOnePassArgs<T, In2, Out> > a;
         for (uint32_t k = 0; k < MAX_LANES; k++)
         {
             const ScanJob<T, In1, In2, Out> &j = jobs[k < count ? k : 0];
             const uint32_t tiles = k < count ? std::max(scanTiles(j.n), 1u) : 0u;
-            a.a[k] = ScanOnePassArgs<T, In2, Out>{j.in2, j.out, j.dTileSums, flags + (uint64_t) k * SCAN_ONEPASS_MAX_TILES, j.n, j.nDev,
+            a.a[k] = ScanOnePassArgs<T, In2, Out>{j.in2, j.out, j.dTileSums, flags + (uint64_t) k * SCAN_ONEPASS_MAX_TILES,
+                                                  tickets + (uint64_t) k * SCAN_TICKET_STRIDE, bases[k], j.n, j.nDev,
                                                   j.seed, j.dTotal, tiles};
         }
-        maxTiles = std::max(maxTiles, 1u);
         LAUNCH(ctx, statName, (scanOnePassKernel<T, In2, Out>), dim3(maxTiles, count), dim3(PRIM_BLOCK), a, epoch);
         return MLSGPU_OK;
     }
