@@ -966,17 +966,28 @@ def main():
             svox = sum(b.cells for b in sbuckets)
             sprist = m.DeviceBuffer(ctx, nbytes=sb_t.numel() * 4, borrow=sb_t.data_ptr())
             swork = m.DeviceBuffer(ctx, nbytes=sb_t.numel() * 4)
+            # the HEADLINE's protocol (round 5 ran this leg on the old one -- a restore copy and a host synchronisation inside
+            # the loop, bucket by bucket, mutating workers -- and printed a number 17-20 % below the one the same cloud gives as
+            # `--dist shells`): resident splats processed in place by non-mutating workers, `batch` buckets per set of launches
             sworkers = [m.Worker(c, smax, max_cells=scells, mesh_memory=args.mesh_memory_mb << 20) for c in ctxs]
+            sbatch = max(1, min(args.batch, m.binding.MAX_BATCH, -(-len(sbuckets) // nworkers)))
+            for w in sworkers:
+                w.set_mls_variant(args.variant)
+                w.set_keep_splats(True)
+                w.set_batch(sbatch)
+                w.set_marching_group(max(0, min(args.marching_group, m.binding.MAX_BATCH)))
             scol = [m.binding.SizeCollector() for _ in range(nworkers)]
+            sshares = [list(farm.worker_share(sbuckets, k, nworkers)) for k in range(nworkers)]
 
             def s_share(k):
-                for b in farm.worker_share(sbuckets, k, nworkers):
-                    sworkers[k].process(swork, b.first, b.count, b.low, b.num_vertices, collector=scol[k])
+                if sbatch > 1:
+                    sworkers[k].process_batch(sprist, sshares[k], collector=scol[k])
+                else:
+                    for b in sshares[k]:
+                        sworkers[k].process(sprist, b.first, b.count, b.low, b.num_vertices, collector=scol[k])
                 ctxs[k].synchronize()
 
             def s_step():
-                swork.copy_from(sprist)
-                ctx.synchronize()
                 list(pool.map(s_share, range(nworkers)))
             for _ in range(2):
                 s_step()
@@ -988,8 +999,29 @@ def main():
             s_dt = (time.perf_counter() - t0) / ssteps
             shells = {"value": round(svox / s_dt / 1e6, 3), "unit": "Mvoxels/s", "ms_per_step": round(s_dt * 1e3, 3), "steps": ssteps,
                       "workload": "cfg3 grid, %d splats on concentric shells (D1 of SURVEY 8d), %d buckets" % (int(50_000_000 * args.scale), len(sbuckets)),
+                      "input_protocol": "resident_in_place (the headline's: non-mutating workers, batches of %d, no restore copy)" % sbatch,
                       "triangles_per_step": sum(c.triangles for c in scol) // ssteps,
                       "vertices_per_step": sum(c.vertices for c in scol) // ssteps}
+            # the other splat protocol (mutating build, every pass starts from a restored copy: the reference's work items
+            # arrive by H2D copy), a few passes, never the leg's `value`
+            for w in sworkers:
+                w.set_keep_splats(False)
+            swork = m.DeviceBuffer(ctx, nbytes=sb_t.numel() * 4)
+
+            def s_share_restore(k):
+                for b in sshares[k]:
+                    m.binding.check(m.lib().mlsgpu_hip_memcpy_d2d(ctxs[k].h, swork.ptr + 32 * b.first, sprist.ptr + 32 * b.first, 32 * b.count))
+                if sbatch > 1:
+                    sworkers[k].process_batch(swork, sshares[k], collector=scol[k])
+                else:
+                    for b in sshares[k]:
+                        sworkers[k].process(swork, b.first, b.count, b.low, b.num_vertices, collector=scol[k])
+                ctxs[k].synchronize()
+            list(pool.map(s_share_restore, range(nworkers)))
+            t0 = time.perf_counter()
+            for _ in range(3):
+                list(pool.map(s_share_restore, range(nworkers)))
+            shells["other_splat_protocol"] = {"mode": "restore_per_bucket", "ms_per_step": round((time.perf_counter() - t0) / 3 * 1e3, 3)}
             sb_host = synth.to_host_splats(sb_t) if not args.no_transfer else None
             del sworkers, swork, sprist, sb_t
             torch.cuda.empty_cache()

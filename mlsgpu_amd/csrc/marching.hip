@@ -971,6 +971,158 @@ __global__ __launch_bounds__(256) void latticeMaskKernel(Lanes<LatticeMaskArgs> 
     }
 }
 
+/*
+ * The same masks, one THREAD per 64-bit word (32 corners) instead of one wave per row of corners.  The wave-per-row kernel
+ * above spends ~730 vector and ~460 scalar instructions per row of 171 corners -- seven ballots per 64 corners, each followed
+ * by scalar mask arithmetic and a 16-byte store from one lane -- and is bound by issuing them (VALU 61 %, one scalar unit per
+ * CU 58 % busy; profiles/r05b_sq_stage_kernels.csv): 0.95 ms per step for 0.35 GB.  Here a lane walks its word's 32 corners
+ * with bit operations of its own: per corner four table lookups (what the cell (x, y - dy, z - dz) gives the corner as its
+ * own cell, low byte, and as the cell to its left, high byte; bits 2h + 1 / 2h = the odd / even point of lattice row h),
+ * three ORs and four two-bit inserts -- ~22 vector instructions per corner and LANE, i.e. a third of an instruction per
+ * corner and wave.  The lanes of a row of corners (nw consecutive ones; 64 / nw rows per wave) exchange their popcounts for
+ * the words' prefixes, and every lattice row leaves as one run of 16-byte stores.  Words, counts and flags are the ones
+ * the wave-per-row kernel writes, bit for bit (MLSGPU_HIP_LATTICE_MASK_ROWS=1 selects it for A/B).
+ */
+__global__ __launch_bounds__(256) void latticeMaskWordKernel(Lanes<LatticeMaskArgs> lanes, const uint16_t *edgeLut16)
+{
+    __shared__ uint16_t sLut[4][256];
+    for (uint32_t i = threadIdx.x; i < 1024; i += 256)
+        (&sLut[0][0])[i] = edgeLut16[i];
+    __syncthreads();
+    const LatticeMaskArgs A = lanes.a[blockIdx.y];
+    const Lattice L = A.L;
+    const CodeView C = A.C;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t nw = L.nw, rowsPerWave = 64u / nw;
+    const uint32_t sub = lane / nw, w = lane - sub * nw;
+    const uint32_t cr = (blockIdx.x * 4 + (threadIdx.x >> 6)) * rowsPerWave + sub;
+    const bool active = sub < rowsPerWave && cr < A.numCornerRows;
+    const uint32_t H = A.H, zCellFirst = A.zCellFirst, zCellLast = A.zCellLast;
+    const uint32_t crc = active ? cr : 0u;
+    const uint32_t y = crc % H, z = crc / H + zCellFirst;
+    const uint32_t cw = L.cw;
+    const uint32_t x0 = 32u * w;                 /* the word's first corner */
+
+    /* the word's 4 x 32 code bytes (cell x of the four adjacent rows of cells), and the byte before them; the bytes behind a
+     * row's end are the next row's (or the buffer's pad) and are masked away */
+    uint32_t keep[8];
+    {
+        const uint32_t have = x0 < cw ? min(cw - x0, 32u) : 0u;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+        {
+            const uint32_t n = have > 4u * j ? min(have - 4u * j, 4u) : 0u;      /* bytes of dword j that exist */
+            keep[j] = n >= 4u ? 0xFFFFFFFFu : (1u << (8u * n)) - 1u;
+        }
+    }
+    uint32_t cd[4][8], before[4];
+    uint32_t occupied = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+        const int dy = r & 1, dz = r >> 1;
+        const int cy = (int) y - dy, cz = (int) z - dz;
+        const bool ok = active && cy >= 0 && cy < (int) L.ch && cz >= (int) zCellFirst && cz < (int) zCellLast;
+        const uint64_t rowIndex = ok ? (uint64_t) ((uint32_t) cz - C.z0) * C.ch + (uint32_t) cy : 0ull;
+        const uint8_t *const rowBase = C.codes + rowIndex * C.cw;
+        const uint8_t *p = rowBase + (x0 < cw ? x0 : 0u);
+        if (ok)
+            occupied += A.cellRowCounts[rowIndex].a;
+        uint4 lo = make_uint4(0, 0, 0, 0), hi = make_uint4(0, 0, 0, 0);
+        if (ok && x0 < cw)
+        {
+            __builtin_memcpy(&lo, p, 16);
+            __builtin_memcpy(&hi, p + 16, 16);
+        }
+        cd[r][0] = lo.x & keep[0]; cd[r][1] = lo.y & keep[1]; cd[r][2] = lo.z & keep[2]; cd[r][3] = lo.w & keep[3];
+        cd[r][4] = hi.x & keep[4]; cd[r][5] = hi.y & keep[5]; cd[r][6] = hi.z & keep[6]; cd[r][7] = hi.w & keep[7];
+        before[r] = (ok && x0 > 0 && x0 - 1 < cw) ? (uint32_t) rowBase[x0 - 1] : 0u;     /* (a word may begin AT the row's end) */
+    }
+
+    /* the four lattice rows of the corner row: h = py | pz << 1 */
+    uint64_t bits[4] = {0, 0, 0, 0};
+    if (occupied != 0)
+    {
+        uint32_t lo32[4] = {0, 0, 0, 0}, hi32[4] = {0, 0, 0, 0};
+        /* what the cell left of the word's first corner gives it */
+        uint32_t leftPrev = ((uint32_t) sLut[0][before[0]] | sLut[1][before[1]] | sLut[2][before[2]] | sLut[3][before[3]]) >> 8;
+#pragma unroll
+        for (int i = 0; i < 32; i++)
+        {
+            const uint32_t e = (uint32_t) sLut[0][(cd[0][i >> 2] >> (8 * (i & 3))) & 0xFFu]
+                | sLut[1][(cd[1][i >> 2] >> (8 * (i & 3))) & 0xFFu]
+                | sLut[2][(cd[2][i >> 2] >> (8 * (i & 3))) & 0xFFu]
+                | sLut[3][(cd[3][i >> 2] >> (8 * (i & 3))) & 0xFFu];
+            const uint32_t pk = (e & 0xFFu) | leftPrev;
+            leftPrev = e >> 8;
+#pragma unroll
+            for (int h = 0; h < 4; h++)
+            {
+                const uint32_t pair = (pk >> (2 * h)) & 3u;
+                if (i < 16)
+                    lo32[h] |= pair << (2 * i);
+                else
+                    hi32[h] |= pair << (2 * (i - 16));
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 4; h++)
+            bits[h] = (uint64_t) lo32[h] | (uint64_t) hi32[h] << 32;
+    }
+
+    /* per lattice row: the word, its bits' count and the column bits; prefixes over the row's words */
+    uint32_t rowId[4], rowCls[4], cnt[4], colCnt[4], colBits[4];
+    bool rowExists[4];
+    uint64_t mainBits[4];
+#pragma unroll
+    for (int h = 0; h < 4; h++)
+    {
+        const uint32_t y2 = 2 * y + (h & 1), z2 = 2 * z + (h >> 1);
+        rowExists[h] = active && y2 <= L.topy && z2 <= L.z2Last;
+        rowId[h] = (z2 - L.z2First) * L.rowsPerLayer + y2;
+        rowCls[h] = L.rowClass(y2, z2);
+        /* points beyond the row's end cannot exist (their cells do not), so the word needs no trimming */
+        const uint64_t cm = rowCls[h] == 2 ? 0ull : L.columnMask(w);
+        const uint64_t col = bits[h] & cm;
+        const uint64_t topBit = w == (L.topx >> 6) ? 1ull << (L.topx & 63) : 0ull;
+        colBits[h] = ((w == 0 && (col & 1ull)) ? LAT_FLAG_X0 : 0u) | ((col & topBit) ? LAT_FLAG_TOP : 0u);
+        mainBits[h] = bits[h] & ~cm;
+        cnt[h] = (uint32_t) __popcll(mainBits[h]);
+        colCnt[h] = (uint32_t) __popcll(col);
+    }
+    /* inclusive sums over the lanes of the row of corners (w' <= w): counts up to 64 * nw <= 512 in 16-bit fields */
+    uint32_t pa = cnt[0] | cnt[1] << 16, pb = cnt[2] | cnt[3] << 16, pc = colCnt[0] | colCnt[1] << 8 | colCnt[2] << 16 | colCnt[3] << 24;
+    uint32_t ia = pa, ib = pb, ic = pc;
+    for (uint32_t d = 1; d < nw; d++)
+    {
+        const uint32_t ta = (uint32_t) __shfl_up((int) pa, d, 64), tb = (uint32_t) __shfl_up((int) pb, d, 64),
+                       tc = (uint32_t) __shfl_up((int) pc, d, 64);
+        if (w >= d)
+        {
+            ia += ta;
+            ib += tb;
+            ic += tc;
+        }
+    }
+    const uint32_t incl[4] = {ia & 0xFFFFu, ia >> 16, ib & 0xFFFFu, ib >> 16};
+#pragma unroll
+    for (int h = 0; h < 4; h++)
+    {
+        if (!rowExists[h])
+            continue;
+        L.words[(uint64_t) rowId[h] * nw + w] = LatWord{mainBits[h], incl[h] - cnt[h], colBits[h]};
+        if (w == nw - 1)
+        {
+            const uint32_t total = incl[h], nFlag = (ic >> (8 * h)) & 0xFFu;
+            U3 c{0u, 0u, 0u};
+            if (rowCls[h] == 0) { c.a = total; c.c = nFlag; }
+            else if (rowCls[h] == 1) { c.b = total; c.c = nFlag; }
+            else c.c = total;
+            L.rowCounts[rowId[h]] = c;
+        }
+    }
+}
+
 /* After the scan of the row counts, one thread per word: make the word's prefix an absolute output index and
  * give every word of a class-0/1 row the row's class-2 start and its two column bits. */
 struct LatticePatchArgs
@@ -1523,6 +1675,33 @@ std::vector<uint64_t> makeEdgeLut()
     return lut;
 }
 
+/* latticeMaskWordKernel's tables, [r = dy | dz << 1][code]: low byte = what the cell gives the corner as its own cell, high
+ * byte = as the cell to its left; bit 2h + 1 = the odd point of lattice row h (+x, +xy, +xz, +xyz), bit 2h = its even point
+ * (h = 1 .. 3: +y, +z, +yz) -- a rearrangement of makeEdgeLut's bytes */
+std::vector<uint16_t> makeEdgeLut16()
+{
+    const std::vector<uint64_t> lut = makeEdgeLut();
+    auto remap = [](uint32_t old)
+    {
+        uint32_t v = 0;
+        for (int h = 0; h < 4; h++)
+        {
+            v |= ((old >> h) & 1u) << (2 * h + 1);
+            if (h > 0)
+                v |= ((old >> (4 + h)) & 1u) << (2 * h);
+        }
+        return v;
+    };
+    std::vector<uint16_t> out(4 * 256, 0);
+    for (uint32_t code = 0; code < 256; code++)
+        for (int r = 0; r < 4; r++)
+        {
+            const uint32_t own = (uint32_t) (lut[code] >> (8 * r)) & 0xFFu, left = (uint32_t) (lut[code] >> (32 + 8 * r)) & 0xFFu;
+            out[r * 256 + code] = (uint16_t) (remap(own) | remap(left) << 8);
+        }
+    return out;
+}
+
 struct Readback
 {
     U3 totals;              /* occupied cells, vertices, indices of the (sub-)swathe */
@@ -1551,6 +1730,7 @@ struct mlsgpu_marching
     uint32_t *dKey = nullptr;
     uint32_t *dCodeRec = nullptr;
     uint64_t *dEdgeLut = nullptr;           /* latticeMaskKernel: per code byte, the lattice points a cell gives a corner */
+    uint16_t *dEdgeLut16 = nullptr;         /* latticeMaskWordKernel: the same, per (dy, dz) */
     uint2 *dCells = nullptr, *dViStart = nullptr, *dHistogram = nullptr;
     U3 *dTileSums3 = nullptr;
     float4 *dVertices = nullptr;
@@ -1700,6 +1880,7 @@ MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, ui
     alloc((void **) &m->dKey, 2432 * 4);
     alloc((void **) &m->dCodeRec, 256 * 16 * 4);
     alloc((void **) &m->dEdgeLut, 256 * 8);
+    alloc((void **) &m->dEdgeLut16, 4 * 256 * 2);
     alloc((void **) &m->dCells, sc * 8);
     alloc((void **) &m->dViStart, sc * 8);
     alloc((void **) &m->dHistogram, (uint64_t) maxDepth * 8);
@@ -1707,7 +1888,7 @@ MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, ui
     m->latRowsMax = (uint64_t) (2 * m->maxSwathe + 1) * (2 * maxHeight - 1);
     m->latWords = (2 * maxWidth - 1 + 63) / 64;
     alloc((void **) &m->dTileSums3, ((uint64_t) scanTiles(std::max(sc, m->latRowsMax)) + 1) * sizeof(U3));
-    alloc((void **) &m->dCellCode, sc);
+    alloc((void **) &m->dCellCode, sc + 64);        /* latticeMaskWordKernel reads whole 32-byte words: up to 31 bytes behind the last row */
     alloc((void **) &m->dRowCounts, ((uint64_t) m->maxSwathe * (maxHeight - 1) + 1) * sizeof(U3));
     alloc((void **) &m->dRowStarts, ((uint64_t) m->maxSwathe * (maxHeight - 1) + 1) * sizeof(U3));
     alloc((void **) &m->dLatWords, m->latRowsMax * m->latWords * sizeof(LatWord));
@@ -1772,6 +1953,8 @@ MLSGPU_API int mlsgpu_hip_marching_create(mlsgpu_ctx *ctx, uint32_t maxWidth, ui
     if (e == hipSuccess) e = hipMemcpy(m->dCodeRec, codeRec.data(), codeRec.size() * 4, hipMemcpyHostToDevice);
     const std::vector<uint64_t> edgeLut = makeEdgeLut();
     if (e == hipSuccess) e = hipMemcpy(m->dEdgeLut, edgeLut.data(), edgeLut.size() * 8, hipMemcpyHostToDevice);
+    const std::vector<uint16_t> edgeLut16 = makeEdgeLut16();
+    if (e == hipSuccess) e = hipMemcpy(m->dEdgeLut16, edgeLut16.data(), edgeLut16.size() * 2, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->dStart, m->tables.start, 257 * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->dData, m->tables.data.data(), 8192, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(m->dKey, packedKey.data(), 2432 * 4, hipMemcpyHostToDevice);
@@ -1789,7 +1972,7 @@ MLSGPU_API void mlsgpu_hip_marching_destroy(mlsgpu_marching *m)
     if (!m)
         return;
     hipSetDevice(m->ctx->device);
-    hipFree(m->dField); hipFree(m->dCount); hipFree(m->dStart); hipFree(m->dData); hipFree(m->dKey); hipFree(m->dCodeRec); hipFree(m->dEdgeLut);
+    hipFree(m->dField); hipFree(m->dCount); hipFree(m->dStart); hipFree(m->dData); hipFree(m->dKey); hipFree(m->dCodeRec); hipFree(m->dEdgeLut); hipFree(m->dEdgeLut16);
     hipFree(m->dCells); hipFree(m->dViStart); hipFree(m->dHistogram); hipFree(m->dTileSums3);
     hipFree(m->dVertices); hipFree(m->dKeysA); hipFree(m->dKeysB); hipFree(m->dValsA); hipFree(m->dValsB);
     hipFree(m->dIndices); hipFree(m->dIndexRemap); hipFree(m->dWelded); hipFree(m->dWeldedKeys);
@@ -1982,8 +2165,19 @@ static int shipOutLatticeLanes(ShipLane *lanes, uint32_t count)
                                      lanes[k].sw.height, j < count ? cornerRows[k] : 0u};
             most = std::max(most, A.a[j].numCornerRows);
         }
-        LAUNCH(ctx, "kernel.marching.countUniqueVertices.time", latticeMaskKernel, dim3(divUp(most, 4), count), dim3(256), A,
-               (const uint64_t *) lanes[0].m->dEdgeLut);
+        static const bool byRows = getenv("MLSGPU_HIP_LATTICE_MASK_ROWS") != nullptr && atoi(getenv("MLSGPU_HIP_LATTICE_MASK_ROWS")) != 0;
+        if (byRows)
+            LAUNCH(ctx, "kernel.marching.countUniqueVertices.time", latticeMaskKernel, dim3(divUp(most, 4), count), dim3(256), A,
+                   (const uint64_t *) lanes[0].m->dEdgeLut);
+        else
+        {
+            /* a thread per word: 64 / nw rows of corners per wave, four waves per workgroup */
+            uint32_t groups = 1;
+            for (uint32_t j = 0; j < count; j++)
+                groups = std::max(groups, divUp(A.a[j].numCornerRows, 4 * (64u / A.a[j].L.nw)));
+            LAUNCH(ctx, "kernel.marching.countUniqueVertices.time", latticeMaskWordKernel, dim3(groups, count), dim3(256), A,
+                   (const uint16_t *) lanes[0].m->dEdgeLut16);
+        }
     }
     typedef ScanJob<U3, ArrayIn<U3>, ArrayIn<U3>, ArrayOut<U3> > RowJob;
     {
