@@ -105,6 +105,11 @@ def parse_args():
                         "takes the whole batch); 0 = all (mlsgpu_hip_worker_set_marching_group)")
     p.add_argument("--variant", type=int, default=5, choices=[1, 4, 5],
                    help="MLS kernel: 5 sub-block culling + matrix-core prefilter (default), 4 sub-block culling + cube streams, 1 the reference's structure")
+    p.add_argument("--dispatch", default="ranks", choices=["ranks", "greedy"],
+                   help="ranks (default; what the driver launches): one process per GPU, rank r = z-slab r of the cfg4 cloud.  "
+                        "greedy: ONE process, a device worker group per GPU, the buckets of the WHOLE cfg4 cloud handed out by the "
+                        "reference's rule (the group with the most unallocated capacity, src/workers.cpp:320-351), every bucket "
+                        "checked against its pin; MLSGPU_TEST_DEVICES=0,0,... runs it on a one-GPU box")
     p.add_argument("--leg-steps", type=int, default=3, help="passes of every secondary leg")
     p.add_argument("--legs", default="all", choices=["all", "none"],
                    help="none: only the timed region, its roofline and (N > 1) the in-run per-GPU reference; all: the secondary legs "
@@ -227,6 +232,11 @@ from benchlegs import (CFG5_PARTITION, cfg5_paths, cpu_baseline, cpu_sample_boxe
 
 def main():
     args = parse_args()
+    if args.dispatch == "greedy":
+        from benchlegs import run_greedy
+        if args.steps == 200:
+            args.steps = 10          # a pass moves the whole cloud over the links: the default K of the resident headline is too long
+        return run_greedy(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))

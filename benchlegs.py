@@ -228,6 +228,168 @@ def run_cfg5(args, rank, world, local_rank, device, dist, reduce_device):
     fs.close()
 
 
+# ------------------------------------------------------------------------------- the reference's dispatch
+
+def test_devices(n):
+    """The GPUs of a one-process job of `n` device groups: 0 .. n - 1, or MLSGPU_TEST_DEVICES=0,0,... (a one-GPU box standing
+    in for n GPUs: a check of the code path, not an n-GPU measurement)."""
+    env = os.environ.get("MLSGPU_TEST_DEVICES")
+    if env:
+        devs = [int(x) for x in env.split(",")]
+        if len(devs) != n:
+            raise SystemExit("MLSGPU_TEST_DEVICES names %d devices, --gpus %d" % (len(devs), n))
+        return devs, True
+    return list(range(n)), False
+
+
+def cfg4_bucket_pins(dist_name):
+    path = os.path.join(ROOT, "tests", "golden", "cfg4_buckets_%s.json" % dist_name)
+    try:
+        return json.load(open(path))
+    except Exception:   # noqa: BLE001
+        return None
+
+
+def run_greedy(args):
+    """`bench.py --gpus N --dispatch greedy`: BASELINE configs[3] the way the reference runs it -- ONE process, a device
+    worker group per GPU behind one copy side per socket, every bucket of the WHOLE cfg4 cloud (125 buckets of <= 255 cells
+    per side) pushed in partition order to the group with the most unallocated capacity that can take an item
+    (src/workers.cpp:320-351, src/mlsgpu_core.cpp:704-741).  Which GPU a bucket lands on depends on timing, so the check is
+    per bucket and order-independent: every bucket's ship-outs digest against its pin (tests/golden/cfg4_buckets_<dist>.json,
+    written next to oracle parity on sampled buckets by tests/test_gpu_configs.py::test_cfg4_bucket_pins)."""
+    import torch
+    import mlsgpu_amd as m
+    from mlsgpu_amd import synth
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) > 1:
+        raise SystemExit("--dispatch greedy is ONE process over N GPUs: run `python bench.py --gpus N --dispatch greedy` itself")
+    n = args.gpus
+    devs, shared = test_devices(n)
+    if max(devs) >= torch.cuda.device_count():
+        raise SystemExit("--gpus %d --dispatch greedy: device %d is not there (%d visible; MLSGPU_TEST_DEVICES=0,0,... runs the "
+                         "code path on fewer)" % (n, max(devs), torch.cuda.device_count()))
+    torch.cuda.set_device(devs[0])
+    device = torch.device("cuda", devs[0])
+    cloud, g = synth.make_cloud_device("cfg4", device, scale=args.scale, dist=args.dist)
+    n_splats = len(cloud)
+    bucketed, buckets = synth.bucketize_device(cloud, synth.grid_buckets((g, g, g), 255))
+    del cloud
+    max_count = max(b.count for b in buckets)
+    max_cells = max(max(b.num_vertices) for b in buckets) - 1
+    voxels = sum(b.cells for b in buckets)
+    host = synth.to_host_splats(bucketed)
+    views = [host[b.first:b.first + b.count] for b in buckets]
+    farm = m.BucketFarm(devs, max_count, workers_per_device=args.farm_workers, spare=args.farm_spare, collect="checksum",
+                        max_cells=max_cells, mesh_memory=args.mesh_memory_mb << 20, copy_threads=args.copy_threads,
+                        staging_buffers=args.staging_buffers)
+    if args.farm_batch > 1:
+        farm.set_batch(args.farm_batch)
+
+    def host_fed():
+        for i, (b, v) in enumerate(zip(buckets, views)):
+            farm.submit(v, b.low, b.num_vertices, i)
+        farm.finish()
+
+    # ---- the checked pass: every bucket against its pin ----
+    host_fed()
+    got = {i: m.binding.digest_of_sums(farm.sums.get(i, [])) for i in range(len(buckets))}
+    totals = dict(triangles=sum(r[1] for v in farm.sums.values() for r in v), vertices=sum(r[0] for v in farm.sums.values() for r in v))
+    pins = cfg4_bucket_pins(args.dist) if args.scale == 1.0 else None
+    check = {"buckets": len(buckets), "pinned": pins is not None}
+    if pins is not None:
+        bad = [i for i in range(len(buckets)) if got[i] != pins["buckets"][i]["digest"]]
+        check.update(ok=not bad, mismatches=bad[:8], totals_ok=totals == {k: pins["total"][k] for k in totals})
+        if bad or not check["totals_ok"]:
+            raise SystemExit("greedy dispatch: %d of %d buckets differ from tests/golden/cfg4_buckets_%s.json (first: %s)"
+                             % (len(bad), len(buckets), args.dist, bad[:8]))
+    farm.checksums = False
+    for _ in range(args.warmup):
+        host_fed()
+    s0, c0, w0 = farm.stats(), farm.copy_clock(), farm.worker_clock()
+    g0 = [farm.group_clock(k) for k in range(n)]
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        host_fed()
+    elapsed = time.perf_counter() - t0
+    s1, c1, w1 = farm.stats(), farm.copy_clock(), farm.worker_clock()
+    g1 = [farm.group_clock(k) for k in range(n)]
+    per_dev = []
+    for k in range(n):
+        d = {key: g1[k][key] - g0[k][key] for key in g1[k]}
+        workers = max(args.farm_workers, 1)
+        per_dev.append({"device": devs[k], "buckets": d["buckets"], "launch_sets": d["launch_sets"],
+                        "busy_s_per_worker": round(d["busy_s"] / workers, 4), "idle_s_per_worker": round(d["idle_s"] / workers, 4),
+                        "idle_frac": round(d["idle_s"] / max(d["idle_s"] + d["busy_s"], 1e-12), 4)})
+    value = voxels * args.steps / elapsed / 1e6
+
+    # ---- the same buckets from the cloud resident on the first GPU: device gathers, peer copies to the other GPUs' items ----
+    device_fed = None
+    try:
+        ctx = m.Context(devs[0])
+        raw = m.DeviceBuffer(ctx, nbytes=bucketed.numel() * 4, borrow=bucketed.data_ptr())
+        iota = m.DeviceBuffer(ctx, array=np.arange(max_count, dtype=np.uint32))
+        ext = (0, g - 1, 0, g - 1, 0, g - 1)
+
+        class _Sub:
+            def __init__(self, ptr):
+                self.ptr = ptr
+
+        def dev_fed():
+            for i, b in enumerate(buckets):
+                farm.submit_device(devs[0], _Sub(raw.ptr + 32 * b.first), iota.ptr, b.count, (0.0, 0.0, 0.0), 1.0, ext, b.low,
+                                   b.num_vertices, i)
+            farm.finish()
+        farm.checksums = True
+        farm.sums.clear()
+        dev_fed()
+        dgot = {i: m.binding.digest_of_sums(farm.sums.get(i, [])) for i in range(len(buckets))}
+        if dgot != got:
+            raise SystemExit("greedy dispatch: the device-fed pass produced other meshes than the host-fed one")
+        farm.checksums = False
+        dev_fed()
+        ds = max(2, min(args.steps, 10))
+        t1 = time.perf_counter()
+        for _ in range(ds):
+            dev_fed()
+        d_el = (time.perf_counter() - t1) / ds
+        device_fed = {"value": round(voxels / d_el / 1e6, 3), "unit": "Mvoxels/s", "ms_per_pass": round(d_el * 1e3, 2), "passes": ds,
+                      "digests": "equal to the host-fed pass, bucket by bucket"}
+        del raw, iota
+    except SystemExit:
+        raise
+    except Exception as e:      # noqa: BLE001 - a secondary figure
+        device_fed = {"error": "%s: %s" % (type(e).__name__, e)}
+    placement = farm.placement() if hasattr(farm, "placement") else None
+    farm.close()
+    result = {
+        "metric": "Mvoxels/s evaluated+triangulated (and Msplats/s in)", "value": round(value, 3), "unit": "Mvoxels/s", "n_gpus": n,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "msplats_per_s": round(n_splats * args.steps / elapsed / 1e6, 3),
+        "input_protocol": "host_fed_greedy: every pass hands the buckets' splats over from host memory (copy threads -> pinned "
+                          "staging -> H2D to the chosen GPU), as the reference's loader does; meshes are counted and checksummed "
+                          "on the device, not read back",
+        "config": {"workload": "cfg4 (BASELINE configs[3]) WHOLE: %d^3 grid, %d splats (%s), %d buckets of <= %d cells per side, "
+                               "one process, greedy dispatch over %d device group(s)" % (g, n_splats, args.dist, len(buckets), max_cells, n),
+                   "dispatch": "greedy (src/workers.cpp:320-351): the group with the most unallocated splat capacity that can take an item",
+                   "devices": devs, "workers_per_device": args.farm_workers, "spare_items": args.farm_spare, "farm_batch": args.farm_batch,
+                   "parallelism": "%d device group(s), one process" % n},
+        "output_digest": check,
+        "per_device": per_dev,
+        "copy_side": {"h2d_GBps": round((s1["h2d_bytes"] - s0["h2d_bytes"]) / elapsed / 1e9, 2),
+                      "h2d_stream_s_over_span": round((c1["h2d_s"] - c0["h2d_s"]) / max(c1["span_s"] - c0["span_s"], 1e-12), 4),   # summed over the GPUs' copy streams: up to N
+                      "wait_item_s": round(c1["wait_item_s"] - c0["wait_item_s"], 4),
+                      "wait_staging_s": round(c1["wait_staging_s"] - c0["wait_staging_s"], 4)},
+        "buckets_per_launch_set": round((w1["buckets"] - w0["buckets"]) / max(w1["launch_sets"] - w0["launch_sets"], 1), 2),
+        "in_flight_max": s1.get("in_flight_max"),
+        "device_fed": device_fed,
+        "placement": placement,
+    }
+    if shared:
+        result["debug_shared_gpu"] = ("%d device groups on GPU(s) %s (MLSGPU_TEST_DEVICES): a check of the dispatch, NOT an "
+                                      "N-GPU measurement" % (n, sorted(set(devs))))
+    print(json.dumps(result))
+
+
 # ---------------------------------------------------------------------------------------------------- legs
 
 def drain_utilisation(c):

@@ -416,6 +416,9 @@ int mlsgpu_hip_farm_copy_clock(mlsgpu_farm *farm, double out[8]);
  * or one bucket), [1] buckets in them ([1] / [0] = buckets per set of launches), [2] seconds the workers waited for an item,
  * [3] seconds they spent processing, both summed over the workers. */
 int mlsgpu_hip_farm_worker_clock(mlsgpu_farm *farm, double out[4]);
+/* the same four figures for ONE device group (the `group`-th device of the configuration): what the greedy dispatch of
+ * src/workers.cpp:320-351 gave that GPU and how long its workers sat without an item */
+int mlsgpu_hip_farm_group_clock(mlsgpu_farm *farm, uint32_t group, double out[4]);
 /* The most device items (DeviceWorkerGroup::WorkItem, src/workers.h:165-181) that were in flight at once since the farm
  * was created: taken from a group's pool by the copy side and not yet returned by a device worker. */
 int mlsgpu_hip_farm_in_flight_max(mlsgpu_farm *farm, uint64_t *out);

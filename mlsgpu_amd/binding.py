@@ -246,6 +246,7 @@ def lib():
     sig("mlsgpu_hip_farm_copy_clock", C.c_int, vp, vp)
     sig("mlsgpu_hip_farm_submit_device_async", C.c_int, vp, C.c_int, vp, vp, u64, vp, vp, vp, u64, vp)
     sig("mlsgpu_hip_farm_worker_clock", C.c_int, vp, vp)
+    sig("mlsgpu_hip_farm_group_clock", C.c_int, vp, u32, vp)
     sig("mlsgpu_hip_host_mesher_trim_cache", u64, u64)
     sig("mlsgpu_hip_host_mesher_set_node", C.c_int, vp, C.c_int)
     sig("mlsgpu_hip_host_mesher_node", C.c_int, vp)
@@ -1412,6 +1413,12 @@ class BucketFarm:
         """The device workers' clock (mlsgpu_hip_farm_worker_clock): launch sets, buckets, idle and busy seconds."""
         out = np.zeros(4, np.float64)
         check(lib().mlsgpu_hip_farm_worker_clock(self.h, _p(out)))
+        return dict(launch_sets=int(out[0]), buckets=int(out[1]), idle_s=float(out[2]), busy_s=float(out[3]))
+
+    def group_clock(self, group):
+        """One device group's share of worker_clock() (mlsgpu_hip_farm_group_clock)."""
+        out = np.zeros(4, np.float64)
+        check(lib().mlsgpu_hip_farm_group_clock(self.h, group, _p(out)))
         return dict(launch_sets=int(out[0]), buckets=int(out[1]), idle_s=float(out[2]), busy_s=float(out[3]))
 
     def host_stats(self):

@@ -61,6 +61,7 @@ struct DeviceGroup               /* DeviceWorkerGroup, src/workers.h:214-350 */
     std::deque<WorkItem *> queue;        /* pushed, not yet taken by a worker */
     uint64_t unallocated = 0;
     uint64_t bucketsDone = 0;
+    double clock[4] = {0, 0, 0, 0};      /* this group's share of the farm's worker clock: sets, buckets, waited, worked */
     std::vector<std::thread> threads;
     std::vector<hipEvent_t> eventPool;   /* read-back events of this device (guarded by the farm's mutex) */
     /* Buckets of a cloud resident HERE on their way to another GPU's item: gathered into one buffer of a small ring,
@@ -401,7 +402,9 @@ void workerMain(Farm *farm, DeviceGroup *g)
         {
             std::unique_lock<std::mutex> l(farm->mutex);
             farm->queueCond.wait(l, [&] { return farm->stopping || !g->queue.empty(); });
-            farm->workerClock[2] += secondsSince(tIdle);
+            const double waited = secondsSince(tIdle);
+            farm->workerClock[2] += waited;
+            g->clock[2] += waited;
             if (g->queue.empty())
                 break;
             size_t subs = 0;
@@ -508,9 +511,13 @@ void workerMain(Farm *farm, DeviceGroup *g)
             }
         {
             std::lock_guard<std::mutex> l(farm->mutex);
+            const double worked = secondsSince(tWork);
             farm->workerClock[0] += 1;
             farm->workerClock[1] += (double) numSubs;
-            farm->workerClock[3] += secondsSince(tWork);
+            farm->workerClock[3] += worked;
+            g->clock[0] += 1;
+            g->clock[1] += (double) numSubs;
+            g->clock[3] += worked;
         }
         for (size_t t = 0; t < taken.size(); t++)
         {
@@ -1283,6 +1290,16 @@ MLSGPU_API int mlsgpu_hip_farm_worker_clock(mlsgpu_farm *f, double out[4])
     std::lock_guard<std::mutex> l(f->mutex);
     for (int i = 0; i < 4; i++)
         out[i] = f->workerClock[i];
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_farm_group_clock(mlsgpu_farm *f, uint32_t group, double out[4])
+{
+    REQUIRE(f != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(group < f->groups.size(), MLSGPU_ERR_LENGTH);
+    std::lock_guard<std::mutex> l(f->mutex);
+    for (int i = 0; i < 4; i++)
+        out[i] = f->groups[group]->clock[i];
     return MLSGPU_OK;
 }
 

@@ -169,3 +169,18 @@ def test_bench_rccl_code_path_with_one_rank():
     assert d["per_gpu_reference"]["value"] > 0 and "leg_errors" not in d
     assert d["transfer_inclusive"]["device_sink_global_weld"]["value"] > 0
     assert d["single_process"]["host_fed"]["value"] > 0 and d["single_process"]["device_fed"]["value"] > 0
+
+
+def test_bench_greedy_dispatch_two_groups_on_one_gpu():
+    """`bench.py --gpus 2 --dispatch greedy`: ONE process, two device groups (both on GPU 0 here: MLSGPU_TEST_DEVICES=0,0), the
+    whole cfg4 cloud's 125 buckets handed out by the reference's rule, every bucket against its pin, host-fed and
+    device-fed; both groups get work."""
+    env = dict(os.environ, MLSGPU_TEST_DEVICES="0,0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dispatch", "greedy", "--steps", "2",
+                        "--warmup", "1"], capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["output_digest"]["pinned"] and line["output_digest"]["ok"] and line["output_digest"]["totals_ok"]
+    assert [d["device"] for d in line["per_device"]] == [0, 0]
+    assert sum(d["buckets"] for d in line["per_device"]) == 2 * 125 and min(d["buckets"] for d in line["per_device"]) > 0
+    assert "debug_shared_gpu" in line and "error" not in (line["device_fed"] or {})

@@ -12,6 +12,9 @@ cfg4s ALL EIGHT slabs of the sharded cfg4 cloud at FULL density (what bench.py -
       the other on this GPU, as an inner and as a last slab: totals + digest of every rank of an N = 2 / 4 / 8 job pinned in
       tests/golden/cfg4slab_uniform.json (bench.py compares every rank's digest with its pin), oracle bit-parity on a
       bucket of slabs 0, 3 and 7, and the seven slab seams bit-identical from both sides.
+cfg4w the WHOLE cfg4 cloud as the reference's partition would cut it on a regular grid (125 buckets): per-bucket digests for
+      bench.py --dispatch greedy (one process, device groups, the reference's dispatch rule), uniform and shells, next to
+      oracle bit-parity on three buckets.
 cfg5  2048^3 grid, 10^9 splats (a smaller count only if the box lacks the RAM) written as 8 PLY files by the device
       generator -> FileSet reader threads -> HBM -> Bucket::bucket on the device -> eight device groups by device-side
       gathers: partition properties on all ~730 buckets, oracle bit-parity on three leaves, cross-bucket agreement on a
@@ -192,6 +195,63 @@ def test_cfg2_full_size(ctx, dist):
         assert st["shipouts"] == len(batches) >= 1
         assert_batches_equal(batches, exp_b)
         del batches, w
+
+
+@pytest.mark.parametrize("dist", ["uniform", "shells"])
+def test_cfg4_bucket_pins(ctx, dist):
+    """BASELINE configs[3] WHOLE (1024^3 grid, 200 M splats, 125 buckets of <= 255 cells per side), bucket by bucket on one
+    worker: the per-bucket digests `bench.py --gpus N --dispatch greedy` holds every bucket against, whichever GPU the
+    reference's greedy rule (src/workers.cpp:320-351) sends it to -- pinned in tests/golden/cfg4_buckets_<dist>.json next to
+    oracle bit-parity on a corner, the centre and the far-corner bucket."""
+    import torch
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as mb, synth
+    dev = torch.device("cuda", 0)
+    cloud, g = synth.make_cloud_device("cfg4", dev, dist=dist)
+    assert len(cloud) == 200_000_000 and g == 1024
+    record_size("cfg4 whole, %s" % dist, "%d splats, 125 buckets, per-bucket digests" % len(cloud))
+    bucketed, buckets = synth.bucketize_device(cloud, synth.grid_buckets((g, g, g), 255))
+    del cloud
+    torch.cuda.synchronize()
+    assert len(buckets) == 125 and sum(b.cells for b in buckets) == (g - 1) ** 3
+    max_cells = max(max(b.num_vertices) for b in buckets) - 1
+    max_count = max(b.count for b in buckets)
+    pristine = m.DeviceBuffer(ctx, nbytes=bucketed.numel() * 4, borrow=bucketed.data_ptr())
+    w = m.Worker(ctx, max_count, max_cells=max_cells, mesh_memory=4096 << 20)
+    w.set_keep_splats(True)
+    per, tri, ver = [], 0, 0
+    for b in buckets:
+        col = w.process(pristine, b.first, b.count, b.low, b.num_vertices, collector=mb.ChecksumCollector(ctx))
+        per.append(dict(low=list(b.low), num_vertices=list(b.num_vertices), splats=int(b.count), triangles=int(col.triangles),
+                        digest=col.digest()))
+        tri += int(col.triangles)
+        ver += int(col.vertices)
+    got = dict(buckets=per, total=dict(triangles=tri, vertices=ver))
+    golden = os.path.join(os.path.dirname(GOLDEN), "cfg4_buckets_%s.json" % dist)
+    if os.environ.get("MLSGPU_WRITE_GOLDEN"):
+        out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "cfg4_buckets_%s.json" % dist)
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        json.dump(got, open(out, "w"), indent=0)
+    else:
+        assert got == json.load(open(golden))
+    del w
+    # ---- oracle bit-parity on three buckets ----
+    mm = 1 << 30
+    w = m.Worker(ctx, max_count, max_cells=max_cells, mesh_memory=mm)
+    w.set_keep_splats(True)
+    # (a corner, the centre and the far corner where they hold a surface; on the shells cloud the buckets with the most, the
+    # median and the fewest triangles among those that have any)
+    nonempty = sorted((i for i in range(len(per)) if per[i]["triangles"] > 0), key=lambda i: per[i]["triangles"])
+    assert len(nonempty) >= 3
+    sample = (0, 62, 124) if all(per[i]["triangles"] > 0 for i in (0, 62, 124)) else (nonempty[0], nonempty[len(nonempty) // 2], nonempty[-1])
+    for i in sample:
+        b = buckets[i]
+        host = bucketed[b.first:b.first + b.count].cpu().numpy().view(m.SPLAT_DTYPE).reshape(-1)
+        batches = w.process(pristine, b.first, b.count, b.low, b.num_vertices)
+        exp_b, st = ob.bucket(host, 0, b.count, b.num_vertices, b.low, max_cells=max_cells, max_swathe=max_cells + 1, mesh_memory=mm)
+        assert st["shipouts"] == len(batches) >= 1
+        assert_batches_equal(batches, exp_b)
+        del batches, exp_b
 
 
 def farm_devices(n):
