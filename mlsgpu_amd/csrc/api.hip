@@ -558,10 +558,24 @@ MLSGPU_API int mlsgpu_hip_worker_set_batch(mlsgpu_worker *w, uint32_t lanes)
     REQUIRE(w != nullptr && !w->lanes.empty(), MLSGPU_ERR_INVALID);
     REQUIRE(lanes >= 1 && lanes <= MLSGPU_MAX_BATCH, MLSGPU_ERR_LENGTH);
     HIP_CHECK(hipSetDevice(w->ctx->device));
+    const size_t before = w->lanes.size();
     while (w->lanes.size() < lanes)
     {
         WorkerLane l;
-        PROPAGATE(createLane(w, &l));
+        const int rc = createLane(w, &l);
+        if (rc != MLSGPU_OK)
+        {
+            /* all or nothing: a caller that falls back to fewer lanes (the farm's workers do, on MLSGPU_ERR_NOMEM) gets the
+             * memory of the lanes this call managed to create back, and no stale HIP error is left pending */
+            const std::string text = mlsgpu::lastError;
+            while (w->lanes.size() > before)
+            {
+                destroyLane(w->lanes.back());
+                w->lanes.pop_back();
+            }
+            (void) hipGetLastError();
+            return setError(rc, "%s", text.c_str());
+        }
         w->lanes.push_back(l);
     }
     return MLSGPU_OK;

@@ -1364,7 +1364,11 @@ int Bucketer::recurseStream(mlsgpu_fileset *files, uint64_t n, const GridBox &gr
                     }
                     dSplats = saved;
                     PROPAGATE(rc);
-                    HIP_CHECK(hipStreamSynchronize(ctx->stream));       /* the batch buffer is refilled next */
+                    /* the batch buffer and this level's member lists are refilled next: behind the callbacks' own reads
+                     * (mlsgpu_bucket::consumed -- a callback may only have ENQUEUED its gather, on any stream), not just behind
+                     * this stream's work */
+                    settleReaders();
+                    HIP_CHECK(hipStreamSynchronize(ctx->stream));
                     r0 = r1;
                 }
             }

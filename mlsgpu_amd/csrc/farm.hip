@@ -1307,19 +1307,32 @@ MLSGPU_API int mlsgpu_hip_farm_copy_clock(mlsgpu_farm *f, double out[8])
 {
     REQUIRE(f != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
     /* the copies still attached to items are added without being consumed: the caller has finished the farm */
-    std::lock_guard<std::mutex> l(f->mutex);
-    for (int i = 0; i < 8; i++)
-        out[i] = f->copyClock[i];
-    for (auto &g : f->groups)
-        for (auto &item : g->items)
-            if (item->copyTimed && hipEventQuery(item->copyStop) == hipSuccess)
-            {
-                float ms = 0.0f;
-                if (hipEventElapsedTime(&ms, item->copyStart, item->copyStop) == hipSuccess)
-                    out[3] += ms * 1e-3;
-            }
+    /* the event handles are snapshotted under the mutex and queried after it is released (the workers contend for it), each
+     * on its own device */
+    struct Timed { int device; hipEvent_t start, stop; };
+    std::vector<Timed> timed;
+    {
+        std::lock_guard<std::mutex> l(f->mutex);
+        for (int i = 0; i < 8; i++)
+            out[i] = f->copyClock[i];
+        for (auto &g : f->groups)
+            for (auto &item : g->items)
+                if (item->copyTimed)
+                    timed.push_back(Timed{g->device, item->copyStart, item->copyStop});
+        out[4] = f->clockRunning ? std::chrono::duration<double>(f->lastFlush - f->firstSubmit).count() : 0.0;
+    }
+    int current = -1;
+    (void) hipGetDevice(&current);
+    for (const Timed &t : timed)
+    {
+        (void) hipSetDevice(t.device);
+        float ms = 0.0f;
+        if (hipEventQuery(t.stop) == hipSuccess && hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess)
+            out[3] += ms * 1e-3;
+    }
+    if (current >= 0)
+        (void) hipSetDevice(current);
     (void) hipGetLastError();
-    out[4] = f->clockRunning ? std::chrono::duration<double>(f->lastFlush - f->firstSubmit).count() : 0.0;
     return MLSGPU_OK;
 }
 

@@ -383,3 +383,35 @@ def test_farm_reports_placement_and_clocks():
     assert cc["copies"] == farm.stats()["items"] >= 1 and cc["h2d_s"] > 0 and cc["fill_s"] > 0 and cc["span_s"] >= cc["h2d_s"] * 0.5
     assert wc["buckets"] == n and 1 <= wc["launch_sets"] <= n and wc["busy_s"] > 0
     farm.close()
+
+
+@pytest.mark.gpu
+def test_farm_keep_splats_digest_equals_mutating_worker():
+    """The farm's workers never write 1/r^2 back into their items (keep_splats: processCorners takes the reciprocal while
+    staging); a plain Worker with the reference's MUTATING build (kernels/octree.cl:193) on the same buckets must produce the
+    same ship-outs -- compared through the device-side digest, bucket by bucket."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import binding as mb, synth
+    cloud = synth.shells_cloud(90_000, 95.0, 16.0, 1.5, 2.5, seed=99)
+    allb, buckets = synth.bucketize(cloud, 96, 48)
+    cap = 2 * max(b.count for b in buckets)
+    farm = m.BucketFarm([0], cap, workers_per_device=2, collect="checksum", max_cells=63)
+    farm.set_batch(3)
+    for i, b in enumerate(buckets):
+        farm.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, i)
+    farm.finish()
+    farm_digests = {i: mb.digest_of_sums(farm.sums.get(i, [])) for i in range(len(buckets))}
+    farm.close()
+    ctx = m.Context(0)
+    w = m.Worker(ctx, max(b.count for b in buckets), max_cells=63)
+    w.set_keep_splats(False)
+    buf = m.DeviceBuffer(ctx, array=allb)
+    nonempty = 0
+    for i, b in enumerate(buckets):
+        col = w.process(buf, b.first, b.count, b.low, b.num_vertices, collector=mb.ChecksumCollector(ctx))
+        assert col.digest() == farm_digests[i], i
+        nonempty += col.triangles > 0
+    assert nonempty >= 4
+    # ... and the mutating worker did write 1/r^2 where the farm's items keep the radius
+    after = buf.download(np.float32).reshape(-1, 8)[:, 3]
+    assert not np.array_equal(after, allb["radius"])
