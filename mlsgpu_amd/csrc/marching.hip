@@ -1172,6 +1172,9 @@ struct LatticeVerticesArgs
     uint32_t numPairs;       /* quads: ceil(layers / 2) x ceil(rowsPerLayer / 2) */
 };
 
+/* XF: the scale / bias of ScaleBiasFilter for every bucket of the launch (1), for none (0), or as each bucket says (2: both
+ * results computed and selected -- nine vector instructions of an iteration's ~40 instead of three) */
+template<int XF>
 __global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVerticesArgs> lanes)
 {
     const LatticeVerticesArgs A = lanes.a[blockIdx.y];
@@ -1273,7 +1276,7 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVertic
                     float vx = fmaf(t, (float) px, (float) (cx + gox));
                     float vy = fmaf(t, (float) py, (float) (cy + goy));
                     float vz = fmaf(t, (float) pz, (float) (cz + goz));
-                    if (X.enabled)
+                    if (XF == 2 ? (bool) X.enabled : XF == 1)
                     {
                         vx = fmaf(vx, X.scale, X.bx);
                         vy = fmaf(vy, X.scale, X.by);
@@ -2213,7 +2216,15 @@ static int shipOutLatticeLanes(ShipLane *lanes, uint32_t count)
                                          j < count ? (numRows[k] / Ls[k].rowsPerLayer + 1) / 2 * ((Ls[k].rowsPerLayer + 1) / 2) : 0u};
             most = std::max(most, A.a[j].numPairs);
         }
-        LAUNCH(ctx, "kernel.marching.compactVertices.time", latticeVerticesKernel, dim3(divUp(most, 4), count), dim3(256), A);
+        uint32_t enabled = 0;
+        for (uint32_t k = 0; k < count; k++)
+            enabled += lanes[k].m->transform.enabled ? 1u : 0u;
+        if (enabled == count)
+            LAUNCH(ctx, "kernel.marching.compactVertices.time", latticeVerticesKernel<1>, dim3(divUp(most, 4), count), dim3(256), A);
+        else if (enabled == 0)
+            LAUNCH(ctx, "kernel.marching.compactVertices.time", latticeVerticesKernel<0>, dim3(divUp(most, 4), count), dim3(256), A);
+        else
+            LAUNCH(ctx, "kernel.marching.compactVertices.time", latticeVerticesKernel<2>, dim3(divUp(most, 4), count), dim3(256), A);
     }
     /* first cell / index slot of every row of cells of the batch, the compacted cells, then the triangles */
     {
