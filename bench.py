@@ -1038,6 +1038,8 @@ def main():
             if not args.no_transfer:
                 shells["transfer_inclusive"] = transfer_legs(m, args, local_rank, sb_host, sbuckets, smax, scells, svox, L)
                 shells["transfer_inclusive"]["host_weld"] = host_weld_leg(m, args, local_rank, sb_host, sbuckets, smax, scells, svox)
+                shells["transfer_inclusive"]["host_weld_ring"] = host_weld_leg(m, args, local_rank, sb_host, sbuckets, smax, scells, svox,
+                                                                               landing=False)
             result["shells"] = shells
         except Exception as e:      # noqa: BLE001 - reported in the line
             result.setdefault("leg_errors", {})['shells'] = "%s: %s" % (type(e).__name__, e)

@@ -674,14 +674,16 @@ def transfer_legs(m, args, device_index, bucketed_host, buckets, max_count, max_
     return out
 
 
-def host_weld_leg(m, args, device_index, bucketed_host, buckets, max_count, max_cells, voxels, steps=3):
+def host_weld_leg(m, args, device_index, bucketed_host, buckets, max_count, max_cells, voxels, steps=3, landing=True):
     """The reference's complete route, welder included: host splats -> farm -> every ship-out read back through the pinned ring
     -> the mesher thread hands it to the host welder (OOCMesher's weld: local components, key map, union-find;
     src/mesher.cpp:220-311 -- a task per block on the welder's pool of threads, where the reference has one thread and an
     OpenMP rewrite, src/mesher.cpp:597-600) -> finalize (components, prune, one mesh per chunk).  One job = one fresh welder;
     a warm-up job first (the welder's memory comes from a cache of mapped slabs).  Two figures: a job ALONE (its latency: pass,
     then finalize), and a STREAM of jobs in which job k's finalize runs on its own thread while job k + 1's buckets are already
-    going through the farm into the next welder -- the steady state `value` is quoted on."""
+    going through the farm into the next welder -- the steady state `value` is quoted on.
+    landing=True (round 6): the read-backs land in page-locked memory of the WELDER and are adopted there
+    (mlsgpu_hip_farm_set_host_landing); landing=False: through the farm's pinned ring, copied out by the welder (rounds 4-5)."""
     import threading
     nworkers = max(1, min(args.farm_workers, len(buckets)))
     farm = m.BucketFarm([device_index], max_count, workers_per_device=nworkers, spare=args.farm_spare, max_cells=max_cells,
@@ -690,7 +692,10 @@ def host_weld_leg(m, args, device_index, bucketed_host, buckets, max_count, max_
     last = {}
 
     def stream_in(welder):
-        farm.set_host_output(2 << 30, welder)
+        if landing:
+            farm.set_host_landing(welder)
+        else:
+            farm.set_host_output(2 << 30, welder)
         for b, v in zip(buckets, views):
             farm.submit(v, b.low, b.num_vertices, 0)
         farm.finish()
@@ -748,6 +753,8 @@ def host_weld_leg(m, args, device_index, bucketed_host, buckets, max_count, max_
                          "stream_in_ms": round(sum(in_times[-jobs:]) / jobs * 1e3, 1),
                          "wait_for_previous_finalize_ms": round(sum(join_times[-jobs:]) / jobs * 1e3, 1),
                          "what": "job k's finalize on its own thread while job k + 1 streams into the next welder"},
+            "route": ("landing: read-backs land in the welder's own page-locked memory, adopted without a copy" if landing
+                      else "ring: read-backs land in the farm's pinned ring, the welder copies every block out"),
             "vertices_welded_per_s": round(st["vertices_added"] / total), "weld_threads": last["threads"], "chunks": last["n"],
             "ring_waits": hs["ring_waits"], "welded_vertices": st["total_vertices"], "kept_triangles": st["kept_triangles"],
             "note": "per job, jobs one after the other: host splats in -> farm -> ring read-backs -> host welder (a task per block on "

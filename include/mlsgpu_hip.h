@@ -447,6 +447,15 @@ typedef int (*mlsgpu_farm_host_output_fn)(void *user, int device, uint64_t chunk
  * mlsgpu_hip_farm_create still runs first.  A ship-out larger than ringBytes is MLSGPU_ERR_LENGTH.  Calling it again
  * BETWEEN jobs (after mlsgpu_hip_farm_finish) hands the next job's meshes to another consumer; the ring keeps its size. */
 int mlsgpu_hip_farm_set_host_output(mlsgpu_farm *farm, uint64_t ringBytes, mlsgpu_farm_host_output_fn fn, void *user);
+/* The same route with the CONSUMER's memory instead of the ring: `landing(user, bytes, &ptr)` hands out room for one
+ * ship-out (page-locked memory that stays the consumer's: mlsgpu_hip_host_mesher_farm_landing), the asynchronous read-back
+ * lands there, and `fn` receives pointers into it which it may keep -- the reference's mesher also reads its
+ * CircularBuffer allocation in place (src/workers.h:488-509, src/mesher.cpp:447-469) before it writes the block to its
+ * temporary file; here the block never moves again.  No ship-out waits for room.  Same calling rules as
+ * mlsgpu_hip_farm_set_host_output (before the first bucket, or between jobs); calling that one afterwards goes back to the
+ * ring. */
+typedef int (*mlsgpu_farm_landing_fn)(void *user, uint64_t bytes, void **out);
+int mlsgpu_hip_farm_set_host_landing(mlsgpu_farm *farm, mlsgpu_farm_landing_fn landing, mlsgpu_farm_host_output_fn fn, void *user);
 /* out[0] meshes read back, [1] bytes, [2] times a worker waited for ring space, [3] largest mesh in bytes */
 int mlsgpu_hip_farm_host_stats(mlsgpu_farm *farm, uint64_t out[4]);
 /* BucketLoader's world -> grid transform (src/bucket_loader.cpp:77-85, Grid::worldToVertex src/grid.cpp:99-106):
@@ -609,6 +618,16 @@ int mlsgpu_hip_host_mesher_node(mlsgpu_host_mesher *mesher);
 int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *mesher, uint64_t chunkId, const mlsgpu_host_mesh *mesh);
 /* a mlsgpu_farm_host_output_fn whose `user` is the mlsgpu_host_mesher */
 int mlsgpu_hip_host_mesher_farm_output(void *mesher, int device, uint64_t chunkId, const mlsgpu_host_mesh *mesh);
+/* Ship-outs that arrive IN PLACE.  landing: `bytes` of the welder's own memory (page-locked where the process has a GPU:
+ * landing_pinned says so), valid until the welder is destroyed; add_landed: add() for a mesh whose arrays lie in such
+ * memory -- adopted, not copied (the index check that rides on add()'s copy runs first thing in the block's task: a bad mesh
+ * makes finalize fail with MLSGPU_ERR_INVALID).  farm_landing / farm_output_landed: the pair for
+ * mlsgpu_hip_farm_set_host_landing, `user` = the mesher. */
+int mlsgpu_hip_host_mesher_landing(mlsgpu_host_mesher *mesher, uint64_t bytes, void **out);
+int mlsgpu_hip_host_mesher_landing_pinned(mlsgpu_host_mesher *mesher);
+int mlsgpu_hip_host_mesher_add_landed(mlsgpu_host_mesher *mesher, uint64_t chunkId, const mlsgpu_host_mesh *mesh);
+int mlsgpu_hip_host_mesher_farm_landing(void *mesher, uint64_t bytes, void **out);
+int mlsgpu_hip_host_mesher_farm_output_landed(void *mesher, int device, uint64_t chunkId, const mlsgpu_host_mesh *mesh);
 int mlsgpu_hip_host_mesher_finalize(mlsgpu_host_mesher *mesher, uint32_t *numChunks);
 /* Output chunk i (chunks in order of first arrival, those without triangles skipped): host pointers, valid until the
  * next add / finalize / destroy; indices relative to the chunk's first vertex. */

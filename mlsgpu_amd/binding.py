@@ -256,6 +256,12 @@ def lib():
     sig("mlsgpu_hip_host_mesher_set_threads", C.c_int, vp, u32)
     sig("mlsgpu_hip_host_mesher_threads", u32, vp)
     sig("mlsgpu_hip_host_mesher_add", C.c_int, vp, u64, P(HostMesh))
+    sig("mlsgpu_hip_host_mesher_landing", C.c_int, vp, u64, P(C.c_void_p))
+    sig("mlsgpu_hip_host_mesher_landing_pinned", C.c_int, vp)
+    sig("mlsgpu_hip_host_mesher_add_landed", C.c_int, vp, u64, P(HostMesh))
+    sig("mlsgpu_hip_farm_set_host_landing", C.c_int, vp, vp, vp, vp)
+    sig("mlsgpu_hip_host_mesher_farm_landing", C.c_int, vp, u64, P(C.c_void_p))
+    sig("mlsgpu_hip_host_mesher_farm_output_landed", C.c_int, vp, C.c_int, u64, P(HostMesh))
     sig("mlsgpu_hip_host_mesher_farm_output", C.c_int, vp, C.c_int, u64, P(HostMesh))
     sig("mlsgpu_hip_host_mesher_finalize", C.c_int, vp, P(u32))
     sig("mlsgpu_hip_host_mesher_boundary", C.c_int, vp, P(u64), P(u64))
@@ -878,6 +884,26 @@ class HostMesher:
         hm = HostMesh(k.ctypes.data, v.ctypes.data, t.ctypes.data, len(v), len(t), num_internal)
         check(lib().mlsgpu_hip_host_mesher_add(self.h, chunk_id, C.byref(hm)))
 
+    def add_landed(self, chunk_id, vertices, num_internal, keys, triangles):
+        """The same mesh through the in-place route: room from mlsgpu_hip_host_mesher_landing (what a farm's read-back lands
+        in), filled here, adopted without a copy by mlsgpu_hip_host_mesher_add_landed."""
+        v = np.ascontiguousarray(vertices, np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(triangles, np.uint32).reshape(-1, 3)
+        k = np.ascontiguousarray(keys, np.uint64)
+        assert len(k) == len(v) - num_internal
+        need = (k.nbytes + v.nbytes + t.nbytes + 63) & ~63
+        ptr = C.c_void_p()
+        check(lib().mlsgpu_hip_host_mesher_landing(self.h, need, C.byref(ptr)))
+        base = ptr.value                                  # HostKeyMesh blob order: keys, vertices, triangles (src/mesh.cpp:51-102)
+        for off, a in ((0, k), (k.nbytes, v), (k.nbytes + v.nbytes, t)):
+            if a.nbytes:
+                C.memmove(base + off, a.ctypes.data, a.nbytes)
+        hm = HostMesh(base, base + k.nbytes, base + k.nbytes + v.nbytes, len(v), len(t), num_internal)
+        check(lib().mlsgpu_hip_host_mesher_add_landed(self.h, chunk_id, C.byref(hm)))
+
+    def landing_pinned(self):
+        return bool(lib().mlsgpu_hip_host_mesher_landing_pinned(self.h))
+
     def finalize(self):
         n = C.c_uint32()
         check(lib().mlsgpu_hip_host_mesher_finalize(self.h, C.byref(n)))
@@ -1363,6 +1389,18 @@ class BucketFarm:
         check(lib().mlsgpu_hip_farm_submit_device_async(self.h, device, d_splats.ptr, d_ids_ptr, num_splats, C.byref(g),
                                                         _p(_i3(low_extent)), _p(_u3(num_vertices)), chunk_id, C.byref(event)))
         return event.value
+
+    def set_host_landing(self, sink):
+        """The host route without the ring: every ship-out is read back straight into memory of the HostMesher `sink`
+        (page-locked slabs of its own) and adopted there without a copy (mlsgpu_hip_farm_set_host_landing)."""
+        assert isinstance(sink, HostMesher)
+        self._host_sink = sink
+        check(lib().mlsgpu_hip_farm_set_host_landing(self.h, C.cast(lib().mlsgpu_hip_host_mesher_farm_landing, C.c_void_p),
+                                                     C.cast(lib().mlsgpu_hip_host_mesher_farm_output_landed, C.c_void_p), sink.h))
+        if lib().mlsgpu_hip_host_mesher_node(sink.h) < 0:
+            node = self.placement()["ring_node"]
+            if node >= 0:
+                lib().mlsgpu_hip_host_mesher_set_node(sink.h, node)
 
     def set_host_output(self, ring_bytes, sink=None):
         """Every ship-out is read back through a pinned circular buffer of `ring_bytes` and handed to ONE mesher thread

@@ -150,6 +150,7 @@ struct Farm
      * (MesherGroup::meshBuffer, --mem-mesh) and consumed in arrival order by ONE mesher thread
      * (MesherGroup, src/workers.cpp:47-85). */
     bool hostOutput = false;
+    mlsgpu_farm_landing_fn landingFn = nullptr;     /* set: ship-outs land in memory the consumer hands out, not in the ring */
     mlsgpu_farm_host_output_fn hostFn = nullptr;
     void *hostUser = nullptr;
     char *ring = nullptr;
@@ -202,7 +203,19 @@ int hostReadBack(OutputThunk *t, const mlsgpu_mesh *mesh)
 {
     Farm *f = t->farm;
     const uint64_t need = (mlsgpu_hip_mesh_host_bytes(mesh) + 63) & ~uint64_t(63);
-    if (need > f->ringBytes)
+    char *landing = nullptr;
+    if (f->landingFn != nullptr)
+    {
+        /* the consumer's own memory (mlsgpu_hip_farm_set_host_landing): nothing to wait for, nothing to give back */
+        void *p = nullptr;
+        if (f->landingFn(f->hostUser, need, &p) != 0 || p == nullptr)
+        {
+            f->fail(MLSGPU_ERR_CALLBACK, "farm: the landing allocator of the host output failed");
+            return setError(MLSGPU_ERR_CALLBACK, "farm: the landing allocator of the host output failed");
+        }
+        landing = static_cast<char *>(p);
+    }
+    else if (need > f->ringBytes)
     {
         /* the first error is the one finish() reports (Marching only says "the output functor failed") */
         char text[160];
@@ -220,6 +233,12 @@ int hostReadBack(OutputThunk *t, const mlsgpu_mesh *mesh)
         {
             if (f->error != MLSGPU_OK)
                 return setError(f->error, "%s", f->errorText.c_str());
+            if (landing != nullptr)
+            {
+                s->offset = 0;
+                s->bytes = 0;           /* no ring space to release */
+                break;
+            }
             /* contiguous room at the head, or after wrapping (the skipped tail end is charged to this slot) */
             const uint64_t toEnd = f->ringBytes - f->ringHead;
             const uint64_t pad = need <= toEnd ? 0 : toEnd;
@@ -256,7 +275,7 @@ int hostReadBack(OutputThunk *t, const mlsgpu_mesh *mesh)
         rc = setError(MLSGPU_ERR_HIP, "farm: cannot select device %d", t->group->device);
     if (rc == MLSGPU_OK && s->done == nullptr && hipEventCreateWithFlags(&s->done, hipEventDisableTiming) != hipSuccess)
         rc = setError(MLSGPU_ERR_HIP, "farm: cannot create a read-back event");
-    char *blob = f->ring + s->offset;
+    char *blob = landing != nullptr ? landing : f->ring + s->offset;
     const uint64_t ne = mesh->numVertices - mesh->numInternalVertices;
     s->mesh.vertexKeys = reinterpret_cast<const uint64_t *>(blob);
     s->mesh.vertices = reinterpret_cast<const float *>(blob + 8 * ne);
@@ -830,6 +849,7 @@ MLSGPU_API int mlsgpu_hip_farm_set_host_output(mlsgpu_farm *f, uint64_t ringByte
         REQUIRE(f->inFlightItems == 0 && f->hostQueue.empty() && f->bufferedItems.empty(), MLSGPU_ERR_INVALID);
         f->hostFn = fn;
         f->hostUser = user;
+        f->landingFn = nullptr;         /* back to the ring (of the size it was created with) */
         return MLSGPU_OK;
     }
     REQUIRE(f->stats[0] == 0, MLSGPU_ERR_INVALID);          /* before the first bucket */
@@ -865,6 +885,21 @@ MLSGPU_API int mlsgpu_hip_farm_set_host_output(mlsgpu_farm *f, uint64_t ringByte
         mesherMain(static_cast<Farm *>(f));
     });
     f->hostOutput = true;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_farm_set_host_landing(mlsgpu_farm *f, mlsgpu_farm_landing_fn landing, mlsgpu_farm_host_output_fn fn, void *user)
+{
+    REQUIRE(f != nullptr && landing != nullptr, MLSGPU_ERR_INVALID);
+    /* the ring route's machinery (slot queue, events, ONE mesher thread in ship-out order) with a token ring: no ship-out
+     * ever waits for room */
+    if (!f->hostOutput)
+        PROPAGATE(mlsgpu_hip_farm_set_host_output(f, 4096, fn, user));
+    std::lock_guard<std::mutex> l(f->mutex);
+    REQUIRE(f->hostQueue.empty(), MLSGPU_ERR_INVALID);
+    f->landingFn = landing;
+    f->hostFn = fn;
+    f->hostUser = user;
     return MLSGPU_OK;
 }
 

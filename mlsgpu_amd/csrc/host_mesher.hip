@@ -60,6 +60,8 @@ struct Slab
 {
     char *base = nullptr;
     size_t cap = 0;
+    bool landing = false;       /* a slab ship-outs land in: registered with the HIP runtime (page-locked) where that works */
+    bool registered = false;
 };
 
 class SlabCache
@@ -70,12 +72,12 @@ public:
         static SlabCache c;
         return c;
     }
-    Slab take(size_t atLeast)
+    Slab take(size_t atLeast, bool landing = false)
     {
         {
             std::lock_guard<std::mutex> l(mutex);
             for (size_t i = 0; i < free.size(); i++)
-                if (free[i].cap >= atLeast)
+                if (free[i].cap >= atLeast && free[i].landing == landing)
                 {
                     Slab s = free[i];
                     free.erase(free.begin() + (long) i);
@@ -92,7 +94,23 @@ public:
             return Slab();
         (void) madvise(p, s.cap, MADV_HUGEPAGE);
         s.base = static_cast<char *>(p);
+        s.landing = landing;
+        if (landing)
+        {
+            /* page-locked, so that a device-to-host copy lands here at the link's rate; a process without a GPU (the CPU tests)
+             * keeps the slab unregistered: the route works, only slower */
+            std::memset(p, 0, s.cap);           /* (touched here: on the caller's NUMA node, before the pages are locked) */
+            s.registered = hipHostRegister(p, s.cap, hipHostRegisterPortable) == hipSuccess;
+            if (!s.registered)
+                (void) hipGetLastError();
+        }
         return s;
+    }
+    static void unmap(Slab &s)
+    {
+        if (s.registered)
+            (void) hipHostUnregister(s.base);
+        munmap(s.base, s.cap);
     }
     void give(Slab s)
     {
@@ -107,12 +125,12 @@ public:
                 return;
             }
         }
-        munmap(s.base, s.cap);
+        unmap(s);
     }
     ~SlabCache()
     {
         for (Slab &s : free)
-            munmap(s.base, s.cap);
+            munmap(s.base, s.cap);      /* (process exit: the HIP runtime may be gone already, nothing is unregistered) */
     }
     /* how much mapped memory stays with the process between jobs; what is held beyond the new limit goes back now */
     size_t setLimit(size_t bytes)
@@ -132,7 +150,7 @@ public:
         for (Slab &s : drop)
         {
             released += s.cap;
-            munmap(s.base, s.cap);
+            unmap(s);
         }
         return released;
     }
@@ -159,7 +177,24 @@ private:
 class Arena
 {
 public:
+    explicit Arena(bool landing_ = false) : landing(landing_) {}
     ~Arena() { release(); }
+    bool contains(const void *p, size_t bytes)
+    {
+        std::lock_guard<std::mutex> l(mutex);
+        for (const Slab &s : slabs)
+            if (static_cast<const char *>(p) >= s.base && static_cast<const char *>(p) + bytes <= s.base + s.cap)
+                return true;
+        return false;
+    }
+    bool allRegistered()
+    {
+        std::lock_guard<std::mutex> l(mutex);
+        for (const Slab &s : slabs)
+            if (!s.registered)
+                return false;
+        return true;
+    }
     void release()
     {
         for (Slab &s : slabs)
@@ -174,7 +209,7 @@ public:
         std::lock_guard<std::mutex> l(mutex);
         if (slabs.empty() || used + bytes > slabs.back().cap)
         {
-            Slab s = SlabCache::instance().take(std::max(bytes, size_t(256) << 20));
+            Slab s = SlabCache::instance().take(std::max(bytes, size_t(256) << 20), landing);
             if (s.base == nullptr)
                 return nullptr;
             slabs.push_back(s);
@@ -225,6 +260,7 @@ private:
     std::mutex mutex;
     std::vector<Slab> slabs;
     size_t used = 0;
+    bool landing = false;
 };
 
 /* ---------------------------------------------------------------- a small pool: tasks and parallel loops */
@@ -483,6 +519,7 @@ struct Block
     uint64_t *keys = nullptr;               /* of the external vertices */
     uint32_t *clumpOf = nullptr;            /* per vertex: local clump number; filled by the block's task */
     uint32_t *remap = nullptr;              /* finalize's scratch, kept for the next finalize */
+    bool checkIndices = false;              /* a landed block: its triangle indices have not been looked at yet */
     std::vector<uint64_t> clumpVertices, clumpTriangles;    /* per local clump */
     /* finalize */
     uint64_t clumpBase = 0;                 /* global id of local clump 0 */
@@ -523,6 +560,7 @@ struct mlsgpu_host_mesher
     uint64_t numKeys = 0;
 
     Arena arena;                            /* blocks, scratch and outputs */
+    Arena landed{true};                     /* ship-outs that arrive in place (mlsgpu_hip_host_mesher_landing): page-locked slabs */
     float *outVertices = nullptr;
     uint32_t *outTriangles = nullptr;
     uint64_t outVCap = 0, outTCap = 0;
@@ -591,6 +629,28 @@ void mlsgpu_host_mesher::processBlock(Block *b)
     const uint32_t *tris = b->triangles;
     const uint64_t SLICE = 1 << 16;
     Pool &P = getPool();
+    if (b->checkIndices)
+    {
+        /* what add()'s copy checks on the way: no triangle index beyond the block's vertices (the union-find below indexes
+         * with them) */
+        std::atomic<uint32_t> bad{0};
+        const uint64_t words = 3 * nt, CSLICE = uint64_t(1) << 20;
+        P.parallelForNow((size_t) ((words + CSLICE - 1) / CSLICE), [&](size_t s) {
+            uint32_t most = 0;
+            for (uint64_t k = s * CSLICE, e = std::min(words, k + CSLICE); k < e; k++)
+                most = tris[k] > most ? tris[k] : most;
+            if (most >= nv)
+                bad.store(1);
+        });
+        b->checkIndices = false;
+        if (bad.load() != 0)
+        {
+            fail(MLSGPU_ERR_INVALID, "host mesher: a landed mesh has a triangle index beyond its vertices");
+            b->nt = 0;      /* the block contributes nothing; finalize reports the error */
+            b->nv = b->nInternal = 0;
+            return;
+        }
+    }
     auto load = [parent](uint32_t v) { return __atomic_load_n(&parent[v], __ATOMIC_RELAXED); };
     auto find = [parent, &load](uint32_t v) {
         for (;;)
@@ -754,6 +814,32 @@ MLSGPU_API uint32_t mlsgpu_hip_host_mesher_threads(mlsgpu_host_mesher *m)
     return m->getPool().size();
 }
 
+/* the common tail of add / add_landed: the block joins the job and its task is queued (the mesher's mutex is held) */
+static int enlistBlock(mlsgpu_host_mesher *m, uint64_t chunkId, std::unique_ptr<Block> &b)
+{
+    REQUIRE(m->blocks.size() < 0xFFFFFFFFu, MLSGPU_ERR_LENGTH);
+    m->finalized = false;
+    auto it = m->chunkIndex.find(chunkId);
+    if (it == m->chunkIndex.end())
+    {
+        b->chunk = (uint32_t) m->chunkIds.size();
+        m->chunkIndex.emplace(chunkId, b->chunk);
+        m->chunkIds.push_back(chunkId);
+    }
+    else
+        b->chunk = it->second;
+    b->seq = (uint32_t) m->blocks.size();
+    Block *raw = b.get();
+    m->blocks.push_back(std::move(b));
+    m->getPool().submit([m, raw] {
+        const auto t0 = std::chrono::steady_clock::now();
+        m->processBlock(raw);
+        if (m->trace.on)
+            m->trace.taskNs += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    });
+    return MLSGPU_OK;
+}
+
 MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkId, const mlsgpu_host_mesh *mesh)
 {
     REQUIRE(m != nullptr && mesh != nullptr, MLSGPU_ERR_INVALID);
@@ -822,30 +908,78 @@ MLSGPU_API int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *m, uint64_t chunkI
         /* a bad mesh leaves the sink unchanged (its copy stays behind in the arena, unused) */
         REQUIRE(badIndex.load() == 0, MLSGPU_ERR_INVALID);
     }
-    REQUIRE(m->blocks.size() < 0xFFFFFFFFu, MLSGPU_ERR_LENGTH);
-    m->finalized = false;
-    auto it = m->chunkIndex.find(chunkId);
-    if (it == m->chunkIndex.end())
-    {
-        b->chunk = (uint32_t) m->chunkIds.size();
-        m->chunkIndex.emplace(chunkId, b->chunk);
-        m->chunkIds.push_back(chunkId);
-    }
-    else
-        b->chunk = it->second;
-    b->seq = (uint32_t) m->blocks.size();
-    Block *raw = b.get();
-    m->blocks.push_back(std::move(b));
-    m->getPool().submit([m, raw] {
-        const auto t0 = std::chrono::steady_clock::now();
-        m->processBlock(raw);
-        if (m->trace.on)
-            m->trace.taskNs += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-    });
+    PROPAGATE(enlistBlock(m, chunkId, b));
     m->trace.adds++;
     m->trace.lastAdd = std::chrono::steady_clock::now();
     m->trace.addS += std::chrono::duration<double>(m->trace.lastAdd - tAdd0).count();
     return MLSGPU_OK;
+}
+
+/* Room for a ship-out that arrives IN PLACE: `bytes` of the welder's own memory, page-locked where the process has a GPU,
+ * valid until the welder is destroyed.  The farm's read-back lands there (mlsgpu_hip_farm_set_host_landing) and
+ * mlsgpu_hip_host_mesher_add_landed adopts it: the copy out of the farm's ring that mlsgpu_hip_host_mesher_add makes -- a
+ * third of the welder's pass on a good day, two thirds on a box whose GPU hangs off the other socket -- does not exist.
+ * (The reference's mesher reads its CircularBuffer allocation in place too, src/workers.h:488-509, src/mesher.cpp:447-469,
+ * and then writes the block to a temporary file; here the landing memory IS the block's home.) */
+MLSGPU_API int mlsgpu_hip_host_mesher_landing(mlsgpu_host_mesher *m, uint64_t bytes, void **out)
+{
+    REQUIRE(m != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    void *p = m->landed.alloc((size_t) std::max<uint64_t>(bytes, 1));
+    if (p == nullptr)
+        return setError(MLSGPU_ERR_NOMEM, "host mesher: out of memory");
+    *out = p;
+    return MLSGPU_OK;
+}
+
+MLSGPU_API int mlsgpu_hip_host_mesher_landing_pinned(mlsgpu_host_mesher *m)
+{
+    return m != nullptr && m->landed.allRegistered() ? 1 : 0;
+}
+
+/* add() for a mesh that lies in memory mlsgpu_hip_host_mesher_landing returned: adopted, not copied.  The check of the
+ * triangle indices (which rides on add()'s copy) is the first thing the block's task does; a bad mesh makes finalize fail
+ * with MLSGPU_ERR_INVALID instead of this call. */
+MLSGPU_API int mlsgpu_hip_host_mesher_add_landed(mlsgpu_host_mesher *m, uint64_t chunkId, const mlsgpu_host_mesh *mesh)
+{
+    REQUIRE(m != nullptr && mesh != nullptr, MLSGPU_ERR_INVALID);
+    REQUIRE(mesh->numInternalVertices <= mesh->numVertices, MLSGPU_ERR_INVALID);
+    REQUIRE(mesh->numVertices < (uint64_t(1) << 31), MLSGPU_ERR_LENGTH);
+    const uint64_t nv = mesh->numVertices, nt = mesh->numTriangles, ni = mesh->numInternalVertices, ne = nv - ni;
+    REQUIRE((nv == 0 || m->landed.contains(mesh->vertices, 12 * nv)) && (nt == 0 || m->landed.contains(mesh->triangles, 12 * nt))
+            && (ne == 0 || m->landed.contains(mesh->vertexKeys, 8 * ne)), MLSGPU_ERR_INVALID);
+    std::unique_ptr<Block> b(new Block);
+    b->nv = nv;
+    b->nInternal = ni;
+    b->nt = nt;
+    b->checkIndices = true;
+    const auto tAdd0 = std::chrono::steady_clock::now();
+    if (m->trace.on && m->trace.adds == 0)
+    {
+        m->trace.firstAdd = tAdd0;
+        m->trace.slabs0 = SlabCache::instance().freshSlabs.load();
+        m->trace.bytes0 = SlabCache::instance().freshBytes.load();
+    }
+    b->vertices = const_cast<float *>(mesh->vertices);
+    b->triangles = const_cast<uint32_t *>(mesh->triangles);
+    b->keys = const_cast<uint64_t *>(mesh->vertexKeys);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    PROPAGATE(enlistBlock(m, chunkId, b));
+    m->trace.adds++;
+    m->trace.lastAdd = std::chrono::steady_clock::now();
+    m->trace.addS += std::chrono::duration<double>(m->trace.lastAdd - tAdd0).count();
+    return MLSGPU_OK;
+}
+
+/* the pair a farm takes (mlsgpu_hip_farm_set_host_landing): `user` is the mlsgpu_host_mesher */
+MLSGPU_API int mlsgpu_hip_host_mesher_farm_landing(void *mesher, uint64_t bytes, void **out)
+{
+    return mlsgpu_hip_host_mesher_landing(static_cast<mlsgpu_host_mesher *>(mesher), bytes, out);
+}
+
+MLSGPU_API int mlsgpu_hip_host_mesher_farm_output_landed(void *mesher, int device, uint64_t chunkId, const mlsgpu_host_mesh *mesh)
+{
+    (void) device;
+    return mlsgpu_hip_host_mesher_add_landed(static_cast<mlsgpu_host_mesher *>(mesher), chunkId, mesh);
 }
 
 MLSGPU_API int mlsgpu_hip_host_mesher_farm_output(void *mesher, int device, uint64_t chunkId, const mlsgpu_host_mesh *mesh)

@@ -121,13 +121,14 @@ def _oracle_meshes(allb, buckets, chunk_of=lambda i: 0):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ring_kb", [512, 65536])
+@pytest.mark.parametrize("ring_kb", [512, 65536, 0])
 def test_farm_host_output_welds_across_device_groups(ring_kb):
     """The reference's route for several GPUs: every device group's ship-outs are read back through the pinned circular
     buffer (OutputGeneratorBuilder::Functor, src/workers.h:488-509) and welded by ONE host mesher
     (src/mesher.cpp:220-469).  Two groups (both on GPU 0 here), two chunks whose blocks arrive interleaved; a 512 KB ring
-    makes the workers wait for the mesher thread and wraps many times.  The result equals the oracle sink fed with the
-    oracle's bucket meshes."""
+    makes the workers wait for the mesher thread and wraps many times.  ring_kb = 0: no ring -- the read-backs land in
+    page-locked memory of the welder and are adopted without a copy (mlsgpu_hip_farm_set_host_landing), over two jobs
+    (a second welder takes the farm's next job).  The result equals the oracle sink fed with the oracle's bucket meshes."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
@@ -139,8 +140,18 @@ def test_farm_host_output_welds_across_device_groups(ring_kb):
     cap = max(b.count for b in buckets)
     welder = m.HostMesher(0.02)
     farm = m.BucketFarm([0, 0], cap, workers_per_device=2, max_cells=63)
-    farm.set_host_output(ring_kb << 10, welder)
     chunk_of = lambda i: i % 2                                      # noqa: E731
+    if ring_kb == 0:
+        first = m.HostMesher(0.02)
+        farm.set_host_landing(first)                                # job 1 lands in another welder's memory ...
+        for i, b in enumerate(buckets):
+            farm.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, chunk_of(i))
+        farm.finish()
+        assert first.landing_pinned()
+        farm.set_host_landing(welder)                               # ... job 2 in this one's
+    else:
+        farm.set_host_output(ring_kb << 10, welder)
+    before = farm.stats()
     for i, b in enumerate(buckets):
         farm.submit(allb[b.first:b.first + b.count], b.low, b.num_vertices, chunk_of(i))
     farm.finish()
@@ -149,6 +160,10 @@ def test_farm_host_output_welds_across_device_groups(ring_kb):
     assert hs["meshes"] == st["shipouts"] and hs["bytes"] > 0
     if ring_kb == 512:
         assert hs["bytes"] > 4 * (ring_kb << 10)                    # the ring wrapped
+    if ring_kb == 0:
+        assert hs["ring_waits"] == 0 and st["shipouts"] == 2 * before["shipouts"]
+        n1 = first.finalize()
+        s1 = first.stats()
     farm.close()
     n = welder.finalize()
     stats = welder.stats()
@@ -159,6 +174,9 @@ def test_farm_host_output_welds_across_device_groups(ring_kb):
     assert [c for c, _, _ in got] == sorted(c for c, _, _ in exp)
     for (c, v, t), (ec, ev, et) in zip(got, sorted(exp, key=lambda c: c[0])):
         assert mo.isomorphic(v, t, ev, et)
+    if ring_kb == 0:
+        assert n1 == n and all(s1[k] == stats[k] for k in exp_stats)         # both jobs welded the same cloud
+        first.close()
     welder.close()
 
 

@@ -166,3 +166,53 @@ def test_slab_cache_can_be_trimmed():
     assert L.mlsgpu_hip_host_mesher_trim_cache(16 << 30) == 0
     for a, b in zip(first[1:], second[1:]):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("prune", [0.0, 0.05])
+def test_landed_meshes_weld_like_copied_ones(prune):
+    """The in-place route (mlsgpu_hip_host_mesher_landing + _add_landed: what a farm's read-back lands in is adopted, not
+    copied) gives the arrays the copying route gives, element for element; blocks of both kinds mix."""
+    import mlsgpu_amd as m
+    meshes = random_meshes(21, blocks=18, chunks=3)
+    outs = []
+    for mode in ("copied", "landed", "mixed"):
+        mesher = m.HostMesher(prune, threads=4)
+        seen = {}
+        for i, mesh in enumerate(meshes):
+            landed = mode == "landed" or (mode == "mixed" and i % 2 == 1)
+            (mesher.add_landed if landed else mesher.add)(seen.setdefault(mesh["chunk"], len(seen)), mesh["vertices"],
+                                                          mesh["num_internal"], mesh["keys"], mesh["triangles"])
+        n = mesher.finalize()
+        outs.append(([mesher.chunk(i) for i in range(n)], mesher.stats()))
+        mesher.close()
+    first, stats0 = outs[0]
+    assert len(first) >= 1
+    for other, stats in outs[1:]:
+        assert stats == stats0 and len(other) == len(first)
+        for (c0, v0, t0), (c1, v1, t1) in zip(first, other):
+            assert c0 == c1
+            np.testing.assert_array_equal(v0.view(np.uint32), v1.view(np.uint32))
+            np.testing.assert_array_equal(t0, t1)
+
+
+def test_landed_argument_checks():
+    """add_landed only adopts memory the welder handed out; a landed mesh with a bad triangle index fails the job at
+    finalize (the check that rides on add()'s copy runs in the block's task)."""
+    import ctypes as C
+    import mlsgpu_amd as m
+    from mlsgpu_amd.binding import HostMesh, lib
+    a = CASES["simple"]["meshes"][0]
+    mesher = m.HostMesher()
+    v = np.ascontiguousarray(a["vertices"], np.float32)
+    t = np.ascontiguousarray(a["triangles"], np.uint32)
+    k = np.ascontiguousarray(a["keys"], np.uint64)
+    hm = HostMesh(k.ctypes.data, v.ctypes.data, t.ctypes.data, len(v), len(t), a["num_internal"])      # the caller's own memory
+    assert lib().mlsgpu_hip_host_mesher_add_landed(mesher.h, 0, C.byref(hm)) != 0
+    assert mesher.finalize() == 0
+    mesher.close()
+    mesher = m.HostMesher()
+    mesher.add_landed(0, a["vertices"], a["num_internal"], a["keys"], a["triangles"])
+    mesher.add_landed(0, a["vertices"], a["num_internal"], a["keys"], np.array([[0, 1, 99]], np.uint32))
+    with pytest.raises(m.InvalidArgument):
+        mesher.finalize()
+    mesher.close()
