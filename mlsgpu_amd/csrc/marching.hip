@@ -1152,6 +1152,22 @@ __global__ __launch_bounds__(256) void latticePatchKernel(Lanes<LatticePatchArgs
     L.words[i].flag = (off2 + rs.c) | x0 | top;
 }
 
+/* 1.0f / x, correctly rounded, in three vector instructions where the compiler's division takes twelve: v_rcp_f32 and one
+ * Newton step in fused arithmetic give the correctly rounded quotient for EVERY x with a biased exponent of 1 .. 252 --
+ * checked exhaustively on gfx950 over all 2^32 inputs (tools/microbench/rcp_exact.hip: the only differences are zeros and
+ * denormals, |x| >= 2^126, infinities and NaNs) -- and those take the division.  latticeVertices spent a third of an
+ * iteration's vector instructions in it. */
+__device__ __forceinline__ float exactRcp(float x)
+{
+    const uint32_t e = (__float_as_uint(x) >> 23) & 0xFFu;
+    if (e - 1u < 252u)
+    {
+        const float r = __builtin_amdgcn_rcpf(x);
+        return fmaf(r, fmaf(-x, r, 1.0f), r);
+    }
+    return 1.0f / x;
+}
+
 /* Positions (interp, kernels/marching.cl:130-138) and external keys of the existing points.  One wave per QUAD of lattice
  * rows -- (z2, y2) = (2 cz + pz, 2 cy + py): the four rows whose points hang off the corner row (cy, cz) -- lane = x2 within
  * a word.  The kernel was bound by memory latency times resident waves, not by bytes or instructions, so a wave carries as
@@ -1271,7 +1287,7 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVertic
                     if (!(((exists >> lane) & 1) || column))
                         continue;
                     /* endpoint A = owner corner, B = A + (px,py,pz): A has the lower local corner id in every cell */
-                    const float inv = 1.0f / (iso0[j] - iso1[pz][py][j]);
+                    const float inv = exactRcp(iso0[j] - iso1[pz][py][j]);
                     const float t = iso0[j] * inv;
                     float vx = fmaf(t, (float) px, (float) (cx + gox));
                     float vy = fmaf(t, (float) py, (float) (cy + goy));
