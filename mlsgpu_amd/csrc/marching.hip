@@ -1225,6 +1225,27 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVertic
 #pragma unroll
     for (int pz = 0; pz < 2; pz++)
         wordsOf[pz] = (const uint32_t *) (L.words + (uint64_t) ((2 * slab + (hasZ ? pz : 0)) * L.rowsPerLayer + 2 * cy) * L.nw);
+    /* interp (kernels/marching.cl:130-138), scale / bias, the vertex and -- for an external one -- its key.  Endpoint A =
+     * owner corner, B = A + (px, py, pz): A has the lower local corner id in every cell */
+    auto emit = [&](uint32_t x2, uint32_t cx, uint32_t ex, uint32_t ey, uint32_t ez, uint32_t idx, float isoA, float isoB, bool withKey)
+    {
+        const float inv = exactRcp(isoA - isoB);
+        const float t = isoA * inv;
+        float vx = fmaf(t, (float) ex, (float) (cx + gox));
+        float vy = fmaf(t, (float) ey, (float) (cy + goy));
+        float vz = fmaf(t, (float) ez, (float) (cz + goz));
+        if (XF == 2 ? (bool) X.enabled : XF == 1)
+        {
+            vx = fmaf(vx, X.scale, X.bx);
+            vy = fmaf(vy, X.scale, X.by);
+            vz = fmaf(vz, X.scale, X.bz);
+        }
+        outVertices[3 * (uint64_t) idx + 0] = vx;
+        outVertices[3 * (uint64_t) idx + 1] = vy;
+        outVertices[3 * (uint64_t) idx + 2] = vz;
+        if (withKey)
+            outKeys[idx] = (((uint64_t) (2 * cz + ez) << (2 * KEY_AXIS_BITS)) | ((uint64_t) (2 * cy + ey) << KEY_AXIS_BITS) | (uint64_t) x2) + keyOffset;
+    };
     constexpr int G = 8;
     for (uint32_t w0 = 0; w0 < L.nw; w0 += G)
     {
@@ -1267,43 +1288,33 @@ __global__ __launch_bounds__(256) void latticeVerticesKernel(Lanes<LatticeVertic
                     const uint32_t cls = L.rowClass(y2, z2);
                     const uint32_t at = 32 * py + 4 * j;
                     const uint64_t exists = (uint64_t) readLane(latDword[pz], at) | (uint64_t) readLane(latDword[pz], at + 1) << 32;
-                    const uint32_t prefix = readLane(latDword[pz], at + 2), flag = readLane(latDword[pz], at + 3);
-                    bool column = false;
-                    uint32_t idx = prefix + (uint32_t) __popcll(exists & ((1ull << lane) - 1));
-                    if (cls != 2)
-                    {
-                        /* the row's two class-2 points are not in the mask */
-                        if (x2 == 0 && (flag & LAT_FLAG_X0))
-                        {
-                            column = true;
-                            idx = flag & LAT_FLAG_INDEX;
-                        }
-                        else if (x2 == L.topx && (flag & LAT_FLAG_TOP))
-                        {
-                            column = true;
-                            idx = (flag & LAT_FLAG_INDEX) + (flag >> 31);
-                        }
-                    }
-                    if (!(((exists >> lane) & 1) || column))
+                    const uint32_t prefix = readLane(latDword[pz], at + 2);
+                    if (!((exists >> lane) & 1))
                         continue;
-                    /* endpoint A = owner corner, B = A + (px,py,pz): A has the lower local corner id in every cell */
-                    const float inv = exactRcp(iso0[j] - iso1[pz][py][j]);
-                    const float t = iso0[j] * inv;
-                    float vx = fmaf(t, (float) px, (float) (cx + gox));
-                    float vy = fmaf(t, (float) py, (float) (cy + goy));
-                    float vz = fmaf(t, (float) pz, (float) (cz + goz));
-                    if (XF == 2 ? (bool) X.enabled : XF == 1)
-                    {
-                        vx = fmaf(vx, X.scale, X.bx);
-                        vy = fmaf(vy, X.scale, X.by);
-                        vz = fmaf(vz, X.scale, X.bz);
-                    }
-                    outVertices[3 * (uint64_t) idx + 0] = vx;
-                    outVertices[3 * (uint64_t) idx + 1] = vy;
-                    outVertices[3 * (uint64_t) idx + 2] = vz;
-                    if (cls != 0 || column)
-                        outKeys[idx] = (((uint64_t) z2 << (2 * KEY_AXIS_BITS)) | ((uint64_t) y2 << KEY_AXIS_BITS) | (uint64_t) x2) + keyOffset;
+                    /* (a class-0/1 row's two class-2 points, x2 = 0 and x2 = top.x, are not in the mask: see below) */
+                    const uint32_t idx = prefix + (uint32_t) __popcll(exists & ((1ull << lane) - 1));
+                    emit(x2, cx, px, (uint32_t) py, (uint32_t) pz, idx, iso0[j], iso1[pz][py][j], cls != 0);
                 }
+            }
+        }
+    }
+    /* The class-2 points inside class-0/1 rows -- x2 = 0 and x2 = top.x of each of the quad's four rows, where the row's flag
+     * word says they exist (the same in every word of the row, latticePatchKernel) -- once per wave, a lane per candidate,
+     * instead of two comparisons and their scalar bookkeeping in each of the loop's iterations (24 per wave on cfg3: the
+     * kernel issued as many scalar as vector instructions, 63 % of the CU's scalar unit). */
+    if (lane < 8)
+    {
+        const uint32_t r = lane >> 1, py = r & 1u, pz = r >> 1, top = lane & 1u;
+        const uint32_t y2 = 2 * cy + py, z2 = 2 * cz + pz;
+        if ((py == 0 || hasY) && (pz == 0 || hasZ) && L.rowClass(y2, z2) != 2)
+        {
+            const uint32_t flag = (pz ? wordsOf[1] : wordsOf[0])[(py ? rowDwords : 0u) + 3u];
+            if (flag & (top ? LAT_FLAG_TOP : LAT_FLAG_X0))
+            {
+                const uint32_t x2 = top ? L.topx : 0u, cx = x2 >> 1;            /* top.x is even: px = 0 */
+                const uint32_t idx = (flag & LAT_FLAG_INDEX) + (top ? flag >> 31 : 0u);
+                const float *const rowB = F.field + (uint64_t) (cy + py + F.zStride * (cz + pz) + (uint32_t) F.zBias) * F.pitch;
+                emit(x2, cx, 0u, py, pz, idx, field0[cx], rowB[cx], true);
             }
         }
     }
