@@ -33,7 +33,7 @@ TRACKED = {
     "processCorners": "processCornersMatrixKernel<0, false>",
     "latticeTriangles": "latticeTriangles",      # by rows (noise cloud) or by cells (surface-like data)
     "latticeVertices": "latticeVerticesKernel",
-    "latticeMask": "latticeMaskKernel",
+    "latticeMask": "latticeMaskWordKernel",
     "sortScatter": "sortScatterKernel",
     "sortHist": "sortHistKernel",
     "cellCode": "cellCodeKernel",
