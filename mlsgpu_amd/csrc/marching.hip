@@ -2195,7 +2195,10 @@ static int shipOutLatticeLanes(ShipLane *lanes, uint32_t count)
                                      lanes[k].sw.height, j < count ? cornerRows[k] : 0u};
             most = std::max(most, A.a[j].numCornerRows);
         }
-        static const bool byRows = getenv("MLSGPU_HIP_LATTICE_MASK_ROWS") != nullptr && atoi(getenv("MLSGPU_HIP_LATTICE_MASK_ROWS")) != 0;
+        static const bool byRowsEnv = getenv("MLSGPU_HIP_LATTICE_MASK_ROWS") != nullptr && atoi(getenv("MLSGPU_HIP_LATTICE_MASK_ROWS")) != 0;
+        bool byRows = byRowsEnv;
+        for (uint32_t j = 0; j < count; j++)
+            byRows = byRows || A.a[j].L.nw > 64;        /* (rows wider than 2 048 corners: more words than a wave has lanes) */
         if (byRows)
             LAUNCH(ctx, "kernel.marching.countUniqueVertices.time", latticeMaskKernel, dim3(divUp(most, 4), count), dim3(256), A,
                    (const uint64_t *) lanes[0].m->dEdgeLut);
