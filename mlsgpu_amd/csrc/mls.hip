@@ -779,8 +779,12 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
          * loops into a vector register each: twelve of the kernel's 64) */
         auto uniformFloat = [](int v)
         {
-            float out;          /* (the builtin is folded away for a value the compiler knows to be uniform) */
-            asm("v_readfirstlane_b32 %0, %1" : "=s"(out) : "v"((float) v));
+            /* (the builtin is folded away for a value the compiler knows to be uniform.)  The wait states are part of the
+             * statement: the compiler's hazard recogniser does not look into inline assembly, and a v_readfirstlane issued
+             * right behind the conversion that writes its source READ THE OLD REGISTER on gfx950 -- one block of one test case,
+             * found when a rearrangement of this kernel put the two back to back (profiles/NOTES_r06.md, section 1). */
+            float out;
+            asm("s_nop 3\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(out) : "v"((float) v));
             return out;
         };
         const float bx0 = uniformFloat(wx + A.ox), by0 = uniformFloat(wy + A.oy), bz0 = uniformFloat(wz + A.oz);
