@@ -233,3 +233,30 @@ def test_enqueue_checks(ctx):
         gen.enqueue(field, 16, fx["rows"], sw)                    # image narrower than roundUp(width, 8)
     with pytest.raises(m.LengthError):
         gen.enqueue(field, fx["image_w"], 10, sw)                 # image too short
+
+
+def test_prefilter_counters_on_a_bucket(ctx):
+    """The instrumented kernels on a whole bucket (cfg1: 50 k splats on a sphere, 64^3 grid): the matrix prefilter hands the
+    drain every hit of the reference's test (word 42 = 0) and few candidates more; listed splats and hits are the same numbers
+    whichever kernel counts them; the field is the same bits."""
+    import mlsgpu_amd as m
+    from mlsgpu_amd import synth
+    cloud, g = synth.make_cloud("cfg1")
+    seen = {}
+    for variant in (5, 4, 1):
+        w = m.Worker(ctx, len(cloud), max_cells=63)
+        w.set_mls_variant(variant)
+        counters = m.DeviceBuffer(ctx, array=np.zeros(m.binding.MLS_STATS_WORDS, np.uint64))
+        w.set_mls_stats(counters)
+        buf = m.DeviceBuffer(ctx, array=cloud)
+        col = w.process(buf, 0, len(cloud), (0, 0, 0), (g, g, g), collector=m.binding.ChecksumCollector(ctx))
+        ctx.synchronize()
+        c = [int(x) for x in counters.download(np.uint64)]
+        w.set_mls_stats(None)
+        seen[variant] = (c, col.digest())
+        del w, buf
+    c5, c4, c1 = seen[5][0], seen[4][0], seen[1][0]
+    assert c5[0] == c4[0] == c1[0] > 0 and c5[2] == c4[2] == c1[2] > 0            # listed, hits
+    assert c5[42] == 0 and c5[2] <= c5[41] <= 1.05 * c5[2]                         # nothing missed, < 5 % false candidates
+    assert c5[1] % 2048 == 0 and c1[1] >= c4[1] >= c5[2]                           # 32 x 64 pairs per tile; tests executed
+    assert seen[5][1] == seen[4][1] == seen[1][1]
