@@ -131,7 +131,10 @@ int mlsgpu_hip_ctx_set_timing(mlsgpu_ctx *ctx, int enabled);
 /* Synchronises, then returns total milliseconds and launch count of `name` since the last reset. */
 int mlsgpu_hip_ctx_get_stat(mlsgpu_ctx *ctx, const char *name, double *totalMs, uint64_t *launches);
 int mlsgpu_hip_ctx_reset_stats(mlsgpu_ctx *ctx);
-/* Writes "name total_ms launches\n" lines; returns number of bytes needed. */
+/* Writes "name total_ms launches\n" lines; returns number of bytes needed.  The registry also carries the reference's
+ * non-timer statistics of Marching under their own names (src/marching.cpp:350-352, always on): marching.overflow,
+ * marching.slices.nonempty, marching.shipouts -- the SUM of the samples in the total_ms column, their number in the launches
+ * column (Statistics::Variable's sum and n). */
 size_t mlsgpu_hip_ctx_dump_stats(mlsgpu_ctx *ctx, char *buf, size_t bufSize);
 
 /* ---- SplatTreeCL (src/splat_tree_cl.h:216-296) ---- */

@@ -117,6 +117,15 @@ struct mlsgpu_ctx
     int scanFlags(uint32_t **flags, uint32_t *epoch, uint32_t **tickets, uint32_t *bases, uint32_t gridX, uint32_t count);
 
     int statId(const char *name);
+    /* a sample of one of the reference's non-timer statistics (Statistics::Counter / Variable: marching.overflow,
+     * marching.slices.nonempty, marching.shipouts; src/marching.cpp:350-352): the sum in the "ms" column, the samples in the
+     * launch column of mlsgpu_hip_ctx_get_stat / _dump_stats */
+    void addValue(const char *name, double value)
+    {
+        mlsgpu::Stat &st = stats[(size_t) statId(name)];
+        st.totalMs += value;
+        st.launches += 1;
+    }
     int beginTiming(int id);          /* returns index into pending or -1 */
     void endTiming(int pendingIdx);
     int resolveTimings();             /* synchronises the stream */

@@ -2408,6 +2408,7 @@ int mlsgpu_marching::addSlices(const mlsgpu_swathe &swathe, uint32_t offsets[2],
         if (counts[0] > vertexSpace || counts[1] > indexSpace)
         {
             counters[0]++;
+            ctx->addValue("marching.overflow", 1.0);                /* overflowStat, src/marching.cpp:655 */
             /* Swathe is too big on its own: split it into maximal runs of slices using the
              * per-slice histogram and recurse (:652-701). */
             PROPAGATE(sliceHistogram(swathe));
@@ -2489,6 +2490,7 @@ int mlsgpu_marching::addSlices(const mlsgpu_swathe &swathe, uint32_t offsets[2],
         }
     }
     counters[2] += compacted > 0;
+    ctx->addValue("marching.slices.nonempty", compacted > 0 ? 1.0 : 0.0);      /* nonemptyStat, src/marching.cpp:739 */
     return MLSGPU_OK;
 }
 
@@ -2554,6 +2556,7 @@ MLSGPU_API int mlsgpu_hip_marching_generate(mlsgpu_marching *m, const mlsgpu_gen
     uint32_t offsets[2] = {0, 0};
     uint32_t zTop = 0;
     uint32_t shipOuts = 0;
+    const uint64_t shipOutsBefore = m->counters[1];
     for (uint32_t z = 0; z < depth; z += m->maxSwathe)
     {
         swathe.zFirst = z;
@@ -2573,6 +2576,7 @@ MLSGPU_API int mlsgpu_hip_marching_generate(mlsgpu_marching *m, const mlsgpu_gen
         PROPAGATE(m->shipOut(swathe, offsets, zTop, depth - 1));
         shipOuts++;
     }
+    ctx->addValue("marching.shipouts", (double) (m->counters[1] - shipOutsBefore));     /* shipoutsStat, src/marching.cpp:822 */
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return MLSGPU_OK;
 }
@@ -2681,6 +2685,9 @@ MLSGPU_API int mlsgpu_hip_marching_generate_batch(mlsgpu_marching *const *ms, co
     ShipLane ship[MAX_LANES];
     uint32_t shipOf[MAX_LANES], numShip = 0;
     bool split[MAX_LANES];
+    uint64_t shipOutsBefore[MAX_LANES];
+    for (uint32_t k = 0; k < count; k++)
+        shipOutsBefore[k] = ms[k]->counters[1];
     for (uint32_t k = 0; k < count; k++)
     {
         mlsgpu_marching *m = ms[k];
@@ -2689,15 +2696,19 @@ MLSGPU_API int mlsgpu_hip_marching_generate_batch(mlsgpu_marching *const *ms, co
         split[k] = false;
         shipOf[k] = MAX_LANES;
         if (totals.a == 0)
+        {
+            ctx->addValue("marching.slices.nonempty", 0.0);
             continue;
+        }
         if (totals.b > m->vertexSpace || totals.c > m->indexSpace)
         {
-            split[k] = true;
+            split[k] = true;            /* (addSlices below accounts for it) */
             continue;
         }
         m->bufferedCells += totals.a;
         m->counters[3] += totals.a;
         m->counters[2] += 1;
+        ctx->addValue("marching.slices.nonempty", 1.0);
         shipOf[k] = numShip;
         ship[numShip++] = ShipLane{m, sws[k], {totals.b, totals.c}, 0u, sizes[3 * k + 2] - 1, mlsgpu_mesh()};
     }
@@ -2716,6 +2727,7 @@ MLSGPU_API int mlsgpu_hip_marching_generate_batch(mlsgpu_marching *const *ms, co
             if (offsets[0] > 0)
                 PROPAGATE(m->shipOut(sws[k], offsets, zTop, sizes[3 * k + 2] - 1));
         }
+        ctx->addValue("marching.shipouts", (double) (m->counters[1] - shipOutsBefore[k]));
     }
     HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return MLSGPU_OK;

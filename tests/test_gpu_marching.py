@@ -114,10 +114,17 @@ def test_generate_swathe_and_memory_variants(ctx, swathe, mem_slices, alignment,
     mw, mh, md = 88, 80, 72
     mesh_memory = (mw - 1) * (mh - 1) * 872 * mem_slices
     mc = m.Marching(ctx, mw, mh, md, swathe, mesh_memory, alignment)
+    ctx.reset_stats()
     got = mc.generate(m.binding.HostGenerator(ctx, fn, alignment), size, key_offset)
     oracle = ob.MarchingOracle(mw, mh, md, swathe, mesh_memory, alignment)
     exp = oracle.generate(host_generator(fn), size, key_offset)
     assert_batches_equal(got, exp)
+    # the reference's own statistics of Marching (src/marching.cpp:350-352, 655, 739, 822), under its names, in the context's
+    # registry: sum and number of samples
+    st, cnt, ost = ctx.stats(), mc.counters(), oracle.stats()
+    assert st["marching.shipouts"] == (float(len(got)), 1)
+    assert st["marching.slices.nonempty"][0] == cnt["nonempty"] and st["marching.slices.nonempty"][1] >= cnt["nonempty"] >= 1
+    assert st.get("marching.overflow", (0.0, 0))[0] == cnt["overflows"] == ost["overflows"]
 
 
 @pytest.mark.parametrize("name", sorted(GENERATE_CASES))
