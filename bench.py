@@ -405,7 +405,8 @@ def main():
         single_worker_ms = (time.perf_counter() - t0) / sw_steps * 1e3
 
     # ---- algorithmic work + output digest (one instrumented, untimed pass on worker 0) ----
-    counters = m.DeviceBuffer(ctx, array=np.zeros(m.binding.MLS_STATS_WORDS, np.uint64))
+    # (MLSGPU_BENCH_MLS_STATS_WORDS: room for what an instrumented library writes behind the counters, tools/drain_sim.py)
+    counters = m.DeviceBuffer(ctx, array=np.zeros(int(os.environ.get("MLSGPU_BENCH_MLS_STATS_WORDS", m.binding.MLS_STATS_WORDS)), np.uint64))
     w0 = workers[0]
     before = w0.marching_counters()
     w0.set_mls_stats(counters)
@@ -420,6 +421,11 @@ def main():
             corners += int(np.prod([-(-n // 8) * 8 for n in b.num_vertices]))
     ctx.synchronize()
     mls_counters = [int(x) for x in counters.download(np.uint64)]
+    if os.environ.get("MLSGPU_BENCH_MLS_STATS_FILE"):
+        np.savez_compressed(os.environ["MLSGPU_BENCH_MLS_STATS_FILE"], words=np.array(mls_counters, np.uint64))
+    if os.environ.get("MLSGPU_BENCH_DUMP_MLS_COUNTERS"):
+        # the raw words (tools/mls_clock.sh: a library built with -DMLSGPU_MLS5_CLOCK leaves a wave's cycle sums in words 0-7)
+        print("mls counters:", " ".join(str(x) for x in mls_counters[:64]), file=sys.stderr, flush=True)
     listed, tests, hits = mls_counters[:3]
     if args.variant == 5 and mls_counters[42] != 0:
         raise SystemExit("processCorners: the matrix prefilter missed %d hits of the reference's test" % mls_counters[42])

@@ -710,6 +710,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
  * (cfg3: 563-576 -> 510-516 us per launch of two buckets; shells cloud 497 -> 411): it executes 19 % fewer vector
  * instructions and 25 % fewer LDS instructions (profiles/r06_cfg3_processCorners_sq_counters.csv), the matrix pipe is 4 %
  * busy.  The drain requests the next candidate's records before it works on this one's (-1.5 %).
+ *
+ * Where a wave's time goes (s_memtime at the phase boundaries, -DMLSGPU_MLS5_CLOCK, tools/mls_clock.sh; cfg3 uniform): 15 %
+ * before its first round (kernel arguments, start[], the list head, the ids: four dependent loads), 12 % staging, 6 % at the
+ * barrier behind it, 9 % compaction, 43 % tiles and drains, 10 % at the round's last barrier.  Two things follow from it:
+ * a round's records are requested BEFORE the wave waits for the others to leave the round before (the barrier that guards
+ * the staged arrays sits between the loads and the LDS writes, and waits for LDS operations only), and a lane's eight
+ * sub-block masks lie side by side so that the compaction reads them once (together -1.8 %).  -DMLSGPU_MLS5_DUMP leaves
+ * the candidate masks of a sample of tiles behind the work counters: tools/drain_sim.py replays them under other ways of
+ * walking the masks (profiles/NOTES_r06.md, section 10).
  */
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -752,6 +761,16 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
     const MlsArgs A = lanes.a[blockIdx.y];
     if (blockIdx.x >= A.numBlocks)
         return;
+#ifdef MLSGPU_MLS5_CLOCK
+    /* where a wave's time goes (an instrumented build for profiles/NOTES only: tools/mls_clock.sh); s_memtime at the points
+     * where the wave waits for its LDS operations anyway */
+    uint64_t clkMark = __builtin_amdgcn_s_memtime();
+    const uint64_t clkStart = clkMark;
+    uint64_t clkHead = 0, clkStage = 0, clkBar1 = 0, clkCompact = 0, clkTiles = 0, clkBar2 = 0;
+#define MLS5_CLOCK(sum) do { uint64_t now_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_) : : "memory"); sum += now_ - clkMark; clkMark = now_; } while (0)
+#else
+#define MLS5_CLOCK(sum) do { } while (0)
+#endif
     if (STATS)
     {
         if (threadIdx.x < 33)
@@ -907,15 +926,31 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
         int32_t end = A.commands[pos++];
         /* a round's splat ids are requested while the round before it is processed */
         int32_t idAhead = pos + (int32_t) tid < end ? A.commands[pos + (int32_t) tid] : -1;
+        MLS5_CLOCK(clkHead);
+        bool laterRound = false;
         while (pos < end)
         {
             {
                 uint32_t mask = 0;
                 const int32_t mine = idAhead;
+                /* the round's records are requested BEFORE the wave waits for the others to be done with the round before:
+                 * the barrier only guards the staged arrays */
+                float4 pr = {0.0f, 0.0f, 0.0f, 0.0f}, nq = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (mine >= 0)
                 {
-                    const float4 pr = stagedPosRad(A, mine);
-                    const float4 nq = A.splats[2 * (int64_t) mine + 1];
+                    pr = A.splats[2 * (int64_t) mine];
+                    nq = A.splats[2 * (int64_t) mine + 1];
+                }
+                if (laterRound)
+                {
+                    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory");
+                    MLS5_CLOCK(clkBar2);
+                }
+                laterRound = true;
+                if (mine >= 0)
+                {
+                    if (A.rawRadius)
+                        pr.w = 1.0f / (pr.w * pr.w);
                     sPosRad[tid] = pr;
                     sNormQ[tid] = nq;
                     float d[3][2];
@@ -961,7 +996,7 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
                         sColHi[tid] = make_uint4(packHi(z0, z1), packHi(z2, q0), packHi(q1, q2), c2 >> 16);
                     }
                 }
-                sMask[tid] = (uint8_t) mask;
+                sMask[lane * 8 + wave] = (uint8_t) mask;        /* a lane's eight groups side by side: one read in the compaction */
                 if (STATS)
                     nListed += __popcll(__ballot(mine >= 0));
             }
@@ -973,7 +1008,9 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
                 end = (pos >= 0) ? A.commands[pos++] : INT32_MIN;
             }
             idAhead = pos + (int32_t) tid < end ? A.commands[pos + (int32_t) tid] : -1;
+            MLS5_CLOCK(clkStage);
             __syncthreads();
+            MLS5_CLOCK(clkBar1);
 
             /* the round's relevant splats of this wave's sub-block, in list order; a table that cannot take the next group of
              * 64 is worked off first (no cloud of the BASELINE configs gets there) */
@@ -981,9 +1018,10 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
             do
             {
             uint32_t nt = 0;
+            const uint64_t mm = *(const uint64_t *) (sMask + lane * 8);
             for (; g < staged; g += 64)
             {
-                const uint32_t m = sMask[g + lane];
+                const uint32_t m = (uint32_t) (mm >> ((uint32_t) g >> 3));       /* byte g / 64 */
                 const uint64_t todo = __ballot((m >> wave) & 1u);
                 const uint32_t n = (uint32_t) __popcll(todo);
                 if (nt + n > MATRIX_SLOTS)
@@ -996,6 +1034,7 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            MLS5_CLOCK(clkCompact);
 
             LdsSlot *tile = mySlots;        /* the tile's first slot; this lane's row reads tile[rowSplat] */
             for (uint32_t t0 = 0; t0 < nt; t0 += 32, tile += 32)
@@ -1039,21 +1078,53 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
                     }
                     nMissed += waveSum((uint32_t) __popc(exact & ~cur));
                 }
+#ifdef MLSGPU_MLS5_DUMP
+                /* a sample of the drain's input for offline what-ifs (tools/drain_sim.py): per tile a header word and the 64
+                 * lanes' candidate masks, behind a word count in word 0 */
+                if (A.stats != nullptr && blockIdx.x % 499 == 0)
+                {
+                    unsigned long long at = 0;
+                    if (lane == 0)
+                        at = atomicAdd(&A.stats[0], 65ull);
+                    at = __shfl(at, 0);
+                    if (at + 65 < MLSGPU_MLS5_DUMP)
+                    {
+                        if (lane == 0)
+                            A.stats[1 + at] = ((unsigned long long) blockIdx.y << 56) | ((unsigned long long) blockIdx.x << 24) | (wave << 16) | t0;
+                        A.stats[2 + at + lane] = cur;
+                    }
+                }
+#endif
                 drain(cur, tile);
             }
+            MLS5_CLOCK(clkTiles);
             } while (g < staged);
             if (STATS)
             {
                 sumMostRound += waveMax(roundCnt);
                 roundCnt = 0;
             }
-            __syncthreads();
         }
         fit.sumWpx = sWpxy.x;
         fit.sumWpy = sWpxy.y;
         fit.sumWnx = sWnxy.x;
         fit.sumWny = sWnxy.y;
         f = finishCorner<SHAPE>(fit, A.boundaryFactor);
+#ifdef MLSGPU_MLS5_CLOCK
+        if (A.stats != nullptr && lane == 0 && blockIdx.x % 61 == 0)     /* a sample: 18 M atomics on eight words would be the measurement */
+        {
+            /* words 0-5: cycles of a wave before its first round / staging (its loads included) / at the barrier behind it /
+             * compaction / tiles and drains / at the round's last barrier; 6: from the first instruction to here; 7: waves */
+            atomicAdd(&A.stats[0], (unsigned long long) clkHead);
+            atomicAdd(&A.stats[1], (unsigned long long) clkStage);
+            atomicAdd(&A.stats[2], (unsigned long long) clkBar1);
+            atomicAdd(&A.stats[3], (unsigned long long) clkCompact);
+            atomicAdd(&A.stats[4], (unsigned long long) clkTiles);
+            atomicAdd(&A.stats[5], (unsigned long long) clkBar2);
+            atomicAdd(&A.stats[6], (unsigned long long) (__builtin_amdgcn_s_memtime() - clkStart));
+            atomicAdd(&A.stats[7], 1ull);
+        }
+#endif
         if (STATS)
         {
             const unsigned long long hits = waveSum(fit.hits);
@@ -1233,8 +1304,13 @@ static int mlsEnqueueLanes(mlsgpu_mls *const *ms, const MlsArgs *args, uint32_t 
         const long v = e ? atol(e) : 0;
         return (uint32_t) (v < 0 ? 0 : (v > 120 * 1024 ? 120 * 1024 : v));
     }();
+#if defined(MLSGPU_MLS5_CLOCK) || defined(MLSGPU_MLS5_DUMP)
+    /* the clock build times the PLAIN kernel: it writes its cycle sums where the work counters would go */
+    const bool sphere = m->shape == MLSGPU_SHAPE_SPHERE, stats = m->dStats != nullptr && m->variant != 5;
+#else
     const bool sphere = m->shape == MLSGPU_SHAPE_SPHERE, stats = m->dStats != nullptr;    /* stats: an instrumented build,
                                                                                             * never in a timed run */
+#endif
 #define MLS_LAUNCH(KERNEL, SHAPE, STATS) LAUNCH_LDS(ctx, stat, (KERNEL<SHAPE, STATS>), grid, block, ldsPad, L)
 #define MLS_LAUNCH_ANY(KERNEL)                                                                                   \
     do {                                                                                                         \
