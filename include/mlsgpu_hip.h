@@ -618,6 +618,14 @@ uint32_t mlsgpu_hip_host_mesher_threads(mlsgpu_host_mesher *mesher);
  * caches.  -1 (default): unbound.  Before the first add.  The reference's mesher thread is not placed. */
 int mlsgpu_hip_host_mesher_set_node(mlsgpu_host_mesher *mesher, int node);
 int mlsgpu_hip_host_mesher_node(mlsgpu_host_mesher *mesher);
+/* Bounded-memory mode -- OOCMesher's temporary files (src/mesher.cpp:404-419 writes every block's vertices and triangles to
+ * them, :763-852 reads them back): the welder's memory becomes mappings of nameless temporary files in `dir`, and once more
+ * than `residentBytes` of blocks have arrived a block is written out and dropped from memory when its task is done; the
+ * output passes fault it back in.  Results are the in-memory mode's, element for element.  Before the first add; an unusable
+ * directory is MLSGPU_ERR_INVALID; NULL or "" = in memory (the default).  tmp_usage: out[0] = bytes of temporary files mapped,
+ * out[1] = of which in memory right now, out[2] = bytes of blocks handed to the kernel to write out and drop. */
+int mlsgpu_hip_host_mesher_set_tmp_dir(mlsgpu_host_mesher *mesher, const char *dir, uint64_t residentBytes);
+int mlsgpu_hip_host_mesher_tmp_usage(mlsgpu_host_mesher *mesher, uint64_t out[3]);
 int mlsgpu_hip_host_mesher_add(mlsgpu_host_mesher *mesher, uint64_t chunkId, const mlsgpu_host_mesh *mesh);
 /* a mlsgpu_farm_host_output_fn whose `user` is the mlsgpu_host_mesher */
 int mlsgpu_hip_host_mesher_farm_output(void *mesher, int device, uint64_t chunkId, const mlsgpu_host_mesh *mesh);

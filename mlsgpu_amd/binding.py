@@ -249,6 +249,8 @@ def lib():
     sig("mlsgpu_hip_farm_group_clock", C.c_int, vp, u32, vp)
     sig("mlsgpu_hip_host_mesher_trim_cache", u64, u64)
     sig("mlsgpu_hip_host_mesher_set_node", C.c_int, vp, C.c_int)
+    sig("mlsgpu_hip_host_mesher_set_tmp_dir", C.c_int, vp, C.c_char_p, C.c_uint64)
+    sig("mlsgpu_hip_host_mesher_tmp_usage", C.c_int, vp, C.POINTER(C.c_uint64))
     sig("mlsgpu_hip_host_mesher_node", C.c_int, vp)
     sig("mlsgpu_hip_host_mesher_create", C.c_int, P(vp))
     sig("mlsgpu_hip_host_mesher_destroy", None, vp)
@@ -874,6 +876,16 @@ class HostMesher:
     def set_node(self, node):
         """Bind the welder's threads to a NUMA node's CPUs (before the first add); -1 = unbound."""
         check(lib().mlsgpu_hip_host_mesher_set_node(self.h, int(node)))
+
+    def set_tmp_dir(self, path, resident_bytes=0):
+        """Bounded-memory mode (OOCMesher's temporary files): the welder's memory is file-backed, blocks beyond
+        `resident_bytes` are written out and dropped once welded.  Before the first add."""
+        check(lib().mlsgpu_hip_host_mesher_set_tmp_dir(self.h, None if path is None else str(path).encode(), int(resident_bytes)))
+
+    def tmp_usage(self):
+        out = (C.c_uint64 * 3)()
+        check(lib().mlsgpu_hip_host_mesher_tmp_usage(self.h, out))
+        return {"mapped": int(out[0]), "resident": int(out[1]), "paged_out": int(out[2])}
 
     def add(self, chunk_id, vertices, num_internal, keys, triangles):
         """keys: the external vertices' keys (len(vertices) - num_internal of them)."""

@@ -1,5 +1,5 @@
 /*
- * Host mesh sink: the weld OOCMesher performs on the host (src/mesher.cpp:220-469), kept in memory.  This is the
+ * Host mesh sink: the weld OOCMesher performs on the host (src/mesher.cpp:220-469).  This is the
  * north_star's "welding stays on host" route and the cross-GPU welder: ship-outs of any device reach it through the
  * bucket farm's pinned circular buffer (mlsgpu_hip_farm_set_host_output).
  *
@@ -19,9 +19,11 @@
  * (:763-852): the unions, component sizes, the prune threshold uint64(total * threshold) with the `>=` keep test
  * (getStatistics :491-536), and one mesh per chunk in which a key occurs once, built by the pool block by block (three
  * passes: what is emitted, vertex ranks and copies, aliases and triangles).  Differences from the reference, all invisible
- * up to the isomorphism its own tests compare by (test/test_mesher.cpp:401-460): no temporary files and no reorder buffer
- * (host memory is the arena), output order is (chunk by first arrival, block arrival, order inside the block) exactly as
- * the device sink's (mesher.hip), so the two sinks can be compared element for element.
+ * up to the isomorphism its own tests compare by (test/test_mesher.cpp:401-460): no writer / reader threads of our own and no
+ * reorder buffer (the arena is host memory, or -- mlsgpu_hip_host_mesher_set_tmp_dir, the reference's --tmp-dir -- mappings of
+ * temporary files that the kernel writes out and drops once a block is welded: a mesh larger than host memory has a path),
+ * output order is (chunk by first arrival, block arrival, order inside the block) exactly as the device sink's (mesher.hip),
+ * so the two sinks can be compared element for element.
  *
  * Host code only; it lives in the HIP library because the farm's mesher thread calls it.
  */
@@ -42,7 +44,9 @@
 #include <thread>
 #include <unordered_map>
 
+#include <fcntl.h>
 #include <sys/mman.h>
+#include <unistd.h>
 
 using namespace mlsgpu;
 
@@ -62,7 +66,44 @@ struct Slab
     size_t cap = 0;
     bool landing = false;       /* a slab ship-outs land in: registered with the HIP runtime (page-locked) where that works */
     bool registered = false;
+    bool file = false;          /* a mapping of an unlinked temporary file (mlsgpu_hip_host_mesher_set_tmp_dir): never cached */
 };
+
+/* Bounded-memory mode: the slab is a shared mapping of a temporary file that has no name any more.  What the welder writes
+ * there is the kernel's to write back and to drop from memory, and comes back with a page fault when the output passes
+ * read it -- OOCMesher's temporary vertex / triangle files (src/mesher.cpp:404-419, 763-852) without a reader and a writer
+ * of our own.  Returns an empty slab when the directory does not take the file. */
+std::atomic<uint64_t> tmpBytesMapped{0};
+
+Slab takeFileSlab(size_t atLeast, const std::string &dir)
+{
+    Slab s;
+    const size_t cap = (atLeast + (size_t(2) << 20) - 1) & ~((size_t(2) << 20) - 1);
+    int fd = open(dir.c_str(), O_TMPFILE | O_RDWR | O_CLOEXEC, 0600);
+    if (fd < 0)
+    {
+        /* a file system without O_TMPFILE: a named file, unlinked at once */
+        std::string name = dir + "/mlsgpu-welder-XXXXXX";
+        fd = mkstemp(&name[0]);
+        if (fd < 0)
+            return s;
+        unlink(name.c_str());
+    }
+    if (ftruncate(fd, (off_t) cap) != 0)
+    {
+        close(fd);
+        return s;
+    }
+    void *p = mmap(nullptr, cap, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);                  /* the mapping keeps the file */
+    if (p == MAP_FAILED)
+        return s;
+    s.base = static_cast<char *>(p);
+    s.cap = cap;
+    s.file = true;
+    tmpBytesMapped += cap;
+    return s;
+}
 
 class SlabCache
 {
@@ -116,6 +157,11 @@ public:
     {
         if (s.base == nullptr)
             return;
+        if (s.file)
+        {
+            munmap(s.base, s.cap);      /* the file goes with its last mapping */
+            return;
+        }
         {
             std::lock_guard<std::mutex> l(mutex);
             if (held + s.cap <= limit)
@@ -179,6 +225,28 @@ class Arena
 public:
     explicit Arena(bool landing_ = false) : landing(landing_) {}
     ~Arena() { release(); }
+    /* every slab from now on is a mapping of a temporary file in `dir` (and no landing slab is page-locked) */
+    void setTmpDir(const std::string &dir)
+    {
+        std::lock_guard<std::mutex> l(mutex);
+        tmpDir = dir;
+    }
+    /* bytes of the arena's file-backed slabs, and how many of them are in memory right now (mincore) */
+    void fileUsage(uint64_t &mapped, uint64_t &resident)
+    {
+        std::lock_guard<std::mutex> l(mutex);
+        const size_t page = (size_t) sysconf(_SC_PAGESIZE);
+        std::vector<unsigned char> vec;
+        for (const Slab &s : slabs)
+            if (s.file)
+            {
+                mapped += s.cap;
+                vec.resize(s.cap / page);
+                if (mincore(s.base, s.cap, vec.data()) == 0)
+                    for (unsigned char c : vec)
+                        resident += (c & 1u) ? page : 0;
+            }
+    }
     bool contains(const void *p, size_t bytes)
     {
         std::lock_guard<std::mutex> l(mutex);
@@ -209,7 +277,8 @@ public:
         std::lock_guard<std::mutex> l(mutex);
         if (slabs.empty() || used + bytes > slabs.back().cap)
         {
-            Slab s = SlabCache::instance().take(std::max(bytes, size_t(256) << 20), landing);
+            Slab s = tmpDir.empty() ? SlabCache::instance().take(std::max(bytes, size_t(256) << 20), landing)
+                                    : takeFileSlab(std::max(bytes, size_t(256) << 20), tmpDir);
             if (s.base == nullptr)
                 return nullptr;
             slabs.push_back(s);
@@ -261,6 +330,7 @@ private:
     std::vector<Slab> slabs;
     size_t used = 0;
     bool landing = false;
+    std::string tmpDir;
 };
 
 /* ---------------------------------------------------------------- a small pool: tasks and parallel loops */
@@ -559,6 +629,11 @@ struct mlsgpu_host_mesher
     std::vector<uint64_t> compVertices, compTriangles;      /* valid at roots */
     uint64_t numKeys = 0;
 
+    /* bounded-memory mode (mlsgpu_hip_host_mesher_set_tmp_dir): the arenas are mappings of temporary files, and a block whose
+     * task is done is handed to the kernel to write out and drop once more than tmpResident bytes of blocks have arrived */
+    std::string tmpDir;
+    uint64_t tmpResident = 0;
+    std::atomic<uint64_t> blockBytes{0}, pagedOut{0};
     Arena arena;                            /* blocks, scratch and outputs */
     Arena landed{true};                     /* ship-outs that arrive in place (mlsgpu_hip_host_mesher_landing): page-locked slabs */
     float *outVertices = nullptr;
@@ -606,9 +681,36 @@ struct mlsgpu_host_mesher
         return r;
     }
     void processBlock(Block *b);
+    void pageOut(Block *b);
     int resolve();
     int finalizeWith(const uint8_t *keepClump, uint32_t *numChunks);
 };
+
+/* Bounded-memory mode: the block's arrays are not looked at again before the output passes.  Beyond the resident budget
+ * they are given to the kernel to write to the temporary file and drop (whole pages inside the arrays; MADV_PAGEOUT is a
+ * request: a kernel without it, or a file system in memory, keeps the pages and the job is merely not bounded). */
+void mlsgpu_host_mesher::pageOut(Block *b)
+{
+    const uint64_t bytes = 3 * b->nv * sizeof(float) + 3 * b->nt * sizeof(uint32_t) + (b->nv - b->nInternal) * sizeof(uint64_t);
+    if (blockBytes.fetch_add(bytes) + bytes <= tmpResident)
+        return;
+    const uintptr_t page = (uintptr_t) sysconf(_SC_PAGESIZE);
+    auto drop = [&](void *p, size_t n) {
+        const uintptr_t lo = ((uintptr_t) p + page - 1) & ~(page - 1), hi = ((uintptr_t) p + n) & ~(page - 1);
+        if (hi > lo)
+        {
+#ifdef MADV_PAGEOUT
+            if (madvise((void *) lo, hi - lo, MADV_PAGEOUT) == 0)
+                pagedOut += hi - lo;
+            else
+#endif
+                (void) msync((void *) lo, hi - lo, MS_ASYNC);       /* at least clean: the kernel can drop the pages when it wants the memory */
+        }
+    };
+    drop(b->vertices, 3 * b->nv * sizeof(float));
+    drop(b->triangles, 3 * b->nt * sizeof(uint32_t));
+    drop(b->keys, (b->nv - b->nInternal) * sizeof(uint64_t));
+}
 
 /* the block's task: computeLocalComponents + updateGlobalClumps + updateClumpKeyMap (src/mesher.cpp:220-311) */
 void mlsgpu_host_mesher::processBlock(Block *b)
@@ -780,6 +882,48 @@ MLSGPU_API int mlsgpu_hip_host_mesher_set_prune_threshold(mlsgpu_host_mesher *m,
     return MLSGPU_OK;
 }
 
+/* Bounded-memory mode, OOCMesher's temporary files (src/mesher.cpp:404-419 writes every block's vertices and triangles to
+ * them, :763-852 reads them back clump by clump): every slab of the welder -- blocks, scratch, the output arrays -- becomes a
+ * mapping of a nameless temporary file in `dir`, and once more than `residentBytes` of blocks have arrived a block is
+ * written out and dropped from memory as soon as its task is done.  The job's resident memory is then the per-vertex and
+ * per-clump bookkeeping plus what the kernel chooses to keep, not the mesh.  The output passes fault the blocks back in
+ * arrival order (the order they were written in).  Results are the in-memory mode's, element for element.  Ship-outs that
+ * land in place (mlsgpu_hip_host_mesher_landing) land in pageable file-backed memory: not page-locked, slower, still
+ * in place.  Before the first add; an unusable directory is MLSGPU_ERR_INVALID.  NULL or "" = back to memory. */
+MLSGPU_API int mlsgpu_hip_host_mesher_set_tmp_dir(mlsgpu_host_mesher *m, const char *dir, uint64_t residentBytes)
+{
+    REQUIRE(m != nullptr, MLSGPU_ERR_INVALID);
+    std::lock_guard<std::mutex> lock(m->mutex);
+    REQUIRE(m->blocks.empty(), MLSGPU_ERR_INVALID);
+    const std::string d = dir != nullptr ? dir : "";
+    if (!d.empty())
+    {
+        Slab probe = takeFileSlab(1, d);
+        if (probe.base == nullptr)
+            return setError(MLSGPU_ERR_INVALID, "host mesher: cannot create a temporary file in the given directory");
+        probe.base[0] = 1;
+        tmpBytesMapped -= probe.cap;
+        munmap(probe.base, probe.cap);
+    }
+    m->tmpDir = d;
+    m->tmpResident = residentBytes;
+    m->arena.setTmpDir(d);
+    m->landed.setTmpDir(d);
+    return MLSGPU_OK;
+}
+
+/* out[0] = bytes of temporary files mapped by this welder, out[1] = how many of them are in memory right now, out[2] = bytes
+ * of blocks handed to the kernel to write out and drop */
+MLSGPU_API int mlsgpu_hip_host_mesher_tmp_usage(mlsgpu_host_mesher *m, uint64_t out[3])
+{
+    REQUIRE(m != nullptr && out != nullptr, MLSGPU_ERR_INVALID);
+    out[0] = out[1] = 0;
+    m->arena.fileUsage(out[0], out[1]);
+    m->landed.fileUsage(out[0], out[1]);
+    out[2] = m->pagedOut.load();
+    return MLSGPU_OK;
+}
+
 /* Threads of the welder (block tasks and the output passes); 0 = the default: MLSGPU_HIP_HOST_MESHER_THREADS, else
  * min(32, hardware threads).  Before the first add. */
 MLSGPU_API int mlsgpu_hip_host_mesher_set_threads(mlsgpu_host_mesher *m, uint32_t threads)
@@ -834,6 +978,8 @@ static int enlistBlock(mlsgpu_host_mesher *m, uint64_t chunkId, std::unique_ptr<
     m->getPool().submit([m, raw] {
         const auto t0 = std::chrono::steady_clock::now();
         m->processBlock(raw);
+        if (!m->tmpDir.empty())
+            m->pageOut(raw);
         if (m->trace.on)
             m->trace.taskNs += (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
     });

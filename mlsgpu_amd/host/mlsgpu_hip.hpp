@@ -618,6 +618,12 @@ public:
     /// the welder's threads on one NUMA node (the one its meshes arrive on); -1 = unbound.  Before the first add.
     void setNode(int node) { check(mlsgpu_hip_host_mesher_set_node(h, node)); }
     int node() const { return mlsgpu_hip_host_mesher_node(h); }
+    /// the reference's --tmp-dir (TmpWriterWorkerGroup, src/mesher.cpp:404-419): blocks live in temporary files there and
+    /// leave memory once welded, beyond `residentBytes` of them.  Before the first add.
+    void setTmpDir(const std::string &dir, std::uint64_t residentBytes = 0)
+    {
+        check(mlsgpu_hip_host_mesher_set_tmp_dir(h, dir.c_str(), residentBytes));
+    }
     void add(std::uint64_t chunkId, const mlsgpu_host_mesh &mesh) { check(mlsgpu_hip_host_mesher_add(h, chunkId, &mesh)); }
     std::size_t write(const Namer &namer, const std::vector<std::string> &comments = std::vector<std::string>())
     {

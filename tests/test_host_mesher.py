@@ -216,3 +216,83 @@ def test_landed_argument_checks():
     with pytest.raises(m.InvalidArgument):
         mesher.finalize()
     mesher.close()
+
+
+@pytest.mark.parametrize("prune", [0.0, 0.05])
+def test_temporary_files_give_the_same_mesh(prune, tmp_path):
+    """Bounded-memory mode (mlsgpu_hip_host_mesher_set_tmp_dir; OOCMesher's temporary files, src/mesher.cpp:404-419, 763-852):
+    the welder's blocks, scratch and outputs live in mappings of nameless temporary files, every block is handed to the
+    kernel to write out once it is welded (resident budget 0) -- and the meshes are the in-memory mode's, element for element,
+    whichever route the blocks arrive by."""
+    import mlsgpu_amd as m
+    meshes = random_meshes(31, blocks=20, chunks=3)
+    outs = []
+    for mode in ("memory", "files", "files-landed"):
+        mesher = m.HostMesher(prune, threads=4)
+        if mode != "memory":
+            mesher.set_tmp_dir(tmp_path, 0)
+        seen = {}
+        for i, mesh in enumerate(meshes):
+            landed = mode == "files-landed" and i % 2 == 0
+            (mesher.add_landed if landed else mesher.add)(seen.setdefault(mesh["chunk"], len(seen)), mesh["vertices"],
+                                                          mesh["num_internal"], mesh["keys"], mesh["triangles"])
+        n = mesher.finalize()
+        outs.append(([mesher.chunk(i) for i in range(n)], mesher.stats()))
+        usage = mesher.tmp_usage()
+        if mode == "memory":
+            assert usage["mapped"] == 0
+        else:
+            assert usage["mapped"] >= 256 << 20 and usage["resident"] <= usage["mapped"]
+            assert not mesher.landing_pinned() or mode == "files"      # file-backed landing memory is not page-locked
+            assert list(tmp_path.iterdir()) == []                   # the files have no names
+        mesher.close()
+    first, stats0 = outs[0]
+    assert len(first) >= 1
+    for other, stats in outs[1:]:
+        assert stats == stats0 and len(other) == len(first)
+        for (c0, v0, t0), (c1, v1, t1) in zip(first, other):
+            assert c0 == c1
+            np.testing.assert_array_equal(v0.view(np.uint32), v1.view(np.uint32))
+            np.testing.assert_array_equal(t0, t1)
+
+
+def test_temporary_files_argument_checks(tmp_path):
+    import mlsgpu_amd as m
+    mesher = m.HostMesher()
+    with pytest.raises(m.InvalidArgument):
+        mesher.set_tmp_dir(tmp_path / "not-there", 0)
+    a = CASES["simple"]["meshes"][0]
+    mesher.set_tmp_dir(tmp_path, 1 << 30)
+    mesher.set_tmp_dir(None)                                        # back to memory
+    mesher.add(0, a["vertices"], a["num_internal"], a["keys"], a["triangles"])
+    with pytest.raises(m.InvalidArgument):
+        mesher.set_tmp_dir(tmp_path, 0)                             # not once blocks have arrived
+    assert mesher.finalize() == 1 and mesher.tmp_usage()["mapped"] == 0
+    mesher.close()
+
+
+def test_temporary_files_leave_memory(tmp_path):
+    """What bounded means: 96 MB of blocks through a welder with a resident budget of 8 MB -- once they are welded all but the
+    budget has been handed to the kernel to write out and drop.  Whether the pages really leave is the kernel's business
+    (MADV_PAGEOUT needs Linux 5.4 and a file system on a disk): reported, and checked only where the kernel did it."""
+    import mlsgpu_amd as m
+    rng = np.random.default_rng(5)
+    mesher = m.HostMesher(0.0, threads=4)
+    mesher.set_tmp_dir(tmp_path, 8 << 20)
+    nv, nt = 400_000, 800_000
+    total = 0
+    for b in range(6):
+        v = rng.random((nv, 3)).astype(np.float32)
+        t = rng.integers(0, nv, (nt, 3)).astype(np.uint32)
+        k = (np.arange(1000, dtype=np.uint64) + np.uint64(b * 1000))
+        mesher.add(b % 2, v, nv - 1000, k, t)
+        total += v.nbytes + t.nbytes + k.nbytes
+    n = mesher.finalize()
+    assert n == 2
+    usage = mesher.tmp_usage()
+    assert usage["mapped"] >= total
+    if usage["paged_out"]:
+        assert usage["paged_out"] >= total - (8 << 20) - 6 * 3 * 8192   # whole pages inside the arrays beyond the budget
+    st = mesher.stats()
+    assert st["vertices_added"] == 6 * nv and st["triangles_added"] == 6 * nt
+    mesher.close()
