@@ -12,7 +12,7 @@
  *                        prune there); --weld host: every ship-out read back through the pinned circular buffer and welded
  *                        by mlsgpu::hip::OOCMesher on the mesher thread (the reference's route)
  *
- * usage: reconstruct [--devices 0,1,...] [--weld device|host] [--buffer BYTES] <in.ply> [more.ply ...] <out.ply>
+ * usage: reconstruct [--devices 0,1,...] [--weld device|host] [--tmp-dir DIR] [--buffer BYTES] <in.ply> [more.ply ...] <out.ply>
  *                    <spacing> [smooth=4] [levels=6] [subsampling=3] [prune=0.02] [maxSplats=2097152]
  * (defaults as src/mlsgpu_core.cpp:86-135: --fit-smooth 4, --levels 6, --subsampling 3, --fit-prune 0.02)
  */
@@ -34,6 +34,7 @@ int main(int argc, char **argv)
     std::vector<std::int32_t> devices(1, 0);
     bool hostWeld = false;
     std::uint64_t bufferBytes = 0, hbmSplats = 0;
+    std::string tmpDir;
     std::vector<std::string> plys, rest;
     for (int i = 1; i < argc; i++)
     {
@@ -50,6 +51,8 @@ int main(int argc, char **argv)
             hostWeld = std::string(argv[++i]) == "host";
         else if (a == "--buffer" && i + 1 < argc)
             bufferBytes = strtoull(argv[++i], NULL, 10);
+        else if (a == "--tmp-dir" && i + 1 < argc)             // --weld host: the welder's blocks in temporary files there (src/mlsgpu_core.cpp --tmp-dir)
+            tmpDir = argv[++i];
         else if (a == "--hbm-splats" && i + 1 < argc)       // the cloud does not fit the device: stream it, this many at a time
             hbmSplats = strtoull(argv[++i], NULL, 10);
         else if (rest.empty() && isPly(a))
@@ -59,7 +62,7 @@ int main(int argc, char **argv)
     }
     if (plys.size() < 2 || rest.empty() || devices.empty())
     {
-        std::cerr << "usage: reconstruct [--devices 0,1] [--weld device|host] [--buffer BYTES] [--hbm-splats N] in.ply [more.ply ...] out.ply "
+        std::cerr << "usage: reconstruct [--devices 0,1] [--weld device|host] [--tmp-dir DIR] [--buffer BYTES] [--hbm-splats N] in.ply [more.ply ...] out.ply "
                      "spacing [smooth] [levels] [subsampling] [prune] [maxSplats]\n";
         return 2;
     }
@@ -117,6 +120,8 @@ int main(int argc, char **argv)
         deviceMesher.setPruneThreshold(prune);
         OOCMesher hostMesher;
         hostMesher.setPruneThreshold(prune);
+        if (!tmpDir.empty())
+            hostMesher.setTmpDir(tmpDir, 0);
         std::size_t bins = 0, written = 0;
         std::uint64_t st[8];
         {

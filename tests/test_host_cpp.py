@@ -138,13 +138,15 @@ def test_reconstruct_ply_to_ply(tmp_path):
     smooth, levels, subsampling, prune, max_splats = 1.5, 4, 3, 0.02, 30000
     tail = [repr(float(spacing)), str(smooth), str(levels), str(subsampling), str(prune), str(max_splats)]
     meshes_out = {}
-    for weld, devices in (("device", "0"), ("device", "0,0,0"), ("host", "0,0"), ("device", "0,0,0,0")):
+    for weld, devices in (("device", "0"), ("device", "0,0,0"), ("host", "0,0"), ("device", "0,0,0,0"), ("host", "0")):
         out_ply = tmp_path / ("out_%s_%d.ply" % (weld, len(devices)))
         env = dict(os.environ)
         if devices == "0,0,0":
             env.update(MLSGPU_HIP_FARM_FORCE_PEER="1", MLSGPU_HIP_MESHER_FORCE_PEER="1")      # the cross-GPU routes
         # the fourth run streams the set: at most 25 000 splats of it resident at a time (mlsgpu_hip_bucket_stream)
         extra = ["--hbm-splats", "25000"] if devices == "0,0,0,0" else []
+        if (weld, devices) == ("host", "0"):
+            extra = ["--tmp-dir", str(tmp_path)]                  # the host welder's blocks in temporary files (OOCMesher's --tmp-dir)
         out = subprocess.check_output([exe, "--devices", devices, "--weld", weld, "--buffer", "65536"] + extra + names
                                       + [str(out_ply)] + tail, timeout=600, env=env).decode()
         assert "files in 3" in out and "files 1" in out and "weld " + weld in out, out
