@@ -214,6 +214,41 @@ def test_process_corners_on_the_cutoff(ctx, variant):
         assert c[41] <= 1.5 * c[2] + 64                                 # and not many more
 
 
+def dense_fixture(seed=9, n=1300):
+    """A list whose every splat reaches every sub-block of its block (radii of 10-14 cells around the 16^3 grid): all 512 staged
+    splats of a round are relevant to each wave, more than its slot table holds (440), so the table is worked off and refilled
+    inside a round; the list has two segments joined by a jump (kernels/mls.cl:354-358) and three rounds in the first."""
+    rng = np.random.default_rng(seed)
+    offset = (40, 50, 60)
+    splats = np.zeros(n, ob.SPLAT_DTYPE)
+    splats["position"] = (rng.uniform(-2.0, 18.0, (n, 3)) + np.array(offset)).astype(np.float32)
+    r = rng.uniform(10.0, 14.0, n)
+    splats["radius"] = (1.0 / (r * r)).astype(np.float32)
+    nrm = rng.normal(size=(n, 3))
+    splats["normal"] = (nrm / np.linalg.norm(nrm, axis=1)[:, None]).astype(np.float32)
+    splats["quality"] = rng.uniform(0.5, 2.0, n).astype(np.float32)
+    first = 1100                                            # ids 0 .. 1099, then a jump to the second segment
+    seg2 = first + 2
+    commands = np.array([first + 1] + list(range(first)) + [seg2]
+                        + [seg2 + 1 + (n - first)] + list(range(first, n)) + [-1], np.int32)
+    start = np.zeros(8, np.int32)
+    return dict(offset=offset, splats=splats, commands=commands, start=start, subsampling=3, size=(16, 16, 16),
+                image_w=16, rows=16 * 16, z_stride=16, z_bias=0, z_first=0, z_last=15)
+
+
+@pytest.mark.parametrize("variant", [1, 4, 5])
+@pytest.mark.parametrize("shape", [0, 1])
+def test_process_corners_dense_list(ctx, variant, shape):
+    """Every listed splat is a hit for (nearly) every corner: full tiles, a slot table that overflows within a round (variant 5
+    flushes it), several rounds and a jump -- bit-equal to the oracle."""
+    fx = dense_fixture()
+    got, exp = _run_process_corners(ctx, fx, variant, shape, fx["splats"])
+    np.testing.assert_array_equal(np.isnan(got), np.isnan(exp))     # (a fit without a surface nearby is NaN in both)
+    ok = ~np.isnan(exp)
+    assert ok.sum() > 3000
+    np.testing.assert_array_equal(got[ok].view(np.uint32), exp[ok].view(np.uint32))
+
+
 def test_enqueue_checks(ctx):
     import mlsgpu_amd as m
     fx = process_corners_fixture()

@@ -64,6 +64,9 @@ int main()
         {"rows of 3264 dwords (aligned), 4 B/lane", 3264, 1, 1u << 30, 0, 1024},
         {"rows of 3271 dwords (unaligned), 4 B/lane", 3271, 1, 1u << 30, 0, 1024},
         {"rows of 3264 dwords (aligned), 16 B/lane", 3264, 4, 1u << 30, 0, 1024},
+        {"rows of 3268 dwords (16-byte aligned only), 16 B/lane", 3268, 4, 1u << 30, 0, 1024},
+        {"the same, 6 WGs/CU", 3268, 4, 1u << 30, 0, 26 * 1024},
+        {"the same, 6 WGs/CU, bursts of 1 + 6 LDS trips", 3268, 4, 1, 6, 26 * 1024},
         {"unaligned, 6 WGs/CU (26 KB of LDS)", 3271, 1, 1u << 30, 0, 26 * 1024},
         {"unaligned, 6 WGs/CU, bursts of 13 + 8 LDS trips", 3271, 1, 13, 8, 26 * 1024},
         {"unaligned, 6 WGs/CU, bursts of 13 + 24 LDS trips", 3271, 1, 13, 24, 26 * 1024},
