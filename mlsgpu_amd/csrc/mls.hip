@@ -745,6 +745,7 @@ __device__ __forceinline__ uint32_t packHi(uint32_t e0, uint32_t e1)
 #define MLSGPU_MLS5_WAVES 8
 #endif
 
+
 template<int SHAPE, bool STATS>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(MLSGPU_MLS5_WAVES, MLSGPU_MLS5_WAVES)))
 void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
@@ -1035,6 +1036,10 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             MLS5_CLOCK(clkCompact);
+            /* the tiles and drains issue ahead of the waves that stage, compact or wait: the vector work is the long pole, and
+             * a wave kept waiting in it holds its workgroup's next barrier back (-1 % on the uniform cloud, -1.5 % on the shells
+             * cloud; the other way round -- the waiting phases first -- costs 4 %) */
+            __builtin_amdgcn_s_setprio(1);
 
             LdsSlot *tile = mySlots;        /* the tile's first slot; this lane's row reads tile[rowSplat] */
             for (uint32_t t0 = 0; t0 < nt; t0 += 32, tile += 32)
@@ -1099,6 +1104,7 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
             }
             MLS5_CLOCK(clkTiles);
             } while (g < staged);
+            __builtin_amdgcn_s_setprio(0);
             if (STATS)
             {
                 sumMostRound += waveMax(roundCnt);
