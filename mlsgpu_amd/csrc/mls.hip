@@ -219,6 +219,11 @@ struct MlsArgs
     uint32_t numBlocks;          /* blocksX * blocksY * blocksZ: workgroups of this lane; the grid covers the largest lane */
     float boundaryFactor;
     uint32_t xcdChunk;           /* see xcdRemap */
+    /* the block's place without a division (processCornersMatrixKernel): a workgroup's first ~100 instructions were four
+     * 32-bit divisions.  superShift = log2(8 * xcdChunk) when xcdChunk is a power of two, full = numBlocks rounded down to
+     * a multiple of 8 * xcdChunk, magicX / magicY = ceil(2^32 / blocksX), ceil(2^32 / blocksY), exact for every dividend the
+     * lane has (checked where they are made: mlsLaneArgs); superShift = 0: none of this holds, the kernel divides. */
+    uint32_t superShift, full, magicX, magicY;
     uint32_t rawRadius;          /* splat.w is the radius, not 1/radius^2 */
     unsigned long long *stats;   /* MLSGPU_MLS_STATS_WORDS counters, see mlsgpu_hip_mls_set_stats */
 };
@@ -778,8 +783,25 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
             sHist[threadIdx.x] = 0;
         __syncthreads();
     }
-    const uint32_t bid = xcdRemap(blockIdx.x, A.numBlocks, A.xcdChunk);
-    const uint32_t gx = bid % A.blocksX, gy = (bid / A.blocksX) % A.blocksY, gz = bid / (A.blocksX * A.blocksY);
+    uint32_t gx, gy, gz;
+    if (A.superShift != 0)
+    {
+        /* xcdRemap and the three coordinates by shifts and two multiplications (see MlsArgs) */
+        const uint32_t id = blockIdx.x, sh = A.superShift;
+        const uint32_t j = id & ((1u << sh) - 1u);
+        const uint32_t bid = id >= A.full ? id : (id >> sh << sh) + ((j & 7u) << (sh - 3u)) + (j >> 3);
+        const uint32_t t = __umulhi(bid, A.magicX);
+        gx = bid - t * A.blocksX;
+        gz = __umulhi(t, A.magicY);
+        gy = t - gz * A.blocksY;
+    }
+    else
+    {
+        const uint32_t bid = xcdRemap(blockIdx.x, A.numBlocks, A.xcdChunk);
+        gx = bid % A.blocksX;
+        gy = (bid / A.blocksX) % A.blocksY;
+        gz = bid / (A.blocksX * A.blocksY);
+    }
     const int wx = (int) (gx * 8), wy = (int) (gy * 8), wz = (int) (gz * 8 + A.zFirst);
     const uint32_t sub = A.startShift / 3;
     const uint32_t code = spread3((uint32_t) wx >> sub) | (spread3((uint32_t) wy >> sub) << 1) | (spread3((uint32_t) wz >> sub) << 2);
@@ -797,20 +819,26 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
         const float cx = (float) (wx + lx + A.ox), cy = (float) (wy + ly + A.oy), cz = (float) (wz + lz + A.oz);
         /* wave-uniform floats live in scalar registers (a float made by a vector instruction would be hoisted out of the
          * loops into a vector register each: twelve of the kernel's 64) */
-        auto uniformFloat = [](int v)
+        /* (the builtin is folded away for a value the compiler knows to be uniform.)  The wait states are part of the
+         * statement: the compiler's hazard recogniser does not look into inline assembly, and a v_readfirstlane issued
+         * right behind the conversion that writes its source READ THE OLD REGISTER on gfx950 -- one block of one test case,
+         * found when a rearrangement of this kernel put the two back to back (profiles/NOTES_r06.md, section 1).  Four bounds
+         * of an axis per statement: one pair of wait states for the four. */
+        float bx0, by0, bz0;
+        float boxLo[3][2], boxHi[3][2];
+        auto axisBounds = [](int o, float &lo0, float &hi0, float &lo1, float &hi1)
         {
-            /* (the builtin is folded away for a value the compiler knows to be uniform.)  The wait states are part of the
-             * statement: the compiler's hazard recogniser does not look into inline assembly, and a v_readfirstlane issued
-             * right behind the conversion that writes its source READ THE OLD REGISTER on gfx950 -- one block of one test case,
-             * found when a rearrangement of this kernel put the two back to back (profiles/NOTES_r06.md, section 1). */
-            float out;
-            asm("s_nop 3\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(out) : "v"((float) v));
-            return out;
+            asm("s_nop 3\n\tv_readfirstlane_b32 %0, %4\n\tv_readfirstlane_b32 %1, %5\n\tv_readfirstlane_b32 %2, %6\n\t"
+                "v_readfirstlane_b32 %3, %7\n\ts_nop 1"
+                : "=s"(lo0), "=s"(hi0), "=s"(lo1), "=s"(hi1)
+                : "v"((float) o), "v"((float) (o + 3)), "v"((float) (o + 4)), "v"((float) (o + 7)));
         };
-        const float bx0 = uniformFloat(wx + A.ox), by0 = uniformFloat(wy + A.oy), bz0 = uniformFloat(wz + A.oz);
-        const float boxLo[3][2] = {{bx0, uniformFloat(wx + A.ox + 4)}, {by0, uniformFloat(wy + A.oy + 4)}, {bz0, uniformFloat(wz + A.oz + 4)}};
-        const float boxHi[3][2] = {{uniformFloat(wx + A.ox + 3), uniformFloat(wx + A.ox + 7)}, {uniformFloat(wy + A.oy + 3), uniformFloat(wy + A.oy + 7)},
-                                   {uniformFloat(wz + A.oz + 3), uniformFloat(wz + A.oz + 7)}};
+        axisBounds(wx + A.ox, boxLo[0][0], boxHi[0][0], boxLo[0][1], boxHi[0][1]);
+        axisBounds(wy + A.oy, boxLo[1][0], boxHi[1][0], boxLo[1][1], boxHi[1][1]);
+        axisBounds(wz + A.oz, boxLo[2][0], boxHi[2][0], boxLo[2][1], boxHi[2][1]);
+        bx0 = boxLo[0][0];
+        by0 = boxLo[1][0];
+        bz0 = boxLo[2][0];
         Fit fit;
         fitInit(fit);
         unsigned long long nListed = 0, nTests = 0, nCand = 0, nMissed = 0;
@@ -841,9 +869,10 @@ void processCornersMatrixKernel(Lanes<MlsArgs> lanes)
         const uint32_t rowSplat = 16u * ((rowM >> 2) & 1u) + 4u * (rowM >> 3) + (rowM & 3u);
         const char *const colBase = (lane >> 5) ? (const char *) sColHi : (const char *) sColLo;
 
-        /* every slot that is ever read is a valid offset: zero until written */
-        for (uint32_t i = lane; i < MATRIX_SLOTS + 40; i += 64)
-            sSlot[wave][i] = 0;
+        /* every slot that is ever read is a valid offset: zero until written (960 bytes per wave: one 16-byte store of 60 lanes) */
+        static_assert((MATRIX_SLOTS + 40) * sizeof(uint16_t) % 16 == 0 && (MATRIX_SLOTS + 40) * sizeof(uint16_t) <= 64 * 16, "one store per lane");
+        if (lane < (MATRIX_SLOTS + 40) * sizeof(uint16_t) / 16)
+            reinterpret_cast<uint4 *>(sSlot[wave])[lane] = make_uint4(0u, 0u, 0u, 0u);
 
         /* one candidate: the reference's test and sums (kernels/mls.cl:362-390) */
         auto accumulate = [&](const float4 pr, const float4 nq)
@@ -1276,6 +1305,25 @@ static int mlsLaneArgs(mlsgpu_mls *m, float *dField, uint64_t pitch, uint64_t fi
      *   The kernel is not HBM-bound, so the faster setting wins. */
     static const uint32_t xcdChunk = getenv("MLSGPU_HIP_MLS_XCD_CHUNK") ? (uint32_t) atoi(getenv("MLSGPU_HIP_MLS_XCD_CHUNK")) : 16u;
     A.xcdChunk = xcdChunk;
+    A.superShift = A.full = A.magicX = A.magicY = 0;
+    if (xcdChunk != 0 && (xcdChunk & (xcdChunk - 1)) == 0 && xcdChunk <= (1u << 20) && A.blocksX >= 2 && A.blocksY >= 2)
+    {
+        /* q = umulhi(n, ceil(2^32 / d)) is floor(n / d) when n * (ceil(2^32 / d) * d - 2^32) < 2^32: with n = q d + r the
+         * product is q + r / d + n e / (d 2^32), and r <= d - 1 */
+        const uint64_t two32 = uint64_t(1) << 32;
+        const uint64_t mx = (two32 + A.blocksX - 1) / A.blocksX, my = (two32 + A.blocksY - 1) / A.blocksY;
+        const uint64_t nx = A.numBlocks - 1, ny = nx / A.blocksX;
+        if (nx * (mx * A.blocksX - two32) < two32 && ny * (my * A.blocksY - two32) < two32)
+        {
+            uint32_t shift = 3;
+            while ((1u << (shift - 3)) < xcdChunk)
+                shift++;
+            A.superShift = shift;
+            A.full = A.numBlocks >> shift << shift;
+            A.magicX = (uint32_t) mx;
+            A.magicY = (uint32_t) my;
+        }
+    }
     A.rawRadius = m->rawRadius ? 1u : 0u;
     A.stats = m->dStats;
     *out = A;
