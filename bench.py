@@ -86,15 +86,16 @@ def parse_args():
     p.add_argument("--dist", default="uniform", choices=["uniform", "shells"])
     p.add_argument("--scale", type=float, default=1.0, help="splat-count scale (debug only; 1.0 = BASELINE size)")
     p.add_argument("--mesh-memory-mb", type=int, default=4096, help="Marching mesh arena per worker")
-    p.add_argument("--workers", type=int, default=2,
+    p.add_argument("--workers", type=int, default=3,
                    help="device worker threads per GPU for the resident-input passes (round 3, cfg3 uniform: 1 / 2 / 3 / 4 / 6 workers "
                         "23.1 / 21.2-21.6 / 21.6-22.2 / 22.2-22.5 / 22.1 ms per step -- every kernel fills the GPU, a second worker "
-                        "hides the host's gaps and more only interleave)")
+                        "hides the host's gaps and more only interleave.  End of round 6, processCorners 13 %% shorter: 2 workers x "
+                        "batches of 6 / 8 14.05 / 14.06 ms, 3 workers 13.95 / 13.89, four rounds on one box)")
     p.add_argument("--farm-workers", type=int, default=2,
                    help="device workers per GPU of the farm legs (host splats in, meshes out).  Round 5, shells cloud, 8d region with "
                         "six spare items: 2 workers 33.5-34 ms per job (the host-to-device copies busy 0.90-0.92 of it), 4 workers "
                         "36.5-38 (0.80), 8 workers 41 (0.74): the link is the floor, and fewer streams queue less in front of it")
-    p.add_argument("--batch", type=int, default=6,
+    p.add_argument("--batch", type=int, default=8,
                    help="buckets a device worker takes through the path in lock-step (mlsgpu_hip_worker_process_batch: every "
                         "kernel has a bucket dimension, one set of launches and three host decisions per batch); 1 = bucket by "
                         "bucket (mlsgpu_hip_worker_process).  With the octree's kernels a quarter shorter than when 4 was chosen, "
